@@ -1,0 +1,206 @@
+/*
+ * monica_amd.h -- C-ABI of the MI355X-native read-classification engine.
+ *
+ * This is the drop-in boundary for monica's aligner hot path.  In the reference the
+ * boundary is the Python->C crossing into mappy (minimap2 2.17) at
+ *   monica/genomes/aligner.py:45-46   mappy.Aligner(fn_idx_in=<fasta.gz>, preset='map-ont',
+ *                                                   best_n=15, fn_idx_out=<index file>)
+ *   monica/genomes/aligner.py:59      mappy.Aligner(fn_idx_in=<index file>)
+ *   monica/genomes/aligner.py:193,215 index.map(str(seq_record.seq)) -> hits
+ *                                     (.is_primary .mapq .ctg .NM .mlen, lines 194-195, 216-217)
+ * and the per-read Python that consumes the hits (aligner.py:218-263, 328-339).
+ * Each entry point below names the reference interface it replaces.
+ *
+ * Conventions: every function returns MNC_OK (0) or a negative MNC_ERR_* code and never
+ * throws or aborts across the ABI.  Handles are opaque.  The library never keeps a caller
+ * pointer past the call.  An mnc_index is immutable after build/load/upload and may be
+ * shared by any number of engines and threads; an mnc_engine (stream + HBM workspace)
+ * must be used by one thread at a time.
+ *
+ * There is no CPU execution path in this library: classification entry points fail with
+ * MNC_ERR_NODEVICE when no gfx950 device is present.
+ */
+#ifndef MONICA_AMD_H
+#define MONICA_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MNC_OK               0
+#define MNC_ERR_ARG         (-1)   /* bad argument                                        */
+#define MNC_ERR_IO          (-2)   /* file cannot be opened / read / written               */
+#define MNC_ERR_FORMAT      (-3)   /* damaged or empty index / FASTA                       */
+#define MNC_ERR_NOMEM       (-4)   /* host or device allocation failed                     */
+#define MNC_ERR_HIP         (-5)   /* HIP runtime error (see mnc_last_error())             */
+#define MNC_ERR_NODEVICE    (-6)   /* no usable gfx950 device                              */
+#define MNC_ERR_UNSUPPORTED (-7)   /* parameter outside what the kernels implement         */
+#define MNC_ERR_RANGE       (-8)   /* caller buffer too small; required size is reported   */
+
+/* per-read decision codes in out_assign[] (aligner.py:218-233, 264-265) */
+#define MNC_UNMAPPED   (-1)        /* no gated hit        -> unmapped/<sample>             */
+#define MNC_AMBIGUOUS  (-2)        /* best_hit() returned 0 -> ambiguous/<sample>          */
+
+typedef struct mnc_index  mnc_index;
+typedef struct mnc_engine mnc_engine;
+
+/* one gated hit = the (ctg, NM, mlen) tuple of aligner.py:195,217 plus its mapq */
+typedef struct {
+	int32_t rid;    /* contig index; ctg = mnc_index_contig_name(rid) */
+	int32_t mapq;
+	int32_t nm;     /* NM := blen - mlen (chain-level contract) */
+	int32_t mlen;
+} mnc_hit_t;
+
+typedef struct {
+	int32_t k, w;
+	int32_t n_contigs;
+	int32_t n_genomes;      /* distinct contig names ("tax_unit:accession", database.py:59) */
+	int32_t mid_occ;        /* occurrence cut-off derived from the index (mid_occ_frac 2e-4) */
+	int32_t reserved;
+	int64_t n_keys;         /* distinct minimizer hashes    */
+	int64_t n_occ;          /* minimizer occurrences        */
+	int64_t total_len;      /* sum of contig lengths        */
+	int64_t table_slots;    /* HBM hash-table slots         */
+	int64_t device_bytes;   /* bytes resident in HBM after upload (0 before) */
+} mnc_index_info_t;
+
+/* ---------------------------------------------------------------- errors */
+const char *mnc_strerror(int code);
+const char *mnc_last_error(void);          /* thread-local detail of the last failure */
+
+/* ---------------------------------------------------------------- device */
+int mnc_device_count(int *n);              /* counts devices without initialising them */
+int mnc_device_name(int device, char *buf, size_t cap);
+
+/* ---------------------------------------------------------------- index: build / load
+ * mnc_index_build      <- mappy.Aligner(fn_idx_in=fasta(.gz), preset='map-ont', best_n=15,
+ *                         fn_idx_out=out_path)                      aligner.py:45-46
+ *                         out_path may be NULL (no file written).  k=15,w=10 is 'map-ont'.
+ * mnc_index_load       <- mappy.Aligner(fn_idx_in=index file)       aligner.py:59
+ *                         a falsy Aligner maps to MNC_ERR_FORMAT ('Damaged or empty index').
+ */
+int  mnc_index_build(const char *fasta_path, const char *out_path, int k, int w, mnc_index **out);
+int  mnc_index_build_mem(int n_seq, const char *const *names, const char *const *seqs,
+                         const int64_t *lens, int k, int w, mnc_index **out);
+int  mnc_index_save(const mnc_index *idx, const char *path);
+int  mnc_index_load(const char *path, mnc_index **out);
+void mnc_index_free(mnc_index *idx);
+int  mnc_index_info(const mnc_index *idx, mnc_index_info_t *info);
+const char *mnc_index_contig_name(const mnc_index *idx, int rid);      /* hit.ctg, aligner.py:195 */
+int64_t     mnc_index_contig_len(const mnc_index *idx, int rid);
+int         mnc_index_contig_genome(const mnc_index *idx, int rid);    /* contig -> genome id     */
+const char *mnc_index_genome_name(const mnc_index *idx, int gid);      /* "tax_unit:accession"    */
+int64_t     mnc_index_genome_len(const mnc_index *idx, int gid);       /* database.py:57-65 sum   */
+/* dump (hash, y) pairs sorted by (hash, y); for tests.  *n receives the pair count. */
+int  mnc_index_dump(const mnc_index *idx, uint64_t *hash, uint64_t *y, int64_t cap, int64_t *n);
+/* override the occurrence cut-off (index shards of one logical index share one value) */
+int  mnc_index_set_mid_occ(mnc_index *idx, int mid_occ);
+
+/* ---------------------------------------------------------------- engine
+ * One engine = one HIP stream + a growable HBM workspace on `device`.  The first engine
+ * created for an index on a device uploads the index tables to that device's HBM.
+ */
+int  mnc_engine_create(mnc_index *idx, int device, mnc_engine **out);
+void mnc_engine_destroy(mnc_engine *eng);
+void *mnc_engine_stream(mnc_engine *eng);                              /* hipStream_t */
+
+/* ---------------------------------------------------------------- classify
+ * mnc_classify_batch   <- the per-read loop body aligner.py:212-233 for one index part:
+ *                         index.map(seq) -> gate `is_primary and mapq >= min_mapq`
+ *                         -> single hit | best_hit(hits) | ambiguous.
+ *   bases     host, concatenated read bases (ASCII; anything but ACGTUacgtu is ambiguous)
+ *   offsets   host, n_reads+1 byte offsets into bases
+ *   out_assign[n_reads]  contig index of the chosen hit | MNC_UNMAPPED | MNC_AMBIGUOUS
+ *   out_best[n_reads]    the chosen hit (zero when assign < 0); may be NULL
+ *   out_nhits[n_reads]   number of gated hits of the read; may be NULL
+ * The gated hit lists themselves stay in HBM until the next call; fetch them with
+ * mnc_engine_fetch_hits (needed for the multi-part merge, aligner.py:196-203, 218-223).
+ */
+int mnc_classify_batch(mnc_engine *eng, const uint8_t *bases, const int64_t *offsets,
+                       uint32_t n_reads, int min_mapq,
+                       int32_t *out_assign, mnc_hit_t *out_best, int32_t *out_nhits);
+
+/* Same, all buffers device-resident (HBM), asynchronous on the engine's stream.
+ * total_bases = offsets[n_reads].  d_counts (may be NULL) is an int64[n_genomes*3] table
+ * that the call ADDS to: {reads, read bases, mlen} per genome, i.e. the three counting
+ * modes of aligner.py:247-263 ('basic', 'query_length', 'matching'). */
+int mnc_classify_device(mnc_engine *eng, const uint8_t *d_bases, const int64_t *d_offsets,
+                        uint32_t n_reads, int64_t total_bases, int max_read_len, int min_mapq,
+                        int32_t *d_assign, mnc_hit_t *d_best, int32_t *d_nhits, int64_t *d_counts);
+int mnc_engine_sync(mnc_engine *eng);
+
+/* gated hits of the last batch: hit_offsets[n_reads+1] and hits[cap]; *n_hits = total.
+ * Returns MNC_ERR_RANGE (with *n_hits set) if cap is too small. */
+int mnc_engine_fetch_hits(mnc_engine *eng, int64_t *hit_offsets, mnc_hit_t *hits, int64_t cap,
+                          int64_t *n_hits);
+
+/* mnc_counts  <- the Counter accumulation aligner.py:247-263 on host arrays.
+ * mode: 1 'basic' (+1), 2 'query_length' (+len(seq)), 3 'matching' (+mlen).
+ * counts[n_genomes] is ADDED to. */
+int mnc_counts(const mnc_index *idx, const int32_t *assign, const mnc_hit_t *best,
+               const int64_t *offsets, uint32_t n_reads, int mode, int64_t *counts);
+
+/* cross-part merge of gated hit lists <- aligner.py:219-233 + best_hit 328-339 in exact
+ * integer arithmetic.  hits of all parts of one read are concatenated in part order;
+ * rid values must already be global.  Writes the decision per read. */
+int mnc_best_hit(const mnc_hit_t *hits, int n, int *best_index /* -1 = ambiguous */);
+
+/* ---------------------------------------------------------------- profiling / introspection */
+#define MNC_STAGE_PACK     0
+#define MNC_STAGE_SKETCH   1
+#define MNC_STAGE_PROBE    2   /* index probe: the HBM-roofline kernel */
+#define MNC_STAGE_EXPAND   3
+#define MNC_STAGE_SORT     4
+#define MNC_STAGE_CHAIN    5
+#define MNC_STAGE_BACKTRACK 6
+#define MNC_STAGE_REGIONS  7
+#define MNC_STAGE_DECIDE   8
+#define MNC_N_STAGES       9
+int mnc_engine_set_profiling(mnc_engine *eng, int on);    /* HIP events around every stage */
+/* accumulated since the last reset: ms[MNC_N_STAGES], launches[MNC_N_STAGES] */
+int mnc_engine_get_timings(mnc_engine *eng, double *ms, int64_t *launches, int reset);
+const char *mnc_stage_name(int stage);
+const char *mnc_stage_kernel(int stage);                  /* kernel symbol, for rocprof matching */
+/* counters of the last batch: [0] minimizers, [1] probe hits, [2] anchors, [3] chains,
+ * [4] regions, [5] gated hits, [6] reads with ambiguous bases, [7] table slot reads */
+int mnc_engine_get_counters(mnc_engine *eng, int64_t *c, int n);
+
+/* stage dumps of the last batch, for kernel-level parity tests */
+#define MNC_DUMP_MINIMIZERS 1  /* u32 pairs {hash, pos<<1|strand} in read order                    */
+#define MNC_DUMP_MZ_OFFSETS 2  /* int64[n_reads+1]                                              */
+#define MNC_DUMP_ANCHORS    3  /* u64 x,y pairs sorted by (x,y), per read                       */
+#define MNC_DUMP_AN_OFFSETS 4  /* int64[n_reads+1]                                              */
+#define MNC_DUMP_CHAIN_F    5  /* int32 per anchor                                              */
+#define MNC_DUMP_CHAIN_P    6  /* int32 per anchor (read-local index, -1 none)                  */
+#define MNC_DUMP_CHAIN_V    7  /* int32 per anchor                                              */
+#define MNC_DUMP_REGS       8  /* mnc_reg_t per region                                          */
+#define MNC_DUMP_REG_OFFSETS 9 /* int64[n_reads+1]                                              */
+#define MNC_DUMP_REP_LEN    10 /* int32 per read                                                */
+typedef struct {
+	int32_t id, parent, rid, rev, rs, re, qs, qe, score, score0, cnt, as, mlen, blen,
+	        subsc, n_sub, mapq;
+	uint32_t hash;
+} mnc_reg_t;
+int mnc_engine_dump(mnc_engine *eng, int what, void *dst, int64_t cap_bytes, int64_t *n_bytes);
+
+/* ---------------------------------------------------------------- synthetic data (bench/tests)
+ * Deterministic counter-based generator (SplitMix64), SURVEY.md section 8d. */
+int mnc_synth_genome(uint64_t seed, int64_t len, char *out);
+int mnc_synth_diverge(const char *src, int64_t len, uint64_t seed, int rate_ppm, char *out);
+/* reads: ordinal r in [first, first+n) draws from stream (seed, r).  Rates in 1e-4 units.
+ * random_frac_e4 of the reads are pure random sequence (truth = -1). */
+int mnc_synth_reads(int n_genomes, const char *const *genomes, const int64_t *lens,
+                    uint64_t seed, int64_t first, int n_reads, int read_len,
+                    int sub_e4, int ins_e4, int del_e4, int random_frac_e4,
+                    char *out_bases, int32_t *out_truth);
+
+const char *mnc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,329 @@
+"""ctypes binding of ``libmonica_amd.so`` (C-ABI: ``include/monica_amd.h``).
+
+The library holds the hand-written gfx950 kernels; there is no CPU execution path.  Loading
+fails loudly when the shared object is missing -- build it with ``python -c 'import
+__graft_entry__ as g; g.build()'`` or ``make -C monica_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmonica_amd.so")
+
+OK = 0
+ERR_ARG, ERR_IO, ERR_FORMAT, ERR_NOMEM, ERR_HIP, ERR_NODEVICE, ERR_UNSUPPORTED, ERR_RANGE = range(-1, -9, -1)
+UNMAPPED = -1
+AMBIGUOUS = -2
+
+HIT_DTYPE = np.dtype([("rid", "<i4"), ("mapq", "<i4"), ("nm", "<i4"), ("mlen", "<i4")])
+REG_DTYPE = np.dtype([("id", "<i4"), ("parent", "<i4"), ("rid", "<i4"), ("rev", "<i4"),
+                      ("rs", "<i4"), ("re", "<i4"), ("qs", "<i4"), ("qe", "<i4"),
+                      ("score", "<i4"), ("score0", "<i4"), ("cnt", "<i4"), ("as", "<i4"),
+                      ("mlen", "<i4"), ("blen", "<i4"), ("subsc", "<i4"), ("n_sub", "<i4"),
+                      ("mapq", "<i4"), ("hash", "<u4")])
+MZ_DTYPE = np.dtype([("hash", "<u4"), ("pos_strand", "<u4")])
+ANCHOR_DTYPE = np.dtype([("x", "<u8"), ("y", "<u8")])
+
+N_STAGES = 9
+(STAGE_PACK, STAGE_SKETCH, STAGE_PROBE, STAGE_EXPAND, STAGE_SORT, STAGE_CHAIN, STAGE_BACKTRACK,
+ STAGE_REGIONS, STAGE_DECIDE) = range(N_STAGES)
+(DUMP_MINIMIZERS, DUMP_MZ_OFFSETS, DUMP_ANCHORS, DUMP_AN_OFFSETS, DUMP_CHAIN_F, DUMP_CHAIN_P,
+ DUMP_CHAIN_V, DUMP_REGS, DUMP_REG_OFFSETS, DUMP_REP_LEN) = range(1, 11)
+
+# every symbol include/monica_amd.h declares (checked by tests/test_capi.py)
+EXPORTS = [
+    "mnc_strerror", "mnc_last_error", "mnc_device_count", "mnc_device_name",
+    "mnc_index_build", "mnc_index_build_mem", "mnc_index_save", "mnc_index_load", "mnc_index_free",
+    "mnc_index_info", "mnc_index_contig_name", "mnc_index_contig_len", "mnc_index_contig_genome",
+    "mnc_index_genome_name", "mnc_index_genome_len", "mnc_index_dump", "mnc_index_set_mid_occ",
+    "mnc_engine_create", "mnc_engine_destroy", "mnc_engine_stream",
+    "mnc_classify_batch", "mnc_classify_device", "mnc_engine_sync", "mnc_engine_fetch_hits",
+    "mnc_counts", "mnc_best_hit",
+    "mnc_engine_set_profiling", "mnc_engine_get_timings", "mnc_stage_name", "mnc_stage_kernel",
+    "mnc_engine_get_counters", "mnc_engine_dump",
+    "mnc_synth_genome", "mnc_synth_diverge", "mnc_synth_reads", "mnc_version",
+]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("k", C.c_int32), ("w", C.c_int32), ("n_contigs", C.c_int32), ("n_genomes", C.c_int32),
+                ("mid_occ", C.c_int32), ("reserved", C.c_int32), ("n_keys", C.c_int64),
+                ("n_occ", C.c_int64), ("total_len", C.c_int64), ("table_slots", C.c_int64),
+                ("device_bytes", C.c_int64)]
+
+
+class MncError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        msg = lib().mnc_strerror(code).decode()
+        super().__init__(f"{msg}" + (f": {detail}" if detail else ""))
+
+
+_LIB = None
+
+
+def lib():
+    """Load the shared object once.  Raises if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: the HIP extension has not been built "
+                          "(run __graft_entry__.build() or make -C monica_amd/csrc)")
+    # PyTorch wheels bundle their own libamdhip64 under the same SONAME.  Two HIP runtimes in
+    # one process cannot both open the GPU, so when torch is installed let it load its copy
+    # first; our NEEDED entry then resolves to that already-loaded runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64, u32, cp = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_uint32, C.c_char_p
+    pp = C.POINTER(vp)
+
+    def sig(name, res, args):
+        f = getattr(L, name)
+        f.restype, f.argtypes = res, args
+
+    sig("mnc_strerror", cp, [i32])
+    sig("mnc_last_error", cp, [])
+    sig("mnc_version", cp, [])
+    sig("mnc_device_count", i32, [C.POINTER(i32)])
+    sig("mnc_device_name", i32, [i32, cp, C.c_size_t])
+    sig("mnc_index_build", i32, [cp, cp, i32, i32, pp])
+    sig("mnc_index_build_mem", i32, [i32, C.POINTER(cp), C.POINTER(cp), C.POINTER(i64), i32, i32, pp])
+    sig("mnc_index_save", i32, [vp, cp])
+    sig("mnc_index_load", i32, [cp, pp])
+    sig("mnc_index_free", None, [vp])
+    sig("mnc_index_info", i32, [vp, C.POINTER(IndexInfo)])
+    sig("mnc_index_contig_name", cp, [vp, i32])
+    sig("mnc_index_contig_len", i64, [vp, i32])
+    sig("mnc_index_contig_genome", i32, [vp, i32])
+    sig("mnc_index_genome_name", cp, [vp, i32])
+    sig("mnc_index_genome_len", i64, [vp, i32])
+    sig("mnc_index_dump", i32, [vp, vp, vp, i64, C.POINTER(i64)])
+    sig("mnc_index_set_mid_occ", i32, [vp, i32])
+    sig("mnc_engine_create", i32, [vp, i32, pp])
+    sig("mnc_engine_destroy", None, [vp])
+    sig("mnc_engine_stream", vp, [vp])
+    sig("mnc_classify_batch", i32, [vp, vp, vp, u32, i32, vp, vp, vp])
+    sig("mnc_classify_device", i32, [vp, vp, vp, u32, i64, i32, i32, vp, vp, vp, vp])
+    sig("mnc_engine_sync", i32, [vp])
+    sig("mnc_engine_fetch_hits", i32, [vp, vp, vp, i64, C.POINTER(i64)])
+    sig("mnc_counts", i32, [vp, vp, vp, vp, u32, i32, vp])
+    sig("mnc_best_hit", i32, [vp, i32, C.POINTER(i32)])
+    sig("mnc_engine_set_profiling", i32, [vp, i32])
+    sig("mnc_engine_get_timings", i32, [vp, vp, vp, i32])
+    sig("mnc_stage_name", cp, [i32])
+    sig("mnc_stage_kernel", cp, [i32])
+    sig("mnc_engine_get_counters", i32, [vp, vp, i32])
+    sig("mnc_engine_dump", i32, [vp, i32, vp, i64, C.POINTER(i64)])
+    sig("mnc_synth_genome", i32, [u64, i64, vp])
+    sig("mnc_synth_diverge", i32, [vp, i64, u64, i32, vp])
+    sig("mnc_synth_reads", i32, [i32, C.POINTER(vp), C.POINTER(i64), u64, i64, i32, i32,
+                                 i32, i32, i32, i32, vp, vp])
+    _LIB = L
+    return L
+
+
+def check(code):
+    if code != OK:
+        raise MncError(code, lib().mnc_last_error().decode(errors="replace"))
+
+
+def _b(s):
+    return s if isinstance(s, (bytes, bytearray)) else str(s).encode()
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().mnc_device_count(C.byref(n)))
+    return n.value
+
+
+# ---------------------------------------------------------------------------------- index
+class Index:
+    """Owner of an ``mnc_index`` handle (the object mappy.Aligner is for monica)."""
+
+    def __init__(self, handle):
+        self._h = handle
+        info = self.info()
+        self.k, self.w = info.k, info.w
+        L = lib()
+        self.contig_names = [L.mnc_index_contig_name(handle, i).decode() for i in range(info.n_contigs)]
+        self.contig_lens = [int(L.mnc_index_contig_len(handle, i)) for i in range(info.n_contigs)]
+        self.contig_genome = np.array([L.mnc_index_contig_genome(handle, i) for i in range(info.n_contigs)],
+                                      dtype=np.int32)
+        self.genome_names = [L.mnc_index_genome_name(handle, g).decode() for g in range(info.n_genomes)]
+        self.genome_lens = [int(L.mnc_index_genome_len(handle, g)) for g in range(info.n_genomes)]
+
+    @classmethod
+    def build(cls, fasta_path, out_path=None, k=15, w=10):
+        h = C.c_void_p()
+        check(lib().mnc_index_build(_b(fasta_path), _b(out_path) if out_path else None, k, w, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_seqs(cls, names, seqs, k=15, w=10):
+        n = len(names)
+        bn = [_b(x) for x in names]
+        bs = [x if isinstance(x, (bytes, bytearray)) else (x.tobytes() if isinstance(x, np.ndarray) else _b(x))
+              for x in seqs]
+        an = (C.c_char_p * n)(*bn)
+        as_ = (C.c_char_p * n)(*bs)
+        al = (C.c_int64 * n)(*[len(x) for x in bs])
+        h = C.c_void_p()
+        check(lib().mnc_index_build_mem(n, an, as_, al, k, w, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def load(cls, path):
+        h = C.c_void_p()
+        check(lib().mnc_index_load(_b(path), C.byref(h)))
+        return cls(h)
+
+    def save(self, path):
+        check(lib().mnc_index_save(self._h, _b(path)))
+
+    def info(self):
+        info = IndexInfo()
+        check(lib().mnc_index_info(self._h, C.byref(info)))
+        return info
+
+    @property
+    def mid_occ(self):
+        return self.info().mid_occ
+
+    def set_mid_occ(self, v):
+        check(lib().mnc_index_set_mid_occ(self._h, int(v)))
+
+    def dump(self):
+        n = C.c_int64(0)
+        lib().mnc_index_dump(self._h, None, None, 0, C.byref(n))
+        h = np.zeros(n.value, dtype=np.uint64)
+        y = np.zeros(n.value, dtype=np.uint64)
+        check(lib().mnc_index_dump(self._h, h.ctypes.data, y.ctypes.data, n.value, C.byref(n)))
+        return h, y
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mnc_index_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------------- engine
+class Engine:
+    """One HIP stream + HBM workspace on one device, bound to one index."""
+
+    def __init__(self, index, device=0):
+        self.index = index
+        self.device = device
+        h = C.c_void_p()
+        check(lib().mnc_engine_create(index._h, device, C.byref(h)))
+        self._h = h
+        self.n_reads = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mnc_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self):
+        return lib().mnc_engine_stream(self._h)
+
+    def classify(self, bases, offsets, min_mapq=60):
+        """Host buffers in, host arrays out: (assign, best, nhits)."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = len(offsets) - 1
+        assign = np.empty(n, dtype=np.int32)
+        best = np.zeros(n, dtype=HIT_DTYPE)
+        nhits = np.zeros(n, dtype=np.int32)
+        check(lib().mnc_classify_batch(self._h, bases.ctypes.data, offsets.ctypes.data, n, min_mapq,
+                                       assign.ctypes.data, best.ctypes.data, nhits.ctypes.data))
+        self.n_reads = n
+        return assign, best, nhits
+
+    def classify_device(self, d_bases, d_offsets, n_reads, total_bases, max_read_len, min_mapq,
+                        d_assign, d_best=0, d_nhits=0, d_counts=0):
+        """All arguments are raw device pointers (ints); asynchronous on the engine stream."""
+        check(lib().mnc_classify_device(self._h, d_bases, d_offsets, n_reads, total_bases, max_read_len,
+                                        min_mapq, d_assign, d_best or None, d_nhits or None,
+                                        d_counts or None))
+        self.n_reads = n_reads
+
+    def sync(self):
+        check(lib().mnc_engine_sync(self._h))
+
+    def fetch_hits(self):
+        """Gated hit lists of the last batch as CSR (offsets[n+1], hits)."""
+        n = C.c_int64(0)
+        off = np.zeros(self.n_reads + 1, dtype=np.int64)
+        rc = lib().mnc_engine_fetch_hits(self._h, None, None, 0, C.byref(n))
+        if rc not in (OK, ERR_RANGE):
+            check(rc)
+        hits = np.zeros(max(n.value, 1), dtype=HIT_DTYPE)
+        check(lib().mnc_engine_fetch_hits(self._h, off.ctypes.data, hits.ctypes.data, len(hits), C.byref(n)))
+        return off, hits[:n.value]
+
+    def set_profiling(self, on=True):
+        check(lib().mnc_engine_set_profiling(self._h, 1 if on else 0))
+
+    def timings(self, reset=False):
+        ms = np.zeros(N_STAGES, dtype=np.float64)
+        ln = np.zeros(N_STAGES, dtype=np.int64)
+        check(lib().mnc_engine_get_timings(self._h, ms.ctypes.data, ln.ctypes.data, 1 if reset else 0))
+        names = [lib().mnc_stage_name(s).decode() for s in range(N_STAGES)]
+        return {names[s]: (float(ms[s]), int(ln[s])) for s in range(N_STAGES)}
+
+    def counters(self):
+        c = np.zeros(8, dtype=np.int64)
+        check(lib().mnc_engine_get_counters(self._h, c.ctypes.data, 8))
+        keys = ["minimizers", "probe_hits", "anchors", "chains", "regions", "gated_hits", "ambiguous_reads", "_"]
+        return dict(zip(keys, (int(x) for x in c)))
+
+    def dump(self, what, dtype):
+        n = C.c_int64(0)
+        rc = lib().mnc_engine_dump(self._h, what, None, 0, C.byref(n))
+        if rc not in (OK, ERR_RANGE):
+            check(rc)
+        buf = np.zeros(max(n.value, 1), dtype=np.uint8)
+        check(lib().mnc_engine_dump(self._h, what, buf.ctypes.data, len(buf), C.byref(n)))
+        return buf[:n.value].view(dtype).copy()
+
+
+# ---------------------------------------------------------------------------------- host helpers
+def best_hit(hits):
+    """Exact-integer restatement of aligner.best_hit over (nm, mlen) pairs -> index or -1."""
+    arr = np.zeros(len(hits), dtype=HIT_DTYPE)
+    for i, (nm, mlen) in enumerate(hits):
+        arr[i]["nm"], arr[i]["mlen"] = nm, mlen
+    out = C.c_int(0)
+    check(lib().mnc_best_hit(arr.ctypes.data, len(hits), C.byref(out)))
+    return out.value
+
+
+def counts(index, assign, best, offsets, mode):
+    """Host accumulation of aligner.py:247-263 into an int64[n_genomes] vector."""
+    assign = np.ascontiguousarray(assign, dtype=np.int32)
+    best = np.ascontiguousarray(best, dtype=HIT_DTYPE)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    out = np.zeros(len(index.genome_names), dtype=np.int64)
+    check(lib().mnc_counts(index._h, assign.ctypes.data, best.ctypes.data, offsets.ctypes.data,
+                           len(assign), mode, out.ctypes.data))
+    return out

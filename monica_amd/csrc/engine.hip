@@ -1,0 +1,611 @@
+// Host orchestration: HBM residency of the index, per-engine workspace, stage launches,
+// HIP-event timing, stage dumps.  Public surface: include/monica_amd.h.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "device.h"
+
+namespace mnc {
+
+// launches implemented in the k_*.hip units
+void launch_pack(const Batch &B, hipStream_t st);
+void launch_sketch(const Batch &B, hipStream_t st);
+void launch_probe(const Batch &B, hipStream_t st);
+void launch_expand_sort(const Batch &B, hipStream_t st);
+void launch_chain_dp_serial(const Batch &B, const uint32_t *read_list, uint32_t n_list, hipStream_t st);
+void launch_backtrack(const Batch &B, hipStream_t st);
+void launch_regions(const Batch &B, void *regx, uint64_t *k64a, uint64_t *k64b, mnc_hit_t *gated, hipStream_t st);
+void launch_gather_hits(const Batch &B, const mnc_hit_t *gated, const int64_t *hit_off, mnc_hit_t *out, hipStream_t st);
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+	set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+	return e_ == hipErrorOutOfMemory ? MNC_ERR_NOMEM : MNC_ERR_HIP; } } while (0)
+
+// ================================================================ exclusive scan (int -> int64)
+constexpr int SC_THREADS = 256, SC_ITEMS = 4, SC_TILE = SC_THREADS * SC_ITEMS;
+
+template <class T>
+__global__ __launch_bounds__(SC_THREADS) void mnc_scan_reduce(const T *in, int64_t n, int64_t *sums)
+{
+	__shared__ long long s[SC_THREADS / 64];
+	const int64_t base = (int64_t)blockIdx.x * SC_TILE;
+	long long x = 0;
+	for (int k = 0; k < SC_ITEMS; ++k) {
+		const int64_t i = base + (int64_t)threadIdx.x * SC_ITEMS + k;
+		if (i < n) x += (long long)in[i];
+	}
+	for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d);
+	if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = x;
+	__syncthreads();
+	if (threadIdx.x == 0) sums[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+__global__ __launch_bounds__(64) void mnc_scan_sums(int64_t *sums, int64_t n_blocks)
+{
+	// one wave: serial over 64-wide strips; n_blocks is small (n / 1024)
+	long long carry = 0;
+	for (int64_t i0 = 0; i0 < n_blocks; i0 += 64) {
+		const int64_t i = i0 + threadIdx.x;
+		long long x = i < n_blocks ? sums[i] : 0, inc = x;
+		for (int d = 1; d < 64; d <<= 1) {
+			long long o = __shfl_up(inc, d);
+			if ((int)threadIdx.x >= d) inc += o;
+		}
+		if (i < n_blocks) sums[i] = carry + inc - x;
+		carry += __shfl(inc, 63);
+	}
+}
+
+template <class T>
+__global__ __launch_bounds__(SC_THREADS) void mnc_scan_apply(const T *in, int64_t n, const int64_t *sums, int64_t *out)
+{
+	__shared__ long long s[SC_THREADS / 64];
+	const int64_t base = (int64_t)blockIdx.x * SC_TILE + (int64_t)threadIdx.x * SC_ITEMS;
+	long long v[SC_ITEMS], x = 0;
+	for (int k = 0; k < SC_ITEMS; ++k) { v[k] = base + k < n ? (long long)in[base + k] : 0; x += v[k]; }
+	long long inc = x;
+	for (int d = 1; d < 64; d <<= 1) {
+		long long o = __shfl_up(inc, d);
+		if ((int)(threadIdx.x & 63) >= d) inc += o;
+	}
+	if ((threadIdx.x & 63) == 63) s[threadIdx.x >> 6] = inc;
+	__syncthreads();
+	long long pre = sums[blockIdx.x] + inc - x;
+	for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) pre += s[w];
+	for (int k = 0; k < SC_ITEMS; ++k) {
+		if (base + k < n) out[base + k] = pre;
+		pre += v[k];
+		if (base + k == n - 1) out[n] = pre;
+	}
+}
+
+template <class T>
+static void exclusive_scan(const T *in, int64_t n, int64_t *out, int64_t *sums, hipStream_t st)
+{
+	if (n <= 0) { (void)hipMemsetAsync(out, 0, 8, st); return; }
+	const int64_t nb = (n + SC_TILE - 1) / SC_TILE;
+	hipLaunchKernelGGL(mnc_scan_reduce<T>, dim3((unsigned)nb), dim3(SC_THREADS), 0, st, in, n, sums);
+	hipLaunchKernelGGL(mnc_scan_sums, dim3(1), dim3(64), 0, st, sums, nb);
+	hipLaunchKernelGGL(mnc_scan_apply<T>, dim3((unsigned)nb), dim3(SC_THREADS), 0, st, in, n, sums, out);
+}
+
+// ================================================================ device buffer
+struct Buf {
+	void *p = nullptr;
+	size_t cap = 0;
+	int ensure(size_t bytes)
+	{
+		if (bytes <= cap) return MNC_OK;
+		if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+		size_t want = bytes + bytes / 8 + 256;
+		hipError_t e = hipMalloc(&p, want);
+		if (e != hipSuccess) { p = nullptr; set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return MNC_ERR_NOMEM; }
+		cap = want;
+		return MNC_OK;
+	}
+	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+	template <class T> T *as() const { return reinterpret_cast<T*>(p); }
+};
+
+// ================================================================ index residency
+static int check_device(int device)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device visible"); return MNC_ERR_NODEVICE; }
+	if (device < 0 || device >= n) { set_error("device %d out of range (have %d)", device, n); return MNC_ERR_NODEVICE; }
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, device));
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+		set_error("device %d is %s; this library holds gfx950 code only", device, prop.gcnArchName);
+		return MNC_ERR_NODEVICE;
+	}
+	return MNC_OK;
+}
+
+int index_upload(mnc_index *idx, int device, DeviceIndex **out)
+{
+	std::lock_guard<std::mutex> lk(idx->dev_mutex);
+	for (auto &d : idx->dev) if (d.device == device) { *out = &d; return MNC_OK; }
+	if (idx->keys.empty()) { set_error("empty index"); return MNC_ERR_FORMAT; }
+	HIP_TRY(hipSetDevice(device));
+	// open-addressed table, load <= 0.5; home slot = hash & mask (the minimizer hash is an
+	// invertible mix of the k-mer, so its low bits are already uniform)
+	uint64_t slots = 1024;
+	while (slots < idx->keys.size() * 2) slots <<= 1;
+	std::vector<TableSlot> tab;
+	try { tab.assign(slots, TableSlot{0, 0, 0}); } catch (const std::bad_alloc &) { return MNC_ERR_NOMEM; }
+	const uint64_t mask = slots - 1;
+	for (size_t i = 0; i < idx->keys.size(); ++i) {
+		const uint32_t h = idx->keys[i];
+		const uint64_t o = idx->key_off[i], c = idx->key_off[i + 1] - o;
+		uint64_t s = (uint64_t)h & mask;
+		while (tab[s].key) s = (s + 1) & mask;
+		tab[s].key = h + 1;
+		tab[s].cnt = (uint32_t)c;
+		tab[s].val = c == 1 ? idx->pos[o] : o;
+	}
+	DeviceIndex d;
+	d.device = device, d.table_mask = mask;
+	HIP_TRY(hipMalloc((void**)&d.table, slots * sizeof(TableSlot)));
+	HIP_TRY(hipMemcpy(d.table, tab.data(), slots * sizeof(TableSlot), hipMemcpyHostToDevice));
+	HIP_TRY(hipMalloc((void**)&d.positions, (idx->pos.size() + 1) * 8));
+	HIP_TRY(hipMemcpy(d.positions, idx->pos.data(), idx->pos.size() * 8, hipMemcpyHostToDevice));
+	HIP_TRY(hipMalloc((void**)&d.contig_genome, idx->contig_genome.size() * 4));
+	HIP_TRY(hipMemcpy(d.contig_genome, idx->contig_genome.data(), idx->contig_genome.size() * 4, hipMemcpyHostToDevice));
+	d.bytes = (int64_t)(slots * sizeof(TableSlot) + (idx->pos.size() + 1) * 8 + idx->contig_genome.size() * 4);
+	idx->dev.reserve(16);
+	idx->dev.push_back(d);
+	*out = &idx->dev.back();
+	return MNC_OK;
+}
+
+void index_release_device(mnc_index *idx)
+{
+	std::lock_guard<std::mutex> lk(idx->dev_mutex);
+	for (auto &d : idx->dev) {
+		if (hipSetDevice(d.device) != hipSuccess) continue;
+		if (d.table) (void)hipFree(d.table);
+		if (d.positions) (void)hipFree(d.positions);
+		if (d.contig_genome) (void)hipFree(d.contig_genome);
+	}
+	idx->dev.clear();
+}
+
+} // namespace mnc
+
+using namespace mnc;
+
+// ================================================================ engine
+struct mnc_engine {
+	mnc_index *idx = nullptr;
+	DeviceIndex *didx = nullptr;
+	int device = 0;
+	hipStream_t stream = nullptr;
+	// constant tables
+	Buf gap_lut, logf_lut;
+	int logf_n = 0;
+	// inputs / outputs for the host-buffer entry point
+	Buf in_bases, in_offsets, out_assign, out_best, out_nhits;
+	// per base slot
+	Buf packed, mz, hits;
+	// per read
+	Buf ambig, mz_cnt, hit_cnt, rep_len, an_cnt, an_off, n_chain, n_reg, scan_sums, hit_off;
+	// per anchor
+	Buf a, f, p, v, t, u;
+	// per chain slot
+	Buf chains, chains_tmp, regs, regx, k64a, k64b, tmp_i32, gated, hits_csr;
+	Buf stats;
+	// last batch
+	Batch B{};
+	bool have_batch = false;
+	int64_t last_total_anchors = 0, last_total_hits = -1;
+	std::vector<int64_t> h_offsets;          // host copy of the last offsets (for dumps)
+	// profiling
+	bool profiling = false;
+	hipEvent_t ev[MNC_N_STAGES][2]{};
+	bool ev_used[MNC_N_STAGES]{};
+	double ms[MNC_N_STAGES]{};
+	int64_t launches[MNC_N_STAGES]{};
+};
+
+static const char *STAGE_NAME[MNC_N_STAGES] = { "pack", "sketch", "probe", "expand", "sort", "chain", "backtrack", "regions", "decide" };
+static const char *STAGE_KERNEL[MNC_N_STAGES] = {
+	"mnc_pack_bases", "mnc_sketch_minimizers", "mnc_probe_index", "mnc_scan_apply", "mnc_expand_sort",
+	"mnc_chain_dp_serial", "mnc_chain_backtrack", "mnc_regions_decide", "mnc_gather_hits" };
+
+extern "C" const char *mnc_stage_name(int s) { return s >= 0 && s < MNC_N_STAGES ? STAGE_NAME[s] : nullptr; }
+extern "C" const char *mnc_stage_kernel(int s) { return s >= 0 && s < MNC_N_STAGES ? STAGE_KERNEL[s] : nullptr; }
+
+extern "C" int mnc_device_count(int *n)
+{
+	if (!n) return MNC_ERR_ARG;
+	int c = 0;
+	if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+	*n = c;
+	return MNC_OK;
+}
+
+extern "C" int mnc_device_name(int device, char *buf, size_t cap)
+{
+	if (!buf || cap == 0) return MNC_ERR_ARG;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return MNC_ERR_NODEVICE;
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, device));
+	snprintf(buf, cap, "%s (%s)", prop.name, prop.gcnArchName);
+	return MNC_OK;
+}
+
+extern "C" void mnc_engine_destroy(mnc_engine *e)
+{
+	if (!e) return;
+	(void)hipSetDevice(e->device);
+	if (e->stream) (void)hipStreamSynchronize(e->stream);
+	Buf *all[] = { &e->gap_lut, &e->logf_lut, &e->in_bases, &e->in_offsets, &e->out_assign, &e->out_best, &e->out_nhits,
+	               &e->packed, &e->mz, &e->hits, &e->ambig, &e->mz_cnt, &e->hit_cnt, &e->rep_len, &e->an_cnt, &e->an_off,
+	               &e->n_chain, &e->n_reg, &e->scan_sums, &e->hit_off, &e->a, &e->f, &e->p, &e->v, &e->t, &e->u,
+	               &e->chains, &e->chains_tmp, &e->regs, &e->regx, &e->k64a, &e->k64b, &e->tmp_i32, &e->gated,
+	               &e->hits_csr, &e->stats };
+	for (Buf *b : all) b->release();
+	for (int s = 0; s < MNC_N_STAGES; ++s) for (int k = 0; k < 2; ++k) if (e->ev[s][k]) (void)hipEventDestroy(e->ev[s][k]);
+	if (e->stream) (void)hipStreamDestroy(e->stream);
+	delete e;
+}
+
+extern "C" int mnc_engine_create(mnc_index *idx, int device, mnc_engine **out)
+{
+	if (!idx || !out) return MNC_ERR_ARG;
+	*out = nullptr;
+	if (int rc = check_device(device)) return rc;
+	if (idx->par.bw >= GAP_LUT) { set_error("bw too large for the gap look-up"); return MNC_ERR_UNSUPPORTED; }
+	mnc_engine *e = new (std::nothrow) mnc_engine;
+	if (!e) return MNC_ERR_NOMEM;
+	e->idx = idx, e->device = device;
+	int rc = index_upload(idx, device, &e->didx);
+	if (rc) { delete e; return rc; }
+	hipError_t he = hipSetDevice(device);
+	if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+	if (he != hipSuccess) { set_error("stream creation failed: %s", hipGetErrorString(he)); delete e; return MNC_ERR_HIP; }
+	for (int s = 0; s < MNC_N_STAGES; ++s) for (int k = 0; k < 2; ++k) (void)hipEventCreate(&e->ev[s][k]);
+	// gap cost: (int)(dd * .01 * avg_span) + (ilog2(dd) >> 1), evaluated in double exactly as
+	// minimap2 does; avg_span is the float mean of the spans == k
+	std::vector<int32_t> gap(GAP_LUT);
+	const float avg_span = (float)idx->k;
+	for (int dd = 0; dd < GAP_LUT; ++dd) {
+		int lg = 0;
+		for (uint32_t v = (uint32_t)dd; v >>= 1;) ++lg;
+		gap[dd] = (int)(dd * .01 * avg_span) + (dd ? lg >> 1 : 0);
+	}
+	e->logf_n = 1 << 21;
+	std::vector<float> lg((size_t)e->logf_n);
+	for (int i = 0; i < e->logf_n; ++i) lg[i] = logf((float)i);
+	rc = e->gap_lut.ensure(GAP_LUT * 4);
+	if (!rc) rc = e->logf_lut.ensure((size_t)e->logf_n * 4);
+	if (!rc) rc = e->stats.ensure(16 * 8);
+	if (!rc) {
+		he = hipMemcpy(e->gap_lut.p, gap.data(), GAP_LUT * 4, hipMemcpyHostToDevice);
+		if (he == hipSuccess) he = hipMemcpy(e->logf_lut.p, lg.data(), (size_t)e->logf_n * 4, hipMemcpyHostToDevice);
+		if (he == hipSuccess) he = hipMemset(e->stats.p, 0, 16 * 8);
+		if (he != hipSuccess) { set_error("table upload failed: %s", hipGetErrorString(he)); rc = MNC_ERR_HIP; }
+	}
+	if (rc) { mnc_engine_destroy(e); return rc; }
+	*out = e;
+	return MNC_OK;
+}
+
+extern "C" void *mnc_engine_stream(mnc_engine *e) { return e ? (void*)e->stream : nullptr; }
+
+extern "C" int mnc_engine_sync(mnc_engine *e)
+{
+	if (!e) return MNC_ERR_ARG;
+	HIP_TRY(hipSetDevice(e->device));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	if (e->profiling) {
+		for (int s = 0; s < MNC_N_STAGES; ++s) {
+			if (!e->ev_used[s]) continue;
+			float t = 0;
+			if (hipEventElapsedTime(&t, e->ev[s][0], e->ev[s][1]) == hipSuccess) e->ms[s] += t, e->launches[s] += 1;
+			e->ev_used[s] = false;
+		}
+	}
+	return MNC_OK;
+}
+
+extern "C" int mnc_engine_set_profiling(mnc_engine *e, int on)
+{
+	if (!e) return MNC_ERR_ARG;
+	e->profiling = on != 0;
+	return MNC_OK;
+}
+
+extern "C" int mnc_engine_get_timings(mnc_engine *e, double *ms, int64_t *launches, int reset)
+{
+	if (!e) return MNC_ERR_ARG;
+	for (int s = 0; s < MNC_N_STAGES; ++s) {
+		if (ms) ms[s] = e->ms[s];
+		if (launches) launches[s] = e->launches[s];
+		if (reset) e->ms[s] = 0, e->launches[s] = 0;
+	}
+	return MNC_OK;
+}
+
+namespace {
+struct StageTimer {
+	mnc_engine *e; int s;
+	StageTimer(mnc_engine *e_, int s_) : e(e_), s(s_) { if (e->profiling) (void)hipEventRecord(e->ev[s][0], e->stream); }
+	~StageTimer() { if (e->profiling) { (void)hipEventRecord(e->ev[s][1], e->stream); e->ev_used[s] = true; } }
+};
+}
+
+// ---------------------------------------------------------------- one batch, device-resident
+extern "C" int mnc_classify_device(mnc_engine *e, const uint8_t *d_bases, const int64_t *d_offsets,
+                                   uint32_t n_reads, int64_t total_bases, int max_read_len, int min_mapq,
+                                   int32_t *d_assign, mnc_hit_t *d_best, int32_t *d_nhits, int64_t *d_counts)
+{
+	if (!e || !d_offsets || !d_assign || (total_bases > 0 && !d_bases) || total_bases < 0) return MNC_ERR_ARG;
+	if (((uintptr_t)d_bases & 15u) != 0) { set_error("d_bases must be 16-byte aligned"); return MNC_ERR_ARG; }
+	if (max_read_len < 0 || max_read_len >= (1 << 20)) { set_error("reads of 2^20 bases or more are not supported"); return MNC_ERR_UNSUPPORTED; }
+	if (n_reads >= (1u << 30) || total_bases >= (1LL << 40)) return MNC_ERR_UNSUPPORTED;
+	HIP_TRY(hipSetDevice(e->device));
+	hipStream_t st = e->stream;
+	const mnc_index *idx = e->idx;
+	e->have_batch = false, e->last_total_hits = -1;
+	const size_t nr = (size_t)n_reads, nb = (size_t)total_bases;
+
+	int rc = MNC_OK;
+#define ENS(buf, bytes) do { if (!rc) rc = e->buf.ensure(bytes); } while (0)
+	ENS(packed, (nb / 16 + 4) * 4);
+	ENS(mz, (nb + 1) * sizeof(uint2));
+	ENS(hits, (nb + 1) * sizeof(HitRec));
+	ENS(ambig, (nr + 1) * 4);
+	ENS(mz_cnt, (nr + 1) * 4);
+	ENS(hit_cnt, (nr + 1) * 4);
+	ENS(rep_len, (nr + 1) * 4);
+	ENS(an_cnt, (nr + 1) * 8);
+	ENS(an_off, (nr + 2) * 8);
+	ENS(n_chain, (nr + 1) * 4);
+	ENS(n_reg, (nr + 1) * 4);
+	ENS(hit_off, (nr + 2) * 8);
+	ENS(scan_sums, (nr / SC_TILE + 2) * 8);
+	if (!d_nhits) ENS(out_nhits, (nr + 1) * 4);
+	if (rc) return rc;
+
+	Batch &B = e->B;
+	memset(&B, 0, sizeof(B));
+	B.bases = d_bases, B.offsets = d_offsets, B.n_reads = n_reads, B.total_bases = total_bases, B.min_mapq = min_mapq;
+	B.table = e->didx->table, B.table_mask = e->didx->table_mask, B.positions = e->didx->positions;
+	B.contig_genome = e->didx->contig_genome, B.mid_occ = idx->mid_occ, B.n_genomes = (int)idx->genome_name.size();
+	const MapParams &P = idx->par;
+	B.min_cnt = P.min_cnt, B.min_sc = P.min_chain_score, B.bw = P.bw, B.max_gap = P.max_gap, B.max_skip = P.max_chain_skip;
+	B.max_iter = P.max_chain_iter, B.best_n = P.best_n, B.seed = P.seed, B.max_join_long = P.max_join_long;
+	B.max_join_short = P.max_join_short, B.min_join_flank_sc = P.min_join_flank_sc, B.mask_level = P.mask_level;
+	B.pri_ratio = P.pri_ratio, B.min_join_flank_ratio = P.min_join_flank_ratio;
+	B.gap_lut = e->gap_lut.as<int32_t>(), B.logf_lut = e->logf_lut.as<float>(), B.logf_n = e->logf_n;
+	B.packed = e->packed.as<uint32_t>(), B.ambig = e->ambig.as<uint32_t>(), B.mz = e->mz.as<uint2>(), B.hits = e->hits.as<HitRec>();
+	B.mz_cnt = e->mz_cnt.as<int32_t>(), B.hit_cnt = e->hit_cnt.as<int32_t>(), B.rep_len = e->rep_len.as<int32_t>();
+	B.an_cnt = e->an_cnt.as<int64_t>(), B.an_off = e->an_off.as<int64_t>(), B.n_chain = e->n_chain.as<int32_t>(), B.n_reg = e->n_reg.as<int32_t>();
+	B.assign = d_assign, B.best = d_best, B.nhits = d_nhits ? d_nhits : e->out_nhits.as<int32_t>(), B.counts = d_counts;
+	B.stats = e->stats.as<int64_t>();
+
+	HIP_TRY(hipMemsetAsync(B.ambig, 0, (nr + 1) * 4, st));
+	HIP_TRY(hipMemsetAsync(B.packed + nb / 16, 0, 16, st));
+	if (n_reads == 0) { e->have_batch = true; e->last_total_anchors = 0; return MNC_OK; }
+
+	{ StageTimer t(e, MNC_STAGE_PACK);   launch_pack(B, st); }
+	{ StageTimer t(e, MNC_STAGE_SKETCH); launch_sketch(B, st); }
+	{ StageTimer t(e, MNC_STAGE_PROBE);  launch_probe(B, st); }
+	{ StageTimer t(e, MNC_STAGE_EXPAND); exclusive_scan(B.an_cnt, (int64_t)n_reads, B.an_off, e->scan_sums.as<int64_t>(), st); }
+	HIP_TRY(hipGetLastError());
+
+	// the anchor total sizes every later buffer: one 8-byte read-back per batch
+	int64_t total_anchors = 0;
+	HIP_TRY(hipMemcpyAsync(&total_anchors, B.an_off + n_reads, 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	if (total_anchors < 0 || total_anchors >= (1LL << 31) * 16) { set_error("anchor count %lld out of range", (long long)total_anchors); return MNC_ERR_UNSUPPORTED; }
+	e->last_total_anchors = total_anchors;
+	const size_t na = (size_t)total_anchors + 4, ns = (size_t)total_anchors / 3 + 4;
+	ENS(a, na * sizeof(Anchor));
+	ENS(f, na * 4); ENS(p, na * 4); ENS(v, na * 4); ENS(t, na * 4);
+	ENS(u, na * 8);
+	ENS(chains, ns * sizeof(ChainRec)); ENS(chains_tmp, ns * sizeof(ChainRec));
+	ENS(regs, ns * sizeof(mnc_reg_t)); ENS(regx, ns * 32);
+	ENS(k64a, ns * 8); ENS(k64b, ns * 8); ENS(tmp_i32, ns * 16); ENS(gated, ns * sizeof(mnc_hit_t));
+	if (rc) return rc;
+#undef ENS
+	B.an_cap = (int64_t)na;
+	B.a = e->a.as<Anchor>(), B.chains_tmp = e->chains_tmp.as<ChainRec>();
+	B.f = e->f.as<int32_t>(), B.p = e->p.as<int32_t>(), B.v = e->v.as<int32_t>(), B.t = e->t.as<int32_t>(), B.u = e->u.as<uint64_t>();
+	B.chains = e->chains.as<ChainRec>(), B.regs = e->regs.as<mnc_reg_t>(), B.tmp_i32 = e->tmp_i32.as<int32_t>();
+
+	{ StageTimer t(e, MNC_STAGE_SORT);      launch_expand_sort(B, st); }
+	{ StageTimer t(e, MNC_STAGE_CHAIN);     launch_chain_dp_serial(B, nullptr, n_reads, st); }
+	{ StageTimer t(e, MNC_STAGE_BACKTRACK); launch_backtrack(B, st); }
+	{ StageTimer t(e, MNC_STAGE_REGIONS);   launch_regions(B, e->regx.p, e->k64a.as<uint64_t>(), e->k64b.as<uint64_t>(), e->gated.as<mnc_hit_t>(), st); }
+	HIP_TRY(hipGetLastError());
+	e->have_batch = true;
+	return MNC_OK;
+}
+
+// ---------------------------------------------------------------- one batch, host buffers
+extern "C" int mnc_classify_batch(mnc_engine *e, const uint8_t *bases, const int64_t *offsets, uint32_t n_reads,
+                                  int min_mapq, int32_t *out_assign, mnc_hit_t *out_best, int32_t *out_nhits)
+{
+	if (!e || !offsets || !out_assign) return MNC_ERR_ARG;
+	const int64_t total = offsets[n_reads] - offsets[0];
+	if (offsets[0] != 0 || total < 0 || (total > 0 && !bases)) { set_error("offsets must start at 0 and be non-decreasing"); return MNC_ERR_ARG; }
+	int max_len = 0;
+	for (uint32_t r = 0; r < n_reads; ++r) {
+		const int64_t l = offsets[r + 1] - offsets[r];
+		if (l < 0) { set_error("offsets must be non-decreasing"); return MNC_ERR_ARG; }
+		if (l >= (1 << 20)) { set_error("read %u has %lld bases; 2^20 or more is not supported", r, (long long)l); return MNC_ERR_UNSUPPORTED; }
+		if (l > max_len) max_len = (int)l;
+	}
+	HIP_TRY(hipSetDevice(e->device));
+	const size_t nr = n_reads;
+	int rc = e->in_bases.ensure((size_t)total + 32);
+	if (!rc) rc = e->in_offsets.ensure((nr + 1) * 8);
+	if (!rc) rc = e->out_assign.ensure((nr + 1) * 4);
+	if (!rc) rc = e->out_best.ensure((nr + 1) * sizeof(mnc_hit_t));
+	if (!rc) rc = e->out_nhits.ensure((nr + 1) * 4);
+	if (rc) return rc;
+	hipStream_t st = e->stream;
+	if (total > 0) HIP_TRY(hipMemcpyAsync(e->in_bases.p, bases, (size_t)total, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(e->in_offsets.p, offsets, (nr + 1) * 8, hipMemcpyHostToDevice, st));
+	rc = mnc_classify_device(e, e->in_bases.as<uint8_t>(), e->in_offsets.as<int64_t>(), n_reads, total, max_len, min_mapq,
+	                         e->out_assign.as<int32_t>(), e->out_best.as<mnc_hit_t>(), e->out_nhits.as<int32_t>(), nullptr);
+	if (rc) return rc;
+	if (nr) {
+		HIP_TRY(hipMemcpyAsync(out_assign, e->out_assign.p, nr * 4, hipMemcpyDeviceToHost, st));
+		if (out_best) HIP_TRY(hipMemcpyAsync(out_best, e->out_best.p, nr * sizeof(mnc_hit_t), hipMemcpyDeviceToHost, st));
+		if (out_nhits) HIP_TRY(hipMemcpyAsync(out_nhits, e->out_nhits.p, nr * 4, hipMemcpyDeviceToHost, st));
+	}
+	rc = mnc_engine_sync(e);
+	if (rc) return rc;
+	HIP_TRY(hipGetLastError());
+	e->h_offsets.assign(offsets, offsets + nr + 1);
+	return MNC_OK;
+}
+
+// ---------------------------------------------------------------- gated hits of the last batch
+extern "C" int mnc_engine_fetch_hits(mnc_engine *e, int64_t *hit_offsets, mnc_hit_t *hits, int64_t cap, int64_t *n_hits)
+{
+	if (!e || !n_hits) return MNC_ERR_ARG;
+	if (!e->have_batch) { set_error("no batch has been classified"); return MNC_ERR_ARG; }
+	HIP_TRY(hipSetDevice(e->device));
+	hipStream_t st = e->stream;
+	Batch &B = e->B;
+	const size_t nr = B.n_reads;
+	if (nr == 0) { *n_hits = 0; if (hit_offsets) hit_offsets[0] = 0; return MNC_OK; }
+	int64_t *d_off = e->hit_off.as<int64_t>();
+	if (e->last_total_hits < 0) {
+		StageTimer t(e, MNC_STAGE_DECIDE);
+		exclusive_scan(B.nhits, (int64_t)nr, d_off, e->scan_sums.as<int64_t>(), st);
+		int64_t total = 0;
+		HIP_TRY(hipMemcpyAsync(&total, d_off + nr, 8, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		int rc = e->hits_csr.ensure(((size_t)total + 1) * sizeof(mnc_hit_t));
+		if (rc) return rc;
+		launch_gather_hits(B, e->gated.as<mnc_hit_t>(), d_off, e->hits_csr.as<mnc_hit_t>(), st);
+		e->last_total_hits = total;
+	}
+	*n_hits = e->last_total_hits;
+	if (cap < e->last_total_hits || !hits || !hit_offsets) { (void)mnc_engine_sync(e); return MNC_ERR_RANGE; }
+	HIP_TRY(hipMemcpyAsync(hit_offsets, d_off, (nr + 1) * 8, hipMemcpyDeviceToHost, st));
+	if (e->last_total_hits > 0) HIP_TRY(hipMemcpyAsync(hits, e->hits_csr.p, (size_t)e->last_total_hits * sizeof(mnc_hit_t), hipMemcpyDeviceToHost, st));
+	return mnc_engine_sync(e);
+}
+
+// ---------------------------------------------------------------- counters / dumps
+extern "C" int mnc_engine_get_counters(mnc_engine *e, int64_t *c, int n)
+{
+	if (!e || !c || n < 8) return MNC_ERR_ARG;
+	if (!e->have_batch) { set_error("no batch has been classified"); return MNC_ERR_ARG; }
+	HIP_TRY(hipSetDevice(e->device));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	const Batch &B = e->B;
+	const size_t nr = B.n_reads;
+	std::vector<int32_t> a(nr), b(nr), d(nr), g(nr), h(nr);
+	std::vector<uint32_t> amb(nr);
+	if (nr) {
+		HIP_TRY(hipMemcpy(a.data(), B.mz_cnt, nr * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(b.data(), B.hit_cnt, nr * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(d.data(), B.n_chain, nr * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(g.data(), B.n_reg, nr * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(h.data(), B.nhits, nr * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(amb.data(), B.ambig, nr * 4, hipMemcpyDeviceToHost));
+	}
+	for (int i = 0; i < n; ++i) c[i] = 0;
+	for (size_t r = 0; r < nr; ++r) c[0] += a[r], c[1] += b[r], c[3] += d[r], c[4] += g[r], c[5] += h[r], c[6] += amb[r] ? 1 : 0;
+	c[2] = e->last_total_anchors;
+	c[7] = 0;
+	return MNC_OK;
+}
+
+namespace {
+// copy per-read segments [base[r], base[r]+cnt[r]) of a device array into one host run
+template <class T>
+int dump_segments(const T *d_arr, const std::vector<int64_t> &base, const std::vector<int64_t> &cnt,
+                  void *dst, int64_t cap_bytes, int64_t *n_bytes)
+{
+	int64_t total = 0;
+	for (size_t r = 0; r < cnt.size(); ++r) total += cnt[r];
+	*n_bytes = total * (int64_t)sizeof(T);
+	if (!dst || cap_bytes < *n_bytes) return MNC_ERR_RANGE;
+	T *o = reinterpret_cast<T*>(dst);
+	for (size_t r = 0; r < cnt.size(); ++r) {
+		if (cnt[r] > 0) HIP_TRY(hipMemcpy(o, d_arr + base[r], (size_t)cnt[r] * sizeof(T), hipMemcpyDeviceToHost));
+		o += cnt[r];
+	}
+	return MNC_OK;
+}
+template <class T>
+int dump_offsets(const std::vector<T> &cnt, void *dst, int64_t cap_bytes, int64_t *n_bytes)
+{
+	*n_bytes = (int64_t)(cnt.size() + 1) * 8;
+	if (!dst || cap_bytes < *n_bytes) return MNC_ERR_RANGE;
+	int64_t *o = reinterpret_cast<int64_t*>(dst), s = 0;
+	for (size_t r = 0; r < cnt.size(); ++r) { o[r] = s; s += (int64_t)cnt[r]; }
+	o[cnt.size()] = s;
+	return MNC_OK;
+}
+}
+
+extern "C" int mnc_engine_dump(mnc_engine *e, int what, void *dst, int64_t cap_bytes, int64_t *n_bytes)
+{
+	if (!e || !n_bytes) return MNC_ERR_ARG;
+	if (!e->have_batch) { set_error("no batch has been classified"); return MNC_ERR_ARG; }
+	HIP_TRY(hipSetDevice(e->device));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	const Batch &B = e->B;
+	const size_t nr = B.n_reads;
+	std::vector<int64_t> off(nr + 1), an_off(nr + 1);
+	std::vector<int32_t> c32(nr);
+	if (nr) {
+		HIP_TRY(hipMemcpy(off.data(), B.offsets, (nr + 1) * 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(an_off.data(), B.an_off, (nr + 1) * 8, hipMemcpyDeviceToHost));
+	}
+	std::vector<int64_t> base(nr), cnt(nr);
+	switch (what) {
+	case MNC_DUMP_MINIMIZERS:
+	case MNC_DUMP_MZ_OFFSETS: {
+		if (nr) HIP_TRY(hipMemcpy(c32.data(), B.mz_cnt, nr * 4, hipMemcpyDeviceToHost));
+		if (what == MNC_DUMP_MZ_OFFSETS) return dump_offsets(c32, dst, cap_bytes, n_bytes);
+		for (size_t r = 0; r < nr; ++r) base[r] = off[r], cnt[r] = c32[r];
+		return dump_segments(B.mz, base, cnt, dst, cap_bytes, n_bytes);
+	}
+	case MNC_DUMP_AN_OFFSETS:
+		*n_bytes = (int64_t)(nr + 1) * 8;
+		if (!dst || cap_bytes < *n_bytes) return MNC_ERR_RANGE;
+		memcpy(dst, an_off.data(), (size_t)*n_bytes);
+		return MNC_OK;
+	case MNC_DUMP_ANCHORS: case MNC_DUMP_CHAIN_F: case MNC_DUMP_CHAIN_P: case MNC_DUMP_CHAIN_V: {
+		const int64_t n = nr ? an_off[nr] : 0;
+		const size_t es = what == MNC_DUMP_ANCHORS ? sizeof(Anchor) : 4;
+		*n_bytes = n * (int64_t)es;
+		if (!dst || cap_bytes < *n_bytes) return MNC_ERR_RANGE;
+		const void *src = what == MNC_DUMP_ANCHORS ? (const void*)B.a : what == MNC_DUMP_CHAIN_F ? (const void*)B.f
+		                : what == MNC_DUMP_CHAIN_P ? (const void*)B.p : (const void*)B.v;
+		if (n) HIP_TRY(hipMemcpy(dst, src, (size_t)*n_bytes, hipMemcpyDeviceToHost));
+		return MNC_OK;
+	}
+	case MNC_DUMP_REGS:
+	case MNC_DUMP_REG_OFFSETS: {
+		if (nr) HIP_TRY(hipMemcpy(c32.data(), B.n_reg, nr * 4, hipMemcpyDeviceToHost));
+		if (what == MNC_DUMP_REG_OFFSETS) return dump_offsets(c32, dst, cap_bytes, n_bytes);
+		for (size_t r = 0; r < nr; ++r) base[r] = an_off[r] / 3, cnt[r] = c32[r];
+		return dump_segments(B.regs, base, cnt, dst, cap_bytes, n_bytes);
+	}
+	case MNC_DUMP_REP_LEN:
+		*n_bytes = (int64_t)nr * 4;
+		if (!dst || cap_bytes < *n_bytes) return MNC_ERR_RANGE;
+		if (nr) HIP_TRY(hipMemcpy(dst, B.rep_len, nr * 4, hipMemcpyDeviceToHost));
+		return MNC_OK;
+	default:
+		return MNC_ERR_ARG;
+	}
+}

@@ -1,0 +1,104 @@
+"""Deterministic synthetic genomes and nanopore-like reads.
+
+No real genome or read set is available offline, so the workloads of BASELINE.json are
+generated: i.i.d. uniform ACGT contigs, optionally with point-diverged copies, and reads of a
+fixed length with an i.i.d. substitution / insertion / deletion model.  The generator is a
+counter-based SplitMix64 (``csrc/synth.cpp``): a value depends only on (seed, index), so every
+rank and every machine produces identical bytes for the same ordinal.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+SEED_ECOLI = 0xEC011
+SEED_20 = 0x20
+SEED_20_DIV = 0x2020
+SEED_500 = 0x500
+SEED_READS = 0x5EED
+
+
+def _mix(z):
+    z &= (1 << 64) - 1
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & ((1 << 64) - 1)
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & ((1 << 64) - 1)
+    return z ^ (z >> 31)
+
+
+def genome(seed, length):
+    out = np.empty(length, dtype=np.uint8)
+    _capi.check(_capi.lib().mnc_synth_genome(seed, length, out.ctypes.data))
+    return out
+
+
+def diverge(src, seed, rate_ppm):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    out = np.empty_like(src)
+    _capi.check(_capi.lib().mnc_synth_diverge(src.ctypes.data, len(src), seed, rate_ppm, out.ctypes.data))
+    return out
+
+
+def contig_name(i):
+    """``tax_unit:accession`` header convention of database.py:59."""
+    return f"Genus{i}_species{i}:ACC{i:06d}.1"
+
+
+def genome_set(n_genomes, seed=SEED_20, div_seed=SEED_20_DIV, min_len=2_000_000, max_len=7_000_000,
+               diverged_half=True, rate_ppm=30_000):
+    """n contigs with lengths uniform in [min_len, max_len]; when ``diverged_half`` the second
+    half are ``rate_ppm`` point-diverged copies of the first half (so secondaries, sub-optimal
+    scores and ambiguous decisions are exercised)."""
+    names, seqs = [], []
+    base = n_genomes // 2 if diverged_half else n_genomes
+    for i in range(n_genomes):
+        if i < base or not diverged_half:
+            length = min_len + _mix(seed * 1_000_003 + i) % (max_len - min_len + 1)
+            seqs.append(genome(_mix(seed) + i, int(length)))
+        else:
+            seqs.append(diverge(seqs[i - base], _mix(div_seed) + i, rate_ppm))
+        names.append(contig_name(i))
+    return names, seqs
+
+
+def ecoli_like():
+    return [contig_name(0)], [genome(SEED_ECOLI, 4_641_652)]
+
+
+def reads(genomes, n_reads, read_len=5000, seed=SEED_READS, first=0, sub=400, ins=300, dele=300,
+          random_frac=200):
+    """Returns (bases uint8[n_reads*read_len], offsets int64[n_reads+1], truth int32[n_reads]).
+    Rates are in 1e-4 units: 4 % substitutions, 3 % insertions, 3 % deletions, 2 % pure-random
+    reads (truth -1) by default."""
+    n = len(genomes)
+    keep = [np.ascontiguousarray(g, dtype=np.uint8) for g in genomes]
+    ptrs = (C.c_void_p * n)(*[g.ctypes.data for g in keep])
+    lens = (C.c_int64 * n)(*[len(g) for g in keep])
+    out = np.empty(n_reads * read_len, dtype=np.uint8)
+    truth = np.empty(n_reads, dtype=np.int32)
+    _capi.check(_capi.lib().mnc_synth_reads(n, ptrs, lens, seed, first, n_reads, read_len,
+                                            sub, ins, dele, random_frac, out.ctypes.data, truth.ctypes.data))
+    offsets = np.arange(n_reads + 1, dtype=np.int64) * read_len
+    return out, offsets, truth
+
+
+def write_fasta(path, names, seqs, width=80, gz=None):
+    """Write contigs as (optionally gzipped) FASTA."""
+    import gzip
+    gz = path.endswith(".gz") if gz is None else gz
+    opener = gzip.open if gz else open
+    with opener(path, "wb") as f:
+        for name, s in zip(names, seqs):
+            f.write(b">" + name.encode() + b"\n")
+            b = np.ascontiguousarray(s, dtype=np.uint8).tobytes()
+            for i in range(0, len(b), width):
+                f.write(b[i:i + width] + b"\n")
+
+
+def write_fastq(path, bases, offsets, ids=None, qual=b"I"):
+    with open(path, "wb") as f:
+        b = np.ascontiguousarray(bases, dtype=np.uint8).tobytes()
+        for r in range(len(offsets) - 1):
+            s = b[offsets[r]:offsets[r + 1]]
+            rid = ids[r] if ids is not None else f"read{r}"
+            f.write(b"@" + rid.encode() + b"\n" + s + b"\n+\n" + qual * len(s) + b"\n")

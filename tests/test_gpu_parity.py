@@ -1,0 +1,129 @@
+"""GPU parity: every stage of the HIP path against the CPU oracle, through the C-ABI.
+
+Bit-exact is the bar: minimizers, anchors, chaining scores/back-pointers, regions (every
+field), per-read decisions, gated hit lists, taxon counts."""
+import numpy as np
+import pytest
+
+from monica_amd import synth
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def world(capi, oracle):
+    names, seqs = util.small_genomes()
+    idx = capi.Index.from_seqs(names, seqs)
+    oidx = oracle.Index.from_seqs(names, [s.tobytes() for s in seqs])
+    eng = capi.Engine(idx, 0)
+    return dict(names=names, seqs=seqs, idx=idx, oidx=oidx, eng=eng)
+
+
+def _compare_batch(capi, oracle, world, bases, offsets, min_mapq=60):
+    eng, oidx = world["eng"], world["oidx"]
+    n = len(offsets) - 1
+    assign, best, nhits = eng.classify(bases, offsets, min_mapq)
+    mz = eng.dump(capi.DUMP_MINIMIZERS, capi.MZ_DTYPE)
+    mz_off = eng.dump(capi.DUMP_MZ_OFFSETS, np.int64)
+    an = eng.dump(capi.DUMP_ANCHORS, capi.ANCHOR_DTYPE)
+    an_off = eng.dump(capi.DUMP_AN_OFFSETS, np.int64)
+    f = eng.dump(capi.DUMP_CHAIN_F, np.int32)
+    p = eng.dump(capi.DUMP_CHAIN_P, np.int32)
+    regs = eng.dump(capi.DUMP_REGS, capi.REG_DTYPE)
+    reg_off = eng.dump(capi.DUMP_REG_OFFSETS, np.int64)
+    rep = eng.dump(capi.DUMP_REP_LEN, np.int32)
+    hit_off, hits = eng.fetch_hits()
+    raw = bases.tobytes()
+    for r in range(n):
+        s = raw[offsets[r]:offsets[r + 1]]
+        # K1
+        omz = oracle.sketch(s)
+        got = mz[mz_off[r]:mz_off[r + 1]]
+        assert len(got) == len(omz), f"read {r}: minimizer count {len(got)} != {len(omz)}"
+        assert np.array_equal(got["hash"].astype(np.uint64), omz["x"] >> np.uint64(8)), f"read {r}: hashes"
+        assert np.array_equal(got["pos_strand"].astype(np.uint64), omz["y"] & np.uint64(0xffffffff)), f"read {r}: positions"
+        # K2/K3
+        oa, orep = oidx.seeds(s)
+        ga = an[an_off[r]:an_off[r + 1]]
+        assert rep[r] == orep, f"read {r}: rep_len {rep[r]} != {orep}"
+        assert len(ga) == len(oa), f"read {r}: anchor count {len(ga)} != {len(oa)}"
+        assert np.array_equal(ga["x"], oa["x"]) and np.array_equal(ga["y"], oa["y"]), f"read {r}: anchors"
+        # K4
+        _, of, op, ov, ou, ob = oidx.chain(s)
+        assert np.array_equal(f[an_off[r]:an_off[r + 1]], of), f"read {r}: chain f"
+        assert np.array_equal(p[an_off[r]:an_off[r + 1]], op), f"read {r}: chain p"
+        # K5/K6
+        oregs = oidx.map(s)
+        gr = regs[reg_off[r]:reg_off[r + 1]]
+        assert len(gr) == len(oregs), f"read {r}: region count {len(gr)} != {len(oregs)}"
+        for name in capi.REG_DTYPE.names:
+            assert np.array_equal(gr[name], oregs[name]), f"read {r}: region field {name}: {gr[name]} != {oregs[name]}"
+    oassign, obest, onh, oflat = oidx.classify(bases, offsets, min_mapq)
+    assert np.array_equal(assign, oassign)
+    assert np.array_equal(nhits, onh)
+    for name in capi.HIT_DTYPE.names:
+        assert np.array_equal(best[name], obest[name]), name
+        assert np.array_equal(hits[name], oflat[name]), name
+    assert np.array_equal(np.diff(hit_off), onh)
+    return assign, best, nhits
+
+
+def test_edge_cases(capi, oracle, world):
+    rng = np.random.default_rng(7)
+    reads = util.edge_reads(world["seqs"], rng)
+    bases, offsets = util.pack_reads(reads)
+    assign, best, nhits = _compare_batch(capi, oracle, world, bases, offsets)
+    assert assign[0] == capi.UNMAPPED and assign[1] == capi.UNMAPPED
+    assert assign[6] == 0 and assign[7] == 0            # error-free reads hit their contig
+
+
+def test_synthetic_reads(capi, oracle, world):
+    bases, offsets, truth = synth.reads(world["seqs"], 400, 5000, seed=0x5EED + 1)
+    assign, best, nhits = _compare_batch(capi, oracle, world, bases, offsets)
+    mapped = assign >= 0
+    assert (assign[mapped] == truth[mapped]).mean() > 0.98
+    assert (assign[truth < 0] == capi.UNMAPPED).all()
+
+
+def test_ragged_lengths_and_low_mapq(capi, oracle, world):
+    rng = np.random.default_rng(11)
+    full, offs, _ = synth.reads(world["seqs"], 120, 6000, seed=99)
+    reads = []
+    for r in range(120):
+        L = int(rng.integers(1, 6000))
+        reads.append(full[offs[r]:offs[r] + L])
+    bases, offsets = util.pack_reads(reads)
+    _compare_batch(capi, oracle, world, bases, offsets, min_mapq=0)
+    _compare_batch(capi, oracle, world, bases, offsets, min_mapq=30)
+
+
+def test_empty_batch(capi, world):
+    assign, best, nhits = world["eng"].classify(np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.int64))
+    assert len(assign) == 0
+
+
+def test_device_counts_match_host_counts(capi, oracle, world):
+    import torch
+    bases, offsets, truth = synth.reads(world["seqs"], 300, 3000, seed=5)
+    eng, idx = world["eng"], world["idx"]
+    dev = torch.device("cuda:0")
+    d_bases = torch.from_numpy(bases).to(dev)
+    d_off = torch.from_numpy(offsets).to(dev)
+    d_assign = torch.empty(len(truth), dtype=torch.int32, device=dev)
+    d_best = torch.zeros(len(truth) * 4, dtype=torch.int32, device=dev)
+    d_counts = torch.zeros(len(idx.genome_names) * 3, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    eng.classify_device(d_bases.data_ptr(), d_off.data_ptr(), len(truth), int(offsets[-1]), 3000, 60,
+                        d_assign.data_ptr(), d_best.data_ptr(), 0, d_counts.data_ptr())
+    eng.sync()
+    assign = d_assign.cpu().numpy()
+    best = d_best.cpu().numpy().view(capi.HIT_DTYPE)
+    got = d_counts.cpu().numpy().reshape(-1, 3)
+    for mode in (1, 2, 3):
+        want = capi.counts(idx, assign, best, offsets, mode)
+        assert np.array_equal(got[:, mode - 1], want)
+    oassign, obest, _, _ = world["oidx"].classify(bases, offsets, 60)
+    assert np.array_equal(assign, oassign)
+    assert got[:, 0].sum() == (oassign >= 0).sum()
+    assert got[:, 1].sum() == 3000 * (oassign >= 0).sum()
