@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Headline benchmark: reads/s classified on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path (2-bit pack -> minimizer sketch -> index probe ->
+anchor sort -> chain -> regions/MAPQ -> decision + taxon counts) over one batch of synthetic
+5 kb reads already resident in HBM, followed -- for N > 1 -- by the RCCL all-reduce of the
+per-taxon count vector (the analogue of alignment_update, aligner.py:282-302).  Reads shard
+across ranks with no other collective ("weak" scaling: every rank classifies its own
+`--reads` reads per step).
+
+Workload at N=1 = BASELINE.json configs[1]: 100 k synthetic 5 kb reads vs the 20-genome
+index.  Rank 0 prints one JSON line with `roofline` (index-probe kernel, HIP-event timed on
+the engine stream over the timed region) and, at N=1, `cpu_baseline` (the CPU oracle timed on
+a bounded sample of the same reads on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=100_000, help="reads per rank per step")
+    ap.add_argument("--read-len", type=int, default=5000)
+    ap.add_argument("--genomes", type=int, default=20)
+    ap.add_argument("--min-len", type=int, default=2_000_000)
+    ap.add_argument("--max-len", type=int, default=7_000_000)
+    ap.add_argument("--min-mapq", type=int, default=60)
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1 auto, 0 off)")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "probe_traffic.json"),
+                    help="optional PMC-derived HBM bytes per launch of the probe kernel")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    import torch
+    import torch.distributed as dist
+    from monica_amd import _capi, synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---------------------------------------------------------------- workload (deterministic)
+    t0 = time.time()
+    names, seqs = synth.genome_set(args.genomes, min_len=args.min_len, max_len=args.max_len)
+    index = _capi.Index.from_seqs(names, seqs)
+    info = index.info()
+    bases, offsets, truth = synth.reads(seqs, args.reads, args.read_len, seed=synth.SEED_READS + 2,
+                                        first=rank * args.reads)
+    engine = _capi.Engine(index, local_rank)
+    n_genomes = info.n_genomes
+    t_setup = time.time() - t0
+
+    d_bases = torch.from_numpy(bases).to(dev)
+    d_off = torch.from_numpy(offsets).to(dev)
+    d_assign = torch.empty(args.reads, dtype=torch.int32, device=dev)
+    d_best = torch.zeros(args.reads * 4, dtype=torch.int32, device=dev)
+    d_nhits = torch.zeros(args.reads, dtype=torch.int32, device=dev)
+    d_counts = torch.zeros(n_genomes * 3, dtype=torch.int64, device=dev)
+    total_bases = int(offsets[-1])
+    torch.cuda.synchronize()
+
+    def step():
+        d_counts.zero_()
+        torch.cuda.current_stream().synchronize()
+        engine.classify_device(d_bases.data_ptr(), d_off.data_ptr(), args.reads, total_bases, args.read_len,
+                               args.min_mapq, d_assign.data_ptr(), d_best.data_ptr(), d_nhits.data_ptr(),
+                               d_counts.data_ptr())
+        engine.sync()
+        if world > 1:
+            dist.all_reduce(d_counts)          # RCCL over xGMI: n_genomes*3 int64
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    engine.set_profiling(True)
+    engine.timings(reset=True)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t1
+    engine.set_profiling(False)
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    timings = engine.timings()
+    counters = engine.counters()
+    assign = d_assign.cpu().numpy()
+    counts = d_counts.cpu().numpy().reshape(-1, 3)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---------------------------------------------------------------- roofline of the probe kernel
+    probe_ms, probe_n = timings["probe"]
+    M, H = counters["minimizers"], counters["probe_hits"]
+    # algorithmic bytes of one launch: queries 8 B + one 16-B table slot
+    # per query + one 16-B hit record per probe hit + 3 per-read result words
+    algo_bytes = M * 8 + M * 16 + H * 16 + args.reads * (4 + 4 + 8 + 4 + 16)
+    roofline = None
+    if probe_n > 0 and probe_ms > 0:
+        avg_s = probe_ms / probe_n / 1e3
+        achieved = algo_bytes / avg_s / 1e9
+        traffic = None
+        try:
+            with open(args.traffic_json) as f:
+                tj = json.load(f)
+            if tj.get("reads") == args.reads and tj.get("read_len") == args.read_len:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+        roofline = {"bound": "hbm", "kernel": "mnc_probe_index", "achieved": round(achieved, 2),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "algorithmic_bytes_per_launch": int(algo_bytes),
+                    "avg_launch_ms": round(probe_ms / probe_n, 4), "launches": probe_n}
+
+    # ---------------------------------------------------------------- CPU baseline (oracle, bounded sample)
+    cpu = None
+    if world == 1 and args.cpu_sample != 0:
+        from oracle import pyoracle
+        cores = os.cpu_count() or 1
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except Exception:
+            pass
+        oidx = pyoracle.Index.from_seqs(names, [s.tobytes() for s in seqs])
+        n_s = args.cpu_sample if args.cpu_sample > 0 else min(args.reads, 2000)
+        ob, oo = bases[: n_s * args.read_len], offsets[: n_s + 1]
+        tc = time.perf_counter()
+        oa, _, _, _ = oidx.classify(ob, oo, args.min_mapq, n_threads=cores)
+        dt = time.perf_counter() - tc
+        if args.cpu_sample < 0 and dt < 10.0:       # scale the sample to ~15 s of CPU work
+            n_s2 = int(min(args.reads, max(n_s, n_s * 15.0 / max(dt, 1e-3))))
+            if n_s2 > n_s:
+                n_s = n_s2
+                ob, oo = bases[: n_s * args.read_len], offsets[: n_s + 1]
+                tc = time.perf_counter()
+                oa, _, _, _ = oidx.classify(ob, oo, args.min_mapq, n_threads=cores)
+                dt = time.perf_counter() - tc
+        agree = bool(np.array_equal(oa, assign[:n_s]))
+        cpu = {"value": round(n_s / dt, 1), "unit": "reads/s", "cores": cores, "kind": "port",
+               "sample": f"first {n_s} reads of the same batch, CPU oracle (chain-level minimap2-2.17 restatement, "
+                         f"OpenMP over reads), {dt:.1f} s", "agrees_with_gpu": agree}
+
+    n_total = args.reads * args.steps * world
+    mapped = int((assign >= 0).sum())
+    out = {
+        "metric": "reads/sec classified",
+        "value": round(n_total / elapsed, 1),
+        "unit": "reads/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32/u64 integer (float32 islands: overlap ratio, MAPQ)",
+        "data": "synthetic",
+        "config": {"workload": f"{args.reads} synthetic {args.read_len} nt reads per GPU per step vs "
+                               f"{args.genomes}-genome minimizer index ({info.total_len} bp, {info.n_keys} keys, "
+                               f"mid_occ {info.mid_occ})",
+                   "reads_per_gpu_per_step": args.reads, "read_len": args.read_len, "genomes": args.genomes,
+                   "parallelism": f"read-sharded x{world}, index replicated, RCCL all-reduce of "
+                                  f"{n_genomes * 3} int64 counts per step"},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "stage_ms_per_step": {k: round(v[0] / max(v[1], 1), 4) for k, v in timings.items() if v[1]},
+        "batch_counters": counters,
+        "mapped_reads_last_step": mapped,
+        "counts_checksum": int(counts[:, 0].sum()),
+        "setup_s": round(t_setup, 1),
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
