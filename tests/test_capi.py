@@ -1,0 +1,170 @@
+"""CPU tests of the C-ABI library: it loads, exports every symbol the header declares, the
+host-side index builder agrees with the oracle, the host-side monica helpers agree with the
+oracle, and compute entry points fail loudly without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from monica_amd import synth
+import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "monica_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mnc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(capi):
+    declared = header_functions()
+    assert len(declared) >= 30
+    L = capi.lib()
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/monica_amd.h but not exported"
+    assert sorted(capi.EXPORTS) == declared
+    assert b"gfx950" in L.mnc_version()
+
+
+def test_error_strings(capi):
+    L = capi.lib()
+    assert L.mnc_strerror(0) == b"ok"
+    assert L.mnc_strerror(capi.ERR_FORMAT) == b"Damaged or empty index"     # aligner.py:61
+    for code in range(-8, 0):
+        assert L.mnc_strerror(code) != b"unknown error"
+
+
+@pytest.fixture(scope="module")
+def world(capi, oracle):
+    names, seqs = util.small_genomes(4, 100_000, 140_000)
+    # a genome split over two contigs sharing one name (database.py:59-64) and an N run
+    s2 = seqs[2].copy()
+    s2[5000:5040] = ord("N")
+    names = names[:2] + [names[2], names[2], names[3]]
+    seqs = seqs[:2] + [s2[:60_000], s2[60_000:], seqs[3]]
+    idx = capi.Index.from_seqs(names, seqs)
+    oidx = oracle.Index.from_seqs(names, [s.tobytes() for s in seqs])
+    return names, seqs, idx, oidx
+
+
+def test_index_matches_oracle(capi, world):
+    names, seqs, idx, oidx = world
+    info = idx.info()
+    assert (info.k, info.w) == (15, 10)
+    assert info.n_contigs == 5 and info.n_genomes == 4
+    assert info.n_keys == oidx.n_keys and info.n_occ == oidx.n_minimizers
+    assert info.mid_occ == oidx.mid_occ
+    h, y = idx.dump()
+    oh, oy = oidx.dump()
+    assert np.array_equal(h, oh) and np.array_equal(y, oy)
+    assert idx.contig_names == names
+    assert idx.contig_genome.tolist() == [0, 1, 2, 2, 3]
+    assert idx.genome_lens[2] == len(seqs[2]) + len(seqs[3])       # database.py:57-65 sums contigs
+    assert info.total_len == sum(len(s) for s in seqs)
+
+
+def test_index_file_roundtrip_and_fasta_build(capi, world, tmp_path):
+    names, seqs, idx, oidx = world
+    p = str(tmp_path / "index0.mmi")
+    idx.save(p)
+    again = capi.Index.load(p)
+    assert again.contig_names == idx.contig_names and again.mid_occ == idx.mid_occ
+    a, b = again.dump(), idx.dump()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for gz in (False, True):
+        fa = str(tmp_path / ("database0.fna.gz" if gz else "database0.fna"))
+        synth.write_fasta(fa, [n + " some description" for n in names], seqs, width=70, gz=gz)
+        out = str(tmp_path / f"built{int(gz)}.mmi")
+        built = capi.Index.build(fa, out)
+        assert built.contig_names == names                               # name = text before whitespace
+        c = built.dump()
+        assert np.array_equal(c[0], b[0]) and np.array_equal(c[1], b[1])
+        assert os.path.getsize(out) > 0
+        assert capi.Index.load(out).info().n_keys == idx.info().n_keys
+
+
+def test_damaged_or_empty_index_is_refused(capi, world, tmp_path):
+    names, seqs, idx, _ = world
+    p = str(tmp_path / "index0.mmi")
+    idx.save(p)
+    raw = open(p, "rb").read()
+    for name, blob in (("trunc.mmi", raw[: len(raw) // 2]), ("junk.mmi", b"not an index at all" * 10), ("empty.mmi", b"")):
+        q = str(tmp_path / name)
+        open(q, "wb").write(blob)
+        with pytest.raises(capi.MncError) as e:
+            capi.Index.load(q)
+        assert e.value.code == capi.ERR_FORMAT and "Damaged or empty index" in str(e.value)
+    with pytest.raises(capi.MncError) as e:
+        capi.Index.load(str(tmp_path / "missing.mmi"))
+    assert e.value.code == capi.ERR_IO
+    fa = str(tmp_path / "empty.fna")
+    open(fa, "w").write("")
+    with pytest.raises(capi.MncError) as e:
+        capi.Index.build(fa)
+    assert e.value.code == capi.ERR_FORMAT
+    with pytest.raises(capi.MncError) as e:
+        capi.Index.from_seqs(["a:b"], [b"ACGT" * 100], k=21, w=11)
+    assert e.value.code == capi.ERR_UNSUPPORTED
+
+
+def test_best_hit_integer_restatement_equals_float_reference(capi, oracle):
+    table = [([(1, 10), (1, 10)], -1), ([(1, 10), (2, 10)], 0), ([(2, 10), (1, 10)], 1),
+             ([(2, 10), (1, 10), (1, 10)], -1), ([(1, 10), (1, 10), (1, 20)], 2), ([(5, 9)], 0),
+             ([(2, 20), (1, 10)], -1)]
+    for hits, want in table:
+        assert capi.best_hit(hits) == want
+    rng = np.random.default_rng(2)
+    for _ in range(3000):
+        n = int(rng.integers(1, 6))
+        hi = int(rng.choice([4, 50, 5000, 1 << 20]))
+        hits = [(int(rng.integers(0, hi)), int(rng.integers(1, hi + 1))) for _ in range(n)]
+        assert capi.best_hit(hits) == oracle.best_hit(hits), hits
+
+
+def test_host_counts(capi, world):
+    names, seqs, idx, _ = world
+    assign = np.array([0, 3, -1, -2, 2, 4, 0], dtype=np.int32)
+    best = np.zeros(7, dtype=capi.HIT_DTYPE)
+    best["mlen"] = [100, 200, 0, 0, 300, 400, 50]
+    offsets = np.arange(8, dtype=np.int64) * 1000
+    assert capi.counts(idx, assign, best, offsets, 1).tolist() == [2, 0, 2, 1]
+    assert capi.counts(idx, assign, best, offsets, 2).tolist() == [2000, 0, 2000, 1000]
+    assert capi.counts(idx, assign, best, offsets, 3).tolist() == [150, 0, 500, 400]
+
+
+def test_synth_is_deterministic_and_sliceable(capi):
+    g = synth.genome(5, 10_000)
+    assert np.array_equal(g, synth.genome(5, 10_000)) and not np.array_equal(g, synth.genome(6, 10_000))
+    assert set(np.unique(g)) == set(b"ACGT")
+    d = synth.diverge(g, 9, 30_000)
+    assert 0.02 < (d != g).mean() < 0.04
+    seqs = [synth.genome(1, 50_000), synth.genome(2, 60_000)]
+    b, o, t = synth.reads(seqs, 64, 1000, seed=4)
+    b2, _, t2 = synth.reads(seqs, 32, 1000, seed=4, first=32)
+    assert np.array_equal(b[32 * 1000:], b2) and np.array_equal(t[32:], t2)     # any slice, same bytes
+    assert set(np.unique(t)) <= {-1, 0, 1}
+
+
+def test_no_cpu_fallback(capi, world):
+    """Without a gfx950 device the product refuses to classify (it never falls back to CPU)."""
+    n = capi.device_count()
+    if n > 0:
+        pytest.skip("a GPU is present")
+    names, seqs, idx, _ = world
+    with pytest.raises(capi.MncError) as e:
+        capi.Engine(idx, 0)
+    assert e.value.code == capi.ERR_NODEVICE
+
+
+def test_product_does_not_touch_the_oracle():
+    """The product package must not import, link or read anything under oracle/."""
+    pkg = os.path.join(ROOT, "monica_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "pyoracle" not in text and "liborc" not in text and "mm_oracle" not in text, f

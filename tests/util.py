@@ -59,3 +59,21 @@ def edge_reads(seqs, rng):
     out.append(ACGT[rng.integers(0, 4, 5000)])                    # random: unmapped
     out.append(np.frombuffer(b"N" * 500, dtype=np.uint8).copy())  # all ambiguous
     return out
+
+
+def edge_reads_small(seqs, rng):
+    """Corner cases scaled for the small golden fixture (contigs of 50-70 kb)."""
+    g0, g1 = seqs[0], seqs[1]
+    out = [np.zeros(0, dtype=np.uint8), g0[100:110].copy(), g0[100:115].copy(), g0[100:124].copy(), g0[100:125].copy()]
+    out.append(g0[5000:7000].copy())
+    out.append(revcomp(g0[5000:7000]))
+    r = g0[9000:11000].copy(); r[700] = ord("N"); out.append(r)
+    r = g1[9000:11000].copy(); r[::300] = ord("n"); out.append(r)
+    out.append(np.frombuffer(g0[12000:14000].tobytes().lower(), dtype=np.uint8).copy())
+    out.append(np.full(1500, ord("A"), dtype=np.uint8))
+    out.append(np.tile(np.frombuffer(b"AC", dtype=np.uint8), 800))
+    out.append(np.concatenate([g0[15000:15400], np.tile(np.frombuffer(b"GATTACA", dtype=np.uint8), 50), g0[15400:16600]]))
+    out.append(np.concatenate([g0[20000:21500], g1[30000:31500]]))
+    out.append(np.concatenate([g0[33000:35500], g0[36500:39000]]))
+    out.append(ACGT[rng.integers(0, 4, 2000)])
+    return out
