@@ -1,0 +1,274 @@
+"""Host-side mirror of `monica.genomes.aligner` (reference: monica/genomes/aligner.py).
+
+Same public names, argument order, defaults, return shapes and on-disk side effects, so
+`monica.monica` (monica.py:264, 437-439, 464-467) and `test/test_aligner.py` can call this
+module instead of the reference one.  What changes is underneath: `index.map(read)` per read
+(aligner.py:193, 215) becomes one C-ABI call per micro-batch into the gfx950 kernels
+(`mappy_compat.Aligner.map_batch`), and Biopython record objects become flat arrays.
+
+Deviations, all deliberate:
+* hits follow the chain-level contract: no base-level DP, NM := blen - mlen;
+* index files are this library's own format under the reference's `indexN.mmi` names;
+* `n_threads=None` means 4 worker threads, not one per core: a thread only feeds the GPU.
+"""
+import itertools
+import os
+import pickle
+from collections import Counter
+from multiprocessing.dummy import Pool as ThreadPool
+
+from . import fastq
+from . import mappy_compat as mappy
+
+
+def _monica_root():
+    """MONICA_ROOT as the reference resolves it (aligner.py:15-16), or None when monica has
+    not been initialised on this machine (the reference would fail at import)."""
+    env = os.environ.get("MONICA_ROOT")
+    if env:
+        return env
+    try:
+        with open(os.path.join(os.path.expanduser("~"), ".monica", ".root"), "r") as root:
+            return root.readline()
+    except OSError:
+        return None
+
+
+MONICA_ROOT = _monica_root()
+GENOMES_PATH = os.path.join(MONICA_ROOT, "genomes") if MONICA_ROOT else None
+
+BEST_N = 15
+INDEXES_PATH = os.path.join(MONICA_ROOT, "indexes") if MONICA_ROOT else None
+INDEX_NAME = ["index", ".mmi"]
+
+ALIGNMENT_PICKLE_FILENAME = "alignment.pkl"
+
+MAPPED_FILES_FOLDER = "mapped"
+UNMAPPED_FILES_FOLDER = "unmapped"
+AMBIGUOUS_FILES_FOLDER = "ambiguous"
+HITS_FILES_FOLDER = "hits"
+FOCUS_FILES_FOLDER = "focus"
+
+DEFAULT_THREADS = 4
+
+
+def _marker(name):
+    # progress breadcrumbs of the reference (aligner.py:40, 51)
+    if GENOMES_PATH and os.path.isdir(GENOMES_PATH):
+        with open(os.path.join(GENOMES_PATH, name), "wb"):
+            pass
+
+
+def indexer(databases, indexes_path=INDEXES_PATH):
+    """Build one index per `databaseN.fna.gz` chunk (aligner.py:31-53)."""
+    if not os.path.exists(indexes_path):
+        os.makedirs(indexes_path)
+    else:
+        for stale in os.listdir(indexes_path):
+            if stale.endswith(".mmi"):
+                os.remove(os.path.join(indexes_path, stale))
+    built = []
+    print("Started building {} index".format(indexes_path))
+    _marker("entered_indexer")
+    for database in os.listdir(databases):
+        if not database.endswith(".fna.gz"):
+            continue
+        number = os.path.split(database)[1][8:-7]
+        target = os.path.join(indexes_path, str(number).join(INDEX_NAME))
+        index = mappy.Aligner(fn_idx_in=os.path.join(databases, database), preset="map-ont", best_n=BEST_N,
+                              fn_idx_out=target)
+        if not index:
+            raise Exception("Index building failed")
+        built.append(target)
+    print("Finished building {} index".format(indexes_path))
+    _marker("finished_indexing")
+    return built
+
+
+def index_loader(index_file):
+    """Load one index part (aligner.py:56-62)."""
+    if index_file.endswith(".mmi"):
+        print(f"aligning on {index_file}")
+        index = mappy.Aligner(fn_idx_in=index_file)
+        if not index:
+            raise Exception("Damaged or empty index")
+        return index
+
+
+def multi_threaded_aligner(query_folder, indexes_paths, mode=None, mapping_quality=60, overnight=False, n_threads=None,
+                           focus_species=[], output_folder=None, mapped_files_folder=MAPPED_FILES_FOLDER,
+                           unmapped_files_folder=UNMAPPED_FILES_FOLDER, ambiguous_files_folder=AMBIGUOUS_FILES_FOLDER,
+                           hits_files_folder=HITS_FILES_FOLDER, focus_file_folder=FOCUS_FILES_FOLDER):
+    """Classify every non-empty `*fastq` file of `query_folder` against the index parts
+    (aligner.py:65-111): every part but the last only collects hits; the last part decides."""
+    os.chdir(query_folder)
+    samples = [f for f in os.listdir(".") if f.endswith("fastq") and os.stat(f).st_size]
+    if not samples:
+        print("No query files were provided")
+        return 0
+    samples_name = [s.split(".")[0] for s in samples]
+
+    folders = {k: os.path.join(query_folder, v) for k, v in (
+        ("mapped", mapped_files_folder), ("unmapped", unmapped_files_folder), ("ambiguous", ambiguous_files_folder),
+        ("hits", hits_files_folder), ("focus", focus_file_folder))}
+    if not os.path.exists(folders["mapped"]):
+        for key in ("mapped", "unmapped", "ambiguous", "hits"):
+            os.mkdir(folders[key])
+        if focus_species:
+            os.mkdir(folders["focus"])
+
+    pool = ThreadPool(n_threads if n_threads else DEFAULT_THREADS)
+    rep = itertools.repeat
+    try:
+        for part in indexes_paths[:-1]:
+            index = index_loader(part)
+            pool.starmap(aligner, zip(samples, samples_name, rep(index), rep(mode), rep(folders["hits"]),
+                                      rep(mapping_quality)))
+        index = index_loader(indexes_paths[-1])
+        results = pool.starmap(aligner, zip(samples, samples_name, rep(index), rep(mode), rep(folders["hits"]),
+                                            rep(mapping_quality), rep(overnight), rep(focus_species),
+                                            rep(folders["mapped"]), rep(folders["unmapped"]),
+                                            rep(folders["ambiguous"]), rep(folders["focus"]), rep(True)))
+    finally:
+        pool.close()
+    return alignment_update(results, output_folder)
+
+
+def _gated_tuples(index, hit_off, hits, r):
+    """The `(hit.ctg, hit.NM, hit.mlen)` tuples of read r that passed the gate (aligner.py:194-195)."""
+    names = index.index.contig_names
+    return [(names[int(h["rid"])], int(h["nm"]), int(h["mlen"])) for h in hits[hit_off[r]:hit_off[r + 1]]]
+
+
+def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_quality=None, overnight=False,
+            focus_species=[], mapped_folder=None, unmapped_folder=None, ambiguous_folder=None, focus_folder=None,
+            last_index=False):
+    """One sample file against one index part (aligner.py:179-279)."""
+    # mode parameter is for testing only (reference comment)
+    print(f"{sample}, mode is {mode}\t")
+    if mapping_quality is None:
+        raise TypeError("'>=' not supported between instances of 'int' and 'NoneType'")
+    carried_file = os.path.join(hits_folder, sample_name + "_hits.pkl")
+    if os.path.exists(carried_file):
+        with open(carried_file, "rb") as f:
+            sample_hits = pickle.load(f)
+    else:
+        sample_hits = dict()
+
+    def collect(batch, hit_off, hits):
+        for r in range(len(batch)):
+            if hit_off[r + 1] > hit_off[r]:
+                sample_hits.setdefault(batch.ids[r], []).extend(_gated_tuples(index, hit_off, hits, r))
+
+    if not last_index:
+        for batch in fastq.read_batches(sample):
+            _, _, _, hit_off, hits = index.map_batch(batch.bases, batch.offsets, mapping_quality)
+            collect(batch, hit_off, hits)
+        with open(carried_file, "wb") as f:
+            pickle.dump(sample_hits, f)
+        return None
+
+    sample_alignment = dict()
+    focus = open(os.path.join(focus_folder, sample), "ab") if focus_species else None
+    with open(os.path.join(mapped_folder, sample), "ab") as mapped, \
+            open(os.path.join(unmapped_folder, sample), "ab") as unmapped, \
+            open(os.path.join(ambiguous_folder, sample), "ab") as ambiguous:
+        for batch in fastq.read_batches(sample):
+            _, _, _, hit_off, hits = index.map_batch(batch.bases, batch.offsets, mapping_quality)
+            collect(batch, hit_off, hits)
+            for r in range(len(batch)):
+                read = batch.ids[r]
+                if read not in sample_hits:
+                    unmapped.write(fastq.format_record(batch, r))
+                    continue
+                read_hits = sample_hits[read]
+                best = read_hits[0] if len(read_hits) == 1 else best_hit(read_hits)
+                if not best:
+                    ambiguous.write(fastq.format_record(batch, r))
+                    continue
+                tax_unit, accession = best[0].split(sep=":")[0], best[0].split(sep=":")[1]
+                if tax_unit in focus_species:
+                    focus.write(fastq.format_record(batch, r))
+                if overnight:
+                    tax_unit = tax_unit.split(sep="_")[0]        # tax_unit becomes the genus
+                mapped.write(fastq.format_record(batch, r, new_id=tax_unit))
+                if mode == "basic":
+                    amount = 1
+                elif mode == "query_length":
+                    amount = int(batch.offsets[r + 1] - batch.offsets[r])
+                elif mode == "matching":
+                    amount = best[2]
+                else:
+                    continue
+                sample_alignment.setdefault(tax_unit, Counter()).update({accession: amount})
+    if os.path.exists(carried_file):
+        os.remove(carried_file)
+    if focus:
+        focus.close()
+    print(f"{sample} done")
+    os.remove(sample)
+    return sample_alignment, sample_name
+
+
+def alignment_update(results, output_folder):
+    """Merge per-sample counts into the persisted `alignment.pkl` (aligner.py:282-302)."""
+    alignment_pickle = os.path.join(output_folder, ALIGNMENT_PICKLE_FILENAME)
+    alignment = dict()
+    if os.path.exists(alignment_pickle):
+        with open(alignment_pickle, "rb") as f:
+            alignment = pickle.load(f)
+    for alignment_sample, sample_name in results:
+        if sample_name not in alignment:
+            alignment[sample_name] = alignment_sample
+            continue
+        for tax_unit, counter in alignment_sample.items():
+            if tax_unit in alignment[sample_name]:
+                alignment[sample_name][tax_unit].update(counter)
+            else:
+                alignment[sample_name][tax_unit] = counter
+    with open(alignment_pickle, "wb") as f:
+        pickle.dump(alignment, f)
+    return alignment
+
+
+def normalizer(alignment, genomes_length=None):
+    """counts / genome length, then fraction of the sample total (aligner.py:305-319)."""
+    if not genomes_length:
+        with open(os.path.join(GENOMES_PATH, "current_genomes_length.pkl"), "rb") as f:
+            genomes_length = pickle.load(f)
+    for sample in alignment.keys():
+        sample_total = 0
+        for counter in alignment[sample].values():
+            for accession, count in counter.items():
+                per_base = count / genomes_length[accession]
+                sample_total += per_base
+                counter[accession] = per_base
+        for counter in alignment[sample].values():
+            for accession, per_base in counter.items():
+                counter[accession] = per_base / sample_total
+    return alignment
+
+
+def alignment_to_data_frame(alignment, output_folder=None, filename="monica.dataframe"):
+    """dict -> MultiIndex DataFrame -> CSV (aligner.py:322-325)."""
+    import pandas as pd
+    data_frame = pd.concat({k: pd.DataFrame(v).unstack() for k, v in alignment.items() if v}, axis=1).dropna(how="all")
+    pd.DataFrame.to_csv(data_frame, os.path.join(output_folder, filename))
+    return data_frame
+
+
+def best_hit(hits):
+    """Smallest NM/mlen wins; an exact tie for the minimum means ambiguous -> 0
+    (aligner.py:328-339: the distance recorded at the last update of the minimum is zero)."""
+    smallest, winner, gap = float("inf"), None, 0
+    for hit in hits:
+        ratio = float(hit[1]) / hit[2]
+        if ratio <= smallest:
+            gap = smallest - ratio
+            smallest, winner = ratio, hit
+    return winner if gap else 0
+
+
+def any_result(alignment):
+    """1 if any sample has at least one taxon (aligner.py:342-350)."""
+    return 1 if any(bool(v) for v in alignment.values()) else 0

@@ -1,0 +1,140 @@
+"""Drop-in for the slice of `mappy` that monica consumes.
+
+The reference uses exactly this surface (monica/genomes/aligner.py):
+
+* `mappy.Aligner(fn_idx_in=<fasta.gz>, preset='map-ont', best_n=15, fn_idx_out=<path>)`  (45-46)
+* `mappy.Aligner(fn_idx_in=<index file>)`                                                  (59)
+* truthiness of the object (`if not index: raise ...`)                                     (47, 60)
+* `index.map(str(seq))` yielding hits with `.is_primary .mapq .ctg .NM .mlen`              (193-195, 215-217)
+
+`Aligner.map` is the per-read slow path kept for fidelity; `Aligner.map_batch` is what
+`monica_amd.aligner.aligner` uses: one C-ABI call per micro-batch, all compute on the GPU.
+Hits follow the chain-level contract of DESIGN.md section 1 (no base-level DP):
+`NM := blen - mlen`, MAPQ from the chain-level branch of minimap2's formula.
+"""
+import os
+import threading
+
+import numpy as np
+
+from . import _capi
+
+
+def default_device():
+    for var in ("MONICA_AMD_DEVICE", "LOCAL_RANK"):
+        v = os.environ.get(var)
+        if v is not None and v.strip().lstrip("-").isdigit():
+            return int(v)
+    return 0
+
+
+class Hit:
+    """The attributes of a mappy alignment that exist without base-level alignment."""
+    __slots__ = ("ctg", "ctg_len", "r_st", "r_en", "q_st", "q_en", "strand", "mapq", "mlen", "blen", "NM",
+                 "is_primary", "score", "n_anchors")
+
+    def __init__(self, reg, index):
+        rid = int(reg["rid"])
+        self.ctg = index.contig_names[rid]
+        self.ctg_len = index.contig_lens[rid]
+        self.r_st, self.r_en = int(reg["rs"]), int(reg["re"])
+        self.q_st, self.q_en = int(reg["qs"]), int(reg["qe"])
+        self.strand = -1 if reg["rev"] else 1
+        self.mapq = int(reg["mapq"])
+        self.mlen, self.blen = int(reg["mlen"]), int(reg["blen"])
+        self.NM = self.blen - self.mlen
+        self.is_primary = bool(reg["id"] == reg["parent"])
+        self.score = int(reg["score"])
+        self.n_anchors = int(reg["cnt"])
+
+    def __repr__(self):
+        return (f"{self.q_st}\t{self.q_en}\t{'+' if self.strand > 0 else '-'}\t{self.ctg}\t{self.ctg_len}\t"
+                f"{self.r_st}\t{self.r_en}\t{self.mlen}\t{self.blen}\t{self.mapq}\t"
+                f"tp:A:{'P' if self.is_primary else 'S'}")
+
+
+class Aligner:
+    """Index handle with mappy's constructor and truthiness."""
+
+    def __init__(self, fn_idx_in=None, preset=None, k=None, w=None, min_cnt=None, min_chain_score=None,
+                 min_dp_score=None, bw=None, best_n=None, n_threads=3, fn_idx_out=None, max_frag_len=None,
+                 extra_flags=None, seq=None, scoring=None, device=None):
+        self._index = None
+        self._tls = threading.local()
+        self._device = default_device() if device is None else int(device)
+        self.error = None
+        kk = 15 if k is None else int(k)
+        ww = 10 if w is None else int(w)
+        try:
+            if seq is not None:
+                self._index = _capi.Index.from_seqs(["N/A"], [seq], kk, ww)
+            elif fn_idx_in is None:
+                raise ValueError("fn_idx_in or seq is required")
+            elif self._is_index_file(fn_idx_in):
+                self._index = _capi.Index.load(fn_idx_in)
+            else:
+                self._index = _capi.Index.build(fn_idx_in, fn_idx_out, kk, ww)
+        except (_capi.MncError, OSError, ValueError) as e:      # mappy: a falsy Aligner, no exception
+            self.error = e
+            self._index = None
+
+    @staticmethod
+    def _is_index_file(path):
+        try:
+            with open(path, "rb") as f:
+                return f.read(7) == b"MNCIDX1"
+        except OSError:
+            return False
+
+    def __bool__(self):
+        return self._index is not None
+
+    @property
+    def index(self):
+        return self._index
+
+    @property
+    def k(self):
+        return self._index.k
+
+    @property
+    def w(self):
+        return self._index.w
+
+    @property
+    def n_seq(self):
+        return len(self._index.contig_names)
+
+    @property
+    def seq_names(self):
+        return list(self._index.contig_names)
+
+    def engine(self):
+        """One engine (HIP stream + HBM workspace) per calling thread: the reference shares one
+        index between the threads of its pool (aligner.py:89-103)."""
+        e = getattr(self._tls, "engine", None)
+        if e is None:
+            e = _capi.Engine(self._index, self._device)
+            self._tls.engine = e
+        return e
+
+    # ------------------------------------------------------------------ batched fast path
+    def map_batch(self, bases, offsets, min_mapq=0):
+        """Classify one micro-batch.  Returns (assign, best, nhits, hit_offsets, hits) where
+        hits[hit_offsets[r]:hit_offsets[r+1]] are the (rid, mapq, nm, mlen) of the hits of read r
+        that pass `is_primary and mapq >= min_mapq`."""
+        eng = self.engine()
+        assign, best, nhits = eng.classify(bases, offsets, min_mapq)
+        hit_off, hits = eng.fetch_hits()
+        return assign, best, nhits, hit_off, hits
+
+    # ------------------------------------------------------------------ per-read compatibility path
+    def map(self, seq, seq2=None, buf=None, cs=False, MD=False, max_frag_len=None, extra_flags=None):
+        if self._index is None:
+            return
+        b = seq if isinstance(seq, (bytes, bytearray)) else str(seq).encode()
+        eng = self.engine()
+        eng.classify(np.frombuffer(b, dtype=np.uint8), np.array([0, len(b)], dtype=np.int64), 0)
+        regs = eng.dump(_capi.DUMP_REGS, _capi.REG_DTYPE)
+        for reg in regs:
+            yield Hit(reg, self._index)

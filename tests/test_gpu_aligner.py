@@ -1,0 +1,151 @@
+"""GPU test that replays the call sequence of the reference's test/test_aligner.py
+(indexer -> multi_threaded_aligner -> alignment_to_data_frame -> normalizer) on a temp
+directory with synthetic FASTQ files, single-part and two-part indexes, and checks the
+returned dict and every side effect against the CPU oracle."""
+import os
+import pickle
+from collections import Counter
+
+import numpy as np
+import pytest
+
+from monica_amd import aligner, synth, fastq
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def expected_from_oracle(oracle, parts, names, bases, offsets, mode, min_mapq=60):
+    """aligner.py:184-263 on top of the oracle's per-part gated hit lists."""
+    n = len(offsets) - 1
+    per_read = [[] for _ in range(n)]
+    for part_names, part_seqs, rid_base in parts:
+        oidx = oracle.Index.from_seqs(part_names, [s.tobytes() for s in part_seqs])
+        assign, best, nhits, flat = oidx.classify(bases, offsets, min_mapq)
+        k = 0
+        for r in range(n):
+            for h in flat[k:k + nhits[r]]:
+                per_read[r].append((part_names[int(h["rid"])], int(h["nm"]), int(h["mlen"])))
+            k += nhits[r]
+    counts, route = {}, []
+    for r in range(n):
+        hits = per_read[r]
+        if not hits:
+            route.append("unmapped")
+            continue
+        best = hits[0] if len(hits) == 1 else aligner.best_hit(hits)
+        if not best:
+            route.append("ambiguous")
+            continue
+        tax, acc = best[0].split(":")
+        route.append("mapped:" + tax)
+        amount = {"basic": 1, "query_length": int(offsets[r + 1] - offsets[r]), "matching": best[2]}[mode]
+        counts.setdefault(tax, Counter()).update({acc: amount})
+    return counts, route
+
+
+def count_records(path):
+    return sum(len(b) for b in fastq.read_batches(path)) if os.path.exists(path) and os.path.getsize(path) else 0
+
+
+@pytest.mark.parametrize("n_parts,mode", [(1, "query_length"), (2, "basic"), (2, "matching")])
+def test_reference_call_sequence(oracle, tmp_path, n_parts, mode):
+    names, seqs = util.small_genomes(4, 150_000, 200_000)
+    dbs = tmp_path / "databases"
+    dbs.mkdir()
+    if n_parts == 1:
+        chunks = [(names, seqs, 0)]
+    else:
+        # genome i and its 3 %-diverged copy i+2 land in different parts, as monica's
+        # chunking by size can do (database.py:70-92)
+        chunks = [(names[:2], seqs[:2], 0), (names[2:], seqs[2:], 2)]
+    for i, (cn, cs, _) in enumerate(chunks):
+        synth.write_fasta(str(dbs / f"database{i}.fna.gz"), cn, cs)
+    idx_dir = str(tmp_path / "indexes")
+    paths = sorted(aligner.indexer(str(dbs), idx_dir))
+    assert [os.path.basename(p) for p in paths] == [f"index{i}.mmi" for i in range(n_parts)]
+
+    query = tmp_path / "query"
+    query.mkdir()
+    out = tmp_path / "output"
+    out.mkdir()
+    bases, offsets, truth = synth.reads(seqs, 240, 2500, seed=77)
+    extra = util.edge_reads_small(seqs, np.random.default_rng(1))
+    eb, eo = util.pack_reads([bases[offsets[i]:offsets[i + 1]] for i in range(240)] + extra)
+    half = 130
+    synth.write_fastq(str(query / "sampleA.pass.fastq"), eb[:eo[half]], eo[:half + 1], ids=[f"a{i} ch=1" for i in range(half)])
+    n_b = len(eo) - 1 - half
+    synth.write_fastq(str(query / "sampleB.fastq"), eb[eo[half]:], eo[half:] - eo[half], ids=[f"b{i}" for i in range(n_b)])
+    (query / "empty.fastq").write_bytes(b"")
+
+    cwd = os.getcwd()
+    try:
+        alignment = aligner.multi_threaded_aligner(str(query), paths, mode=mode, n_threads=2,
+                                                   focus_species=["Genus1_species1"], output_folder=str(out))
+    finally:
+        os.chdir(cwd)
+
+    parts = [(cn, cs, b) for cn, cs, b in chunks]
+    want_a, route_a = expected_from_oracle(oracle, parts, names, eb[:eo[half]], eo[:half + 1], mode)
+    want_b, route_b = expected_from_oracle(oracle, parts, names, eb[eo[half]:], eo[half:] - eo[half], mode)
+    assert alignment == {"sampleA": want_a, "sampleB": want_b}
+    assert sum(sum(c.values()) for c in want_a.values()) > 0
+
+    # side effects of aligner.py:81-87, 208-211, 242-243, 265, 273, 278, 300
+    for sample, route in (("sampleA.pass.fastq", route_a), ("sampleB.fastq", route_b)):
+        assert not os.path.exists(query / sample)                       # consumed
+        assert count_records(str(query / "mapped" / sample)) == sum(r.startswith("mapped") for r in route)
+        assert count_records(str(query / "unmapped" / sample)) == route.count("unmapped")
+        assert count_records(str(query / "ambiguous" / sample)) == route.count("ambiguous")
+        assert count_records(str(query / "focus" / sample)) == route.count("mapped:Genus1_species1")
+    first = next(fastq.read_batches(str(query / "mapped" / "sampleA.pass.fastq")))
+    mapped_a = [r for r in route_a if r.startswith("mapped")]
+    assert first.ids[0] == mapped_a[0].split(":")[1] and " ch=1" in first.headers[0]   # id replaced by tax_unit
+    assert os.listdir(query / "hits") == []                                           # carried hits removed
+    assert os.path.exists(query / "empty.fastq")                                      # empty files are skipped
+    with open(out / "alignment.pkl", "rb") as f:
+        assert pickle.load(f) == alignment
+
+    lens = {n.split(":")[1]: len(s) for n, s in zip(names, seqs)}
+    raw_df = aligner.alignment_to_data_frame(alignment, output_folder=str(out), filename="raw_monica.dataframe")
+    norm = aligner.normalizer(alignment, genomes_length=lens)
+    df = aligner.alignment_to_data_frame(norm, output_folder=str(out))
+    assert raw_df.shape == df.shape and abs(float(df["sampleA"].sum()) - 1.0) < 1e-9
+    assert aligner.any_result(alignment) == 1
+
+    # a second invocation on a folder that received new reads merges into alignment.pkl
+    synth.write_fastq(str(query / "sampleA.pass.fastq"), eb[:eo[20]], eo[:21], ids=[f"n{i}" for i in range(20)])
+    try:
+        again = aligner.multi_threaded_aligner(str(query), paths, mode="basic", n_threads=1, output_folder=str(out))
+    finally:
+        os.chdir(cwd)
+    assert set(again) == {"sampleA", "sampleB"}
+    assert count_records(str(query / "mapped" / "sampleA.pass.fastq")) >= sum(r.startswith("mapped") for r in route_a)
+
+
+def test_no_samples_returns_zero(tmp_path, capsys):
+    cwd = os.getcwd()
+    try:
+        assert aligner.multi_threaded_aligner(str(tmp_path), ["x.mmi"], output_folder=str(tmp_path)) == 0
+    finally:
+        os.chdir(cwd)
+    assert "No query files were provided" in capsys.readouterr().out
+
+
+def test_index_loader_errors(tmp_path):
+    bad = tmp_path / "index0.mmi"
+    bad.write_bytes(b"garbage")
+    with pytest.raises(Exception, match="Damaged or empty index"):
+        aligner.index_loader(str(bad))
+    assert aligner.index_loader(str(tmp_path / "notes.txt")) is None
+
+
+def test_mappy_compat_map_yields_hits(oracle):
+    from monica_amd import mappy_compat
+    names, seqs = util.small_genomes(2, 80_000, 90_000)
+    a = mappy_compat.Aligner(seq=seqs[0].tobytes())
+    assert a and a.k == 15 and a.w == 10
+    hits = list(a.map(seqs[0][1000:4000].tobytes().decode()))
+    assert len(hits) == 1 and hits[0].is_primary and hits[0].mapq == 60 and hits[0].ctg == "N/A"
+    assert hits[0].r_st <= 1020 and hits[0].r_en >= 3980 and hits[0].strand == 1 and hits[0].NM == hits[0].blen - hits[0].mlen
+    assert not mappy_compat.Aligner(fn_idx_in="/nonexistent/file.fa")
