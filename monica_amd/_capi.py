@@ -41,7 +41,7 @@ EXPORTS = [
     "mnc_engine_create", "mnc_engine_destroy", "mnc_engine_stream",
     "mnc_classify_batch", "mnc_classify_device", "mnc_engine_sync", "mnc_engine_fetch_hits",
     "mnc_counts", "mnc_best_hit",
-    "mnc_engine_set_profiling", "mnc_engine_get_timings", "mnc_stage_name", "mnc_stage_kernel",
+    "mnc_engine_set_profiling", "mnc_engine_set_debug", "mnc_engine_get_timings", "mnc_stage_name", "mnc_stage_kernel",
     "mnc_engine_get_counters", "mnc_engine_dump",
     "mnc_synth_genome", "mnc_synth_diverge", "mnc_synth_reads", "mnc_version",
 ]
@@ -115,6 +115,7 @@ def lib():
     sig("mnc_counts", i32, [vp, vp, vp, vp, u32, i32, vp])
     sig("mnc_best_hit", i32, [vp, i32, C.POINTER(i32)])
     sig("mnc_engine_set_profiling", i32, [vp, i32])
+    sig("mnc_engine_set_debug", i32, [vp, i32])
     sig("mnc_engine_get_timings", i32, [vp, vp, vp, i32])
     sig("mnc_stage_name", cp, [i32])
     sig("mnc_stage_kernel", cp, [i32])
@@ -283,6 +284,9 @@ class Engine:
 
     def set_profiling(self, on=True):
         check(lib().mnc_engine_set_profiling(self._h, 1 if on else 0))
+
+    def set_debug(self, on=True):
+        check(lib().mnc_engine_set_debug(self._h, 1 if on else 0))
 
     def timings(self, reset=False):
         ms = np.zeros(N_STAGES, dtype=np.float64)

@@ -85,6 +85,10 @@ struct Batch {
 	int64_t *stats;               // device counters (see mnc_engine_get_counters)
 };
 
+// size classes of the row chaining kernel (anchors per LDS tile)
+constexpr int MAX_CHAIN_CLASSES = 24;
+struct ChainClasses { int n; int nm[MAX_CHAIN_CLASSES]; };
+
 // ---------------------------------------------------------------- helpers
 
 __device__ __forceinline__ uint32_t hash30(uint32_t key)

@@ -18,7 +18,15 @@ void launch_sketch(const Batch &B, hipStream_t st);
 void launch_probe(const Batch &B, hipStream_t st);
 void launch_expand_sort(const Batch &B, hipStream_t st);
 void launch_chain_dp_serial(const Batch &B, const uint32_t *read_list, uint32_t n_list, hipStream_t st);
-void launch_backtrack(const Batch &B, hipStream_t st);
+void launch_backtrack(const Batch &B, const uint32_t *read_list, uint32_t n_list, hipStream_t st);
+void launch_bin_reads(const Batch &B, const ChainClasses &C, uint32_t *cls_count, uint32_t *cls_list, hipStream_t st);
+void launch_chain_rows(const Batch &B, const uint32_t *list, uint32_t count, int NM, int store_fp, hipStream_t st);
+size_t chain_rows_lds_bytes(int NM);
+int chain_rows_prepare(size_t max_lds);
+
+// LDS tile sizes (anchors per read) of the row chaining kernel; reads above the last one,
+// or with >= 65 536 bases, take the sequential kernels
+static const ChainClasses CHAIN_CLASSES = { 18, { 64, 128, 192, 256, 320, 384, 448, 512, 576, 640, 768, 896, 1024, 1280, 1536, 1792, 2048, 2560 } };
 void launch_regions(const Batch &B, void *regx, uint64_t *k64a, uint64_t *k64b, mnc_hit_t *gated, hipStream_t st);
 void launch_gather_hits(const Batch &B, const mnc_hit_t *gated, const int64_t *hit_off, mnc_hit_t *out, hipStream_t st);
 
@@ -199,7 +207,8 @@ struct mnc_engine {
 	Buf a, f, p, v, t, u;
 	// per chain slot
 	Buf chains, chains_tmp, regs, regx, k64a, k64b, tmp_i32, gated, hits_csr;
-	Buf stats;
+	Buf stats, cls_count, cls_list;
+	bool debug = false;                      // keep stage intermediates (f, p, v) for dumps
 	// last batch
 	Batch B{};
 	bool have_batch = false;
@@ -216,7 +225,7 @@ struct mnc_engine {
 static const char *STAGE_NAME[MNC_N_STAGES] = { "pack", "sketch", "probe", "expand", "sort", "chain", "backtrack", "regions", "decide" };
 static const char *STAGE_KERNEL[MNC_N_STAGES] = {
 	"mnc_pack_bases", "mnc_sketch_minimizers", "mnc_probe_index", "mnc_scan_apply", "mnc_expand_sort",
-	"mnc_chain_dp_serial", "mnc_chain_backtrack", "mnc_regions_decide", "mnc_gather_hits" };
+	"mnc_chain_rows", "mnc_chain_dp_serial", "mnc_regions_decide", "mnc_gather_hits" };
 
 extern "C" const char *mnc_stage_name(int s) { return s >= 0 && s < MNC_N_STAGES ? STAGE_NAME[s] : nullptr; }
 extern "C" const char *mnc_stage_kernel(int s) { return s >= 0 && s < MNC_N_STAGES ? STAGE_KERNEL[s] : nullptr; }
@@ -250,7 +259,7 @@ extern "C" void mnc_engine_destroy(mnc_engine *e)
 	               &e->packed, &e->mz, &e->hits, &e->ambig, &e->mz_cnt, &e->hit_cnt, &e->rep_len, &e->an_cnt, &e->an_off,
 	               &e->n_chain, &e->n_reg, &e->scan_sums, &e->hit_off, &e->a, &e->f, &e->p, &e->v, &e->t, &e->u,
 	               &e->chains, &e->chains_tmp, &e->regs, &e->regx, &e->k64a, &e->k64b, &e->tmp_i32, &e->gated,
-	               &e->hits_csr, &e->stats };
+	               &e->hits_csr, &e->stats, &e->cls_count, &e->cls_list };
 	for (Buf *b : all) b->release();
 	for (int s = 0; s < MNC_N_STAGES; ++s) for (int k = 0; k < 2; ++k) if (e->ev[s][k]) (void)hipEventDestroy(e->ev[s][k]);
 	if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -287,6 +296,8 @@ extern "C" int mnc_engine_create(mnc_index *idx, int device, mnc_engine **out)
 	rc = e->gap_lut.ensure(GAP_LUT * 4);
 	if (!rc) rc = e->logf_lut.ensure((size_t)e->logf_n * 4);
 	if (!rc) rc = e->stats.ensure(16 * 8);
+	if (!rc) rc = e->cls_count.ensure((MAX_CHAIN_CLASSES + 1) * 4 + 64);
+	if (!rc) rc = chain_rows_prepare(chain_rows_lds_bytes(CHAIN_CLASSES.nm[CHAIN_CLASSES.n - 1]));
 	if (!rc) {
 		he = hipMemcpy(e->gap_lut.p, gap.data(), GAP_LUT * 4, hipMemcpyHostToDevice);
 		if (he == hipSuccess) he = hipMemcpy(e->logf_lut.p, lg.data(), (size_t)e->logf_n * 4, hipMemcpyHostToDevice);
@@ -320,6 +331,13 @@ extern "C" int mnc_engine_set_profiling(mnc_engine *e, int on)
 {
 	if (!e) return MNC_ERR_ARG;
 	e->profiling = on != 0;
+	return MNC_OK;
+}
+
+extern "C" int mnc_engine_set_debug(mnc_engine *e, int on)
+{
+	if (!e) return MNC_ERR_ARG;
+	e->debug = on != 0;
 	return MNC_OK;
 }
 
@@ -372,6 +390,7 @@ extern "C" int mnc_classify_device(mnc_engine *e, const uint8_t *d_bases, const 
 	ENS(n_reg, (nr + 1) * 4);
 	ENS(hit_off, (nr + 2) * 8);
 	ENS(scan_sums, (nr / SC_TILE + 2) * 8);
+	ENS(cls_list, (size_t)(CHAIN_CLASSES.n + 1) * (nr + 1) * 4);
 	if (!d_nhits) ENS(out_nhits, (nr + 1) * 4);
 	if (rc) return rc;
 
@@ -399,12 +418,19 @@ extern "C" int mnc_classify_device(mnc_engine *e, const uint8_t *d_bases, const 
 	{ StageTimer t(e, MNC_STAGE_PACK);   launch_pack(B, st); }
 	{ StageTimer t(e, MNC_STAGE_SKETCH); launch_sketch(B, st); }
 	{ StageTimer t(e, MNC_STAGE_PROBE);  launch_probe(B, st); }
-	{ StageTimer t(e, MNC_STAGE_EXPAND); exclusive_scan(B.an_cnt, (int64_t)n_reads, B.an_off, e->scan_sums.as<int64_t>(), st); }
+	{
+		StageTimer t(e, MNC_STAGE_EXPAND);
+		exclusive_scan(B.an_cnt, (int64_t)n_reads, B.an_off, e->scan_sums.as<int64_t>(), st);
+		HIP_TRY(hipMemsetAsync(e->cls_count.p, 0, (MAX_CHAIN_CLASSES + 1) * 4, st));
+		launch_bin_reads(B, CHAIN_CLASSES, e->cls_count.as<uint32_t>(), e->cls_list.as<uint32_t>(), st);
+	}
 	HIP_TRY(hipGetLastError());
 
 	// the anchor total sizes every later buffer: one 8-byte read-back per batch
 	int64_t total_anchors = 0;
+	uint32_t cls_count[MAX_CHAIN_CLASSES + 1] = {0};
 	HIP_TRY(hipMemcpyAsync(&total_anchors, B.an_off + n_reads, 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(cls_count, e->cls_count.p, (MAX_CHAIN_CLASSES + 1) * 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	if (total_anchors < 0 || total_anchors >= (1LL << 31) * 16) { set_error("anchor count %lld out of range", (long long)total_anchors); return MNC_ERR_UNSUPPORTED; }
 	e->last_total_anchors = total_anchors;
@@ -423,8 +449,18 @@ extern "C" int mnc_classify_device(mnc_engine *e, const uint8_t *d_bases, const 
 	B.chains = e->chains.as<ChainRec>(), B.regs = e->regs.as<mnc_reg_t>(), B.tmp_i32 = e->tmp_i32.as<int32_t>();
 
 	{ StageTimer t(e, MNC_STAGE_SORT);      launch_expand_sort(B, st); }
-	{ StageTimer t(e, MNC_STAGE_CHAIN);     launch_chain_dp_serial(B, nullptr, n_reads, st); }
-	{ StageTimer t(e, MNC_STAGE_BACKTRACK); launch_backtrack(B, st); }
+	{
+		StageTimer t(e, MNC_STAGE_CHAIN);
+		const uint32_t *lists = e->cls_list.as<uint32_t>();
+		for (int c = 0; c < CHAIN_CLASSES.n; ++c)
+			launch_chain_rows(B, lists + (size_t)c * n_reads, cls_count[c], CHAIN_CLASSES.nm[c], e->debug ? 1 : 0, st);
+	}
+	{
+		StageTimer t(e, MNC_STAGE_BACKTRACK);       // reads too large for the LDS tiles
+		const uint32_t *large = e->cls_list.as<uint32_t>() + (size_t)CHAIN_CLASSES.n * n_reads;
+		launch_chain_dp_serial(B, large, cls_count[CHAIN_CLASSES.n], st);
+		launch_backtrack(B, large, cls_count[CHAIN_CLASSES.n], st);
+	}
 	{ StageTimer t(e, MNC_STAGE_REGIONS);   launch_regions(B, e->regx.p, e->k64a.as<uint64_t>(), e->k64b.as<uint64_t>(), e->gated.as<mnc_hit_t>(), st); }
 	HIP_TRY(hipGetLastError());
 	e->have_batch = true;

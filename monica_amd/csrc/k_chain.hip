@@ -82,10 +82,11 @@ __device__ void heapsort_u64(uint64_t *a, int n)
 
 // One thread per read: chain ends -> peak walk -> best-first backtrack -> chain records
 // ordered by (first anchor x, rank in backtrack order).
-__global__ __launch_bounds__(64) void mnc_chain_backtrack(Batch B)
+__global__ __launch_bounds__(64) void mnc_chain_backtrack(Batch B, const uint32_t *read_list, uint32_t n_list)
 {
-	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= B.n_reads) return;
+	const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+	if (li >= n_list) return;
+	const uint32_t r = read_list ? read_list[li] : li;
 	const int64_t a_off = B.an_off[r];
 	const int n = (int)(B.an_off[r + 1] - a_off);
 	B.n_chain[r] = 0;
@@ -94,9 +95,7 @@ __global__ __launch_bounds__(64) void mnc_chain_backtrack(Batch B)
 	const int32_t *f = B.f + a_off, *p = B.p + a_off;
 	int32_t *v = B.v + a_off, *t = B.t + a_off;
 	uint64_t *u = B.u + a_off;
-	const int64_t slot = a_off / 3;
-	ChainRec *tmp = B.chains_tmp + slot;
-	ChainRec *out = B.chains + slot;
+	ChainRec *out = B.chains_tmp + a_off / 3;              // backtrack order; K6 orders by first anchor
 	const int min_sc = B.min_sc, min_cnt = B.min_cnt;
 
 	for (int i = 0; i < n; ++i) t[i] = 0;
@@ -147,52 +146,9 @@ __global__ __launch_bounds__(64) void mnc_chain_backtrack(Batch B)
 				prev = cur;
 			}
 			c.as = 0, c.pad = k;
-			tmp[k++] = c;
+			out[k++] = c;
 		} else n_v = n_v0;
 	}
-	if (k == 0) return;
-	// order by (x0, rank): keys are distinct.  Insertion sort on the (small) record list
-	// for short lists, heap sort on an index key otherwise.
-	if (k <= 16) {
-		for (int i = 0; i < k; ++i) {
-			ChainRec c = tmp[i];
-			int j = i - 1;
-			while (j >= 0 && (out[j].x0 > c.x0 || (out[j].x0 == c.x0 && out[j].pad > c.pad))) { out[j + 1] = out[j]; --j; }
-			out[j + 1] = c;
-		}
-	} else {
-		// sort ranks by x0 with a stable two-key trick: x0 may use all 64 bits, so sort an
-		// index array by repeated selection through a heap on (x0, rank)
-		int32_t *idx = B.tmp_i32 + slot * 4;           // >= k ints available (4 per slot)
-		for (int i = 0; i < k; ++i) idx[i] = i;
-		auto less = [&](int x, int y) { return tmp[x].x0 < tmp[y].x0 || (tmp[x].x0 == tmp[y].x0 && x < y); };
-		for (int start = k / 2 - 1; start >= 0; --start) {
-			int root = start;
-			for (;;) {
-				int c = 2 * root + 1;
-				if (c >= k) break;
-				if (c + 1 < k && less(idx[c], idx[c + 1])) ++c;
-				if (!less(idx[root], idx[c])) break;
-				int x = idx[root]; idx[root] = idx[c], idx[c] = x;
-				root = c;
-			}
-		}
-		for (int end = k - 1; end > 0; --end) {
-			int x = idx[0]; idx[0] = idx[end], idx[end] = x;
-			int root = 0;
-			for (;;) {
-				int c = 2 * root + 1;
-				if (c >= end) break;
-				if (c + 1 < end && less(idx[c], idx[c + 1])) ++c;
-				if (!less(idx[root], idx[c])) break;
-				int y = idx[root]; idx[root] = idx[c], idx[c] = y;
-				root = c;
-			}
-		}
-		for (int i = 0; i < k; ++i) out[i] = tmp[idx[i]];
-	}
-	int as = 0;
-	for (int i = 0; i < k; ++i) { out[i].as = as; as += out[i].cnt; }
 	B.n_chain[r] = k;
 }
 
@@ -202,10 +158,44 @@ void launch_chain_dp_serial(const Batch &B, const uint32_t *read_list, uint32_t 
 	hipLaunchKernelGGL(mnc_chain_dp_serial, dim3((n_list + 63) / 64), dim3(64), 0, st, B, read_list, n_list);
 }
 
-void launch_backtrack(const Batch &B, hipStream_t st)
+void launch_backtrack(const Batch &B, const uint32_t *read_list, uint32_t n_list, hipStream_t st)
+{
+	if (n_list == 0) return;
+	hipLaunchKernelGGL(mnc_chain_backtrack, dim3((n_list + 63) / 64), dim3(64), 0, st, B, read_list, n_list);
+}
+
+// ================================================================ size classes for the row kernel
+// One thread per read: smallest class whose LDS tile holds the read's anchors, or the
+// "large" class (sequential kernels) for > 4096 anchors or >= 65 536 bases.
+__global__ __launch_bounds__(256) void mnc_bin_reads(Batch B, ChainClasses C, uint32_t *cls_count, uint32_t *cls_list)
+{
+	// block-level histogram in LDS, then one global atomic per class and block
+	__shared__ uint32_t s_cnt[MAX_CHAIN_CLASSES + 1], s_base[MAX_CHAIN_CLASSES + 1];
+	if (threadIdx.x <= MAX_CHAIN_CLASSES) s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	int c = -1;
+	uint32_t local = 0;
+	if (r < B.n_reads) {
+		const int64_t n = B.an_cnt[r];
+		B.n_chain[r] = 0;
+		if (n > 0) {
+			const int64_t qlen = B.offsets[r + 1] - B.offsets[r];
+			c = C.n;                                   // large
+			if (qlen < 65536) for (int k = 0; k < C.n; ++k) if (n <= C.nm[k]) { c = k; break; }
+			local = atomicAdd(&s_cnt[c], 1u);
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x <= (unsigned)C.n && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&cls_count[threadIdx.x], s_cnt[threadIdx.x]);
+	__syncthreads();
+	if (c >= 0) cls_list[(size_t)c * B.n_reads + s_base[c] + local] = r;
+}
+
+void launch_bin_reads(const Batch &B, const ChainClasses &C, uint32_t *cls_count, uint32_t *cls_list, hipStream_t st)
 {
 	if (B.n_reads == 0) return;
-	hipLaunchKernelGGL(mnc_chain_backtrack, dim3((B.n_reads + 63) / 64), dim3(64), 0, st, B);
+	hipLaunchKernelGGL(mnc_bin_reads, dim3((B.n_reads + 255) / 256), dim3(256), 0, st, B, C, cls_count, cls_list);
 }
 
 } // namespace mnc

@@ -124,13 +124,26 @@ __global__ __launch_bounds__(64) void mnc_regions_decide(Batch B, RegX *regx_all
 	int n_regs = 0;
 	if (n > 0) {
 		const int64_t slot = B.an_off[rd] / 3;
-		const ChainRec *ch = B.chains + slot;
+		ChainRec *ch = B.chains_tmp + slot;                     // backtrack order (pad = rank)
 		mnc_reg_t *r = B.regs + slot;
 		RegX *ex = regx_all + slot;
 		uint64_t *ka = k64a_all + slot, *kb = k64b_all + slot;
 		int32_t *w = B.tmp_i32 + slot * 4, *tmp = w + n;        // n ints each (4 per slot available)
 		mnc_hit_t *gated = gated_all + slot;
 
+		// ---------------- chains ordered by (first anchor x, rank); `as` = running anchor count
+		// in that order (mm_chain_dp's final ordering; total order instead of an unstable sort)
+		for (int i = 0; i < n; ++i) w[i] = i;
+		for (int i = 1; i < n; ++i) {
+			const int c = w[i];
+			int j = i - 1;
+			while (j >= 0 && (ch[w[j]].x0 > ch[c].x0 || (ch[w[j]].x0 == ch[c].x0 && w[j] > c))) { w[j + 1] = w[j]; --j; }
+			w[j + 1] = c;
+		}
+		{
+			int as = 0;
+			for (int i = 0; i < n; ++i) { ch[w[i]].as = as; as += ch[w[i]].cnt; }
+		}
 		// ---------------- regions, sorted by score (desc) with the pseudo-random tie-break
 		uint32_t hash = wang32((uint32_t)qlen) + wang32((uint32_t)B.seed);
 		hash = wang32(hash);

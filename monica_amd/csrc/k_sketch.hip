@@ -65,15 +65,25 @@ __global__ __launch_bounds__(256) void mnc_pack_bases(Batch B)
 }
 
 // ================================================================ K1: minimizers
-constexpr int SK_THREADS = 256;
-constexpr int SK_CHUNK = 8192;                      // k-mer positions per LDS chunk
-constexpr int SK_HALO = WIN - 1;
+constexpr int SK_THREADS = 256;                     // 4 waves = 4 reads per workgroup
+constexpr int SK_CHUNK = 1024;                      // k-mer positions per LDS chunk of one wave
+constexpr int SK_PAD = 10;                          // halo on each side (>= WIN - 1, even)
+constexpr int SK_SLOTS = SK_CHUNK + 2 * SK_PAD + 4; // hash slots per wave (+4: the 22-value read-ahead)
+constexpr int SK_WORDS = (SK_CHUNK + 2 * SK_PAD + KMER) / 16 + 4;
+constexpr int SK_ITERS = (SK_CHUNK + 2 * SK_PAD + 63) / 64;
 
 __device__ __forceinline__ uint32_t revcomp30(uint32_t fw)
 {
 	uint32_t r = __brev(~fw & KMASK);
 	r = ((r & 0xAAAAAAAAu) >> 1) | ((r & 0x55555555u) << 1);
 	return r >> 2;
+}
+
+__device__ __forceinline__ void wave_lds_order()
+{
+	// LDS operations of one wave execute in issue order; this only pins the compiler
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+	asm volatile("" ::: "memory");
 }
 
 // Serial minimizer state machine for reads that hold ambiguous bases:
@@ -127,8 +137,9 @@ __device__ int sketch_serial(const uint8_t *s, int len, uint2 *out)
 	return n_out;
 }
 
-// One 256-thread workgroup per read.  For a read without ambiguous bases the emitted set
-// has a closed form: with n k-mers and hashes h[0..n),
+// One wave per read (4 reads per workgroup, no workgroup barrier).  For a read without
+// ambiguous bases the emitted set has a closed form: with n k-mers
+// and hashes h[0..n),
 //   n <  WIN : the right-most minimum of h[0..n)
 //   n >= WIN : every p whose hash is the minimum of SOME full window containing p, i.e.
 //              (run of h >= h[p] to the left, clipped at 0) + (same to the right, clipped
@@ -136,108 +147,109 @@ __device__ int sketch_serial(const uint8_t *s, int len, uint2 *out)
 //              with m' = min h[0..WIN-2] and P' its right-most position,
 //                every p <= WIN-2, p != P', h[p] == m' IS emitted, and
 //                P' is NOT emitted when h[WIN-1] == m'.
+// Hashes of a chunk sit in LDS with a -1 sentinel outside [0, n) (so clipping needs no
+// test); every lane decides two adjacent positions from eleven 8-byte LDS reads.
 // Output order is increasing position, 8 bytes per minimizer: {hash, pos<<1 | strand},
 // pos = index of the k-mer's last base.
 __global__ __launch_bounds__(SK_THREADS) void mnc_sketch_minimizers(Batch B)
 {
-	__shared__ uint32_t s_hash[SK_CHUNK + 2 * SK_HALO];
-	__shared__ uint32_t s_words[(SK_CHUNK + 2 * SK_HALO + KMER) / 16 + 4];
-	__shared__ int s_wcnt[SK_THREADS / 64];
+	__shared__ __align__(16) int32_t s_hash_all[SK_THREADS / 64][SK_SLOTS];
+	__shared__ uint32_t s_words_all[SK_THREADS / 64][SK_WORDS];
+	__shared__ unsigned long long s_strand_all[SK_THREADS / 64][SK_ITERS];
 
-	const uint32_t r = blockIdx.x;
-	const int tid = threadIdx.x;
+	const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const uint32_t r = blockIdx.x * (SK_THREADS / 64) + wv;
+	if (r >= B.n_reads) return;
+	int32_t *s_hash = s_hash_all[wv];
+	uint32_t *s_words = s_words_all[wv];
+	unsigned long long *s_strand = s_strand_all[wv];
 	const int64_t off = B.offsets[r];
 	const int len = (int)(B.offsets[r + 1] - off);
 	const int n = len - (KMER - 1);
 	uint2 *out = B.mz + off;
-	if (n <= 0) { if (tid == 0) B.mz_cnt[r] = 0; return; }
+	if (n <= 0) { if (lane == 0) B.mz_cnt[r] = 0; return; }
 	if (B.ambig[r]) {
-		if (tid == 0) {
-			B.mz_cnt[r] = sketch_serial(B.bases + off, len, out);
-			atomicAdd((unsigned long long*)&B.stats[6], 1ULL);
-		}
+		if (lane == 0) B.mz_cnt[r] = sketch_serial(B.bases + off, len, out);
 		return;
 	}
+	const unsigned long long lt = (1ULL << lane) - 1ULL;
 
 	int total = 0;                                  // minimizers written so far (uniform)
 	for (int c0 = 0; c0 < n; c0 += SK_CHUNK) {
 		const int cend = min(c0 + SK_CHUNK, n);
-		const int lo = max(c0 - SK_HALO, 0), hi = min(cend + SK_HALO, n);
-		const int64_t w_lo = (off + lo) >> 4;
-		const int n_words = (int)(((off + hi - 1 + KMER - 1) >> 4) - w_lo) + 2;
-		__syncthreads();
-		for (int i = tid; i < n_words; i += SK_THREADS) s_words[i] = B.packed[w_lo + i];
-		__syncthreads();
-		for (int p = lo + tid; p < hi; p += SK_THREADS) {
-			const int64_t gb = off + p;
-			const int wi = (int)((gb >> 4) - w_lo), sh = (int)(gb & 15) * 2;
-			const uint64_t two = (uint64_t)s_words[wi] << 32 | s_words[wi + 1];
-			const uint32_t fw = (uint32_t)(two >> (34 - sh)) & KMASK;
-			const uint32_t rv = revcomp30(fw);
-			const uint32_t strand = fw < rv ? 0u : 1u;
-			s_hash[p - lo] = hash30(strand ? rv : fw) | strand << 31;
-		}
-		__syncthreads();
-
-		// first-window quirk operands (chunk 0 only)
-		uint32_t q_m = 0; int q_P = -1;
-		if (c0 == 0 && n >= WIN) {
-			q_m = s_hash[0] & KMASK, q_P = 0;
-			for (int j = 1; j <= WIN - 2; ++j) {
-				uint32_t h = s_hash[j] & KMASK;
-				if (h <= q_m) q_m = h, q_P = j;
+		const int span = cend - c0 + 2 * SK_PAD;    // slots to fill: positions c0-PAD .. cend+PAD
+		const int p_lo = max(c0 - SK_PAD, 0), p_hi = min(cend + SK_PAD, n);
+		const int64_t w_lo = (off + p_lo) >> 4;
+		const int n_words = (int)(((off + p_hi - 1 + KMER - 1) >> 4) - w_lo) + 2;
+		wave_lds_order();
+		for (int i = lane; i < n_words; i += 64) s_words[i] = B.packed[w_lo + i];
+		wave_lds_order();
+		for (int q0 = 0; q0 < span + 4; q0 += 64) {
+			const int q = q0 + lane, p = c0 - SK_PAD + q;
+			int32_t h = -1;
+			uint32_t strand = 0;
+			if (p >= 0 && p < n && q < span) {
+				const int64_t gb = off + p;
+				const int wi = (int)((gb >> 4) - w_lo), sh = (int)(gb & 15) * 2;
+				const uint64_t two = (uint64_t)s_words[wi] << 32 | s_words[wi + 1];
+				const uint32_t fw = (uint32_t)(two >> (34 - sh)) & KMASK;
+				const uint32_t rv = revcomp30(fw);
+				strand = fw < rv ? 0u : 1u;
+				h = (int32_t)hash30(strand ? rv : fw);
 			}
+			if (q < SK_SLOTS) s_hash[q] = h;
+			const unsigned long long sm = __ballot(strand != 0);
+			if (lane == 0) s_strand[q0 >> 6] = sm;
 		}
+		wave_lds_order();
 
-		for (int t0 = c0; t0 < cend; t0 += SK_THREADS) {
-			const int p = t0 + tid;
-			bool e = false;
-			uint32_t hv = 0, h = 0;
-			if (p < cend) {
-				hv = s_hash[p - lo], h = hv & KMASK;
-				if (n < WIN) {                          // no full window: right-most minimum
-					e = true;
-					for (int q = 0; q < n; ++q) {
-						uint32_t o = s_hash[q - lo] & KMASK;
-						if (q < p && o < h) e = false;
-						if (q > p && o <= h) e = false;
+		for (int t0 = c0; t0 < cend; t0 += 128) {
+			const int p0 = t0 + 2 * lane, q = p0 - c0 + SK_PAD;     // q is even
+			int32_t v[22];
+			const int2 *src = reinterpret_cast<const int2*>(s_hash + (q - 10));
+#pragma unroll
+			for (int k = 0; k < 11; ++k) { const int2 x = src[k]; v[2 * k] = x.x, v[2 * k + 1] = x.y; }
+			const int32_t h0 = v[10], h1 = v[11];
+			int L0 = 0, R0 = 0, L1 = 0, R1 = 0;
+			bool a0 = true, b0 = true, a1 = true, b1 = true;
+#pragma unroll
+			for (int d = 1; d < WIN; ++d) {
+				a0 = a0 && v[10 - d] >= h0; L0 += a0;
+				b0 = b0 && v[10 + d] >= h0; R0 += b0;
+				a1 = a1 && v[11 - d] >= h1; L1 += a1;
+				b1 = b1 && v[11 + d] >= h1; R1 += b1;
+			}
+			bool e0 = p0 < cend && L0 + R0 + 1 >= WIN;
+			bool e1 = p0 + 1 < cend && L1 + R1 + 1 >= WIN;
+			if (t0 == 0) {                              // first tile: short reads and first-window quirks
+				if (n < WIN) {
+					e0 = p0 < n, e1 = p0 + 1 < n;
+					for (int k = 0; k < n; ++k) {
+						const int32_t o = s_hash[SK_PAD + k];
+						if ((k < p0 && o < h0) || (k > p0 && o <= h0)) e0 = false;
+						if ((k < p0 + 1 && o < h1) || (k > p0 + 1 && o <= h1)) e1 = false;
 					}
 				} else {
-					int L = 0, R = 0;
-					bool okL = true, okR = true;
-#pragma unroll
-					for (int d = 1; d < WIN; ++d) {
-						const int ql = p - d, qr = p + d;
-						okL = okL && ql >= 0 && (s_hash[max(ql, lo) - lo] & KMASK) >= h;
-						okR = okR && qr < n && (s_hash[min(qr, hi - 1) - lo] & KMASK) >= h;
-						L += okL, R += okR;
+					int32_t q_m = s_hash[SK_PAD];
+					int q_P = 0;
+					for (int k = 1; k <= WIN - 2; ++k) {
+						const int32_t o = s_hash[SK_PAD + k];
+						if (o <= q_m) q_m = o, q_P = k;
 					}
-					e = L + R + 1 >= WIN;
-					if (p <= WIN - 2) {
-						if (h == q_m && p != q_P) e = true;
-						if (p == q_P && (s_hash[WIN - 1] & KMASK) == q_m) e = false;
-					}
+					const bool drop = s_hash[SK_PAD + WIN - 1] == q_m;
+					if (p0 <= WIN - 2) { if (h0 == q_m && p0 != q_P) e0 = true; if (p0 == q_P && drop) e0 = false; }
+					if (p0 + 1 <= WIN - 2) { if (h1 == q_m && p0 + 1 != q_P) e1 = true; if (p0 + 1 == q_P && drop) e1 = false; }
 				}
 			}
-			const unsigned long long m = __ballot(e);
-			const int wv = tid >> 6;
-			if ((tid & 63) == 0) s_wcnt[wv] = __popcll(m);
-			__syncthreads();
-			int base = total, all = 0;
-#pragma unroll
-			for (int w = 0; w < SK_THREADS / 64; ++w) {
-				if (w < wv) base += s_wcnt[w];
-				all += s_wcnt[w];
-			}
-			if (e) {
-				const int rank = __popcll(m & ((1ULL << (tid & 63)) - 1ULL));
-				out[base + rank] = make_uint2(h, (uint32_t)(p + KMER - 1) << 1 | hv >> 31);
-			}
-			total += all;
-			__syncthreads();
+			const unsigned long long m0 = __ballot(e0), m1 = __ballot(e1);
+			const int rank = __popcll(m0 & lt) + __popcll(m1 & lt);
+			const unsigned long long sb = s_strand[q >> 6];       // q and q+1 share one 64-bit word (q even)
+			if (e0) out[total + rank] = make_uint2((uint32_t)h0, (uint32_t)(p0 + KMER - 1) << 1 | (uint32_t)(sb >> (q & 63) & 1));
+			if (e1) out[total + rank + (e0 ? 1 : 0)] = make_uint2((uint32_t)h1, (uint32_t)(p0 + KMER) << 1 | (uint32_t)(sb >> ((q + 1) & 63) & 1));
+			total += __popcll(m0) + __popcll(m1);
 		}
 	}
-	if (tid == 0) B.mz_cnt[r] = total;
+	if (lane == 0) B.mz_cnt[r] = total;
 }
 
 void launch_pack(const Batch &B, hipStream_t st)
@@ -252,7 +264,8 @@ void launch_pack(const Batch &B, hipStream_t st)
 void launch_sketch(const Batch &B, hipStream_t st)
 {
 	if (B.n_reads == 0) return;
-	hipLaunchKernelGGL(mnc_sketch_minimizers, dim3(B.n_reads), dim3(SK_THREADS), 0, st, B);
+	const unsigned blocks = (B.n_reads + SK_THREADS / 64 - 1) / (SK_THREADS / 64);
+	hipLaunchKernelGGL(mnc_sketch_minimizers, dim3(blocks), dim3(SK_THREADS), 0, st, B);
 }
 
 } // namespace mnc

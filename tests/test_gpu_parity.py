@@ -17,6 +17,7 @@ def world(capi, oracle):
     idx = capi.Index.from_seqs(names, seqs)
     oidx = oracle.Index.from_seqs(names, [s.tobytes() for s in seqs])
     eng = capi.Engine(idx, 0)
+    eng.set_debug(True)
     return dict(names=names, seqs=seqs, idx=idx, oidx=oidx, eng=eng)
 
 
