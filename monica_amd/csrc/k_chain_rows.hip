@@ -5,14 +5,15 @@
 // Appendix A.5) for reads with at most 4096 anchors and fewer than 65 536 bases; longer
 // reads take the sequential kernels of k_chain.hip.
 //
-// Mapping.  One wave = four DPP rows of 16 lanes = four reads.  A row evaluates 16 candidate
-// predecessors j = jb, jb-1, ... of its current anchor i per step; a chain anchor needs about
-// 27 candidates before minimap2's max_skip rule stops the scan, i.e. two steps.  The
-// order-dependent parts of the sequential loop are reproduced exactly with row scans:
-//   * running maximum (strict '>' updates)      -> exclusive prefix-max over the row (row_shr)
-//   * n_skip (decrement-with-floor / increment) -> scan of the maps x -> max(x + a, b)
+// Mapping.  One wave = two half-waves of 32 lanes = two reads.  A half-wave evaluates 32
+// candidate predecessors j = jb, jb-1, ... of its current anchor i per step; a chain anchor
+// needs about 27 candidates before minimap2's max_skip rule stops the scan, i.e. one step.
+// The order-dependent parts of the sequential loop are reproduced exactly with scans over
+// the half-wave (DPP row_shr inside a 16-lane row, row_bcast:15 into the upper row):
+//   * running maximum (strict '>' updates)      -> exclusive prefix-max
+//   * n_skip (decrement-with-floor / increment) -> prefix sum + prefix max (see below)
 //   * break at the first lane where n_skip > max_skip, argmax = first lane at the maximum
-// The four rows advance independently (no lock-step over i).
+// The two halves advance independently (no lock-step over i).
 //
 // LDS per anchor, 14 bytes: one 64-bit word {p:16, f:16, t:16, v:16}, the low 32 bits of the
 // reference coordinate, the 16-bit query position.  t[] holds the "seen for anchor i" stamp
@@ -22,7 +23,8 @@
 
 namespace mnc {
 
-constexpr int ROWS = 4;                       // reads per wave
+constexpr int ROWS = 2;                       // reads per wave
+constexpr int RW = 64 / ROWS;                 // lanes per read
 constexpr uint32_t NONE16 = 0xffffu;
 constexpr int NEG = -(1 << 24);
 #ifndef INT32_MIN
@@ -44,28 +46,37 @@ MNC_DPP_OP(add_shr4, "v_add_u32_dpp", "row_shr:4") MNC_DPP_OP(add_shr8, "v_add_u
 MNC_DPP_OP(max_ror1, "v_max_i32_dpp", "row_ror:1") MNC_DPP_OP(max_ror2, "v_max_i32_dpp", "row_ror:2")
 MNC_DPP_OP(max_ror4, "v_max_i32_dpp", "row_ror:4") MNC_DPP_OP(max_ror8, "v_max_i32_dpp", "row_ror:8")
 #undef MNC_DPP_OP
-
-__device__ __forceinline__ int row_incl_max(int v) { return max_shr8(max_shr4(max_shr2(max_shr1(v)))); }
-__device__ __forceinline__ int row_incl_add(int v) { return add_shr8(add_shr4(add_shr2(add_shr1(v)))); }
-__device__ __forceinline__ int row_all_max(int v) { return max_ror1(max_ror2(max_ror4(max_ror8(v)))); }
-
-// lane l <- lane l-1 of the row; lane 0 keeps `fill`
-__device__ __forceinline__ int row_shift1(int v, int fill)
+// lane 15 of rows 0 and 2 combined into every lane of rows 1 and 3 (row_mask 0xa)
+__device__ __forceinline__ int max_bcast15(int v)
 {
-	asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(fill) : "v"(v));
-	return fill;
+	asm("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v)); return v;
 }
-// lane 0 <- lane 15 of the row (other lanes: rotated neighbours)
-__device__ __forceinline__ int row_rot1(int v)
+__device__ __forceinline__ int add_bcast15(int v)
 {
-	int r;
-	asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_ror:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
-	return r;
+	asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v)); return v;
+}
+
+// scans / reductions over one 32-lane half
+__device__ __forceinline__ int row_incl_max(int v) { return max_bcast15(max_shr8(max_shr4(max_shr2(max_shr1(v))))); }
+__device__ __forceinline__ int row_incl_add(int v) { return add_bcast15(add_shr8(add_shr4(add_shr2(add_shr1(v))))); }
+__device__ __forceinline__ int row_all_max(int v)
+{
+	v = max_ror1(max_ror2(max_ror4(max_ror8(v))));                       // every 16-lane row: its maximum
+	const auto sw = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+	return max((int)sw[0], (int)sw[1]);                                  // pair the two rows of a half
+}
+
+// lane l <- lane l-1 of the half; lane 0 of the half gets `fill`
+__device__ __forceinline__ int row_shift1(int v, int fill, int lr)
+{
+	int r = fill;
+	asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(v));
+	return lr == 0 ? fill : r;
 }
 
 __device__ __forceinline__ uint32_t row_ballot(bool pred, int row)
 {
-	return (uint32_t)(__ballot(pred) >> (row * 16)) & 0xffffu;
+	return (uint32_t)(__ballot(pred) >> (row * RW));
 }
 
 __device__ __forceinline__ void lds_order()
@@ -80,7 +91,7 @@ __device__ __forceinline__ void lds_order()
 __global__ __launch_bounds__(64) void mnc_chain_rows(Batch B, const uint32_t *list, uint32_t count, int NM, int store_fp)
 {
 	extern __shared__ __align__(16) uint8_t smem[];
-	const int lane = threadIdx.x, row = lane >> 4, lr = lane & 15;
+	const int lane = threadIdx.x, row = lane / RW, lr = lane % RW;
 	uint8_t *rbase = smem + (size_t)row * ((size_t)NM * 14 + 64 * 8);
 	uint64_t *W = reinterpret_cast<uint64_t*>(rbase);                  // NM words
 	uint32_t *xlo = reinterpret_cast<uint32_t*>(rbase + (size_t)NM * 8);
@@ -100,7 +111,7 @@ __global__ __launch_bounds__(64) void mnc_chain_rows(Batch B, const uint32_t *li
 	const double avg_span = (double)(float)KMER;
 
 	// ---- load: low coordinate, query position, segment-start flag (kept in f until f[i] is set)
-	for (int idx = lr; idx < n; idx += 16) {
+	for (int idx = lr; idx < n; idx += RW) {
 		const Anchor e = ga[idx];
 		const uint32_t hi = (uint32_t)(e.x >> 32);
 		const uint32_t phi = idx ? (uint32_t)(ga[idx - 1].x >> 32) : ~hi;
@@ -121,7 +132,7 @@ __global__ __launch_bounds__(64) void mnc_chain_rows(Batch B, const uint32_t *li
 	int pend_i = -1, pend_f = 0;
 	uint32_t pend_vp = 0;
 	while (__any(active)) {
-		// ---- one step: 16 candidates j = jb - lr
+		// ---- one step: RW candidates j = jb - lr
 		const int j = jb - lr;
 		const int lo = max(seg, i - max_iter);
 		const bool inb = active && j >= lo;
@@ -152,25 +163,26 @@ __global__ __launch_bounds__(64) void mnc_chain_rows(Batch B, const uint32_t *li
 		const bool tflag = ev && W16[4 * jc + 2] == (uint16_t)i;       // t[j] == i
 		// running maximum: strict '>' against everything before this lane
 		const int incl = row_incl_max(sc);
-		const int excl = max(row_shift1(incl, NEG), max_f);
+		const int excl = max(row_shift1(incl, NEG, lr), max_f);
 		const bool improve = ev && sc > excl;
 		// n_skip after each lane: maps x -> max(x + a, b) with (a,b) = (-1,0) on an improvement,
 		// (+1,-inf) on a seen non-improvement, identity otherwise; with S = prefix sum of a,
 		// the value is max(S, S + max_{k<=l, improve_k}(-S_k)).  The carry enters at lane 0.
 		int a = improve ? -1 : (tflag ? 1 : 0);
-		const int carry = row_rot1(ns_prev);
-		if (lr == 0 && !fresh) a += carry;
+		// carry: n_skip after the last lane of the previous step of this anchor
+		const int c0 = __builtin_amdgcn_readlane(ns_prev, RW - 1), c1 = __builtin_amdgcn_readlane(ns_prev, 2 * RW - 1);
+		if (lr == 0 && !fresh) a += row ? c1 : c0;
 		const int S = row_incl_add(a);
 		const int M = row_incl_max(improve ? -S : NEG);
 		const int ns = max(S, S + M);
 		const bool brk = tflag && !improve && ns > max_skip;
 		const uint32_t bm = row_ballot(brk, row);
-		const int bl = bm ? __ffs((int)bm) - 1 : 15;
+		const int bl = bm ? __ffs((int)bm) - 1 : RW - 1;
 		// best candidate among the lanes the sequential loop reaches; first lane wins ties
-		const int mk = row_all_max(lr <= bl && ev ? sc * 16 + (15 - lr) : INT32_MIN);
-		if ((mk >> 4) > max_f) max_f = mk >> 4, max_j = jb - (15 - (mk & 15));
+		const int mk = row_all_max(lr <= bl && ev ? sc * RW + (RW - 1 - lr) : INT32_MIN);
+		if ((mk >> 5) > max_f) max_f = mk >> 5, max_j = jb - (RW - 1 - (mk & (RW - 1)));
 		const uint32_t wm = row_ballot(inwin, row);
-		const bool done = active && (bm != 0 || (wm & 0x8000u) == 0 || jb - 16 < lo);
+		const bool done = active && (bm != 0 || (wm >> (RW - 1)) == 0 || jb - RW < lo);
 		ns_prev = ns, fresh = false;
 		if (done) {
 			if (lr == 0) {
@@ -186,14 +198,14 @@ __global__ __launch_bounds__(64) void mnc_chain_rows(Batch B, const uint32_t *li
 			xi = nxi, qi = nqi;
 			if (nflag) seg = i;
 			jb = i - 1, max_f = span, max_j = -1, fresh = true;
-		} else if (active) jb -= 16;
+		} else if (active) jb -= RW;
 		lds_order();
 	}
 	if (lr == 0 && pend_i >= 0) W16[4 * pend_i + 3] = (uint16_t)max((uint32_t)pend_f, pend_vp);
 	lds_order();
 
 	if (store_fp) {                                                  // stage dumps for the parity tests
-		for (int idx = lr; idx < n; idx += 16) {
+		for (int idx = lr; idx < n; idx += RW) {
 			const uint64_t w = W[idx];
 			const uint32_t p = (uint32_t)w & 0xffffu;
 			B.f[a_off + idx] = (int32_t)((uint32_t)w >> 16);
@@ -203,9 +215,9 @@ __global__ __launch_bounds__(64) void mnc_chain_rows(Batch B, const uint32_t *li
 	}
 
 	// ---- backtrack.  (A) which anchors are somebody's predecessor
-	for (int idx = lr; idx < n; idx += 16) W16[4 * idx + 2] = 0;
+	for (int idx = lr; idx < n; idx += RW) W16[4 * idx + 2] = 0;
 	lds_order();
-	for (int idx = lr; idx < n; idx += 16) {
+	for (int idx = lr; idx < n; idx += RW) {
 		const uint32_t p = (uint32_t)W[idx] & 0xffffu;
 		if (p != NONE16) W16[4 * p + 2] = 1;
 	}
@@ -213,8 +225,8 @@ __global__ __launch_bounds__(64) void mnc_chain_rows(Batch B, const uint32_t *li
 	// (B) chain ends with peak >= min_sc; walk each back to its peak
 	int n_u = 0;
 	uint64_t *gu = B.u + a_off;
-	const int n16 = (n + 15) & ~15;
-	for (int base = 0; base < n16; base += 16) {
+	const int n_up = (n + RW - 1) / RW * RW;
+	for (int base = 0; base < n_up; base += RW) {
 		const int idx = base + lr;
 		bool is_end = false;
 		uint64_t key = 0;
@@ -248,7 +260,7 @@ __global__ __launch_bounds__(64) void mnc_chain_rows(Batch B, const uint32_t *li
 		int rank[4];
 #pragma unroll
 		for (int s = 0; s < 4; ++s) {
-			const int e = lr + 16 * s;
+			const int e = lr + RW * s;
 			mine[s] = e < n_u ? ubuf[e] : 0, rank[s] = 0;
 		}
 		for (int k = 0; k < n_u; ++k) {
@@ -258,7 +270,7 @@ __global__ __launch_bounds__(64) void mnc_chain_rows(Batch B, const uint32_t *li
 		}
 		lds_order();
 #pragma unroll
-		for (int s = 0; s < 4; ++s) if (lr + 16 * s < n_u) ubuf[rank[s]] = mine[s];
+		for (int s = 0; s < 4; ++s) if (lr + RW * s < n_u) ubuf[rank[s]] = mine[s];
 	} else if (lr == 0 && n_u > 0) {
 		// rare: many chain ends; heap-sort ascending in HBM and read it backwards below
 		for (int start = n_u / 2 - 1; start >= 0; --start) {
@@ -286,7 +298,7 @@ __global__ __launch_bounds__(64) void mnc_chain_rows(Batch B, const uint32_t *li
 		}
 	}
 	// (D) clear the "used" marks
-	for (int idx = lr; idx < n; idx += 16) W16[4 * idx + 2] = 0;
+	for (int idx = lr; idx < n; idx += RW) W16[4 * idx + 2] = 0;
 	lds_order();
 	// (E) best-first backtrack by the row's first lane; chain records in backtrack order
 	if (lr == 0 && has) {
