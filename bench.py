@@ -147,7 +147,7 @@ def main():
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             pass
-        roofline = {"bound": "hbm", "kernel": "mnc_probe_index", "achieved": round(achieved, 2),
+        roofline = {"bound": "hbm", "kernel": "mnc_probe_buckets", "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "algorithmic_bytes_per_launch": int(algo_bytes),
                     "avg_launch_ms": round(probe_ms / probe_n, 4), "launches": probe_n}

@@ -150,16 +150,18 @@ int mnc_counts(const mnc_index *idx, const int32_t *assign, const mnc_hit_t *bes
 int mnc_best_hit(const mnc_hit_t *hits, int n, int *best_index /* -1 = ambiguous */);
 
 /* ---------------------------------------------------------------- profiling / introspection */
-#define MNC_STAGE_PACK     0
-#define MNC_STAGE_SKETCH   1
-#define MNC_STAGE_PROBE    2   /* index probe: the HBM-roofline kernel */
-#define MNC_STAGE_EXPAND   3
-#define MNC_STAGE_SORT     4
-#define MNC_STAGE_CHAIN    5   /* chaining DP + backtrack, reads held in LDS */
-#define MNC_STAGE_BACKTRACK 6  /* sequential chaining for reads too large for LDS */
-#define MNC_STAGE_REGIONS  7
-#define MNC_STAGE_DECIDE   8
-#define MNC_N_STAGES       9
+#define MNC_STAGE_PACK        0
+#define MNC_STAGE_SKETCH      1
+#define MNC_STAGE_PARTITION   2   /* scan + scatter of query records by table region        */
+#define MNC_STAGE_PROBE       3   /* index probe: the HBM-roofline kernel                    */
+#define MNC_STAGE_COLLECT     4   /* probe hits back to per-read lists                       */
+#define MNC_STAGE_SORT        5   /* anchor offsets (scan) + size classes                    */
+#define MNC_STAGE_SORT2       6   /* expand hits to anchors + sort                           */
+#define MNC_STAGE_CHAIN       7   /* chaining DP + backtrack, reads held in LDS              */
+#define MNC_STAGE_CHAIN_LARGE 8   /* sequential chaining for reads too large for LDS         */
+#define MNC_STAGE_REGIONS     9   /* regions, MAPQ, decision, counts                         */
+#define MNC_STAGE_GATHER      10  /* gated hit lists -> CSR (mnc_engine_fetch_hits)          */
+#define MNC_N_STAGES          11
 int mnc_engine_set_profiling(mnc_engine *eng, int on);    /* HIP events around every stage */
 int mnc_engine_set_debug(mnc_engine *eng, int on);        /* keep chaining intermediates for mnc_engine_dump */
 /* accumulated since the last reset: ms[MNC_N_STAGES], launches[MNC_N_STAGES] */

@@ -26,9 +26,9 @@ REG_DTYPE = np.dtype([("id", "<i4"), ("parent", "<i4"), ("rid", "<i4"), ("rev", 
 MZ_DTYPE = np.dtype([("hash", "<u4"), ("pos_strand", "<u4")])
 ANCHOR_DTYPE = np.dtype([("x", "<u8"), ("y", "<u8")])
 
-N_STAGES = 9
-(STAGE_PACK, STAGE_SKETCH, STAGE_PROBE, STAGE_EXPAND, STAGE_SORT, STAGE_CHAIN, STAGE_BACKTRACK,
- STAGE_REGIONS, STAGE_DECIDE) = range(N_STAGES)
+N_STAGES = 11
+(STAGE_PACK, STAGE_SKETCH, STAGE_PARTITION, STAGE_PROBE, STAGE_COLLECT, STAGE_SORT, STAGE_SORT2, STAGE_CHAIN,
+ STAGE_CHAIN_LARGE, STAGE_REGIONS, STAGE_GATHER) = range(N_STAGES)
 (DUMP_MINIMIZERS, DUMP_MZ_OFFSETS, DUMP_ANCHORS, DUMP_AN_OFFSETS, DUMP_CHAIN_F, DUMP_CHAIN_P,
  DUMP_CHAIN_V, DUMP_REGS, DUMP_REG_OFFSETS, DUMP_REP_LEN) = range(1, 11)
 

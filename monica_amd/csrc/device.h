@@ -14,6 +14,45 @@ constexpr int GAP_LUT = 512;         // gap cost look-up (dd <= bw = 500)
 
 struct Anchor { uint64_t x, y; };    // x = strand<<63 | rid<<32 | rpos ; y = span<<32 | qpos
 
+// ---------------------------------------------------------------- partitioned probe
+// The hash table is cut into 2^PB_BITS contiguous regions ("buckets") by the top bits of the
+// home line.  Query minimizers are partitioned by bucket so that the probe of one bucket
+// touches one region (2 MiB for the 20-genome index: L2-resident) instead of random HBM lines.
+constexpr int PB_BITS = 8;
+constexpr int PB_N = 1 << PB_BITS;
+constexpr int PT_READS = 4;                 // reads per partition tile (= one sketch workgroup)
+constexpr int PS_TILES = 64;                // tiles per super-tile (probe / collect granularity: 256 reads)
+constexpr int PF_BITS = 19;                 // presence filter: 2^18 bits = 32 KiB per table region (fits LDS)
+constexpr int PF_WORDS = (1 << PF_BITS) / 32;
+constexpr uint32_t HIT_HIGH = 0x7fffffffu;  // cnt marker: occurrences >= mid_occ (only feeds rep_len)
+
+// 64-bit query record: [21:0] hash without its bucket bits, [22] strand, [23] tandem,
+// [43:24] query position (last base of the k-mer), [63:44] read ordinal in the batch
+__device__ __forceinline__ uint32_t pb_bucket(uint32_t hash, uint32_t mask, int sbits)
+{
+	return (hash & mask) >> (sbits - PB_BITS);
+}
+__device__ __forceinline__ uint32_t pb_rest(uint32_t hash, int sbits)
+{
+	const int lo = sbits - PB_BITS;
+	return ((hash >> sbits) << lo) | (hash & ((1u << lo) - 1u));
+}
+__device__ __forceinline__ uint32_t pb_hash(uint32_t rest, uint32_t bucket, int sbits)
+{
+	const int lo = sbits - PB_BITS;
+	return ((rest >> lo) << sbits) | (bucket << lo) | (rest & ((1u << lo) - 1u));
+}
+
+// start of run (bucket, tile) in the bucket-major record array.  The offsets are stored
+// tile-major ([tile][bucket], so a tile's 256 starts are one contiguous 2 KiB row); the end of
+// a run is the start of the next one in bucket-major order.
+__device__ __forceinline__ int64_t q_start(const int64_t *q_off, uint32_t n_tiles, uint32_t bucket, uint32_t tile)
+{
+	if (tile >= n_tiles) { tile = 0; ++bucket; }
+	if (bucket >= (uint32_t)PB_N) return q_off[(size_t)n_tiles * PB_N];
+	return q_off[(size_t)tile * PB_N + bucket];
+}
+
 // one probe hit = one query minimizer with 0 < cnt < mid_occ
 struct HitRec {
 	uint64_t val;      // cnt == 1: occurrence word ; cnt > 1: offset into positions[]
@@ -41,10 +80,12 @@ struct Batch {
 	int64_t total_bases;
 	int min_mapq;
 	// ---- index
-	const TableSlot *table;
+	const TableLine *table;
+	const uint32_t *filter;       // [PB_N][PF_WORDS] presence bits of (region, 18 low bits of the rest of the hash)
 	uint64_t table_mask;
 	const uint64_t *positions;
 	const int32_t *contig_genome;
+	int table_bits;               // log2(table lines)
 	int mid_occ;
 	int n_genomes;
 	// ---- parameters
@@ -59,6 +100,16 @@ struct Batch {
 	uint32_t *ambig;              // per read: 1 if it holds a non-ACGTU byte
 	uint2 *mz;                    // minimizers of read r at [offsets[r], offsets[r]+mz_cnt[r])
 	HitRec *hits;                 // probe hits of read r at [offsets[r], offsets[r]+hit_cnt[r])
+	// ---- partitioned probe
+	uint32_t n_tiles;             // ceil(n_reads / PT_READS)
+	uint32_t n_super;             // ceil(n_tiles / PS_TILES)
+	uint32_t *hist_tm;            // [tile][bucket] minimizer counts (tile-major, written by the sketch)
+	int64_t *q_off;               // exclusive scan in bucket-major order, STORED tile-major: see q_start()
+	uint64_t *qrec;               // query records in bucket-major order
+	int64_t q_cap;                // capacity of qrec / bhits in records
+	HitRec *bhits;                // probe hits, compacted at the start of each (bucket, super-tile) run
+	uint32_t *bhit_cnt;           // [bucket][super-tile] number of hits in the run
+	uint32_t *overflow;           // set when the batch needs more than q_cap records
 	// ---- per read
 	int32_t *mz_cnt;
 	int32_t *hit_cnt;

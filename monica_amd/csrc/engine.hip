@@ -16,7 +16,9 @@ namespace mnc {
 // launches implemented in the k_*.hip units
 void launch_pack(const Batch &B, hipStream_t st);
 void launch_sketch(const Batch &B, hipStream_t st);
+void launch_partition(const Batch &B, hipStream_t st);
 void launch_probe(const Batch &B, hipStream_t st);
+void launch_collect(const Batch &B, hipStream_t st);
 void launch_expand_sort(const Batch &B, hipStream_t st);
 void launch_chain_dp_serial(const Batch &B, const uint32_t *read_list, uint32_t n_list, hipStream_t st);
 void launch_backtrack(const Batch &B, const uint32_t *read_list, uint32_t n_list, hipStream_t st);
@@ -38,15 +40,25 @@ void launch_gather_hits(const Batch &B, const mnc_hit_t *gated, const int64_t *h
 // ================================================================ exclusive scan (int -> int64)
 constexpr int SC_THREADS = 256, SC_ITEMS = 4, SC_TILE = SC_THREADS * SC_ITEMS;
 
-template <class T>
-__global__ __launch_bounds__(SC_THREADS) void mnc_scan_reduce(const T *in, int64_t n, int64_t *sums)
+template <class T> struct ScanInPlain {
+	const T *p;
+	__device__ long long operator()(int64_t i) const { return (long long)p[i]; }
+};
+// bucket-major view of the tile-major histogram the sketch writes: element b*n_tiles + t
+struct ScanInHist {
+	const uint32_t *p; int64_t n_tiles;
+	__device__ long long operator()(int64_t i) const { return (long long)p[(i % n_tiles) * PB_N + i / n_tiles]; }
+};
+
+template <class In>
+__global__ __launch_bounds__(SC_THREADS) void mnc_scan_reduce(In in, int64_t n, int64_t *sums)
 {
 	__shared__ long long s[SC_THREADS / 64];
 	const int64_t base = (int64_t)blockIdx.x * SC_TILE;
 	long long x = 0;
 	for (int k = 0; k < SC_ITEMS; ++k) {
 		const int64_t i = base + (int64_t)threadIdx.x * SC_ITEMS + k;
-		if (i < n) x += (long long)in[i];
+		if (i < n) x += in(i);
 	}
 	for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d);
 	if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = x;
@@ -70,13 +82,13 @@ __global__ __launch_bounds__(64) void mnc_scan_sums(int64_t *sums, int64_t n_blo
 	}
 }
 
-template <class T>
-__global__ __launch_bounds__(SC_THREADS) void mnc_scan_apply(const T *in, int64_t n, const int64_t *sums, int64_t *out)
+template <class In>
+__global__ __launch_bounds__(SC_THREADS) void mnc_scan_apply(In in, int64_t n, const int64_t *sums, int64_t *out, int64_t out_tiles)
 {
 	__shared__ long long s[SC_THREADS / 64];
 	const int64_t base = (int64_t)blockIdx.x * SC_TILE + (int64_t)threadIdx.x * SC_ITEMS;
 	long long v[SC_ITEMS], x = 0;
-	for (int k = 0; k < SC_ITEMS; ++k) { v[k] = base + k < n ? (long long)in[base + k] : 0; x += v[k]; }
+	for (int k = 0; k < SC_ITEMS; ++k) { v[k] = base + k < n ? in(base + k) : 0; x += v[k]; }
 	long long inc = x;
 	for (int d = 1; d < 64; d <<= 1) {
 		long long o = __shfl_up(inc, d);
@@ -87,20 +99,23 @@ __global__ __launch_bounds__(SC_THREADS) void mnc_scan_apply(const T *in, int64_
 	long long pre = sums[blockIdx.x] + inc - x;
 	for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) pre += s[w];
 	for (int k = 0; k < SC_ITEMS; ++k) {
-		if (base + k < n) out[base + k] = pre;
+		if (base + k < n) {
+			const int64_t i = base + k;
+			out[out_tiles ? (i % out_tiles) * PB_N + i / out_tiles : i] = pre;
+		}
 		pre += v[k];
 		if (base + k == n - 1) out[n] = pre;
 	}
 }
 
-template <class T>
-static void exclusive_scan(const T *in, int64_t n, int64_t *out, int64_t *sums, hipStream_t st)
+template <class In>
+static void exclusive_scan(In in, int64_t n, int64_t *out, int64_t *sums, hipStream_t st, int64_t out_tiles = 0)
 {
 	if (n <= 0) { (void)hipMemsetAsync(out, 0, 8, st); return; }
 	const int64_t nb = (n + SC_TILE - 1) / SC_TILE;
-	hipLaunchKernelGGL(mnc_scan_reduce<T>, dim3((unsigned)nb), dim3(SC_THREADS), 0, st, in, n, sums);
+	hipLaunchKernelGGL(mnc_scan_reduce<In>, dim3((unsigned)nb), dim3(SC_THREADS), 0, st, in, n, sums);
 	hipLaunchKernelGGL(mnc_scan_sums, dim3(1), dim3(64), 0, st, sums, nb);
-	hipLaunchKernelGGL(mnc_scan_apply<T>, dim3((unsigned)nb), dim3(SC_THREADS), 0, st, in, n, sums, out);
+	hipLaunchKernelGGL(mnc_scan_apply<In>, dim3((unsigned)nb), dim3(SC_THREADS), 0, st, in, n, sums, out, out_tiles);
 }
 
 // ================================================================ device buffer
@@ -142,31 +157,48 @@ int index_upload(mnc_index *idx, int device, DeviceIndex **out)
 	for (auto &d : idx->dev) if (d.device == device) { *out = &d; return MNC_OK; }
 	if (idx->keys.empty()) { set_error("empty index"); return MNC_ERR_FORMAT; }
 	HIP_TRY(hipSetDevice(device));
-	// open-addressed table, load <= 0.5; home slot = hash & mask (the minimizer hash is an
-	// invertible mix of the k-mer, so its low bits are already uniform)
-	uint64_t slots = 1024;
-	while (slots < idx->keys.size() * 2) slots <<= 1;
-	std::vector<TableSlot> tab;
-	try { tab.assign(slots, TableSlot{0, 0, 0}); } catch (const std::bad_alloc &) { return MNC_ERR_NOMEM; }
-	const uint64_t mask = slots - 1;
+	// 4-key lines, load <= 0.5; home line = hash & mask (the minimizer hash is an invertible
+	// mix of the k-mer, so its low bits are already uniform); at least 2^PB_BITS lines
+	uint64_t lines = 1024;
+	while (lines * 4 < idx->keys.size() * 2) lines <<= 1;
+	std::vector<TableLine> tab;
+	try { tab.assign(lines, TableLine{}); } catch (const std::bad_alloc &) { return MNC_ERR_NOMEM; }
+	const uint64_t mask = lines - 1;
 	for (size_t i = 0; i < idx->keys.size(); ++i) {
 		const uint32_t h = idx->keys[i];
 		const uint64_t o = idx->key_off[i], c = idx->key_off[i + 1] - o;
-		uint64_t s = (uint64_t)h & mask;
-		while (tab[s].key) s = (s + 1) & mask;
-		tab[s].key = h + 1;
-		tab[s].cnt = (uint32_t)c;
-		tab[s].val = c == 1 ? idx->pos[o] : o;
+		uint64_t l = (uint64_t)h & mask;
+		while (tab[l].key[3]) l = (l + 1) & mask;
+		int k = 0;
+		while (tab[l].key[k]) ++k;
+		const uint64_t v = c == 1 ? idx->pos[o] : o;
+		tab[l].key[k] = h + 1;
+		tab[l].cv[k].cnt = (uint32_t)c, tab[l].cv[k].val_lo = (uint32_t)v, tab[l].cv[k].val_hi = (uint32_t)(v >> 32);
+	}
+	// presence filter per table region: bit (rest of the hash mod 2^PF_BITS); a query whose bit
+	// is clear cannot be in the table, so it never costs a gather
+	int lbits = 0;
+	while ((1ULL << lbits) < lines) ++lbits;
+	std::vector<uint32_t> filt((size_t)PB_N * PF_WORDS, 0u);
+	for (size_t i = 0; i < idx->keys.size(); ++i) {
+		const uint32_t h = idx->keys[i];
+		const int lo = lbits - PB_BITS;
+		const uint32_t b = (uint32_t)((h & mask) >> lo);
+		const uint32_t rest = ((h >> lbits) << lo) | (h & ((1u << lo) - 1u));
+		const uint32_t bit = rest & ((1u << PF_BITS) - 1u);
+		filt[(size_t)b * PF_WORDS + (bit >> 5)] |= 1u << (bit & 31);
 	}
 	DeviceIndex d;
 	d.device = device, d.table_mask = mask;
-	HIP_TRY(hipMalloc((void**)&d.table, slots * sizeof(TableSlot)));
-	HIP_TRY(hipMemcpy(d.table, tab.data(), slots * sizeof(TableSlot), hipMemcpyHostToDevice));
+	HIP_TRY(hipMalloc((void**)&d.filter, filt.size() * 4));
+	HIP_TRY(hipMemcpy(d.filter, filt.data(), filt.size() * 4, hipMemcpyHostToDevice));
+	HIP_TRY(hipMalloc((void**)&d.table, lines * sizeof(TableLine)));
+	HIP_TRY(hipMemcpy(d.table, tab.data(), lines * sizeof(TableLine), hipMemcpyHostToDevice));
 	HIP_TRY(hipMalloc((void**)&d.positions, (idx->pos.size() + 1) * 8));
 	HIP_TRY(hipMemcpy(d.positions, idx->pos.data(), idx->pos.size() * 8, hipMemcpyHostToDevice));
 	HIP_TRY(hipMalloc((void**)&d.contig_genome, idx->contig_genome.size() * 4));
 	HIP_TRY(hipMemcpy(d.contig_genome, idx->contig_genome.data(), idx->contig_genome.size() * 4, hipMemcpyHostToDevice));
-	d.bytes = (int64_t)(slots * sizeof(TableSlot) + (idx->pos.size() + 1) * 8 + idx->contig_genome.size() * 4);
+	d.bytes = (int64_t)(lines * sizeof(TableLine) + filt.size() * 4 + (idx->pos.size() + 1) * 8 + idx->contig_genome.size() * 4);
 	idx->dev.reserve(16);
 	idx->dev.push_back(d);
 	*out = &idx->dev.back();
@@ -179,6 +211,7 @@ void index_release_device(mnc_index *idx)
 	for (auto &d : idx->dev) {
 		if (hipSetDevice(d.device) != hipSuccess) continue;
 		if (d.table) (void)hipFree(d.table);
+		if (d.filter) (void)hipFree(d.filter);
 		if (d.positions) (void)hipFree(d.positions);
 		if (d.contig_genome) (void)hipFree(d.contig_genome);
 	}
@@ -201,13 +234,14 @@ struct mnc_engine {
 	// inputs / outputs for the host-buffer entry point
 	Buf in_bases, in_offsets, out_assign, out_best, out_nhits;
 	// per base slot
-	Buf packed, mz, hits;
+	Buf packed, mz, hits, hist_tm, q_off, qrec, bhits, bhit_cnt;
+	size_t q_cap_override = 0;              // grown after an overflowing batch
 	// per read
 	Buf ambig, mz_cnt, hit_cnt, rep_len, an_cnt, an_off, n_chain, n_reg, scan_sums, hit_off;
 	// per anchor
 	Buf a, f, p, v, t, u;
 	// per chain slot
-	Buf chains, chains_tmp, regs, regx, k64a, k64b, tmp_i32, gated, hits_csr;
+	Buf chains_tmp, regs, regx, k64a, k64b, tmp_i32, gated, hits_csr;
 	Buf stats, cls_count, cls_list;
 	bool debug = false;                      // keep stage intermediates (f, p, v) for dumps
 	// last batch
@@ -223,10 +257,10 @@ struct mnc_engine {
 	int64_t launches[MNC_N_STAGES]{};
 };
 
-static const char *STAGE_NAME[MNC_N_STAGES] = { "pack", "sketch", "probe", "expand", "sort", "chain", "backtrack", "regions", "decide" };
+static const char *STAGE_NAME[MNC_N_STAGES] = { "pack", "sketch", "partition", "probe", "collect", "offsets", "sort", "chain", "chain_large", "regions", "gather" };
 static const char *STAGE_KERNEL[MNC_N_STAGES] = {
-	"mnc_pack_bases", "mnc_sketch_minimizers", "mnc_probe_index", "mnc_scan_apply", "mnc_expand_sort",
-	"mnc_chain_rows", "mnc_chain_dp_serial", "mnc_regions_decide", "mnc_gather_hits" };
+	"mnc_pack_bases", "mnc_sketch_minimizers", "mnc_partition_queries", "mnc_probe_buckets", "mnc_collect_hits",
+	"mnc_bin_reads", "mnc_expand_sort", "mnc_chain_rows", "mnc_chain_dp_serial", "mnc_regions_decide", "mnc_gather_hits" };
 
 extern "C" const char *mnc_stage_name(int s) { return s >= 0 && s < MNC_N_STAGES ? STAGE_NAME[s] : nullptr; }
 extern "C" const char *mnc_stage_kernel(int s) { return s >= 0 && s < MNC_N_STAGES ? STAGE_KERNEL[s] : nullptr; }
@@ -257,9 +291,9 @@ extern "C" void mnc_engine_destroy(mnc_engine *e)
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
 	Buf *all[] = { &e->gap_lut, &e->logf_lut, &e->in_bases, &e->in_offsets, &e->out_assign, &e->out_best, &e->out_nhits,
-	               &e->packed, &e->mz, &e->hits, &e->ambig, &e->mz_cnt, &e->hit_cnt, &e->rep_len, &e->an_cnt, &e->an_off,
+	               &e->packed, &e->mz, &e->hits, &e->hist_tm, &e->q_off, &e->qrec, &e->bhits, &e->bhit_cnt, &e->ambig, &e->mz_cnt, &e->hit_cnt, &e->rep_len, &e->an_cnt, &e->an_off,
 	               &e->n_chain, &e->n_reg, &e->scan_sums, &e->hit_off, &e->a, &e->f, &e->p, &e->v, &e->t, &e->u,
-	               &e->chains, &e->chains_tmp, &e->regs, &e->regx, &e->k64a, &e->k64b, &e->tmp_i32, &e->gated,
+	               &e->chains_tmp, &e->regs, &e->regx, &e->k64a, &e->k64b, &e->tmp_i32, &e->gated,
 	               &e->hits_csr, &e->stats, &e->cls_count, &e->cls_list };
 	for (Buf *b : all) b->release();
 	for (int s = 0; s < MNC_N_STAGES; ++s) for (int k = 0; k < 2; ++k) if (e->ev[s][k]) (void)hipEventDestroy(e->ev[s][k]);
@@ -362,19 +396,19 @@ struct StageTimer {
 }
 
 // ---------------------------------------------------------------- one batch, device-resident
-extern "C" int mnc_classify_device(mnc_engine *e, const uint8_t *d_bases, const int64_t *d_offsets,
-                                   uint32_t n_reads, int64_t total_bases, int max_read_len, int min_mapq,
-                                   int32_t *d_assign, mnc_hit_t *d_best, int32_t *d_nhits, int64_t *d_counts)
+static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d_offsets,
+                         uint32_t n_reads, int64_t total_bases, int min_mapq,
+                         int32_t *d_assign, mnc_hit_t *d_best, int32_t *d_nhits, int64_t *d_counts, bool *overflowed)
 {
-	if (!e || !d_offsets || !d_assign || (total_bases > 0 && !d_bases) || total_bases < 0) return MNC_ERR_ARG;
-	if (((uintptr_t)d_bases & 15u) != 0) { set_error("d_bases must be 16-byte aligned"); return MNC_ERR_ARG; }
-	if (max_read_len < 0 || max_read_len >= (1 << 20)) { set_error("reads of 2^20 bases or more are not supported"); return MNC_ERR_UNSUPPORTED; }
-	if (n_reads >= (1u << 30) || total_bases >= (1LL << 40)) return MNC_ERR_UNSUPPORTED;
-	HIP_TRY(hipSetDevice(e->device));
 	hipStream_t st = e->stream;
 	const mnc_index *idx = e->idx;
-	e->have_batch = false, e->last_total_hits = -1;
+	*overflowed = false;
 	const size_t nr = (size_t)n_reads, nb = (size_t)total_bases;
+	const size_t n_tiles = (nr + PT_READS - 1) / PT_READS, n_super = (n_tiles + PS_TILES - 1) / PS_TILES;
+	// query records: a (w,k)-minimizer sketch keeps ~2/(w+1) of the k-mers; room for a third
+	// of the bases, and the whole batch is redone with room for all of them if that overflows
+	size_t q_cap = nb / 3 + 4096;
+	if (e->q_cap_override > q_cap) q_cap = e->q_cap_override < nb + 4096 ? e->q_cap_override : nb + 4096;
 
 	int rc = MNC_OK;
 #define ENS(buf, bytes) do { if (!rc) rc = e->buf.ensure(bytes); } while (0)
@@ -390,7 +424,12 @@ extern "C" int mnc_classify_device(mnc_engine *e, const uint8_t *d_bases, const 
 	ENS(n_chain, (nr + 1) * 4);
 	ENS(n_reg, (nr + 1) * 4);
 	ENS(hit_off, (nr + 2) * 8);
-	ENS(scan_sums, (nr / SC_TILE + 2) * 8);
+	ENS(hist_tm, (n_tiles + 1) * PB_N * 4);
+	ENS(q_off, (n_tiles * PB_N + 2) * 8);
+	ENS(qrec, (q_cap + 1) * 8);
+	ENS(bhits, (q_cap + 1) * sizeof(HitRec));
+	ENS(bhit_cnt, (n_super + 1) * PB_N * 4);
+	ENS(scan_sums, ((n_tiles * PB_N + nr) / SC_TILE + 4) * 8);
 	ENS(cls_list, (size_t)(CHAIN_CLASSES.n + 1) * (nr + 1) * 4);
 	if (!d_nhits) ENS(out_nhits, (nr + 1) * 4);
 	if (rc) return rc;
@@ -398,7 +437,9 @@ extern "C" int mnc_classify_device(mnc_engine *e, const uint8_t *d_bases, const 
 	Batch &B = e->B;
 	memset(&B, 0, sizeof(B));
 	B.bases = d_bases, B.offsets = d_offsets, B.n_reads = n_reads, B.total_bases = total_bases, B.min_mapq = min_mapq;
-	B.table = e->didx->table, B.table_mask = e->didx->table_mask, B.positions = e->didx->positions;
+	B.table = e->didx->table, B.filter = e->didx->filter, B.table_mask = e->didx->table_mask, B.positions = e->didx->positions;
+	B.table_bits = 0;
+	while ((1ULL << B.table_bits) <= B.table_mask) ++B.table_bits;
 	B.contig_genome = e->didx->contig_genome, B.mid_occ = idx->mid_occ, B.n_genomes = (int)idx->genome_name.size();
 	const MapParams &P = idx->par;
 	B.min_cnt = P.min_cnt, B.min_sc = P.min_chain_score, B.bw = P.bw, B.max_gap = P.max_gap, B.max_skip = P.max_chain_skip;
@@ -409,47 +450,63 @@ extern "C" int mnc_classify_device(mnc_engine *e, const uint8_t *d_bases, const 
 	B.packed = e->packed.as<uint32_t>(), B.ambig = e->ambig.as<uint32_t>(), B.mz = e->mz.as<uint2>(), B.hits = e->hits.as<HitRec>();
 	B.mz_cnt = e->mz_cnt.as<int32_t>(), B.hit_cnt = e->hit_cnt.as<int32_t>(), B.rep_len = e->rep_len.as<int32_t>();
 	B.an_cnt = e->an_cnt.as<int64_t>(), B.an_off = e->an_off.as<int64_t>(), B.n_chain = e->n_chain.as<int32_t>(), B.n_reg = e->n_reg.as<int32_t>();
+	B.n_tiles = (uint32_t)n_tiles, B.n_super = (uint32_t)n_super;
+	B.hist_tm = e->hist_tm.as<uint32_t>(), B.q_off = e->q_off.as<int64_t>(), B.qrec = e->qrec.as<uint64_t>();
+	B.q_cap = (int64_t)q_cap, B.bhits = e->bhits.as<HitRec>(), B.bhit_cnt = e->bhit_cnt.as<uint32_t>();
+	B.overflow = reinterpret_cast<uint32_t*>(e->stats.as<int64_t>() + 8);
 	B.assign = d_assign, B.best = d_best, B.nhits = d_nhits ? d_nhits : e->out_nhits.as<int32_t>(), B.counts = d_counts;
 	B.stats = e->stats.as<int64_t>();
 
 	HIP_TRY(hipMemsetAsync(B.ambig, 0, (nr + 1) * 4, st));
 	HIP_TRY(hipMemsetAsync(B.packed + nb / 16, 0, 16, st));
-	if (n_reads == 0) { e->have_batch = true; e->last_total_anchors = 0; return MNC_OK; }
+	HIP_TRY(hipMemsetAsync(B.overflow, 0, 8, st));
 
 	{ StageTimer t(e, MNC_STAGE_PACK);   launch_pack(B, st); }
 	{ StageTimer t(e, MNC_STAGE_SKETCH); launch_sketch(B, st); }
-	{ StageTimer t(e, MNC_STAGE_PROBE);  launch_probe(B, st); }
 	{
-		StageTimer t(e, MNC_STAGE_EXPAND);
-		exclusive_scan(B.an_cnt, (int64_t)n_reads, B.an_off, e->scan_sums.as<int64_t>(), st);
+		StageTimer t(e, MNC_STAGE_PARTITION);
+		exclusive_scan(ScanInHist{B.hist_tm, (int64_t)n_tiles}, (int64_t)(n_tiles * PB_N), B.q_off, e->scan_sums.as<int64_t>(), st, (int64_t)n_tiles);
+		launch_partition(B, st);
+	}
+	{ StageTimer t(e, MNC_STAGE_PROBE);   launch_probe(B, st); }
+	{ StageTimer t(e, MNC_STAGE_COLLECT); launch_collect(B, st); }
+	HIP_TRY(hipGetLastError());
+	int64_t total_anchors = 0, total_q = 0;
+	uint32_t cls_count[MAX_CHAIN_CLASSES + 1] = {0}, overflow = 0;
+	{
+		StageTimer t(e, MNC_STAGE_SORT);
+		exclusive_scan(ScanInPlain<int64_t>{B.an_cnt}, (int64_t)n_reads, B.an_off, e->scan_sums.as<int64_t>(), st);
 		HIP_TRY(hipMemsetAsync(e->cls_count.p, 0, (MAX_CHAIN_CLASSES + 1) * 4, st));
 		launch_bin_reads(B, CHAIN_CLASSES, e->cls_count.as<uint32_t>(), e->cls_list.as<uint32_t>(), st);
+		// the anchor total sizes every later buffer: one small read-back per batch
+		HIP_TRY(hipMemcpyAsync(&total_anchors, B.an_off + n_reads, 8, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipMemcpyAsync(&total_q, B.q_off + n_tiles * PB_N, 8, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipMemcpyAsync(cls_count, e->cls_count.p, (MAX_CHAIN_CLASSES + 1) * 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipMemcpyAsync(&overflow, B.overflow, 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
 	}
-	HIP_TRY(hipGetLastError());
-
-	// the anchor total sizes every later buffer: one 8-byte read-back per batch
-	int64_t total_anchors = 0;
-	uint32_t cls_count[MAX_CHAIN_CLASSES + 1] = {0};
-	HIP_TRY(hipMemcpyAsync(&total_anchors, B.an_off + n_reads, 8, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(cls_count, e->cls_count.p, (MAX_CHAIN_CLASSES + 1) * 4, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
+	if (overflow || total_q > (int64_t)q_cap) {
+		e->q_cap_override = (size_t)total_q + (size_t)total_q / 8 + 4096;
+		*overflowed = true;
+		return MNC_OK;
+	}
 	if (total_anchors < 0 || total_anchors >= (1LL << 31) * 16) { set_error("anchor count %lld out of range", (long long)total_anchors); return MNC_ERR_UNSUPPORTED; }
 	e->last_total_anchors = total_anchors;
 	const size_t na = (size_t)total_anchors + 4, ns = (size_t)total_anchors / 3 + 4;
 	ENS(a, na * sizeof(Anchor));
 	ENS(f, na * 4); ENS(p, na * 4); ENS(v, na * 4); ENS(t, na * 4);
 	ENS(u, na * 8);
-	ENS(chains, ns * sizeof(ChainRec)); ENS(chains_tmp, ns * sizeof(ChainRec));
+	ENS(chains_tmp, ns * sizeof(ChainRec));
 	ENS(regs, ns * sizeof(mnc_reg_t)); ENS(regx, ns * 32);
 	ENS(k64a, ns * 8); ENS(k64b, ns * 8); ENS(tmp_i32, ns * 16); ENS(gated, ns * sizeof(mnc_hit_t));
 	if (rc) return rc;
 #undef ENS
 	B.an_cap = (int64_t)na;
-	B.a = e->a.as<Anchor>(), B.chains_tmp = e->chains_tmp.as<ChainRec>();
+	B.a = e->a.as<Anchor>(), B.chains_tmp = e->chains_tmp.as<ChainRec>(), B.chains = nullptr;
 	B.f = e->f.as<int32_t>(), B.p = e->p.as<int32_t>(), B.v = e->v.as<int32_t>(), B.t = e->t.as<int32_t>(), B.u = e->u.as<uint64_t>();
-	B.chains = e->chains.as<ChainRec>(), B.regs = e->regs.as<mnc_reg_t>(), B.tmp_i32 = e->tmp_i32.as<int32_t>();
+	B.regs = e->regs.as<mnc_reg_t>(), B.tmp_i32 = e->tmp_i32.as<int32_t>();
 
-	{ StageTimer t(e, MNC_STAGE_SORT);      launch_expand_sort(B, st); }
+	{ StageTimer t(e, MNC_STAGE_SORT2); launch_expand_sort(B, st); }
 	{
 		StageTimer t(e, MNC_STAGE_CHAIN);
 		const uint32_t *lists = e->cls_list.as<uint32_t>();
@@ -457,7 +514,7 @@ extern "C" int mnc_classify_device(mnc_engine *e, const uint8_t *d_bases, const 
 			launch_chain_rows(B, lists + (size_t)c * n_reads, cls_count[c], CHAIN_CLASSES.nm[c], e->debug ? 1 : 0, st);
 	}
 	{
-		StageTimer t(e, MNC_STAGE_BACKTRACK);       // reads too large for the LDS tiles
+		StageTimer t(e, MNC_STAGE_CHAIN_LARGE);     // reads too large for the LDS tiles
 		const uint32_t *large = e->cls_list.as<uint32_t>() + (size_t)CHAIN_CLASSES.n * n_reads;
 		launch_chain_dp_serial(B, large, cls_count[CHAIN_CLASSES.n], st);
 		launch_backtrack(B, large, cls_count[CHAIN_CLASSES.n], st);
@@ -466,6 +523,30 @@ extern "C" int mnc_classify_device(mnc_engine *e, const uint8_t *d_bases, const 
 	HIP_TRY(hipGetLastError());
 	e->have_batch = true;
 	return MNC_OK;
+}
+
+extern "C" int mnc_classify_device(mnc_engine *e, const uint8_t *d_bases, const int64_t *d_offsets,
+                                   uint32_t n_reads, int64_t total_bases, int max_read_len, int min_mapq,
+                                   int32_t *d_assign, mnc_hit_t *d_best, int32_t *d_nhits, int64_t *d_counts)
+{
+	if (!e || !d_offsets || !d_assign || (total_bases > 0 && !d_bases) || total_bases < 0) return MNC_ERR_ARG;
+	if (((uintptr_t)d_bases & 15u) != 0) { set_error("d_bases must be 16-byte aligned"); return MNC_ERR_ARG; }
+	if (max_read_len < 0 || max_read_len >= (1 << 20)) { set_error("reads of 2^20 bases or more are not supported"); return MNC_ERR_UNSUPPORTED; }
+	if (n_reads > (1u << 20)) { set_error("at most 2^20 reads per batch (query records hold a 20-bit read ordinal)"); return MNC_ERR_UNSUPPORTED; }
+	if (total_bases >= (1LL << 40)) return MNC_ERR_UNSUPPORTED;
+	HIP_TRY(hipSetDevice(e->device));
+	e->have_batch = false, e->last_total_hits = -1;
+	if (n_reads == 0) {
+		memset(&e->B, 0, sizeof(e->B));
+		e->have_batch = true, e->last_total_anchors = 0;
+		return MNC_OK;
+	}
+	bool overflowed = false;
+	int rc = classify_once(e, d_bases, d_offsets, n_reads, total_bases, min_mapq, d_assign, d_best, d_nhits, d_counts, &overflowed);
+	if (!rc && overflowed)                          // denser sketch than budgeted: redo with exact room
+		rc = classify_once(e, d_bases, d_offsets, n_reads, total_bases, min_mapq, d_assign, d_best, d_nhits, d_counts, &overflowed);
+	if (!rc && overflowed) { set_error("query record budget exceeded twice"); rc = MNC_ERR_NOMEM; }
+	return rc;
 }
 
 // ---------------------------------------------------------------- one batch, host buffers
@@ -520,8 +601,8 @@ extern "C" int mnc_engine_fetch_hits(mnc_engine *e, int64_t *hit_offsets, mnc_hi
 	if (nr == 0) { *n_hits = 0; if (hit_offsets) hit_offsets[0] = 0; return MNC_OK; }
 	int64_t *d_off = e->hit_off.as<int64_t>();
 	if (e->last_total_hits < 0) {
-		StageTimer t(e, MNC_STAGE_DECIDE);
-		exclusive_scan(B.nhits, (int64_t)nr, d_off, e->scan_sums.as<int64_t>(), st);
+		StageTimer t(e, MNC_STAGE_GATHER);
+		exclusive_scan(ScanInPlain<int32_t>{B.nhits}, (int64_t)nr, d_off, e->scan_sums.as<int64_t>(), st);
 		int64_t total = 0;
 		HIP_TRY(hipMemcpyAsync(&total, d_off + nr, 8, hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));

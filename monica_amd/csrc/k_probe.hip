@@ -1,106 +1,306 @@
-// Stage kernel K2: index probe -- the HBM-roofline kernel -- gfx950.
+// Stage kernels K2a (partition queries by table region), K2b (index probe -- the HBM-roofline
+// kernel) and K2c (collect probe hits per read) -- gfx950.
 //
 // Replaces mm_idx_get() + the occurrence filter of collect_matches() that run inside every
 // index.map(seq) call of monica/genomes/aligner.py:193,215.
 //
-// One wave per read.  Per 64-minimizer step every lane streams one 8-byte query
-// {hash, pos<<1|strand} (coalesced), gathers one 16-byte slot of the open-addressed table
-// resident in HBM (linear probing; ~1.3 slots per query at load <= 0.5), and the wave
-// writes the probe hits (0 < occurrences < mid_occ) as one compacted, ordered run of
-// 16-byte records.  Queries that are too frequent only feed rep_len (A.4).
+// A random 16-byte gather into a 0.5 GB table costs a whole 64-byte HBM request (measured:
+// 6.8 GB fetched for 2.6 GB of algorithmic traffic, profiles/r01b).  So the batch's query
+// minimizers are first partitioned by table region (PB_N = 256 regions of contiguous slots,
+// 2 MiB each for the 20-genome index); the probe of one region then runs out of one XCD's
+// L2, and HBM only sees the streams: query records in, the table once, hit records out.
+//
+//   K1 (sketch)  per tile of 4 reads: histogram of its minimizers over the 256 regions
+//   scan         bucket-major exclusive scan of the histogram -> run offsets
+//   K2a          scatter 8-byte query records into bucket-major order
+//   K2b          one wave per (bucket, super-tile of 256 reads) run: probe, compact hits
+//   K2c          one workgroup per super-tile: gather its 256 runs, split hits per read
 #include "device.h"
 
 namespace mnc {
 
-constexpr int PR_THREADS = 256;
+// ================================================================ K2a: partition
+// One workgroup per tile (4 reads, one wave each).  Records are first laid out in LDS in
+// bucket order (the tile's histogram row gives the local offsets), then copied out so that
+// consecutive lanes write consecutive addresses of a run.  A tile with more records than the
+// LDS stage holds (very long reads) writes its records directly.
+constexpr int PA_THREADS = 64 * PT_READS;
+constexpr int PA_STAGE = 4096;                      // records staged per tile
+constexpr int PA_PRE = 16;                          // minimizers a lane fetches ahead (1024 per wave)
 
-__global__ __launch_bounds__(PR_THREADS) void mnc_probe_index(Batch B)
+__global__ __launch_bounds__(PA_THREADS) void mnc_partition_queries(Batch B)
 {
-	const uint32_t r = (blockIdx.x * PR_THREADS + threadIdx.x) >> 6;
-	if (r >= B.n_reads) return;
-	const int lane = lane_id();
-	const unsigned long long lt = (1ULL << lane) - 1ULL;
-	const int64_t off = B.offsets[r];
-	const int n = B.mz_cnt[r];
+	__shared__ uint32_t s_cur[PB_N];
+	__shared__ uint32_t s_loc[PB_N + 1];            // local exclusive offsets of the buckets
+	__shared__ int64_t s_off[PB_N];
+	__shared__ uint64_t s_rec[PA_STAGE];
+	__shared__ uint8_t s_bkt[PA_STAGE];
+	const uint32_t tile = blockIdx.x;
+	const int tid = threadIdx.x, lane = lane_id();
+	// this wave's read: fetch its first minimizers before anything else waits on memory
+	const uint32_t r = tile * PT_READS + (tid >> 6);
+	const bool has = r < B.n_reads;
+	const int64_t off = has ? B.offsets[r] : 0;
+	const int n = has ? B.mz_cnt[r] : 0;
 	const uint2 *mz = B.mz + off;
-	HitRec *out = B.hits + off;
-	const uint32_t mid_occ = (uint32_t)B.mid_occ;
+	uint2 pre[PA_PRE];
+#pragma unroll
+	for (int k = 0; k < PA_PRE; ++k) pre[k] = k * 64 + lane < n ? mz[k * 64 + lane] : make_uint2(0xffffffffu, 0);
 
-	int n_hit = 0, rep = 0, last_en = 0;
-	bool have_last = false;
-	long long n_anchor = 0;
+	for (int k = tid; k < PB_N; k += PA_THREADS) {
+		s_cur[k] = 0;
+		s_off[k] = B.q_off[(size_t)tile * PB_N + k];
+		s_loc[k + 1] = B.hist_tm[(size_t)tile * PB_N + k];
+	}
+	if (tid == 0) s_loc[0] = 0;
+	__syncthreads();
+	if (tid < 64) {                                  // inclusive scan of 256 counts by one wave
+		uint32_t v[4], sum = 0;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { v[k] = s_loc[1 + tid * 4 + k]; sum += v[k]; }
+		uint32_t inc = sum;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (tid >= d) inc += o; }
+		uint32_t run = inc - sum;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { run += v[k]; s_loc[1 + tid * 4 + k] = run; }
+	}
+	__syncthreads();
+	const uint32_t total = s_loc[PB_N];
+	const bool staged = total <= (uint32_t)PA_STAGE;
+	const uint32_t tmask = (uint32_t)B.table_mask;
+	const int sbits = B.table_bits;
 	uint32_t prev_hash = 0xffffffffu;               // hash of minimizer i0 - 1
-
 	for (int i0 = 0; i0 < n; i0 += 64) {
 		const int i = i0 + lane;
 		const bool valid = i < n;
-		uint2 q = valid ? mz[i] : make_uint2(0xffffffffu, 0);
-		uint32_t cnt = 0;
-		uint64_t val = 0;
-		if (valid) {
-			uint64_t slot = (uint64_t)q.x & B.table_mask;
-			const uint32_t want = q.x + 1;
-			for (;;) {
-				const TableSlot s = B.table[slot];
-				if (s.key == want) { cnt = s.cnt, val = s.val; break; }
-				if (s.key == 0) break;
-				slot = (slot + 1) & B.table_mask;
-			}
-		}
+		uint2 q = make_uint2(0xffffffffu, 0);
+		if (i0 < PA_PRE * 64) {
+#pragma unroll
+			for (int k = 0; k < PA_PRE; ++k) if (i0 == k * 64) q = pre[k];
+		} else if (valid) q = mz[i];
 		// tandem flag: same hash as the neighbouring query minimizer (A.4)
 		uint32_t left = __shfl_up(q.x, 1), right = __shfl_down(q.x, 1);
 		if (lane == 0) left = prev_hash;
 		if (lane == 63 || i + 1 >= n) right = (i + 1 < n) ? mz[i + 1].x : 0xffffffffu;
 		const bool tandem = valid && (q.x == left || q.x == right);
 		prev_hash = __shfl(q.x, 63);
+		if (valid) {
+			const uint32_t b = pb_bucket(q.x, tmask, sbits);
+			const uint32_t rank = atomicAdd(&s_cur[b], 1u);
+			const int64_t dst = s_off[b] + rank;
+			const uint64_t rec = (uint64_t)pb_rest(q.x, sbits) | (uint64_t)(q.y & 1u) << 22 | (uint64_t)(tandem ? 1u : 0u) << 23 |
+			                     (uint64_t)(q.y >> 1) << 24 | (uint64_t)r << 44;
+			if (dst >= B.q_cap) *B.overflow = 1u;
+			else if (staged) { const uint32_t at = s_loc[b] + rank; s_rec[at] = rec; s_bkt[at] = (uint8_t)b; }
+			else B.qrec[dst] = rec;
+		}
+	}
+	__syncthreads();
+	if (staged) {
+		for (uint32_t i = tid; i < total; i += PA_THREADS) {
+			const uint32_t b = s_bkt[i];
+			const int64_t dst = s_off[b] + (int64_t)(i - s_loc[b]);
+			if (dst < B.q_cap) B.qrec[dst] = s_rec[i];
+		}
+	}
+}
 
-		const bool high = valid && cnt >= mid_occ;
-		const bool hit = valid && cnt > 0 && !high;
+// ================================================================ K2b: probe
+// One wave per run = (bucket, super-tile of 256 reads), about 930 queries.  Workgroups are
+// dealt round-robin over the 8 XCDs, so workgroup g takes bucket (g/8 / W)*8 + g%8: every XCD
+// walks its own buckets in order, and the ~256 workgroups resident on it at any time span two
+// or three buckets, whose 2 MiB table regions stay hot in its 4 MiB L2 (speed only, never
+// correctness).
+constexpr int PR_THREADS = 1024;
+constexpr int PR_U = 4;                             // queries per lane in flight
 
-		// rep_len: union length of the k-mer intervals of too-frequent minimizers;
-		// each contributes min(KMER, distance to the previous one)
-		const unsigned long long hm = __ballot(high);
-		if (hm) {
-			const int en = (int)(q.y >> 1) + 1;
-			const unsigned long long below = hm & lt;
-			const int src = below ? 63 - __clzll((long long)below) : 0;
-			const int prev_en = __shfl(en, src);
+__global__ __launch_bounds__(PR_THREADS) void mnc_probe_buckets(Batch B, uint32_t wgs_per_bucket)
+{
+	const uint32_t g = blockIdx.x, x = g & 7u, seq = g >> 3;
+	const uint32_t bucket = (seq / wgs_per_bucket) * 8u + x;
+	const uint32_t T = (seq % wgs_per_bucket) * (PR_THREADS / 64) + (threadIdx.x >> 6);
+	// the region's presence filter (32 KiB) into LDS: 3 of 4 queries are absent from the table
+	// and most of them stop here, at LDS speed, instead of costing a gather
+	__shared__ __align__(16) uint32_t s_filter[PF_WORDS];
+	if (bucket < (uint32_t)PB_N) {
+		const uint4 *src = reinterpret_cast<const uint4*>(B.filter + (size_t)bucket * PF_WORDS);
+		uint4 *dst = reinterpret_cast<uint4*>(s_filter);
+#pragma unroll
+		for (int k = 0; k < PF_WORDS / 4 / PR_THREADS; ++k) dst[k * PR_THREADS + threadIdx.x] = src[k * PR_THREADS + threadIdx.x];
+	}
+	__syncthreads();
+	if (bucket >= (uint32_t)PB_N || T >= B.n_super) return;
+	const int lane = lane_id();
+	const unsigned long long lt = (1ULL << lane) - 1ULL;
+	const uint32_t mid_occ = (uint32_t)B.mid_occ;
+	const int sbits = B.table_bits;
+	const TableLine *table = B.table;
+	const uint64_t lmask = B.table_mask;
+	{
+		const uint32_t t0 = T * PS_TILES, t1 = min(t0 + PS_TILES, B.n_tiles);
+		const int64_t q0 = q_start(B.q_off, B.n_tiles, bucket, t0), q1 = q_start(B.q_off, B.n_tiles, bucket, t1);
+		const uint32_t read0 = T * (PS_TILES * PT_READS);
+		int n_out = 0;
+		if (q1 <= B.q_cap) {
+			// PR_U queries per lane in flight: their probe chains overlap; the records of the
+			// next step are fetched before this step's probes wait on memory
+			uint64_t nxt[PR_U];
+#pragma unroll
+			for (int u = 0; u < PR_U; ++u) { const int64_t i = q0 + u * 64 + lane; nxt[u] = i < q1 ? B.qrec[i] : 0; }
+			for (int64_t i0 = q0; i0 < q1; i0 += 64 * PR_U) {
+				uint64_t rec[PR_U], line[PR_U], val[PR_U];
+				uint32_t want[PR_U], cnt[PR_U];
+				bool pend[PR_U];
+#pragma unroll
+				for (int u = 0; u < PR_U; ++u) {
+					pend[u] = i0 + u * 64 + lane < q1;
+					rec[u] = nxt[u];
+					cnt[u] = 0, val[u] = 0;
+					const int64_t j = i0 + 64 * PR_U + u * 64 + lane;
+					nxt[u] = j < q1 ? B.qrec[j] : 0;
+				}
+#pragma unroll
+				for (int u = 0; u < PR_U; ++u) {
+					const uint32_t rest = (uint32_t)rec[u] & 0x3fffffu;
+					const uint32_t hash = pb_hash(rest, bucket, sbits);
+					line[u] = (uint64_t)hash & lmask, want[u] = hash + 1;
+					const uint32_t bit = rest & ((1u << PF_BITS) - 1u);
+					pend[u] = pend[u] && ((s_filter[bit >> 5] >> (bit & 31)) & 1u);
+				}
+				bool any = true;
+				while (__any(any)) {
+					uint4 k[PR_U];
+#pragma unroll
+					for (int u = 0; u < PR_U; ++u) if (pend[u]) k[u] = *reinterpret_cast<const uint4*>(table[line[u]].key);
+					any = false;
+#pragma unroll
+					for (int u = 0; u < PR_U; ++u) if (pend[u]) {
+						const uint32_t w = want[u];
+						const int at = k[u].x == w ? 0 : k[u].y == w ? 1 : k[u].z == w ? 2 : k[u].w == w ? 3 : -1;
+						if (at >= 0) {                          // second touch of the same 64-byte line
+							const TableCV cv = table[line[u]].cv[at];
+							cnt[u] = cv.cnt, val[u] = (uint64_t)cv.val_hi << 32 | cv.val_lo;
+							pend[u] = false;
+						} else if (k[u].w == 0) pend[u] = false;      // the line has room: key absent
+						else { line[u] = (line[u] + 1) & lmask; any = true; }
+					}
+				}
+#pragma unroll
+				for (int u = 0; u < PR_U; ++u) {
+					const bool emit = cnt[u] > 0;       // a hit, or a too-frequent minimizer (for rep_len)
+					const unsigned long long m = __ballot(emit);
+					if (emit) {
+						HitRec h;
+						const uint32_t qpos = (uint32_t)(rec[u] >> 24) & 0xfffffu, rd = (uint32_t)(rec[u] >> 44);
+						h.val = val[u];
+						h.qinfo = qpos << 1 | ((uint32_t)(rec[u] >> 22) & 1u) | (rd - read0) << 21;
+						h.cnt = cnt[u] >= mid_occ ? HIT_HIGH : (cnt[u] | ((uint32_t)(rec[u] >> 23) & 1u) << 31);
+						B.bhits[q0 + n_out + __popcll(m & lt)] = h;
+					}
+					n_out += __popcll(m);
+				}
+			}
+		}
+		if (lane == 0) B.bhit_cnt[(size_t)bucket * B.n_super + T] = (uint32_t)n_out;
+	}
+}
+
+// ================================================================ K2c: collect
+// One workgroup per super-tile: its 256 runs of hits are read back and dealt to the 256 reads
+// (hits from the bottom of the read's slot range, too-frequent minimizers from the top), then
+// one wave per read finishes hit_cnt / an_cnt / rep_len.
+constexpr int CO_THREADS = 256;
+constexpr int SUPER_READS = PS_TILES * PT_READS;
+
+__global__ __launch_bounds__(CO_THREADS) void mnc_collect_hits(Batch B)
+{
+	__shared__ int64_t s_start[PB_N];
+	__shared__ uint32_t s_pre[PB_N + 1];
+	__shared__ uint32_t s_cur[SUPER_READS], s_hi[SUPER_READS];
+	__shared__ unsigned long long s_an[SUPER_READS];
+	const uint32_t T = blockIdx.x;
+	const uint32_t t0 = T * PS_TILES;
+	const int tid = threadIdx.x;
+	for (int b = tid; b < PB_N; b += CO_THREADS) {
+		s_start[b] = B.q_off[(size_t)t0 * PB_N + b];
+		s_pre[b + 1] = B.bhit_cnt[(size_t)b * B.n_super + T];
+	}
+	if (tid < SUPER_READS) s_cur[tid] = 0, s_hi[tid] = 0, s_an[tid] = 0;
+	if (tid == 0) s_pre[0] = 0;
+	__syncthreads();
+	if (tid == 0) for (int b = 0; b < PB_N; ++b) s_pre[b + 1] += s_pre[b];     // 256 additions
+	__syncthreads();
+	const uint32_t total = s_pre[PB_N];
+	const uint32_t read0 = T * SUPER_READS;
+	for (uint32_t f = tid; f < total; f += CO_THREADS) {
+		int lo = 0, hi = PB_N;                        // run holding flat index f
+		while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_pre[mid] <= f) lo = mid; else hi = mid; }
+		HitRec h = B.bhits[s_start[lo] + (f - s_pre[lo])];
+		const uint32_t lr = (h.qinfo >> 21) & (SUPER_READS - 1);
+		const uint32_t r = read0 + lr;
+		const int64_t off = B.offsets[r];
+		h.qinfo &= 0x1fffffu;
+		if (h.cnt == HIT_HIGH) {
+			const int64_t cap = B.offsets[r + 1] - off;
+			B.hits[off + cap - 1 - atomicAdd(&s_hi[lr], 1u)] = h;
+		} else {
+			B.hits[off + atomicAdd(&s_cur[lr], 1u)] = h;
+			atomicAdd(&s_an[lr], (unsigned long long)(h.cnt & 0x7fffffffu));
+		}
+	}
+	__syncthreads();
+	// per read: counts and rep_len = sum over too-frequent minimizers, in position order, of
+	// min(k, distance to the previous one)
+	const int lane = lane_id();
+	for (uint32_t lr = tid >> 6; lr < (uint32_t)SUPER_READS; lr += CO_THREADS / 64) {
+		const uint32_t r = read0 + lr;
+		if (r >= B.n_reads) break;
+		const int64_t off = B.offsets[r];
+		const int64_t cap = B.offsets[r + 1] - off;
+		const int nh = (int)s_hi[lr];
+		int rep = 0;
+		for (int i0 = 0; i0 < nh; i0 += 64) {
+			const int i = i0 + lane;
 			int c = 0;
-			if (high) {
-				if (below) c = min(KMER, en - prev_en);
-				else c = have_last ? min(KMER, en - last_en) : KMER;
+			if (i < nh) {
+				const int en = (int)(B.hits[off + cap - 1 - i].qinfo >> 1) + 1;
+				int prev = -1;
+				for (int j = 0; j < nh; ++j) {
+					const int o = (int)(B.hits[off + cap - 1 - j].qinfo >> 1) + 1;
+					if (o < en && o > prev) prev = o;
+				}
+				c = prev < 0 ? KMER : min(KMER, en - prev);
 			}
 #pragma unroll
 			for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
 			rep += c;
-			last_en = __shfl(en, 63 - __clzll((long long)hm));
-			have_last = true;
 		}
+		if (lane == 0) {
+			B.hit_cnt[r] = (int32_t)s_cur[lr];
+			B.an_cnt[r] = (int64_t)s_an[lr];
+			B.rep_len[r] = rep;
+		}
+	}
+}
 
-		const unsigned long long m = __ballot(hit);
-		if (hit) {
-			HitRec h;
-			h.val = val, h.qinfo = q.y, h.cnt = cnt | (tandem ? 0x80000000u : 0u);
-			out[n_hit + __popcll(m & lt)] = h;
-		}
-		n_hit += __popcll(m);
-		long long c = hit ? (long long)cnt : 0;
-#pragma unroll
-		for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
-		n_anchor += c;
-	}
-	if (lane == 0) {
-		B.hit_cnt[r] = n_hit;
-		B.an_cnt[r] = n_anchor;
-		B.rep_len[r] = rep;
-	}
+void launch_partition(const Batch &B, hipStream_t st)
+{
+	if (B.n_tiles == 0) return;
+	hipLaunchKernelGGL(mnc_partition_queries, dim3(B.n_tiles), dim3(PA_THREADS), 0, st, B);
 }
 
 void launch_probe(const Batch &B, hipStream_t st)
 {
-	if (B.n_reads == 0) return;
-	const unsigned blocks = (B.n_reads + PR_THREADS / 64 - 1) / (PR_THREADS / 64);
-	hipLaunchKernelGGL(mnc_probe_index, dim3(blocks), dim3(PR_THREADS), 0, st, B);
+	if (B.n_super == 0) return;
+	const uint32_t W = (B.n_super + PR_THREADS / 64 - 1) / (PR_THREADS / 64);
+	hipLaunchKernelGGL(mnc_probe_buckets, dim3(PB_N * W), dim3(PR_THREADS), 0, st, B, W);
+}
+
+void launch_collect(const Batch &B, hipStream_t st)
+{
+	if (B.n_super == 0) return;
+	hipLaunchKernelGGL(mnc_collect_hits, dim3(B.n_super), dim3(CO_THREADS), 0, st, B);
 }
 
 } // namespace mnc

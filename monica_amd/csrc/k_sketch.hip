@@ -71,6 +71,7 @@ constexpr int SK_PAD = 10;                          // halo on each side (>= WIN
 constexpr int SK_SLOTS = SK_CHUNK + 2 * SK_PAD + 4; // hash slots per wave (+4: the 22-value read-ahead)
 constexpr int SK_WORDS = (SK_CHUNK + 2 * SK_PAD + KMER) / 16 + 4;
 constexpr int SK_ITERS = (SK_CHUNK + 2 * SK_PAD + 63) / 64;
+static_assert(SK_THREADS / 64 == PT_READS, "one sketch workgroup = one partition tile");
 
 __device__ __forceinline__ uint32_t revcomp30(uint32_t fw)
 {
@@ -151,28 +152,38 @@ __device__ int sketch_serial(const uint8_t *s, int len, uint2 *out)
 // test); every lane decides two adjacent positions from eleven 8-byte LDS reads.
 // Output order is increasing position, 8 bytes per minimizer: {hash, pos<<1 | strand},
 // pos = index of the k-mer's last base.
+__device__ void sketch_one_read(const Batch &B, uint32_t r, int wv, int lane, int32_t *s_hash, uint32_t *s_words,
+                                unsigned long long *s_strand, uint32_t *s_hist);
+
 __global__ __launch_bounds__(SK_THREADS) void mnc_sketch_minimizers(Batch B)
 {
 	__shared__ __align__(16) int32_t s_hash_all[SK_THREADS / 64][SK_SLOTS];
 	__shared__ uint32_t s_words_all[SK_THREADS / 64][SK_WORDS];
 	__shared__ unsigned long long s_strand_all[SK_THREADS / 64][SK_ITERS];
+	__shared__ uint32_t s_hist[PB_N];             // minimizers of this tile per table bucket
 
 	const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const uint32_t r = blockIdx.x * (SK_THREADS / 64) + wv;
+	for (int k = threadIdx.x; k < PB_N; k += SK_THREADS) s_hist[k] = 0;
+	__syncthreads();
+	sketch_one_read(B, r, wv, lane, s_hash_all[wv], s_words_all[wv], s_strand_all[wv], s_hist);
+	__syncthreads();
+	for (int k = threadIdx.x; k < PB_N; k += SK_THREADS) B.hist_tm[(size_t)blockIdx.x * PB_N + k] = s_hist[k];
+}
+
+__device__ void sketch_one_read(const Batch &B, uint32_t r, int wv, int lane, int32_t *s_hash, uint32_t *s_words,
+                                unsigned long long *s_strand, uint32_t *s_hist)
+{
 	if (r >= B.n_reads) return;
-	int32_t *s_hash = s_hash_all[wv];
-	uint32_t *s_words = s_words_all[wv];
-	unsigned long long *s_strand = s_strand_all[wv];
 	const int64_t off = B.offsets[r];
 	const int len = (int)(B.offsets[r + 1] - off);
 	const int n = len - (KMER - 1);
 	uint2 *out = B.mz + off;
 	if (n <= 0) { if (lane == 0) B.mz_cnt[r] = 0; return; }
-	if (B.ambig[r]) {
-		if (lane == 0) B.mz_cnt[r] = sketch_serial(B.bases + off, len, out);
-		return;
-	}
+	if (B.ambig[r]) return;                         // mnc_sketch_ambiguous handles it
 	const unsigned long long lt = (1ULL << lane) - 1ULL;
+	const uint32_t tmask = (uint32_t)B.table_mask;
+	const int sbits = B.table_bits;
 
 	int total = 0;                                  // minimizers written so far (uniform)
 	for (int c0 = 0; c0 < n; c0 += SK_CHUNK) {
@@ -244,12 +255,30 @@ __global__ __launch_bounds__(SK_THREADS) void mnc_sketch_minimizers(Batch B)
 			const unsigned long long m0 = __ballot(e0), m1 = __ballot(e1);
 			const int rank = __popcll(m0 & lt) + __popcll(m1 & lt);
 			const unsigned long long sb = s_strand[q >> 6];       // q and q+1 share one 64-bit word (q even)
+			if (e0) atomicAdd(&s_hist[pb_bucket((uint32_t)h0, tmask, sbits)], 1u);
+			if (e1) atomicAdd(&s_hist[pb_bucket((uint32_t)h1, tmask, sbits)], 1u);
 			if (e0) out[total + rank] = make_uint2((uint32_t)h0, (uint32_t)(p0 + KMER - 1) << 1 | (uint32_t)(sb >> (q & 63) & 1));
 			if (e1) out[total + rank + (e0 ? 1 : 0)] = make_uint2((uint32_t)h1, (uint32_t)(p0 + KMER) << 1 | (uint32_t)(sb >> ((q + 1) & 63) & 1));
 			total += __popcll(m0) + __popcll(m1);
 		}
 	}
 	if (lane == 0) B.mz_cnt[r] = total;
+}
+
+// Reads with ambiguous bases: the serial state machine, one thread per such read.  Runs
+// after mnc_sketch_minimizers, so it adds its bucket counts to the tile's histogram row.
+__global__ __launch_bounds__(64) void mnc_sketch_ambiguous(Batch B)
+{
+	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= B.n_reads || !B.ambig[r]) return;
+	const int64_t off = B.offsets[r];
+	const int len = (int)(B.offsets[r + 1] - off);
+	if (len < KMER) return;                         // mz_cnt already 0
+	uint2 *out = B.mz + off;
+	const int n = sketch_serial(B.bases + off, len, out);
+	B.mz_cnt[r] = n;
+	uint32_t *row = B.hist_tm + (size_t)(r / PT_READS) * PB_N;
+	for (int i = 0; i < n; ++i) atomicAdd(&row[pb_bucket(out[i].x, (uint32_t)B.table_mask, B.table_bits)], 1u);
 }
 
 void launch_pack(const Batch &B, hipStream_t st)
@@ -266,6 +295,7 @@ void launch_sketch(const Batch &B, hipStream_t st)
 	if (B.n_reads == 0) return;
 	const unsigned blocks = (B.n_reads + SK_THREADS / 64 - 1) / (SK_THREADS / 64);
 	hipLaunchKernelGGL(mnc_sketch_minimizers, dim3(blocks), dim3(SK_THREADS), 0, st, B);
+	hipLaunchKernelGGL(mnc_sketch_ambiguous, dim3((B.n_reads + 63) / 64), dim3(64), 0, st, B);
 }
 
 } // namespace mnc
