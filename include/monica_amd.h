@@ -115,7 +115,8 @@ void *mnc_engine_stream(mnc_engine *eng);                              /* hipStr
  *   bases     host, concatenated read bases (ASCII; anything but ACGTUacgtu is ambiguous)
  *   offsets   host, n_reads+1 byte offsets into bases
  *   out_assign[n_reads]  contig index of the chosen hit | MNC_UNMAPPED | MNC_AMBIGUOUS
- *   out_best[n_reads]    the chosen hit (zero when assign < 0); may be NULL
+ *   out_best[n_reads]    the hit with the smallest NM/mlen (the last such hit when tied, i.e.
+ *                        also for MNC_AMBIGUOUS; zero when there is no gated hit); may be NULL
  *   out_nhits[n_reads]   number of gated hits of the read; may be NULL
  * The gated hit lists themselves stay in HBM until the next call; fetch them with
  * mnc_engine_fetch_hits (needed for the multi-part merge, aligner.py:196-203, 218-223).

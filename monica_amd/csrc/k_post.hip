@@ -349,9 +349,9 @@ __global__ __launch_bounds__(64) void mnc_regions_decide(Batch B, RegX *regx_all
 				++nhits;
 			}
 		}
-		if (nhits > 0) {
-			if (nhits == 1 || ties == 1) assign = gated[bi].rid, best = gated[bi];
-			else assign = MNC_AMBIGUOUS;
+		if (nhits > 0) {                                  // best = the minimal hit, also when it is tied
+			best = gated[bi];
+			assign = (nhits == 1 || ties == 1) ? gated[bi].rid : MNC_AMBIGUOUS;
 		}
 	}
 	B.n_reg[rd] = n_regs;

@@ -1,0 +1,107 @@
+"""Multi-GPU helpers: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over
+xGMI on the GPU box, "gloo" in CPU tests).
+
+Two ways the path shards:
+
+* **Reads sharded, index replicated** (BASELINE configs 2, 3, 5).  No data-path collective;
+  one `all_reduce(sum)` of the per-genome count table per batch -- the analogue of
+  `alignment_update` (monica/genomes/aligner.py:282-302).
+* **Index sharded** (config 4): every rank maps all reads against its part of the genomes,
+  exactly like one pass of the reference's multi-part loop (aligner.py:91-103): MAPQ and the
+  gate are per part, and `best_hit` (aligner.py:328-339) runs over the union of the parts'
+  gated hits.  Because `best_hit` only asks whether the smallest NM/mlen is unique, a part
+  is summarised per read by five integers {hits, nm, mlen, contig, tied}; the summaries are
+  all-gathered (20 B per read and rank) and reduced identically on every rank.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+UNMAPPED = -1
+AMBIGUOUS = -2
+
+
+def init(backend=None, device=None):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (set by
+    torch.distributed.run); returns (rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous block of read ordinals [lo, hi) of `rank` (sizes differ by at most one)."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def allreduce_counts(counts):
+    """Sum the per-genome count table over ranks, in place (torch tensor)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    return counts
+
+
+def shard_summary(assign, best, nhits, rid_offset=0):
+    """Per-read summary of one index part: int32[n, 5] = {hits, nm, mlen, global contig, tied}.
+    `best` is the engine's minimal gated hit (also for AMBIGUOUS reads)."""
+    t = torch.as_tensor
+    assign, nhits = t(assign), t(nhits)
+    best = t(np.ascontiguousarray(best).view(np.int32).reshape(-1, 4)) if isinstance(best, np.ndarray) else best.reshape(-1, 4)
+    out = torch.zeros((assign.shape[0], 5), dtype=torch.int32, device=assign.device)
+    has = nhits > 0
+    out[:, 0] = nhits
+    out[:, 1] = best[:, 2]                       # nm
+    out[:, 2] = best[:, 3]                       # mlen
+    out[:, 3] = torch.where(has, best[:, 0] + rid_offset, torch.full_like(best[:, 0], -1))
+    out[:, 4] = (assign == AMBIGUOUS).to(torch.int32)
+    return out
+
+
+def merge_summaries(stacked):
+    """best_hit over the union of the parts.  stacked: int32[parts, n, 5] in part order.
+    Returns (assign int32[n] with global contig ids, nm, mlen, total hits)."""
+    s = stacked.to(torch.int64)
+    n = s.shape[1]
+    dev = s.device
+    has = torch.zeros(n, dtype=torch.bool, device=dev)
+    nm = torch.zeros(n, dtype=torch.int64, device=dev)
+    ml = torch.ones(n, dtype=torch.int64, device=dev)
+    rid = torch.full((n,), -1, dtype=torch.int64, device=dev)
+    tied = torch.zeros(n, dtype=torch.bool, device=dev)
+    total = torch.zeros(n, dtype=torch.int64, device=dev)
+    for p in range(s.shape[0]):
+        c_has = s[p, :, 0] > 0
+        c_nm, c_ml, c_rid, c_tied = s[p, :, 1], torch.clamp(s[p, :, 2], min=1), s[p, :, 3], s[p, :, 4] > 0
+        lhs, rhs = c_nm * ml, nm * c_ml              # c_nm/c_ml ? nm/ml, exact in int64
+        better = c_has & (~has | (lhs < rhs))
+        equal = c_has & has & (lhs == rhs)
+        tied = torch.where(better, c_tied, tied | equal)
+        nm = torch.where(better | equal, c_nm, nm)
+        ml = torch.where(better | equal, c_ml, ml)
+        rid = torch.where(better | equal, c_rid, rid)
+        has = has | c_has
+        total = total + s[p, :, 0]
+    assign = torch.where(~has, torch.full_like(rid, UNMAPPED), torch.where(tied, torch.full_like(rid, AMBIGUOUS), rid))
+    return assign.to(torch.int32), nm.to(torch.int32), ml.to(torch.int32), total.to(torch.int32)
+
+
+def gather_and_merge(summary):
+    """All-gather the per-part summaries (rank order = part order) and merge them."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        parts = [torch.empty_like(summary) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, summary.contiguous())
+        stacked = torch.stack(parts)
+    else:
+        stacked = summary.unsqueeze(0)
+    return merge_summaries(stacked)

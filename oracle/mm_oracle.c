@@ -867,7 +867,7 @@ int orc_map(const orc_index *mi, const orc_opt_t *opt, int mid_occ, const char *
 
 /* aligner.py:328-339.  Python float semantics: float(NM)/mlen in binary64, `<=`,
  * distance = best - new at the LAST update; falsy distance (0.0) => "0" (ambiguous). */
-int orc_best_hit(const orc_hit_t *hits, int n)
+static int best_hit_arg(const orc_hit_t *hits, int n, int *arg)
 {
 	double best = INFINITY, distance = 0.0;
 	int best_i = -1, i;
@@ -878,9 +878,12 @@ int orc_best_hit(const orc_hit_t *hits, int n)
 			best = inverse_identity, best_i = i;
 		}
 	}
+	if (arg) *arg = best_i;                  /* the last hit that set the minimum */
 	if (distance == 0.0) return -1;          /* `if not distance` (NaN cannot arise: mlen > 0) */
 	return best_i;
 }
+
+int orc_best_hit(const orc_hit_t *hits, int n) { return best_hit_arg(hits, n, 0); }
 
 /* aligner.py:212-233 for a single index part: gate, then single hit | best_hit | ambiguous */
 static int classify_one(const orc_index *mi, const orc_opt_t *opt, int mid_occ, const char *seq,
@@ -912,8 +915,8 @@ static int classify_one(const orc_index *mi, const orc_opt_t *opt, int mid_occ, 
 	else if (n_h > hits_cap) *assign = ORC_AMBIGUOUS;          /* caller re-runs with more room */
 	else if (n_h == 1) *assign = hits[0].rid, *chosen = hits[0];
 	else {
-		int b = orc_best_hit(hits, n_h);
-		if (b < 0) *assign = ORC_AMBIGUOUS;
+		int arg = -1, b = best_hit_arg(hits, n_h, &arg);
+		if (b < 0) *assign = ORC_AMBIGUOUS, *chosen = hits[arg];   /* the tied minimum, for cross-shard merges */
 		else *assign = hits[b].rid, *chosen = hits[b];
 	}
 	return n_h;

@@ -125,7 +125,7 @@ int orc_best_hit(const orc_hit_t *hits, int n);
 
 /* classify a batch: bases = concatenated ASCII reads, offsets[n_reads+1].
  * out_assign[r] = contig id of the chosen hit | ORC_UNMAPPED | ORC_AMBIGUOUS
- * out_hit[r]    = the chosen hit (valid when assign >= 0)
+ * out_hit[r]    = the hit with the smallest NM/mlen (last one when tied; zero without hits)
  * out_nhits[r]  = number of gated hits
  * hits_flat/hits_cap: optional flat list of all gated hits in read order (may be NULL)
  * returns total number of gated hits. n_threads<=1: scalar. */

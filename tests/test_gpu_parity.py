@@ -128,3 +128,42 @@ def test_device_counts_match_host_counts(capi, oracle, world):
     assert np.array_equal(assign, oassign)
     assert got[:, 0].sum() == (oassign >= 0).sum()
     assert got[:, 1].sum() == 3000 * (oassign >= 0).sum()
+
+
+def test_index_sharded_merge_equals_multi_part_reference(capi, oracle):
+    """BASELINE config 4 on one GPU: two index parts (a genome and its diverged copy in
+    different parts), per-part summaries merged like dist.gather_and_merge does across
+    ranks, against the reference's multi-part loop evaluated with the oracle."""
+    import torch
+    from monica_amd import aligner, dist as mdist
+    names, seqs = util.small_genomes(4, 120_000, 150_000)
+    bases, offsets, truth = synth.reads(seqs, 300, 3000, seed=17)
+    parts = [(names[:2], seqs[:2], 0), (names[2:], seqs[2:], 2)]
+    summaries, lists = [], [[] for _ in range(300)]
+    for pn, ps, base in parts:
+        idx = capi.Index.from_seqs(pn, ps)
+        eng = capi.Engine(idx, 0)
+        assign, best, nhits = eng.classify(bases, offsets, 60)
+        summaries.append(mdist.shard_summary(assign, best, nhits, rid_offset=base))
+        oidx = oracle.Index.from_seqs(pn, [s.tobytes() for s in ps])
+        oa, ob, onh, flat = oidx.classify(bases, offsets, 60)
+        assert np.array_equal(assign, oa) and np.array_equal(nhits, onh)
+        for k in capi.HIT_DTYPE.names:
+            assert np.array_equal(best[k], ob[k]), k
+        k = 0
+        for r in range(300):
+            for h in flat[k:k + onh[r]]:
+                lists[r].append((int(h["rid"]) + base, int(h["nm"]), int(h["mlen"])))
+            k += onh[r]
+        eng.close()
+    got, nm, ml, tot = mdist.merge_summaries(torch.stack(summaries))
+    want = []
+    for hits in lists:
+        if not hits:
+            want.append(mdist.UNMAPPED)
+        else:
+            b = hits[0] if len(hits) == 1 else aligner.best_hit(hits)
+            want.append(b[0] if b else mdist.AMBIGUOUS)
+    assert got.tolist() == want
+    assert tot.tolist() == [len(h) for h in lists]
+    assert (np.array(want) >= 0).sum() > 250
