@@ -42,6 +42,10 @@ def parse():
     ap.add_argument("--max-len", type=int, default=7_000_000)
     ap.add_argument("--min-mapq", type=int, default=60)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1 auto, 0 off)")
+    ap.add_argument("--mode", choices=["batch", "stream"], default="batch",
+                    help="batch: the headline metric; stream: BASELINE config 5 (400 reads/s arrival, 1-s micro-batches)")
+    ap.add_argument("--stream-seconds", type=int, default=1800)
+    ap.add_argument("--stream-rate", type=int, default=400)
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "probe_traffic.json"),
                     help="optional PMC-derived HBM bytes per launch of the probe kernel")
     return ap.parse_args()
@@ -77,6 +81,9 @@ def main():
     engine = _capi.Engine(index, local_rank)
     n_genomes = info.n_genomes
     t_setup = time.time() - t0
+
+    if args.mode == "stream":
+        return stream_mode(args, engine, index, seqs, synth)
 
     d_bases = torch.from_numpy(bases).to(dev)
     d_off = torch.from_numpy(offsets).to(dev)
@@ -161,24 +168,22 @@ def main():
             cores = len(os.sched_getaffinity(0))
         except Exception:
             pass
+        cores = min(cores, 16)                       # the GPU box's CPU share for one GPU
         oidx = pyoracle.Index.from_seqs(names, [s.tobytes() for s in seqs])
-        n_s = args.cpu_sample if args.cpu_sample > 0 else min(args.reads, 2000)
+        n_s = args.cpu_sample if args.cpu_sample > 0 else args.reads
         ob, oo = bases[: n_s * args.read_len], offsets[: n_s + 1]
-        tc = time.perf_counter()
-        oa, _, _, _ = oidx.classify(ob, oo, args.min_mapq, n_threads=cores)
-        dt = time.perf_counter() - tc
-        if args.cpu_sample < 0 and dt < 10.0:       # scale the sample to ~15 s of CPU work
-            n_s2 = int(min(args.reads, max(n_s, n_s * 15.0 / max(dt, 1e-3))))
-            if n_s2 > n_s:
-                n_s = n_s2
-                ob, oo = bases[: n_s * args.read_len], offsets[: n_s + 1]
-                tc = time.perf_counter()
-                oa, _, _, _ = oidx.classify(ob, oo, args.min_mapq, n_threads=cores)
-                dt = time.perf_counter() - tc
+        reps, dt = 0, 0.0
+        while True:                                  # about 10-30 s of CPU work on the sample
+            tc = time.perf_counter()
+            oa, _, _, _ = oidx.classify(ob, oo, args.min_mapq, n_threads=cores)
+            dt += time.perf_counter() - tc
+            reps += 1
+            if args.cpu_sample > 0 or dt >= 10.0 or reps >= 50:
+                break
         agree = bool(np.array_equal(oa, assign[:n_s]))
-        cpu = {"value": round(n_s / dt, 1), "unit": "reads/s", "cores": cores, "kind": "port",
-               "sample": f"first {n_s} reads of the same batch, CPU oracle (chain-level minimap2-2.17 restatement, "
-                         f"OpenMP over reads), {dt:.1f} s", "agrees_with_gpu": agree}
+        cpu = {"value": round(n_s * reps / dt, 1), "unit": "reads/s", "cores": cores, "kind": "port",
+               "sample": f"first {n_s} reads of the same batch x {reps} passes, CPU oracle (chain-level "
+                         f"minimap2-2.17 restatement, OpenMP over reads), {dt:.1f} s", "agrees_with_gpu": agree}
 
     n_total = args.reads * args.steps * world
     mapped = int((assign >= 0).sum())
@@ -212,6 +217,39 @@ def main():
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def stream_mode(args, engine, index, seqs, synth):
+    """BASELINE config 5: a MinION run delivering `--stream-rate` reads/s for `--stream-seconds`
+    seconds, classified as 1-second micro-batches through the host-buffer entry point
+    (`mnc_classify_batch`: H2D of the bases, all kernels, D2H of the results).  The simulated
+    clock is compressed: batches are processed back to back and the per-batch wall time is the
+    latency a read would see after its batch closes."""
+    n_batches, rate = args.stream_seconds, args.stream_rate
+    pool, offs, truth = synth.reads(seqs, rate * 64, args.read_len, seed=synth.SEED_READS + 5)
+    lat, mapped, total = [], 0, 0
+    counts = np.zeros(len(index.genome_names), dtype=np.int64)
+    t_all = time.perf_counter()
+    for b in range(n_batches):
+        k = b % 64
+        bb = pool[k * rate * args.read_len:(k + 1) * rate * args.read_len]
+        bo = offs[: rate + 1]
+        t0 = time.perf_counter()
+        assign, best, nhits = engine.classify(bb, bo, args.min_mapq)
+        lat.append(time.perf_counter() - t0)
+        ok = assign >= 0
+        mapped += int(ok.sum())
+        total += rate
+        np.add.at(counts, index.contig_genome[assign[ok]], 1)
+    wall = time.perf_counter() - t_all
+    lat = np.array(lat[5:]) * 1e3
+    print(json.dumps({
+        "metric": "streaming micro-batch latency (BASELINE config 5)", "unit": "ms",
+        "p50_ms": round(float(np.percentile(lat, 50)), 3), "p99_ms": round(float(np.percentile(lat, 99)), 3),
+        "max_ms": round(float(lat.max()), 3), "batches": n_batches, "reads_per_batch": rate,
+        "arrival_reads_per_s": rate, "sustained_reads_per_s": round(total / wall, 1),
+        "real_time_factor": round(total / wall / rate, 1), "mapped_fraction": round(mapped / total, 4),
+        "path": "host buffers -> mnc_classify_batch (H2D + kernels + D2H), 1 MI355X", "data": "synthetic"}))
 
 
 if __name__ == "__main__":
