@@ -36,26 +36,31 @@ struct MapParams {
 };
 
 // ---------------------------------------------------------------- HBM table
-// Open-addressed, power-of-two number of 64-byte lines, 4 keys per line, linear probing over
-// LINES: a lookup reads the 16 bytes of keys of its home line (hash & line_mask) and stops
-// there unless that line is full (rare at load <= 0.5), so the longest probe chain inside a
-// wave stays at one or two round trips (with 16-byte slots the slowest of 64 lanes needed 5-6).
-//   key  = hash + 1 (0 marks an empty slot; a line fills from slot 0 upwards)
-//   cv   = {occurrences, value}: value = the occurrence word itself (rid<<32 | pos<<1 | strand)
-//          when occurrences == 1, else the offset of the first occurrence in positions[]
+// The 30-bit minimizer hash splits into a REGION (low PB_BITS = 8 bits) and a 22-bit REST.
+// Every region owns a power-of-two block of 16-byte slots {key = hash+1, cnt, val} (load
+// <= 0.5) and is perfectly hashed by hash-and-displace: the rest picks one of NB displacement
+// buckets (rest & (NB-1)), a base slot and an odd step (two multiplicative mixes of the rest);
+// the key sits at slot (base + disp[bucket] * step) & (R-1).  So a lookup is: one 8-bit displacement (LDS),
+// ONE 16-byte gather, one compare -- no probe chain, whose longest member would otherwise
+// hold up the other 63 lanes of the wave.
+//   cnt  = occurrences
+//   val  = cnt == 1 : the occurrence word itself (rid<<32 | pos<<1 | strand)
+//          cnt  > 1 : offset of the first occurrence word in the positions array
 // Queries that are not in the table at all (3 of 4) are stopped before the gather by a
-// per-region presence filter held in LDS (k_probe.hip).
-struct TableCV { uint32_t cnt, val_lo, val_hi; };   // 12 bytes: one dwordx3 request
-struct alignas(64) TableLine {
-	uint32_t key[4];
-	TableCV cv[4];
+// per-region presence filter, also held in LDS (k_probe.hip).
+struct alignas(16) TableSlot {
+	uint32_t key;
+	uint32_t cnt;
+	uint64_t val;
 };
 
 struct DeviceIndex {          // one per (index, device)
 	int device = -1;
-	TableLine *table = nullptr;
-	uint64_t table_mask = 0;       // number of lines - 1
-	uint32_t *filter = nullptr;    // per table region: 2^18-bit presence filter (see k_probe.hip)
+	TableSlot *table = nullptr;    // PB_N regions x region_slots
+	int region_bits = 0;           // log2(slots per region)
+	int disp_bits = 0;             // log2(displacement buckets per region)
+	uint8_t *disp = nullptr;       // [PB_N][1 << disp_bits]
+	uint32_t *filter = nullptr;    // per region: 2^PF_BITS-bit presence filter (see k_probe.hip)
 	uint64_t *positions = nullptr;
 	int32_t *contig_genome = nullptr;
 	int64_t bytes = 0;

@@ -16,31 +16,36 @@ struct Anchor { uint64_t x, y; };    // x = strand<<63 | rid<<32 | rpos ; y = sp
 
 // ---------------------------------------------------------------- partitioned probe
 // The hash table is cut into 2^PB_BITS contiguous regions ("buckets") by the top bits of the
-// home line.  Query minimizers are partitioned by bucket so that the probe of one bucket
+// hash.  Query minimizers are partitioned by bucket so that the probe of one bucket
 // touches one region (2 MiB for the 20-genome index: L2-resident) instead of random HBM lines.
 constexpr int PB_BITS = 8;
 constexpr int PB_N = 1 << PB_BITS;
 constexpr int PT_READS = 4;                 // reads per partition tile (= one sketch workgroup)
 constexpr int PS_TILES = 64;                // tiles per super-tile (probe / collect granularity: 256 reads)
-constexpr int PF_BITS = 19;                 // presence filter: 2^18 bits = 32 KiB per table region (fits LDS)
+constexpr int PF_BITS = 18;                 // presence filter: 2^18 bits = 32 KiB per table region (fits LDS)
 constexpr int PF_WORDS = (1 << PF_BITS) / 32;
 constexpr uint32_t HIT_HIGH = 0x7fffffffu;  // cnt marker: occurrences >= mid_occ (only feeds rep_len)
 
-// 64-bit query record: [21:0] hash without its bucket bits, [22] strand, [23] tandem,
+// 64-bit query record: [21:0] rest of the hash, [22] strand, [23] tandem,
 // [43:24] query position (last base of the k-mer), [63:44] read ordinal in the batch
-__device__ __forceinline__ uint32_t pb_bucket(uint32_t hash, uint32_t mask, int sbits)
+constexpr int PB_REST_BITS = 2 * KMER - PB_BITS;            // 22
+constexpr int PD_MAX_BITS = 14;                             // at most 16384 displacement buckets (16 KiB of LDS)
+// The region comes from the LOW hash bits: minimizers are window minima, so their hash values
+// crowd towards zero and the high bits are far from uniform (region 0 would hold 5x its share).
+__host__ __device__ __forceinline__ uint32_t pb_bucket(uint32_t hash) { return hash & (uint32_t)(PB_N - 1); }
+__host__ __device__ __forceinline__ uint32_t pb_rest(uint32_t hash) { return hash >> PB_BITS; }
+__host__ __device__ __forceinline__ uint32_t pb_hash(uint32_t rest, uint32_t bucket) { return rest << PB_BITS | bucket; }
+// base slot of a rest inside its region (independent of the low bits that pick the displacement bucket)
+__host__ __device__ __forceinline__ uint32_t pd_base(uint32_t rest, int region_bits)
 {
-	return (hash & mask) >> (sbits - PB_BITS);
+	return (uint32_t)(((uint64_t)(rest * 0x9E3779B1u) * (uint64_t)(1u << region_bits)) >> 32);
 }
-__device__ __forceinline__ uint32_t pb_rest(uint32_t hash, int sbits)
+// slot = base + disp * step with a key-dependent odd step (double hashing), so two keys of one
+// displacement bucket that share a base still separate for some disp
+__host__ __device__ __forceinline__ uint32_t pd_step(uint32_t rest) { return ((rest * 0x85EBCA6Bu) >> 7) | 1u; }
+__host__ __device__ __forceinline__ uint32_t pd_slot(uint32_t rest, uint32_t disp, int region_bits)
 {
-	const int lo = sbits - PB_BITS;
-	return ((hash >> sbits) << lo) | (hash & ((1u << lo) - 1u));
-}
-__device__ __forceinline__ uint32_t pb_hash(uint32_t rest, uint32_t bucket, int sbits)
-{
-	const int lo = sbits - PB_BITS;
-	return ((rest >> lo) << sbits) | (bucket << lo) | (rest & ((1u << lo) - 1u));
+	return (pd_base(rest, region_bits) + disp * pd_step(rest)) & ((1u << region_bits) - 1u);
 }
 
 // start of run (bucket, tile) in the bucket-major record array.  The offsets are stored
@@ -80,12 +85,12 @@ struct Batch {
 	int64_t total_bases;
 	int min_mapq;
 	// ---- index
-	const TableLine *table;
-	const uint32_t *filter;       // [PB_N][PF_WORDS] presence bits of (region, 18 low bits of the rest of the hash)
-	uint64_t table_mask;
+	const TableSlot *table;       // [PB_N][1 << region_bits]
+	const uint8_t *disp;          // [PB_N][1 << disp_bits] hash-and-displace displacements
+	const uint32_t *filter;       // [PB_N][PF_WORDS] presence bits of (region, low PF_BITS of the rest)
+	int region_bits, disp_bits;
 	const uint64_t *positions;
 	const int32_t *contig_genome;
-	int table_bits;               // log2(table lines)
 	int mid_occ;
 	int n_genomes;
 	// ---- parameters

@@ -157,48 +157,72 @@ int index_upload(mnc_index *idx, int device, DeviceIndex **out)
 	for (auto &d : idx->dev) if (d.device == device) { *out = &d; return MNC_OK; }
 	if (idx->keys.empty()) { set_error("empty index"); return MNC_ERR_FORMAT; }
 	HIP_TRY(hipSetDevice(device));
-	// 4-key lines, load <= 0.5; home line = hash & mask (the minimizer hash is an invertible
-	// mix of the k-mer, so its low bits are already uniform); at least 2^PB_BITS lines
-	uint64_t lines = 1024;
-	while (lines * 4 < idx->keys.size() * 2) lines <<= 1;
-	std::vector<TableLine> tab;
-	try { tab.assign(lines, TableLine{}); } catch (const std::bad_alloc &) { return MNC_ERR_NOMEM; }
-	const uint64_t mask = lines - 1;
-	for (size_t i = 0; i < idx->keys.size(); ++i) {
-		const uint32_t h = idx->keys[i];
-		const uint64_t o = idx->key_off[i], c = idx->key_off[i + 1] - o;
-		uint64_t l = (uint64_t)h & mask;
-		while (tab[l].key[3]) l = (l + 1) & mask;
-		int k = 0;
-		while (tab[l].key[k]) ++k;
-		const uint64_t v = c == 1 ? idx->pos[o] : o;
-		tab[l].key[k] = h + 1;
-		tab[l].cv[k].cnt = (uint32_t)c, tab[l].cv[k].val_lo = (uint32_t)v, tab[l].cv[k].val_hi = (uint32_t)(v >> 32);
-	}
-	// presence filter per table region: bit (rest of the hash mod 2^PF_BITS); a query whose bit
-	// is clear cannot be in the table, so it never costs a gather
-	int lbits = 0;
-	while ((1ULL << lbits) < lines) ++lbits;
+	// ---- regions: PB_N blocks of R slots (load <= 0.5), perfectly hashed by hash-and-displace
+	std::vector<std::vector<uint32_t>> reg(PB_N);       // key indices per region
+	for (size_t i = 0; i < idx->keys.size(); ++i) reg[pb_bucket(idx->keys[i])].push_back((uint32_t)i);
+	size_t biggest = 0;
+	for (auto &v : reg) biggest = std::max(biggest, v.size());
+	int region_bits = 6;
+	while ((1ULL << region_bits) < biggest * 2) ++region_bits;
+	if (region_bits > 28) { set_error("index too large for one device table"); return MNC_ERR_UNSUPPORTED; }
+	const int disp_bits = std::min(PD_MAX_BITS, std::max(0, region_bits - 3));
+	const size_t R = (size_t)1 << region_bits, NB = (size_t)1 << disp_bits;
+	std::vector<TableSlot> tab;
+	std::vector<uint8_t> disp((size_t)PB_N * NB, 0);
 	std::vector<uint32_t> filt((size_t)PB_N * PF_WORDS, 0u);
-	for (size_t i = 0; i < idx->keys.size(); ++i) {
-		const uint32_t h = idx->keys[i];
-		const int lo = lbits - PB_BITS;
-		const uint32_t b = (uint32_t)((h & mask) >> lo);
-		const uint32_t rest = ((h >> lbits) << lo) | (h & ((1u << lo) - 1u));
-		const uint32_t bit = rest & ((1u << PF_BITS) - 1u);
-		filt[(size_t)b * PF_WORDS + (bit >> 5)] |= 1u << (bit & 31);
+	try { tab.assign((size_t)PB_N * R, TableSlot{0, 0, 0}); } catch (const std::bad_alloc &) { return MNC_ERR_NOMEM; }
+	{
+		std::vector<std::vector<uint32_t>> bk(NB);
+		std::vector<uint32_t> order(NB);
+		for (int b = 0; b < PB_N; ++b) {
+			TableSlot *T = tab.data() + (size_t)b * R;
+			for (auto &v : bk) v.clear();
+			for (uint32_t ki : reg[b]) {
+				const uint32_t rest = pb_rest(idx->keys[ki]);
+				bk[rest & (NB - 1)].push_back(ki);
+				const uint32_t bit = rest & ((1u << PF_BITS) - 1u);
+				filt[(size_t)b * PF_WORDS + (bit >> 5)] |= 1u << (bit & 31);
+			}
+			for (size_t i = 0; i < NB; ++i) order[i] = (uint32_t)i;
+			std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return bk[x].size() != bk[y].size() ? bk[x].size() > bk[y].size() : x < y; });
+			for (uint32_t o : order) {                   // largest displacement buckets first
+				const auto &keys = bk[o];
+				if (keys.empty()) break;
+				int d = 0;
+				for (; d < 256; ++d) {
+					bool ok = true;
+					for (size_t a = 0; a < keys.size() && ok; ++a) {
+						const uint32_t sa = pd_slot(pb_rest(idx->keys[keys[a]]), (uint32_t)d, region_bits);
+						if (T[sa].key) ok = false;
+						for (size_t c = 0; c < a && ok; ++c)
+							if (sa == pd_slot(pb_rest(idx->keys[keys[c]]), (uint32_t)d, region_bits)) ok = false;
+					}
+					if (ok) break;
+				}
+				if (d == 256) { set_error("perfect hashing of table region %d failed (bucket of %zu keys, region %zu keys, R %zu, NB %zu)", b, keys.size(), reg[b].size(), R, NB); return MNC_ERR_UNSUPPORTED; }
+				disp[(size_t)b * NB + o] = (uint8_t)d;
+				for (uint32_t ki : keys) {
+					const uint32_t h = idx->keys[ki];
+					const uint64_t off = idx->key_off[ki], c = idx->key_off[ki + 1] - off;
+					TableSlot &s = T[pd_slot(pb_rest(h), (uint32_t)d, region_bits)];
+					s.key = h + 1, s.cnt = (uint32_t)c, s.val = c == 1 ? idx->pos[off] : off;
+				}
+			}
+		}
 	}
 	DeviceIndex d;
-	d.device = device, d.table_mask = mask;
+	d.device = device, d.region_bits = region_bits, d.disp_bits = disp_bits;
 	HIP_TRY(hipMalloc((void**)&d.filter, filt.size() * 4));
 	HIP_TRY(hipMemcpy(d.filter, filt.data(), filt.size() * 4, hipMemcpyHostToDevice));
-	HIP_TRY(hipMalloc((void**)&d.table, lines * sizeof(TableLine)));
-	HIP_TRY(hipMemcpy(d.table, tab.data(), lines * sizeof(TableLine), hipMemcpyHostToDevice));
+	HIP_TRY(hipMalloc((void**)&d.disp, disp.size()));
+	HIP_TRY(hipMemcpy(d.disp, disp.data(), disp.size(), hipMemcpyHostToDevice));
+	HIP_TRY(hipMalloc((void**)&d.table, tab.size() * sizeof(TableSlot)));
+	HIP_TRY(hipMemcpy(d.table, tab.data(), tab.size() * sizeof(TableSlot), hipMemcpyHostToDevice));
 	HIP_TRY(hipMalloc((void**)&d.positions, (idx->pos.size() + 1) * 8));
 	HIP_TRY(hipMemcpy(d.positions, idx->pos.data(), idx->pos.size() * 8, hipMemcpyHostToDevice));
 	HIP_TRY(hipMalloc((void**)&d.contig_genome, idx->contig_genome.size() * 4));
 	HIP_TRY(hipMemcpy(d.contig_genome, idx->contig_genome.data(), idx->contig_genome.size() * 4, hipMemcpyHostToDevice));
-	d.bytes = (int64_t)(lines * sizeof(TableLine) + filt.size() * 4 + (idx->pos.size() + 1) * 8 + idx->contig_genome.size() * 4);
+	d.bytes = (int64_t)(tab.size() * sizeof(TableSlot) + filt.size() * 4 + disp.size() + (idx->pos.size() + 1) * 8 + idx->contig_genome.size() * 4);
 	idx->dev.reserve(16);
 	idx->dev.push_back(d);
 	*out = &idx->dev.back();
@@ -212,6 +236,7 @@ void index_release_device(mnc_index *idx)
 		if (hipSetDevice(d.device) != hipSuccess) continue;
 		if (d.table) (void)hipFree(d.table);
 		if (d.filter) (void)hipFree(d.filter);
+		if (d.disp) (void)hipFree(d.disp);
 		if (d.positions) (void)hipFree(d.positions);
 		if (d.contig_genome) (void)hipFree(d.contig_genome);
 	}
@@ -437,9 +462,8 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	Batch &B = e->B;
 	memset(&B, 0, sizeof(B));
 	B.bases = d_bases, B.offsets = d_offsets, B.n_reads = n_reads, B.total_bases = total_bases, B.min_mapq = min_mapq;
-	B.table = e->didx->table, B.filter = e->didx->filter, B.table_mask = e->didx->table_mask, B.positions = e->didx->positions;
-	B.table_bits = 0;
-	while ((1ULL << B.table_bits) <= B.table_mask) ++B.table_bits;
+	B.table = e->didx->table, B.filter = e->didx->filter, B.disp = e->didx->disp, B.positions = e->didx->positions;
+	B.region_bits = e->didx->region_bits, B.disp_bits = e->didx->disp_bits;
 	B.contig_genome = e->didx->contig_genome, B.mid_occ = idx->mid_occ, B.n_genomes = (int)idx->genome_name.size();
 	const MapParams &P = idx->par;
 	B.min_cnt = P.min_cnt, B.min_sc = P.min_chain_score, B.bw = P.bw, B.max_gap = P.max_gap, B.max_skip = P.max_chain_skip;

@@ -372,7 +372,7 @@ extern "C" int mnc_index_info(const mnc_index *idx, mnc_index_info_t *info)
 	info->n_keys = (int64_t)idx->keys.size();
 	info->n_occ = (int64_t)idx->pos.size();
 	info->total_len = idx->total_len;
-	for (auto &d : idx->dev) { info->device_bytes += d.bytes; info->table_slots = ((int64_t)d.table_mask + 1) * 4; }
+	for (auto &d : idx->dev) { info->device_bytes += d.bytes; info->table_slots = (int64_t)256 << d.region_bits; }
 	return MNC_OK;
 }
 

@@ -68,8 +68,6 @@ __global__ __launch_bounds__(PA_THREADS) void mnc_partition_queries(Batch B)
 	__syncthreads();
 	const uint32_t total = s_loc[PB_N];
 	const bool staged = total <= (uint32_t)PA_STAGE;
-	const uint32_t tmask = (uint32_t)B.table_mask;
-	const int sbits = B.table_bits;
 	uint32_t prev_hash = 0xffffffffu;               // hash of minimizer i0 - 1
 	for (int i0 = 0; i0 < n; i0 += 64) {
 		const int i = i0 + lane;
@@ -86,10 +84,10 @@ __global__ __launch_bounds__(PA_THREADS) void mnc_partition_queries(Batch B)
 		const bool tandem = valid && (q.x == left || q.x == right);
 		prev_hash = __shfl(q.x, 63);
 		if (valid) {
-			const uint32_t b = pb_bucket(q.x, tmask, sbits);
+			const uint32_t b = pb_bucket(q.x);
 			const uint32_t rank = atomicAdd(&s_cur[b], 1u);
 			const int64_t dst = s_off[b] + rank;
-			const uint64_t rec = (uint64_t)pb_rest(q.x, sbits) | (uint64_t)(q.y & 1u) << 22 | (uint64_t)(tandem ? 1u : 0u) << 23 |
+			const uint64_t rec = (uint64_t)pb_rest(q.x) | (uint64_t)(q.y & 1u) << 22 | (uint64_t)(tandem ? 1u : 0u) << 23 |
 			                     (uint64_t)(q.y >> 1) << 24 | (uint64_t)r << 44;
 			if (dst >= B.q_cap) *B.overflow = 1u;
 			else if (staged) { const uint32_t at = s_loc[b] + rank; s_rec[at] = rec; s_bkt[at] = (uint8_t)b; }
@@ -112,7 +110,7 @@ __global__ __launch_bounds__(PA_THREADS) void mnc_partition_queries(Batch B)
 // walks its own buckets in order, and the ~256 workgroups resident on it at any time span two
 // or three buckets, whose 2 MiB table regions stay hot in its 4 MiB L2 (speed only, never
 // correctness).
-constexpr int PR_THREADS = 1024;
+constexpr int PR_THREADS = 512;
 constexpr int PR_U = 4;                             // queries per lane in flight
 
 __global__ __launch_bounds__(PR_THREADS) void mnc_probe_buckets(Batch B, uint32_t wgs_per_bucket)
@@ -120,23 +118,30 @@ __global__ __launch_bounds__(PR_THREADS) void mnc_probe_buckets(Batch B, uint32_
 	const uint32_t g = blockIdx.x, x = g & 7u, seq = g >> 3;
 	const uint32_t bucket = (seq / wgs_per_bucket) * 8u + x;
 	const uint32_t T = (seq % wgs_per_bucket) * (PR_THREADS / 64) + (threadIdx.x >> 6);
-	// the region's presence filter (32 KiB) into LDS: 3 of 4 queries are absent from the table
-	// and most of them stop here, at LDS speed, instead of costing a gather
+	// the region's presence filter and displacement table into LDS: 3 of 4 queries are absent
+	// from the table and most of them stop at the filter, at LDS speed; a survivor costs one
+	// 8-bit LDS read and exactly one 16-byte gather
 	__shared__ __align__(16) uint32_t s_filter[PF_WORDS];
+	__shared__ __align__(16) uint8_t s_disp[1 << PD_MAX_BITS];
+	const int nb = 1 << B.disp_bits;
 	if (bucket < (uint32_t)PB_N) {
 		const uint4 *src = reinterpret_cast<const uint4*>(B.filter + (size_t)bucket * PF_WORDS);
 		uint4 *dst = reinterpret_cast<uint4*>(s_filter);
 #pragma unroll
 		for (int k = 0; k < PF_WORDS / 4 / PR_THREADS; ++k) dst[k * PR_THREADS + threadIdx.x] = src[k * PR_THREADS + threadIdx.x];
+		const uint8_t *ds = B.disp + (size_t)bucket * nb;
+		if (nb >= 16 * PR_THREADS) {
+			for (int k = threadIdx.x; k < nb / 16; k += PR_THREADS)
+				reinterpret_cast<uint4*>(s_disp)[k] = reinterpret_cast<const uint4*>(ds)[k];
+		} else for (int k = threadIdx.x; k < nb; k += PR_THREADS) s_disp[k] = ds[k];
 	}
 	__syncthreads();
 	if (bucket >= (uint32_t)PB_N || T >= B.n_super) return;
 	const int lane = lane_id();
 	const unsigned long long lt = (1ULL << lane) - 1ULL;
 	const uint32_t mid_occ = (uint32_t)B.mid_occ;
-	const int sbits = B.table_bits;
-	const TableLine *table = B.table;
-	const uint64_t lmask = B.table_mask;
+	const int rbits = B.region_bits;
+	const TableSlot *table = B.table + ((size_t)bucket << rbits);
 	{
 		const uint32_t t0 = T * PS_TILES, t1 = min(t0 + PS_TILES, B.n_tiles);
 		const int64_t q0 = q_start(B.q_off, B.n_tiles, bucket, t0), q1 = q_start(B.q_off, B.n_tiles, bucket, t1);
@@ -149,8 +154,8 @@ __global__ __launch_bounds__(PR_THREADS) void mnc_probe_buckets(Batch B, uint32_
 #pragma unroll
 			for (int u = 0; u < PR_U; ++u) { const int64_t i = q0 + u * 64 + lane; nxt[u] = i < q1 ? B.qrec[i] : 0; }
 			for (int64_t i0 = q0; i0 < q1; i0 += 64 * PR_U) {
-				uint64_t rec[PR_U], line[PR_U], val[PR_U];
-				uint32_t want[PR_U], cnt[PR_U];
+				uint64_t rec[PR_U], val[PR_U];
+				uint32_t cnt[PR_U], want[PR_U], slot[PR_U];
 				bool pend[PR_U];
 #pragma unroll
 				for (int u = 0; u < PR_U; ++u) {
@@ -163,29 +168,16 @@ __global__ __launch_bounds__(PR_THREADS) void mnc_probe_buckets(Batch B, uint32_
 #pragma unroll
 				for (int u = 0; u < PR_U; ++u) {
 					const uint32_t rest = (uint32_t)rec[u] & 0x3fffffu;
-					const uint32_t hash = pb_hash(rest, bucket, sbits);
-					line[u] = (uint64_t)hash & lmask, want[u] = hash + 1;
 					const uint32_t bit = rest & ((1u << PF_BITS) - 1u);
 					pend[u] = pend[u] && ((s_filter[bit >> 5] >> (bit & 31)) & 1u);
+					want[u] = pb_hash(rest, bucket) + 1;
+					slot[u] = pd_slot(rest, s_disp[rest & (uint32_t)(nb - 1)], rbits);
 				}
-				bool any = true;
-				while (__any(any)) {
-					uint4 k[PR_U];
+				TableSlot sl[PR_U];
 #pragma unroll
-					for (int u = 0; u < PR_U; ++u) if (pend[u]) k[u] = *reinterpret_cast<const uint4*>(table[line[u]].key);
-					any = false;
+				for (int u = 0; u < PR_U; ++u) if (pend[u]) sl[u] = table[slot[u]];
 #pragma unroll
-					for (int u = 0; u < PR_U; ++u) if (pend[u]) {
-						const uint32_t w = want[u];
-						const int at = k[u].x == w ? 0 : k[u].y == w ? 1 : k[u].z == w ? 2 : k[u].w == w ? 3 : -1;
-						if (at >= 0) {                          // second touch of the same 64-byte line
-							const TableCV cv = table[line[u]].cv[at];
-							cnt[u] = cv.cnt, val[u] = (uint64_t)cv.val_hi << 32 | cv.val_lo;
-							pend[u] = false;
-						} else if (k[u].w == 0) pend[u] = false;      // the line has room: key absent
-						else { line[u] = (line[u] + 1) & lmask; any = true; }
-					}
-				}
+				for (int u = 0; u < PR_U; ++u) if (pend[u] && sl[u].key == want[u]) cnt[u] = sl[u].cnt, val[u] = sl[u].val;
 #pragma unroll
 				for (int u = 0; u < PR_U; ++u) {
 					const bool emit = cnt[u] > 0;       // a hit, or a too-frequent minimizer (for rep_len)

@@ -182,8 +182,6 @@ __device__ void sketch_one_read(const Batch &B, uint32_t r, int wv, int lane, in
 	if (n <= 0) { if (lane == 0) B.mz_cnt[r] = 0; return; }
 	if (B.ambig[r]) return;                         // mnc_sketch_ambiguous handles it
 	const unsigned long long lt = (1ULL << lane) - 1ULL;
-	const uint32_t tmask = (uint32_t)B.table_mask;
-	const int sbits = B.table_bits;
 
 	int total = 0;                                  // minimizers written so far (uniform)
 	for (int c0 = 0; c0 < n; c0 += SK_CHUNK) {
@@ -255,8 +253,8 @@ __device__ void sketch_one_read(const Batch &B, uint32_t r, int wv, int lane, in
 			const unsigned long long m0 = __ballot(e0), m1 = __ballot(e1);
 			const int rank = __popcll(m0 & lt) + __popcll(m1 & lt);
 			const unsigned long long sb = s_strand[q >> 6];       // q and q+1 share one 64-bit word (q even)
-			if (e0) atomicAdd(&s_hist[pb_bucket((uint32_t)h0, tmask, sbits)], 1u);
-			if (e1) atomicAdd(&s_hist[pb_bucket((uint32_t)h1, tmask, sbits)], 1u);
+			if (e0) atomicAdd(&s_hist[pb_bucket((uint32_t)h0)], 1u);
+			if (e1) atomicAdd(&s_hist[pb_bucket((uint32_t)h1)], 1u);
 			if (e0) out[total + rank] = make_uint2((uint32_t)h0, (uint32_t)(p0 + KMER - 1) << 1 | (uint32_t)(sb >> (q & 63) & 1));
 			if (e1) out[total + rank + (e0 ? 1 : 0)] = make_uint2((uint32_t)h1, (uint32_t)(p0 + KMER) << 1 | (uint32_t)(sb >> ((q + 1) & 63) & 1));
 			total += __popcll(m0) + __popcll(m1);
@@ -278,7 +276,7 @@ __global__ __launch_bounds__(64) void mnc_sketch_ambiguous(Batch B)
 	const int n = sketch_serial(B.bases + off, len, out);
 	B.mz_cnt[r] = n;
 	uint32_t *row = B.hist_tm + (size_t)(r / PT_READS) * PB_N;
-	for (int i = 0; i < n; ++i) atomicAdd(&row[pb_bucket(out[i].x, (uint32_t)B.table_mask, B.table_bits)], 1u);
+	for (int i = 0; i < n; ++i) atomicAdd(&row[pb_bucket(out[i].x)], 1u);
 }
 
 void launch_pack(const Batch &B, hipStream_t st)
