@@ -111,7 +111,7 @@ __global__ __launch_bounds__(PA_THREADS) void mnc_partition_queries(Batch B)
 // or three buckets, whose 2 MiB table regions stay hot in its 4 MiB L2 (speed only, never
 // correctness).
 constexpr int PR_THREADS = 512;
-constexpr int PR_U = 4;                             // queries per lane in flight
+constexpr int PR_U = 8;                             // queries per lane in flight
 
 __global__ __launch_bounds__(PR_THREADS) void mnc_probe_buckets(Batch B, uint32_t wgs_per_bucket)
 {
