@@ -19,7 +19,8 @@ void launch_sketch(const Batch &B, hipStream_t st);
 void launch_partition(const Batch &B, hipStream_t st);
 void launch_probe(const Batch &B, hipStream_t st);
 void launch_collect(const Batch &B, hipStream_t st);
-void launch_expand_sort(const Batch &B, hipStream_t st);
+void launch_expand_sort(const Batch &B, const uint32_t *list, uint32_t count, int NM, hipStream_t st);
+int expand_sort_prepare(int max_nm);
 void launch_chain_dp_serial(const Batch &B, const uint32_t *read_list, uint32_t n_list, hipStream_t st);
 void launch_backtrack(const Batch &B, const uint32_t *read_list, uint32_t n_list, hipStream_t st);
 void launch_bin_reads(const Batch &B, const ChainClasses &C, uint32_t *cls_count, uint32_t *cls_list, hipStream_t st);
@@ -358,6 +359,7 @@ extern "C" int mnc_engine_create(mnc_index *idx, int device, mnc_engine **out)
 	if (!rc) rc = e->stats.ensure(16 * 8);
 	if (!rc) rc = e->cls_count.ensure((MAX_CHAIN_CLASSES + 1) * 4 + 64);
 	if (!rc) rc = chain_rows_prepare(chain_rows_lds_bytes(CHAIN_CLASSES.nm[CHAIN_CLASSES.n - 1]));
+	if (!rc) rc = expand_sort_prepare(CHAIN_CLASSES.nm[CHAIN_CLASSES.n - 1]);
 	if (!rc) {
 		he = hipMemcpy(e->gap_lut.p, gap.data(), GAP_LUT * 4, hipMemcpyHostToDevice);
 		if (he == hipSuccess) he = hipMemcpy(e->logf_lut.p, lg.data(), (size_t)e->logf_n * 4, hipMemcpyHostToDevice);
@@ -530,7 +532,12 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	B.f = e->f.as<int32_t>(), B.p = e->p.as<int32_t>(), B.v = e->v.as<int32_t>(), B.t = e->t.as<int32_t>(), B.u = e->u.as<uint64_t>();
 	B.regs = e->regs.as<mnc_reg_t>(), B.tmp_i32 = e->tmp_i32.as<int32_t>();
 
-	{ StageTimer t(e, MNC_STAGE_SORT2); launch_expand_sort(B, st); }
+	{
+		StageTimer t(e, MNC_STAGE_SORT2);
+		const uint32_t *lists = e->cls_list.as<uint32_t>();
+		for (int c = 0; c <= CHAIN_CLASSES.n; ++c)      // the last list: reads too large for LDS (NM = 0)
+			launch_expand_sort(B, lists + (size_t)c * n_reads, cls_count[c], c < CHAIN_CLASSES.n ? CHAIN_CLASSES.nm[c] : 0, st);
+	}
 	{
 		StageTimer t(e, MNC_STAGE_CHAIN);
 		const uint32_t *lists = e->cls_list.as<uint32_t>();

@@ -4,7 +4,8 @@
 // (monica/genomes/aligner.py:193,215).  Upstream sorts by x only
 // with an unstable radix sort; here the order is the total order (x, y), as in the oracle.
 //
-// One 256-thread workgroup per read.  Anchors are generated straight into LDS, sorted
+// One 256-thread workgroup per read; reads come in size classes (anchors per read) so the
+// LDS tile is as small as the class allows.  Anchors are generated straight into LDS, sorted
 // there with a bitonic network whose compare-exchanges are all ascending (so the +inf
 // padding never moves), and written out once, sorted.  Reads with more anchors than the
 // LDS tile fall back to the same network on the read's HBM segment.
@@ -13,7 +14,6 @@
 namespace mnc {
 
 constexpr int SO_THREADS = 256;
-constexpr int SO_CAP = 2048;                       // anchors per LDS tile (32 KiB)
 
 __device__ __forceinline__ bool anchor_less(const Anchor &a, const Anchor &b)
 {
@@ -55,12 +55,16 @@ __device__ void bitonic_sort(Ptr s, int n, int tid)
 	}
 }
 
-__global__ __launch_bounds__(SO_THREADS) void mnc_expand_sort(Batch B)
+// `list`/`count` = the reads of one size class (at most NM anchors each; NM == 0: the class
+// of reads too large for LDS, sorted in their HBM segment); LDS tile = NM anchors.
+__global__ __launch_bounds__(SO_THREADS) void mnc_expand_sort(Batch B, const uint32_t *list, uint32_t count, int NM)
 {
-	__shared__ Anchor s_a[SO_CAP];
+	extern __shared__ __align__(16) uint8_t so_smem[];
+	Anchor *s_a = reinterpret_cast<Anchor*>(so_smem);
 	__shared__ int s_scan[SO_THREADS / 64];
 
-	const uint32_t r = blockIdx.x;
+	if (blockIdx.x >= count) return;
+	const uint32_t r = list[blockIdx.x];
 	const int tid = threadIdx.x;
 	const int64_t off = B.offsets[r];
 	const int qlen = (int)(B.offsets[r + 1] - off);
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(SO_THREADS) void mnc_expand_sort(Batch B)
 	const int64_t n64 = B.an_off[r + 1] - a_off;
 	if (n64 <= 0) return;
 	const int n = (int)n64;
-	const bool in_lds = n <= SO_CAP;
+	const bool in_lds = n <= NM;
 	Anchor *g = B.a + a_off;
 	const HitRec *hits = B.hits + off;
 
@@ -130,10 +134,18 @@ __global__ __launch_bounds__(SO_THREADS) void mnc_expand_sort(Batch B)
 	}
 }
 
-void launch_expand_sort(const Batch &B, hipStream_t st)
+void launch_expand_sort(const Batch &B, const uint32_t *list, uint32_t count, int NM, hipStream_t st)
 {
-	if (B.n_reads == 0) return;
-	hipLaunchKernelGGL(mnc_expand_sort, dim3(B.n_reads), dim3(SO_THREADS), 0, st, B);
+	if (count == 0) return;
+	hipLaunchKernelGGL(mnc_expand_sort, dim3(count), dim3(SO_THREADS), (size_t)NM * sizeof(Anchor), st, B, list, count, NM);
+}
+
+int expand_sort_prepare(int max_nm)
+{
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_expand_sort),
+	                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)max_nm * sizeof(Anchor)));
+	if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return MNC_ERR_HIP; }
+	return MNC_OK;
 }
 
 } // namespace mnc
