@@ -13,7 +13,7 @@
 
 namespace mnc {
 
-constexpr int SO_THREADS = 256;
+constexpr int SO_THREADS = 128;
 
 __device__ __forceinline__ bool anchor_less(const Anchor &a, const Anchor &b)
 {

@@ -167,3 +167,71 @@ def test_index_sharded_merge_equals_multi_part_reference(capi, oracle):
     assert got.tolist() == want
     assert tot.tolist() == [len(h) for h in lists]
     assert (np.array(want) >= 0).sum() > 250
+
+
+def _world_from(capi, oracle, names, seqs):
+    idx = capi.Index.from_seqs(names, seqs)
+    oidx = oracle.Index.from_seqs(names, [s.tobytes() for s in seqs])
+    eng = capi.Engine(idx, 0)
+    eng.set_debug(True)
+    return dict(names=names, seqs=seqs, idx=idx, oidx=oidx, eng=eng)
+
+
+def test_long_reads_take_the_sequential_chain_path(capi, oracle):
+    """Reads of 65 536 bases or more (and LDS-stage overflows in the partition kernel) leave
+    the half-wave chain kernel for the sequential one; results must not change."""
+    names, seqs = util.small_genomes(2, 400_000, 450_000)
+    w = _world_from(capi, oracle, names, seqs)
+    g0, g1 = seqs
+    rng = np.random.default_rng(3)
+    def noisy(a, rate=0.03):
+        a = a.copy()
+        m = rng.random(len(a)) < rate
+        a[m] = util.ACGT[rng.integers(0, 4, int(m.sum()))]
+        return a
+    reads = [g0[1000:71_000], noisy(g1[5000:155_000]), util.revcomp(noisy(g0[100_000:370_000])),
+             g0[2000:67_535], g0[2000:67_536], g1[300:5300], np.concatenate([g0[10_000:50_000], g1[10_000:50_000]])]
+    bases, offsets = util.pack_reads(reads)
+    assign, best, nhits = _compare_batch(capi, oracle, w, bases, offsets)
+    assert assign.tolist()[:6] == [0, 1, 0, 0, 0, 1]
+    assert nhits[6] == 2                                  # chimera of two contigs: two primaries
+
+
+def test_repetitive_index_gives_many_anchors(capi, oracle):
+    """Four diverged copies of one genome: most minimizers occur 2-4 times, so a read collects
+    thousands of anchors (the largest chain / sort size classes and the HBM sort fallback)."""
+    base = synth.genome(0x77, 150_000)
+    seqs = [base] + [synth.diverge(base, 0x78 + i, 3000) for i in range(3)] + [synth.genome(0x99, 120_000)]
+    names = [synth.contig_name(i) for i in range(5)]
+    w = _world_from(capi, oracle, names, seqs)
+    assert w["idx"].mid_occ >= 5
+    b, o, truth = synth.reads(seqs, 60, 6000, seed=41, sub=100, ins=50, dele=50)
+    long_one = seqs[1][10_000:50_000]
+    reads = [b[o[i]:o[i + 1]] for i in range(60)] + [long_one, seqs[4][1000:9000]]
+    bases, offsets = util.pack_reads(reads)
+    assign, best, nhits = _compare_batch(capi, oracle, w, bases, offsets, min_mapq=0)
+    c = w["eng"].counters()
+    assert c["anchors"] / len(reads) > 2500               # the regime this test is for
+    _compare_batch(capi, oracle, w, bases, offsets, min_mapq=60)
+
+
+def test_dense_sketch_overflows_the_query_budget_and_is_redone(capi, oracle, world):
+    """Low-complexity reads keep (almost) every k-mer as a minimizer: more query records than
+    the one-per-three-bases budget, so the batch is redone with exact room."""
+    reads = [np.full(4000, c, dtype=np.uint8) for c in b"ACGT"] * 6
+    reads += [np.tile(np.frombuffer(b"AC", dtype=np.uint8), 2500), np.tile(np.frombuffer(b"ACG", dtype=np.uint8), 1500)]
+    reads += [world["seqs"][0][5000:8000]]
+    bases, offsets = util.pack_reads(reads)
+    assign, best, nhits = _compare_batch(capi, oracle, world, bases, offsets)
+    assert world["eng"].counters()["minimizers"] > int(offsets[-1]) // 3
+    assert assign[-1] == 0
+    # the engine stays usable and exact afterwards
+    b2, o2, _ = synth.reads(world["seqs"], 50, 2000, seed=8)
+    _compare_batch(capi, oracle, world, b2, o2)
+
+
+def test_batch_shapes(capi, oracle, world):
+    """Batch sizes around the tile / super-tile / workgroup granularities."""
+    full, offs, _ = synth.reads(world["seqs"], 1100, 1200, seed=77)
+    for n in (1, 3, 4, 5, 63, 64, 65, 255, 256, 257, 1025):
+        _compare_batch(capi, oracle, world, full[: offs[n]], offs[: n + 1])
