@@ -158,13 +158,13 @@ int mnc_best_hit(const mnc_hit_t *hits, int n, int *best_index /* -1 = ambiguous
 #define MNC_STAGE_COLLECT     4   /* probe hits back to per-read lists                       */
 #define MNC_STAGE_SORT        5   /* anchor offsets (scan) + size classes                    */
 #define MNC_STAGE_SORT2       6   /* expand hits to anchors + sort                           */
-#define MNC_STAGE_CHAIN       7   /* chaining DP + backtrack, reads held in LDS              */
-#define MNC_STAGE_CHAIN_LARGE 8   /* sequential chaining for reads too large for LDS         */
+#define MNC_STAGE_CHAIN       7   /* chaining DP (LDS ring per read)                         */
+#define MNC_STAGE_BACKTRACK   8   /* backtrack -> chain records                              */
 #define MNC_STAGE_REGIONS     9   /* regions, MAPQ, decision, counts                         */
 #define MNC_STAGE_GATHER      10  /* gated hit lists -> CSR (mnc_engine_fetch_hits)          */
 #define MNC_N_STAGES          11
 int mnc_engine_set_profiling(mnc_engine *eng, int on);    /* HIP events around every stage */
-int mnc_engine_set_debug(mnc_engine *eng, int on);        /* keep chaining intermediates for mnc_engine_dump */
+int mnc_engine_set_debug(mnc_engine *eng, int mode);      /* 2: stress build of the chaining ring (tests)  */
 /* accumulated since the last reset: ms[MNC_N_STAGES], launches[MNC_N_STAGES] */
 int mnc_engine_get_timings(mnc_engine *eng, double *ms, int64_t *launches, int reset);
 const char *mnc_stage_name(int stage);
@@ -178,7 +178,7 @@ int mnc_engine_get_counters(mnc_engine *eng, int64_t *c, int n);
 #define MNC_DUMP_MZ_OFFSETS 2  /* int64[n_reads+1]                                              */
 #define MNC_DUMP_ANCHORS    3  /* u64 x,y pairs sorted by (x,y), per read                       */
 #define MNC_DUMP_AN_OFFSETS 4  /* int64[n_reads+1]                                              */
-#define MNC_DUMP_CHAIN_F    5  /* int32 per anchor (needs mnc_engine_set_debug)                 */
+#define MNC_DUMP_CHAIN_F    5  /* int32 per anchor                                              */
 #define MNC_DUMP_CHAIN_P    6  /* int32 per anchor (read-local index, -1 none)                  */
 #define MNC_DUMP_CHAIN_V    7  /* int32 per anchor                                              */
 #define MNC_DUMP_REGS       8  /* mnc_reg_t per region                                          */

@@ -28,7 +28,7 @@ ANCHOR_DTYPE = np.dtype([("x", "<u8"), ("y", "<u8")])
 
 N_STAGES = 11
 (STAGE_PACK, STAGE_SKETCH, STAGE_PARTITION, STAGE_PROBE, STAGE_COLLECT, STAGE_SORT, STAGE_SORT2, STAGE_CHAIN,
- STAGE_CHAIN_LARGE, STAGE_REGIONS, STAGE_GATHER) = range(N_STAGES)
+ STAGE_BACKTRACK, STAGE_REGIONS, STAGE_GATHER) = range(N_STAGES)
 (DUMP_MINIMIZERS, DUMP_MZ_OFFSETS, DUMP_ANCHORS, DUMP_AN_OFFSETS, DUMP_CHAIN_F, DUMP_CHAIN_P,
  DUMP_CHAIN_V, DUMP_REGS, DUMP_REG_OFFSETS, DUMP_REP_LEN) = range(1, 11)
 
@@ -285,8 +285,9 @@ class Engine:
     def set_profiling(self, on=True):
         check(lib().mnc_engine_set_profiling(self._h, 1 if on else 0))
 
-    def set_debug(self, on=True):
-        check(lib().mnc_engine_set_debug(self._h, 1 if on else 0))
+    def set_debug(self, mode=1):
+        """mode 2 = stress build of the chaining kernel (every look-back through HBM)."""
+        check(lib().mnc_engine_set_debug(self._h, int(mode)))
 
     def timings(self, reset=False):
         ms = np.zeros(N_STAGES, dtype=np.float64)

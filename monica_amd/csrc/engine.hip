@@ -21,15 +21,15 @@ void launch_probe(const Batch &B, hipStream_t st);
 void launch_collect(const Batch &B, hipStream_t st);
 void launch_expand_sort(const Batch &B, const uint32_t *list, uint32_t count, int NM, hipStream_t st);
 int expand_sort_prepare(int max_nm);
-void launch_chain_dp_serial(const Batch &B, const uint32_t *read_list, uint32_t n_list, hipStream_t st);
 void launch_backtrack(const Batch &B, const uint32_t *read_list, uint32_t n_list, hipStream_t st);
 void launch_bin_reads(const Batch &B, const ChainClasses &C, uint32_t *cls_count, uint32_t *cls_list, hipStream_t st);
-void launch_chain_rows(const Batch &B, const uint32_t *list, uint32_t count, int NM, int store_fp, hipStream_t st);
-size_t chain_rows_lds_bytes(int NM);
-int chain_rows_prepare(size_t max_lds);
+void launch_chain_dp_ring(const Batch &B, const uint32_t *list, uint32_t count, int stress, hipStream_t st);
+void launch_chain_tail(const Batch &B, const uint32_t *list, uint32_t count, int NM, hipStream_t st);
+size_t chain_tail_lds_bytes(int NM);
+int chain_tail_prepare(size_t max_lds);
 
-// LDS tile sizes (anchors per read) of the row chaining kernel; reads above the last one,
-// or with >= 65 536 bases, take the sequential kernels
+// LDS tile sizes (anchors per read) of the sort and backtrack kernels; reads above the last
+// one, or with >= 65 536 bases, are sorted in HBM and take the sequential backtrack
 static const ChainClasses CHAIN_CLASSES = { 18, { 64, 128, 192, 256, 320, 384, 448, 512, 576, 640, 768, 896, 1024, 1280, 1536, 1792, 2048, 2560 } };
 void launch_regions(const Batch &B, void *regx, uint64_t *k64a, uint64_t *k64b, mnc_hit_t *gated, hipStream_t st);
 void launch_gather_hits(const Batch &B, const mnc_hit_t *gated, const int64_t *hit_off, mnc_hit_t *out, hipStream_t st);
@@ -269,7 +269,7 @@ struct mnc_engine {
 	// per chain slot
 	Buf chains_tmp, regs, regx, k64a, k64b, tmp_i32, gated, hits_csr;
 	Buf stats, cls_count, cls_list;
-	bool debug = false;                      // keep stage intermediates (f, p, v) for dumps
+	int debug = 0;                           // 2: stress build of the chaining ring (tests)
 	// last batch
 	Batch B{};
 	bool have_batch = false;
@@ -283,10 +283,10 @@ struct mnc_engine {
 	int64_t launches[MNC_N_STAGES]{};
 };
 
-static const char *STAGE_NAME[MNC_N_STAGES] = { "pack", "sketch", "partition", "probe", "collect", "offsets", "sort", "chain", "chain_large", "regions", "gather" };
+static const char *STAGE_NAME[MNC_N_STAGES] = { "pack", "sketch", "partition", "probe", "collect", "offsets", "sort", "chain", "backtrack", "regions", "gather" };
 static const char *STAGE_KERNEL[MNC_N_STAGES] = {
 	"mnc_pack_bases", "mnc_sketch_minimizers", "mnc_partition_queries", "mnc_probe_buckets", "mnc_collect_hits",
-	"mnc_bin_reads", "mnc_expand_sort", "mnc_chain_rows", "mnc_chain_dp_serial", "mnc_regions_decide", "mnc_gather_hits" };
+	"mnc_bin_reads", "mnc_expand_sort", "mnc_chain_dp_ring", "mnc_chain_tail", "mnc_regions_decide", "mnc_gather_hits" };
 
 extern "C" const char *mnc_stage_name(int s) { return s >= 0 && s < MNC_N_STAGES ? STAGE_NAME[s] : nullptr; }
 extern "C" const char *mnc_stage_kernel(int s) { return s >= 0 && s < MNC_N_STAGES ? STAGE_KERNEL[s] : nullptr; }
@@ -358,7 +358,7 @@ extern "C" int mnc_engine_create(mnc_index *idx, int device, mnc_engine **out)
 	if (!rc) rc = e->logf_lut.ensure((size_t)e->logf_n * 4);
 	if (!rc) rc = e->stats.ensure(16 * 8);
 	if (!rc) rc = e->cls_count.ensure((MAX_CHAIN_CLASSES + 1) * 4 + 64);
-	if (!rc) rc = chain_rows_prepare(chain_rows_lds_bytes(CHAIN_CLASSES.nm[CHAIN_CLASSES.n - 1]));
+	if (!rc) rc = chain_tail_prepare(chain_tail_lds_bytes(CHAIN_CLASSES.nm[CHAIN_CLASSES.n - 1]));
 	if (!rc) rc = expand_sort_prepare(CHAIN_CLASSES.nm[CHAIN_CLASSES.n - 1]);
 	if (!rc) {
 		he = hipMemcpy(e->gap_lut.p, gap.data(), GAP_LUT * 4, hipMemcpyHostToDevice);
@@ -399,7 +399,7 @@ extern "C" int mnc_engine_set_profiling(mnc_engine *e, int on)
 extern "C" int mnc_engine_set_debug(mnc_engine *e, int on)
 {
 	if (!e) return MNC_ERR_ARG;
-	e->debug = on != 0;
+	e->debug = on;
 	return MNC_OK;
 }
 
@@ -539,16 +539,17 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 			launch_expand_sort(B, lists + (size_t)c * n_reads, cls_count[c], c < CHAIN_CLASSES.n ? CHAIN_CLASSES.nm[c] : 0, st);
 	}
 	{
-		StageTimer t(e, MNC_STAGE_CHAIN);
+		StageTimer t(e, MNC_STAGE_CHAIN);           // DP: every read, whatever its size
 		const uint32_t *lists = e->cls_list.as<uint32_t>();
-		for (int c = 0; c < CHAIN_CLASSES.n; ++c)
-			launch_chain_rows(B, lists + (size_t)c * n_reads, cls_count[c], CHAIN_CLASSES.nm[c], e->debug ? 1 : 0, st);
+		for (int c = 0; c <= CHAIN_CLASSES.n; ++c)
+			launch_chain_dp_ring(B, lists + (size_t)c * n_reads, cls_count[c], e->debug == 2, st);
 	}
 	{
-		StageTimer t(e, MNC_STAGE_CHAIN_LARGE);     // reads too large for the LDS tiles
-		const uint32_t *large = e->cls_list.as<uint32_t>() + (size_t)CHAIN_CLASSES.n * n_reads;
-		launch_chain_dp_serial(B, large, cls_count[CHAIN_CLASSES.n], st);
-		launch_backtrack(B, large, cls_count[CHAIN_CLASSES.n], st);
+		StageTimer t(e, MNC_STAGE_BACKTRACK);       // LDS form per size class; sequential form beyond
+		const uint32_t *lists = e->cls_list.as<uint32_t>();
+		for (int c = 0; c < CHAIN_CLASSES.n; ++c)
+			launch_chain_tail(B, lists + (size_t)c * n_reads, cls_count[c], CHAIN_CLASSES.nm[c], st);
+		launch_backtrack(B, lists + (size_t)CHAIN_CLASSES.n * n_reads, cls_count[CHAIN_CLASSES.n], st);
 	}
 	{ StageTimer t(e, MNC_STAGE_REGIONS);   launch_regions(B, e->regx.p, e->k64a.as<uint64_t>(), e->k64b.as<uint64_t>(), e->gated.as<mnc_hit_t>(), st); }
 	HIP_TRY(hipGetLastError());

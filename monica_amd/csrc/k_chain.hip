@@ -1,4 +1,5 @@
-// Stage kernels K4 (chaining DP) and K5 (backtrack -> chains) -- gfx950.
+// Stage kernel K5, sequential form (backtrack -> chains for reads too large for the LDS
+// classes of k_chain_ring.hip) and the size-class binning -- gfx950.
 //
 // Replaces mm_chain_dp() inside index.map(seq) (monica/genomes/aligner.py:193,215;
 // SURVEY.md Appendix A.5).  All arithmetic is integer: the one floating-point term of the
@@ -6,51 +7,6 @@
 #include "device.h"
 
 namespace mnc {
-
-// ================================================================ K4, form 1: one thread per read
-// Straight sequential evaluation; used as the in-library cross-check of the wave kernel
-// and for reads whose anchor count exceeds what the wave kernel keeps in LDS.
-__global__ __launch_bounds__(64) void mnc_chain_dp_serial(Batch B, const uint32_t *read_list, uint32_t n_list)
-{
-	const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
-	if (li >= n_list) return;
-	const uint32_t r = read_list ? read_list[li] : li;
-	const int64_t a_off = B.an_off[r];
-	const int n = (int)(B.an_off[r + 1] - a_off);
-	if (n <= 0) return;
-	const Anchor *a = B.a + a_off;
-	int32_t *f = B.f + a_off, *p = B.p + a_off, *v = B.v + a_off, *t = B.t + a_off;
-	const uint64_t max_dist = (uint64_t)B.max_gap;
-	for (int i = 0; i < n; ++i) t[i] = 0;
-	int st = 0;
-	for (int i = 0; i < n; ++i) {
-		const uint64_t ri = a[i].x;
-		const int32_t qi = (int32_t)a[i].y, q_span = (int32_t)(a[i].y >> 32 & 0xff);
-		int32_t max_f = q_span, max_j = -1, n_skip = 0;
-		while (st < i && ri > a[st].x + max_dist) ++st;
-		if (i - st > B.max_iter) st = i - B.max_iter;
-		for (int j = i - 1; j >= st; --j) {
-			const int64_t dr = (int64_t)(ri - a[j].x);
-			const int32_t dq = qi - (int32_t)a[j].y;
-			if (dr == 0 || dq <= 0 || dq > B.max_gap) continue;
-			const int32_t dd = dr > dq ? (int32_t)(dr - dq) : (int32_t)(dq - dr);
-			if (dd > B.bw) continue;
-			const int32_t min_d = dq < dr ? dq : (int32_t)dr;
-			int32_t sc = min_d > q_span ? q_span : min_d;
-			sc -= B.gap_lut[dd];
-			sc += f[j];
-			if (sc > max_f) {
-				max_f = sc, max_j = j;
-				if (n_skip > 0) --n_skip;
-			} else if (t[j] == i) {
-				if (++n_skip > B.max_skip) break;
-			}
-			if (p[j] >= 0) t[p[j]] = i;
-		}
-		f[i] = max_f, p[i] = max_j;
-		v[i] = max_j >= 0 && v[max_j] > max_f ? v[max_j] : max_f;
-	}
-}
 
 // ================================================================ K5: backtrack
 __device__ void heapsort_u64(uint64_t *a, int n)
@@ -150,12 +106,6 @@ __global__ __launch_bounds__(64) void mnc_chain_backtrack(Batch B, const uint32_
 		} else n_v = n_v0;
 	}
 	B.n_chain[r] = k;
-}
-
-void launch_chain_dp_serial(const Batch &B, const uint32_t *read_list, uint32_t n_list, hipStream_t st)
-{
-	if (n_list == 0) return;
-	hipLaunchKernelGGL(mnc_chain_dp_serial, dim3((n_list + 63) / 64), dim3(64), 0, st, B, read_list, n_list);
 }
 
 void launch_backtrack(const Batch &B, const uint32_t *read_list, uint32_t n_list, hipStream_t st)

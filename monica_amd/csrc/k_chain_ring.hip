@@ -1,30 +1,37 @@
-// Stage kernel K4+K5, row form: chaining DP and backtrack with the anchors of a read held in
-// LDS -- gfx950.
+// Stage kernels K4 (chaining DP, ring form) and K5 (backtrack, LDS form) -- gfx950.
 //
 // Replaces mm_chain_dp() inside index.map(seq) (monica/genomes/aligner.py:193,215; SURVEY.md
-// Appendix A.5) for reads with at most 4096 anchors and fewer than 65 536 bases; longer
-// reads take the sequential kernels of k_chain.hip.
+// Appendix A.5).
 //
-// Mapping.  One wave = two half-waves of 32 lanes = two reads.  A half-wave evaluates 32
+// K4 mapping.  One wave = two half-waves of 32 lanes = two reads.  A half-wave evaluates 32
 // candidate predecessors j = jb, jb-1, ... of its current anchor i per step; a chain anchor
 // needs about 27 candidates before minimap2's max_skip rule stops the scan, i.e. one step.
-// The order-dependent parts of the sequential loop are reproduced exactly with scans over
-// the half-wave (DPP row_shr inside a 16-lane row, row_bcast:15 into the upper row):
+// The order-dependent parts of the sequential loop are reproduced exactly with scans over the
+// half-wave (DPP row_shr inside a 16-lane row, row_bcast:15 into the upper row):
 //   * running maximum (strict '>' updates)      -> exclusive prefix-max
 //   * n_skip (decrement-with-floor / increment) -> prefix sum + prefix max (see below)
 //   * break at the first lane where n_skip > max_skip, argmax = first lane at the maximum
 // The two halves advance independently (no lock-step over i).
 //
-// LDS per anchor, 14 bytes: one 64-bit word {p:16, f:16, t:16, v:16}, the low 32 bits of the
-// reference coordinate, the 16-bit query position.  t[] holds the "seen for anchor i" stamp
-// of the skip rule; v[] the peak score along the chain.  Scores fit 16 bits because a chain
-// score never exceeds the read length.
+// K4 memory.  The DP only ever looks a short way back, so a read keeps just a RING of its
+// anchors in LDS: blocks of 32, the block being filled, PAST completed blocks behind it and
+// the prefetched next block (128 entries x 24 bytes with PAST = 2).  A completed block's f/p/v
+// go to HBM at once (coalesced); a block's skip-rule stamps t[] follow when it is evicted.
+// The rare candidate or stamp that lies behind the ring is read / written in HBM instead, so
+// there is no limit on anchors per read and LDS no longer caps occupancy.  (The first form of
+// this kernel held all anchors of a read in LDS: 2.75 waves/SIMD, 8.2 ms; profiles/README.md.)
+//
+// K5.  The backtrack needs random access to a whole read, so it is its own kernel with the
+// read's {p, f, v, mark} + coordinates in LDS (14 bytes per anchor, size classes), two reads
+// per wave: chain ends found in parallel and rank-sorted in LDS, best-first walk by the half's
+// first lane, one 56-byte record per chain.  Reads beyond the largest class take the
+// sequential mnc_chain_backtrack of k_chain.hip.
 #include "device.h"
 
 namespace mnc {
 
 constexpr int ROWS = 2;                       // reads per wave
-constexpr int RW = 64 / ROWS;                 // lanes per read
+constexpr int RW = 64 / ROWS;                 // lanes per read = ring block size
 constexpr uint32_t NONE16 = 0xffffu;
 constexpr int NEG = -(1 << 24);
 #ifndef INT32_MIN
@@ -86,81 +93,101 @@ __device__ __forceinline__ void lds_order()
 	asm volatile("" ::: "memory");
 }
 
-// ---------------------------------------------------------------- the kernel
-// word layout: bits 0-15 p, 16-31 f, 32-47 t, 48-63 v
-__global__ __launch_bounds__(64) void mnc_chain_rows(Batch B, const uint32_t *list, uint32_t count, int NM, int store_fp)
-{
-	extern __shared__ __align__(16) uint8_t smem[];
-	const int lane = threadIdx.x, row = lane / RW, lr = lane % RW;
-	uint8_t *rbase = smem + (size_t)row * ((size_t)NM * 14 + 64 * 8);
-	uint64_t *W = reinterpret_cast<uint64_t*>(rbase);                  // NM words
-	uint32_t *xlo = reinterpret_cast<uint32_t*>(rbase + (size_t)NM * 8);
-	uint16_t *qp = reinterpret_cast<uint16_t*>(rbase + (size_t)NM * 12);
-	uint64_t *ubuf = reinterpret_cast<uint64_t*>(rbase + (size_t)NM * 14);   // 64 chain-end keys
-	uint16_t *W16 = reinterpret_cast<uint16_t*>(W);
-	uint32_t *W32 = reinterpret_cast<uint32_t*>(W);
+// ================================================================ K4: DP over a ring
+// PAST = completed blocks kept behind the current one (2 in production; 0 in the stress build
+// the tests use to drive every look-back through the HBM fall-back).
+constexpr int DP_WAVES = 4;                   // waves per workgroup (no workgroup barrier is used)
 
-	const uint32_t li = blockIdx.x * ROWS + row;
+template <int PAST>
+__global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, const uint32_t *list, uint32_t count)
+{
+	constexpr int NBLK = PAST + 2;                                       // past + current + next
+	constexpr int RING = NBLK * RW;
+	__shared__ int2 s_pf_all[ROWS * DP_WAVES][RING];                     // {p, f}; p = -2 marks a segment start until set
+	__shared__ int2 s_xq_all[ROWS * DP_WAVES][RING];                     // {low 32 bits of x, query position}
+	__shared__ int32_t s_t_all[ROWS * DP_WAVES][RING], s_v_all[ROWS * DP_WAVES][RING];
+	const int lane = threadIdx.x & 63, row = lane / RW, lr = lane % RW;
+	const int slot_row = (threadIdx.x >> 6) * ROWS + row;
+	int2 *s_pf = s_pf_all[slot_row], *s_xq = s_xq_all[slot_row];
+	int32_t *s_t = s_t_all[slot_row], *s_v = s_v_all[slot_row];
+
+	const uint32_t li = blockIdx.x * (ROWS * DP_WAVES) + slot_row;
 	const bool has = li < count;
 	const uint32_t r = has ? list[li] : 0;
 	const int64_t a_off = has ? B.an_off[r] : 0;
 	const int n = has ? (int)(B.an_off[r + 1] - a_off) : 0;
 	const Anchor *ga = B.a + a_off;
+	int32_t *gf = B.f + a_off, *gp = B.p + a_off, *gv = B.v + a_off, *gt = B.t + a_off;
 	const int span = KMER;
 	const int max_gap = B.max_gap, bw = B.bw, max_skip = B.max_skip, max_iter = B.max_iter;
 	const double avg_span = (double)(float)KMER;
 
-	// ---- load: low coordinate, query position, segment-start flag (kept in f until f[i] is set)
-	for (int idx = lr; idx < n; idx += RW) {
-		const Anchor e = ga[idx];
-		const uint32_t hi = (uint32_t)(e.x >> 32);
-		const uint32_t phi = idx ? (uint32_t)(ga[idx - 1].x >> 32) : ~hi;
-		xlo[idx] = (uint32_t)e.x;
-		qp[idx] = (uint16_t)e.y;
-		W[idx] = (uint64_t)NONE16 | (uint64_t)(hi != phi ? 1u : 0u) << 16;
-	}
+	// block b of the read -> its ring slots: coordinates, segment-start flag, cleared DP fields
+	auto load_block = [&](int b) {
+		const int idx = b * RW + lr;
+		if (idx < n) {
+			const Anchor e = ga[idx];
+			const uint32_t hi = (uint32_t)(e.x >> 32);
+			const uint32_t phi = idx ? (uint32_t)(ga[idx - 1].x >> 32) : ~hi;
+			const int s = idx % RING;
+			s_xq[s] = make_int2((int)(uint32_t)e.x, (int)(uint32_t)e.y);
+			s_pf[s] = make_int2(hi != phi ? -2 : -1, 0);
+			s_t[s] = 0, s_v[s] = 0;
+		}
+	};
+	load_block(0);
+	load_block(1);
 	lds_order();
 
-	// ---- DP: every row walks its own i.  Row-uniform state lives in VGPRs.
+	// ---- DP: every half walks its own i.  Half-uniform state lives in VGPRs.
 	// The predecessor window of anchor i is { j < i : same (strand, contig) segment,
 	// x_i - x_j <= max_gap, i - j <= max_iter }: contiguous because anchors are sorted, so it
 	// is tested per lane instead of keeping minimap2's running start index.
 	bool active = n > 0, fresh = true;
-	int i = 0, seg = 0, jb = -1, max_f = span, max_j = -1, ns_prev = 0;
-	uint32_t xi = active ? xlo[0] : 0;
-	int qi = active ? (int)qp[0] : 0;
-	int pend_i = -1, pend_f = 0;
-	uint32_t pend_vp = 0;
+	int i = 0, seg = 0, jb = -1, max_f = span, max_j = -1, ns_prev = 0, ring_lo = 0;
+	uint32_t xi = active ? (uint32_t)s_xq[0].x : 0;
+	int qi = active ? s_xq[0].y : 0;
+	int pend_i = -1, pend_f = 0, pend_vp = 0;
 	while (__any(active)) {
 		// ---- one step: RW candidates j = jb - lr
 		const int j = jb - lr;
 		const int lo = max(seg, i - max_iter);
 		const bool inb = active && j >= lo;
-		const int jc = inb ? j : 0;
-		const uint64_t w = W[jc];
-		const uint32_t xj = xlo[jc];
-		const int qj = (int)qp[jc];
+		const bool far = inb && j < ring_lo;                              // behind the ring: HBM
+		const int sj = (inb ? j : 0) % RING;
+		int2 pf = s_pf[sj], xq = s_xq[sj];
+		if (far) {
+			const Anchor e = ga[j];
+			pf = make_int2(gp[j], gf[j]);
+			xq = make_int2((int)(uint32_t)e.x, (int)(uint32_t)e.y);
+		}
 		// operands of the next anchor, fetched early (used when this anchor completes)
-		const int inext = min(i + 1, NM - 1);
-		const uint32_t nxi = xlo[inext];
-		const int nqi = (int)qp[inext];
-		const uint32_t nflag = (W32[2 * inext] >> 16) & 1u;
+		const int sn = (i + 1) % RING;
+		const int2 nxq = s_xq[sn];
+		const int nflag = s_pf[sn].x;
 
-		const uint32_t pj = (uint32_t)w & 0xffffu;
-		const int fj = (int)((uint32_t)w >> 16);
-		const uint32_t dru = xi - xj;
+		const int pj = pf.x, fj = pf.y;
+		const uint32_t dru = xi - (uint32_t)xq.x;
 		const bool inwin = inb && dru <= (uint32_t)max_gap;
 		const int dr = (int)dru;
-		const int dq = qi - qj;
+		const int dq = qi - xq.y;
 		const int dd = dr > dq ? dr - dq : dq - dr;
 		const bool ev = inwin && dr != 0 && dq > 0 && dq <= max_gap && dd <= bw;
 		const int mind = dq < dr ? dq : dr;
 		// gap cost (int)(dd * .01 * avg_span) + (ilog2(dd) >> 1): IEEE double products, as minimap2
 		const int gap = (int)((double)dd * .01 * avg_span) + (dd > 0 ? (31 - __clz(dd)) >> 1 : 0);
 		const int sc = ev ? (mind > span ? span : mind) - gap + fj : NEG;
-		if (ev && pj != NONE16) W16[4 * pj + 2] = (uint16_t)i;         // t[p[j]] = i
+		// t[p[j]] = i, then t[j] == i
+		const bool mark = ev && pj >= 0;
+		const bool mark_far = mark && pj < ring_lo;
+		if (mark && !mark_far) s_t[pj % RING] = i;
+		if (mark_far) gt[pj] = i;
+		const bool any_far = __any(far || mark_far);
+		if (any_far) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		lds_order();
-		const bool tflag = ev && W16[4 * jc + 2] == (uint16_t)i;       // t[j] == i
+		int tj = s_t[sj];
+		if (far) tj = gt[j];
+		const bool tflag = ev && tj == i;
 		// running maximum: strict '>' against everything before this lane
 		const int incl = row_incl_max(sc);
 		const int excl = max(row_shift1(incl, NEG, lr), max_f);
@@ -169,7 +196,6 @@ __global__ __launch_bounds__(64) void mnc_chain_rows(Batch B, const uint32_t *li
 		// (+1,-inf) on a seen non-improvement, identity otherwise; with S = prefix sum of a,
 		// the value is max(S, S + max_{k<=l, improve_k}(-S_k)).  The carry enters at lane 0.
 		int a = improve ? -1 : (tflag ? 1 : 0);
-		// carry: n_skip after the last lane of the previous step of this anchor
 		const int c0 = __builtin_amdgcn_readlane(ns_prev, RW - 1), c1 = __builtin_amdgcn_readlane(ns_prev, 2 * RW - 1);
 		if (lr == 0 && !fresh) a += row ? c1 : c0;
 		const int S = row_incl_add(a);
@@ -187,36 +213,78 @@ __global__ __launch_bounds__(64) void mnc_chain_rows(Batch B, const uint32_t *li
 		if (done) {
 			if (lr == 0) {
 				// v[] of the previous anchor completes now (its operand was fetched a step ago)
-				if (pend_i >= 0) W16[4 * pend_i + 3] = (uint16_t)max((uint32_t)pend_f, pend_vp);
-				W32[2 * i] = (max_j >= 0 ? (uint32_t)max_j : NONE16) | (uint32_t)max_f << 16;
+				if (pend_i >= 0) s_v[pend_i % RING] = max(pend_f, pend_vp);
+				s_pf[i % RING] = make_int2(max_j, max_f);
 				lds_order();
-				pend_vp = max_j >= 0 ? (uint32_t)W16[4 * max_j + 3] : 0u;
+				pend_vp = max_j < 0 ? 0 : max_j >= ring_lo ? s_v[max_j % RING] : gv[max_j];
 				pend_i = i, pend_f = max_f;
 			}
 			++i;
 			if (i >= n) active = false;
-			xi = nxi, qi = nqi;
-			if (nflag) seg = i;
+			xi = (uint32_t)nxq.x, qi = nxq.y;
+			if (nflag == -2) seg = i;
 			jb = i - 1, max_f = span, max_j = -1, fresh = true;
+			if (active && i % RW == 0) {                                  // entering block nb
+				const int nb = i / RW;
+				if (lr == 0) { s_v[pend_i % RING] = max(pend_f, pend_vp); pend_i = -1; }
+				lds_order();
+				const int fi = (nb - 1) * RW + lr, fs = fi % RING;        // the block just completed -> HBM
+				const int2 w = s_pf[fs];
+				gf[fi] = w.y, gp[fi] = w.x, gv[fi] = s_v[fs];
+				const int ob = nb - PAST - 1;                             // block about to lose its slots
+				if (ob >= 0) gt[ob * RW + lr] = s_t[(ob * RW + lr) % RING];
+				lds_order();
+				load_block(nb + 1);
+				ring_lo = max(0, nb - PAST) * RW;
+			}
 		} else if (active) jb -= RW;
 		lds_order();
 	}
-	if (lr == 0 && pend_i >= 0) W16[4 * pend_i + 3] = (uint16_t)max((uint32_t)pend_f, pend_vp);
+	if (lr == 0 && pend_i >= 0) s_v[pend_i % RING] = max(pend_f, pend_vp);
 	lds_order();
-
-	if (store_fp) {                                                  // stage dumps for the parity tests
-		for (int idx = lr; idx < n; idx += RW) {
-			const uint64_t w = W[idx];
-			const uint32_t p = (uint32_t)w & 0xffffu;
-			B.f[a_off + idx] = (int32_t)((uint32_t)w >> 16);
-			B.p[a_off + idx] = p == NONE16 ? -1 : (int32_t)p;
-			B.v[a_off + idx] = (int32_t)(w >> 48);
+	if (n > 0) {                                                         // the last (partial) block
+		const int fi = (n - 1) / RW * RW + lr;
+		if (fi < n) {
+			const int fs = fi % RING;
+			const int2 w = s_pf[fs];
+			gf[fi] = w.y, gp[fi] = w.x, gv[fi] = s_v[fs];
 		}
 	}
+}
 
-	// ---- backtrack.  (A) which anchors are somebody's predecessor
-	for (int idx = lr; idx < n; idx += RW) W16[4 * idx + 2] = 0;
+// ================================================================ K5: backtrack in LDS
+// word layout: bits 0-15 p, 16-31 f, 32-47 mark, 48-63 v
+__global__ __launch_bounds__(64) void mnc_chain_tail(Batch B, const uint32_t *list, uint32_t count, int NM)
+{
+	extern __shared__ __align__(16) uint8_t smem[];
+	const int lane = threadIdx.x, row = lane / RW, lr = lane % RW;
+	uint8_t *rbase = smem + (size_t)row * ((size_t)NM * 14 + 64 * 8);
+	uint64_t *W = reinterpret_cast<uint64_t*>(rbase);                  // NM words
+	uint32_t *xlo = reinterpret_cast<uint32_t*>(rbase + (size_t)NM * 8);
+	uint16_t *qp = reinterpret_cast<uint16_t*>(rbase + (size_t)NM * 12);
+	uint64_t *ubuf = reinterpret_cast<uint64_t*>(rbase + (size_t)NM * 14);   // 64 chain-end keys
+	uint16_t *W16 = reinterpret_cast<uint16_t*>(W);
+
+	const uint32_t li = blockIdx.x * ROWS + row;
+	const bool has = li < count;
+	const uint32_t r = has ? list[li] : 0;
+	const int64_t a_off = has ? B.an_off[r] : 0;
+	const int n = has ? (int)(B.an_off[r + 1] - a_off) : 0;
+	const Anchor *ga = B.a + a_off;
+	const int span = KMER;
+
+	// ---- load the DP result of the read
+	for (int idx = lr; idx < n; idx += RW) {
+		const Anchor e = ga[idx];
+		const int p = B.p[a_off + idx];
+		xlo[idx] = (uint32_t)e.x;
+		qp[idx] = (uint16_t)e.y;
+		W[idx] = (uint64_t)(p < 0 ? NONE16 : (uint32_t)p) | (uint64_t)(uint32_t)B.f[a_off + idx] << 16 |
+		         (uint64_t)(uint32_t)B.v[a_off + idx] << 48;
+	}
 	lds_order();
+
+	// (A) which anchors are somebody's predecessor
 	for (int idx = lr; idx < n; idx += RW) {
 		const uint32_t p = (uint32_t)W[idx] & 0xffffu;
 		if (p != NONE16) W16[4 * p + 2] = 1;
@@ -256,21 +324,21 @@ __global__ __launch_bounds__(64) void mnc_chain_rows(Batch B, const uint32_t *li
 	// (C) order the ends: score descending, then index descending (keys are distinct)
 	const bool u_in_lds = n_u <= 64;
 	if (u_in_lds) {
-		uint64_t mine[4];
-		int rank[4];
+		uint64_t mine[2];
+		int rank[2];
 #pragma unroll
-		for (int s = 0; s < 4; ++s) {
+		for (int s = 0; s < 2; ++s) {
 			const int e = lr + RW * s;
 			mine[s] = e < n_u ? ubuf[e] : 0, rank[s] = 0;
 		}
 		for (int k = 0; k < n_u; ++k) {
 			const uint64_t o = ubuf[k];
 #pragma unroll
-			for (int s = 0; s < 4; ++s) rank[s] += o > mine[s];
+			for (int s = 0; s < 2; ++s) rank[s] += o > mine[s];
 		}
 		lds_order();
 #pragma unroll
-		for (int s = 0; s < 4; ++s) if (lr + RW * s < n_u) ubuf[rank[s]] = mine[s];
+		for (int s = 0; s < 2; ++s) if (lr + RW * s < n_u) ubuf[rank[s]] = mine[s];
 	} else if (lr == 0 && n_u > 0) {
 		// rare: many chain ends; heap-sort ascending in HBM and read it backwards below
 		for (int start = n_u / 2 - 1; start >= 0; --start) {
@@ -297,10 +365,10 @@ __global__ __launch_bounds__(64) void mnc_chain_rows(Batch B, const uint32_t *li
 			}
 		}
 	}
-	// (D) clear the "used" marks
+	// (D) clear the marks: from here on they mean "used by a chain"
 	for (int idx = lr; idx < n; idx += RW) W16[4 * idx + 2] = 0;
 	lds_order();
-	// (E) best-first backtrack by the row's first lane; chain records in backtrack order
+	// (E) best-first backtrack by the half's first lane; chain records in backtrack order
 	if (lr == 0 && has) {
 		ChainRec *out = B.chains_tmp + a_off / 3;
 		int k = 0;
@@ -343,22 +411,30 @@ __global__ __launch_bounds__(64) void mnc_chain_rows(Batch B, const uint32_t *li
 	}
 }
 
-int chain_rows_prepare(size_t max_lds)
+int chain_tail_prepare(size_t max_lds)
 {
 	// dynamic LDS above 64 KiB has to be opted into once per function
-	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_chain_rows),
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_chain_tail),
 	                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
 	if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return MNC_ERR_HIP; }
 	return MNC_OK;
 }
 
-size_t chain_rows_lds_bytes(int NM) { return (size_t)ROWS * ((size_t)NM * 14 + 64 * 8); }
+size_t chain_tail_lds_bytes(int NM) { return (size_t)ROWS * ((size_t)NM * 14 + 64 * 8); }
 
-void launch_chain_rows(const Batch &B, const uint32_t *list, uint32_t count, int NM, int store_fp, hipStream_t st)
+void launch_chain_dp_ring(const Batch &B, const uint32_t *list, uint32_t count, int stress, hipStream_t st)
+{
+	if (count == 0) return;
+	const unsigned per = ROWS * DP_WAVES, blocks = (count + per - 1) / per;
+	if (stress) hipLaunchKernelGGL(mnc_chain_dp_ring<0>, dim3(blocks), dim3(64 * DP_WAVES), 0, st, B, list, count);
+	else hipLaunchKernelGGL(mnc_chain_dp_ring<2>, dim3(blocks), dim3(64 * DP_WAVES), 0, st, B, list, count);
+}
+
+void launch_chain_tail(const Batch &B, const uint32_t *list, uint32_t count, int NM, hipStream_t st)
 {
 	if (count == 0) return;
 	const unsigned blocks = (count + ROWS - 1) / ROWS;
-	hipLaunchKernelGGL(mnc_chain_rows, dim3(blocks), dim3(64), chain_rows_lds_bytes(NM), st, B, list, count, NM, store_fp);
+	hipLaunchKernelGGL(mnc_chain_tail, dim3(blocks), dim3(64), chain_tail_lds_bytes(NM), st, B, list, count, NM);
 }
 
 } // namespace mnc

@@ -17,7 +17,6 @@ def world(capi, oracle):
     idx = capi.Index.from_seqs(names, seqs)
     oidx = oracle.Index.from_seqs(names, [s.tobytes() for s in seqs])
     eng = capi.Engine(idx, 0)
-    eng.set_debug(True)
     return dict(names=names, seqs=seqs, idx=idx, oidx=oidx, eng=eng)
 
 
@@ -173,7 +172,6 @@ def _world_from(capi, oracle, names, seqs):
     idx = capi.Index.from_seqs(names, seqs)
     oidx = oracle.Index.from_seqs(names, [s.tobytes() for s in seqs])
     eng = capi.Engine(idx, 0)
-    eng.set_debug(True)
     return dict(names=names, seqs=seqs, idx=idx, oidx=oidx, eng=eng)
 
 
@@ -213,6 +211,9 @@ def test_repetitive_index_gives_many_anchors(capi, oracle):
     c = w["eng"].counters()
     assert c["anchors"] / len(reads) > 2500               # the regime this test is for
     _compare_batch(capi, oracle, w, bases, offsets, min_mapq=60)
+    w["eng"].set_debug(2)                                 # and with every look-back through HBM
+    _compare_batch(capi, oracle, w, bases, offsets, min_mapq=0)
+    w["eng"].set_debug(0)
 
 
 def test_dense_sketch_overflows_the_query_budget_and_is_redone(capi, oracle, world):
@@ -235,3 +236,20 @@ def test_batch_shapes(capi, oracle, world):
     full, offs, _ = synth.reads(world["seqs"], 1100, 1200, seed=77)
     for n in (1, 3, 4, 5, 63, 64, 65, 255, 256, 257, 1025):
         _compare_batch(capi, oracle, world, full[: offs[n]], offs[: n + 1])
+
+
+def test_chain_ring_stress_build(capi, oracle, world):
+    """The chaining kernel keeps only a ring of recent anchors in LDS and reads anything older
+    from HBM.  The stress build (no completed block kept in the ring) sends every look-back
+    through that fall-back; results must stay bit-identical."""
+    eng = world["eng"]
+    bases, offsets, truth = synth.reads(world["seqs"], 300, 5000, seed=0x5EED + 9)
+    extra = util.edge_reads(world["seqs"], np.random.default_rng(2))
+    eb, eo = util.pack_reads([bases[offsets[i]:offsets[i + 1]] for i in range(300)] + extra)
+    try:
+        eng.set_debug(2)
+        _compare_batch(capi, oracle, world, eb, eo)
+        _compare_batch(capi, oracle, world, eb, eo, min_mapq=0)
+    finally:
+        eng.set_debug(0)
+    _compare_batch(capi, oracle, world, eb, eo)
