@@ -42,8 +42,12 @@ def parse():
     ap.add_argument("--max-len", type=int, default=7_000_000)
     ap.add_argument("--min-mapq", type=int, default=60)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1 auto, 0 off)")
-    ap.add_argument("--mode", choices=["batch", "stream"], default="batch",
-                    help="batch: the headline metric; stream: BASELINE config 5 (400 reads/s arrival, 1-s micro-batches)")
+    ap.add_argument("--mode", choices=["batch", "stream", "shard", "files"], default="batch",
+                    help="batch: the headline metric; stream: BASELINE config 5 (400 reads/s arrival, 1-s "
+                         "micro-batches); shard: config 4 (index parts spread over the ranks, every part sees "
+                         "all reads, summaries all-gathered and merged); files: the Python aligner API end to "
+                         "end on FASTQ files (parse, H2D, kernels, D2H, routed FASTQ output)")
+    ap.add_argument("--parts", type=int, default=8, help="index parts in --mode shard")
     ap.add_argument("--stream-seconds", type=int, default=1800)
     ap.add_argument("--stream-rate", type=int, default=400)
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "probe_traffic.json"),
@@ -74,6 +78,10 @@ def main():
     # ---------------------------------------------------------------- workload (deterministic)
     t0 = time.time()
     names, seqs = synth.genome_set(args.genomes, min_len=args.min_len, max_len=args.max_len)
+    if args.mode == "shard":
+        return shard_mode(args, names, seqs, rank, local_rank, world, dev)
+    if args.mode == "files":
+        return files_mode(args, names, seqs, local_rank)
     index = _capi.Index.from_seqs(names, seqs)
     info = index.info()
     bases, offsets, truth = synth.reads(seqs, args.reads, args.read_len, seed=synth.SEED_READS + 2,
@@ -250,6 +258,133 @@ def stream_mode(args, engine, index, seqs, synth):
         "arrival_reads_per_s": rate, "sustained_reads_per_s": round(total / wall, 1),
         "real_time_factor": round(total / wall / rate, 1), "mapped_fraction": round(mapped / total, 4),
         "path": "host buffers -> mnc_classify_batch (H2D + kernels + D2H), 1 MI355X", "data": "synthetic"}))
+
+
+def shard_mode(args, names, seqs, rank, local_rank, world, dev):
+    """BASELINE config 4: the genomes are split into `--parts` index parts, spread round-robin
+    over the ranks; every part classifies ALL reads (MAPQ and the gate are per part, as in the
+    reference's multi-part loop, aligner.py:91-103), and the per-read summaries {hits, nm, mlen,
+    contig, tied} are all-gathered (20 B per read and part, RCCL) and reduced with best_hit's
+    rule on every rank.  A genome and its diverged copy sit in different parts, so the merge
+    decides real ties."""
+    import torch
+    import torch.distributed as dist
+    from monica_amd import _capi, synth
+    from monica_amd import dist as mdist
+
+    t0 = time.time()
+    P, G = args.parts, len(names)
+    if P % world:
+        raise SystemExit(f"--parts {P} must be a multiple of the number of ranks {world}")
+    bounds = [mdist.shard_bounds(G, p, P) for p in range(P)]
+    mine = [p for p in range(P) if p % world == rank]
+    parts = []
+    for p in mine:
+        lo, hi = bounds[p]
+        idx = _capi.Index.from_seqs(names[lo:hi], seqs[lo:hi])
+        parts.append((lo, idx, _capi.Engine(idx, local_rank)))
+    bases, offsets, truth = synth.reads(seqs, args.reads, args.read_len, seed=synth.SEED_READS + 4)
+    n = args.reads
+    d_bases, d_off = torch.from_numpy(bases).to(dev), torch.from_numpy(offsets).to(dev)
+    d_assign = torch.empty(n, dtype=torch.int32, device=dev)
+    d_best = torch.zeros(n * 4, dtype=torch.int32, device=dev)
+    d_nhits = torch.zeros(n, dtype=torch.int32, device=dev)
+    total_bases = int(offsets[-1])
+    t_setup = time.time() - t0
+    result = {}
+
+    def step():
+        local = []
+        for lo, idx, eng in parts:
+            torch.cuda.current_stream().synchronize()
+            eng.classify_device(d_bases.data_ptr(), d_off.data_ptr(), n, total_bases, args.read_len, args.min_mapq,
+                                d_assign.data_ptr(), d_best.data_ptr(), d_nhits.data_ptr(), 0)
+            eng.sync()
+            local.append(mdist.shard_summary(d_assign, d_best, d_nhits, rid_offset=lo))
+        stacked = torch.stack(local)                                  # [local parts, n, 5]
+        if world > 1:
+            gathered = [torch.empty_like(stacked) for _ in range(world)]
+            dist.all_gather(gathered, stacked)                        # RCCL over xGMI
+            stacked = torch.cat(gathered)
+        result["assign"], _, _, _ = mdist.merge_summaries(stacked)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t1
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    assign = result["assign"].cpu().numpy()
+    if rank == 0:
+        ok = truth >= 0
+        print(json.dumps({
+            "metric": "reads/sec classified, index sharded (BASELINE config 4)", "value": round(n * args.steps / elapsed, 1),
+            "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32/u64 integer", "data": "synthetic",
+            "config": {"workload": f"{n} synthetic {args.read_len} nt reads vs {G} genomes "
+                                   f"({sum(len(s) for s in seqs)} bp) in {P} index parts, {P // world} per GPU; "
+                                   "every part maps all reads",
+                       "parallelism": f"index-sharded x{world}, all-gather of {P}x{n}x20 B summaries + best_hit merge"},
+            "mapped_reads": int((assign >= 0).sum()), "ambiguous_reads": int((assign == -2).sum()),
+            "assigned_to_source_genome": round(float((assign[ok] == truth[ok]).mean()), 4),
+            "setup_s": round(t_setup, 1)}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def files_mode(args, names, seqs, local_rank):
+    """The drop-in surface end to end (monica_amd.aligner.multi_threaded_aligner, the mirror of
+    monica/genomes/aligner.py:65-111) on files: index file load, FASTQ parse, H2D, kernels, D2H,
+    carried-hits update, routed FASTQ output, alignment.pkl.  PCIe- and disk-inclusive; never the
+    headline `value`."""
+    import shutil
+    import tempfile
+    from monica_amd import _capi, synth
+    from monica_amd import aligner as al
+
+    os.environ["MONICA_AMD_DEVICE"] = str(local_rank)
+    work = tempfile.mkdtemp(prefix="mnc_files_")
+    try:
+        query, out = os.path.join(work, "query"), os.path.join(work, "out")
+        os.makedirs(query), os.makedirs(out)
+        idx_path = os.path.join(work, "index1.mmi")
+        _capi.Index.from_seqs(names, seqs).save(idx_path)
+        bases, offsets, truth = synth.reads(seqs, args.reads, args.read_len, seed=synth.SEED_READS + 2)
+        fq = os.path.join(query, "sample.fastq")
+        t0 = time.perf_counter()
+        synth.write_fastq(fq, bases, offsets)
+        t_write = time.perf_counter() - t0
+        size = os.path.getsize(fq)
+        cwd = os.getcwd()
+        t0 = time.perf_counter()
+        result = al.multi_threaded_aligner(query, [idx_path], mode="basic", n_threads=1, output_folder=out)
+        wall = time.perf_counter() - t0
+        os.chdir(cwd)
+        counted = sum(sum(c.values()) for c in result["sample"].values())
+        routed = {k: os.path.getsize(os.path.join(query, k, "sample.fastq")) for k in ("mapped", "unmapped", "ambiguous")}
+        print(json.dumps({
+            "metric": "reads/sec through the Python aligner API on FASTQ files", "value": round(args.reads / wall, 1),
+            "unit": "reads/s", "n_gpus": 1, "reads": args.reads, "fastq_bytes": size, "wall_s": round(wall, 3),
+            "includes": "index load + upload, FASTQ parse, H2D, kernels, D2H, carried-hits update, routed FASTQ "
+                        "output, alignment.pkl", "mapped_reads_counted": int(counted), "routed_bytes": routed,
+            "fastq_write_s_python": round(t_write, 2),
+            "aligner_phase_s": {k: round(v, 3) for k, v in al.TIMINGS.get("sample", {}).items()},
+            "index_load_s": round(al.TIMINGS.get("_index_loader", {}).get("load", 0.0), 3), "data": "synthetic"}))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 if __name__ == "__main__":

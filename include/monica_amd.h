@@ -191,6 +191,63 @@ typedef struct {
 } mnc_reg_t;
 int mnc_engine_dump(mnc_engine *eng, int what, void *dst, int64_t cap_bytes, int64_t *n_bytes);
 
+/* ---------------------------------------------------------------- FASTQ batches and read routing
+ * Replaces the per-record Biopython objects of the reference's loop:
+ * SeqIO.parse(sample, 'fastq') + str(seq_record.seq) (monica/genomes/aligner.py:191-193,
+ * 212-215) and SeqIO.write(seq_record, handle, 'fastq') into mapped/ unmapped/ ambiguous/
+ * focus/ (aligner.py:232-243, 265).  Records follow Biopython's FASTQ rules (multi-line
+ * sequence / quality, '+' caption check, length check); a malformed file gives
+ * MNC_ERR_FORMAT with Biopython's message in mnc_last_error().  A reader owns one batch at a
+ * time; pointers returned by the accessors stay valid until the next mnc_fastq_next/close. */
+typedef struct mnc_fastq mnc_fastq;
+int mnc_fastq_open(const char *path, mnc_fastq **out);
+void mnc_fastq_close(mnc_fastq *fq);
+/* parse the next batch: stops after max_reads records or once max_bases bases are held.
+ * *n_reads = 0 at the end of the file. */
+int mnc_fastq_next(mnc_fastq *fq, uint32_t max_reads, uint64_t max_bases, uint32_t *n_reads);
+const uint8_t *mnc_fastq_bases(const mnc_fastq *fq);     /* concatenated sequences (page-locked when a GPU is present) */
+const int64_t *mnc_fastq_offsets(const mnc_fastq *fq);   /* n_reads + 1, starts at 0 */
+const uint8_t *mnc_fastq_quals(const mnc_fastq *fq);     /* quality characters, same offsets */
+/* title line of read r (without '@'); *id_len = length of its first word (seq_record.id) */
+int mnc_fastq_title(const mnc_fastq *fq, uint32_t r, const char **title, uint32_t *len, uint32_t *id_len);
+/* Append every record of the batch to the files its dest[r] bits name:
+ *   MNC_TO_UNMAPPED / MNC_TO_AMBIGUOUS / MNC_TO_FOCUS: the record as read;
+ *   MNC_TO_MAPPED: the record with its id replaced by labels[label[r]]
+ *   (seq_record.id = tax_unit, aligner.py:242; Biopython then writes "<id> <old title>").
+ * paths[4] = {unmapped, ambiguous, mapped, focus}; a NULL path must not be addressed. */
+#define MNC_TO_UNMAPPED  1
+#define MNC_TO_AMBIGUOUS 2
+#define MNC_TO_MAPPED    4
+#define MNC_TO_FOCUS     8
+int mnc_fastq_route(const mnc_fastq *fq, const uint8_t *dest, const int32_t *label,
+                    const char *const *labels, int n_labels, const char *const *paths);
+
+/* ---------------------------------------------------------------- hits carried across index parts
+ * Replaces the `sample_hits` dict and its <sample>_hits.pkl (aligner.py:184-188, 196-203,
+ * 218-223, 267-273): per read id, the gated hits of all index parts seen so far.  best_hit
+ * (aligner.py:328-339) only asks for the smallest NM/mlen and whether it is attained once,
+ * so a read's list is held as {hits, nm, mlen, contig name, tied}; extending the list and
+ * reducing it commute with this summary, exactly (int64 cross-products). */
+typedef struct mnc_hitmap mnc_hitmap;
+int mnc_hitmap_create(mnc_hitmap **out);
+int mnc_hitmap_load(const char *path, mnc_hitmap **out);
+int mnc_hitmap_save(const mnc_hitmap *hm, const char *path);
+void mnc_hitmap_free(mnc_hitmap *hm);
+int64_t mnc_hitmap_size(const mnc_hitmap *hm);           /* ids with at least one hit */
+/* For every read of the batch, in order: sample_hits[id].extend(this part's gated hits),
+ * given as the engine's outputs (nhits, best = minimal hit, assign == MNC_AMBIGUOUS: tied);
+ * then out[r] = the state of sample_hits[id]: {hits, nm, mlen, name id, tied}
+ * (hits == 0: the id is not in the dict).  Name ids index mnc_hitmap_name(). */
+int mnc_hitmap_update(mnc_hitmap *hm, const mnc_fastq *fq, const mnc_index *idx,
+                      const int32_t *assign, const mnc_hit_t *best, const int32_t *nhits,
+                      int32_t *out /* n_reads x 5 */);
+int mnc_hitmap_n_names(const mnc_hitmap *hm);
+const char *mnc_hitmap_name(const mnc_hitmap *hm, int id);
+
+/* page-locked host memory for batch buffers (plain malloc when no GPU is present) */
+void *mnc_host_alloc(size_t bytes);
+void mnc_host_free(void *p);
+
 /* ---------------------------------------------------------------- synthetic data (bench/tests)
  * Deterministic counter-based generator (SplitMix64), SURVEY.md section 8d. */
 int mnc_synth_genome(uint64_t seed, int64_t len, char *out);

@@ -43,6 +43,10 @@ EXPORTS = [
     "mnc_counts", "mnc_best_hit",
     "mnc_engine_set_profiling", "mnc_engine_set_debug", "mnc_engine_get_timings", "mnc_stage_name", "mnc_stage_kernel",
     "mnc_engine_get_counters", "mnc_engine_dump",
+    "mnc_fastq_open", "mnc_fastq_close", "mnc_fastq_next", "mnc_fastq_bases", "mnc_fastq_offsets",
+    "mnc_fastq_quals", "mnc_fastq_title", "mnc_fastq_route",
+    "mnc_hitmap_create", "mnc_hitmap_load", "mnc_hitmap_save", "mnc_hitmap_free", "mnc_hitmap_size",
+    "mnc_hitmap_update", "mnc_hitmap_n_names", "mnc_hitmap_name", "mnc_host_alloc", "mnc_host_free",
     "mnc_synth_genome", "mnc_synth_diverge", "mnc_synth_reads", "mnc_version",
 ]
 
@@ -125,6 +129,24 @@ def lib():
     sig("mnc_synth_diverge", i32, [vp, i64, u64, i32, vp])
     sig("mnc_synth_reads", i32, [i32, C.POINTER(vp), C.POINTER(i64), u64, i64, i32, i32,
                                  i32, i32, i32, i32, vp, vp])
+    sig("mnc_fastq_open", i32, [cp, pp])
+    sig("mnc_fastq_close", None, [vp])
+    sig("mnc_fastq_next", i32, [vp, u32, u64, C.POINTER(u32)])
+    sig("mnc_fastq_bases", vp, [vp])
+    sig("mnc_fastq_offsets", vp, [vp])
+    sig("mnc_fastq_quals", vp, [vp])
+    sig("mnc_fastq_title", i32, [vp, u32, C.POINTER(vp), C.POINTER(u32), C.POINTER(u32)])
+    sig("mnc_fastq_route", i32, [vp, vp, vp, C.POINTER(cp), i32, C.POINTER(cp)])
+    sig("mnc_hitmap_create", i32, [pp])
+    sig("mnc_hitmap_load", i32, [cp, pp])
+    sig("mnc_hitmap_save", i32, [vp, cp])
+    sig("mnc_hitmap_free", None, [vp])
+    sig("mnc_hitmap_size", i64, [vp])
+    sig("mnc_hitmap_update", i32, [vp, vp, vp, vp, vp, vp, vp])
+    sig("mnc_hitmap_n_names", i32, [vp])
+    sig("mnc_hitmap_name", cp, [vp, i32])
+    sig("mnc_host_alloc", vp, [C.c_size_t])
+    sig("mnc_host_free", None, [vp])
     _LIB = L
     return L
 
@@ -260,6 +282,16 @@ class Engine:
         self.n_reads = n
         return assign, best, nhits
 
+    def classify_ptr(self, bases_ptr, offsets_ptr, n, min_mapq=60):
+        """As classify(), on caller-owned host buffers given by address (e.g. a FastqReader batch)."""
+        assign = np.empty(n, dtype=np.int32)
+        best = np.zeros(n, dtype=HIT_DTYPE)
+        nhits = np.zeros(n, dtype=np.int32)
+        check(lib().mnc_classify_batch(self._h, bases_ptr, offsets_ptr, n, min_mapq,
+                                       assign.ctypes.data, best.ctypes.data, nhits.ctypes.data))
+        self.n_reads = n
+        return assign, best, nhits
+
     def classify_device(self, d_bases, d_offsets, n_reads, total_bases, max_read_len, min_mapq,
                         d_assign, d_best=0, d_nhits=0, d_counts=0):
         """All arguments are raw device pointers (ints); asynchronous on the engine stream."""
@@ -332,3 +364,122 @@ def counts(index, assign, best, offsets, mode):
     check(lib().mnc_counts(index._h, assign.ctypes.data, best.ctypes.data, offsets.ctypes.data,
                            len(assign), mode, out.ctypes.data))
     return out
+
+
+# ---------------------------------------------------------------------------------- FASTQ + carried hits
+TO_UNMAPPED, TO_AMBIGUOUS, TO_MAPPED, TO_FOCUS = 1, 2, 4, 8
+
+
+class FastqReader:
+    """Batches of a FASTQ file as flat arrays held by the library (``mnc_fastq``).  A malformed
+    file raises ValueError with Biopython's message, as SeqIO.parse would."""
+
+    def __init__(self, path):
+        h = C.c_void_p()
+        check(lib().mnc_fastq_open(_b(path), C.byref(h)))
+        self._h = h
+        self.n = 0
+
+    def next(self, max_reads=100_000, max_bases=1 << 29):
+        n = C.c_uint32(0)
+        rc = lib().mnc_fastq_next(self._h, max_reads, max_bases, C.byref(n))
+        if rc == ERR_FORMAT:
+            raise ValueError(lib().mnc_last_error().decode(errors="replace"))
+        check(rc)
+        self.n = n.value
+        return self.n
+
+    @property
+    def bases_ptr(self):
+        return lib().mnc_fastq_bases(self._h)
+
+    @property
+    def offsets_ptr(self):
+        return lib().mnc_fastq_offsets(self._h)
+
+    def offsets(self):
+        """int64[n + 1] view, valid until the next batch."""
+        return np.ctypeslib.as_array(C.cast(self.offsets_ptr, C.POINTER(C.c_int64)), shape=(self.n + 1,))
+
+    def bases(self):
+        total = int(self.offsets()[-1])
+        if total == 0:
+            return np.zeros(0, dtype=np.uint8)
+        return np.ctypeslib.as_array(C.cast(self.bases_ptr, C.POINTER(C.c_uint8)), shape=(total,))
+
+    def quals(self):
+        total = int(self.offsets()[-1])
+        if total == 0:
+            return np.zeros(0, dtype=np.uint8)
+        return np.ctypeslib.as_array(C.cast(lib().mnc_fastq_quals(self._h), C.POINTER(C.c_uint8)), shape=(total,))
+
+    def title(self, r):
+        p, ln, idl = C.c_void_p(), C.c_uint32(0), C.c_uint32(0)
+        check(lib().mnc_fastq_title(self._h, r, C.byref(p), C.byref(ln), C.byref(idl)))
+        return C.string_at(p.value, ln.value).decode(errors="replace") if ln.value else ""
+
+    def route(self, dest, label=None, labels=(), paths=(None, None, None, None)):
+        """Append the batch's records to paths = (unmapped, ambiguous, mapped, focus) by dest bits."""
+        dest = np.ascontiguousarray(dest, dtype=np.uint8)
+        assert len(dest) == self.n
+        lab = np.ascontiguousarray(label, dtype=np.int32) if label is not None else None
+        bl = [_b(x) for x in labels]
+        al = (C.c_char_p * max(len(bl), 1))(*bl)
+        ap = (C.c_char_p * 4)(*[(_b(x) if x is not None else None) for x in paths])
+        check(lib().mnc_fastq_route(self._h, dest.ctypes.data, lab.ctypes.data if lab is not None else None,
+                                    al, len(bl), ap))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mnc_fastq_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HitMap:
+    """`sample_hits` of the reference as per-id summaries (``mnc_hitmap``)."""
+
+    def __init__(self, path=None):
+        h = C.c_void_p()
+        if path is None:
+            check(lib().mnc_hitmap_create(C.byref(h)))
+        else:
+            check(lib().mnc_hitmap_load(_b(path), C.byref(h)))
+        self._h = h
+
+    def save(self, path):
+        check(lib().mnc_hitmap_save(self._h, _b(path)))
+
+    def __len__(self):
+        return int(lib().mnc_hitmap_size(self._h))
+
+    def update(self, reader, index, assign, best, nhits):
+        """Extend every read's list by this part's hits; returns int32[n, 5] =
+        {hits, nm, mlen, name id, tied} of the lists as they stand."""
+        out = np.zeros((reader.n, 5), dtype=np.int32)
+        assign = np.ascontiguousarray(assign, dtype=np.int32)
+        best = np.ascontiguousarray(best, dtype=HIT_DTYPE)
+        nhits = np.ascontiguousarray(nhits, dtype=np.int32)
+        check(lib().mnc_hitmap_update(self._h, reader._h, index._h, assign.ctypes.data, best.ctypes.data,
+                                      nhits.ctypes.data, out.ctypes.data))
+        return out
+
+    def names(self):
+        L = lib()
+        return [L.mnc_hitmap_name(self._h, i).decode() for i in range(L.mnc_hitmap_n_names(self._h))]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mnc_hitmap_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

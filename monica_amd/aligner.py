@@ -14,10 +14,13 @@ Deviations, all deliberate:
 import itertools
 import os
 import pickle
+import time
 from collections import Counter
 from multiprocessing.dummy import Pool as ThreadPool
 
-from . import fastq
+import numpy as np
+
+from . import _capi
 from . import mappy_compat as mappy
 
 
@@ -50,6 +53,9 @@ HITS_FILES_FOLDER = "hits"
 FOCUS_FILES_FOLDER = "focus"
 
 DEFAULT_THREADS = 4
+BATCH_READS = 100_000            # reads / bases per C-ABI call
+BATCH_BASES = 1 << 29
+TIMINGS = {}                      # per sample name: seconds spent per phase of aligner() (diagnostics)
 
 
 def _marker(name):
@@ -89,9 +95,11 @@ def index_loader(index_file):
     """Load one index part (aligner.py:56-62)."""
     if index_file.endswith(".mmi"):
         print(f"aligning on {index_file}")
+        t0 = time.perf_counter()
         index = mappy.Aligner(fn_idx_in=index_file)
         if not index:
             raise Exception("Damaged or empty index")
+        TIMINGS.setdefault("_index_loader", {"load": 0.0})["load"] += time.perf_counter() - t0
         return index
 
 
@@ -134,80 +142,118 @@ def multi_threaded_aligner(query_folder, indexes_paths, mode=None, mapping_quali
     return alignment_update(results, output_folder)
 
 
-def _gated_tuples(index, hit_off, hits, r):
-    """The `(hit.ctg, hit.NM, hit.mlen)` tuples of read r that passed the gate (aligner.py:194-195)."""
-    names = index.index.contig_names
-    return [(names[int(h["rid"])], int(h["nm"]), int(h["mlen"])) for h in hits[hit_off[r]:hit_off[r + 1]]]
-
-
 def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_quality=None, overnight=False,
             focus_species=[], mapped_folder=None, unmapped_folder=None, ambiguous_folder=None, focus_folder=None,
             last_index=False):
-    """One sample file against one index part (aligner.py:179-279)."""
+    """One sample file against one index part (aligner.py:179-279).
+
+    Per batch: the library parses the FASTQ records (`mnc_fastq_next`), the GPU classifies them
+    (`mnc_classify_batch`), the per-id hit lists carried over from earlier index parts are
+    extended (`mnc_hitmap_update`, the reference's `sample_hits`), and on the last part the
+    records are appended to mapped/ unmapped/ ambiguous/ focus/ (`mnc_fastq_route`).  Python
+    only sees batch-level arrays and the handful of contig names that were hit."""
     # mode parameter is for testing only (reference comment)
     print(f"{sample}, mode is {mode}\t")
     if mapping_quality is None:
         raise TypeError("'>=' not supported between instances of 'int' and 'NoneType'")
     carried_file = os.path.join(hits_folder, sample_name + "_hits.pkl")
-    if os.path.exists(carried_file):
-        with open(carried_file, "rb") as f:
-            sample_hits = pickle.load(f)
-    else:
-        sample_hits = dict()
+    sample_hits = _capi.HitMap(carried_file if os.path.exists(carried_file) else None)
+    t_engine = time.perf_counter()
+    engine = index.engine()
+    t_engine = time.perf_counter() - t_engine
+    reader = _capi.FastqReader(sample)
 
-    def collect(batch, hit_off, hits):
-        for r in range(len(batch)):
-            if hit_off[r + 1] > hit_off[r]:
-                sample_hits.setdefault(batch.ids[r], []).extend(_gated_tuples(index, hit_off, hits, r))
+    clock = TIMINGS.setdefault(sample_name, dict.fromkeys(("parse", "classify", "carry", "route", "count", "engine"), 0.0))
+    clock["engine"] += t_engine
 
-    if not last_index:
-        for batch in fastq.read_batches(sample):
-            _, _, _, hit_off, hits = index.map_batch(batch.bases, batch.offsets, mapping_quality)
-            collect(batch, hit_off, hits)
-        with open(carried_file, "wb") as f:
-            pickle.dump(sample_hits, f)
-        return None
+    def classify_next():
+        t0 = time.perf_counter()
+        if not reader.next(BATCH_READS, BATCH_BASES):
+            return None
+        t1 = time.perf_counter()
+        assign, best, nhits = engine.classify_ptr(reader.bases_ptr, reader.offsets_ptr, reader.n, mapping_quality)
+        t2 = time.perf_counter()
+        state = sample_hits.update(reader, index.index, assign, best, nhits)
+        clock["parse"] += t1 - t0
+        clock["classify"] += t2 - t1
+        clock["carry"] += time.perf_counter() - t2
+        return state
 
+    try:
+        if not last_index:
+            while classify_next() is not None:
+                pass
+            sample_hits.save(carried_file)
+            return None
+
+        paths = [os.path.join(unmapped_folder, sample), os.path.join(ambiguous_folder, sample),
+                 os.path.join(mapped_folder, sample), os.path.join(focus_folder, sample) if focus_species else None]
+        for path in paths:                                # the reference opens them all in 'a' mode
+            if path:
+                open(path, "ab").close()
+        totals = np.zeros(0, dtype=np.int64)              # per contig name: counted amount, first read ordinal
+        first = np.zeros(0, dtype=np.int64)
+        decoded = []                                      # per contig name: (tax_unit, accession, in focus)
+        seen_reads = 0
+        while True:
+            state = classify_next()
+            if state is None:
+                break
+            hits, mlen, name, tied = state[:, 0], state[:, 2], state[:, 3], state[:, 4]
+            mapped = (hits > 0) & (tied == 0)             # one hit, or best_hit found a unique minimum
+            names = sample_hits.names()
+            for ctg in names[len(decoded):]:
+                decoded.append(None if ":" not in ctg else _decode(ctg, overnight, focus_species))
+            used = np.unique(name[mapped])
+            for u in used:
+                if decoded[u] is None:
+                    raise IndexError("list index out of range")      # best[0].split(sep=':')[1]
+            if len(totals) < len(names):
+                totals = np.concatenate([totals, np.zeros(len(names) - len(totals), dtype=np.int64)])
+                first = np.concatenate([first, np.full(len(names) - len(first), -1, dtype=np.int64)])
+            dest = np.where(hits == 0, _capi.TO_UNMAPPED, np.where(mapped, _capi.TO_MAPPED, _capi.TO_AMBIGUOUS)).astype(np.uint8)
+            if focus_species and len(used):
+                in_focus = np.array([bool(d and d[2]) for d in decoded], dtype=bool)
+                dest[mapped & in_focus[np.where(mapped, name, 0)]] |= _capi.TO_FOCUS
+            t0 = time.perf_counter()
+            reader.route(dest, np.where(mapped, name, -1), [d[0] if d else "" for d in decoded], paths)
+            clock["route"] += time.perf_counter() - t0
+            if mode == "basic":
+                amount = np.ones(reader.n, dtype=np.int64)
+            elif mode == "query_length":
+                amount = np.diff(reader.offsets())
+            elif mode == "matching":
+                amount = mlen.astype(np.int64)
+            else:
+                amount = None
+            if amount is not None and len(used):
+                np.add.at(totals, name[mapped], amount[mapped])
+                ordinal = seen_reads + np.flatnonzero(mapped)
+                for u in used:
+                    if first[u] < 0:
+                        first[u] = ordinal[np.argmax(name[mapped] == u)]
+            seen_reads += reader.n
+    finally:
+        reader.close()
     sample_alignment = dict()
-    focus = open(os.path.join(focus_folder, sample), "ab") if focus_species else None
-    with open(os.path.join(mapped_folder, sample), "ab") as mapped, \
-            open(os.path.join(unmapped_folder, sample), "ab") as unmapped, \
-            open(os.path.join(ambiguous_folder, sample), "ab") as ambiguous:
-        for batch in fastq.read_batches(sample):
-            _, _, _, hit_off, hits = index.map_batch(batch.bases, batch.offsets, mapping_quality)
-            collect(batch, hit_off, hits)
-            for r in range(len(batch)):
-                read = batch.ids[r]
-                if read not in sample_hits:
-                    unmapped.write(fastq.format_record(batch, r))
-                    continue
-                read_hits = sample_hits[read]
-                best = read_hits[0] if len(read_hits) == 1 else best_hit(read_hits)
-                if not best:
-                    ambiguous.write(fastq.format_record(batch, r))
-                    continue
-                tax_unit, accession = best[0].split(sep=":")[0], best[0].split(sep=":")[1]
-                if tax_unit in focus_species:
-                    focus.write(fastq.format_record(batch, r))
-                if overnight:
-                    tax_unit = tax_unit.split(sep="_")[0]        # tax_unit becomes the genus
-                mapped.write(fastq.format_record(batch, r, new_id=tax_unit))
-                if mode == "basic":
-                    amount = 1
-                elif mode == "query_length":
-                    amount = int(batch.offsets[r + 1] - batch.offsets[r])
-                elif mode == "matching":
-                    amount = best[2]
-                else:
-                    continue
-                sample_alignment.setdefault(tax_unit, Counter()).update({accession: amount})
+    for u in sorted(np.flatnonzero(first >= 0), key=lambda u: first[u]):
+        tax_unit, accession, _ = decoded[u]
+        sample_alignment.setdefault(tax_unit, Counter()).update({accession: int(totals[u])})
     if os.path.exists(carried_file):
         os.remove(carried_file)
-    if focus:
-        focus.close()
     print(f"{sample} done")
     os.remove(sample)
     return sample_alignment, sample_name
+
+
+def _decode(ctg, overnight, focus_species):
+    """Contig name -> (tax_unit or genus, accession, tax_unit in focus) (aligner.py:234-240)."""
+    parts = ctg.split(sep=":")
+    tax_unit, accession = parts[0], parts[1]
+    in_focus = tax_unit in focus_species
+    if overnight:
+        tax_unit = tax_unit.split(sep="_")[0]            # tax_unit becomes the genus
+    return tax_unit, accession, in_focus
 
 
 def alignment_update(results, output_folder):

@@ -10,6 +10,8 @@
 #include <vector>
 
 #include "device.h"
+#include <atomic>
+#include <thread>
 
 namespace mnc {
 
@@ -173,42 +175,59 @@ int index_upload(mnc_index *idx, int device, DeviceIndex **out)
 	std::vector<uint32_t> filt((size_t)PB_N * PF_WORDS, 0u);
 	try { tab.assign((size_t)PB_N * R, TableSlot{0, 0, 0}); } catch (const std::bad_alloc &) { return MNC_ERR_NOMEM; }
 	{
-		std::vector<std::vector<uint32_t>> bk(NB);
-		std::vector<uint32_t> order(NB);
-		for (int b = 0; b < PB_N; ++b) {
-			TableSlot *T = tab.data() + (size_t)b * R;
-			for (auto &v : bk) v.clear();
-			for (uint32_t ki : reg[b]) {
-				const uint32_t rest = pb_rest(idx->keys[ki]);
-				bk[rest & (NB - 1)].push_back(ki);
-				const uint32_t bit = rest & ((1u << PF_BITS) - 1u);
-				filt[(size_t)b * PF_WORDS + (bit >> 5)] |= 1u << (bit & 31);
-			}
-			for (size_t i = 0; i < NB; ++i) order[i] = (uint32_t)i;
-			std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return bk[x].size() != bk[y].size() ? bk[x].size() > bk[y].size() : x < y; });
-			for (uint32_t o : order) {                   // largest displacement buckets first
-				const auto &keys = bk[o];
-				if (keys.empty()) break;
-				int d = 0;
-				for (; d < 256; ++d) {
-					bool ok = true;
-					for (size_t a = 0; a < keys.size() && ok; ++a) {
-						const uint32_t sa = pd_slot(pb_rest(idx->keys[keys[a]]), (uint32_t)d, region_bits);
-						if (T[sa].key) ok = false;
-						for (size_t c = 0; c < a && ok; ++c)
-							if (sa == pd_slot(pb_rest(idx->keys[keys[c]]), (uint32_t)d, region_bits)) ok = false;
+		// regions are independent: build them on a few host threads
+		std::atomic<int> next_region{0}, failed{-1};
+		auto work = [&]() {
+			std::vector<std::vector<uint32_t>> bk(NB);
+			std::vector<uint32_t> order(NB);
+			for (;;) {
+				const int b = next_region.fetch_add(1);
+				if (b >= PB_N || failed.load() >= 0) return;
+				TableSlot *T = tab.data() + (size_t)b * R;
+				for (auto &v : bk) v.clear();
+				for (uint32_t ki : reg[b]) {
+					const uint32_t rest = pb_rest(idx->keys[ki]);
+					bk[rest & (NB - 1)].push_back(ki);
+					const uint32_t bit = rest & ((1u << PF_BITS) - 1u);
+					filt[(size_t)b * PF_WORDS + (bit >> 5)] |= 1u << (bit & 31);
+				}
+				for (size_t i = 0; i < NB; ++i) order[i] = (uint32_t)i;
+				std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return bk[x].size() != bk[y].size() ? bk[x].size() > bk[y].size() : x < y; });
+				for (uint32_t o : order) {                   // largest displacement buckets first
+					const auto &keys = bk[o];
+					if (keys.empty()) break;
+					int d = 0;
+					for (; d < 256; ++d) {
+						bool ok = true;
+						for (size_t a = 0; a < keys.size() && ok; ++a) {
+							const uint32_t sa = pd_slot(pb_rest(idx->keys[keys[a]]), (uint32_t)d, region_bits);
+							if (T[sa].key) ok = false;
+							for (size_t c = 0; c < a && ok; ++c)
+								if (sa == pd_slot(pb_rest(idx->keys[keys[c]]), (uint32_t)d, region_bits)) ok = false;
+						}
+						if (ok) break;
 					}
-					if (ok) break;
-				}
-				if (d == 256) { set_error("perfect hashing of table region %d failed (bucket of %zu keys, region %zu keys, R %zu, NB %zu)", b, keys.size(), reg[b].size(), R, NB); return MNC_ERR_UNSUPPORTED; }
-				disp[(size_t)b * NB + o] = (uint8_t)d;
-				for (uint32_t ki : keys) {
-					const uint32_t h = idx->keys[ki];
-					const uint64_t off = idx->key_off[ki], c = idx->key_off[ki + 1] - off;
-					TableSlot &s = T[pd_slot(pb_rest(h), (uint32_t)d, region_bits)];
-					s.key = h + 1, s.cnt = (uint32_t)c, s.val = c == 1 ? idx->pos[off] : off;
+					if (d == 256) { failed.store(b); return; }
+					disp[(size_t)b * NB + o] = (uint8_t)d;
+					for (uint32_t ki : keys) {
+						const uint32_t h = idx->keys[ki];
+						const uint64_t off = idx->key_off[ki], c = idx->key_off[ki + 1] - off;
+						TableSlot &sl = T[pd_slot(pb_rest(h), (uint32_t)d, region_bits)];
+						sl.key = h + 1, sl.cnt = (uint32_t)c, sl.val = c == 1 ? idx->pos[off] : off;
+					}
 				}
 			}
+		};
+		unsigned nt = std::thread::hardware_concurrency();
+		nt = nt == 0 ? 4 : nt > 16 ? 16 : nt;
+		std::vector<std::thread> pool;
+		for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work);
+		work();
+		for (auto &t : pool) t.join();
+		if (failed.load() >= 0) {
+			const int b = failed.load();
+			set_error("perfect hashing of table region %d failed (region of %zu keys, R %zu, NB %zu)", b, reg[b].size(), R, NB);
+			return MNC_ERR_UNSUPPORTED;
 		}
 	}
 	DeviceIndex d;
@@ -290,6 +309,40 @@ static const char *STAGE_KERNEL[MNC_N_STAGES] = {
 
 extern "C" const char *mnc_stage_name(int s) { return s >= 0 && s < MNC_N_STAGES ? STAGE_NAME[s] : nullptr; }
 extern "C" const char *mnc_stage_kernel(int s) { return s >= 0 && s < MNC_N_STAGES ? STAGE_KERNEL[s] : nullptr; }
+
+// page-locked host buffers for the batch readers (hostio.cpp); plain malloc without a GPU
+static std::mutex g_pinned_mu;
+static std::vector<void*> g_pinned;
+
+extern "C" void *mnc_host_alloc(size_t bytes)
+{
+	if (bytes == 0) bytes = 1;
+	int c = 0;
+	void *p = nullptr;
+	if (hipGetDeviceCount(&c) == hipSuccess && c > 0 && hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p) {
+		std::lock_guard<std::mutex> g(g_pinned_mu);
+		g_pinned.push_back(p);
+		return p;
+	}
+	(void)hipGetLastError();
+	return malloc(bytes);
+}
+
+extern "C" void mnc_host_free(void *p)
+{
+	if (!p) return;
+	{
+		std::lock_guard<std::mutex> g(g_pinned_mu);
+		for (size_t i = 0; i < g_pinned.size(); ++i)
+			if (g_pinned[i] == p) {
+				g_pinned[i] = g_pinned.back();
+				g_pinned.pop_back();
+				(void)hipHostFree(p);
+				return;
+			}
+	}
+	free(p);
+}
 
 extern "C" int mnc_device_count(int *n)
 {

@@ -90,3 +90,102 @@ def test_module_surface_matches_reference():
     for name in ("indexer", "index_loader", "alignment_update", "normalizer", "alignment_to_data_frame", "best_hit",
                  "any_result"):
         assert callable(getattr(aligner, name))
+
+
+def test_fastq_errors_follow_biopython(tmp_path):
+    cases = {
+        b"r1\nACGT\n+\nIIII\n": "Records in Fastq files should start with '@' character",
+        b"@r1\nACGT\n": "End of file without quality information.",
+        b"@r1\nACGT\n+r2\nIIII\n": "Sequence and quality captions differ.",
+        b"@r1\nAC GT\n+\nIIIII\n": "Whitespace is not allowed in the sequence.",
+        b"@r1\nACGT\n+\nII\x07I\n": "Invalid character in quality string",
+        b"@r1 d\nACGT\n+\nIIIII\n": "Lengths of sequence and quality values differs for r1 d (4 and 5).",
+    }
+    for i, (data, msg) in enumerate(cases.items()):
+        p = tmp_path / f"bad{i}.fastq"
+        p.write_bytes(data)
+        with pytest.raises(ValueError) as ei:
+            list(fastq.read_batches(str(p)))
+        assert str(ei.value) == msg
+    empty = tmp_path / "empty.fastq"
+    empty.write_bytes(b"")
+    assert list(fastq.read_batches(str(empty))) == []
+    # a quality line that starts with '@' belongs to the record while characters are missing
+    tricky = tmp_path / "tricky.fastq"
+    tricky.write_bytes(b"@r1\nACGTAC\n+\n@II\n@II\n@r2\nAC\n+\n@I")
+    (b,) = list(fastq.read_batches(str(tricky)))
+    assert b.ids == ["r1", "r2"] and b.qual(0) == b"@II@II" and b.qual(1) == b"@I"
+
+
+def test_route_writes_what_seqio_write_would(tmp_path):
+    from monica_amd import _capi
+    src = tmp_path / "s.fastq"
+    src.write_bytes(b"@r1 ch=1\nACGT\n+\nIIII\n@r2\nGGGG\n+\n!!!!\n@r3 z\nTT\n+\n##\n@Genus_a k\nCC\n+\nII\n@r5\nAAAA\n+\nIIII\n")
+    rd = _capi.FastqReader(str(src))
+    assert rd.next() == 5
+    paths = [str(tmp_path / n) for n in ("unmapped.fq", "ambiguous.fq", "mapped.fq", "focus.fq")]
+    (tmp_path / "mapped.fq").write_bytes(b"@old\nA\n+\nI\n")             # append mode
+    dest = [_capi.TO_MAPPED | _capi.TO_FOCUS, _capi.TO_UNMAPPED, _capi.TO_AMBIGUOUS, _capi.TO_MAPPED, 0]
+    rd.route(dest, [1, -1, -1, 0, -1], ["Genus_a", "Genus_b"], paths)
+    assert open(paths[0], "rb").read() == b"@r2\nGGGG\n+\n!!!!\n"
+    assert open(paths[1], "rb").read() == b"@r3 z\nTT\n+\n##\n"
+    assert open(paths[2], "rb").read() == b"@old\nA\n+\nI\n@Genus_b r1 ch=1\nACGT\n+\nIIII\n@Genus_a k\nCC\n+\nII\n"
+    assert open(paths[3], "rb").read() == b"@r1 ch=1\nACGT\n+\nIIII\n"
+    with pytest.raises(_capi.MncError):
+        rd.route([_capi.TO_FOCUS, 0, 0, 0, 0], None, [], paths[:3] + [None])
+    rd.close()
+
+
+def test_hitmap_is_sample_hits_with_best_hit(tmp_path):
+    """Extending per-id lists part by part and reducing them with best_hit equals the carried summary."""
+    import numpy as np
+    from monica_amd import _capi
+    rng = np.random.default_rng(5)
+    n, parts = 300, 3
+    ids = [f"read{i % 250}" for i in range(n)]                             # 50 duplicated ids
+    src = tmp_path / "s.fastq"
+    src.write_bytes(b"".join(f"@{i} x\nACGT\n+\nIIII\n".encode() for i in ids))
+    names = [f"Genus_{c}:ACC{c}" for c in range(6)]
+    idx = _capi.Index.from_seqs(names, ["ACGTTGCATGCATGACTGACTGATCGATCGTAGCTAGCTAGCATGCATGCAT" * 3] * 6)
+    ref = {}                                                               # the reference's dict of lists
+    hm = _capi.HitMap()
+    for part in range(parts):
+        if part == 1:                                                      # through the carried file
+            hm.save(str(tmp_path / "h.pkl"))
+            hm = _capi.HitMap(str(tmp_path / "h.pkl"))
+        rd = _capi.FastqReader(str(src))
+        base = 0
+        while rd.next(max_reads=128):
+            m = rd.n
+            nh = rng.integers(0, 4, m).astype(np.int32)
+            lists = [[(names[int(rng.integers(0, 6))], int(rng.integers(0, 4)), int(rng.integers(1, 4)) * 10)
+                      for _ in range(k)] for k in nh]
+            assign = np.full(m, _capi.UNMAPPED, dtype=np.int32)
+            best = np.zeros(m, dtype=_capi.HIT_DTYPE)
+            for r, hl in enumerate(lists):
+                if not hl:
+                    continue
+                lo = min(h[1] / h[2] for h in hl)
+                at = [h for h in hl if h[1] / h[2] == lo]
+                b = at[-1]
+                best[r] = (names.index(b[0]), 60, b[1], b[2])
+                assign[r] = names.index(b[0]) if len(at) == 1 else _capi.AMBIGUOUS
+            state = hm.update(rd, idx, assign, best, nh)
+            hm_names = hm.names()
+            for r, hl in enumerate(lists):
+                rid = ids[base + r]
+                if hl:
+                    ref.setdefault(rid, []).extend(hl)
+                if rid not in ref:
+                    assert state[r, 0] == 0
+                    continue
+                cur = ref[rid]
+                want = cur[0] if len(cur) == 1 else aligner.best_hit(cur)
+                assert state[r, 0] == len(cur)
+                if not want:
+                    assert state[r, 4] == 1
+                else:
+                    assert state[r, 4] == 0 and hm_names[state[r, 3]] == want[0] and state[r, 2] == want[2]
+            base += m
+        rd.close()
+    assert len(hm) == len(ref)
