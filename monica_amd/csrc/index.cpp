@@ -13,6 +13,7 @@
 #include <zlib.h>
 
 #include "common.h"
+#include <parallel/algorithm>
 
 namespace mnc {
 
@@ -134,7 +135,7 @@ int cal_mid_occ(const mnc_index *idx, float f)
 // pairs (hash, occurrence word) -> sorted arrays + genome table + mid_occ
 int index_finalize(mnc_index *idx, std::vector<std::pair<uint64_t, uint64_t>> &pairs)
 {
-	std::sort(pairs.begin(), pairs.end());
+	__gnu_parallel::sort(pairs.begin(), pairs.end());      // (hash, occurrence word): a total order
 	idx->keys.clear(), idx->key_off.clear(), idx->pos.resize(pairs.size());
 	for (size_t i = 0; i < pairs.size(); ++i) {
 		if (i == 0 || pairs[i].first != pairs[i - 1].first) {
@@ -218,8 +219,26 @@ extern "C" int mnc_index_build_mem(int n_seq, const char *const *names, const ch
 			if (lens[i] < 0 || lens[i] > 0x7fffffffLL) { delete idx; set_error("contig %d too long", i); return MNC_ERR_UNSUPPORTED; }
 			idx->contig_name.emplace_back(names[i]);
 			idx->contig_len.push_back(lens[i]);
-			contig_minimizers(seqs[i], lens[i], w, k, (uint32_t)i, pairs);
 		}
+		// contigs are independent: sketch them on the host threads, longest first
+		std::vector<std::vector<std::pair<uint64_t, uint64_t>>> per(n_seq);
+		std::vector<int> order(n_seq);
+		for (int i = 0; i < n_seq; ++i) order[i] = i;
+		std::sort(order.begin(), order.end(), [&](int a, int b) { return lens[a] != lens[b] ? lens[a] > lens[b] : a < b; });
+		bool oom = false;
+#pragma omp parallel for schedule(dynamic, 1)
+		for (int j = 0; j < n_seq; ++j) {
+			const int i = order[j];
+			try {
+				per[i].reserve((size_t)(lens[i] / 5 + 16));
+				contig_minimizers(seqs[i], lens[i], w, k, (uint32_t)i, per[i]);
+			} catch (const std::bad_alloc &) { oom = true; }
+		}
+		if (oom) { delete idx; return MNC_ERR_NOMEM; }
+		size_t total = 0;
+		for (auto &v : per) total += v.size();
+		pairs.reserve(total);
+		for (auto &v : per) { pairs.insert(pairs.end(), v.begin(), v.end()); std::vector<std::pair<uint64_t, uint64_t>>().swap(v); }
 		index_finalize(idx, pairs);
 	} catch (const std::bad_alloc &) { delete idx; return MNC_ERR_NOMEM; }
 	*out = idx;

@@ -81,9 +81,12 @@ __device__ __forceinline__ int row_shift1(int v, int fill, int lr)
 	return lr == 0 ? fill : r;
 }
 
+// the builtin takes the condition as it is (the __any / __ballot wrappers go through an integer)
+__device__ __forceinline__ bool any64(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0; }
+
 __device__ __forceinline__ uint32_t row_ballot(bool pred, int row)
 {
-	return (uint32_t)(__ballot(pred) >> (row * RW));
+	return (uint32_t)(__builtin_amdgcn_ballot_w64(pred) >> (row * RW));
 }
 
 __device__ __forceinline__ void lds_order()
@@ -103,13 +106,20 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 {
 	constexpr int NBLK = PAST + 2;                                       // past + current + next
 	constexpr int RING = NBLK * RW;
-	__shared__ int2 s_pf_all[ROWS * DP_WAVES][RING];                     // {p, f}; p = -2 marks a segment start until set
-	__shared__ int2 s_xq_all[ROWS * DP_WAVES][RING];                     // {low 32 bits of x, query position}
-	__shared__ int32_t s_t_all[ROWS * DP_WAVES][RING], s_v_all[ROWS * DP_WAVES][RING];
+	static_assert((RING & (RING - 1)) == 0 && RW == 32, "ring slots are taken with a mask");
+	auto slot = [](int x) { return (int)((uint32_t)x & (uint32_t)(RING - 1)); };
+	// one block of LDS per read, so that a slot's fields sit at constant offsets from one address
+	struct RowLds {
+		int2 pf[RING];                                                   // {p, f}; p = -2 marks a segment start until set
+		int2 xq[RING];                                                   // {low 32 bits of x, query position}
+		int32_t t[RING], v[RING];
+	};
+	__shared__ RowLds s_rows[ROWS * DP_WAVES];
 	const int lane = threadIdx.x & 63, row = lane / RW, lr = lane % RW;
 	const int slot_row = (threadIdx.x >> 6) * ROWS + row;
-	int2 *s_pf = s_pf_all[slot_row], *s_xq = s_xq_all[slot_row];
-	int32_t *s_t = s_t_all[slot_row], *s_v = s_v_all[slot_row];
+	RowLds &L = s_rows[slot_row];
+	int2 *s_pf = L.pf, *s_xq = L.xq;
+	int32_t *s_t = L.t, *s_v = L.v;
 
 	const uint32_t li = blockIdx.x * (ROWS * DP_WAVES) + slot_row;
 	const bool has = li < count;
@@ -120,7 +130,9 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 	int32_t *gf = B.f + a_off, *gp = B.p + a_off, *gv = B.v + a_off, *gt = B.t + a_off;
 	const int span = KMER;
 	const int max_gap = B.max_gap, bw = B.bw, max_skip = B.max_skip, max_iter = B.max_iter;
-	const double avg_span = (double)(float)KMER;
+	__shared__ uint16_t s_gap[GAP_LUT];
+	for (int k = threadIdx.x; k < GAP_LUT; k += 64 * DP_WAVES) s_gap[k] = (uint16_t)B.gap_lut[k];
+	__syncthreads();
 
 	// block b of the read -> its ring slots: coordinates, segment-start flag, cleared DP fields
 	auto load_block = [&](int b) {
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 			const Anchor e = ga[idx];
 			const uint32_t hi = (uint32_t)(e.x >> 32);
 			const uint32_t phi = idx ? (uint32_t)(ga[idx - 1].x >> 32) : ~hi;
-			const int s = idx % RING;
+			const int s = slot(idx);
 			s_xq[s] = make_int2((int)(uint32_t)e.x, (int)(uint32_t)e.y);
 			s_pf[s] = make_int2(hi != phi ? -2 : -1, 0);
 			s_t[s] = 0, s_v[s] = 0;
@@ -147,14 +159,14 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 	int i = 0, seg = 0, jb = -1, max_f = span, max_j = -1, ns_prev = 0, ring_lo = 0;
 	uint32_t xi = active ? (uint32_t)s_xq[0].x : 0;
 	int qi = active ? s_xq[0].y : 0;
-	int pend_i = -1, pend_f = 0, pend_vp = 0;
-	while (__any(active)) {
+	const uint64_t last_lane = 1ULL << (row * RW + RW - 1);
+	while (any64(active)) {
 		// ---- one step: RW candidates j = jb - lr
 		const int j = jb - lr;
 		const int lo = max(seg, i - max_iter);
 		const bool inb = active && j >= lo;
 		const bool far = inb && j < ring_lo;                              // behind the ring: HBM
-		const int sj = (inb ? j : 0) % RING;
+		const int sj = slot(j);                                           // any slot will do for lanes outside [lo, jb]
 		int2 pf = s_pf[sj], xq = s_xq[sj];
 		if (far) {
 			const Anchor e = ga[j];
@@ -162,7 +174,7 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 			xq = make_int2((int)(uint32_t)e.x, (int)(uint32_t)e.y);
 		}
 		// operands of the next anchor, fetched early (used when this anchor completes)
-		const int sn = (i + 1) % RING;
+		const int sn = slot(i + 1);
 		const int2 nxq = s_xq[sn];
 		const int nflag = s_pf[sn].x;
 
@@ -174,65 +186,69 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 		const int dd = dr > dq ? dr - dq : dq - dr;
 		const bool ev = inwin && dr != 0 && dq > 0 && dq <= max_gap && dd <= bw;
 		const int mind = dq < dr ? dq : dr;
-		// gap cost (int)(dd * .01 * avg_span) + (ilog2(dd) >> 1): IEEE double products, as minimap2
-		const int gap = (int)((double)dd * .01 * avg_span) + (dd > 0 ? (31 - __clz(dd)) >> 1 : 0);
-		const int sc = ev ? (mind > span ? span : mind) - gap + fj : NEG;
+		// gap cost (int)(dd * .01 * avg_span) + (ilog2(dd) >> 1): a table the host fills with IEEE
+		// double products, as minimap2 evaluates it (dd <= bw < GAP_LUT wherever `ev` holds)
+		const int gap = s_gap[min(dd, GAP_LUT - 1)];
+		const int sc = (mind > span ? span : mind) - gap + fj;
+		// score and lane in one word: maxima of it break ties towards the first lane
+		const int key = ev ? sc * RW + (RW - 1 - lr) : INT32_MIN;
 		// t[p[j]] = i, then t[j] == i
 		const bool mark = ev && pj >= 0;
 		const bool mark_far = mark && pj < ring_lo;
-		if (mark && !mark_far) s_t[pj % RING] = i;
+		if (mark && !mark_far) s_t[slot(pj)] = i;
 		if (mark_far) gt[pj] = i;
-		const bool any_far = __any(far || mark_far);
+		const bool any_far = any64(far || mark_far);
 		if (any_far) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		lds_order();
 		int tj = s_t[sj];
-		if (far) tj = gt[j];
+		asm volatile("" : "+v"(tj));                                      // keep this a plain LDS read (no flat-pointer select)
+		if (any_far) { if (far) tj = gt[j]; }
 		const bool tflag = ev && tj == i;
-		// running maximum: strict '>' against everything before this lane
-		const int incl = row_incl_max(sc);
-		const int excl = max(row_shift1(incl, NEG, lr), max_f);
-		const bool improve = ev && sc > excl;
+		// running maximum, strict '>' against everything before this lane: keys are distinct and
+		// order equal scores by lane, so a lane beats all earlier ones iff it is the inclusive maximum
+		const int incl = row_incl_max(key);
+		const bool improve = ev && incl == key && sc > max_f;
 		// n_skip after each lane: maps x -> max(x + a, b) with (a,b) = (-1,0) on an improvement,
 		// (+1,-inf) on a seen non-improvement, identity otherwise; with S = prefix sum of a,
 		// the value is max(S, S + max_{k<=l, improve_k}(-S_k)).  The carry enters at lane 0.
 		int a = improve ? -1 : (tflag ? 1 : 0);
-		const int c0 = __builtin_amdgcn_readlane(ns_prev, RW - 1), c1 = __builtin_amdgcn_readlane(ns_prev, 2 * RW - 1);
-		if (lr == 0 && !fresh) a += row ? c1 : c0;
+		if (any64(active && !fresh)) {                                   // rare: an anchor needing a second step
+			const int c0 = __builtin_amdgcn_readlane(ns_prev, RW - 1), c1 = __builtin_amdgcn_readlane(ns_prev, 2 * RW - 1);
+			if (lr == 0 && !fresh) a += row ? c1 : c0;
+		}
 		const int S = row_incl_add(a);
 		const int M = row_incl_max(improve ? -S : NEG);
 		const int ns = max(S, S + M);
-		const bool brk = tflag && !improve && ns > max_skip;
-		const uint32_t bm = row_ballot(brk, row);
-		const int bl = bm ? __ffs((int)bm) - 1 : RW - 1;
-		// best candidate among the lanes the sequential loop reaches; first lane wins ties
-		const int mk = row_all_max(lr <= bl && ev ? sc * RW + (RW - 1 - lr) : INT32_MIN);
+		// first lane where the sequential loop breaks (lane RW-1 if none): one compare gives the mask
+		const uint32_t bm = row_ballot((tflag && !improve ? ns : INT32_MIN) > max_skip, row);
+		const int bl = __builtin_ctz(bm | 0x80000000u);
+		// best candidate among the lanes the sequential loop reaches (first lane wins ties) =
+		// the inclusive maximum at the break lane
+		const int mk = __builtin_amdgcn_ds_bpermute(((lane & RW) | bl) << 2, incl);
 		if ((mk >> 5) > max_f) max_f = mk >> 5, max_j = jb - (RW - 1 - (mk & (RW - 1)));
-		const uint32_t wm = row_ballot(inwin, row);
-		const bool done = active && (bm != 0 || (wm >> (RW - 1)) == 0 || jb - RW < lo);
+		const uint64_t wm = __builtin_amdgcn_ballot_w64(inwin);
+		const bool done = active && (bm != 0 || (wm & last_lane) == 0 || jb - RW < lo);
 		ns_prev = ns, fresh = false;
 		if (done) {
 			if (lr == 0) {
-				// v[] of the previous anchor completes now (its operand was fetched a step ago)
-				if (pend_i >= 0) s_v[pend_i % RING] = max(pend_f, pend_vp);
-				s_pf[i % RING] = make_int2(max_j, max_f);
-				lds_order();
-				pend_vp = max_j < 0 ? 0 : max_j >= ring_lo ? s_v[max_j % RING] : gv[max_j];
-				pend_i = i, pend_f = max_f;
+				// v[i] = max(f[i], v[p[i]]): the operand was written at an earlier step
+				s_pf[slot(i)] = make_int2(max_j, max_f);
+				const int vp = max_j < 0 ? 0 : max_j >= ring_lo ? s_v[slot(max_j)] : gv[max_j];
+				s_v[slot(i)] = max(max_f, vp);
 			}
 			++i;
 			if (i >= n) active = false;
 			xi = (uint32_t)nxq.x, qi = nxq.y;
 			if (nflag == -2) seg = i;
 			jb = i - 1, max_f = span, max_j = -1, fresh = true;
-			if (active && i % RW == 0) {                                  // entering block nb
-				const int nb = i / RW;
-				if (lr == 0) { s_v[pend_i % RING] = max(pend_f, pend_vp); pend_i = -1; }
+			if (active && (i & (RW - 1)) == 0) {                          // entering block nb
+				const int nb = i >> 5;
 				lds_order();
-				const int fi = (nb - 1) * RW + lr, fs = fi % RING;        // the block just completed -> HBM
+				const int fi = (nb - 1) * RW + lr, fs = slot(fi);        // the block just completed -> HBM
 				const int2 w = s_pf[fs];
 				gf[fi] = w.y, gp[fi] = w.x, gv[fi] = s_v[fs];
 				const int ob = nb - PAST - 1;                             // block about to lose its slots
-				if (ob >= 0) gt[ob * RW + lr] = s_t[(ob * RW + lr) % RING];
+				if (ob >= 0) gt[ob * RW + lr] = s_t[slot(ob * RW + lr)];
 				lds_order();
 				load_block(nb + 1);
 				ring_lo = max(0, nb - PAST) * RW;
@@ -240,12 +256,11 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 		} else if (active) jb -= RW;
 		lds_order();
 	}
-	if (lr == 0 && pend_i >= 0) s_v[pend_i % RING] = max(pend_f, pend_vp);
 	lds_order();
 	if (n > 0) {                                                         // the last (partial) block
 		const int fi = (n - 1) / RW * RW + lr;
 		if (fi < n) {
-			const int fs = fi % RING;
+			const int fs = slot(fi);
 			const int2 w = s_pf[fs];
 			gf[fi] = w.y, gp[fi] = w.x, gv[fi] = s_v[fs];
 		}
