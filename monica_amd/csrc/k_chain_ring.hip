@@ -101,6 +101,15 @@ __device__ __forceinline__ void lds_order()
 // the tests use to drive every look-back through the HBM fall-back).
 constexpr int DP_WAVES = 4;                   // waves per workgroup (no workgroup barrier is used)
 
+// first DPP step of an inclusive scan, out of place: lanes without a source lane combine with 0
+// (bound_ctrl), which is the identity for the non-negative keys and for sums
+__device__ __forceinline__ int max_shr1_from(int v)
+{
+	int r;
+	asm("s_nop 1\n\tv_max_i32_dpp %0, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=&v"(r) : "v"(v));
+	return r;
+}
+
 template <int PAST>
 __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, const uint32_t *list, uint32_t count)
 {
@@ -108,18 +117,16 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 	constexpr int RING = NBLK * RW;
 	static_assert((RING & (RING - 1)) == 0 && RW == 32, "ring slots are taken with a mask");
 	auto slot = [](int x) { return (int)((uint32_t)x & (uint32_t)(RING - 1)); };
-	// one block of LDS per read, so that a slot's fields sit at constant offsets from one address
-	struct RowLds {
-		int2 pf[RING];                                                   // {p, f}; p = -2 marks a segment start until set
-		int2 xq[RING];                                                   // {low 32 bits of x, query position}
-		int32_t t[RING], v[RING];
+	// one 24-byte record per ring slot: every field of a candidate comes from one address
+	struct Slot {
+		int p, f;                                                        // p = -2 marks a segment start until set
+		int x, q;                                                        // low 32 bits of x, query position
+		int t, v;
 	};
-	__shared__ RowLds s_rows[ROWS * DP_WAVES];
+	__shared__ Slot s_rows[ROWS * DP_WAVES][RING];
 	const int lane = threadIdx.x & 63, row = lane / RW, lr = lane % RW;
 	const int slot_row = (threadIdx.x >> 6) * ROWS + row;
-	RowLds &L = s_rows[slot_row];
-	int2 *s_pf = L.pf, *s_xq = L.xq;
-	int32_t *s_t = L.t, *s_v = L.v;
+	Slot *S = s_rows[slot_row];
 
 	const uint32_t li = blockIdx.x * (ROWS * DP_WAVES) + slot_row;
 	const bool has = li < count;
@@ -141,10 +148,9 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 			const Anchor e = ga[idx];
 			const uint32_t hi = (uint32_t)(e.x >> 32);
 			const uint32_t phi = idx ? (uint32_t)(ga[idx - 1].x >> 32) : ~hi;
-			const int s = slot(idx);
-			s_xq[s] = make_int2((int)(uint32_t)e.x, (int)(uint32_t)e.y);
-			s_pf[s] = make_int2(hi != phi ? -2 : -1, 0);
-			s_t[s] = 0, s_v[s] = 0;
+			Slot w;
+			w.p = hi != phi ? -2 : -1, w.f = 0, w.x = (int)(uint32_t)e.x, w.q = (int)(uint32_t)e.y, w.t = 0, w.v = 0;
+			S[slot(idx)] = w;
 		}
 	};
 	load_block(0);
@@ -155,34 +161,41 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 	// The predecessor window of anchor i is { j < i : same (strand, contig) segment,
 	// x_i - x_j <= max_gap, i - j <= max_iter }: contiguous because anchors are sorted, so it
 	// is tested per lane instead of keeping minimap2's running start index.
-	bool active = n > 0, fresh = true;
+	// Scores enter the scans as key = (score + KEY_BIAS) * 32 + (31 - lane) > 0 (a score is at
+	// least span + 1 - max gap cost > -KEY_BIAS), 0 = no candidate: maxima of keys break ties
+	// towards the first lane, and 0 is the identity the DPP scans fill in.
+	constexpr int KEY_BIAS = 256;
+	bool fresh = true;
 	int i = 0, seg = 0, jb = -1, max_f = span, max_j = -1, ns_prev = 0, ring_lo = 0;
-	uint32_t xi = active ? (uint32_t)s_xq[0].x : 0;
-	int qi = active ? s_xq[0].y : 0;
+	uint32_t xi = n > 0 ? (uint32_t)S[0].x : 0;
+	int qi = n > 0 ? S[0].q : 0;
 	const uint64_t last_lane = 1ULL << (row * RW + RW - 1);
-	while (any64(active)) {
+	for (;;) {
+		const bool active = i < n;
+		if (!any64(active)) break;
 		// ---- one step: RW candidates j = jb - lr
 		const int j = jb - lr;
 		const int lo = max(seg, i - max_iter);
 		const bool inb = active && j >= lo;
 		const bool far = inb && j < ring_lo;                              // behind the ring: HBM
-		const int sj = slot(j);                                           // any slot will do for lanes outside [lo, jb]
-		int2 pf = s_pf[sj], xq = s_xq[sj];
+		const Slot *c = S + slot(j);                                      // any slot will do for lanes outside [lo, jb]
+		int pj = c->p, fj = c->f, xj = c->x, qj = c->q;
 		if (far) {
-			const Anchor e = ga[j];
-			pf = make_int2(gp[j], gf[j]);
-			xq = make_int2((int)(uint32_t)e.x, (int)(uint32_t)e.y);
+			const Anchor e = ga[(uint32_t)j];
+			pj = gp[(uint32_t)j], fj = gf[(uint32_t)j];
+			xj = (int)(uint32_t)e.x, qj = (int)(uint32_t)e.y;
 		}
 		// operands of the next anchor, fetched early (used when this anchor completes)
-		const int sn = slot(i + 1);
-		const int2 nxq = s_xq[sn];
-		const int nflag = s_pf[sn].x;
+		const Slot *nx = S + slot(i + 1);
+		const int nxx = nx->x, nxq = nx->q, nflag = nx->p;
 
-		const int pj = pf.x, fj = pf.y;
-		const uint32_t dru = xi - (uint32_t)xq.x;
-		const bool inwin = inb && dru <= (uint32_t)max_gap;
+		uint32_t dru = xi - (uint32_t)xj;
 		const int dr = (int)dru;
-		const int dq = qi - xq.y;
+		if (!inb) dru = 0xffffffffu;
+		asm volatile("" : "+v"(dru));                                     // one compare gives the window mask
+		const bool inwin = dru <= (uint32_t)max_gap;
+		const uint64_t wm = __builtin_amdgcn_ballot_w64(inwin);
+		const int dq = qi - qj;
 		const int dd = dr > dq ? dr - dq : dq - dr;
 		const bool ev = inwin && dr != 0 && dq > 0 && dq <= max_gap && dd <= bw;
 		const int mind = dq < dr ? dq : dr;
@@ -190,23 +203,22 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 		// double products, as minimap2 evaluates it (dd <= bw < GAP_LUT wherever `ev` holds)
 		const int gap = s_gap[min(dd, GAP_LUT - 1)];
 		const int sc = (mind > span ? span : mind) - gap + fj;
-		// score and lane in one word: maxima of it break ties towards the first lane
-		const int key = ev ? sc * RW + (RW - 1 - lr) : INT32_MIN;
+		const int key = ev ? (sc + KEY_BIAS) * RW + (RW - 1 - lr) : 0;
 		// t[p[j]] = i, then t[j] == i
 		const bool mark = ev && pj >= 0;
 		const bool mark_far = mark && pj < ring_lo;
-		if (mark && !mark_far) s_t[slot(pj)] = i;
-		if (mark_far) gt[pj] = i;
+		if (mark && !mark_far) S[slot(pj)].t = i;
+		if (mark_far) gt[(uint32_t)pj] = i;
 		const bool any_far = any64(far || mark_far);
 		if (any_far) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		lds_order();
-		int tj = s_t[sj];
+		int tj = c->t;
 		asm volatile("" : "+v"(tj));                                      // keep this a plain LDS read (no flat-pointer select)
-		if (any_far) { if (far) tj = gt[j]; }
+		if (any_far) { if (far) tj = gt[(uint32_t)j]; }
 		const bool tflag = ev && tj == i;
 		// running maximum, strict '>' against everything before this lane: keys are distinct and
 		// order equal scores by lane, so a lane beats all earlier ones iff it is the inclusive maximum
-		const int incl = row_incl_max(key);
+		const int incl = max_bcast15(max_shr8(max_shr4(max_shr2(max_shr1_from(key)))));
 		const bool improve = ev && incl == key && sc > max_f;
 		// n_skip after each lane: maps x -> max(x + a, b) with (a,b) = (-1,0) on an improvement,
 		// (+1,-inf) on a seen non-improvement, identity otherwise; with S = prefix sum of a,
@@ -216,39 +228,41 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 			const int c0 = __builtin_amdgcn_readlane(ns_prev, RW - 1), c1 = __builtin_amdgcn_readlane(ns_prev, 2 * RW - 1);
 			if (lr == 0 && !fresh) a += row ? c1 : c0;
 		}
-		const int S = row_incl_add(a);
-		const int M = row_incl_max(improve ? -S : NEG);
-		const int ns = max(S, S + M);
+		const int Sa = row_incl_add(a);
+		const int M = row_incl_max(improve ? -Sa : NEG);
+		const int ns = max(Sa, Sa + M);
 		// first lane where the sequential loop breaks (lane RW-1 if none): one compare gives the mask
-		const uint32_t bm = row_ballot((tflag && !improve ? ns : INT32_MIN) > max_skip, row);
+		int nsb = tflag && !improve ? ns : INT32_MIN;
+		asm volatile("" : "+v"(nsb));
+		const uint32_t bm = row_ballot(nsb > max_skip, row);
 		const int bl = __builtin_ctz(bm | 0x80000000u);
 		// best candidate among the lanes the sequential loop reaches (first lane wins ties) =
 		// the inclusive maximum at the break lane
 		const int mk = __builtin_amdgcn_ds_bpermute(((lane & RW) | bl) << 2, incl);
-		if ((mk >> 5) > max_f) max_f = mk >> 5, max_j = jb - (RW - 1 - (mk & (RW - 1)));
-		const uint64_t wm = __builtin_amdgcn_ballot_w64(inwin);
+		const int best = (mk >> 5) - KEY_BIAS;                            // -KEY_BIAS when there was no candidate
+		if (best > max_f) max_f = best, max_j = jb - (RW - 1 - (mk & (RW - 1)));
 		const bool done = active && (bm != 0 || (wm & last_lane) == 0 || jb - RW < lo);
 		ns_prev = ns, fresh = false;
 		if (done) {
 			if (lr == 0) {
 				// v[i] = max(f[i], v[p[i]]): the operand was written at an earlier step
-				s_pf[slot(i)] = make_int2(max_j, max_f);
-				const int vp = max_j < 0 ? 0 : max_j >= ring_lo ? s_v[slot(max_j)] : gv[max_j];
-				s_v[slot(i)] = max(max_f, vp);
+				Slot *me = S + slot(i);
+				me->p = max_j, me->f = max_f;
+				const int vp = max_j < 0 ? 0 : max_j >= ring_lo ? S[slot(max_j)].v : gv[(uint32_t)max_j];
+				me->v = max(max_f, vp);
 			}
 			++i;
-			if (i >= n) active = false;
-			xi = (uint32_t)nxq.x, qi = nxq.y;
+			xi = (uint32_t)nxx, qi = nxq;
 			if (nflag == -2) seg = i;
 			jb = i - 1, max_f = span, max_j = -1, fresh = true;
-			if (active && (i & (RW - 1)) == 0) {                          // entering block nb
+			if (i < n && (i & (RW - 1)) == 0) {                           // entering block nb
 				const int nb = i >> 5;
 				lds_order();
-				const int fi = (nb - 1) * RW + lr, fs = slot(fi);        // the block just completed -> HBM
-				const int2 w = s_pf[fs];
-				gf[fi] = w.y, gp[fi] = w.x, gv[fi] = s_v[fs];
+				const int fi = (nb - 1) * RW + lr;                        // the block just completed -> HBM
+				const Slot *w = S + slot(fi);
+				gf[fi] = w->f, gp[fi] = w->p, gv[fi] = w->v;
 				const int ob = nb - PAST - 1;                             // block about to lose its slots
-				if (ob >= 0) gt[ob * RW + lr] = s_t[slot(ob * RW + lr)];
+				if (ob >= 0) gt[ob * RW + lr] = S[slot(ob * RW + lr)].t;
 				lds_order();
 				load_block(nb + 1);
 				ring_lo = max(0, nb - PAST) * RW;
@@ -260,9 +274,8 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 	if (n > 0) {                                                         // the last (partial) block
 		const int fi = (n - 1) / RW * RW + lr;
 		if (fi < n) {
-			const int fs = slot(fi);
-			const int2 w = s_pf[fs];
-			gf[fi] = w.y, gp[fi] = w.x, gv[fi] = s_v[fs];
+			const Slot *w = S + slot(fi);
+			gf[fi] = w->f, gp[fi] = w->p, gv[fi] = w->v;
 		}
 	}
 }
