@@ -180,6 +180,7 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 		const bool far = inb && j < ring_lo;                              // behind the ring: HBM
 		const Slot *c = S + slot(j);                                      // any slot will do for lanes outside [lo, jb]
 		int pj = c->p, fj = c->f, xj = c->x, qj = c->q;
+		asm volatile("" : "+v"(pj), "+v"(fj), "+v"(xj), "+v"(qj));     // plain LDS reads (no flat-pointer select with the HBM path)
 		if (far) {
 			const Anchor e = ga[(uint32_t)j];
 			pj = gp[(uint32_t)j], fj = gf[(uint32_t)j];
