@@ -282,17 +282,35 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 }
 
 // ================================================================ K5: backtrack in LDS
-// word layout: bits 0-15 p, 16-31 f, 32-47 mark, 48-63 v
+// minimap2 backtracks best-first: chain ends ordered by peak score, each walked from its peak
+// towards the root, stopping at the first anchor an earlier walk has marked (rejected walks
+// mark too).  An anchor is therefore taken by the best-ranked start among its descendants
+// (itself included): owner(x) = min rank over the starts in x's subtree of the p[] forest, and
+// the walk of rank e covers exactly the anchors it owns -- a path from its start upwards.
+// Owners come from one backward sweep (p[x] < x): a block of 32 anchors first settles its
+// in-block paths by pointer doubling, then hands its owners to the parents in earlier blocks.
+// Counts and the match / block lengths of a chain are sums over its (parent, child) pairs, so
+// they are accumulated per anchor as well.  Nothing here is sequential in the chain length.
+//
+// LDS per anchor: word0 = p | owner << 16 (during (A)-(C) the high half is the "is a
+// predecessor" flag), word1 = f | v << 16, x low word, 16-bit query position; per read 64
+// chain-end keys and 64 accumulators.  Reads with more than 64 chain ends take the
+// sequential walk below instead.
+constexpr int TAIL_ENDS = 64;
+constexpr uint32_t OWN_NONE = 0xffffu;
+
 __global__ __launch_bounds__(64) void mnc_chain_tail(Batch B, const uint32_t *list, uint32_t count, int NM)
 {
 	extern __shared__ __align__(16) uint8_t smem[];
 	const int lane = threadIdx.x, row = lane / RW, lr = lane % RW;
-	uint8_t *rbase = smem + (size_t)row * ((size_t)NM * 14 + 64 * 8);
-	uint64_t *W = reinterpret_cast<uint64_t*>(rbase);                  // NM words
-	uint32_t *xlo = reinterpret_cast<uint32_t*>(rbase + (size_t)NM * 8);
-	uint16_t *qp = reinterpret_cast<uint16_t*>(rbase + (size_t)NM * 12);
-	uint64_t *ubuf = reinterpret_cast<uint64_t*>(rbase + (size_t)NM * 14);   // 64 chain-end keys
-	uint16_t *W16 = reinterpret_cast<uint16_t*>(W);
+	uint8_t *rbase = smem + (size_t)row * ((size_t)NM * 14 + TAIL_ENDS * 32);
+	uint32_t *W0 = reinterpret_cast<uint32_t*>(rbase);                  // p | owner << 16
+	uint32_t *W1 = W0 + NM;                                             // f | v << 16
+	uint32_t *xlo = W1 + NM;
+	uint16_t *qp = reinterpret_cast<uint16_t*>(xlo + NM);
+	uint64_t *ubuf = reinterpret_cast<uint64_t*>(rbase + (size_t)NM * 14);   // TAIL_ENDS chain-end keys
+	uint32_t *acc = reinterpret_cast<uint32_t*>(ubuf + TAIL_ENDS);      // TAIL_ENDS x {cnt, mlen, blen, top, stop f, -}
+	uint16_t *H0 = reinterpret_cast<uint16_t*>(W0);
 
 	const uint32_t li = blockIdx.x * ROWS + row;
 	const bool has = li < count;
@@ -301,6 +319,7 @@ __global__ __launch_bounds__(64) void mnc_chain_tail(Batch B, const uint32_t *li
 	const int n = has ? (int)(B.an_off[r + 1] - a_off) : 0;
 	const Anchor *ga = B.a + a_off;
 	const int span = KMER;
+	const int n_up = (n + RW - 1) / RW * RW;
 
 	// ---- load the DP result of the read
 	for (int idx = lr; idx < n; idx += RW) {
@@ -308,68 +327,155 @@ __global__ __launch_bounds__(64) void mnc_chain_tail(Batch B, const uint32_t *li
 		const int p = B.p[a_off + idx];
 		xlo[idx] = (uint32_t)e.x;
 		qp[idx] = (uint16_t)e.y;
-		W[idx] = (uint64_t)(p < 0 ? NONE16 : (uint32_t)p) | (uint64_t)(uint32_t)B.f[a_off + idx] << 16 |
-		         (uint64_t)(uint32_t)B.v[a_off + idx] << 48;
+		W0[idx] = p < 0 ? NONE16 : (uint32_t)p;
+		W1[idx] = ((uint32_t)B.f[a_off + idx] & 0xffffu) | (uint32_t)B.v[a_off + idx] << 16;
 	}
 	lds_order();
 
 	// (A) which anchors are somebody's predecessor
 	for (int idx = lr; idx < n; idx += RW) {
-		const uint32_t p = (uint32_t)W[idx] & 0xffffu;
-		if (p != NONE16) W16[4 * p + 2] = 1;
+		const uint32_t p = W0[idx] & 0xffffu;
+		if (p != NONE16) H0[2 * p + 1] = 1;
 	}
 	lds_order();
 	// (B) chain ends with peak >= min_sc; walk each back to its peak
 	int n_u = 0;
 	uint64_t *gu = B.u + a_off;
-	const int n_up = (n + RW - 1) / RW * RW;
 	for (int base = 0; base < n_up; base += RW) {
 		const int idx = base + lr;
 		bool is_end = false;
 		uint64_t key = 0;
 		if (idx < n) {
-			uint64_t w = W[idx];
-			is_end = ((uint32_t)(w >> 32) & 0xffffu) == 0 && (int)(w >> 48) >= B.min_sc;
+			uint32_t w0 = W0[idx], w1 = W1[idx];
+			is_end = (w0 >> 16) == 0 && (int)(w1 >> 16) >= B.min_sc;
 			if (is_end) {
 				int jj = idx;
-				while ((uint32_t)((uint32_t)w >> 16) < (uint32_t)(w >> 48)) {     // f < v
-					const uint32_t p = (uint32_t)w & 0xffffu;
+				while ((w1 & 0xffffu) < (w1 >> 16)) {                          // f < v
+					const uint32_t p = w0 & 0xffffu;
 					if (p == NONE16) { jj = -1; break; }
-					jj = (int)p, w = W[jj];
+					jj = (int)p, w0 = W0[jj], w1 = W1[jj];
 				}
-				if (jj < 0) jj = idx, w = W[idx];
-				key = (uint64_t)((uint32_t)w >> 16) << 32 | (uint32_t)jj;
+				if (jj < 0) jj = idx, w1 = W1[idx];
+				key = (uint64_t)(w1 & 0xffffu) << 32 | (uint32_t)jj;
 			}
 		}
 		const uint32_t bits = row_ballot(is_end, row);
 		if (is_end) {
 			const int pos = n_u + __popc(bits & ((1u << lr) - 1u));
-			if (pos < 64) ubuf[pos] = key;
+			if (pos < TAIL_ENDS) ubuf[pos] = key;
 			gu[pos] = key;
 		}
 		n_u += __popc(bits);
 	}
 	lds_order();
-	// (C) order the ends: score descending, then index descending (keys are distinct)
-	const bool u_in_lds = n_u <= 64;
+	const bool u_in_lds = n_u <= TAIL_ENDS;
+	ChainRec *out = B.chains_tmp + a_off / 3;
+
 	if (u_in_lds) {
-		uint64_t mine[2];
-		int rank[2];
+		// (C) order the ends: score descending, then index descending; equal keys (two ends
+		// behind one peak) keep their order, so ranks are distinct
+		{
+			uint64_t mine[2];
+			int rank[2];
 #pragma unroll
-		for (int s = 0; s < 2; ++s) {
-			const int e = lr + RW * s;
-			mine[s] = e < n_u ? ubuf[e] : 0, rank[s] = 0;
+			for (int s = 0; s < 2; ++s) {
+				const int e = lr + RW * s;
+				mine[s] = e < n_u ? ubuf[e] : 0, rank[s] = 0;
+			}
+			for (int k = 0; k < n_u; ++k) {
+				const uint64_t o = ubuf[k];
+#pragma unroll
+				for (int s = 0; s < 2; ++s) rank[s] += o > mine[s] || (o == mine[s] && k < lr + RW * s);
+			}
+			lds_order();
+#pragma unroll
+			for (int s = 0; s < 2; ++s) if (lr + RW * s < n_u) ubuf[rank[s]] = mine[s];
 		}
-		for (int k = 0; k < n_u; ++k) {
-			const uint64_t o = ubuf[k];
-#pragma unroll
-			for (int s = 0; s < 2; ++s) rank[s] += o > mine[s];
+		// (D) no owners yet; clear the accumulators
+		for (int idx = lr; idx < n; idx += RW) H0[2 * idx + 1] = (uint16_t)OWN_NONE;
+		for (int k = lr; k < TAIL_ENDS * 6; k += RW) acc[k] = 0;
+		lds_order();
+		// (E1) a start owns itself unless a better rank starts there too
+		for (int e = lr; e < n_u; e += RW) {
+			const uint32_t sidx = (uint32_t)ubuf[e];
+			atomicMin(&W0[sidx], (uint32_t)e << 16 | (W0[sidx] & 0xffffu));
 		}
 		lds_order();
+		// (E2) owners, blocks from the last to the first
+		for (int base = n_up - RW; base >= 0; base -= RW) {
+			const int x = base + lr;
+			const uint32_t w0 = x < n ? W0[x] : (OWN_NONE << 16 | NONE16);
+			const uint32_t px = w0 & 0xffffu;
+			uint32_t own = w0 >> 16;
+			if (row_ballot(own != OWN_NONE, row) == 0) continue;             // nothing to hand on in this block
+			int jl = px != NONE16 && (int)px >= base ? (int)px - base : -1;  // lane of the in-block parent
 #pragma unroll
-		for (int s = 0; s < 2; ++s) if (lr + RW * s < n_u) ubuf[rank[s]] = mine[s];
-	} else if (lr == 0 && n_u > 0) {
-		// rare: many chain ends; heap-sort ascending in HBM and read it backwards below
+			for (int round = 0; round < 5; ++round) {
+				// hand the owner to the ancestor 2^round steps up, then jump twice as far
+				const int src = (lane & RW) | (jl < 0 ? lr : jl);
+				const uint32_t tp = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)px);      // p of that ancestor
+				const int jj = __builtin_amdgcn_ds_bpermute(src << 2, jl);
+				if (jl >= 0 && own != OWN_NONE) atomicMin(&W0[base + jl], own << 16 | tp);
+				lds_order();
+				own = x < n ? W0[x] >> 16 : OWN_NONE;
+				jl = jl < 0 ? -1 : jj;
+			}
+			if (px != NONE16 && (int)px < base && own != OWN_NONE)
+				atomicMin(&W0[px], own << 16 | (W0[px] & 0xffffu));
+			lds_order();
+		}
+		// (E3) per-anchor share of its chain: count, (parent, child) lengths, top anchor
+		for (int x = lr; x < n; x += RW) {
+			const uint32_t w0 = W0[x], own = w0 >> 16, px = w0 & 0xffffu;
+			if (own == OWN_NONE) continue;
+			uint32_t *A = acc + own * 6;
+			atomicAdd(&A[0], 1u);
+			const bool same = px != NONE16 && (W0[px] >> 16) == own;
+			if (same) {
+				const int tl = (int)(xlo[x] - xlo[px]), ql = (int)qp[x] - (int)qp[px];
+				atomicAdd(&A[1], (uint32_t)(tl > span && ql > span ? span : tl < ql ? tl : ql));
+				atomicAdd(&A[2], (uint32_t)(tl > ql ? tl : ql));
+			} else {
+				A[3] = (uint32_t)x;                                            // the walk stops above this anchor
+				A[4] = px == NONE16 ? 0xffffffffu : (W1[px] & 0xffffu);
+			}
+		}
+		lds_order();
+		// (E4) chain records in rank order
+		int k = 0;
+		for (int e0 = 0; e0 < n_u; e0 += RW) {
+			const int e = e0 + lr;
+			bool ok = false;
+			uint32_t cnt = 0, sidx = 0;
+			int score = 0;
+			if (e < n_u) {
+				const uint64_t key = ubuf[e];
+				const int peak = (int)(key >> 32);
+				sidx = (uint32_t)key;
+				const uint32_t *A = acc + e * 6;
+				cnt = A[0];
+				score = A[4] == 0xffffffffu ? peak : peak - (int)A[4];
+				ok = (W0[sidx] >> 16) == (uint32_t)e && (int)cnt >= B.min_cnt && (A[4] == 0xffffffffu || score >= B.min_sc);
+			}
+			const uint32_t bits = row_ballot(ok, row);
+			if (ok) {
+				const uint32_t *A = acc + e * 6;
+				const int kk = k + __popc(bits & ((1u << lr) - 1u));
+				ChainRec c;
+				const Anchor af = ga[A[3]], al = ga[sidx];
+				c.x0 = af.x, c.y0 = af.y, c.x1 = al.x, c.y1 = al.y;
+				c.score = score, c.cnt = (int)cnt, c.mlen = span + (int)A[1], c.blen = span + (int)A[2], c.as = 0, c.pad = kk;
+				out[kk] = c;
+			}
+			k += __popc(bits);
+		}
+		if (lr == 0 && has) B.n_chain[r] = k;
+		return;
+	}
+
+	// ---- rare: more than TAIL_ENDS chain ends.  Heap-sort them in HBM (ascending; read
+	// backwards) and walk sequentially on the half's first lane.
+	if (lr == 0 && n_u > 0) {
 		for (int start = n_u / 2 - 1; start >= 0; --start) {
 			int root = start;
 			for (;;) {
@@ -394,24 +500,21 @@ __global__ __launch_bounds__(64) void mnc_chain_tail(Batch B, const uint32_t *li
 			}
 		}
 	}
-	// (D) clear the marks: from here on they mean "used by a chain"
-	for (int idx = lr; idx < n; idx += RW) W16[4 * idx + 2] = 0;
+	for (int idx = lr; idx < n; idx += RW) H0[2 * idx + 1] = 0;           // marks now mean "used by a chain"
 	lds_order();
-	// (E) best-first backtrack by the half's first lane; chain records in backtrack order
 	if (lr == 0 && has) {
-		ChainRec *out = B.chains_tmp + a_off / 3;
 		int k = 0;
 		for (int e = 0; e < n_u; ++e) {
-			const uint64_t key = u_in_lds ? ubuf[e] : gu[n_u - 1 - e];
+			const uint64_t key = gu[n_u - 1 - e];
 			const int peak = (int)(key >> 32);
 			const int last = (int)(uint32_t)key;
 			int j = last, first = last, cnt = 0, mlen = span, blen = span, score = -1;
 			uint32_t nx = 0;
 			int nq = 0;
 			for (;;) {
-				const uint64_t w = W[j];
-				if (cnt > 0 && ((uint32_t)(w >> 32) & 0xffffu) != 0) {       // reached a used anchor
-					const int rest = peak - (int)((uint32_t)w >> 16);
+				const uint32_t w0 = W0[j];
+				if (cnt > 0 && (w0 >> 16) != 0) {                              // reached a used anchor
+					const int rest = peak - (int)(W1[j] & 0xffffu);
 					if (rest >= B.min_sc) score = rest;
 					break;
 				}
@@ -422,9 +525,9 @@ __global__ __launch_bounds__(64) void mnc_chain_tail(Batch B, const uint32_t *li
 					blen += tl > ql ? tl : ql;
 					mlen += tl > span && ql > span ? span : tl < ql ? tl : ql;
 				}
-				W16[4 * j + 2] = 1;
+				H0[2 * j + 1] = 1;
 				nx = cx, nq = cq, first = j, ++cnt;
-				const uint32_t p = (uint32_t)w & 0xffffu;
+				const uint32_t p = w0 & 0xffffu;
 				if (p == NONE16) { score = peak; break; }
 				j = (int)p;
 			}
@@ -449,7 +552,7 @@ int chain_tail_prepare(size_t max_lds)
 	return MNC_OK;
 }
 
-size_t chain_tail_lds_bytes(int NM) { return (size_t)ROWS * ((size_t)NM * 14 + 64 * 8); }
+size_t chain_tail_lds_bytes(int NM) { return (size_t)ROWS * ((size_t)NM * 14 + TAIL_ENDS * 32); }
 
 void launch_chain_dp_ring(const Batch &B, const uint32_t *list, uint32_t count, int stress, hipStream_t st)
 {
