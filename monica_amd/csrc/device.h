@@ -93,6 +93,7 @@ struct Batch {
 	const int32_t *contig_genome;
 	int mid_occ;
 	int n_genomes;
+	int rid_bits, rpos_bits;      // bits of a contig id / a contig position; 0: anchors do not pack into 64 bits
 	// ---- parameters
 	int min_cnt, min_sc, bw, max_gap, max_skip, max_iter, best_n, seed;
 	int max_join_long, max_join_short, min_join_flank_sc;

@@ -520,6 +520,17 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	B.table = e->didx->table, B.filter = e->didx->filter, B.disp = e->didx->disp, B.positions = e->didx->positions;
 	B.region_bits = e->didx->region_bits, B.disp_bits = e->didx->disp_bits;
 	B.contig_genome = e->didx->contig_genome, B.mid_occ = idx->mid_occ, B.n_genomes = (int)idx->genome_name.size();
+	{
+		// an anchor is (strand, contig, position, tandem flag, query position < 2^20): when that
+		// fits 64 bits the sort works on packed words (k_sort.hip)
+		int64_t longest = 1;
+		for (int64_t l : idx->contig_len) longest = std::max(longest, l);
+		int rb = 1, pb = 1;
+		while ((1LL << rb) < (int64_t)idx->contig_name.size()) ++rb;
+		while ((1LL << pb) < longest) ++pb;
+		const bool fits = 1 + rb + pb + 21 <= 64;
+		B.rid_bits = fits ? rb : 0, B.rpos_bits = fits ? pb : 0;
+	}
 	const MapParams &P = idx->par;
 	B.min_cnt = P.min_cnt, B.min_sc = P.min_chain_score, B.bw = P.bw, B.max_gap = P.max_gap, B.max_skip = P.max_chain_skip;
 	B.max_iter = P.max_chain_iter, B.best_n = P.best_n, B.seed = P.seed, B.max_join_long = P.max_join_long;

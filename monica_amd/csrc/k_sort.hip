@@ -24,16 +24,15 @@ __device__ __forceinline__ bool anchor_less(const Anchor &a, const Anchor &b)
 template <class Ptr>
 __device__ void bitonic_sort(Ptr s, int n, int tid)
 {
-	int npad = 2;
-	while (npad < n) npad <<= 1;
-	const int half_n = npad >> 1;
-	for (int h = 2; h <= npad; h <<= 1) {
-		// flip: i <-> block_end - (i - block_start)
+	int lg = 1;
+	while ((1 << lg) < n) ++lg;
+	const int half_n = 1 << (lg - 1);
+	for (int lh = 1; lh <= lg; ++lh) {                              // h = 1 << lh
 		{
-			const int hh = h >> 1;
+			const int lhh = lh - 1, hh = 1 << lhh;                     // flip: i <-> block_end - (i - block_start)
 			for (int t = tid; t < half_n; t += SO_THREADS) {
-				const int q = (t / hh) * h, o = t % hh;
-				const int x = q + o, y = q + h - 1 - o;
+				const int q = (t >> lhh) << lh, o = t & (hh - 1);
+				const int x = q + o, y = q + (hh << 1) - 1 - o;
 				if (y < n) {
 					Anchor ax = s[x], ay = s[y];
 					if (anchor_less(ay, ax)) s[x] = ay, s[y] = ax;
@@ -41,9 +40,10 @@ __device__ void bitonic_sort(Ptr s, int n, int tid)
 			}
 			__syncthreads();
 		}
-		for (int hh = h >> 2; hh > 0; hh >>= 1) {       // disperse: i <-> i + hh
+		for (int lhh = lh - 2; lhh >= 0; --lhh) {                      // disperse: i <-> i + hh
+			const int hh = 1 << lhh;
 			for (int t = tid; t < half_n; t += SO_THREADS) {
-				const int q = (t / hh) * (hh << 1), o = t % hh;
+				const int q = (t >> lhh) << (lhh + 1), o = t & (hh - 1);
 				const int x = q + o, y = x + hh;
 				if (y < n) {
 					Anchor ax = s[x], ay = s[y];
@@ -55,12 +55,70 @@ __device__ void bitonic_sort(Ptr s, int n, int tid)
 	}
 }
 
+// ---------------------------------------------------------------- packed anchors
+// (x, y) order = (strand, contig, reference position, tandem flag, query position): with few
+// enough contigs all of it fits one 64-bit word (Batch::rid_bits / rpos_bits), which halves
+// the LDS traffic of the network and makes a compare-exchange one 64-bit compare.
+__device__ __forceinline__ uint64_t pack_anchor(const Anchor &e, int rid_bits, int rpos_bits)
+{
+	const uint64_t strand = e.x >> 63, rid = e.x << 1 >> 33, rpos = (uint32_t)e.x;
+	const uint64_t flag = e.y >> 42 & 1ULL, qpos = (uint32_t)e.y & 0xfffffu;
+	return (((strand << rid_bits | rid) << rpos_bits | rpos) << 21) | flag << 20 | qpos;
+}
+
+__device__ __forceinline__ Anchor unpack_anchor(uint64_t w, int rid_bits, int rpos_bits)
+{
+	Anchor e;
+	const uint64_t hi = w >> 21;
+	const uint64_t rpos = hi & ((1ULL << rpos_bits) - 1ULL), rid = hi >> rpos_bits & ((1ULL << rid_bits) - 1ULL);
+	const uint64_t strand = hi >> (rpos_bits + rid_bits) & 1ULL;
+	e.x = strand << 63 | rid << 32 | rpos;
+	e.y = (w >> 20 & 1ULL) << 42 | (uint64_t)KMER << 32 | (w & 0xfffffULL);
+	return e;
+}
+
+__device__ void bitonic_sort_u64(uint64_t *s, int n, int tid)
+{
+	int lg = 1;
+	while ((1 << lg) < n) ++lg;
+	const int half_n = 1 << (lg - 1);
+	for (int lh = 1; lh <= lg; ++lh) {                              // h = 1 << lh
+		{
+			const int lhh = lh - 1, hh = 1 << lhh;                     // flip: i <-> block_end - (i - block_start)
+			for (int t = tid; t < half_n; t += SO_THREADS) {
+				const int q = (t >> lhh) << lh, o = t & (hh - 1);
+				const int x = q + o, y = q + (hh << 1) - 1 - o;
+				if (y < n) {
+					const uint64_t ax = s[x], ay = s[y];
+					if (ay < ax) s[x] = ay, s[y] = ax;
+				}
+			}
+			__syncthreads();
+		}
+		for (int lhh = lh - 2; lhh >= 0; --lhh) {                      // disperse: i <-> i + hh
+			const int hh = 1 << lhh;
+			for (int t = tid; t < half_n; t += SO_THREADS) {
+				const int q = (t >> lhh) << (lhh + 1), o = t & (hh - 1);
+				const int x = q + o, y = x + hh;
+				if (y < n) {
+					const uint64_t ax = s[x], ay = s[y];
+					if (ay < ax) s[x] = ay, s[y] = ax;
+				}
+			}
+			__syncthreads();
+		}
+	}
+}
+
 // `list`/`count` = the reads of one size class (at most NM anchors each; NM == 0: the class
-// of reads too large for LDS, sorted in their HBM segment); LDS tile = NM anchors.
+// of reads too large for LDS, sorted in their HBM segment); LDS tile = NM anchors (PACKED: NM
+// 64-bit words).
+template <bool PACKED>
 __global__ __launch_bounds__(SO_THREADS) void mnc_expand_sort(Batch B, const uint32_t *list, uint32_t count, int NM)
 {
 	extern __shared__ __align__(16) uint8_t so_smem[];
 	Anchor *s_a = reinterpret_cast<Anchor*>(so_smem);
+	uint64_t *s_w = reinterpret_cast<uint64_t*>(so_smem);
 	__shared__ int s_scan[SO_THREADS / 64];
 
 	if (blockIdx.x >= count) return;
@@ -74,6 +132,7 @@ __global__ __launch_bounds__(SO_THREADS) void mnc_expand_sort(Batch B, const uin
 	if (n64 <= 0) return;
 	const int n = (int)n64;
 	const bool in_lds = n <= NM;
+	const int rid_bits = B.rid_bits, rpos_bits = B.rpos_bits;
 	Anchor *g = B.a + a_off;
 	const HitRec *hits = B.hits + off;
 
@@ -85,7 +144,7 @@ __global__ __launch_bounds__(SO_THREADS) void mnc_expand_sort(Batch B, const uin
 		h.val = 0, h.qinfo = 0, h.cnt = 0;
 		if (i < nh) h = hits[i];
 		const int cnt = (int)(h.cnt & 0x7fffffffu);
-		// inclusive scan inside the wave, then across the 4 waves
+		// inclusive scan inside the wave, then across the waves
 		int inc = cnt;
 #pragma unroll
 		for (int d = 1; d < 64; d <<= 1) {
@@ -116,7 +175,9 @@ __global__ __launch_bounds__(SO_THREADS) void mnc_expand_sort(Batch B, const uin
 					e.y = (uint64_t)KMER << 32 | (uint32_t)(qlen - ((int)q_pos + 1 - KMER) - 1);
 				}
 				e.y |= flags;
-				if (in_lds) s_a[pos + k] = e; else g[pos + k] = e;
+				if (!in_lds) g[pos + k] = e;
+				else if (PACKED) s_w[pos + k] = pack_anchor(e, rid_bits, rpos_bits);
+				else s_a[pos + k] = e;
 			}
 		}
 		base += all;
@@ -126,24 +187,33 @@ __global__ __launch_bounds__(SO_THREADS) void mnc_expand_sort(Batch B, const uin
 	__syncthreads();
 
 	// ---- sort by (x, y)
-	if (in_lds) {
+	if (!in_lds) {
+		bitonic_sort(g, n, tid);
+	} else if (PACKED) {
+		bitonic_sort_u64(s_w, n, tid);
+		for (int i = tid; i < n; i += SO_THREADS) g[i] = unpack_anchor(s_w[i], rid_bits, rpos_bits);
+	} else {
 		bitonic_sort(s_a, n, tid);
 		for (int i = tid; i < n; i += SO_THREADS) g[i] = s_a[i];
-	} else {
-		bitonic_sort(g, n, tid);
 	}
 }
 
 void launch_expand_sort(const Batch &B, const uint32_t *list, uint32_t count, int NM, hipStream_t st)
 {
 	if (count == 0) return;
-	hipLaunchKernelGGL(mnc_expand_sort, dim3(count), dim3(SO_THREADS), (size_t)NM * sizeof(Anchor), st, B, list, count, NM);
+	if (B.rid_bits > 0 && NM > 0)
+		hipLaunchKernelGGL(mnc_expand_sort<true>, dim3(count), dim3(SO_THREADS), (size_t)NM * sizeof(uint64_t), st, B, list, count, NM);
+	else
+		hipLaunchKernelGGL(mnc_expand_sort<false>, dim3(count), dim3(SO_THREADS), (size_t)NM * sizeof(Anchor), st, B, list, count, NM);
 }
 
 int expand_sort_prepare(int max_nm)
 {
-	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_expand_sort),
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_expand_sort<false>),
 	                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)max_nm * sizeof(Anchor)));
+	if (e == hipSuccess)
+		e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_expand_sort<true>),
+		                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)max_nm * sizeof(uint64_t)));
 	if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return MNC_ERR_HIP; }
 	return MNC_OK;
 }
