@@ -139,6 +139,7 @@ struct Batch {
 	mnc_hit_t *best;
 	int32_t *nhits;
 	int64_t *counts;              // [n_genomes * 3] or null
+	int32_t *best_mlen;           // per read: mlen of the minimal gated hit (0 without one)
 	int64_t *stats;               // device counters (see mnc_engine_get_counters)
 };
 

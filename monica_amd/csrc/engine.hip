@@ -282,7 +282,7 @@ struct mnc_engine {
 	Buf packed, mz, hits, hist_tm, q_off, qrec, bhits, bhit_cnt;
 	size_t q_cap_override = 0;              // grown after an overflowing batch
 	// per read
-	Buf ambig, mz_cnt, hit_cnt, rep_len, an_cnt, an_off, n_chain, n_reg, scan_sums, hit_off;
+	Buf ambig, mz_cnt, hit_cnt, rep_len, an_cnt, an_off, n_chain, n_reg, scan_sums, hit_off, best_mlen;
 	// per anchor
 	Buf a, f, p, v, t, u;
 	// per chain slot
@@ -371,7 +371,7 @@ extern "C" void mnc_engine_destroy(mnc_engine *e)
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
 	Buf *all[] = { &e->gap_lut, &e->logf_lut, &e->in_bases, &e->in_offsets, &e->out_assign, &e->out_best, &e->out_nhits,
 	               &e->packed, &e->mz, &e->hits, &e->hist_tm, &e->q_off, &e->qrec, &e->bhits, &e->bhit_cnt, &e->ambig, &e->mz_cnt, &e->hit_cnt, &e->rep_len, &e->an_cnt, &e->an_off,
-	               &e->n_chain, &e->n_reg, &e->scan_sums, &e->hit_off, &e->a, &e->f, &e->p, &e->v, &e->t, &e->u,
+	               &e->n_chain, &e->n_reg, &e->best_mlen, &e->scan_sums, &e->hit_off, &e->a, &e->f, &e->p, &e->v, &e->t, &e->u,
 	               &e->chains_tmp, &e->regs, &e->regx, &e->k64a, &e->k64b, &e->tmp_i32, &e->gated,
 	               &e->hits_csr, &e->stats, &e->cls_count, &e->cls_list };
 	for (Buf *b : all) b->release();
@@ -503,6 +503,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	ENS(an_off, (nr + 2) * 8);
 	ENS(n_chain, (nr + 1) * 4);
 	ENS(n_reg, (nr + 1) * 4);
+	ENS(best_mlen, (nr + 1) * 4);
 	ENS(hit_off, (nr + 2) * 8);
 	ENS(hist_tm, (n_tiles + 1) * PB_N * 4);
 	ENS(q_off, (n_tiles * PB_N + 2) * 8);
@@ -539,7 +540,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	B.gap_lut = e->gap_lut.as<int32_t>(), B.logf_lut = e->logf_lut.as<float>(), B.logf_n = e->logf_n;
 	B.packed = e->packed.as<uint32_t>(), B.ambig = e->ambig.as<uint32_t>(), B.mz = e->mz.as<uint2>(), B.hits = e->hits.as<HitRec>();
 	B.mz_cnt = e->mz_cnt.as<int32_t>(), B.hit_cnt = e->hit_cnt.as<int32_t>(), B.rep_len = e->rep_len.as<int32_t>();
-	B.an_cnt = e->an_cnt.as<int64_t>(), B.an_off = e->an_off.as<int64_t>(), B.n_chain = e->n_chain.as<int32_t>(), B.n_reg = e->n_reg.as<int32_t>();
+	B.an_cnt = e->an_cnt.as<int64_t>(), B.an_off = e->an_off.as<int64_t>(), B.n_chain = e->n_chain.as<int32_t>(), B.n_reg = e->n_reg.as<int32_t>(), B.best_mlen = e->best_mlen.as<int32_t>();
 	B.n_tiles = (uint32_t)n_tiles, B.n_super = (uint32_t)n_super;
 	B.hist_tm = e->hist_tm.as<uint32_t>(), B.q_off = e->q_off.as<int64_t>(), B.qrec = e->qrec.as<uint64_t>();
 	B.q_cap = (int64_t)q_cap, B.bhits = e->bhits.as<HitRec>(), B.bhit_cnt = e->bhit_cnt.as<uint32_t>();

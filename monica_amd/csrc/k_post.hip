@@ -41,7 +41,16 @@ __device__ __forceinline__ uint32_t wang32(uint32_t key)
 	return key;
 }
 
-__device__ void sort_u64(uint64_t *a, int n)       // ascending; insertion for the common tiny case
+// element i of a per-thread array laid out [i][thread] in LDS (stride 64 elements: lanes of a
+// wave touch consecutive addresses)
+template <class T>
+struct Strided {
+	T *p;
+	__device__ __forceinline__ T &operator[](int i) const { return p[(size_t)i * 64]; }
+};
+
+template <class K64P>
+__device__ void sort_u64(K64P a, int n)       // ascending; insertion for the common tiny case
 {
 	if (n <= 24) {
 		for (int i = 1; i < n; ++i) {
@@ -95,7 +104,8 @@ __device__ __forceinline__ void set_coor(mnc_reg_t &r, const RegX &e, int qlen)
 }
 
 // re-number ids after a compaction and re-point parents (mm_sync_regs)
-__device__ void sync_regs(int n_regs, mnc_reg_t *regs, int32_t *tmp)
+template <class RegP, class I32P>
+__device__ void sync_regs(int n_regs, RegP regs, I32P tmp)
 {
 	if (n_regs <= 0) return;
 	int max_id = -1;
@@ -103,266 +113,321 @@ __device__ void sync_regs(int n_regs, mnc_reg_t *regs, int32_t *tmp)
 	for (int i = 0; i <= max_id; ++i) tmp[i] = -1;
 	for (int i = 0; i < n_regs; ++i) if (regs[i].id >= 0) tmp[regs[i].id] = i;
 	for (int i = 0; i < n_regs; ++i) {
-		mnc_reg_t &r = regs[i];
-		r.id = i;
-		if (r.parent == -2) r.parent = i;
-		else if (r.parent >= 0 && tmp[r.parent] >= 0) r.parent = tmp[r.parent];
-		else r.parent = -1;
+		const int pa = regs[i].parent;
+		regs[i].id = i;
+		if (pa == -2) regs[i].parent = i;
+		else if (pa >= 0 && tmp[pa] >= 0) regs[i].parent = tmp[pa];
+		else regs[i].parent = -1;
 	}
 }
+
+// The work of one read on a workspace of n slots per array: `r`, `ex`, `ka`, `kb`, `w`, `tmp`
+// live in LDS for reads with few chains and in HBM scratch otherwise (the function is inlined
+// once per address space).  Returns the number of regions kept; fills assign / best / nhits.
+template <class RegP, class ExP, class K64P, class I32P>
+__device__ __forceinline__ int regions_of_read(const Batch &B, uint32_t rd, int qlen, int n, const ChainRec *ch,
+                                               RegP r, ExP ex, K64P ka, K64P kb, I32P w, I32P tmp, mnc_hit_t *gated,
+                                               int32_t &assign, mnc_hit_t &best, int32_t &nhits)
+{
+	int n_regs = 0;
+	// ---------------- chains ordered by (first anchor x, rank); `as` = running anchor count
+	// in that order (mm_chain_dp's final ordering; total order instead of an unstable sort)
+	for (int i = 0; i < n; ++i) w[i] = i, ka[i] = ch[i].x0, tmp[i] = ch[i].cnt;
+	for (int i = 1; i < n; ++i) {
+		const int c = w[i];
+		const uint64_t xc = ka[c];
+		int j = i - 1;
+		while (j >= 0 && (ka[w[j]] > xc || (ka[w[j]] == xc && w[j] > c))) { w[j + 1] = w[j]; --j; }
+		w[j + 1] = c;
+	}
+	{
+		int as = 0;
+		for (int i = 0; i < n; ++i) { const int c = w[i]; kb[c] = (uint64_t)(uint32_t)as << 32 | (uint32_t)c; as += tmp[c]; }   // `as` is unique: total order
+	}
+	// ---------------- regions, sorted by score (desc) with the pseudo-random tie-break
+	uint32_t hash = wang32((uint32_t)qlen) + wang32((uint32_t)B.seed);
+	hash = wang32(hash);
+	for (int i = 0; i < n; ++i) {
+		const uint32_t h = (uint32_t)mix64((mix64(ka[i]) + mix64(ch[i].y0)) ^ (uint64_t)hash);
+		ka[i] = ((uint64_t)(uint32_t)ch[i].score << 32 | (uint32_t)tmp[i]) ^ (uint64_t)h;
+	}
+	// sort chain indices by (ka, as) descending: insertion (n is small)
+	for (int i = 0; i < n; ++i) w[i] = i;
+	for (int i = 1; i < n; ++i) {
+		const int c = w[i];
+		const uint64_t kc = ka[c], bc = kb[c];
+		int j = i - 1;
+		while (j >= 0 && (ka[w[j]] < kc || (ka[w[j]] == kc && kb[w[j]] < bc))) { w[j + 1] = w[j]; --j; }
+		w[j + 1] = c;
+	}
+	for (int i = 0; i < n; ++i) {
+		const int ci = w[i];
+		const ChainRec c = ch[ci];
+		mnc_reg_t x;
+		x.id = i, x.parent = -1;
+		x.score = x.score0 = (int32_t)(ka[ci] >> 32);
+		x.hash = (uint32_t)ka[ci];
+		x.cnt = c.cnt, x.as = (int32_t)(kb[ci] >> 32), x.mlen = c.mlen, x.blen = c.blen;
+		x.subsc = 0, x.n_sub = 0, x.mapq = 0;
+		RegX e;
+		e.x0 = c.x0, e.y0 = c.y0, e.x1 = c.x1, e.y1 = c.y1;
+		set_coor(x, e, qlen);
+		r[i] = x, ex[i] = e;
+	}
+	n_regs = n;
+
+	// ---------------- parent / secondary, subsc, n_sub (mm_set_parent)
+	{
+		K64P cov = ka;
+		int k = 1;
+		w[0] = 0, r[0].parent = 0;
+		for (int i = 1; i < n_regs; ++i) {
+			const int si = r[i].qs, ei = r[i].qe;
+			int n_cov = 0, uncov_len = 0, j;
+			for (j = 0; j < k; ++j) {
+				const int pj = w[j];
+				int sj = r[pj].qs, ej = r[pj].qe;
+				if (ej <= si || sj >= ei) continue;
+				if (sj < si) sj = si;
+				if (ej > ei) ej = ei;
+				cov[n_cov++] = (uint64_t)(uint32_t)sj << 32 | (uint32_t)ej;
+			}
+			j = k;
+			if (n_cov > 0) {
+				int x = si;
+				sort_u64(cov, n_cov);
+				for (int jj = 0; jj < n_cov; ++jj) {
+					if ((int)(cov[jj] >> 32) > x) uncov_len += (int)(cov[jj] >> 32) - x;
+					x = (int32_t)cov[jj] > x ? (int32_t)cov[jj] : x;
+				}
+				if (ei > x) uncov_len += ei - x;
+				for (j = 0; j < k; ++j) {
+					const int pj = w[j];
+					const int sj = r[pj].qs, ej = r[pj].qe;
+					if (ej <= si || sj >= ei) continue;
+					const int mn = ej - sj < ei - si ? ej - sj : ei - si;
+					const int mx = ej - sj > ei - si ? ej - sj : ei - si;
+					const int ol = si < sj ? (ei < sj ? 0 : ei < ej ? ei - sj : ej - sj)
+					                       : (ej < si ? 0 : ej < ei ? ej - si : ei - si);
+					const float lhs = __fsub_rn(__fdiv_rn((float)ol, (float)mn), __fdiv_rn((float)uncov_len, (float)mx));
+					if (lhs > B.mask_level) {
+						r[i].parent = r[pj].parent;
+						r[pj].subsc = r[pj].subsc > r[i].score ? r[pj].subsc : r[i].score;
+						if (r[i].cnt >= r[pj].cnt) ++r[pj].n_sub;
+						break;
+					}
+				}
+			}
+			if (j == k) w[k++] = i, r[i].parent = i, r[i].n_sub = 0;
+		}
+	}
+
+	// ---------------- keep primaries and the best secondaries (mm_select_sub); the
+	// in-place compaction reads r[p] after earlier slots may have been overwritten
+	if (B.pri_ratio > 0.0f) {
+		const int min_diff = KMER * 2;
+		int k = 0, n_2nd = 0;
+		for (int i = 0; i < n_regs; ++i) {
+			const int p = r[i].parent;
+			if (p == i) {
+				r[k] = r[i], ex[k] = ex[i], ++k;
+			} else if (((float)r[i].score >= __fmul_rn((float)r[p].score, B.pri_ratio) || r[i].score + min_diff >= r[p].score) && n_2nd < B.best_n) {
+				if (!(r[i].qs == r[p].qs && r[i].qe == r[p].qe && r[i].rid == r[p].rid && r[i].rs == r[p].rs && r[i].re == r[p].re)) {
+					r[k] = r[i], ex[k] = ex[i], ++k, ++n_2nd;
+				}
+			}
+		}
+		if (k != n_regs) sync_regs(k, r, tmp);
+		n_regs = k;
+	}
+
+	// ---------------- long-join of adjacent co-linear primaries (mm_join_long)
+	if (n_regs >= 2) {
+		K64P aux = ka;
+		// squeeze: `as` becomes the running anchor count in original-`as` order
+		for (int i = 0; i < n_regs; ++i) aux[i] = (uint64_t)(uint32_t)r[i].as << 32 | (uint32_t)i;
+		sort_u64(aux, n_regs);
+		int as = 0;
+		for (int i = 0; i < n_regs; ++i) {
+			const int ri = (int32_t)(uint32_t)aux[i];
+			r[ri].as = as;
+			as += r[ri].cnt;
+		}
+		int n_aux = 0, n_drop = 0;
+		for (int i = 0; i < n_regs; ++i)
+			if (r[i].parent == i || r[i].parent < 0) aux[n_aux++] = (uint64_t)(uint32_t)r[i].as << 32 | (uint32_t)i;
+		sort_u64(aux, n_aux);
+		for (int i = n_aux - 1; i >= 1; --i) {
+			const int i0 = (int32_t)(uint32_t)aux[i - 1], i1 = (int32_t)(uint32_t)aux[i];
+			mnc_reg_t r0 = r[i0];
+			const mnc_reg_t r1 = r[i1];
+			RegX e0 = ex[i0];
+			const RegX e1 = ex[i1];
+			if (r0.as + r0.cnt != r1.as) continue;
+			if (r0.rid != r1.rid || r0.rev != r1.rev) continue;
+			if (e1.x0 <= e0.x1 || (int32_t)e1.y0 <= (int32_t)e0.y1) continue;
+			const int64_t dx = (int64_t)(e1.x0 - e0.x1);
+			int max_gap = (int32_t)e1.y0 - (int32_t)e0.y1, min_gap = max_gap;
+			max_gap = max_gap > dx ? max_gap : (int)dx;
+			min_gap = min_gap < dx ? min_gap : (int)dx;
+			if (max_gap > B.max_join_long || min_gap > B.max_join_short) continue;
+			const float per = __fdiv_rn((float)B.min_join_flank_sc, (float)B.max_join_long);
+			const int sc_thres = (int)((double)__fmul_rn(per, (float)max_gap) + .499);
+			if (r0.score < sc_thres || r1.score < sc_thres) continue;
+			const int min_flank_len = (int)__fmul_rn((float)max_gap, B.min_join_flank_ratio);
+			if (r0.re - r0.rs < min_flank_len || r0.qe - r0.qs < min_flank_len) continue;
+			if (r1.re - r1.rs < min_flank_len || r1.qe - r1.qs < min_flank_len) continue;
+			// join: r0 absorbs r1
+			{
+				const int sp = (int)(e1.y0 >> 32 & 0xff);
+				const int tl = (int32_t)e1.x0 - (int32_t)e0.x1;
+				const int ql = (int32_t)e1.y0 - (int32_t)e0.y1;
+				r0.blen += (tl > ql ? tl : ql) + (r1.blen - sp);
+				r0.mlen += (tl > sp && ql > sp ? sp : tl < ql ? tl : ql) + (r1.mlen - sp);
+			}
+			r0.cnt += r1.cnt, r0.score += r1.score;
+			e0.x1 = e1.x1, e0.y1 = e1.y1;
+			{ const int32_t m = r0.mlen, b = r0.blen; set_coor(r0, e0, qlen); r0.mlen = m, r0.blen = b; }
+			r[i0] = r0, ex[i0] = e0;
+			r[i1].cnt = 0;
+			r[i1].parent = r0.id;
+			++n_drop;
+		}
+		if (n_drop > 0) {
+			for (int i = 0; i < n_regs; ++i) {
+				const int pa = r[i].parent;
+				if (pa >= 0 && r[i].id != pa)
+					if (r[pa].parent >= 0 && r[pa].parent != pa) r[i].parent = r[pa].parent;
+			}
+			int k = 0;
+			for (int i = 0; i < n_regs; ++i) {          // mm_filter_regs: cnt < min_cnt
+				if (r[i].cnt < B.min_cnt) continue;
+				if (k < i) r[k] = r[i], ex[k] = ex[i];
+				++k;
+			}
+			n_regs = k;
+			sync_regs(n_regs, r, tmp);
+		}
+	}
+
+	// ---------------- chain-level MAPQ (mm_set_mapq, branch without base-level DP)
+	{
+		long long sum_sc = 0;
+		for (int i = 0; i < n_regs; ++i) if (r[i].parent == r[i].id) sum_sc += r[i].score;
+		const float uniq_ratio = __fdiv_rn((float)sum_sc, (float)(sum_sc + (long long)B.rep_len[rd]));
+		for (int i = 0; i < n_regs; ++i) {
+			const mnc_reg_t x = r[i];
+			int mapq = 0;
+			if (x.parent == x.id) {
+				const float pen_s1 = __fmul_rn(x.score > 100 ? 1.0f : __fmul_rn(0.01f, (float)x.score), uniq_ratio);
+				float pen_cm = x.cnt > 10 ? 1.0f : __fmul_rn(0.1f, (float)x.cnt);
+				pen_cm = pen_s1 < pen_cm ? pen_s1 : pen_cm;
+				const int subsc = x.subsc > B.min_sc ? x.subsc : B.min_sc;
+				const float xr = __fdiv_rn((float)subsc, (float)x.score0);
+				const int li = x.score < B.logf_n ? x.score : B.logf_n - 1;
+				const int ls = x.n_sub + 1 < B.logf_n ? x.n_sub + 1 : B.logf_n - 1;
+				float q = __fmul_rn(__fmul_rn(__fmul_rn(pen_cm, 40.0f), __fsub_rn(1.0f, xr)), B.logf_lut[li]);
+				mapq = (int)q;
+				mapq -= (int)__fadd_rn(__fmul_rn(4.343f, B.logf_lut[ls]), .499f);
+				mapq = mapq > 0 ? mapq : 0;
+				mapq = mapq < 60 ? mapq : 60;
+			}
+			r[i].mapq = mapq;
+		}
+	}
+
+	// ---------------- monica: gate, best_hit, decision (aligner.py:216-233)
+	int ties = 0;
+	for (int i = 0; i < n_regs; ++i) {
+		const mnc_reg_t x = r[i];
+		if (x.id == x.parent && x.mapq >= B.min_mapq) {
+			mnc_hit_t h;
+			h.rid = x.rid, h.mapq = x.mapq, h.nm = x.blen - x.mlen, h.mlen = x.mlen;
+			gated[nhits] = h;
+			if (nhits == 0) best = h, ties = 1;
+			else {
+				const long long l = (long long)h.nm * best.mlen, rr = (long long)best.nm * h.mlen;
+				if (l < rr) best = h, ties = 1;
+				else if (l == rr) best = h, ++ties;
+			}
+			++nhits;
+		}
+	}
+	if (nhits > 0) assign = (nhits == 1 || ties == 1) ? best.rid : MNC_AMBIGUOUS;   // best = the minimal hit, also when it is tied
+	return n_regs;
+}
+
+constexpr int RG_LDS_CHAINS = 4;               // reads with at most this many chains work in LDS
 
 __global__ __launch_bounds__(64) void mnc_regions_decide(Batch B, RegX *regx_all, uint64_t *k64a_all,
                                                          uint64_t *k64b_all, mnc_hit_t *gated_all)
 {
+	__shared__ mnc_reg_t s_r[RG_LDS_CHAINS][64];
+	__shared__ RegX s_ex[RG_LDS_CHAINS][64];
+	__shared__ uint64_t s_ka[RG_LDS_CHAINS][64], s_kb[RG_LDS_CHAINS][64];
+	__shared__ int32_t s_w[RG_LDS_CHAINS][64], s_tmp[RG_LDS_CHAINS][64];
 	const uint32_t rd = blockIdx.x * blockDim.x + threadIdx.x;
 	if (rd >= B.n_reads) return;
 	const int qlen = (int)(B.offsets[rd + 1] - B.offsets[rd]);
 	int32_t assign = MNC_UNMAPPED, nhits = 0;
 	mnc_hit_t best;
 	best.rid = best.mapq = best.nm = best.mlen = 0;
-	int n = B.n_chain[rd];
+	const int n = B.n_chain[rd];
 	int n_regs = 0;
 	if (n > 0) {
 		const int64_t slot = B.an_off[rd] / 3;
-		ChainRec *ch = B.chains_tmp + slot;                     // backtrack order (pad = rank)
-		mnc_reg_t *r = B.regs + slot;
-		RegX *ex = regx_all + slot;
-		uint64_t *ka = k64a_all + slot, *kb = k64b_all + slot;
-		int32_t *w = B.tmp_i32 + slot * 4, *tmp = w + n;        // n ints each (4 per slot available)
+		const ChainRec *ch = B.chains_tmp + slot;               // backtrack order (pad = rank)
 		mnc_hit_t *gated = gated_all + slot;
-
-		// ---------------- chains ordered by (first anchor x, rank); `as` = running anchor count
-		// in that order (mm_chain_dp's final ordering; total order instead of an unstable sort)
-		for (int i = 0; i < n; ++i) w[i] = i;
-		for (int i = 1; i < n; ++i) {
-			const int c = w[i];
-			int j = i - 1;
-			while (j >= 0 && (ch[w[j]].x0 > ch[c].x0 || (ch[w[j]].x0 == ch[c].x0 && w[j] > c))) { w[j + 1] = w[j]; --j; }
-			w[j + 1] = c;
-		}
-		{
-			int as = 0;
-			for (int i = 0; i < n; ++i) { ch[w[i]].as = as; as += ch[w[i]].cnt; }
-		}
-		// ---------------- regions, sorted by score (desc) with the pseudo-random tie-break
-		uint32_t hash = wang32((uint32_t)qlen) + wang32((uint32_t)B.seed);
-		hash = wang32(hash);
-		for (int i = 0; i < n; ++i) {
-			const uint32_t h = (uint32_t)mix64((mix64(ch[i].x0) + mix64(ch[i].y0)) ^ (uint64_t)hash);
-			ka[i] = ((uint64_t)(uint32_t)ch[i].score << 32 | (uint32_t)ch[i].cnt) ^ (uint64_t)h;
-			kb[i] = (uint64_t)(uint32_t)ch[i].as << 32 | (uint32_t)i;   // `as` is unique: total order
-		}
-		// sort chain indices by (ka, as) descending: selection through insertion (n is small)
-		for (int i = 0; i < n; ++i) w[i] = i;
-		for (int i = 1; i < n; ++i) {
-			const int c = w[i];
-			int j = i - 1;
-			while (j >= 0 && (ka[w[j]] < ka[c] || (ka[w[j]] == ka[c] && kb[w[j]] < kb[c]))) { w[j + 1] = w[j]; --j; }
-			w[j + 1] = c;
-		}
-		for (int i = 0; i < n; ++i) {
-			const ChainRec &c = ch[w[i]];
-			mnc_reg_t x;
-			x.id = i, x.parent = -1;
-			x.score = x.score0 = (int32_t)(ka[w[i]] >> 32);
-			x.hash = (uint32_t)ka[w[i]];
-			x.cnt = c.cnt, x.as = c.as, x.mlen = c.mlen, x.blen = c.blen;
-			x.subsc = 0, x.n_sub = 0, x.mapq = 0;
-			RegX e;
-			e.x0 = c.x0, e.y0 = c.y0, e.x1 = c.x1, e.y1 = c.y1;
-			set_coor(x, e, qlen);
-			r[i] = x, ex[i] = e;
-		}
-		n_regs = n;
-
-		// ---------------- parent / secondary, subsc, n_sub (mm_set_parent)
-		{
-			uint64_t *cov = ka;
-			int k = 1;
-			w[0] = 0, r[0].parent = 0;
-			for (int i = 1; i < n_regs; ++i) {
-				mnc_reg_t &ri = r[i];
-				const int si = ri.qs, ei = ri.qe;
-				int n_cov = 0, uncov_len = 0, j;
-				for (j = 0; j < k; ++j) {
-					const mnc_reg_t &rp = r[w[j]];
-					int sj = rp.qs, ej = rp.qe;
-					if (ej <= si || sj >= ei) continue;
-					if (sj < si) sj = si;
-					if (ej > ei) ej = ei;
-					cov[n_cov++] = (uint64_t)(uint32_t)sj << 32 | (uint32_t)ej;
-				}
-				j = k;
-				if (n_cov > 0) {
-					int x = si;
-					sort_u64(cov, n_cov);
-					for (int jj = 0; jj < n_cov; ++jj) {
-						if ((int)(cov[jj] >> 32) > x) uncov_len += (int)(cov[jj] >> 32) - x;
-						x = (int32_t)cov[jj] > x ? (int32_t)cov[jj] : x;
-					}
-					if (ei > x) uncov_len += ei - x;
-					for (j = 0; j < k; ++j) {
-						mnc_reg_t &rp = r[w[j]];
-						const int sj = rp.qs, ej = rp.qe;
-						if (ej <= si || sj >= ei) continue;
-						const int mn = ej - sj < ei - si ? ej - sj : ei - si;
-						const int mx = ej - sj > ei - si ? ej - sj : ei - si;
-						const int ol = si < sj ? (ei < sj ? 0 : ei < ej ? ei - sj : ej - sj)
-						                       : (ej < si ? 0 : ej < ei ? ej - si : ei - si);
-						const float lhs = __fsub_rn(__fdiv_rn((float)ol, (float)mn), __fdiv_rn((float)uncov_len, (float)mx));
-						if (lhs > B.mask_level) {
-							ri.parent = rp.parent;
-							rp.subsc = rp.subsc > ri.score ? rp.subsc : ri.score;
-							if (ri.cnt >= rp.cnt) ++rp.n_sub;
-							break;
-						}
-					}
-				}
-				if (j == k) w[k++] = i, ri.parent = i, ri.n_sub = 0;
-			}
-		}
-
-		// ---------------- keep primaries and the best secondaries (mm_select_sub); the
-		// in-place compaction reads r[p] after earlier slots may have been overwritten
-		if (B.pri_ratio > 0.0f) {
-			const int min_diff = KMER * 2;
-			int k = 0, n_2nd = 0;
-			for (int i = 0; i < n_regs; ++i) {
-				const int p = r[i].parent;
-				if (p == i) {
-					r[k] = r[i], ex[k] = ex[i], ++k;
-				} else if (((float)r[i].score >= __fmul_rn((float)r[p].score, B.pri_ratio) || r[i].score + min_diff >= r[p].score) && n_2nd < B.best_n) {
-					if (!(r[i].qs == r[p].qs && r[i].qe == r[p].qe && r[i].rid == r[p].rid && r[i].rs == r[p].rs && r[i].re == r[p].re)) {
-						r[k] = r[i], ex[k] = ex[i], ++k, ++n_2nd;
-					}
-				}
-			}
-			if (k != n_regs) sync_regs(k, r, tmp);
-			n_regs = k;
-		}
-
-		// ---------------- long-join of adjacent co-linear primaries (mm_join_long)
-		if (n_regs >= 2) {
-			uint64_t *aux = ka;
-			// squeeze: `as` becomes the running anchor count in original-`as` order
-			for (int i = 0; i < n_regs; ++i) aux[i] = (uint64_t)(uint32_t)r[i].as << 32 | (uint32_t)i;
-			sort_u64(aux, n_regs);
-			int as = 0;
-			for (int i = 0; i < n_regs; ++i) {
-				mnc_reg_t &x = r[(int32_t)(uint32_t)aux[i]];
-				x.as = as;
-				as += x.cnt;
-			}
-			int n_aux = 0, n_drop = 0;
-			for (int i = 0; i < n_regs; ++i)
-				if (r[i].parent == i || r[i].parent < 0) aux[n_aux++] = (uint64_t)(uint32_t)r[i].as << 32 | (uint32_t)i;
-			sort_u64(aux, n_aux);
-			for (int i = n_aux - 1; i >= 1; --i) {
-				const int i0 = (int32_t)(uint32_t)aux[i - 1], i1 = (int32_t)(uint32_t)aux[i];
-				mnc_reg_t &r0 = r[i0], &r1 = r[i1];
-				RegX &e0 = ex[i0];
-				const RegX &e1 = ex[i1];
-				if (r0.as + r0.cnt != r1.as) continue;
-				if (r0.rid != r1.rid || r0.rev != r1.rev) continue;
-				if (e1.x0 <= e0.x1 || (int32_t)e1.y0 <= (int32_t)e0.y1) continue;
-				const int64_t dx = (int64_t)(e1.x0 - e0.x1);
-				int max_gap = (int32_t)e1.y0 - (int32_t)e0.y1, min_gap = max_gap;
-				max_gap = max_gap > dx ? max_gap : (int)dx;
-				min_gap = min_gap < dx ? min_gap : (int)dx;
-				if (max_gap > B.max_join_long || min_gap > B.max_join_short) continue;
-				const float per = __fdiv_rn((float)B.min_join_flank_sc, (float)B.max_join_long);
-				const int sc_thres = (int)((double)__fmul_rn(per, (float)max_gap) + .499);
-				if (r0.score < sc_thres || r1.score < sc_thres) continue;
-				const int min_flank_len = (int)__fmul_rn((float)max_gap, B.min_join_flank_ratio);
-				if (r0.re - r0.rs < min_flank_len || r0.qe - r0.qs < min_flank_len) continue;
-				if (r1.re - r1.rs < min_flank_len || r1.qe - r1.qs < min_flank_len) continue;
-				// join: r0 absorbs r1
-				{
-					const int sp = (int)(e1.y0 >> 32 & 0xff);
-					const int tl = (int32_t)e1.x0 - (int32_t)e0.x1;
-					const int ql = (int32_t)e1.y0 - (int32_t)e0.y1;
-					r0.blen += (tl > ql ? tl : ql) + (r1.blen - sp);
-					r0.mlen += (tl > sp && ql > sp ? sp : tl < ql ? tl : ql) + (r1.mlen - sp);
-				}
-				r0.cnt += r1.cnt, r0.score += r1.score;
-				e0.x1 = e1.x1, e0.y1 = e1.y1;
-				{ const int32_t m = r0.mlen, b = r0.blen; set_coor(r0, e0, qlen); r0.mlen = m, r0.blen = b; }
-				r1.cnt = 0;
-				r1.parent = r0.id;
-				++n_drop;
-			}
-			if (n_drop > 0) {
-				for (int i = 0; i < n_regs; ++i) {
-					mnc_reg_t &x = r[i];
-					if (x.parent >= 0 && x.id != x.parent)
-						if (r[x.parent].parent >= 0 && r[x.parent].parent != x.parent) x.parent = r[x.parent].parent;
-				}
-				int k = 0;
-				for (int i = 0; i < n_regs; ++i) {          // mm_filter_regs: cnt < min_cnt
-					if (r[i].cnt < B.min_cnt) continue;
-					if (k < i) r[k] = r[i], ex[k] = ex[i];
-					++k;
-				}
-				n_regs = k;
-				sync_regs(n_regs, r, tmp);
-			}
-		}
-
-		// ---------------- chain-level MAPQ (mm_set_mapq, branch without base-level DP)
-		{
-			long long sum_sc = 0;
-			for (int i = 0; i < n_regs; ++i) if (r[i].parent == r[i].id) sum_sc += r[i].score;
-			const float uniq_ratio = __fdiv_rn((float)sum_sc, (float)(sum_sc + (long long)B.rep_len[rd]));
-			for (int i = 0; i < n_regs; ++i) {
-				mnc_reg_t &x = r[i];
-				if (x.parent == x.id) {
-					const float pen_s1 = __fmul_rn(x.score > 100 ? 1.0f : __fmul_rn(0.01f, (float)x.score), uniq_ratio);
-					float pen_cm = x.cnt > 10 ? 1.0f : __fmul_rn(0.1f, (float)x.cnt);
-					pen_cm = pen_s1 < pen_cm ? pen_s1 : pen_cm;
-					const int subsc = x.subsc > B.min_sc ? x.subsc : B.min_sc;
-					const float xr = __fdiv_rn((float)subsc, (float)x.score0);
-					const int li = x.score < B.logf_n ? x.score : B.logf_n - 1;
-					const int ls = x.n_sub + 1 < B.logf_n ? x.n_sub + 1 : B.logf_n - 1;
-					float q = __fmul_rn(__fmul_rn(__fmul_rn(pen_cm, 40.0f), __fsub_rn(1.0f, xr)), B.logf_lut[li]);
-					int mapq = (int)q;
-					mapq -= (int)__fadd_rn(__fmul_rn(4.343f, B.logf_lut[ls]), .499f);
-					mapq = mapq > 0 ? mapq : 0;
-					x.mapq = mapq < 60 ? mapq : 60;
-				} else x.mapq = 0;
-			}
-		}
-
-		// ---------------- monica: gate, best_hit, decision (aligner.py:216-233)
-		int bi = -1, ties = 0;
-		for (int i = 0; i < n_regs; ++i) {
-			const mnc_reg_t &x = r[i];
-			if (x.id == x.parent && x.mapq >= B.min_mapq) {
-				mnc_hit_t h;
-				h.rid = x.rid, h.mapq = x.mapq, h.nm = x.blen - x.mlen, h.mlen = x.mlen;
-				gated[nhits] = h;
-				if (bi < 0) bi = nhits, ties = 1;
-				else {
-					const long long l = (long long)h.nm * gated[bi].mlen, rr = (long long)gated[bi].nm * h.mlen;
-					if (l < rr) bi = nhits, ties = 1;
-					else if (l == rr) bi = nhits, ++ties;
-				}
-				++nhits;
-			}
-		}
-		if (nhits > 0) {                                  // best = the minimal hit, also when it is tied
-			best = gated[bi];
-			assign = (nhits == 1 || ties == 1) ? gated[bi].rid : MNC_AMBIGUOUS;
+		if (n <= RG_LDS_CHAINS) {
+			const int t = threadIdx.x;
+			n_regs = regions_of_read(B, rd, qlen, n, ch, Strided<mnc_reg_t>{&s_r[0][t]}, Strided<RegX>{&s_ex[0][t]},
+			                         Strided<uint64_t>{&s_ka[0][t]}, Strided<uint64_t>{&s_kb[0][t]},
+			                         Strided<int32_t>{&s_w[0][t]}, Strided<int32_t>{&s_tmp[0][t]}, gated, assign, best, nhits);
+			mnc_reg_t *out = B.regs + slot;
+			for (int i = 0; i < n_regs; ++i) out[i] = s_r[i][t];
+		} else {
+			int32_t *w = B.tmp_i32 + slot * 4;                  // n ints each (4 per slot available)
+			n_regs = regions_of_read(B, rd, qlen, n, ch, B.regs + slot, regx_all + slot, k64a_all + slot, k64b_all + slot,
+			                         w, w + n, gated, assign, best, nhits);
 		}
 	}
 	B.n_reg[rd] = n_regs;
 	B.assign[rd] = assign;
 	if (B.best) B.best[rd] = best;
 	B.nhits[rd] = nhits;
-	if (B.counts && assign >= 0) {                          // aligner.py:247-263, all three modes
-		const int g = B.contig_genome[assign];
-		atomicAdd((unsigned long long*)&B.counts[g * 3 + 0], 1ULL);
-		atomicAdd((unsigned long long*)&B.counts[g * 3 + 1], (unsigned long long)qlen);
-		atomicAdd((unsigned long long*)&B.counts[g * 3 + 2], (unsigned long long)best.mlen);
+	B.best_mlen[rd] = best.mlen;
+}
+
+// ---------------------------------------------------------------- taxon counts
+// aligner.py:247-263, all three modes at once: per genome {reads, bases, matching bases}.
+// With a handful of genomes every read of the batch would hit the same few HBM words, so a
+// block first adds its reads up in LDS and then flushes the bins it touched.
+constexpr int CT_THREADS = 256, CT_READS = 4096, CT_LDS_BINS = 3 * 1024;
+
+__global__ __launch_bounds__(CT_THREADS) void mnc_count_taxa(Batch B)
+{
+	__shared__ unsigned long long s_bins[CT_LDS_BINS];
+	const int n_bins = B.n_genomes * 3;
+	const bool in_lds = n_bins <= CT_LDS_BINS;
+	if (in_lds) {
+		for (int k = threadIdx.x; k < n_bins; k += CT_THREADS) s_bins[k] = 0;
+		__syncthreads();
+	}
+	unsigned long long *bins = in_lds ? s_bins : (unsigned long long*)B.counts;
+	const uint32_t lo = blockIdx.x * CT_READS;
+	const uint32_t hi = min(B.n_reads, lo + CT_READS);
+	for (uint32_t rd = lo + threadIdx.x; rd < hi; rd += CT_THREADS) {
+		const int a = B.assign[rd];
+		if (a < 0) continue;
+		const int g = B.contig_genome[a];
+		atomicAdd(&bins[g * 3 + 0], 1ULL);
+		atomicAdd(&bins[g * 3 + 1], (unsigned long long)(B.offsets[rd + 1] - B.offsets[rd]));
+		atomicAdd(&bins[g * 3 + 2], (unsigned long long)B.best_mlen[rd]);
+	}
+	if (in_lds) {
+		__syncthreads();
+		for (int k = threadIdx.x; k < n_bins; k += CT_THREADS)
+			if (s_bins[k]) atomicAdd((unsigned long long*)&B.counts[k], s_bins[k]);
 	}
 }
 
@@ -384,6 +449,7 @@ void launch_regions(const Batch &B, void *regx, uint64_t *k64a, uint64_t *k64b, 
 	if (B.n_reads == 0) return;
 	hipLaunchKernelGGL(mnc_regions_decide, dim3((B.n_reads + 63) / 64), dim3(64), 0, st, B,
 	                   reinterpret_cast<RegX*>(regx), k64a, k64b, gated);
+	if (B.counts) hipLaunchKernelGGL(mnc_count_taxa, dim3((B.n_reads + CT_READS - 1) / CT_READS), dim3(CT_THREADS), 0, st, B);
 }
 
 void launch_gather_hits(const Batch &B, const mnc_hit_t *gated, const int64_t *hit_off, mnc_hit_t *out, hipStream_t st)
