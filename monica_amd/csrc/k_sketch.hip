@@ -68,10 +68,15 @@ __global__ __launch_bounds__(256) void mnc_pack_bases(Batch B)
 constexpr int SK_THREADS = 256;                     // 4 waves = 4 reads per workgroup
 constexpr int SK_CHUNK = 1024;                      // k-mer positions per LDS chunk of one wave
 constexpr int SK_PAD = 10;                          // halo on each side (>= WIN - 1, even)
-constexpr int SK_SLOTS = SK_CHUNK + 2 * SK_PAD + 4; // hash slots per wave (+4: the 22-value read-ahead)
+constexpr int SK_LOGICAL = SK_CHUNK + 2 * SK_PAD + 16;   // hash slots per wave: positions c0-PAD .. c0+CHUNK+PAD, rounded up
+constexpr int SK_SLOTS = SK_LOGICAL + SK_LOGICAL / 16 + 1; // stored with one pad word per 16 slots (see sk_phys)
 constexpr int SK_WORDS = (SK_CHUNK + 2 * SK_PAD + KMER) / 16 + 4;
 constexpr int SK_ITERS = (SK_CHUNK + 2 * SK_PAD + 63) / 64;
 static_assert(SK_THREADS / 64 == PT_READS, "one sketch workgroup = one partition tile");
+
+// slot q of a wave's hash window sits at q + q / 16: a lane that reads the 34 slots around its
+// 16 positions then strides 17 words against its neighbours -- no LDS bank conflicts
+__device__ __forceinline__ int sk_phys(int q) { return q + (q >> 4); }
 
 __device__ __forceinline__ uint32_t revcomp30(uint32_t fw)
 {
@@ -181,8 +186,6 @@ __device__ void sketch_one_read(const Batch &B, uint32_t r, int wv, int lane, in
 	uint2 *out = B.mz + off;
 	if (n <= 0) { if (lane == 0) B.mz_cnt[r] = 0; return; }
 	if (B.ambig[r]) return;                         // mnc_sketch_ambiguous handles it
-	const unsigned long long lt = (1ULL << lane) - 1ULL;
-
 	int total = 0;                                  // minimizers written so far (uniform)
 	for (int c0 = 0; c0 < n; c0 += SK_CHUNK) {
 		const int cend = min(c0 + SK_CHUNK, n);
@@ -206,58 +209,81 @@ __device__ void sketch_one_read(const Batch &B, uint32_t r, int wv, int lane, in
 				strand = fw < rv ? 0u : 1u;
 				h = (int32_t)hash30(strand ? rv : fw);
 			}
-			if (q < SK_SLOTS) s_hash[q] = h;
-			const unsigned long long sm = __ballot(strand != 0);
+			if (q < SK_LOGICAL) s_hash[sk_phys(q)] = h;
+			const unsigned long long sm = __builtin_amdgcn_ballot_w64(strand != 0);
 			if (lane == 0) s_strand[q0 >> 6] = sm;
 		}
 		wave_lds_order();
 
-		for (int t0 = c0; t0 < cend; t0 += 128) {
-			const int p0 = t0 + 2 * lane, q = p0 - c0 + SK_PAD;     // q is even
-			int32_t v[22];
-			const int2 *src = reinterpret_cast<const int2*>(s_hash + (q - 10));
+		// ---- selection: lane l owns the 16 positions c0 + 16 l + t.  With m(s) the minimum of
+		// the window starting at s, position p is reported iff h[p] == max over the ten windows
+		// that contain it (h[p] >= each of those minima, with equality iff p is a minimum of it).
+		int32_t v[36];
+		{
+			const int32_t *src = s_hash + 17 * lane;
 #pragma unroll
-			for (int k = 0; k < 11; ++k) { const int2 x = src[k]; v[2 * k] = x.x, v[2 * k + 1] = x.y; }
-			const int32_t h0 = v[10], h1 = v[11];
-			int L0 = 0, R0 = 0, L1 = 0, R1 = 0;
-			bool a0 = true, b0 = true, a1 = true, b1 = true;
+			for (int k = 1; k <= 34; ++k) v[k] = src[k + (k >> 4)];
+		}
+		uint32_t mask = 0;
+		{
+			int32_t m3[33], m10[26];
 #pragma unroll
-			for (int d = 1; d < WIN; ++d) {
-				a0 = a0 && v[10 - d] >= h0; L0 += a0;
-				b0 = b0 && v[10 + d] >= h0; R0 += b0;
-				a1 = a1 && v[11 - d] >= h1; L1 += a1;
-				b1 = b1 && v[11 + d] >= h1; R1 += b1;
+			for (int k = 1; k <= 32; ++k) m3[k] = min(min(v[k], v[k + 1]), v[k + 2]);
+#pragma unroll
+			for (int k = 1; k <= 25; ++k) m10[k] = min(min(min(m3[k], m3[k + 3]), m3[k + 6]), v[k + 9]);
+			int32_t x3[24];
+#pragma unroll
+			for (int k = 1; k <= 23; ++k) x3[k] = max(max(m10[k], m10[k + 1]), m10[k + 2]);
+#pragma unroll
+			for (int t = 0; t < 16; ++t) {
+				const int k = t + 1;
+				const int32_t top = max(max(max(x3[k], x3[k + 3]), x3[k + 6]), m10[k + 9]);
+				mask |= v[t + 10] == top ? 1u << t : 0u;
 			}
-			bool e0 = p0 < cend && L0 + R0 + 1 >= WIN;
-			bool e1 = p0 + 1 < cend && L1 + R1 + 1 >= WIN;
-			if (t0 == 0) {                              // first tile: short reads and first-window quirks
-				if (n < WIN) {
-					e0 = p0 < n, e1 = p0 + 1 < n;
-					for (int k = 0; k < n; ++k) {
-						const int32_t o = s_hash[SK_PAD + k];
-						if ((k < p0 && o < h0) || (k > p0 && o <= h0)) e0 = false;
-						if ((k < p0 + 1 && o < h1) || (k > p0 + 1 && o <= h1)) e1 = false;
-					}
-				} else {
-					int32_t q_m = s_hash[SK_PAD];
-					int q_P = 0;
-					for (int k = 1; k <= WIN - 2; ++k) {
-						const int32_t o = s_hash[SK_PAD + k];
-						if (o <= q_m) q_m = o, q_P = k;
-					}
-					const bool drop = s_hash[SK_PAD + WIN - 1] == q_m;
-					if (p0 <= WIN - 2) { if (h0 == q_m && p0 != q_P) e0 = true; if (p0 == q_P && drop) e0 = false; }
-					if (p0 + 1 <= WIN - 2) { if (h1 == q_m && p0 + 1 != q_P) e1 = true; if (p0 + 1 == q_P && drop) e1 = false; }
+		}
+		const int first_p = c0 + 16 * lane;
+		if (c0 == 0 && lane == 0) {                     // short reads and the first-window quirks
+			if (n < WIN) {
+				int32_t lowest = v[10];
+				int P = 0;
+#pragma unroll
+				for (int k = 1; k <= WIN - 2; ++k) if (k < n && v[10 + k] <= lowest) lowest = v[10 + k], P = k;   // right-most minimum
+				mask = 1u << P;
+			} else {
+				int32_t q_m = v[10];
+				int q_P = 0;
+#pragma unroll
+				for (int k = 1; k <= WIN - 2; ++k) if (v[10 + k] <= q_m) q_m = v[10 + k], q_P = k;
+				const bool drop = v[10 + WIN - 1] == q_m;
+#pragma unroll
+				for (int k = 0; k <= WIN - 2; ++k) {
+					if (v[10 + k] == q_m && k != q_P) mask |= 1u << k;
+					if (k == q_P && drop) mask &= ~(1u << k);
 				}
 			}
-			const unsigned long long m0 = __ballot(e0), m1 = __ballot(e1);
-			const int rank = __popcll(m0 & lt) + __popcll(m1 & lt);
-			const unsigned long long sb = s_strand[q >> 6];       // q and q+1 share one 64-bit word (q even)
-			if (e0) atomicAdd(&s_hist[pb_bucket((uint32_t)h0)], 1u);
-			if (e1) atomicAdd(&s_hist[pb_bucket((uint32_t)h1)], 1u);
-			if (e0) out[total + rank] = make_uint2((uint32_t)h0, (uint32_t)(p0 + KMER - 1) << 1 | (uint32_t)(sb >> (q & 63) & 1));
-			if (e1) out[total + rank + (e0 ? 1 : 0)] = make_uint2((uint32_t)h1, (uint32_t)(p0 + KMER) << 1 | (uint32_t)(sb >> ((q + 1) & 63) & 1));
-			total += __popcll(m0) + __popcll(m1);
+		}
+		{
+			const int nvalid = min(max(cend - first_p, 0), 16);
+			mask &= (1u << nvalid) - 1u;
+		}
+		// ---- output in position order: lane-contiguous runs
+		const int cnt = __popc(mask);
+		int incl = cnt;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const int o = __shfl_up(incl, d);
+			if (lane >= d) incl += o;
+		}
+		int k_out = total + incl - cnt;
+		total += __builtin_amdgcn_readlane(incl, 63);
+		while (mask) {
+			const int t = __ffs((int)mask) - 1;
+			mask &= mask - 1;
+			const int q = 16 * lane + SK_PAD + t;
+			const int32_t h = s_hash[sk_phys(q)];
+			const uint32_t strand = (uint32_t)(s_strand[q >> 6] >> (q & 63)) & 1u;
+			atomicAdd(&s_hist[pb_bucket((uint32_t)h)], 1u);
+			out[k_out++] = make_uint2((uint32_t)h, (uint32_t)(first_p + t + KMER - 1) << 1 | strand);
 		}
 	}
 	if (lane == 0) B.mz_cnt[r] = total;
