@@ -8,9 +8,9 @@
 // needs about 27 candidates before minimap2's max_skip rule stops the scan, i.e. one step.
 // The order-dependent parts of the sequential loop are reproduced exactly with scans over the
 // half-wave (DPP row_shr inside a 16-lane row, row_bcast:15 into the upper row):
-//   * running maximum (strict '>' updates)      -> exclusive prefix-max
+//   * running maximum (strict '>' updates)      -> inclusive prefix-max of (score, lane) keys
 //   * n_skip (decrement-with-floor / increment) -> prefix sum + prefix max (see below)
-//   * break at the first lane where n_skip > max_skip, argmax = first lane at the maximum
+//   * break at the first lane where n_skip > max_skip; argmax = the key scan at that lane
 // The two halves advance independently (no lock-step over i).
 //
 // K4 memory.  The DP only ever looks a short way back, so a read keeps just a RING of its
@@ -22,10 +22,9 @@
 // this kernel held all anchors of a read in LDS: 2.75 waves/SIMD, 8.2 ms; profiles/README.md.)
 //
 // K5.  The backtrack needs random access to a whole read, so it is its own kernel with the
-// read's {p, f, v, mark} + coordinates in LDS (14 bytes per anchor, size classes), two reads
-// per wave: chain ends found in parallel and rank-sorted in LDS, best-first walk by the half's
-// first lane, one 56-byte record per chain.  Reads beyond the largest class take the
-// sequential mnc_chain_backtrack of k_chain.hip.
+// read's {p | owner, f | v} + coordinates in LDS (14 bytes per anchor, size classes), two reads
+// per wave; it has no sequential walk (see mnc_chain_tail).  Reads beyond the largest class
+// take the sequential mnc_chain_backtrack of k_chain.hip.
 #include "device.h"
 
 namespace mnc {
