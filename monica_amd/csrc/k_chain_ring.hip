@@ -136,8 +136,8 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 	int32_t *gf = B.f + a_off, *gp = B.p + a_off, *gv = B.v + a_off, *gt = B.t + a_off;
 	const int span = KMER;
 	const int max_gap = B.max_gap, bw = B.bw, max_skip = B.max_skip, max_iter = B.max_iter;
-	__shared__ uint16_t s_gap[GAP_LUT];
-	for (int k = threadIdx.x; k < GAP_LUT; k += 64 * DP_WAVES) s_gap[k] = (uint16_t)B.gap_lut[k];
+	__shared__ uint8_t s_gap[GAP_LUT];                                   // gap costs stay below 256 for dd < GAP_LUT
+	for (int k = threadIdx.x; k < GAP_LUT; k += 64 * DP_WAVES) s_gap[k] = (uint8_t)B.gap_lut[k];
 	__syncthreads();
 
 	// block b of the read -> its ring slots: coordinates, segment-start flag, cleared DP fields
@@ -169,6 +169,7 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 	uint32_t xi = n > 0 ? (uint32_t)S[0].x : 0;
 	int qi = n > 0 ? S[0].q : 0;
 	const uint64_t last_lane = 1ULL << (row * RW + RW - 1);
+	const int key_lane = KEY_BIAS * RW + RW - 1 - lr, perm_half = (lane & RW) << 2;
 	for (;;) {
 		const bool active = i < n;
 		if (!any64(active)) break;
@@ -179,11 +180,11 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 		const bool far = inb && j < ring_lo;                              // behind the ring: HBM
 		const Slot *c = S + slot(j);                                      // any slot will do for lanes outside [lo, jb]
 		int pj = c->p, fj = c->f, xj = c->x, qj = c->q;
-		asm volatile("" : "+v"(pj), "+v"(fj), "+v"(xj), "+v"(qj));     // plain LDS reads (no flat-pointer select with the HBM path)
 		if (far) {
-			const Anchor e = ga[(uint32_t)j];
-			pj = gp[(uint32_t)j], fj = gf[(uint32_t)j];
-			xj = (int)(uint32_t)e.x, qj = (int)(uint32_t)e.y;
+			// volatile: the compiler must not merge these with the LDS reads into flat loads
+			const volatile uint32_t *ge = reinterpret_cast<const volatile uint32_t*>(ga + (uint32_t)j);
+			xj = (int)ge[0], qj = (int)ge[2];
+			pj = *(const volatile int32_t*)(gp + (uint32_t)j), fj = *(const volatile int32_t*)(gf + (uint32_t)j);
 		}
 		// operands of the next anchor, fetched early (used when this anchor completes)
 		const Slot *nx = S + slot(i + 1);
@@ -203,18 +204,18 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 		// double products, as minimap2 evaluates it (dd <= bw < GAP_LUT wherever `ev` holds)
 		const int gap = s_gap[min(dd, GAP_LUT - 1)];
 		const int sc = (mind > span ? span : mind) - gap + fj;
-		const int key = ev ? (sc + KEY_BIAS) * RW + (RW - 1 - lr) : 0;
+		const int key = ev ? (sc << 5) + key_lane : 0;
 		// t[p[j]] = i, then t[j] == i
 		const bool mark = ev && pj >= 0;
 		const bool mark_far = mark && pj < ring_lo;
 		if (mark && !mark_far) S[slot(pj)].t = i;
-		if (mark_far) gt[(uint32_t)pj] = i;
-		const bool any_far = any64(far || mark_far);
-		if (any_far) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		if (mark_far) {                                                   // rare: the stamp goes to HBM, ahead of the reads below
+			*(volatile int32_t*)(gt + (uint32_t)pj) = i;
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		}
 		lds_order();
 		int tj = c->t;
-		asm volatile("" : "+v"(tj));                                      // keep this a plain LDS read (no flat-pointer select)
-		if (any_far) { if (far) tj = gt[(uint32_t)j]; }
+		if (far) tj = *(const volatile int32_t*)(gt + (uint32_t)j);
 		const bool tflag = ev && tj == i;
 		// running maximum, strict '>' against everything before this lane: keys are distinct and
 		// order equal scores by lane, so a lane beats all earlier ones iff it is the inclusive maximum
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 			if (lr == 0 && !fresh) a += row ? c1 : c0;
 		}
 		const int Sa = row_incl_add(a);
-		const int M = row_incl_max(improve ? -Sa : NEG);
+		const int M = row_incl_max(-Sa);                                  // over all lanes: the floor never binds off an improvement
 		const int ns = max(Sa, Sa + M);
 		// first lane where the sequential loop breaks (lane RW-1 if none): one compare gives the mask
 		int nsb = tflag && !improve ? ns : INT32_MIN;
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 		const int bl = __builtin_ctz(bm | 0x80000000u);
 		// best candidate among the lanes the sequential loop reaches (first lane wins ties) =
 		// the inclusive maximum at the break lane
-		const int mk = __builtin_amdgcn_ds_bpermute(((lane & RW) | bl) << 2, incl);
+		const int mk = __builtin_amdgcn_ds_bpermute((bl << 2) | perm_half, incl);
 		const int best = (mk >> 5) - KEY_BIAS;                            // -KEY_BIAS when there was no candidate
 		if (best > max_f) max_f = best, max_j = jb - (RW - 1 - (mk & (RW - 1)));
 		const bool done = active && (bm != 0 || (wm & last_lane) == 0 || jb - RW < lo);
