@@ -189,3 +189,54 @@ def test_hitmap_is_sample_hits_with_best_hit(tmp_path):
             base += m
         rd.close()
     assert len(hm) == len(ref)
+
+
+def test_database_builder_header_contract_and_chunks(tmp_path, monkeypatch):
+    """database.multi_threaded_builder -> databaseN.fna.gz with `tax_unit:accession` headers
+    (database.py:52-67), which the index builder turns into one genome per name."""
+    import gzip
+    from monica_amd import database, _capi
+    gen = tmp_path / "genomes"
+    gen.mkdir()
+    monkeypatch.setattr(database, "GENOMES_PATH", str(gen))
+    rng = np.random.default_rng(11)
+
+    def write_genome(name, contigs):
+        path = gen / name
+        with gzip.open(path, "wt") as f:
+            for title, n in contigs:
+                seq = "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+                f.write(">" + title + "\n")
+                for i in range(0, n, 70):
+                    f.write(seq[i:i + 70] + "\n")
+        return str(path)
+
+    g1 = write_genome("g1.fna.gz", [("NZ_1.1 Genus a chromosome", 3000), ("NZ_1p.1 plasmid", 500)])
+    g2 = write_genome("g2.fna.gz", [("NZ_2.1 Genus b", 2500)])
+    g3 = write_genome("g3.fna.gz", [("NZ_3.1 Genus c", 2000)])
+    genomes = [(g1, ("Genus_a", "ACC1.1")), (g2, ("Genus_b", "ACC2.1")), (g3, ("Genus_c", "ACC3.1"))]
+    out = tmp_path / "dbs"
+    path, lengths = database.multi_threaded_builder(genomes=genomes, max_chunk_size=1 << 20, databases_path=str(out),
+                                                    keep_genomes=True, n_threads=2)
+    assert path == str(out) and lengths == {"ACC1.1": 3500, "ACC2.1": 2500, "ACC3.1": 2000}
+    assert sorted(os.listdir(out)) == ["database0.fna.gz"] and os.path.exists(gen / "database_created")
+    with open(gen / "current_genomes_length.pkl", "rb") as f:
+        assert pickle.load(f) == lengths
+    with gzip.open(out / "database0.fna.gz", "rt") as f:
+        text = f.read().splitlines()
+    heads = [l for l in text if l.startswith(">")]
+    assert heads == [">Genus_a:ACC1.1 NZ_1.1 Genus a chromosome", ">Genus_a:ACC1.1 NZ_1p.1 plasmid",
+                     ">Genus_b:ACC2.1 NZ_2.1 Genus b", ">Genus_c:ACC3.1 NZ_3.1 Genus c"]
+    assert max(len(l) for l in text if not l.startswith(">")) == 60
+    idx = _capi.Index.build(str(out / "database0.fna.gz"))
+    assert idx.contig_names == ["Genus_a:ACC1.1", "Genus_a:ACC1.1", "Genus_b:ACC2.1", "Genus_c:ACC3.1"]
+    assert idx.genome_names == ["Genus_a:ACC1.1", "Genus_b:ACC2.1", "Genus_c:ACC3.1"] and idx.genome_lens == [3500, 2500, 2000]
+    # the reference's chunking: a genome larger than the limit goes alone; the genome that closes a
+    # chunk by not fitting is not carried over (database.py:84-90)
+    sizes = [os.path.getsize(g) for g in (g1, g2, g3)]
+    chunks = list(database._genomes_splitter(genomes, max_chunk_size=sizes[0] + 10))
+    assert chunks == [[genomes[0]], [genomes[2]]]
+    assert list(database._genomes_splitter(genomes, max_chunk_size=sizes[1] - 1))[0] == [genomes[0]]
+    # keep_genomes falsy: the downloaded genomes are deleted after the build
+    database.multi_threaded_builder(genomes=genomes, max_chunk_size=1 << 20, databases_path=str(out), n_threads=1)
+    assert not [f for f in os.listdir(gen) if f.endswith(".fna.gz")]
