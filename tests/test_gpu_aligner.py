@@ -123,6 +123,46 @@ def test_reference_call_sequence(oracle, tmp_path, n_parts, mode):
     assert count_records(str(query / "mapped" / "sampleA.pass.fastq")) >= sum(r.startswith("mapped") for r in route_a)
 
 
+def test_focus_second_pass(oracle, tmp_path):
+    """monica.py:455-467: reads routed to focus/ are classified again, by the same function,
+    against strain-level indexes."""
+    names, seqs = util.small_genomes(4, 150_000, 200_000)
+    dbs = tmp_path / "databases"
+    dbs.mkdir()
+    synth.write_fasta(str(dbs / "database0.fna.gz"), names, seqs)
+    paths = aligner.indexer(str(dbs), str(tmp_path / "indexes"))
+    # two "strains" of genome 1: the genome itself and a 1 %-diverged copy
+    strain_names = ["Genus1_species1_strainA:STRA.1", "Genus1_species1_strainB:STRB.1"]
+    strain_seqs = [seqs[1], synth.diverge(seqs[1], 99, 10_000)]
+    fdbs = tmp_path / "focus_databases"
+    fdbs.mkdir()
+    synth.write_fasta(str(fdbs / "database0.fna.gz"), strain_names, strain_seqs)
+    focus_paths = aligner.indexer(str(fdbs), str(tmp_path / "focus_indexes"))
+
+    query, out = tmp_path / "query", tmp_path / "output"
+    query.mkdir(), out.mkdir()
+    bases, offsets, truth = synth.reads(seqs, 200, 2500, seed=78)
+    synth.write_fastq(str(query / "s.fastq"), bases, offsets, ids=[f"r{i}" for i in range(200)])
+    cwd = os.getcwd()
+    try:
+        first = aligner.multi_threaded_aligner(str(query), paths, mode="basic", n_threads=1,
+                                               focus_species=["Genus1_species1"], output_folder=str(out))
+        n_focus = count_records(str(query / "focus" / "s.fastq"))
+        assert n_focus == first["s"].get("Genus1_species1", Counter()).get("ACC000001.1", 0) and n_focus > 10
+        focus_reads = list(fastq.read_batches(str(query / "focus" / "s.fastq")))[0]
+        (out / "focus").mkdir()
+        second = aligner.multi_threaded_aligner(str(query / "focus"), focus_paths, mode="basic", n_threads=1,
+                                                output_folder=str(out / "focus"))
+    finally:
+        os.chdir(cwd)
+    want, route = expected_from_oracle(oracle, [(strain_names, strain_seqs, 0)], strain_names, focus_reads.bases,
+                                       focus_reads.offsets, "basic")
+    assert second == {"s": want}
+    assert focus_reads.ids[0].startswith("r")                              # focus/ keeps the original ids
+    assert count_records(str(query / "focus" / "mapped" / "s.fastq")) == sum(r.startswith("mapped") for r in route)
+    assert count_records(str(query / "focus" / "ambiguous" / "s.fastq")) == route.count("ambiguous")
+
+
 def test_no_samples_returns_zero(tmp_path, capsys):
     cwd = os.getcwd()
     try:
