@@ -202,7 +202,7 @@ __global__ __launch_bounds__(PR_THREADS) void mnc_probe_buckets(Batch B, uint32_
 // One workgroup per super-tile: its 256 runs of hits are read back and dealt to the 256 reads
 // (hits from the bottom of the read's slot range, too-frequent minimizers from the top), then
 // one wave per read finishes hit_cnt / an_cnt / rep_len.
-constexpr int CO_THREADS = 256;
+constexpr int CO_THREADS = 1024;
 constexpr int SUPER_READS = PS_TILES * PT_READS;
 
 __global__ __launch_bounds__(CO_THREADS) void mnc_collect_hits(Batch B)
