@@ -35,7 +35,12 @@ __global__ __launch_bounds__(PA_THREADS) void mnc_partition_queries(Batch B)
 	__shared__ int64_t s_off[PB_N];
 	__shared__ uint64_t s_rec[PA_STAGE];
 	__shared__ uint8_t s_bkt[PA_STAGE];
-	const uint32_t tile = blockIdx.x;
+	// Workgroups are dealt round-robin over the 8 XCDs: give each XCD a contiguous range of
+	// tiles, so that the short runs of neighbouring tiles (adjacent in a bucket's query array)
+	// are merged into full lines by one L2 instead of being written piecemeal by eight
+	const uint32_t per_xcd = (B.n_tiles + 7) / 8;
+	const uint32_t tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+	if (tile >= B.n_tiles) return;
 	const int tid = threadIdx.x, lane = lane_id();
 	// this wave's read: fetch its first minimizers before anything else waits on memory
 	const uint32_t r = tile * PT_READS + (tid >> 6);
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(CO_THREADS) void mnc_collect_hits(Batch B)
 void launch_partition(const Batch &B, hipStream_t st)
 {
 	if (B.n_tiles == 0) return;
-	hipLaunchKernelGGL(mnc_partition_queries, dim3(B.n_tiles), dim3(PA_THREADS), 0, st, B);
+	hipLaunchKernelGGL(mnc_partition_queries, dim3((B.n_tiles + 7) / 8 * 8), dim3(PA_THREADS), 0, st, B);
 }
 
 void launch_probe(const Batch &B, hipStream_t st)
