@@ -60,6 +60,7 @@ struct DeviceIndex {          // one per (index, device)
 	int region_bits = 0;           // log2(slots per region)
 	int disp_bits = 0;             // log2(displacement buckets per region)
 	uint8_t *disp = nullptr;       // [PB_N][1 << disp_bits]
+	uint32_t *salt = nullptr;      // [PB_N] per-region salt of the slot function (pd_slot)
 	uint32_t *filter = nullptr;    // per region: 2^PF_BITS-bit presence filter (see k_probe.hip)
 	uint64_t *positions = nullptr;
 	int32_t *contig_genome = nullptr;

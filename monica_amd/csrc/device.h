@@ -43,9 +43,12 @@ __host__ __device__ __forceinline__ uint32_t pd_base(uint32_t rest, int region_b
 // slot = base + disp * step with a key-dependent odd step (double hashing), so two keys of one
 // displacement bucket that share a base still separate for some disp
 __host__ __device__ __forceinline__ uint32_t pd_step(uint32_t rest) { return ((rest * 0x85EBCA6Bu) >> 7) | 1u; }
-__host__ __device__ __forceinline__ uint32_t pd_slot(uint32_t rest, uint32_t disp, int region_bits)
+// `salt` is a per-region constant mixed into the key: two keys of one displacement bucket with
+// the same (base, step) cannot be separated by any disp, so the builder then re-salts the region
+__host__ __device__ __forceinline__ uint32_t pd_slot(uint32_t rest, uint32_t disp, int region_bits, uint32_t salt)
 {
-	return (pd_base(rest, region_bits) + disp * pd_step(rest)) & ((1u << region_bits) - 1u);
+	const uint32_t k = rest ^ salt;
+	return (pd_base(k, region_bits) + disp * pd_step(k)) & ((1u << region_bits) - 1u);
 }
 
 // start of run (bucket, tile) in the bucket-major record array.  The offsets are stored
@@ -87,6 +90,7 @@ struct Batch {
 	// ---- index
 	const TableSlot *table;       // [PB_N][1 << region_bits]
 	const uint8_t *disp;          // [PB_N][1 << disp_bits] hash-and-displace displacements
+	const uint32_t *salt;         // [PB_N] per-region salt of the slot function
 	const uint32_t *filter;       // [PB_N][PF_WORDS] presence bits of (region, low PF_BITS of the rest)
 	int region_bits, disp_bits;
 	const uint64_t *positions;

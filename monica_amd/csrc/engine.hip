@@ -167,14 +167,19 @@ int index_upload(mnc_index *idx, int device, DeviceIndex **out)
 	for (auto &v : reg) biggest = std::max(biggest, v.size());
 	int region_bits = 6;
 	while ((1ULL << region_bits) < biggest * 2) ++region_bits;
-	if (region_bits > 28) { set_error("index too large for one device table"); return MNC_ERR_UNSUPPORTED; }
-	const int disp_bits = std::min(PD_MAX_BITS, std::max(0, region_bits - 3));
-	const size_t R = (size_t)1 << region_bits, NB = (size_t)1 << disp_bits;
+	int disp_bits = 0;
+	size_t R = 0, NB = 0;
 	std::vector<TableSlot> tab;
-	std::vector<uint8_t> disp((size_t)PB_N * NB, 0);
-	std::vector<uint32_t> filt((size_t)PB_N * PF_WORDS, 0u);
-	try { tab.assign((size_t)PB_N * R, TableSlot{0, 0, 0}); } catch (const std::bad_alloc &) { return MNC_ERR_NOMEM; }
-	{
+	std::vector<uint8_t> disp;
+	std::vector<uint32_t> filt((size_t)PB_N * PF_WORDS, 0u), salt(PB_N, 0u);
+	constexpr int MAX_SALTS = 32, MAX_GROW = 3;
+	for (int grow = 0;; ++grow, ++region_bits) {
+		if (region_bits > 28) { set_error("index too large for one device table"); return MNC_ERR_UNSUPPORTED; }
+		disp_bits = std::min(PD_MAX_BITS, std::max(0, region_bits - 3));
+		R = (size_t)1 << region_bits, NB = (size_t)1 << disp_bits;
+		disp.assign((size_t)PB_N * NB, 0);
+		std::fill(filt.begin(), filt.end(), 0u);
+		try { tab.assign((size_t)PB_N * R, TableSlot{0, 0, 0}); } catch (const std::bad_alloc &) { return MNC_ERR_NOMEM; }
 		// regions are independent: build them on a few host threads
 		std::atomic<int> next_region{0}, failed{-1};
 		auto work = [&]() {
@@ -193,29 +198,42 @@ int index_upload(mnc_index *idx, int device, DeviceIndex **out)
 				}
 				for (size_t i = 0; i < NB; ++i) order[i] = (uint32_t)i;
 				std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return bk[x].size() != bk[y].size() ? bk[x].size() > bk[y].size() : x < y; });
-				for (uint32_t o : order) {                   // largest displacement buckets first
-					const auto &keys = bk[o];
-					if (keys.empty()) break;
-					int d = 0;
-					for (; d < 256; ++d) {
-						bool ok = true;
-						for (size_t a = 0; a < keys.size() && ok; ++a) {
-							const uint32_t sa = pd_slot(pb_rest(idx->keys[keys[a]]), (uint32_t)d, region_bits);
-							if (T[sa].key) ok = false;
-							for (size_t c = 0; c < a && ok; ++c)
-								if (sa == pd_slot(pb_rest(idx->keys[keys[c]]), (uint32_t)d, region_bits)) ok = false;
+				bool placed = false;
+				for (int sx = 0; sx < MAX_SALTS && !placed; ++sx) {
+					// salt 0 first; a region is re-salted only when two keys of one displacement
+					// bucket share base and step (no displacement can separate those)
+					const uint32_t sv = (uint32_t)sx * 0x9E3779B9u;
+					if (sx > 0) {
+						std::fill(T, T + R, TableSlot{0, 0, 0});
+						std::fill(disp.begin() + (size_t)b * NB, disp.begin() + (size_t)(b + 1) * NB, (uint8_t)0);
+					}
+					placed = true;
+					for (uint32_t o : order) {               // largest displacement buckets first
+						const auto &keys = bk[o];
+						if (keys.empty()) break;
+						int d = 0;
+						for (; d < 256; ++d) {
+							bool ok = true;
+							for (size_t a = 0; a < keys.size() && ok; ++a) {
+								const uint32_t sa = pd_slot(pb_rest(idx->keys[keys[a]]), (uint32_t)d, region_bits, sv);
+								if (T[sa].key) ok = false;
+								for (size_t c = 0; c < a && ok; ++c)
+									if (sa == pd_slot(pb_rest(idx->keys[keys[c]]), (uint32_t)d, region_bits, sv)) ok = false;
+							}
+							if (ok) break;
 						}
-						if (ok) break;
+						if (d == 256) { placed = false; break; }
+						disp[(size_t)b * NB + o] = (uint8_t)d;
+						for (uint32_t ki : keys) {
+							const uint32_t h = idx->keys[ki];
+							const uint64_t off = idx->key_off[ki], c = idx->key_off[ki + 1] - off;
+							TableSlot &sl = T[pd_slot(pb_rest(h), (uint32_t)d, region_bits, sv)];
+							sl.key = h + 1, sl.cnt = (uint32_t)c, sl.val = c == 1 ? idx->pos[off] : off;
+						}
 					}
-					if (d == 256) { failed.store(b); return; }
-					disp[(size_t)b * NB + o] = (uint8_t)d;
-					for (uint32_t ki : keys) {
-						const uint32_t h = idx->keys[ki];
-						const uint64_t off = idx->key_off[ki], c = idx->key_off[ki + 1] - off;
-						TableSlot &sl = T[pd_slot(pb_rest(h), (uint32_t)d, region_bits)];
-						sl.key = h + 1, sl.cnt = (uint32_t)c, sl.val = c == 1 ? idx->pos[off] : off;
-					}
+					if (placed) salt[b] = sv;
 				}
+				if (!placed) { failed.store(b); return; }
 			}
 		};
 		unsigned nt = std::thread::hardware_concurrency();
@@ -224,7 +242,8 @@ int index_upload(mnc_index *idx, int device, DeviceIndex **out)
 		for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work);
 		work();
 		for (auto &t : pool) t.join();
-		if (failed.load() >= 0) {
+		if (failed.load() < 0) break;
+		if (grow == MAX_GROW) {                                   // more room did not help either
 			const int b = failed.load();
 			set_error("perfect hashing of table region %d failed (region of %zu keys, R %zu, NB %zu)", b, reg[b].size(), R, NB);
 			return MNC_ERR_UNSUPPORTED;
@@ -236,6 +255,8 @@ int index_upload(mnc_index *idx, int device, DeviceIndex **out)
 	HIP_TRY(hipMemcpy(d.filter, filt.data(), filt.size() * 4, hipMemcpyHostToDevice));
 	HIP_TRY(hipMalloc((void**)&d.disp, disp.size()));
 	HIP_TRY(hipMemcpy(d.disp, disp.data(), disp.size(), hipMemcpyHostToDevice));
+	HIP_TRY(hipMalloc((void**)&d.salt, salt.size() * 4));
+	HIP_TRY(hipMemcpy(d.salt, salt.data(), salt.size() * 4, hipMemcpyHostToDevice));
 	HIP_TRY(hipMalloc((void**)&d.table, tab.size() * sizeof(TableSlot)));
 	HIP_TRY(hipMemcpy(d.table, tab.data(), tab.size() * sizeof(TableSlot), hipMemcpyHostToDevice));
 	HIP_TRY(hipMalloc((void**)&d.positions, (idx->pos.size() + 1) * 8));
@@ -257,6 +278,7 @@ void index_release_device(mnc_index *idx)
 		if (d.table) (void)hipFree(d.table);
 		if (d.filter) (void)hipFree(d.filter);
 		if (d.disp) (void)hipFree(d.disp);
+		if (d.salt) (void)hipFree(d.salt);
 		if (d.positions) (void)hipFree(d.positions);
 		if (d.contig_genome) (void)hipFree(d.contig_genome);
 	}
@@ -518,7 +540,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	Batch &B = e->B;
 	memset(&B, 0, sizeof(B));
 	B.bases = d_bases, B.offsets = d_offsets, B.n_reads = n_reads, B.total_bases = total_bases, B.min_mapq = min_mapq;
-	B.table = e->didx->table, B.filter = e->didx->filter, B.disp = e->didx->disp, B.positions = e->didx->positions;
+	B.table = e->didx->table, B.filter = e->didx->filter, B.disp = e->didx->disp, B.salt = e->didx->salt, B.positions = e->didx->positions;
 	B.region_bits = e->didx->region_bits, B.disp_bits = e->didx->disp_bits;
 	B.contig_genome = e->didx->contig_genome, B.mid_occ = idx->mid_occ, B.n_genomes = (int)idx->genome_name.size();
 	{

@@ -32,7 +32,6 @@ namespace mnc {
 constexpr int ROWS = 2;                       // reads per wave
 constexpr int RW = 64 / ROWS;                 // lanes per read = ring block size
 constexpr uint32_t NONE16 = 0xffffu;
-constexpr int NEG = -(1 << 24);
 #ifndef INT32_MIN
 #define INT32_MIN (-2147483647 - 1)
 #endif

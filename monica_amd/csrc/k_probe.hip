@@ -146,6 +146,7 @@ __global__ __launch_bounds__(PR_THREADS) void mnc_probe_buckets(Batch B, uint32_
 	const unsigned long long lt = (1ULL << lane) - 1ULL;
 	const uint32_t mid_occ = (uint32_t)B.mid_occ;
 	const int rbits = B.region_bits;
+	const uint32_t salt = B.salt[bucket];
 	const TableSlot *table = B.table + ((size_t)bucket << rbits);
 	{
 		const uint32_t t0 = T * PS_TILES, t1 = min(t0 + PS_TILES, B.n_tiles);
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(PR_THREADS) void mnc_probe_buckets(Batch B, uint32_
 					const uint32_t bit = rest & ((1u << PF_BITS) - 1u);
 					pend[u] = pend[u] && ((s_filter[bit >> 5] >> (bit & 31)) & 1u);
 					want[u] = pb_hash(rest, bucket) + 1;
-					slot[u] = pd_slot(rest, s_disp[rest & (uint32_t)(nb - 1)], rbits);
+					slot[u] = pd_slot(rest, s_disp[rest & (uint32_t)(nb - 1)], rbits, salt);
 				}
 				TableSlot sl[PR_U];
 #pragma unroll

@@ -216,6 +216,48 @@ def test_repetitive_index_gives_many_anchors(capi, oracle):
     w["eng"].set_debug(0)
 
 
+def test_many_chain_ends_per_read(capi, oracle):
+    """A hundred diverged copies of one short unit: a short read chains to most of them, i.e. far
+    more than 64 chain ends with a few thousand anchors -- the sequential walk kept inside the
+    LDS backtrack kernel -- next to reads with a few dozen ends, which take the parallel form,
+    and ends that share a peak."""
+    unit = synth.genome(0xA1, 2000)
+    copies = [synth.diverge(unit, 0xB0 + i, 30_000) for i in range(100)]
+    spacer = synth.genome(0xA2, 300)
+    contig = np.concatenate([np.concatenate([c, spacer]) for c in copies])
+    few = [synth.diverge(unit[:1500], 0xC0 + i, 40_000) for i in range(12)]
+    seqs = [contig, np.concatenate(few), synth.genome(0xA3, 50_000)]
+    names = [synth.contig_name(i) for i in range(3)]
+    w = _world_from(capi, oracle, names, seqs)
+    reads = [copies[7][300:450], copies[50][1000:1160], copies[93][40:190], unit[600:760],
+             few[3][100:1400], few[8][:900], seqs[2][1000:4000]]
+    bases, offsets = util.pack_reads(reads)
+    _compare_batch(capi, oracle, w, bases, offsets, min_mapq=0)
+    per_read = np.diff(w["eng"].dump(capi.DUMP_AN_OFFSETS, np.int64))
+    assert w["eng"].counters()["chains"] > 64 * 4 and per_read[:4].max() <= 2560 and per_read[:4].min() > 640   # the regime this test is for
+    _compare_batch(capi, oracle, w, bases, offsets, min_mapq=60)
+
+
+def test_small_indexes_always_get_a_perfect_hash(capi, oracle):
+    """Tiny table regions make it likely that two keys of one displacement bucket share base and
+    step; the builder then re-salts that region (or grows the regions).  Every index must load
+    and answer exactly."""
+    for k in range(12):
+        seqs = [synth.genome(0x5A17 + k, 20_000 + 7_000 * k), synth.genome(0x5B17 + k, 15_000)]
+        names = [synth.contig_name(i) for i in range(2)]
+        w = _world_from(capi, oracle, names, seqs)
+        b, o, truth = synth.reads(seqs, 24, 1500, seed=100 + k)
+        assign, best, nhits = w["eng"].classify(b, o, 60)
+        oassign, obest, onh, oflat = w["oidx"].classify(b, o, 60)
+        assert np.array_equal(assign, oassign) and np.array_equal(nhits, onh)
+        an = w["eng"].dump(capi.DUMP_ANCHORS, capi.ANCHOR_DTYPE)
+        an_off = w["eng"].dump(capi.DUMP_AN_OFFSETS, np.int64)
+        raw = b.tobytes()
+        for r in range(0, 24, 5):
+            oa, _ = w["oidx"].seeds(raw[o[r]:o[r + 1]])
+            assert np.array_equal(an[an_off[r]:an_off[r + 1]]["x"], oa["x"])
+
+
 def test_dense_sketch_overflows_the_query_budget_and_is_redone(capi, oracle, world):
     """Low-complexity reads keep (almost) every k-mer as a minimizer: more query records than
     the one-per-three-bases budget, so the batch is redone with exact room."""
