@@ -93,6 +93,7 @@ struct Batch {
 	const uint32_t *salt;         // [PB_N] per-region salt of the slot function
 	const uint32_t *filter;       // [PB_N][PF_WORDS] presence bits of (region, low PF_BITS of the rest)
 	int region_bits, disp_bits;
+	int disp_in_lds;              // the displacement table of a region fits the probe kernel's LDS copy
 	const uint64_t *positions;
 	const int32_t *contig_genome;
 	int mid_occ;

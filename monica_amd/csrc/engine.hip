@@ -175,7 +175,7 @@ int index_upload(mnc_index *idx, int device, DeviceIndex **out)
 	constexpr int MAX_SALTS = 32, MAX_GROW = 3;
 	for (int grow = 0;; ++grow, ++region_bits) {
 		if (region_bits > 28) { set_error("index too large for one device table"); return MNC_ERR_UNSUPPORTED; }
-		disp_bits = std::min(PD_MAX_BITS, std::max(0, region_bits - 3));
+		disp_bits = std::max(0, region_bits - 3);            // about four keys per displacement bucket at most
 		R = (size_t)1 << region_bits, NB = (size_t)1 << disp_bits;
 		disp.assign((size_t)PB_N * NB, 0);
 		std::fill(filt.begin(), filt.end(), 0u);
@@ -540,7 +540,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	Batch &B = e->B;
 	memset(&B, 0, sizeof(B));
 	B.bases = d_bases, B.offsets = d_offsets, B.n_reads = n_reads, B.total_bases = total_bases, B.min_mapq = min_mapq;
-	B.table = e->didx->table, B.filter = e->didx->filter, B.disp = e->didx->disp, B.salt = e->didx->salt, B.positions = e->didx->positions;
+	B.table = e->didx->table, B.filter = e->didx->filter, B.disp = e->didx->disp, B.salt = e->didx->salt, B.disp_in_lds = (e->didx->disp_bits <= PD_MAX_BITS && !getenv("MNC_DISP_IN_HBM")) ? 1 : 0, B.positions = e->didx->positions;
 	B.region_bits = e->didx->region_bits, B.disp_bits = e->didx->disp_bits;
 	B.contig_genome = e->didx->contig_genome, B.mid_occ = idx->mid_occ, B.n_genomes = (int)idx->genome_name.size();
 	{

@@ -135,7 +135,9 @@ __global__ __launch_bounds__(PR_THREADS) void mnc_probe_buckets(Batch B, uint32_
 #pragma unroll
 		for (int k = 0; k < PF_WORDS / 4 / PR_THREADS; ++k) dst[k * PR_THREADS + threadIdx.x] = src[k * PR_THREADS + threadIdx.x];
 		const uint8_t *ds = B.disp + (size_t)bucket * nb;
-		if (nb >= 16 * PR_THREADS) {
+		if (!B.disp_in_lds) {
+			// a very large index: more displacement buckets per region than LDS holds; read them in place
+		} else if (nb >= 16 * PR_THREADS) {
 			for (int k = threadIdx.x; k < nb / 16; k += PR_THREADS)
 				reinterpret_cast<uint4*>(s_disp)[k] = reinterpret_cast<const uint4*>(ds)[k];
 		} else for (int k = threadIdx.x; k < nb; k += PR_THREADS) s_disp[k] = ds[k];
@@ -147,6 +149,8 @@ __global__ __launch_bounds__(PR_THREADS) void mnc_probe_buckets(Batch B, uint32_
 	const uint32_t mid_occ = (uint32_t)B.mid_occ;
 	const int rbits = B.region_bits;
 	const uint32_t salt = B.salt[bucket];
+	const bool disp_in_lds = B.disp_in_lds != 0;
+	const uint8_t *disp_hbm = B.disp + (size_t)bucket * nb;
 	const TableSlot *table = B.table + ((size_t)bucket << rbits);
 	{
 		const uint32_t t0 = T * PS_TILES, t1 = min(t0 + PS_TILES, B.n_tiles);
@@ -177,7 +181,8 @@ __global__ __launch_bounds__(PR_THREADS) void mnc_probe_buckets(Batch B, uint32_
 					const uint32_t bit = rest & ((1u << PF_BITS) - 1u);
 					pend[u] = pend[u] && ((s_filter[bit >> 5] >> (bit & 31)) & 1u);
 					want[u] = pb_hash(rest, bucket) + 1;
-					slot[u] = pd_slot(rest, s_disp[rest & (uint32_t)(nb - 1)], rbits, salt);
+					const uint32_t db = rest & (uint32_t)(nb - 1);
+					slot[u] = pd_slot(rest, disp_in_lds ? s_disp[db] : (pend[u] ? disp_hbm[db] : 0), rbits, salt);
 				}
 				TableSlot sl[PR_U];
 #pragma unroll

@@ -258,6 +258,14 @@ def test_small_indexes_always_get_a_perfect_hash(capi, oracle):
             assert np.array_equal(an[an_off[r]:an_off[r + 1]]["x"], oa["x"])
 
 
+def test_displacement_table_read_in_place(capi, oracle, world, monkeypatch):
+    """An index with more displacement buckets per region than the probe kernel's LDS copy holds
+    (hundreds of genomes) reads the displacements from HBM; the switch forces that path."""
+    monkeypatch.setenv("MNC_DISP_IN_HBM", "1")
+    b, o, _ = synth.reads(world["seqs"], 200, 2000, seed=19)
+    _compare_batch(capi, oracle, world, b, o)
+
+
 def test_dense_sketch_overflows_the_query_budget_and_is_redone(capi, oracle, world):
     """Low-complexity reads keep (almost) every k-mer as a minimizer: more query records than
     the one-per-three-bases budget, so the batch is redone with exact room."""
