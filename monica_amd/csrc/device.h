@@ -151,6 +151,8 @@ struct Batch {
 // size classes of the row chaining kernel (anchors per LDS tile)
 constexpr int MAX_CHAIN_CLASSES = 24;
 struct ChainClasses { int n; int nm[MAX_CHAIN_CLASSES]; };
+// the per-class read lists laid end to end: list c holds ordinals [start[c], start[c + 1])
+struct ClassSpans { uint32_t start[MAX_CHAIN_CLASSES + 2]; uint32_t stride; int n; };
 
 // ---------------------------------------------------------------- helpers
 

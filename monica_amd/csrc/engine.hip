@@ -25,7 +25,7 @@ void launch_expand_sort(const Batch &B, const uint32_t *list, uint32_t count, in
 int expand_sort_prepare(int max_nm);
 void launch_backtrack(const Batch &B, const uint32_t *read_list, uint32_t n_list, hipStream_t st);
 void launch_bin_reads(const Batch &B, const ChainClasses &C, uint32_t *cls_count, uint32_t *cls_list, hipStream_t st);
-void launch_chain_dp_ring(const Batch &B, const uint32_t *list, uint32_t count, int stress, hipStream_t st);
+void launch_chain_dp_ring(const Batch &B, const uint32_t *lists, const ClassSpans &spans, int stress, hipStream_t st);
 void launch_chain_tail(const Batch &B, const uint32_t *list, uint32_t count, int NM, hipStream_t st);
 size_t chain_tail_lds_bytes(int NM);
 int chain_tail_prepare(size_t max_lds);
@@ -628,8 +628,10 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	{
 		StageTimer t(e, MNC_STAGE_CHAIN);           // DP: every read, whatever its size
 		const uint32_t *lists = e->cls_list.as<uint32_t>();
-		for (int c = 0; c <= CHAIN_CLASSES.n; ++c)
-			launch_chain_dp_ring(B, lists + (size_t)c * n_reads, cls_count[c], e->debug == 2, st);
+		ClassSpans spans;
+		spans.n = CHAIN_CLASSES.n + 1, spans.stride = (uint32_t)n_reads, spans.start[0] = 0;
+		for (int c = 0; c <= CHAIN_CLASSES.n; ++c) spans.start[c + 1] = spans.start[c] + cls_count[c];
+		launch_chain_dp_ring(B, lists, spans, e->debug == 2, st);
 	}
 	{
 		StageTimer t(e, MNC_STAGE_BACKTRACK);       // LDS form per size class; sequential form beyond

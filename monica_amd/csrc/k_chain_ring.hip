@@ -109,7 +109,7 @@ __device__ __forceinline__ int max_shr1_from(int v)
 }
 
 template <int PAST>
-__global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, const uint32_t *list, uint32_t count)
+__global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, const uint32_t *lists, ClassSpans spans)
 {
 	constexpr int NBLK = PAST + 2;                                       // past + current + next
 	constexpr int RING = NBLK * RW;
@@ -126,9 +126,16 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 	const int slot_row = (threadIdx.x >> 6) * ROWS + row;
 	Slot *S = s_rows[slot_row];
 
+	// one launch for every read of the batch, in size-class order (neighbours in a wave have
+	// similar anchor counts): ordinal li -> (class c, index in its list)
 	const uint32_t li = blockIdx.x * (ROWS * DP_WAVES) + slot_row;
-	const bool has = li < count;
-	const uint32_t r = has ? list[li] : 0;
+	const bool has = li < spans.start[spans.n];
+	uint32_t r = 0;
+	if (has) {
+		int c = 0;
+		while (li >= spans.start[c + 1]) ++c;
+		r = lists[(size_t)c * spans.stride + (li - spans.start[c])];
+	}
 	const int64_t a_off = has ? B.an_off[r] : 0;
 	const int n = has ? (int)(B.an_off[r + 1] - a_off) : 0;
 	const Anchor *ga = B.a + a_off;
@@ -553,12 +560,13 @@ int chain_tail_prepare(size_t max_lds)
 
 size_t chain_tail_lds_bytes(int NM) { return (size_t)ROWS * ((size_t)NM * 14 + TAIL_ENDS * 32); }
 
-void launch_chain_dp_ring(const Batch &B, const uint32_t *list, uint32_t count, int stress, hipStream_t st)
+void launch_chain_dp_ring(const Batch &B, const uint32_t *lists, const ClassSpans &spans, int stress, hipStream_t st)
 {
+	const uint32_t count = spans.start[spans.n];
 	if (count == 0) return;
 	const unsigned per = ROWS * DP_WAVES, blocks = (count + per - 1) / per;
-	if (stress) hipLaunchKernelGGL(mnc_chain_dp_ring<0>, dim3(blocks), dim3(64 * DP_WAVES), 0, st, B, list, count);
-	else hipLaunchKernelGGL(mnc_chain_dp_ring<2>, dim3(blocks), dim3(64 * DP_WAVES), 0, st, B, list, count);
+	if (stress) hipLaunchKernelGGL(mnc_chain_dp_ring<0>, dim3(blocks), dim3(64 * DP_WAVES), 0, st, B, lists, spans);
+	else hipLaunchKernelGGL(mnc_chain_dp_ring<2>, dim3(blocks), dim3(64 * DP_WAVES), 0, st, B, lists, spans);
 }
 
 void launch_chain_tail(const Batch &B, const uint32_t *list, uint32_t count, int NM, hipStream_t st)
