@@ -295,6 +295,10 @@ struct mnc_engine {
 	DeviceIndex *didx = nullptr;
 	int device = 0;
 	hipStream_t stream = nullptr;
+	// side streams: the per-size-class launches of one stage are independent and run side by side
+	static constexpr int N_SIDE = 4;
+	hipStream_t side[N_SIDE]{};
+	hipEvent_t ev_fork = nullptr, ev_join[N_SIDE]{};
 	// constant tables
 	Buf gap_lut, logf_lut;
 	int logf_n = 0;
@@ -398,6 +402,11 @@ extern "C" void mnc_engine_destroy(mnc_engine *e)
 	               &e->hits_csr, &e->stats, &e->cls_count, &e->cls_list };
 	for (Buf *b : all) b->release();
 	for (int s = 0; s < MNC_N_STAGES; ++s) for (int k = 0; k < 2; ++k) if (e->ev[s][k]) (void)hipEventDestroy(e->ev[s][k]);
+	for (int k = 0; k < mnc_engine::N_SIDE; ++k) {
+		if (e->side[k]) (void)hipStreamDestroy(e->side[k]);
+		if (e->ev_join[k]) (void)hipEventDestroy(e->ev_join[k]);
+	}
+	if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
 	if (e->stream) (void)hipStreamDestroy(e->stream);
 	delete e;
 }
@@ -415,6 +424,11 @@ extern "C" int mnc_engine_create(mnc_index *idx, int device, mnc_engine **out)
 	if (rc) { delete e; return rc; }
 	hipError_t he = hipSetDevice(device);
 	if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+	for (int k = 0; k < mnc_engine::N_SIDE && he == hipSuccess; ++k) {
+		he = hipStreamCreateWithFlags(&e->side[k], hipStreamNonBlocking);
+		if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming);
+	}
+	if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
 	if (he != hipSuccess) { set_error("stream creation failed: %s", hipGetErrorString(he)); delete e; return MNC_ERR_HIP; }
 	for (int s = 0; s < MNC_N_STAGES; ++s) for (int k = 0; k < 2; ++k) (void)hipEventCreate(&e->ev[s][k]);
 	// gap cost: (int)(dd * .01 * avg_span) + (ilog2(dd) >> 1), evaluated in double exactly as
@@ -619,11 +633,31 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	B.f = e->f.as<int32_t>(), B.p = e->p.as<int32_t>(), B.v = e->v.as<int32_t>(), B.t = e->t.as<int32_t>(), B.u = e->u.as<uint64_t>();
 	B.regs = e->regs.as<mnc_reg_t>(), B.tmp_i32 = e->tmp_i32.as<int32_t>();
 
+	// The launches of one stage differ only in their LDS tile and touch different reads: they go
+	// to side streams between a fork and a join on the engine stream, so that one class fills
+	// the CUs another class's last waves leave idle.
+	auto fork = [&]() -> int {
+		HIP_TRY(hipEventRecord(e->ev_fork, st));
+		for (int k = 0; k < mnc_engine::N_SIDE; ++k) HIP_TRY(hipStreamWaitEvent(e->side[k], e->ev_fork, 0));
+		return MNC_OK;
+	};
+	auto join = [&]() -> int {
+		for (int k = 0; k < mnc_engine::N_SIDE; ++k) {
+			HIP_TRY(hipEventRecord(e->ev_join[k], e->side[k]));
+			HIP_TRY(hipStreamWaitEvent(st, e->ev_join[k], 0));
+		}
+		return MNC_OK;
+	};
 	{
 		StageTimer t(e, MNC_STAGE_SORT2);
 		const uint32_t *lists = e->cls_list.as<uint32_t>();
-		for (int c = 0; c <= CHAIN_CLASSES.n; ++c)      // the last list: reads too large for LDS (NM = 0)
-			launch_expand_sort(B, lists + (size_t)c * n_reads, cls_count[c], c < CHAIN_CLASSES.n ? CHAIN_CLASSES.nm[c] : 0, st);
+		if (int rc = fork()) return rc;
+		for (int c = 0, k = 0; c <= CHAIN_CLASSES.n; ++c) {     // the last list: reads too large for LDS (NM = 0)
+			if (cls_count[c] == 0) continue;
+			launch_expand_sort(B, lists + (size_t)c * n_reads, cls_count[c], c < CHAIN_CLASSES.n ? CHAIN_CLASSES.nm[c] : 0,
+			                   e->side[k++ % mnc_engine::N_SIDE]);
+		}
+		if (int rc = join()) return rc;
 	}
 	{
 		StageTimer t(e, MNC_STAGE_CHAIN);           // DP: every read, whatever its size
@@ -636,9 +670,14 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	{
 		StageTimer t(e, MNC_STAGE_BACKTRACK);       // LDS form per size class; sequential form beyond
 		const uint32_t *lists = e->cls_list.as<uint32_t>();
-		for (int c = 0; c < CHAIN_CLASSES.n; ++c)
-			launch_chain_tail(B, lists + (size_t)c * n_reads, cls_count[c], CHAIN_CLASSES.nm[c], st);
-		launch_backtrack(B, lists + (size_t)CHAIN_CLASSES.n * n_reads, cls_count[CHAIN_CLASSES.n], st);
+		if (int rc = fork()) return rc;
+		int k = 0;
+		for (int c = 0; c < CHAIN_CLASSES.n; ++c) {
+			if (cls_count[c] == 0) continue;
+			launch_chain_tail(B, lists + (size_t)c * n_reads, cls_count[c], CHAIN_CLASSES.nm[c], e->side[k++ % mnc_engine::N_SIDE]);
+		}
+		launch_backtrack(B, lists + (size_t)CHAIN_CLASSES.n * n_reads, cls_count[CHAIN_CLASSES.n], e->side[k % mnc_engine::N_SIDE]);
+		if (int rc = join()) return rc;
 	}
 	{ StageTimer t(e, MNC_STAGE_REGIONS);   launch_regions(B, e->regx.p, e->k64a.as<uint64_t>(), e->k64b.as<uint64_t>(), e->gated.as<mnc_hit_t>(), st); }
 	HIP_TRY(hipGetLastError());
