@@ -430,21 +430,34 @@ __global__ __launch_bounds__(64) void mnc_chain_tail(Batch B, const uint32_t *li
 				atomicMin(&W0[px], own << 16 | (W0[px] & 0xffffu));
 			lds_order();
 		}
-		// (E3) per-anchor share of its chain: count, (parent, child) lengths, top anchor
-		for (int x = lr; x < n; x += RW) {
-			const uint32_t w0 = W0[x], own = w0 >> 16, px = w0 & 0xffffu;
-			if (own == OWN_NONE) continue;
-			uint32_t *A = acc + own * 6;
-			atomicAdd(&A[0], 1u);
-			const bool same = px != NONE16 && (W0[px] >> 16) == own;
-			if (same) {
-				const int tl = (int)(xlo[x] - xlo[px]), ql = (int)qp[x] - (int)qp[px];
-				atomicAdd(&A[1], (uint32_t)(tl > span && ql > span ? span : tl < ql ? tl : ql));
-				atomicAdd(&A[2], (uint32_t)(tl > ql ? tl : ql));
-			} else {
-				A[3] = (uint32_t)x;                                            // the walk stops above this anchor
-				A[4] = px == NONE16 ? 0xffffffffu : (W1[px] & 0xffffu);
+		// (E3) per-anchor share of its chain: count, (parent, child) lengths, top anchor.  A lane's
+		// anchors (32 apart) mostly belong to one chain: sums are kept in registers while the owner
+		// stays the same, so the LDS atomics (every lane on the same three words) are few.
+		{
+			uint32_t c_own = OWN_NONE, c_cnt = 0, c_ml = 0, c_bl = 0;
+			auto flush = [&]() {
+				if (c_own == OWN_NONE) return;
+				uint32_t *A = acc + c_own * 6;
+				atomicAdd(&A[0], c_cnt);
+				if (c_bl) { atomicAdd(&A[1], c_ml); atomicAdd(&A[2], c_bl); }
+			};
+			for (int x = lr; x < n; x += RW) {
+				const uint32_t w0 = W0[x], own = w0 >> 16, px = w0 & 0xffffu;
+				if (own == OWN_NONE) continue;
+				if (own != c_own) { flush(); c_own = own, c_cnt = c_ml = c_bl = 0; }
+				++c_cnt;
+				const bool same = px != NONE16 && (W0[px] >> 16) == own;
+				if (same) {
+					const int tl = (int)(xlo[x] - xlo[px]), ql = (int)qp[x] - (int)qp[px];
+					c_ml += (uint32_t)(tl > span && ql > span ? span : tl < ql ? tl : ql);
+					c_bl += (uint32_t)(tl > ql ? tl : ql);
+				} else {
+					uint32_t *A = acc + own * 6;
+					A[3] = (uint32_t)x;                                        // the walk stops above this anchor
+					A[4] = px == NONE16 ? 0xffffffffu : (W1[px] & 0xffffu);
+				}
 			}
+			flush();
 		}
 		lds_order();
 		// (E4) chain records in rank order
