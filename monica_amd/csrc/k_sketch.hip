@@ -66,17 +66,13 @@ __global__ __launch_bounds__(256) void mnc_pack_bases(Batch B)
 
 // ================================================================ K1: minimizers
 constexpr int SK_THREADS = 256;                     // 4 waves = 4 reads per workgroup
-constexpr int SK_CHUNK = 1024;                      // k-mer positions per LDS chunk of one wave
-constexpr int SK_PAD = 10;                          // halo on each side (>= WIN - 1, even)
-constexpr int SK_LOGICAL = SK_CHUNK + 2 * SK_PAD + 16;   // hash slots per wave: positions c0-PAD .. c0+CHUNK+PAD, rounded up
-constexpr int SK_SLOTS = SK_LOGICAL + SK_LOGICAL / 16 + 1; // stored with one pad word per 16 slots (see sk_phys)
-constexpr int SK_WORDS = (SK_CHUNK + 2 * SK_PAD + KMER) / 16 + 4;
-constexpr int SK_ITERS = (SK_CHUNK + 2 * SK_PAD + 63) / 64;
+constexpr int SK_PER = 17;                          // positions per lane: an odd stride, so no LDS bank conflicts
+constexpr int SK_CHUNK = 64 * SK_PER;               // k-mer positions per LDS chunk of one wave
+constexpr int SK_PAD = 10;                          // halo on each side (>= WIN - 1)
+constexpr int SK_SLOTS = SK_CHUNK + 2 * SK_PAD + 4; // hash slots per wave: positions c0-PAD .. c0+CHUNK+PAD
+constexpr int SK_EXTRA = SK_SLOTS - SK_CHUNK;       // slots beyond the 64 x 17 the lanes hash in their main pass
+constexpr int SK_WORDS = (SK_CHUNK + 2 * SK_PAD + KMER + 32) / 16 + 4;
 static_assert(SK_THREADS / 64 == PT_READS, "one sketch workgroup = one partition tile");
-
-// slot q of a wave's hash window sits at q + q / 16: a lane that reads the 34 slots around its
-// 16 positions then strides 17 words against its neighbours -- no LDS bank conflicts
-__device__ __forceinline__ int sk_phys(int q) { return q + (q >> 4); }
 
 __device__ __forceinline__ uint32_t revcomp30(uint32_t fw)
 {
@@ -158,13 +154,13 @@ __device__ int sketch_serial(const uint8_t *s, int len, uint2 *out)
 // Output order is increasing position, 8 bytes per minimizer: {hash, pos<<1 | strand},
 // pos = index of the k-mer's last base.
 __device__ void sketch_one_read(const Batch &B, uint32_t r, int wv, int lane, int32_t *s_hash, uint32_t *s_words,
-                                unsigned long long *s_strand, uint32_t *s_hist);
+                                uint32_t *s_strand, uint32_t *s_hist);
 
 __global__ __launch_bounds__(SK_THREADS) void mnc_sketch_minimizers(Batch B)
 {
 	__shared__ __align__(16) int32_t s_hash_all[SK_THREADS / 64][SK_SLOTS];
 	__shared__ uint32_t s_words_all[SK_THREADS / 64][SK_WORDS];
-	__shared__ unsigned long long s_strand_all[SK_THREADS / 64][SK_ITERS];
+	__shared__ uint32_t s_strand_all[SK_THREADS / 64][64 + SK_EXTRA];   // per hashing lane: strand bits of its 17 positions
 	__shared__ uint32_t s_hist[PB_N];             // minimizers of this tile per table bucket
 
 	const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -177,7 +173,7 @@ __global__ __launch_bounds__(SK_THREADS) void mnc_sketch_minimizers(Batch B)
 }
 
 __device__ void sketch_one_read(const Batch &B, uint32_t r, int wv, int lane, int32_t *s_hash, uint32_t *s_words,
-                                unsigned long long *s_strand, uint32_t *s_hist)
+                                uint32_t *s_strand, uint32_t *s_hist)
 {
 	if (r >= B.n_reads) return;
 	const int64_t off = B.offsets[r];
@@ -186,62 +182,85 @@ __device__ void sketch_one_read(const Batch &B, uint32_t r, int wv, int lane, in
 	uint2 *out = B.mz + off;
 	if (n <= 0) { if (lane == 0) B.mz_cnt[r] = 0; return; }
 	if (B.ambig[r]) return;                         // mnc_sketch_ambiguous handles it
+	const int64_t n_packed = (B.total_bases + 15) >> 4;
 	int total = 0;                                  // minimizers written so far (uniform)
 	for (int c0 = 0; c0 < n; c0 += SK_CHUNK) {
 		const int cend = min(c0 + SK_CHUNK, n);
-		const int span = cend - c0 + 2 * SK_PAD;    // slots to fill: positions c0-PAD .. cend+PAD
-		const int p_lo = max(c0 - SK_PAD, 0), p_hi = min(cend + SK_PAD, n);
-		const int64_t w_lo = (off + p_lo) >> 4;
-		const int n_words = (int)(((off + p_hi - 1 + KMER - 1) >> 4) - w_lo) + 2;
+		// slot q of the window holds position c0 - PAD + q; the packed words of the window start
+		// at the word of its first base (before the batch's first base: zeros)
+		const int64_t g0 = off + c0 - SK_PAD;                           // global base index of slot 0 (may be < 0)
+		const int64_t wbase = g0 >> 4;                                  // floor
+		const int bo0 = (int)(g0 - wbase * 16);                         // 0..15
 		wave_lds_order();
-		for (int i = lane; i < n_words; i += 64) s_words[i] = B.packed[w_lo + i];
-		wave_lds_order();
-		for (int q0 = 0; q0 < span + 4; q0 += 64) {
-			const int q = q0 + lane, p = c0 - SK_PAD + q;
-			int32_t h = -1;
-			uint32_t strand = 0;
-			if (p >= 0 && p < n && q < span) {
-				const int64_t gb = off + p;
-				const int wi = (int)((gb >> 4) - w_lo), sh = (int)(gb & 15) * 2;
-				const uint64_t two = (uint64_t)s_words[wi] << 32 | s_words[wi + 1];
-				const uint32_t fw = (uint32_t)(two >> (34 - sh)) & KMASK;
-				const uint32_t rv = revcomp30(fw);
-				strand = fw < rv ? 0u : 1u;
-				h = (int32_t)hash30(strand ? rv : fw);
-			}
-			if (q < SK_LOGICAL) s_hash[sk_phys(q)] = h;
-			const unsigned long long sm = __builtin_amdgcn_ballot_w64(strand != 0);
-			if (lane == 0) s_strand[q0 >> 6] = sm;
+		for (int i = lane; i < SK_WORDS; i += 64) {
+			const int64_t w = wbase + i;
+			s_words[i] = w >= 0 && w < n_packed ? B.packed[w] : 0u;
 		}
 		wave_lds_order();
+		// ---- hashing: lane l takes the 17 slots q = 17 l + t.  The 31 bases they span are cut out
+		// of the packed stream once (first base in the top bits), and so is their reverse
+		// complement; every k-mer and its reverse complement are then 30-bit fields of those.
+		{
+			const int bo = bo0 + SK_PER * lane;
+			const int wi = bo >> 4, sh = (bo & 15) * 2;
+			const uint32_t w0 = s_words[wi], w1 = s_words[wi + 1], w2 = s_words[wi + 2];
+			const uint64_t seq = (((uint64_t)w0 << 32 | w1) << sh & 0xffffffff00000000ULL) | (((uint64_t)w1 << 32 | w2) << sh) >> 32;
+			uint64_t rc = __brevll(~seq);                               // complement, bit-reversed ...
+			rc = ((rc & 0xAAAAAAAAAAAAAAAAULL) >> 1) | ((rc & 0x5555555555555555ULL) << 1);   // ... with the two bits of a base back in order
+			uint32_t sbits = 0;
+			int32_t *dst = s_hash + SK_PER * lane;
+#pragma unroll
+			for (int t = 0; t < SK_PER; ++t) {
+				const uint32_t fw = (uint32_t)(seq >> (34 - 2 * t)) & KMASK;
+				const uint32_t rv = (uint32_t)(rc >> (2 * t)) & KMASK;      // reverse complement of bases t .. t+14
+				sbits |= (fw < rv ? 0u : 1u) << t;
+				dst[t] = (int32_t)hash30(min(fw, rv));
+			}
+			s_strand[lane] = sbits;
+		}
+		// the few slots beyond 64 x 17, one per lane
+		if (lane < SK_EXTRA) {
+			const int bo = bo0 + SK_CHUNK + lane;
+			const int wi = bo >> 4, sh = (bo & 15) * 2;
+			const uint64_t two = (uint64_t)s_words[wi] << 32 | s_words[wi + 1];
+			const uint32_t fw = (uint32_t)(two >> (34 - sh)) & KMASK;
+			const uint32_t rv = revcomp30(fw);
+			s_hash[SK_CHUNK + lane] = (int32_t)hash30(min(fw, rv));
+			s_strand[64 + lane] = fw < rv ? 0u : 1u;
+		}
+		wave_lds_order();
+		// positions outside [0, n) hold the -1 sentinel (smaller than every hash)
+		if (c0 == 0 && lane < SK_PAD) s_hash[lane] = -1;
+		for (int q = n - c0 + SK_PAD + lane; q < SK_SLOTS; q += 64) s_hash[q] = -1;
+		wave_lds_order();
 
-		// ---- selection: lane l owns the 16 positions c0 + 16 l + t.  With m(s) the minimum of
+		// ---- selection: lane l owns the 17 positions c0 + 17 l + t.  With m(s) the minimum of
 		// the window starting at s, position p is reported iff h[p] == max over the ten windows
 		// that contain it (h[p] >= each of those minima, with equality iff p is a minimum of it).
-		int32_t v[36];
+		int32_t v[37];
 		{
-			const int32_t *src = s_hash + 17 * lane;
+			const int32_t *src = s_hash + SK_PER * lane;
 #pragma unroll
-			for (int k = 1; k <= 34; ++k) v[k] = src[k + (k >> 4)];
+			for (int k = 1; k <= SK_PER + 18; ++k) v[k] = src[k];
 		}
 		uint32_t mask = 0;
 		{
-			int32_t m3[33], m10[26];
+			int32_t m3[SK_PER + 17], m10[SK_PER + 10];
 #pragma unroll
-			for (int k = 1; k <= 32; ++k) m3[k] = min(min(v[k], v[k + 1]), v[k + 2]);
+			for (int k = 1; k <= SK_PER + 16; ++k) m3[k] = min(min(v[k], v[k + 1]), v[k + 2]);
 #pragma unroll
-			for (int k = 1; k <= 25; ++k) m10[k] = min(min(min(m3[k], m3[k + 3]), m3[k + 6]), v[k + 9]);
-			int32_t x3[24];
+			for (int k = 1; k <= SK_PER + 9; ++k) m10[k] = min(min(min(m3[k], m3[k + 3]), m3[k + 6]), v[k + 9]);
+			int32_t x3[SK_PER + 8];
 #pragma unroll
-			for (int k = 1; k <= 23; ++k) x3[k] = max(max(m10[k], m10[k + 1]), m10[k + 2]);
+			for (int k = 1; k <= SK_PER + 7; ++k) x3[k] = max(max(m10[k], m10[k + 1]), m10[k + 2]);
 #pragma unroll
-			for (int t = 0; t < 16; ++t) {
+			for (int t = 0; t < SK_PER; ++t) {
 				const int k = t + 1;
 				const int32_t top = max(max(max(x3[k], x3[k + 3]), x3[k + 6]), m10[k + 9]);
 				mask |= v[t + 10] == top ? 1u << t : 0u;
 			}
 		}
-		const int first_p = c0 + 16 * lane;
+		const int first_p = c0 + SK_PER * lane;
 		if (c0 == 0 && lane == 0) {                     // short reads and the first-window quirks
 			if (n < WIN) {
 				int32_t lowest = v[10];
@@ -263,7 +282,7 @@ __device__ void sketch_one_read(const Batch &B, uint32_t r, int wv, int lane, in
 			}
 		}
 		{
-			const int nvalid = min(max(cend - first_p, 0), 16);
+			const int nvalid = min(max(cend - first_p, 0), SK_PER);
 			mask &= (1u << nvalid) - 1u;
 		}
 		// ---- output in position order: lane-contiguous runs
@@ -279,9 +298,10 @@ __device__ void sketch_one_read(const Batch &B, uint32_t r, int wv, int lane, in
 		while (mask) {
 			const int t = __ffs((int)mask) - 1;
 			mask &= mask - 1;
-			const int q = 16 * lane + SK_PAD + t;
-			const int32_t h = s_hash[sk_phys(q)];
-			const uint32_t strand = (uint32_t)(s_strand[q >> 6] >> (q & 63)) & 1u;
+			const int q = SK_PER * lane + SK_PAD + t;                   // its hash was made by lane q / 17 (or the extra pass)
+			const int32_t h = s_hash[q];
+			const int hl = t < SK_PER - SK_PAD ? lane : lane + 1, hb = t < SK_PER - SK_PAD ? t + SK_PAD : t + SK_PAD - SK_PER;
+			const uint32_t strand = q < SK_CHUNK ? (s_strand[hl] >> hb) & 1u : s_strand[64 + q - SK_CHUNK];
 			atomicAdd(&s_hist[pb_bucket((uint32_t)h)], 1u);
 			out[k_out++] = make_uint2((uint32_t)h, (uint32_t)(first_p + t + KMER - 1) << 1 | strand);
 		}
