@@ -176,6 +176,7 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 	int qi = n > 0 ? S[0].q : 0;
 	const uint64_t last_lane = 1ULL << (row * RW + RW - 1);
 	const int key_lane = KEY_BIAS * RW + RW - 1 - lr, perm_half = (lane & RW) << 2;
+	Slot *me = S;                                                        // slot of anchor i
 	for (;;) {
 		const bool active = i < n;
 		if (!any64(active)) break;
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 			pj = *(const volatile int32_t*)(gp + (uint32_t)j), fj = *(const volatile int32_t*)(gf + (uint32_t)j);
 		}
 		// operands of the next anchor, fetched early (used when this anchor completes)
-		const Slot *nx = S + slot(i + 1);
+		Slot *nx = S + slot(i + 1);
 		const int nxx = nx->x, nxq = nx->q, nflag = nx->p;
 
 		uint32_t dru = xi - (uint32_t)xj;
@@ -253,12 +254,12 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 		if (done) {
 			if (lr == 0) {
 				// v[i] = max(f[i], v[p[i]]): the operand was written at an earlier step
-				Slot *me = S + slot(i);
 				me->p = max_j, me->f = max_f;
 				const int vp = max_j < 0 ? 0 : max_j >= ring_lo ? S[slot(max_j)].v : gv[(uint32_t)max_j];
 				me->v = max(max_f, vp);
 			}
 			++i;
+			me = nx;
 			xi = (uint32_t)nxx, qi = nxq;
 			if (nflag == -2) seg = i;
 			jb = i - 1, max_f = span, max_j = -1, fresh = true;
