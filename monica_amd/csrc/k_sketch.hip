@@ -150,7 +150,9 @@ __device__ int sketch_serial(const uint8_t *s, int len, uint2 *out)
 //                every p <= WIN-2, p != P', h[p] == m' IS emitted, and
 //                P' is NOT emitted when h[WIN-1] == m'.
 // Hashes of a chunk sit in LDS with a -1 sentinel outside [0, n) (so clipping needs no
-// test); every lane decides two adjacent positions from eleven 8-byte LDS reads.
+// test); a lane hashes 17 adjacent k-mers out of two 64-bit registers and decides 17 adjacent
+// positions from the 35 hashes around them, held in registers (window minima, then their
+// maxima over the ten windows containing a position).
 // Output order is increasing position, 8 bytes per minimizer: {hash, pos<<1 | strand},
 // pos = index of the k-mer's last base.
 __device__ void sketch_one_read(const Batch &B, uint32_t r, int wv, int lane, int32_t *s_hash, uint32_t *s_words,
