@@ -77,12 +77,40 @@ __device__ __forceinline__ Anchor unpack_anchor(uint64_t w, int rid_bits, int rp
 	return e;
 }
 
+__device__ __forceinline__ void cx(uint64_t &a, uint64_t &b)
+{
+	const uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
+	a = lo, b = hi;
+}
+
+// The same ascending-only network, with every run of compare-exchanges at distances 2 and 1
+// (and the whole of the first two stages) done on four consecutive elements in registers: one
+// 32-byte read and write per thread instead of two LDS rounds.  Slots >= n act as +inf.
 __device__ void bitonic_sort_u64(uint64_t *s, int n, int tid)
 {
 	int lg = 1;
 	while ((1 << lg) < n) ++lg;
 	const int half_n = 1 << (lg - 1);
-	for (int lh = 1; lh <= lg; ++lh) {                              // h = 1 << lh
+	const int quads = (n + 3) >> 2;
+	const uint64_t INF = ~0ULL;
+	auto load4 = [&](int g, uint64_t (&r)[4]) {
+#pragma unroll
+		for (int k = 0; k < 4; ++k) r[k] = 4 * g + k < n ? s[4 * g + k] : INF;
+	};
+	auto store4 = [&](int g, const uint64_t (&r)[4]) {
+#pragma unroll
+		for (int k = 0; k < 4; ++k) if (4 * g + k < n) s[4 * g + k] = r[k];
+	};
+	// stages h = 2 and h = 4
+	for (int g = tid; g < quads; g += SO_THREADS) {
+		uint64_t r[4];
+		load4(g, r);
+		cx(r[0], r[1]), cx(r[2], r[3]);                             // h = 2: flip
+		if (lg >= 2) { cx(r[0], r[3]), cx(r[1], r[2]); cx(r[0], r[1]), cx(r[2], r[3]); }   // h = 4: flip, then distance 1
+		store4(g, r);
+	}
+	__syncthreads();
+	for (int lh = 3; lh <= lg; ++lh) {                              // h = 1 << lh
 		{
 			const int lhh = lh - 1, hh = 1 << lhh;                     // flip: i <-> block_end - (i - block_start)
 			for (int t = tid; t < half_n; t += SO_THREADS) {
@@ -95,7 +123,7 @@ __device__ void bitonic_sort_u64(uint64_t *s, int n, int tid)
 			}
 			__syncthreads();
 		}
-		for (int lhh = lh - 2; lhh >= 0; --lhh) {                      // disperse: i <-> i + hh
+		for (int lhh = lh - 2; lhh >= 2; --lhh) {                      // disperse at distances >= 4: i <-> i + hh
 			const int hh = 1 << lhh;
 			for (int t = tid; t < half_n; t += SO_THREADS) {
 				const int q = (t >> lhh) << (lhh + 1), o = t & (hh - 1);
@@ -107,6 +135,14 @@ __device__ void bitonic_sort_u64(uint64_t *s, int n, int tid)
 			}
 			__syncthreads();
 		}
+		for (int g = tid; g < quads; g += SO_THREADS) {                // distances 2 and 1 in registers
+			uint64_t r[4];
+			load4(g, r);
+			cx(r[0], r[2]), cx(r[1], r[3]);
+			cx(r[0], r[1]), cx(r[2], r[3]);
+			store4(g, r);
+		}
+		__syncthreads();
 	}
 }
 
