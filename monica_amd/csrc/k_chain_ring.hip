@@ -146,20 +146,26 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 	for (int k = threadIdx.x; k < GAP_LUT; k += 64 * DP_WAVES) s_gap[k] = (uint8_t)B.gap_lut[k];
 	__syncthreads();
 
-	// block b of the read -> its ring slots: coordinates, segment-start flag, cleared DP fields
-	auto load_block = [&](int b) {
+	// block b of the read -> its ring slots.  An anchor whose nearest neighbour below (in the
+	// sorted order) is on another (strand, contig) or more than max_gap away has no predecessor
+	// at all: it gets its final f = v = span, p = -1 here and the DP walks past it.  Returns the
+	// half's mask of the other ("busy") anchors of the block.
+	auto load_block = [&](int b) -> uint32_t {
 		const int idx = b * RW + lr;
+		bool busy = false;
 		if (idx < n) {
 			const Anchor e = ga[idx];
-			const uint32_t hi = (uint32_t)(e.x >> 32);
-			const uint32_t phi = idx ? (uint32_t)(ga[idx - 1].x >> 32) : ~hi;
+			if (idx > 0) {
+				const uint64_t px = ga[idx - 1].x;
+				busy = (uint32_t)(e.x >> 32) == (uint32_t)(px >> 32) && (uint32_t)e.x - (uint32_t)px <= (uint32_t)max_gap;
+			}
 			Slot w;
-			w.p = hi != phi ? -2 : -1, w.f = 0, w.x = (int)(uint32_t)e.x, w.q = (int)(uint32_t)e.y, w.t = 0, w.v = 0;
+			w.p = -1, w.f = busy ? 0 : span, w.x = (int)(uint32_t)e.x, w.q = (int)(uint32_t)e.y, w.t = 0, w.v = busy ? 0 : span;
 			S[slot(idx)] = w;
 		}
+		return row_ballot(busy, row);
 	};
-	load_block(0);
-	load_block(1);
+	uint32_t busy_cur = load_block(0), busy_next = load_block(1);
 	lds_order();
 
 	// ---- DP: every half walks its own i.  Half-uniform state lives in VGPRs.
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 	// towards the first lane, and 0 is the identity the DPP scans fill in.
 	constexpr int KEY_BIAS = 256;
 	bool fresh = true;
-	int i = 0, seg = 0, jb = -1, max_f = span, max_j = -1, ns_prev = 0, ring_lo = 0;
+	int i = 0, seg = 0, jb = -1, max_f = span, max_j = -1, ns_prev = 0, ring_lo = 0;   // seg: the last anchor <= i without a predecessor
 	uint32_t xi = n > 0 ? (uint32_t)S[0].x : 0;
 	int qi = n > 0 ? S[0].q : 0;
 	const uint64_t last_lane = 1ULL << (row * RW + RW - 1);
@@ -193,9 +199,14 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 			xj = (int)ge[0], qj = (int)ge[2];
 			pj = *(const volatile int32_t*)(gp + (uint32_t)j), fj = *(const volatile int32_t*)(gf + (uint32_t)j);
 		}
-		// operands of the next anchor, fetched early (used when this anchor completes)
-		Slot *nx = S + slot(i + 1);
-		const int nxx = nx->x, nxq = nx->q, nflag = nx->p;
+		// the next anchor to work on: past the run of anchors without predecessors that follows i
+		// (inside this block; the block boundary itself is always visited).  Its operands are
+		// fetched early (used when this anchor completes).
+		const int ik = i & (RW - 1);
+		const uint32_t rest = ik == RW - 1 ? 0u : busy_cur >> (ik + 1);
+		const int inext = rest ? i + 1 + __builtin_ctz(rest) : (i | (RW - 1)) + 1;
+		Slot *nx = S + slot(inext);
+		const int nxx = nx->x, nxq = nx->q;
 
 		uint32_t dru = xi - (uint32_t)xj;
 		const int dr = (int)dru;
@@ -258,11 +269,16 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 				const int vp = max_j < 0 ? 0 : max_j >= ring_lo ? S[slot(max_j)].v : gv[(uint32_t)max_j];
 				me->v = max(max_f, vp);
 			}
-			++i;
+			// every anchor walked past has no predecessor; neither has a non-busy block start
+			if (inext != i + 1) seg = inext - 1;
+			i = inext;
 			me = nx;
 			xi = (uint32_t)nxx, qi = nxq;
-			if (nflag == -2) seg = i;
 			jb = i - 1, max_f = span, max_j = -1, fresh = true;
+			if ((i & (RW - 1)) == 0) {
+				if (!(busy_next & 1u)) seg = i;
+				busy_cur = busy_next;
+			}
 			if (i < n && (i & (RW - 1)) == 0) {                           // entering block nb
 				const int nb = i >> 5;
 				lds_order();
@@ -272,7 +288,7 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 				const int ob = nb - PAST - 1;                             // block about to lose its slots
 				if (ob >= 0) gt[ob * RW + lr] = S[slot(ob * RW + lr)].t;
 				lds_order();
-				load_block(nb + 1);
+				busy_next = load_block(nb + 1);
 				ring_lo = max(0, nb - PAST) * RW;
 			}
 		} else if (active) jb -= RW;
