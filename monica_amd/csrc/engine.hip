@@ -21,7 +21,7 @@ void launch_sketch(const Batch &B, hipStream_t st);
 void launch_partition(const Batch &B, hipStream_t st);
 void launch_probe(const Batch &B, hipStream_t st);
 void launch_collect(const Batch &B, hipStream_t st);
-void launch_expand_sort(const Batch &B, const uint32_t *list, uint32_t count, int NM, hipStream_t st);
+void launch_expand_sort(const Batch &B, const uint32_t *lists, const ClassSpans &spans, int NM, hipStream_t st);
 int expand_sort_prepare(int max_nm);
 void launch_backtrack(const Batch &B, const uint32_t *read_list, uint32_t n_list, hipStream_t st);
 void launch_bin_reads(const Batch &B, const ChainClasses &C, uint32_t *cls_count, uint32_t *cls_list, hipStream_t st);
@@ -652,9 +652,23 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 		StageTimer t(e, MNC_STAGE_SORT2);
 		const uint32_t *lists = e->cls_list.as<uint32_t>();
 		if (int rc = fork()) return rc;
-		for (int c = 0, k = 0; c <= CHAIN_CLASSES.n; ++c) {     // the last list: reads too large for LDS (NM = 0)
+		// the classes up to SORT_MERGE anchors share one launch (their tiles are small either way:
+		// no launch tails between them); the larger ones keep a launch each, on the side streams
+		constexpr int SORT_MERGE = 512;
+		int first_big = 0;
+		while (first_big < CHAIN_CLASSES.n && CHAIN_CLASSES.nm[first_big] <= SORT_MERGE) ++first_big;
+		int k = 0;
+		if (first_big > 0) {
+			ClassSpans sp;
+			sp.n = first_big, sp.stride = (uint32_t)n_reads, sp.start[0] = 0;
+			for (int c = 0; c < first_big; ++c) sp.start[c + 1] = sp.start[c] + cls_count[c];
+			if (sp.start[sp.n]) launch_expand_sort(B, lists, sp, CHAIN_CLASSES.nm[first_big - 1], e->side[k++ % mnc_engine::N_SIDE]);
+		}
+		for (int c = first_big; c <= CHAIN_CLASSES.n; ++c) {    // the last list: reads too large for LDS (NM = 0)
 			if (cls_count[c] == 0) continue;
-			launch_expand_sort(B, lists + (size_t)c * n_reads, cls_count[c], c < CHAIN_CLASSES.n ? CHAIN_CLASSES.nm[c] : 0,
+			ClassSpans sp;
+			sp.n = 1, sp.stride = 0, sp.start[0] = 0, sp.start[1] = cls_count[c];
+			launch_expand_sort(B, lists + (size_t)c * n_reads, sp, c < CHAIN_CLASSES.n ? CHAIN_CLASSES.nm[c] : 0,
 			                   e->side[k++ % mnc_engine::N_SIDE]);
 		}
 		if (int rc = join()) return rc;

@@ -150,15 +150,18 @@ __device__ void bitonic_sort_u64(uint64_t *s, int n, int tid)
 // of reads too large for LDS, sorted in their HBM segment); LDS tile = NM anchors (PACKED: NM
 // 64-bit words).
 template <bool PACKED>
-__global__ __launch_bounds__(SO_THREADS) void mnc_expand_sort(Batch B, const uint32_t *list, uint32_t count, int NM)
+__global__ __launch_bounds__(SO_THREADS) void mnc_expand_sort(Batch B, const uint32_t *lists, ClassSpans spans, int NM)
 {
 	extern __shared__ __align__(16) uint8_t so_smem[];
 	Anchor *s_a = reinterpret_cast<Anchor*>(so_smem);
 	uint64_t *s_w = reinterpret_cast<uint64_t*>(so_smem);
 	__shared__ int s_scan[SO_THREADS / 64];
 
-	if (blockIdx.x >= count) return;
-	const uint32_t r = list[blockIdx.x];
+	// the reads of one or several adjacent size classes: block -> (class, index in its list)
+	if (blockIdx.x >= spans.start[spans.n]) return;
+	int cls = 0;
+	while (blockIdx.x >= spans.start[cls + 1]) ++cls;
+	const uint32_t r = lists[(size_t)cls * spans.stride + (blockIdx.x - spans.start[cls])];
 	const int tid = threadIdx.x;
 	const int64_t off = B.offsets[r];
 	const int qlen = (int)(B.offsets[r + 1] - off);
@@ -234,13 +237,15 @@ __global__ __launch_bounds__(SO_THREADS) void mnc_expand_sort(Batch B, const uin
 	}
 }
 
-void launch_expand_sort(const Batch &B, const uint32_t *list, uint32_t count, int NM, hipStream_t st)
+// `lists` + `spans`: the read lists of adjacent size classes, all sorted with one tile of NM anchors
+void launch_expand_sort(const Batch &B, const uint32_t *lists, const ClassSpans &spans, int NM, hipStream_t st)
 {
+	const uint32_t count = spans.start[spans.n];
 	if (count == 0) return;
 	if (B.rid_bits > 0 && NM > 0)
-		hipLaunchKernelGGL(mnc_expand_sort<true>, dim3(count), dim3(SO_THREADS), (size_t)NM * sizeof(uint64_t), st, B, list, count, NM);
+		hipLaunchKernelGGL(mnc_expand_sort<true>, dim3(count), dim3(SO_THREADS), (size_t)NM * sizeof(uint64_t), st, B, lists, spans, NM);
 	else
-		hipLaunchKernelGGL(mnc_expand_sort<false>, dim3(count), dim3(SO_THREADS), (size_t)NM * sizeof(Anchor), st, B, list, count, NM);
+		hipLaunchKernelGGL(mnc_expand_sort<false>, dim3(count), dim3(SO_THREADS), (size_t)NM * sizeof(Anchor), st, B, lists, spans, NM);
 }
 
 int expand_sort_prepare(int max_nm)
