@@ -26,7 +26,7 @@ int expand_sort_prepare(int max_nm);
 void launch_backtrack(const Batch &B, const uint32_t *read_list, uint32_t n_list, hipStream_t st);
 void launch_bin_reads(const Batch &B, const ChainClasses &C, uint32_t *cls_count, uint32_t *cls_list, hipStream_t st);
 void launch_chain_dp_ring(const Batch &B, const uint32_t *lists, const ClassSpans &spans, int stress, hipStream_t st);
-void launch_chain_tail(const Batch &B, const uint32_t *list, uint32_t count, int NM, hipStream_t st);
+void launch_chain_tail(const Batch &B, const uint32_t *lists, const ClassSpans &spans, int NM, hipStream_t st);
 size_t chain_tail_lds_bytes(int NM);
 int chain_tail_prepare(size_t max_lds);
 
@@ -686,9 +686,20 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 		const uint32_t *lists = e->cls_list.as<uint32_t>();
 		if (int rc = fork()) return rc;
 		int k = 0;
-		for (int c = 0; c < CHAIN_CLASSES.n; ++c) {
+		constexpr int merge_to = 384;                  // smaller classes share a launch (their LDS tiles differ little)
+		int first_big = 0;
+		while (first_big < CHAIN_CLASSES.n && CHAIN_CLASSES.nm[first_big] <= merge_to) ++first_big;
+		if (first_big > 0) {
+			ClassSpans sp;
+			sp.n = first_big, sp.stride = (uint32_t)n_reads, sp.start[0] = 0;
+			for (int c = 0; c < first_big; ++c) sp.start[c + 1] = sp.start[c] + cls_count[c];
+			if (sp.start[sp.n]) launch_chain_tail(B, lists, sp, CHAIN_CLASSES.nm[first_big - 1], e->side[k++ % mnc_engine::N_SIDE]);
+		}
+		for (int c = first_big; c < CHAIN_CLASSES.n; ++c) {
 			if (cls_count[c] == 0) continue;
-			launch_chain_tail(B, lists + (size_t)c * n_reads, cls_count[c], CHAIN_CLASSES.nm[c], e->side[k++ % mnc_engine::N_SIDE]);
+			ClassSpans sp;
+			sp.n = 1, sp.stride = 0, sp.start[0] = 0, sp.start[1] = cls_count[c];
+			launch_chain_tail(B, lists + (size_t)c * n_reads, sp, CHAIN_CLASSES.nm[c], e->side[k++ % mnc_engine::N_SIDE]);
 		}
 		launch_backtrack(B, lists + (size_t)CHAIN_CLASSES.n * n_reads, cls_count[CHAIN_CLASSES.n], e->side[k % mnc_engine::N_SIDE]);
 		if (int rc = join()) return rc;

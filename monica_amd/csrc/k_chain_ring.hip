@@ -322,7 +322,7 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 constexpr int TAIL_ENDS = 64;
 constexpr uint32_t OWN_NONE = 0xffffu;
 
-__global__ __launch_bounds__(64) void mnc_chain_tail(Batch B, const uint32_t *list, uint32_t count, int NM)
+__global__ __launch_bounds__(64) void mnc_chain_tail(Batch B, const uint32_t *lists, ClassSpans spans, int NM)
 {
 	extern __shared__ __align__(16) uint8_t smem[];
 	const int lane = threadIdx.x, row = lane / RW, lr = lane % RW;
@@ -335,9 +335,15 @@ __global__ __launch_bounds__(64) void mnc_chain_tail(Batch B, const uint32_t *li
 	uint32_t *acc = reinterpret_cast<uint32_t*>(ubuf + TAIL_ENDS);      // TAIL_ENDS x {cnt, mlen, blen, top, stop f, -}
 	uint16_t *H0 = reinterpret_cast<uint16_t*>(W0);
 
+	// the reads of one or several adjacent size classes: ordinal -> (class, index in its list)
 	const uint32_t li = blockIdx.x * ROWS + row;
-	const bool has = li < count;
-	const uint32_t r = has ? list[li] : 0;
+	const bool has = li < spans.start[spans.n];
+	uint32_t r = 0;
+	if (has) {
+		int c = 0;
+		while (li >= spans.start[c + 1]) ++c;
+		r = lists[(size_t)c * spans.stride + (li - spans.start[c])];
+	}
 	const int64_t a_off = has ? B.an_off[r] : 0;
 	const int n = has ? (int)(B.an_off[r + 1] - a_off) : 0;
 	const Anchor *ga = B.a + a_off;
@@ -599,11 +605,12 @@ void launch_chain_dp_ring(const Batch &B, const uint32_t *lists, const ClassSpan
 	else hipLaunchKernelGGL(mnc_chain_dp_ring<2>, dim3(blocks), dim3(64 * DP_WAVES), 0, st, B, lists, spans);
 }
 
-void launch_chain_tail(const Batch &B, const uint32_t *list, uint32_t count, int NM, hipStream_t st)
+void launch_chain_tail(const Batch &B, const uint32_t *lists, const ClassSpans &spans, int NM, hipStream_t st)
 {
+	const uint32_t count = spans.start[spans.n];
 	if (count == 0) return;
 	const unsigned blocks = (count + ROWS - 1) / ROWS;
-	hipLaunchKernelGGL(mnc_chain_tail, dim3(blocks), dim3(64), chain_tail_lds_bytes(NM), st, B, list, count, NM);
+	hipLaunchKernelGGL(mnc_chain_tail, dim3(blocks), dim3(64), chain_tail_lds_bytes(NM), st, B, lists, spans, NM);
 }
 
 } // namespace mnc
