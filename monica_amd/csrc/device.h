@@ -135,7 +135,6 @@ struct Batch {
 	int32_t *f, *p, *v, *t;
 	uint64_t *u;                  // chain-end candidates
 	// ---- per chain slot (capacity an_cap/3 + 1): slot base of read r = an_off[r] / 3
-	ChainRec *chains;             // final order: by first anchor
 	ChainRec *chains_tmp;         // backtrack order
 	mnc_reg_t *regs;
 	int32_t *tmp_i32;             // 4 ints per chain slot of scratch
@@ -168,7 +167,5 @@ __device__ __forceinline__ uint32_t hash30(uint32_t key)
 }
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
-
-__device__ __forceinline__ int ilog2_u32(uint32_t v) { return 31 - __clz((int)v); }
 
 } // namespace mnc

@@ -629,7 +629,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	if (rc) return rc;
 #undef ENS
 	B.an_cap = (int64_t)na;
-	B.a = e->a.as<Anchor>(), B.chains_tmp = e->chains_tmp.as<ChainRec>(), B.chains = nullptr;
+	B.a = e->a.as<Anchor>(), B.chains_tmp = e->chains_tmp.as<ChainRec>();
 	B.f = e->f.as<int32_t>(), B.p = e->p.as<int32_t>(), B.v = e->v.as<int32_t>(), B.t = e->t.as<int32_t>(), B.u = e->u.as<uint64_t>();
 	B.regs = e->regs.as<mnc_reg_t>(), B.tmp_i32 = e->tmp_i32.as<int32_t>();
 

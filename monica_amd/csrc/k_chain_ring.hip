@@ -48,8 +48,6 @@ MNC_DPP_OP(max_shr1, "v_max_i32_dpp", "row_shr:1") MNC_DPP_OP(max_shr2, "v_max_i
 MNC_DPP_OP(max_shr4, "v_max_i32_dpp", "row_shr:4") MNC_DPP_OP(max_shr8, "v_max_i32_dpp", "row_shr:8")
 MNC_DPP_OP(add_shr1, "v_add_u32_dpp", "row_shr:1") MNC_DPP_OP(add_shr2, "v_add_u32_dpp", "row_shr:2")
 MNC_DPP_OP(add_shr4, "v_add_u32_dpp", "row_shr:4") MNC_DPP_OP(add_shr8, "v_add_u32_dpp", "row_shr:8")
-MNC_DPP_OP(max_ror1, "v_max_i32_dpp", "row_ror:1") MNC_DPP_OP(max_ror2, "v_max_i32_dpp", "row_ror:2")
-MNC_DPP_OP(max_ror4, "v_max_i32_dpp", "row_ror:4") MNC_DPP_OP(max_ror8, "v_max_i32_dpp", "row_ror:8")
 #undef MNC_DPP_OP
 // lane 15 of rows 0 and 2 combined into every lane of rows 1 and 3 (row_mask 0xa)
 __device__ __forceinline__ int max_bcast15(int v)
@@ -64,21 +62,6 @@ __device__ __forceinline__ int add_bcast15(int v)
 // scans / reductions over one 32-lane half
 __device__ __forceinline__ int row_incl_max(int v) { return max_bcast15(max_shr8(max_shr4(max_shr2(max_shr1(v))))); }
 __device__ __forceinline__ int row_incl_add(int v) { return add_bcast15(add_shr8(add_shr4(add_shr2(add_shr1(v))))); }
-__device__ __forceinline__ int row_all_max(int v)
-{
-	v = max_ror1(max_ror2(max_ror4(max_ror8(v))));                       // every 16-lane row: its maximum
-	const auto sw = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
-	return max((int)sw[0], (int)sw[1]);                                  // pair the two rows of a half
-}
-
-// lane l <- lane l-1 of the half; lane 0 of the half gets `fill`
-__device__ __forceinline__ int row_shift1(int v, int fill, int lr)
-{
-	int r = fill;
-	asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(v));
-	return lr == 0 ? fill : r;
-}
-
 // the builtin takes the condition as it is (the __any / __ballot wrappers go through an integer)
 __device__ __forceinline__ bool any64(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0; }
 
