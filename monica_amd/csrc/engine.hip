@@ -47,12 +47,6 @@ template <class T> struct ScanInPlain {
 	const T *p;
 	__device__ long long operator()(int64_t i) const { return (long long)p[i]; }
 };
-// bucket-major view of the tile-major histogram the sketch writes: element b*n_tiles + t
-struct ScanInHist {
-	const uint32_t *p; int64_t n_tiles;
-	__device__ long long operator()(int64_t i) const { return (long long)p[(i % n_tiles) * PB_N + i / n_tiles]; }
-};
-
 template <class In>
 __global__ __launch_bounds__(SC_THREADS) void mnc_scan_reduce(In in, int64_t n, int64_t *sums)
 {
@@ -119,6 +113,36 @@ static void exclusive_scan(In in, int64_t n, int64_t *out, int64_t *sums, hipStr
 	hipLaunchKernelGGL(mnc_scan_reduce<In>, dim3((unsigned)nb), dim3(SC_THREADS), 0, st, in, n, sums);
 	hipLaunchKernelGGL(mnc_scan_sums, dim3(1), dim3(64), 0, st, sums, nb);
 	hipLaunchKernelGGL(mnc_scan_apply<In>, dim3((unsigned)nb), dim3(SC_THREADS), 0, st, in, n, sums, out, out_tiles);
+}
+
+// ---------------------------------------------------------------- run offsets of the partition
+// The sketch writes one histogram row per tile ([tile][bucket]); the query records are laid out
+// bucket-major, so the offset of run (bucket b, tile t) is the exclusive sum over that order.
+// Rows are read and written whole (coalesced): chunks of HC_TILES tiles are summed per bucket,
+// the [bucket][chunk] sums are scanned as one flat array (which IS the bucket-major order), and
+// each chunk then walks its rows again with the running offsets.
+constexpr int HC_TILES = 64;
+
+__global__ __launch_bounds__(PB_N) void mnc_hist_chunk_sums(const uint32_t *hist_tm, uint32_t n_tiles, uint32_t n_chunks, uint32_t *sums_bm)
+{
+	const uint32_t c = blockIdx.x, b = threadIdx.x;
+	const uint32_t t0 = c * HC_TILES, t1 = min(n_tiles, t0 + HC_TILES);
+	uint32_t s = 0;
+	for (uint32_t t = t0; t < t1; ++t) s += hist_tm[(size_t)t * PB_N + b];
+	sums_bm[(size_t)b * n_chunks + c] = s;
+}
+
+__global__ __launch_bounds__(PB_N) void mnc_hist_offsets(const uint32_t *hist_tm, uint32_t n_tiles, uint32_t n_chunks,
+                                                         const int64_t *chunk_off_bm, int64_t *q_off)
+{
+	const uint32_t c = blockIdx.x, b = threadIdx.x;
+	const uint32_t t0 = c * HC_TILES, t1 = min(n_tiles, t0 + HC_TILES);
+	int64_t run = chunk_off_bm[(size_t)b * n_chunks + c];
+	for (uint32_t t = t0; t < t1; ++t) {
+		q_off[(size_t)t * PB_N + b] = run;
+		run += hist_tm[(size_t)t * PB_N + b];
+	}
+	if (c == 0 && b == 0) q_off[(size_t)n_tiles * PB_N] = chunk_off_bm[(size_t)PB_N * n_chunks];   // the total
 }
 
 // ================================================================ device buffer
@@ -308,7 +332,7 @@ struct mnc_engine {
 	Buf packed, mz, hits, hist_tm, q_off, qrec, bhits, bhit_cnt;
 	size_t q_cap_override = 0;              // grown after an overflowing batch
 	// per read
-	Buf ambig, mz_cnt, hit_cnt, rep_len, an_cnt, an_off, n_chain, n_reg, scan_sums, hit_off, best_mlen;
+	Buf ambig, mz_cnt, hit_cnt, rep_len, an_cnt, an_off, n_chain, n_reg, scan_sums, hit_off, best_mlen, hist_sums, hist_offs;
 	// per anchor
 	Buf a, f, p, v, t, u;
 	// per chain slot
@@ -397,7 +421,7 @@ extern "C" void mnc_engine_destroy(mnc_engine *e)
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
 	Buf *all[] = { &e->gap_lut, &e->logf_lut, &e->in_bases, &e->in_offsets, &e->out_assign, &e->out_best, &e->out_nhits,
 	               &e->packed, &e->mz, &e->hits, &e->hist_tm, &e->q_off, &e->qrec, &e->bhits, &e->bhit_cnt, &e->ambig, &e->mz_cnt, &e->hit_cnt, &e->rep_len, &e->an_cnt, &e->an_off,
-	               &e->n_chain, &e->n_reg, &e->best_mlen, &e->scan_sums, &e->hit_off, &e->a, &e->f, &e->p, &e->v, &e->t, &e->u,
+	               &e->n_chain, &e->n_reg, &e->best_mlen, &e->hist_sums, &e->hist_offs, &e->scan_sums, &e->hit_off, &e->a, &e->f, &e->p, &e->v, &e->t, &e->u,
 	               &e->chains_tmp, &e->regs, &e->regx, &e->k64a, &e->k64b, &e->tmp_i32, &e->gated,
 	               &e->hits_csr, &e->stats, &e->cls_count, &e->cls_list };
 	for (Buf *b : all) b->release();
@@ -547,6 +571,8 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	ENS(bhits, (q_cap + 1) * sizeof(HitRec));
 	ENS(bhit_cnt, (n_super + 1) * PB_N * 4);
 	ENS(scan_sums, ((n_tiles * PB_N + nr) / SC_TILE + 4) * 8);
+	ENS(hist_sums, ((n_tiles / HC_TILES + 2) * PB_N) * 4);
+	ENS(hist_offs, ((n_tiles / HC_TILES + 2) * PB_N + 2) * 8);
 	ENS(cls_list, (size_t)(CHAIN_CLASSES.n + 1) * (nr + 1) * 4);
 	if (!d_nhits) ENS(out_nhits, (nr + 1) * 4);
 	if (rc) return rc;
@@ -592,7 +618,14 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	{ StageTimer t(e, MNC_STAGE_SKETCH); launch_sketch(B, st); }
 	{
 		StageTimer t(e, MNC_STAGE_PARTITION);
-		exclusive_scan(ScanInHist{B.hist_tm, (int64_t)n_tiles}, (int64_t)(n_tiles * PB_N), B.q_off, e->scan_sums.as<int64_t>(), st, (int64_t)n_tiles);
+		{
+			const uint32_t n_chunks = (uint32_t)((n_tiles + HC_TILES - 1) / HC_TILES);
+			uint32_t *sums_bm = e->hist_sums.as<uint32_t>();
+			int64_t *off_bm = e->hist_offs.as<int64_t>();
+			hipLaunchKernelGGL(mnc_hist_chunk_sums, dim3(n_chunks), dim3(PB_N), 0, st, B.hist_tm, (uint32_t)n_tiles, n_chunks, sums_bm);
+			exclusive_scan(ScanInPlain<uint32_t>{sums_bm}, (int64_t)n_chunks * PB_N, off_bm, e->scan_sums.as<int64_t>(), st);
+			hipLaunchKernelGGL(mnc_hist_offsets, dim3(n_chunks), dim3(PB_N), 0, st, B.hist_tm, (uint32_t)n_tiles, n_chunks, off_bm, B.q_off);
+		}
 		launch_partition(B, st);
 	}
 	{ StageTimer t(e, MNC_STAGE_PROBE);   launch_probe(B, st); }
