@@ -232,24 +232,24 @@ __global__ __launch_bounds__(CO_THREADS) void mnc_collect_hits(Batch B)
 	if (tid < SUPER_READS) s_cur[tid] = 0, s_hi[tid] = 0, s_an[tid] = 0;
 	if (tid == 0) s_pre[0] = 0;
 	__syncthreads();
-	if (tid == 0) for (int b = 0; b < PB_N; ++b) s_pre[b + 1] += s_pre[b];     // 256 additions
-	__syncthreads();
-	const uint32_t total = s_pre[PB_N];
 	const uint32_t read0 = T * SUPER_READS;
-	for (uint32_t f = tid; f < total; f += CO_THREADS) {
-		int lo = 0, hi = PB_N;                        // run holding flat index f
-		while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_pre[mid] <= f) lo = mid; else hi = mid; }
-		HitRec h = B.bhits[s_start[lo] + (f - s_pre[lo])];
-		const uint32_t lr = (h.qinfo >> 21) & (SUPER_READS - 1);
-		const uint32_t r = read0 + lr;
-		const int64_t off = B.offsets[r];
-		h.qinfo &= 0x1fffffu;
-		if (h.cnt == HIT_HIGH) {
-			const int64_t cap = B.offsets[r + 1] - off;
-			B.hits[off + cap - 1 - atomicAdd(&s_hi[lr], 1u)] = h;
-		} else {
-			B.hits[off + atomicAdd(&s_cur[lr], 1u)] = h;
-			atomicAdd(&s_an[lr], (unsigned long long)(h.cnt & 0x7fffffffu));
+	// a wave takes whole runs (their hits are contiguous), lanes take the hits of a run
+	for (int b = tid >> 6; b < PB_N; b += CO_THREADS / 64) {
+		const uint32_t cnt = s_pre[b + 1];
+		const HitRec *src = B.bhits + s_start[b];
+		for (uint32_t f = tid & 63; f < cnt; f += 64) {
+			HitRec h = src[f];
+			const uint32_t lr = (h.qinfo >> 21) & (SUPER_READS - 1);
+			const uint32_t r = read0 + lr;
+			const int64_t off = B.offsets[r];
+			h.qinfo &= 0x1fffffu;
+			if (h.cnt == HIT_HIGH) {
+				const int64_t cap = B.offsets[r + 1] - off;
+				B.hits[off + cap - 1 - atomicAdd(&s_hi[lr], 1u)] = h;
+			} else {
+				B.hits[off + atomicAdd(&s_cur[lr], 1u)] = h;
+				atomicAdd(&s_an[lr], (unsigned long long)(h.cnt & 0x7fffffffu));
+			}
 		}
 	}
 	__syncthreads();
