@@ -334,13 +334,29 @@ __global__ __launch_bounds__(64) void mnc_chain_tail(Batch B, const uint32_t *li
 	const int n_up = (n + RW - 1) / RW * RW;
 
 	// ---- load the DP result of the read
-	for (int idx = lr; idx < n; idx += RW) {
-		const Anchor e = ga[idx];
-		const int p = B.p[a_off + idx];
-		xlo[idx] = (uint32_t)e.x;
-		qp[idx] = (uint16_t)e.y;
-		W0[idx] = p < 0 ? NONE16 : (uint32_t)p;
-		W1[idx] = ((uint32_t)B.f[a_off + idx] & 0xffffu) | (uint32_t)B.v[a_off + idx] << 16;
+	// (four blocks of loads in flight per lane: the loop is bound by HBM latency otherwise)
+	for (int i0 = lr; i0 < n; i0 += 4 * RW) {
+		uint32_t ex[4], ey[4];
+		int p[4], f[4], v[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int idx = i0 + k * RW;
+			if (idx < n) {
+				const Anchor e = ga[idx];
+				ex[k] = (uint32_t)e.x, ey[k] = (uint32_t)e.y;
+				p[k] = B.p[a_off + idx], f[k] = B.f[a_off + idx], v[k] = B.v[a_off + idx];
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int idx = i0 + k * RW;
+			if (idx < n) {
+				xlo[idx] = ex[k];
+				qp[idx] = (uint16_t)ey[k];
+				W0[idx] = p[k] < 0 ? NONE16 : (uint32_t)p[k];
+				W1[idx] = ((uint32_t)f[k] & 0xffffu) | (uint32_t)v[k] << 16;
+			}
+		}
 	}
 	lds_order();
 
