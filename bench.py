@@ -48,6 +48,9 @@ def parse():
                          "all reads, summaries all-gathered and merged); files: the Python aligner API end to "
                          "end on FASTQ files (parse, H2D, kernels, D2H, routed FASTQ output)")
     ap.add_argument("--parts", type=int, default=8, help="index parts in --mode shard")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                                                      "the N > 1 path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--stream-seconds", type=int, default=1800)
     ap.add_argument("--stream-rate", type=int, default=400)
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "probe_traffic.json"),
@@ -69,11 +72,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     # ---------------------------------------------------------------- workload (deterministic)
     t0 = time.time()
