@@ -38,14 +38,25 @@ __global__ __launch_bounds__(256) void mnc_pack_bases(Batch B)
 		const int64_t b0 = g << 4;
 		uint32_t word = 0, badmask = 0;
 		if (b0 + 16 <= B.total_bases) {
+			// four bases per 32-bit operation: upper-case, 2-bit code = x ^ (x >> 1) with
+			// x = bits 1-2 of the letter (A0 C1 T2 G3 -> A0 C1 G2 T3), letters outside ACGTU
+			// found with the zero-byte test, codes gathered into one byte by a multiply
 			const uint4 v = *reinterpret_cast<const uint4*>(B.bases + b0);
 			const uint32_t w4[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
-			for (int i = 0; i < 16; ++i) {
-				uint32_t bad = 0;
-				uint32_t c = pack_byte((w4[i >> 2] >> ((i & 3) * 8)) & 0xffu, bad);
-				word |= c << (30 - 2 * i);
-				badmask |= bad << i;
+			for (int k = 0; k < 4; ++k) {
+				const uint32_t u = w4[k] & 0xDFDFDFDFu;
+				const uint32_t x = (u >> 1) & 0x03030303u;
+				const uint32_t code = x ^ ((x >> 1) & 0x01010101u);
+				uint32_t okb = 0;                                  // 0x80 in every byte that is one of A C G T U
+#pragma unroll
+				for (int t = 0; t < 5; ++t) {
+					const uint32_t z = u ^ (0x01010101u * (uint32_t)("ACGTU"[t]));
+					okb |= ~(((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;
+				}
+				const uint32_t bad4 = ~okb & 0x80808080u;          // first base of the word = lowest byte
+				badmask |= ((bad4 >> 7 & 1u) | (bad4 >> 14 & 2u) | (bad4 >> 21 & 4u) | (bad4 >> 28 & 8u)) << (4 * k);
+				word |= ((code * 0x40100401u) >> 24) << (24 - 8 * k);
 			}
 		} else {
 			for (int i = 0; i < 16 && b0 + i < B.total_bases; ++i) {
