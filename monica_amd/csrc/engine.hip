@@ -217,8 +217,7 @@ int index_upload(mnc_index *idx, int device, DeviceIndex **out)
 				for (uint32_t ki : reg[b]) {
 					const uint32_t rest = pb_rest(idx->keys[ki]);
 					bk[rest & (NB - 1)].push_back(ki);
-					const uint32_t bit = rest & ((1u << PF_BITS) - 1u);
-					filt[(size_t)b * PF_WORDS + (bit >> 5)] |= 1u << (bit & 31);
+					filt[(size_t)b * PF_WORDS + pf_word(rest)] |= pf_mask(rest);
 				}
 				for (size_t i = 0; i < NB; ++i) order[i] = (uint32_t)i;
 				std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return bk[x].size() != bk[y].size() ? bk[x].size() > bk[y].size() : x < y; });

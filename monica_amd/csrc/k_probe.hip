@@ -178,8 +178,8 @@ __global__ __launch_bounds__(PR_THREADS) void mnc_probe_buckets(Batch B, uint32_
 #pragma unroll
 				for (int u = 0; u < PR_U; ++u) {
 					const uint32_t rest = (uint32_t)rec[u] & 0x3fffffu;
-					const uint32_t bit = rest & ((1u << PF_BITS) - 1u);
-					pend[u] = pend[u] && ((s_filter[bit >> 5] >> (bit & 31)) & 1u);
+					const uint32_t fm = pf_mask(rest);
+					pend[u] = pend[u] && (s_filter[pf_word(rest)] & fm) == fm;
 					want[u] = pb_hash(rest, bucket) + 1;
 					const uint32_t db = rest & (uint32_t)(nb - 1);
 					slot[u] = pd_slot(rest, disp_in_lds ? s_disp[db] : (pend[u] ? disp_hbm[db] : 0), rbits, salt);
