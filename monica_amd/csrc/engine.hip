@@ -274,18 +274,22 @@ int index_upload(mnc_index *idx, int device, DeviceIndex **out)
 	}
 	DeviceIndex d;
 	d.device = device, d.region_bits = region_bits, d.disp_bits = disp_bits;
-	HIP_TRY(hipMalloc((void**)&d.filter, filt.size() * 4));
-	HIP_TRY(hipMemcpy(d.filter, filt.data(), filt.size() * 4, hipMemcpyHostToDevice));
-	HIP_TRY(hipMalloc((void**)&d.disp, disp.size()));
-	HIP_TRY(hipMemcpy(d.disp, disp.data(), disp.size(), hipMemcpyHostToDevice));
-	HIP_TRY(hipMalloc((void**)&d.salt, salt.size() * 4));
-	HIP_TRY(hipMemcpy(d.salt, salt.data(), salt.size() * 4, hipMemcpyHostToDevice));
-	HIP_TRY(hipMalloc((void**)&d.table, tab.size() * sizeof(TableSlot)));
-	HIP_TRY(hipMemcpy(d.table, tab.data(), tab.size() * sizeof(TableSlot), hipMemcpyHostToDevice));
-	HIP_TRY(hipMalloc((void**)&d.positions, (idx->pos.size() + 1) * 8));
-	HIP_TRY(hipMemcpy(d.positions, idx->pos.data(), idx->pos.size() * 8, hipMemcpyHostToDevice));
-	HIP_TRY(hipMalloc((void**)&d.contig_genome, idx->contig_genome.size() * 4));
-	HIP_TRY(hipMemcpy(d.contig_genome, idx->contig_genome.data(), idx->contig_genome.size() * 4, hipMemcpyHostToDevice));
+	auto upload = [&](void **dst, const void *src, size_t bytes, size_t spare = 0) -> int {
+		HIP_TRY(hipMalloc(dst, bytes + spare ? bytes + spare : 8));
+		if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+		return MNC_OK;
+	};
+	int urc = upload((void**)&d.filter, filt.data(), filt.size() * 4);
+	if (!urc) urc = upload((void**)&d.disp, disp.data(), disp.size());
+	if (!urc) urc = upload((void**)&d.salt, salt.data(), salt.size() * 4);
+	if (!urc) urc = upload((void**)&d.table, tab.data(), tab.size() * sizeof(TableSlot));
+	if (!urc) urc = upload((void**)&d.positions, idx->pos.data(), idx->pos.size() * 8, 8);   // one spare word behind the positions
+	if (!urc) urc = upload((void**)&d.contig_genome, idx->contig_genome.data(), idx->contig_genome.size() * 4);
+	if (urc) {                                               // do not leak the part that made it to the device
+		void *parts[] = { d.filter, d.disp, d.salt, d.table, d.positions, d.contig_genome };
+		for (void *q : parts) if (q) (void)hipFree(q);
+		return urc;
+	}
 	d.bytes = (int64_t)(tab.size() * sizeof(TableSlot) + filt.size() * 4 + disp.size() + (idx->pos.size() + 1) * 8 + idx->contig_genome.size() * 4);
 	idx->dev.reserve(16);
 	idx->dev.push_back(d);
