@@ -20,6 +20,30 @@ import numpy as np
 from . import _capi
 
 
+# monica re-invokes `index_loader` on every pass of its real-time loop (aligner.py:56-62 from
+# monica.py:437-439); the loaded index and its device-resident tables are kept across those
+# calls, keyed by the file's identity, so a pass does not pay the load and upload again.
+_INDEX_CACHE = {}
+_INDEX_CACHE_LOCK = threading.Lock()
+_INDEX_CACHE_MAX = 4
+
+
+def _load_index_cached(path):
+    st = os.stat(path)
+    key = (os.path.realpath(path), st.st_mtime_ns, st.st_size)
+    with _INDEX_CACHE_LOCK:
+        hit = _INDEX_CACHE.get(key)
+        if hit is not None:
+            _INDEX_CACHE[key] = _INDEX_CACHE.pop(key)          # most recently used last
+            return hit
+    index = _capi.Index.load(path)
+    with _INDEX_CACHE_LOCK:
+        _INDEX_CACHE[key] = index
+        while len(_INDEX_CACHE) > _INDEX_CACHE_MAX:
+            _INDEX_CACHE.pop(next(iter(_INDEX_CACHE)))
+    return index
+
+
 def default_device():
     for var in ("MONICA_AMD_DEVICE", "LOCAL_RANK"):
         v = os.environ.get(var)
@@ -71,7 +95,7 @@ class Aligner:
             elif fn_idx_in is None:
                 raise ValueError("fn_idx_in or seq is required")
             elif self._is_index_file(fn_idx_in):
-                self._index = _capi.Index.load(fn_idx_in)
+                self._index = _load_index_cached(fn_idx_in)
             else:
                 self._index = _capi.Index.build(fn_idx_in, fn_idx_out, kk, ww)
         except (_capi.MncError, OSError, ValueError) as e:      # mappy: a falsy Aligner, no exception
