@@ -381,6 +381,14 @@ def files_mode(args, names, seqs, local_rank):
         result = al.multi_threaded_aligner(query, [idx_path], mode="basic", n_threads=1, output_folder=out)
         wall = time.perf_counter() - t0
         os.chdir(cwd)
+        first_phases = {k: round(v, 3) for k, v in al.TIMINGS.get("sample", {}).items()}
+        # monica's real-time loop calls the same function again when new reads have arrived
+        synth.write_fastq(fq, bases, offsets)
+        al.TIMINGS.clear()
+        t0 = time.perf_counter()
+        al.multi_threaded_aligner(query, [idx_path], mode="basic", n_threads=1, output_folder=out)
+        wall2 = time.perf_counter() - t0
+        os.chdir(cwd)
         counted = sum(sum(c.values()) for c in result["sample"].values())
         routed = {k: os.path.getsize(os.path.join(query, k, "sample.fastq")) for k in ("mapped", "unmapped", "ambiguous")}
         print(json.dumps({
@@ -389,7 +397,9 @@ def files_mode(args, names, seqs, local_rank):
             "includes": "index load + upload, FASTQ parse, H2D, kernels, D2H, carried-hits update, routed FASTQ "
                         "output, alignment.pkl", "mapped_reads_counted": int(counted), "routed_bytes": routed,
             "fastq_write_s_python": round(t_write, 2),
-            "aligner_phase_s": {k: round(v, 3) for k, v in al.TIMINGS.get("sample", {}).items()},
+            "aligner_phase_s": first_phases,
+            "second_call": {"value": round(args.reads / wall2, 1), "wall_s": round(wall2, 3),
+                            "aligner_phase_s": {k: round(v, 3) for k, v in al.TIMINGS.get("sample", {}).items()}},
             "index_load_s": round(al.TIMINGS.get("_index_loader", {}).get("load", 0.0), 3), "data": "synthetic"}))
     finally:
         shutil.rmtree(work, ignore_errors=True)
