@@ -44,6 +44,13 @@ def _load_index_cached(path):
     return index
 
 
+def _engine_pool(index):
+    pool = getattr(index, "_engine_pool", None)
+    if pool is None:
+        pool = index._engine_pool = []
+    return pool
+
+
 def default_device():
     for var in ("MONICA_AMD_DEVICE", "LOCAL_RANK"):
         v = os.environ.get(var)
@@ -84,6 +91,7 @@ class Aligner:
                  min_dp_score=None, bw=None, best_n=None, n_threads=3, fn_idx_out=None, max_frag_len=None,
                  extra_flags=None, seq=None, scoring=None, device=None):
         self._index = None
+        self._borrowed = []
         self._tls = threading.local()
         self._device = default_device() if device is None else int(device)
         self.error = None
@@ -135,12 +143,30 @@ class Aligner:
 
     def engine(self):
         """One engine (HIP stream + HBM workspace) per calling thread: the reference shares one
-        index between the threads of its pool (aligner.py:89-103)."""
+        index between the threads of its pool (aligner.py:89-103).  Engines outlive this object:
+        they go back to a pool kept with the (cached) index, so the next pass of monica's loop
+        does not allocate its workspace again."""
         e = getattr(self._tls, "engine", None)
         if e is None:
-            e = _capi.Engine(self._index, self._device)
+            pool = _engine_pool(self._index)
+            with _INDEX_CACHE_LOCK:
+                e = pool.pop() if pool else None
+            if e is None or e.device != self._device:
+                e = _capi.Engine(self._index, self._device)
             self._tls.engine = e
+            with _INDEX_CACHE_LOCK:
+                self._borrowed.append(e)
         return e
+
+    def __del__(self):
+        try:
+            if self._index is not None and self._borrowed:
+                pool = _engine_pool(self._index)
+                with _INDEX_CACHE_LOCK:
+                    pool.extend(self._borrowed[:8 - len(pool)] if len(pool) < 8 else [])
+                    self._borrowed = []
+        except Exception:
+            pass
 
     # ------------------------------------------------------------------ batched fast path
     def map_batch(self, bases, offsets, min_mapq=0):
