@@ -240,3 +240,103 @@ def test_database_builder_header_contract_and_chunks(tmp_path, monkeypatch):
     # keep_genomes falsy: the downloaded genomes are deleted after the build
     database.multi_threaded_builder(genomes=genomes, max_chunk_size=1 << 20, databases_path=str(out), n_threads=1)
     assert not [f for f in os.listdir(gen) if f.endswith(".fna.gz")]
+
+
+def _fastq_general_iterator(text):
+    """Biopython's FastqGeneralIterator + the quality check of FastqPhredIterator, transcribed
+    (plain Python, line by line) as the behaviour the C++ reader has to reproduce."""
+    lines = text.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+    it = iter([l + b"\n" for l in lines])
+    rstrip = lambda b: b.rstrip(b" \t\r\n\x0b\x0c")
+
+    def readline():
+        return next(it, b"")
+    line = readline()
+    if not line:
+        return
+    while line:
+        if line[0:1] != b"@":
+            raise ValueError("Records in Fastq files should start with '@' character")
+        title = rstrip(line[1:])
+        seq = rstrip(readline())
+        while True:
+            line = readline()
+            if not line:
+                raise ValueError("End of file without quality information.")
+            if line[0:1] == b"+":
+                second = rstrip(line[1:])
+                if second and second != title:
+                    raise ValueError("Sequence and quality captions differ.")
+                break
+            seq += rstrip(line)
+        if b" " in seq or b"\t" in seq:
+            raise ValueError("Whitespace is not allowed in the sequence.")
+        qual = rstrip(readline())
+        while True:
+            line = readline()
+            if not line:
+                break
+            if line[0:1] == b"@" and len(qual) >= len(seq):
+                break
+            qual += rstrip(line)
+        if len(seq) != len(qual):
+            raise ValueError("Lengths of sequence and quality values differs for %s (%i and %i)."
+                             % (title.decode(errors="replace"), len(seq), len(qual)))
+        if any(c < 33 or c > 126 for c in qual):
+            raise ValueError("Invalid character in quality string")
+        yield title, seq, qual
+
+
+def test_fastq_reader_against_the_transcribed_biopython_rules(tmp_path):
+    rng = np.random.default_rng(99)
+    alphabet_q = bytes(range(33, 127))
+
+    def chunks(b, rng):
+        out, i = [], 0
+        while i < len(b):
+            step = int(rng.integers(1, max(2, len(b) + 1)))
+            out.append(b[i:i + step])
+            i += step
+        return out or [b""]
+
+    for case in range(400):
+        text = b""
+        for r in range(int(rng.integers(0, 6))):
+            n = int(rng.integers(0, 40))
+            seq = bytes(rng.choice(list(b"ACGTNacgt"), n)) if n else b""
+            qual = bytes(rng.choice(list(alphabet_q), n)) if n else b""
+            title = b"r%d" % r + (b" extra words" if rng.random() < 0.4 else b"")
+            multi = rng.random() < 0.3
+            text += b"@" + title + b"\n"
+            text += b"\n".join(chunks(seq, rng) if multi else [seq]) + b"\n"
+            text += b"+" + (title if rng.random() < 0.3 else b"") + b"\n"
+            text += b"\n".join(chunks(qual, rng) if multi else [qual]) + b"\n"
+        kind = rng.random()
+        if kind < 0.10:
+            text += b"\n\n"
+        elif kind < 0.18 and text:
+            at = int(rng.integers(0, len(text)))                       # damage one byte
+            text = text[:at] + bytes([int(rng.choice(list(b"@+ \n\tA\x07")))]) + text[at + 1:]
+        elif kind < 0.24 and text:
+            text = text[: int(rng.integers(0, len(text)))]                # truncate
+        elif kind < 0.28:
+            text = text.replace(b"\n", b"\r\n")
+        p = tmp_path / "f.fastq"
+        p.write_bytes(text)
+        try:
+            want = list(_fastq_general_iterator(text))
+            want_err = None
+        except ValueError as e:
+            want, want_err = None, str(e)
+        try:
+            got = []
+            for b in fastq.read_batches(str(p), max_reads=int(rng.integers(1, 5))):
+                got += [(b.headers[i].encode(), b.seq(i), b.qual(i)) for i in range(len(b))]
+            got_err = None
+        except ValueError as e:
+            got, got_err = None, str(e)
+        assert got_err == want_err, (case, text, got_err, want_err)
+        if want is not None:
+            assert got == want, (case, text)
