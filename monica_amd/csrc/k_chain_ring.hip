@@ -186,8 +186,9 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 		// (inside this block; the block boundary itself is always visited).  Its operands are
 		// fetched early (used when this anchor completes).
 		const int ik = i & (RW - 1);
-		const uint32_t rest = ik == RW - 1 ? 0u : busy_cur >> (ik + 1);
-		const int inext = rest ? i + 1 + __builtin_ctz(rest) : (i | (RW - 1)) + 1;
+		// busy anchors after i, with a sentinel bit at the block boundary: branch-free
+		const uint32_t rest = ((busy_cur >> 1) >> ik) | (0x80000000u >> ik);
+		const int inext = i + 1 + __builtin_ctz(rest);
 		Slot *nx = S + slot(inext);
 		const int nxx = nx->x, nxq = nx->q;
 
