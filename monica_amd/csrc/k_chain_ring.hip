@@ -164,7 +164,8 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 	uint32_t xi = n > 0 ? (uint32_t)S[0].x : 0;
 	int qi = n > 0 ? S[0].q : 0;
 	const uint64_t last_lane = 1ULL << (row * RW + RW - 1);
-	const int key_lane = KEY_BIAS * RW + RW - 1 - lr, perm_half = (lane & RW) << 2;
+	int key_lane = KEY_BIAS * RW + RW - 1 - lr, perm_half = (lane & RW) << 2;
+	asm volatile("" : "+v"(key_lane), "+v"(perm_half));                  // keep them in registers: one v_lshl_add / v_lshl_or at their use
 	Slot *me = S;                                                        // slot of anchor i
 	for (;;) {
 		const bool active = i < n;
@@ -259,9 +260,11 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 			me = nx;
 			xi = (uint32_t)nxx, qi = nxq;
 			jb = i - 1, max_f = span, max_j = -1, fresh = true;
-			if ((i & (RW - 1)) == 0) {
-				if (!(busy_next & 1u)) seg = i;
-				busy_cur = busy_next;
+			if (any64((i & (RW - 1)) == 0)) {                             // a block boundary (one step in 32): keep it a branch
+				if ((i & (RW - 1)) == 0) {
+					if (!(busy_next & 1u)) seg = i;
+					busy_cur = busy_next;
+				}
 			}
 			if (i < n && (i & (RW - 1)) == 0) {                           // entering block nb
 				const int nb = i >> 5;
