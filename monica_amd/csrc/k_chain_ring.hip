@@ -22,8 +22,9 @@
 // this kernel held all anchors of a read in LDS: 2.75 waves/SIMD, 8.2 ms; profiles/README.md.)
 //
 // K5.  The backtrack needs random access to a whole read, so it is its own kernel with the
-// read's {p | owner, f | v} + coordinates in LDS (14 bytes per anchor, size classes), two reads
-// per wave; it has no sequential walk (see mnc_chain_tail).  Reads beyond the largest class
+// read's {p | owner, f | v} in LDS (8 bytes per anchor, size classes; coordinates are read from
+// HBM only for the anchors a chain owns), two reads per wave; it has no sequential walk (see
+// mnc_chain_tail).  Reads beyond the largest class
 // take the sequential mnc_chain_backtrack of k_chain.hip.
 #include "device.h"
 
@@ -303,8 +304,7 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 // they are accumulated per anchor as well.  Nothing here is sequential in the chain length.
 //
 // LDS per anchor: word0 = p | owner << 16 (during (A)-(C) the high half is the "is a
-// predecessor" flag), word1 = f | v << 16, x low word, 16-bit query position; per read 64
-// chain-end keys and 64 accumulators.  Reads with more than 64 chain ends take the
+// predecessor" flag), word1 = f | v << 16; per read 64 chain-end keys and 64 accumulators.  Reads with more than 64 chain ends take the
 // sequential walk below instead.
 constexpr int TAIL_ENDS = 64;
 constexpr uint32_t OWN_NONE = 0xffffu;
@@ -313,12 +313,10 @@ __global__ __launch_bounds__(64) void mnc_chain_tail(Batch B, const uint32_t *li
 {
 	extern __shared__ __align__(16) uint8_t smem[];
 	const int lane = threadIdx.x, row = lane / RW, lr = lane % RW;
-	uint8_t *rbase = smem + (size_t)row * ((size_t)NM * 14 + TAIL_ENDS * 32);
+	uint8_t *rbase = smem + (size_t)row * ((size_t)NM * 8 + TAIL_ENDS * 32);
 	uint32_t *W0 = reinterpret_cast<uint32_t*>(rbase);                  // p | owner << 16
 	uint32_t *W1 = W0 + NM;                                             // f | v << 16
-	uint32_t *xlo = W1 + NM;
-	uint16_t *qp = reinterpret_cast<uint16_t*>(xlo + NM);
-	uint64_t *ubuf = reinterpret_cast<uint64_t*>(rbase + (size_t)NM * 14);   // TAIL_ENDS chain-end keys
+	uint64_t *ubuf = reinterpret_cast<uint64_t*>(rbase + (size_t)NM * 8);   // TAIL_ENDS chain-end keys
 	uint32_t *acc = reinterpret_cast<uint32_t*>(ubuf + TAIL_ENDS);      // TAIL_ENDS x {cnt, mlen, blen, top, stop f, -}
 	uint16_t *H0 = reinterpret_cast<uint16_t*>(W0);
 
@@ -338,25 +336,19 @@ __global__ __launch_bounds__(64) void mnc_chain_tail(Batch B, const uint32_t *li
 	const int n_up = (n + RW - 1) / RW * RW;
 
 	// ---- load the DP result of the read
-	// (four blocks of loads in flight per lane: the loop is bound by HBM latency otherwise)
+	// (four blocks of loads in flight per lane)  The anchors' coordinates stay in HBM: only the
+	// anchors a chain owns need them, in (E3), next to their parents'.
 	for (int i0 = lr; i0 < n; i0 += 4 * RW) {
-		uint32_t ex[4], ey[4];
 		int p[4], f[4], v[4];
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			const int idx = i0 + k * RW;
-			if (idx < n) {
-				const Anchor e = ga[idx];
-				ex[k] = (uint32_t)e.x, ey[k] = (uint32_t)e.y;
-				p[k] = B.p[a_off + idx], f[k] = B.f[a_off + idx], v[k] = B.v[a_off + idx];
-			}
+			if (idx < n) p[k] = B.p[a_off + idx], f[k] = B.f[a_off + idx], v[k] = B.v[a_off + idx];
 		}
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			const int idx = i0 + k * RW;
 			if (idx < n) {
-				xlo[idx] = ex[k];
-				qp[idx] = (uint16_t)ey[k];
 				W0[idx] = p[k] < 0 ? NONE16 : (uint32_t)p[k];
 				W1[idx] = ((uint32_t)f[k] & 0xffffu) | (uint32_t)v[k] << 16;
 			}
@@ -474,7 +466,8 @@ __global__ __launch_bounds__(64) void mnc_chain_tail(Batch B, const uint32_t *li
 				++c_cnt;
 				const bool same = px != NONE16 && (W0[px] >> 16) == own;
 				if (same) {
-					const int tl = (int)(xlo[x] - xlo[px]), ql = (int)qp[x] - (int)qp[px];
+					const Anchor ac = ga[x], ap = ga[px];
+					const int tl = (int)((uint32_t)ac.x - (uint32_t)ap.x), ql = (int)(uint32_t)ac.y - (int)(uint32_t)ap.y;
 					c_ml += (uint32_t)(tl > span && ql > span ? span : tl < ql ? tl : ql);
 					c_bl += (uint32_t)(tl > ql ? tl : ql);
 				} else {
@@ -563,8 +556,9 @@ __global__ __launch_bounds__(64) void mnc_chain_tail(Batch B, const uint32_t *li
 					if (rest >= B.min_sc) score = rest;
 					break;
 				}
-				const uint32_t cx = xlo[j];
-				const int cq = (int)qp[j];
+				const Anchor aj = ga[j];
+				const uint32_t cx = (uint32_t)aj.x;
+				const int cq = (int)(uint32_t)aj.y;
 				if (cnt > 0) {
 					const int tl = (int)(nx - cx), ql = nq - cq;
 					blen += tl > ql ? tl : ql;
@@ -597,7 +591,7 @@ int chain_tail_prepare(size_t max_lds)
 	return MNC_OK;
 }
 
-size_t chain_tail_lds_bytes(int NM) { return (size_t)ROWS * ((size_t)NM * 14 + TAIL_ENDS * 32); }
+size_t chain_tail_lds_bytes(int NM) { return (size_t)ROWS * ((size_t)NM * 8 + TAIL_ENDS * 32); }
 
 void launch_chain_dp_ring(const Batch &B, const uint32_t *lists, const ClassSpans &spans, int stress, hipStream_t st)
 {
