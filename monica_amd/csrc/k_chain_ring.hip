@@ -306,13 +306,17 @@ __global__ __launch_bounds__(64 * DP_WAVES) void mnc_chain_dp_ring(Batch B, cons
 // LDS per anchor: word0 = p | owner << 16 (during (A)-(C) the high half is the "is a
 // predecessor" flag), word1 = f | v << 16; per read 64 chain-end keys and 64 accumulators.  Reads with more than 64 chain ends take the
 // sequential walk below instead.
-constexpr int TAIL_ENDS = 64;
+constexpr int TAIL_ENDS_MAX = 64;
+// chain ends (and accumulators) held in LDS per read: short reads rarely have many, and the
+// kernel's speed is set by its LDS footprint
+__host__ __device__ __forceinline__ int tail_ends(int NM) { return NM <= 512 ? 32 : TAIL_ENDS_MAX; }
 constexpr uint32_t OWN_NONE = 0xffffu;
 
 __global__ __launch_bounds__(64) void mnc_chain_tail(Batch B, const uint32_t *lists, ClassSpans spans, int NM)
 {
 	extern __shared__ __align__(16) uint8_t smem[];
 	const int lane = threadIdx.x, row = lane / RW, lr = lane % RW;
+	const int TAIL_ENDS = tail_ends(NM);
 	uint8_t *rbase = smem + (size_t)row * ((size_t)NM * 8 + TAIL_ENDS * 32);
 	uint32_t *W0 = reinterpret_cast<uint32_t*>(rbase);                  // p | owner << 16
 	uint32_t *W1 = W0 + NM;                                             // f | v << 16
@@ -591,7 +595,7 @@ int chain_tail_prepare(size_t max_lds)
 	return MNC_OK;
 }
 
-size_t chain_tail_lds_bytes(int NM) { return (size_t)ROWS * ((size_t)NM * 8 + TAIL_ENDS * 32); }
+size_t chain_tail_lds_bytes(int NM) { return (size_t)ROWS * ((size_t)NM * 8 + (size_t)tail_ends(NM) * 32); }
 
 void launch_chain_dp_ring(const Batch &B, const uint32_t *lists, const ClassSpans &spans, int stress, hipStream_t st)
 {
