@@ -33,11 +33,14 @@ def main():
     assign, best, nhits, flat = oidx.classify(bases, offsets, 60)
     raw = bases.tobytes()
     mz_cnt, an_cnt, reg_cnt, regs, mz_first = [], [], [], [], []
+    cf, cp, cv = [], [], []
     for r in range(len(reads)):
         s = raw[offsets[r]:offsets[r + 1]]
         m = pyoracle.sketch(s)
         a, _ = oidx.seeds(s)
         g = oidx.map(s)
+        _, f, p, v, _, _ = oidx.chain(s)
+        cf.append(f), cp.append(p), cv.append(v)
         mz_cnt.append(len(m)), an_cnt.append(len(a)), reg_cnt.append(len(g)), regs.append(g)
         mz_first.append(int(m["x"][0]) if len(m) else 0)
     ih, iy = oidx.dump()
@@ -49,6 +52,7 @@ def main():
         index_y_sum=np.uint64(int(iy.sum(dtype=np.uint64))), n_keys=np.int64(oidx.n_keys), n_occ=np.int64(oidx.n_minimizers),
         assign=assign, best=best, nhits=nhits, hits=flat,
         mz_cnt=np.array(mz_cnt), an_cnt=np.array(an_cnt), reg_cnt=np.array(reg_cnt), mz_first=np.array(mz_first, dtype=np.uint64),
+        chain_f=np.concatenate(cf), chain_p=np.concatenate(cp), chain_v=np.concatenate(cv),
         regs=np.concatenate(regs) if regs else np.zeros(0, dtype=pyoracle.REG_DTYPE))
     print("wrote small_case.npz:", len(reads), "reads,", int((assign >= 0).sum()), "classified")
 

@@ -30,6 +30,7 @@ def _compare_batch(capi, oracle, world, bases, offsets, min_mapq=60):
     an_off = eng.dump(capi.DUMP_AN_OFFSETS, np.int64)
     f = eng.dump(capi.DUMP_CHAIN_F, np.int32)
     p = eng.dump(capi.DUMP_CHAIN_P, np.int32)
+    v = eng.dump(capi.DUMP_CHAIN_V, np.int32)
     regs = eng.dump(capi.DUMP_REGS, capi.REG_DTYPE)
     reg_off = eng.dump(capi.DUMP_REG_OFFSETS, np.int64)
     rep = eng.dump(capi.DUMP_REP_LEN, np.int32)
@@ -53,6 +54,7 @@ def _compare_batch(capi, oracle, world, bases, offsets, min_mapq=60):
         _, of, op, ov, ou, ob = oidx.chain(s)
         assert np.array_equal(f[an_off[r]:an_off[r + 1]], of), f"read {r}: chain f"
         assert np.array_equal(p[an_off[r]:an_off[r + 1]], op), f"read {r}: chain p"
+        assert np.array_equal(v[an_off[r]:an_off[r + 1]], ov), f"read {r}: chain v"
         # K5/K6
         oregs = oidx.map(s)
         gr = regs[reg_off[r]:reg_off[r + 1]]
