@@ -164,7 +164,8 @@ int mnc_best_hit(const mnc_hit_t *hits, int n, int *best_index /* -1 = ambiguous
 #define MNC_STAGE_GATHER      10  /* gated hit lists -> CSR (mnc_engine_fetch_hits)          */
 #define MNC_N_STAGES          11
 int mnc_engine_set_profiling(mnc_engine *eng, int on);    /* HIP events around every stage */
-int mnc_engine_set_debug(mnc_engine *eng, int mode);      /* 2: stress build of the chaining ring (tests)  */
+int mnc_engine_set_debug(mnc_engine *eng, int mode);      /* test switches, a bit mask: 2 stress build of the
+                                                             chaining ring, 4 displacement bytes read from HBM */
 /* accumulated since the last reset: ms[MNC_N_STAGES], launches[MNC_N_STAGES] */
 int mnc_engine_get_timings(mnc_engine *eng, double *ms, int64_t *launches, int reset);
 const char *mnc_stage_name(int stage);

@@ -127,6 +127,7 @@ def multi_threaded_aligner(query_folder, indexes_paths, mode=None, mapping_quali
 
     pool = ThreadPool(n_threads if n_threads else DEFAULT_THREADS)
     rep = itertools.repeat
+    mappy.reserve_index_cache(len(indexes_paths))
     try:
         for part in indexes_paths[:-1]:
             index = index_loader(part)

@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include <mutex>
+#include <deque>
 
 #include "../../include/monica_amd.h"
 
@@ -64,6 +65,8 @@ struct DeviceIndex {          // one per (index, device)
 	uint32_t *filter = nullptr;    // per region: 2^PF_BITS-bit presence filter (see k_probe.hip)
 	uint64_t *positions = nullptr;
 	int32_t *contig_genome = nullptr;
+	uint32_t *seq4 = nullptr;      // contig bases, 4 bits each, 8 per word (base-level DP stage)
+	int64_t *seq_off = nullptr;    // [n_contigs + 1] first base of a contig in seq4
 	int64_t bytes = 0;
 };
 
@@ -81,12 +84,17 @@ struct mnc_index {
 	std::vector<uint32_t> keys;       // distinct hashes, ascending
 	std::vector<uint64_t> key_off;    // n_keys + 1 offsets into pos
 	std::vector<uint64_t> pos;        // occurrence words, ascending inside one key
+	// contig bases for the base-level DP stage: codes 0..3 = ACGT(U), 4 = anything else, 4 bits
+	// each, base i of the concatenation at bits (i & 7) * 4 of seq4[i >> 3] (as minimap2 stores
+	// them next to its minimizer table)
+	std::vector<uint32_t> seq4;
+	std::vector<int64_t> seq_off;     // n_contigs + 1
 	int32_t mid_occ = 0;
 	int64_t total_len = 0;
 	mnc::MapParams par;
 	// device residency
 	std::mutex dev_mutex;
-	std::vector<mnc::DeviceIndex> dev;
+	std::deque<mnc::DeviceIndex> dev;   // a deque: engines keep pointers to its elements
 };
 
 namespace mnc {

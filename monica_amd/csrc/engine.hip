@@ -285,13 +285,15 @@ int index_upload(mnc_index *idx, int device, DeviceIndex **out)
 	if (!urc) urc = upload((void**)&d.table, tab.data(), tab.size() * sizeof(TableSlot));
 	if (!urc) urc = upload((void**)&d.positions, idx->pos.data(), idx->pos.size() * 8, 8);   // one spare word behind the positions
 	if (!urc) urc = upload((void**)&d.contig_genome, idx->contig_genome.data(), idx->contig_genome.size() * 4);
+	if (!urc) urc = upload((void**)&d.seq4, idx->seq4.data(), idx->seq4.size() * 4, 16);
+	if (!urc) urc = upload((void**)&d.seq_off, idx->seq_off.data(), idx->seq_off.size() * 8);
 	if (urc) {                                               // do not leak the part that made it to the device
-		void *parts[] = { d.filter, d.disp, d.salt, d.table, d.positions, d.contig_genome };
+		void *parts[] = { d.filter, d.disp, d.salt, d.table, d.positions, d.contig_genome, d.seq4, d.seq_off };
 		for (void *q : parts) if (q) (void)hipFree(q);
 		return urc;
 	}
-	d.bytes = (int64_t)(tab.size() * sizeof(TableSlot) + filt.size() * 4 + disp.size() + (idx->pos.size() + 1) * 8 + idx->contig_genome.size() * 4);
-	idx->dev.reserve(16);
+	d.bytes = (int64_t)(tab.size() * sizeof(TableSlot) + filt.size() * 4 + disp.size() + (idx->pos.size() + 1) * 8 + idx->contig_genome.size() * 4 +
+	                    idx->seq4.size() * 4 + idx->seq_off.size() * 8);
 	idx->dev.push_back(d);
 	*out = &idx->dev.back();
 	return MNC_OK;
@@ -308,6 +310,8 @@ void index_release_device(mnc_index *idx)
 		if (d.salt) (void)hipFree(d.salt);
 		if (d.positions) (void)hipFree(d.positions);
 		if (d.contig_genome) (void)hipFree(d.contig_genome);
+		if (d.seq4) (void)hipFree(d.seq4);
+		if (d.seq_off) (void)hipFree(d.seq_off);
 	}
 	idx->dev.clear();
 }
@@ -341,7 +345,7 @@ struct mnc_engine {
 	// per chain slot
 	Buf chains_tmp, regs, regx, k64a, k64b, tmp_i32, gated, hits_csr;
 	Buf stats, cls_count, cls_list;
-	int debug = 0;                           // 2: stress build of the chaining ring (tests)
+	int debug = 0;                           // bit mask (tests): 2 stress build of the chaining ring, 4 displacement bytes read from HBM
 	// last batch
 	Batch B{};
 	bool have_batch = false;
@@ -456,7 +460,7 @@ extern "C" int mnc_engine_create(mnc_index *idx, int device, mnc_engine **out)
 		if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming);
 	}
 	if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
-	if (he != hipSuccess) { set_error("stream creation failed: %s", hipGetErrorString(he)); delete e; return MNC_ERR_HIP; }
+	if (he != hipSuccess) { set_error("stream creation failed: %s", hipGetErrorString(he)); mnc_engine_destroy(e); return MNC_ERR_HIP; }
 	for (int s = 0; s < MNC_N_STAGES; ++s) for (int k = 0; k < 2; ++k) (void)hipEventCreate(&e->ev[s][k]);
 	// gap cost: (int)(dd * .01 * avg_span) + (ilog2(dd) >> 1), evaluated in double exactly as
 	// minimap2 does; avg_span is the float mean of the spans == k
@@ -583,7 +587,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	Batch &B = e->B;
 	memset(&B, 0, sizeof(B));
 	B.bases = d_bases, B.offsets = d_offsets, B.n_reads = n_reads, B.total_bases = total_bases, B.min_mapq = min_mapq;
-	B.table = e->didx->table, B.filter = e->didx->filter, B.disp = e->didx->disp, B.salt = e->didx->salt, B.disp_in_lds = (e->didx->disp_bits <= PD_MAX_BITS && !getenv("MNC_DISP_IN_HBM")) ? 1 : 0, B.positions = e->didx->positions;
+	B.table = e->didx->table, B.filter = e->didx->filter, B.disp = e->didx->disp, B.salt = e->didx->salt, B.disp_in_lds = (e->didx->disp_bits <= PD_MAX_BITS && !(e->debug & 4)) ? 1 : 0, B.positions = e->didx->positions;
 	B.region_bits = e->didx->region_bits, B.disp_bits = e->didx->disp_bits;
 	B.contig_genome = e->didx->contig_genome, B.mid_occ = idx->mid_occ, B.n_genomes = (int)idx->genome_name.size();
 	{
@@ -715,7 +719,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 		ClassSpans spans;
 		spans.n = CHAIN_CLASSES.n + 1, spans.stride = (uint32_t)n_reads, spans.start[0] = 0;
 		for (int c = 0; c <= CHAIN_CLASSES.n; ++c) spans.start[c + 1] = spans.start[c] + cls_count[c];
-		launch_chain_dp_ring(B, lists, spans, e->debug == 2, st);
+		launch_chain_dp_ring(B, lists, spans, (e->debug & 2) != 0, st);
 	}
 	{
 		StageTimer t(e, MNC_STAGE_BACKTRACK);       // LDS form per size class; sequential form beyond

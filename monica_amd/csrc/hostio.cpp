@@ -34,6 +34,7 @@ struct LineReader {
 	std::vector<char> buf;
 	size_t lo = 0, hi = 0;
 	bool eof = false;
+	int err = 0;                // errno of a failed read(): reported as MNC_ERR_IO, never taken for the end of the file
 
 	// next line without its terminator; false at end of file.  `raw_len` = bytes consumed
 	bool next(const char *&p, size_t &len)
@@ -56,7 +57,7 @@ struct LineReader {
 			if (buf.size() < hi + IO_CHUNK) buf.resize(hi + IO_CHUNK);
 			ssize_t n;
 			do n = read(fd, buf.data() + hi, IO_CHUNK); while (n < 0 && errno == EINTR);
-			if (n < 0) { eof = true; return false; }
+			if (n < 0) { err = errno ? errno : EIO; eof = true; return false; }
 			if (n == 0) eof = true;
 			hi += (size_t)n;
 		}
@@ -112,6 +113,12 @@ struct mnc_fastq {
 	std::vector<uint32_t> id_len, id_off;   // seq_record.id = first word of the title
 };
 
+static int fq_io_fail(const mnc_fastq *fq)
+{
+	set_error("read of %s failed: %s", fq->path.c_str(), strerror(fq->in.err));
+	return MNC_ERR_IO;
+}
+
 static int fq_fail(const char *msg)
 {
 	set_error("%s", msg);
@@ -161,7 +168,11 @@ extern "C" int mnc_fastq_next(mnc_fastq *fq, uint32_t max_reads, uint64_t max_ba
 	size_t len;
 	if (!fq->started) {
 		fq->started = true;
-		if (!fq->in.next(p, len)) { fq->done = true; return MNC_OK; }      // empty file
+		if (!fq->in.next(p, len)) {
+			if (fq->in.err) return fq_io_fail(fq);
+			fq->done = true;                                                   // empty file
+			return MNC_OK;
+		}
 		fq->pending.assign(p, len);
 		fq->have_pending = true;
 	}
@@ -184,6 +195,7 @@ extern "C" int mnc_fastq_next(mnc_fastq *fq, uint32_t max_reads, uint64_t max_ba
 		bool first = true;
 		for (;;) {
 			if (!fq->in.next(p, len)) {
+				if (fq->in.err) return fq_io_fail(fq);
 				if (first) { first = false; continue; }         // readline() == '' once, then the '+' search fails
 				return fq_fail("End of file without quality information.");
 			}
@@ -207,7 +219,11 @@ extern "C" int mnc_fastq_next(mnc_fastq *fq, uint32_t max_reads, uint64_t max_ba
 		int64_t q_len = 0;
 		bool q_first = true;
 		for (;;) {
-			if (!fq->in.next(p, len)) { fq->done = true; break; }
+			if (!fq->in.next(p, len)) {
+				if (fq->in.err) return fq_io_fail(fq);
+				fq->done = true;
+				break;
+			}
 			if (!q_first && len > 0 && p[0] == '@' && q_len >= s_len) {
 				fq->pending.assign(p, len);
 				fq->have_pending = true;

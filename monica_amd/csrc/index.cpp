@@ -11,6 +11,8 @@
 #include <cstring>
 #include <map>
 #include <zlib.h>
+#include <sys/stat.h>
+#include <stdexcept>
 
 #include "common.h"
 #include <parallel/algorithm>
@@ -115,6 +117,29 @@ static void contig_minimizers(const char *s, int64_t len, int w, int k, uint32_t
 		win.push(cur, run, k);
 	}
 	win.flush();
+}
+
+// contig bases -> 4-bit codes.  Words shared by two contigs are written by one thread only:
+// a contig's leading and trailing partial words are merged serially afterwards.
+static void pack_contigs(mnc_index *idx, const char *const *seqs, const int64_t *lens, int n_seq)
+{
+	uint32_t *S = idx->seq4.data();
+#pragma omp parallel for schedule(dynamic, 1)
+	for (int i = 0; i < n_seq; ++i) {
+		const int64_t o = idx->seq_off[i], e = o + lens[i];
+		const int64_t first_full = (o + 7) / 8 * 8, last_full = e / 8 * 8;
+		for (int64_t b = first_full; b + 8 <= last_full; b += 8) {
+			uint32_t wd = 0;
+			for (int t = 0; t < 8; ++t) wd |= (uint32_t)base_code((unsigned char)seqs[i][b - o + t]) << (t * 4);
+			S[b >> 3] = wd;
+		}
+	}
+	for (int i = 0; i < n_seq; ++i) {
+		const int64_t o = idx->seq_off[i], e = o + lens[i];
+		const int64_t first_full = std::min(e, (o + 7) / 8 * 8), last_full = std::max(first_full, e / 8 * 8);
+		for (int64_t b = o; b < first_full; ++b) S[b >> 3] |= (uint32_t)base_code((unsigned char)seqs[i][b - o]) << ((b & 7) * 4);
+		for (int64_t b = last_full; b < e; ++b) S[b >> 3] |= (uint32_t)base_code((unsigned char)seqs[i][b - o]) << ((b & 7) * 4);
+	}
 }
 
 // ---------------------------------------------------------------- occurrence cut-off
@@ -226,6 +251,9 @@ extern "C" int mnc_index_build_mem(int n_seq, const char *const *names, const ch
 		for (int i = 0; i < n_seq; ++i) order[i] = i;
 		std::sort(order.begin(), order.end(), [&](int a, int b) { return lens[a] != lens[b] ? lens[a] > lens[b] : a < b; });
 		bool oom = false;
+		idx->seq_off.assign((size_t)n_seq + 1, 0);
+		for (int i = 0; i < n_seq; ++i) idx->seq_off[i + 1] = idx->seq_off[i] + lens[i];
+		idx->seq4.assign((size_t)(idx->seq_off[n_seq] + 7) / 8 + 1, 0u);
 #pragma omp parallel for schedule(dynamic, 1)
 		for (int j = 0; j < n_seq; ++j) {
 			const int i = order[j];
@@ -234,6 +262,7 @@ extern "C" int mnc_index_build_mem(int n_seq, const char *const *names, const ch
 				contig_minimizers(seqs[i], lens[i], w, k, (uint32_t)i, per[i]);
 			} catch (const std::bad_alloc &) { oom = true; }
 		}
+		pack_contigs(idx, seqs, lens, n_seq);
 		if (oom) { delete idx; return MNC_ERR_NOMEM; }
 		size_t total = 0;
 		for (auto &v : per) total += v.size();
@@ -293,7 +322,7 @@ extern "C" int mnc_index_build(const char *fasta_path, const char *out_path, int
 }
 
 namespace {
-const char MAGIC[8] = { 'M', 'N', 'C', 'I', 'D', 'X', '1', 0 };
+const char MAGIC[8] = { 'M', 'N', 'C', 'I', 'D', 'X', '2', 0 };   // 2: contig bases follow the occurrence words
 struct FileHeader {
 	char magic[8];
 	int32_t k, w, n_contigs, mid_occ;
@@ -318,7 +347,8 @@ extern "C" int mnc_index_save(const mnc_index *idx, const char *path)
 	          put(f, idx->contig_len.data(), idx->contig_len.size()) &&
 	          put(f, idx->keys.data(), idx->keys.size()) &&
 	          put(f, idx->key_off.data(), idx->key_off.size()) &&
-	          put(f, idx->pos.data(), idx->pos.size());
+	          put(f, idx->pos.data(), idx->pos.size()) &&
+	          put(f, idx->seq4.data(), idx->seq4.size());
 	ok = (fclose(f) == 0) && ok;
 	if (!ok) { set_error("short write to %s", path); return MNC_ERR_IO; }
 	return MNC_OK;
@@ -337,6 +367,18 @@ extern "C" int mnc_index_load(const char *path, mnc_index **out)
 		set_error("%s is not a monica_amd index (or is empty)", path);
 		return MNC_ERR_FORMAT;
 	}
+	// the header must account for the file, byte for byte, before anything is allocated from it
+	struct stat sb;
+	if (fstat(fileno(f), &sb) != 0) { fclose(f); set_error("cannot stat %s", path); return MNC_ERR_IO; }
+	const unsigned __int128 fixed = (unsigned __int128)sizeof(FileHeader) + (unsigned __int128)h.names_bytes +
+	                                (unsigned __int128)h.n_contigs * 8 + (unsigned __int128)h.n_keys * 4 +
+	                                ((unsigned __int128)h.n_keys + 1) * 8 + (unsigned __int128)h.n_occ * 8;
+	if (fixed > (unsigned __int128)sb.st_size || ((unsigned __int128)sb.st_size - fixed) % 4 != 0) {
+		fclose(f);
+		set_error("%s is truncated or damaged (header does not match the file size)", path);
+		return MNC_ERR_FORMAT;
+	}
+	const size_t seq_words = (size_t)(((unsigned __int128)sb.st_size - fixed) / 4);
 	mnc_index *idx = new (std::nothrow) mnc_index;
 	if (!idx) { fclose(f); return MNC_ERR_NOMEM; }
 	int rc = MNC_OK;
@@ -347,26 +389,51 @@ extern "C" int mnc_index_load(const char *path, mnc_index **out)
 		idx->keys.resize((size_t)h.n_keys);
 		idx->key_off.resize((size_t)h.n_keys + 1);
 		idx->pos.resize((size_t)h.n_occ);
+		idx->seq4.resize(seq_words);
 		bool ok = get(f, &names[0], names.size()) && get(f, idx->contig_len.data(), idx->contig_len.size()) &&
 		          get(f, idx->keys.data(), idx->keys.size()) && get(f, idx->key_off.data(), idx->key_off.size()) &&
-		          get(f, idx->pos.data(), idx->pos.size());
+		          get(f, idx->pos.data(), idx->pos.size()) && get(f, idx->seq4.data(), idx->seq4.size());
 		if (ok) {
 			const char *p = names.data(), *e = p + names.size();
-			while (p < e && (int)idx->contig_name.size() < h.n_contigs) { idx->contig_name.emplace_back(p); p += idx->contig_name.back().size() + 1; }
-			ok = (int)idx->contig_name.size() == h.n_contigs && idx->key_off.back() == (uint64_t)h.n_occ;
+			while (p < e && (int)idx->contig_name.size() < h.n_contigs) {
+				const void *z = memchr(p, 0, (size_t)(e - p));
+				if (!z) break;
+				idx->contig_name.emplace_back(p);
+				p = (const char*)z + 1;
+			}
+			ok = (int)idx->contig_name.size() == h.n_contigs && p == e;
+		}
+		// the arrays index each other and, later, device memory: check every invariant here
+		// rather than fault in a kernel
+		int64_t total = 0;
+		for (size_t i = 0; ok && i < idx->contig_len.size(); ++i) {
+			ok = idx->contig_len[i] >= 0 && idx->contig_len[i] <= 0x7fffffffLL;
+			total += idx->contig_len[i];
+		}
+		ok = ok && seq_words == (size_t)(total + 7) / 8 + 1;
+		ok = ok && idx->key_off[0] == 0 && idx->key_off.back() == (uint64_t)h.n_occ;
+		for (size_t i = 0; ok && i < idx->keys.size(); ++i)
+			ok = idx->key_off[i] < idx->key_off[i + 1] && idx->keys[i] < (1u << 30) && (i == 0 || idx->keys[i - 1] < idx->keys[i]);
+		for (size_t i = 0; ok && i < idx->pos.size(); ++i) {
+			const uint64_t rid = idx->pos[i] >> 32, ps = (uint32_t)idx->pos[i] >> 1;
+			ok = rid < (uint64_t)h.n_contigs && (int64_t)ps < idx->contig_len[rid];
 		}
 		if (!ok) { set_error("%s is truncated or damaged", path); rc = MNC_ERR_FORMAT; }
 		else {
+			idx->seq_off.assign((size_t)h.n_contigs + 1, 0);
+			for (int i = 0; i < h.n_contigs; ++i) idx->seq_off[i + 1] = idx->seq_off[i] + idx->contig_len[i];
 			// rebuild genome table; keep the stored cut-off
 			std::vector<std::pair<uint64_t, uint64_t>> none;
 			std::vector<uint32_t> keys; std::vector<uint64_t> off, pos;
 			keys.swap(idx->keys), off.swap(idx->key_off), pos.swap(idx->pos);
 			index_finalize(idx, none);
 			keys.swap(idx->keys), off.swap(idx->key_off), pos.swap(idx->pos);
+			if (h.mid_occ < 1) { set_error("%s is truncated or damaged", path); rc = MNC_ERR_FORMAT; }
 			idx->mid_occ = h.mid_occ;
-			rc = check_kw(idx->k, idx->w);
+			if (!rc) rc = check_kw(idx->k, idx->w);
 		}
 	} catch (const std::bad_alloc &) { rc = MNC_ERR_NOMEM; }
+	catch (const std::exception &ex) { set_error("%s is truncated or damaged (%s)", path, ex.what()); rc = MNC_ERR_FORMAT; }
 	fclose(f);
 	if (rc) { delete idx; return rc; }
 	*out = idx;

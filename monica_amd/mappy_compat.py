@@ -26,6 +26,26 @@ from . import _capi
 _INDEX_CACHE = {}
 _INDEX_CACHE_LOCK = threading.Lock()
 _INDEX_CACHE_MAX = 4
+# idle engines (stream + HBM workspace) per cached index, keyed by id(index).  Kept outside the
+# Index object: an Engine refers to its Index, so a pool stored on the Index would be a
+# reference cycle and an evicted index would hold its HBM until the cyclic collector ran.
+_ENGINE_POOLS = {}
+
+
+def reserve_index_cache(n_parts):
+    """Make room for every part of a multi-part database (monica loops over all parts on every
+    pass, aligner.py:91-103: a cache smaller than the loop would miss on every load)."""
+    global _INDEX_CACHE_MAX
+    with _INDEX_CACHE_LOCK:
+        _INDEX_CACHE_MAX = max(_INDEX_CACHE_MAX, int(n_parts))
+
+
+def _evict_locked():
+    while len(_INDEX_CACHE) > _INDEX_CACHE_MAX:
+        old = _INDEX_CACHE.pop(next(iter(_INDEX_CACHE)))
+        for eng in _ENGINE_POOLS.pop(id(old), []):
+            eng.close()                                        # idle by construction: free its HBM now
+        # the Index frees its device tables when the last Aligner using it lets go
 
 
 def _load_index_cached(path):
@@ -39,16 +59,16 @@ def _load_index_cached(path):
     index = _capi.Index.load(path)
     with _INDEX_CACHE_LOCK:
         _INDEX_CACHE[key] = index
-        while len(_INDEX_CACHE) > _INDEX_CACHE_MAX:
-            _INDEX_CACHE.pop(next(iter(_INDEX_CACHE)))
+        _evict_locked()
     return index
 
 
 def _engine_pool(index):
-    pool = getattr(index, "_engine_pool", None)
-    if pool is None:
-        pool = index._engine_pool = []
-    return pool
+    """Pool of idle engines of a CACHED index (None for an index the cache does not hold)."""
+    with _INDEX_CACHE_LOCK:
+        if not any(v is index for v in _INDEX_CACHE.values()):
+            return None
+        return _ENGINE_POOLS.setdefault(id(index), [])
 
 
 def default_device():
@@ -114,7 +134,7 @@ class Aligner:
     def _is_index_file(path):
         try:
             with open(path, "rb") as f:
-                return f.read(7) == b"MNCIDX1"
+                return f.read(6) == b"MNCIDX"
         except OSError:
             return False
 
@@ -163,8 +183,12 @@ class Aligner:
             if self._index is not None and self._borrowed:
                 pool = _engine_pool(self._index)
                 with _INDEX_CACHE_LOCK:
-                    pool.extend(self._borrowed[:8 - len(pool)] if len(pool) < 8 else [])
-                    self._borrowed = []
+                    keep = self._borrowed[:max(0, 8 - len(pool))] if pool is not None else []
+                    if pool is not None:
+                        pool.extend(keep)
+                    rest, self._borrowed = self._borrowed[len(keep):], []
+                for eng in rest:                               # not pooled: release the HBM now
+                    eng.close()
         except Exception:
             pass
 

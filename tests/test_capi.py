@@ -101,6 +101,35 @@ def test_damaged_or_empty_index_is_refused(capi, world, tmp_path):
     with pytest.raises(capi.MncError) as e:
         capi.Index.load(str(tmp_path / "missing.mmi"))
     assert e.value.code == capi.ERR_IO
+    # bit rot that keeps the size: every field the device code would index with is checked at
+    # load (header counts against the file size, offsets monotone, keys ascending and < 2^30,
+    # occurrence words inside their contig) -- 'Damaged or empty index', never a GPU fault
+    import struct
+    hdr = struct.Struct("<8s4i3q")
+    magic, k, w, n_contigs, mid_occ, n_keys, n_occ, names_bytes = hdr.unpack_from(raw)
+    assert magic[:6] == b"MNCIDX" and n_contigs == len(names)
+    body = hdr.size + names_bytes + n_contigs * 8
+    def patched(off, fmt, value):
+        b = bytearray(raw)
+        struct.pack_into(fmt, b, off, value)
+        return bytes(b)
+    damaged = {
+        "n_keys.mmi": hdr.pack(magic, k, w, n_contigs, mid_occ, n_keys + 1, n_occ, names_bytes) + raw[hdr.size:],
+        "huge.mmi": hdr.pack(magic, k, w, n_contigs, mid_occ, 1 << 60, 1 << 61, names_bytes) + raw[hdr.size:],
+        "contigs.mmi": hdr.pack(magic, k, w, n_contigs + 3, mid_occ, n_keys, n_occ, names_bytes) + raw[hdr.size:],
+        "key_order.mmi": patched(body + 4 * 10, "<I", 0),
+        "key_range.mmi": patched(body + 4 * (n_keys - 1), "<I", 1 << 31),
+        "key_off.mmi": patched(body + 4 * n_keys + 8 * 7, "<Q", n_occ + 5),
+        "pos_rid.mmi": patched(body + 4 * n_keys + 8 * (n_keys + 1) + 8 * 3, "<Q", (n_contigs + 9) << 32 | 100),
+        "pos_off.mmi": patched(body + 4 * n_keys + 8 * (n_keys + 1) + 8 * 3, "<Q", 0x7ffffff0),
+        "tail.mmi": raw + b"\0\0\0\0",
+    }
+    for name, blob in damaged.items():
+        q = str(tmp_path / name)
+        open(q, "wb").write(blob)
+        with pytest.raises(capi.MncError) as e:
+            capi.Index.load(q)
+        assert e.value.code == capi.ERR_FORMAT, name
     fa = str(tmp_path / "empty.fna")
     open(fa, "w").write("")
     with pytest.raises(capi.MncError) as e:

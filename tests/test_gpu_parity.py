@@ -260,12 +260,15 @@ def test_small_indexes_always_get_a_perfect_hash(capi, oracle):
             assert np.array_equal(an[an_off[r]:an_off[r + 1]]["x"], oa["x"])
 
 
-def test_displacement_table_read_in_place(capi, oracle, world, monkeypatch):
+def test_displacement_table_read_in_place(capi, oracle, world):
     """An index with more displacement buckets per region than the probe kernel's LDS copy holds
-    (hundreds of genomes) reads the displacements from HBM; the switch forces that path."""
-    monkeypatch.setenv("MNC_DISP_IN_HBM", "1")
+    (hundreds of genomes) reads the displacements from HBM; the debug switch forces that path."""
     b, o, _ = synth.reads(world["seqs"], 200, 2000, seed=19)
-    _compare_batch(capi, oracle, world, b, o)
+    try:
+        world["eng"].set_debug(4)
+        _compare_batch(capi, oracle, world, b, o)
+    finally:
+        world["eng"].set_debug(0)
 
 
 def test_dense_sketch_overflows_the_query_budget_and_is_redone(capi, oracle, world):
