@@ -19,6 +19,7 @@
 #include <omp.h>
 #endif
 #include "mm_oracle.h"
+#include "mm_internal.h"
 
 #define PARENT_UNSET   (-1)
 #define PARENT_TMP_PRI (-2)
@@ -47,12 +48,21 @@ void orc_opt_init(orc_opt_t *o)
 	o->min_join_flank_sc = 1000;
 	o->min_join_flank_ratio = 0.5f;
 	o->a = 2, o->b = 4;
+	o->cigar = 1;                     /* mappy ORs MM_F_CIGAR in unconditionally (A.1) */
+	o->q = 4, o->e = 2, o->q2 = 24, o->e2 = 1;
+	o->sc_ambi = 1;
+	o->zdrop = 400, o->zdrop_inv = 200;
+	o->end_bonus = -1;
+	o->min_dp_max = o->min_chain_score * o->a;
+	o->min_ksw_len = 200;
+	o->max_clip_ratio = 1.0f;
+	o->max_sw_mat = 100000000;
 }
 
 /* ------------------------------------------------------------------ sketch (A.2) */
 
 /* base -> 0..3, everything else 4 (A.2). U/u counts as T like upstream's table. */
-static unsigned char nt4(unsigned char c)
+unsigned char orc_nt4(unsigned char c)
 {
 	switch (c) {
 	case 'A': case 'a': return 0;
@@ -104,7 +114,7 @@ static void sketch_core(const char *str, int len, int w, int k, uint32_t rid, ve
 	for (j = 0; j < w; ++j) buf[j] = none;
 
 	for (i = 0; i < len; ++i) {
-		int c = nt4((unsigned char)str[i]);
+		int c = orc_nt4((unsigned char)str[i]);
 		orc128_t info = none;
 		if (c < 4) {
 			int z;
@@ -172,6 +182,7 @@ struct orc_index {
 	uint64_t *tval;         /* offset<<32 | count  (count < 2^32, offset < 2^32) */
 	uint64_t *big_off;      /* NULL unless offsets exceed 32 bits */
 	uint32_t *cnts;         /* per distinct key: occurrence count (for mid_occ) */
+	uint8_t **seq;          /* contig bases as codes 0..4 (minimap2 keeps them 4-bit packed; A.3) */
 };
 
 static int cmp128(const void *pa, const void *pb)
@@ -240,9 +251,13 @@ orc_index *orc_index_build_mem(int n_seq, const char *const *names, const char *
 	mi->k = k, mi->w = w, mi->n_seq = n_seq;
 	mi->name = (char**)calloc((size_t)(n_seq ? n_seq : 1), sizeof(char*));
 	mi->len = (int*)calloc((size_t)(n_seq ? n_seq : 1), sizeof(int));
+	mi->seq = (uint8_t**)calloc((size_t)(n_seq ? n_seq : 1), sizeof(uint8_t*));
 	for (i = 0; i < n_seq; ++i) {
+		int j;
 		mi->name[i] = strdup(names[i]);
 		mi->len[i] = lens[i];
+		mi->seq[i] = (uint8_t*)malloc((size_t)(lens[i] ? lens[i] : 1));
+		for (j = 0; j < lens[i]; ++j) mi->seq[i][j] = orc_nt4((unsigned char)seqs[i][j]);
 		sketch_core(seqs[i], lens[i], w, k, (uint32_t)i, &v);
 	}
 	index_from_pairs(mi, &v);
@@ -304,9 +319,18 @@ void orc_index_free(orc_index *mi)
 {
 	int i;
 	if (!mi) return;
-	for (i = 0; i < mi->n_seq; ++i) free(mi->name[i]);
+	for (i = 0; i < mi->n_seq; ++i) free(mi->name[i]), free(mi->seq[i]);
+	free(mi->seq);
 	free(mi->name), free(mi->len), free(mi->P), free(mi->tkey), free(mi->tval), free(mi->cnts);
 	free(mi);
+}
+
+int orc_index_getseq(const orc_index *mi, uint32_t rid, uint32_t st, uint32_t en, uint8_t *seq)
+{
+	if (rid >= (uint32_t)mi->n_seq || st > (uint32_t)mi->len[rid]) return -1;
+	if (en > (uint32_t)mi->len[rid]) en = (uint32_t)mi->len[rid];
+	memcpy(seq, mi->seq[rid] + st, en - st);
+	return (int)(en - st);
 }
 
 int orc_index_k(const orc_index *mi) { return mi->k; }
@@ -574,7 +598,7 @@ static inline uint32_t wang_hash32(uint32_t key)
 	return key;
 }
 
-static void reg_set_coor(orc_reg_t *r, int32_t qlen, const orc128_t *a)
+void orc_reg_set_coor(orc_reg_t *r, int32_t qlen, const orc128_t *a)
 {
 	int32_t k = r->as, q_span = (int32_t)(a[k].y >> 32 & 0xff), i;
 	r->rev = (int32_t)(a[k].x >> 63);
@@ -626,13 +650,13 @@ static orc_reg_t *gen_regs(uint32_t hash, int qlen, int n_u, const uint64_t *u, 
 		ri->hash = (uint32_t)z[i].x;
 		ri->cnt = (int32_t)z[i].y;
 		ri->as = (int32_t)(z[i].y >> 32);
-		reg_set_coor(ri, qlen, a);
+		orc_reg_set_coor(ri, qlen, a);
 	}
 	free(z);
 	return r;
 }
 
-static void sync_regs(int n_regs, orc_reg_t *regs)
+void orc_sync_regs(int n_regs, orc_reg_t *regs)
 {
 	int *tmp, i, max_id = -1, n_tmp;
 	if (n_regs <= 0) return;
@@ -651,8 +675,11 @@ static void sync_regs(int n_regs, orc_reg_t *regs)
 	free(tmp);
 }
 
-/* parent / secondary assignment and subsc, n_sub (A.6); float32 ratio test */
-static void set_parent(float mask_level, int n, orc_reg_t *r)
+/* parent / secondary assignment and subsc, n_sub (A.6); float32 ratio test.  Runs twice when
+ * base-level alignment is on (chain_post, then align_regs): on the second pass both regions
+ * carry a DP result, dp_max2 of the parent is raised and a near-equal DP score also counts as
+ * a sub-optimal hit (sub_diff = a * 2 + b). */
+void orc_set_parent(float mask_level, int n, orc_reg_t *r, int sub_diff)
 {
 	int i, j, k, *w;
 	uint64_t *cov;
@@ -691,9 +718,17 @@ static void set_parent(float mask_level, int n, orc_reg_t *r)
 			ol = si < sj ? (ei < sj ? 0 : ei < ej ? ei - sj : ej - sj)
 			             : (ej < si ? 0 : ej < ei ? ej - si : ei - si);
 			if ((float)ol / min - (float)uncov_len / max > mask_level) {
+				int cnt_sub = 0;
 				ri->parent = rp->parent;
 				rp->subsc = rp->subsc > ri->score ? rp->subsc : ri->score;
-				if (ri->cnt >= rp->cnt) ++rp->n_sub;
+				if (ri->cnt >= rp->cnt) cnt_sub = 1;
+				if ((rp->flags & ORC_REG_HAS_DP) && (ri->flags & ORC_REG_HAS_DP) &&
+				    (rp->rid != ri->rid || rp->rs != ri->rs || rp->re != ri->re || ol != min)) {   /* not the same hit twice */
+					int sc = ri->dp_max;
+					rp->dp_max2 = rp->dp_max2 > sc ? rp->dp_max2 : sc;
+					if (rp->dp_max - ri->dp_max <= sub_diff) cnt_sub = 1;
+				}
+				if (cnt_sub) ++rp->n_sub;
 				break;
 			}
 		}
@@ -705,7 +740,7 @@ set_parent_test:
 
 /* keep primaries and the best secondaries (A.6).  The in-place compaction reads r[p]
  * AFTER earlier slots may have been overwritten, exactly as upstream does. */
-static void select_sub(float pri_ratio, int min_diff, int best_n, int *n_, orc_reg_t *r)
+void orc_select_sub(float pri_ratio, int min_diff, int best_n, int *n_, orc_reg_t *r)
 {
 	if (pri_ratio > 0.0f && *n_ > 0) {
 		int i, k, n = *n_, n_2nd = 0;
@@ -718,12 +753,12 @@ static void select_sub(float pri_ratio, int min_diff, int best_n, int *n_, orc_r
 					r[k++] = r[i], ++n_2nd;
 			}
 		}
-		if (k != n) sync_regs(k, r);
+		if (k != n) orc_sync_regs(k, r);
 		*n_ = k;
 	}
 }
 
-static void squeeze_a(int n_regs, orc_reg_t *regs, orc128_t *a)
+int orc_squeeze_a(int n_regs, orc_reg_t *regs, orc128_t *a)
 {
 	int i, as = 0;
 	uint64_t *aux = (uint64_t*)malloc((size_t)(n_regs ? n_regs : 1) * 8);
@@ -738,13 +773,22 @@ static void squeeze_a(int n_regs, orc_reg_t *regs, orc128_t *a)
 		as += r->cnt;
 	}
 	free(aux);
+	return as;
 }
 
-static void filter_regs(const orc_opt_t *opt, int *n_regs, orc_reg_t *regs)
+void orc_filter_regs(const orc_opt_t *opt, int qlen, int *n_regs, orc_reg_t *regs)
 {
 	int i, k;
 	for (i = k = 0; i < *n_regs; ++i) {
-		if (regs[i].cnt < opt->min_cnt) continue;
+		const orc_reg_t *r = &regs[i];
+		int flt = 0;
+		if (r->cnt < opt->min_cnt) flt = 1;
+		if (r->flags & ORC_REG_HAS_DP) {                    /* only with a base-level alignment */
+			if (r->mlen < opt->min_chain_score) flt = 1;
+			else if (r->dp_max < opt->min_dp_max) flt = 1;
+			else if (r->qs > qlen * opt->max_clip_ratio && qlen - r->qe > qlen * opt->max_clip_ratio) flt = 1;
+		}
+		if (flt) continue;
 		if (k < i) regs[k++] = regs[i]; else ++k;
 	}
 	*n_regs = k;
@@ -756,7 +800,7 @@ static void join_long(const orc_opt_t *opt, int qlen, int *n_regs_, orc_reg_t *r
 	int i, n_aux, n_regs = *n_regs_, n_drop = 0;
 	uint64_t *aux;
 	if (n_regs < 2) return;
-	squeeze_a(n_regs, regs, a);
+	orc_squeeze_a(n_regs, regs, a);
 	aux = (uint64_t*)malloc((size_t)n_regs * 8);
 	for (i = n_aux = 0; i < n_regs; ++i)
 		if (regs[i].parent == i || regs[i].parent < 0)
@@ -784,7 +828,7 @@ static void join_long(const orc_opt_t *opt, int qlen, int *n_regs_, orc_reg_t *r
 		if (r1->re - r1->rs < min_flank_len || r1->qe - r1->qs < min_flank_len) continue;
 		a[r1->as].y |= SEED_LONG_JOIN;
 		r0->cnt += r1->cnt, r0->score += r1->score;
-		reg_set_coor(r0, qlen, a);
+		orc_reg_set_coor(r0, qlen, a);
 		r1->cnt = 0;
 		r1->parent = r0->id;
 		++n_drop;
@@ -797,14 +841,14 @@ static void join_long(const orc_opt_t *opt, int qlen, int *n_regs_, orc_reg_t *r
 				if (regs[r->parent].parent >= 0 && regs[r->parent].parent != r->parent)
 					r->parent = regs[r->parent].parent;
 		}
-		filter_regs(opt, n_regs_, regs);
-		sync_regs(*n_regs_, regs);
+		orc_filter_regs(opt, qlen, n_regs_, regs);
+		orc_sync_regs(*n_regs_, regs);
 	}
 }
 
-/* ------------------------------------------------------------------ MAPQ (A.7, no-DP branch) */
+/* ------------------------------------------------------------------ MAPQ (A.7) */
 
-static void set_mapq(int n_regs, orc_reg_t *regs, int min_chain_sc, int rep_len)
+static void set_mapq(int n_regs, orc_reg_t *regs, int min_chain_sc, int match_sc, int rep_len)
 {
 	static const float q_coef = 40.0f;
 	int64_t sum_sc = 0;
@@ -817,26 +861,57 @@ static void set_mapq(int n_regs, orc_reg_t *regs, int min_chain_sc, int rep_len)
 	for (i = 0; i < n_regs; ++i) {
 		orc_reg_t *r = &regs[i];
 		if (r->parent == r->id) {
+			const int has_dp = r->flags & ORC_REG_HAS_DP;
 			int mapq, subsc;
 			float pen_s1 = (r->score > 100 ? 1.0f : 0.01f * r->score) * uniq_ratio;
 			float pen_cm = r->cnt > 10 ? 1.0f : 0.1f * r->cnt;
-			float x;
 			pen_cm = pen_s1 < pen_cm ? pen_s1 : pen_cm;
 			subsc = r->subsc > min_chain_sc ? r->subsc : min_chain_sc;
-			x = (float)subsc / r->score0;
-			mapq = (int)(pen_cm * q_coef * (1.0f - x) * logf(r->score));
+			if (has_dp && r->dp_max2 > 0 && r->dp_max > 0) {
+				float identity = (float)r->mlen / r->blen;
+				float x = (float)r->dp_max2 * subsc / r->dp_max / r->score0;
+				int mapq_alt;
+				mapq = (int)(identity * pen_cm * q_coef * (1.0f - x * x) * logf((float)r->dp_max / match_sc));
+				mapq_alt = (int)(6.02f * identity * identity * (r->dp_max - r->dp_max2) / match_sc + .499f);
+				mapq = mapq < mapq_alt ? mapq : mapq_alt;
+			} else {
+				float x = (float)subsc / r->score0;
+				if (has_dp) {
+					float identity = (float)r->mlen / r->blen;
+					mapq = (int)(identity * pen_cm * q_coef * (1.0f - x) * logf((float)r->dp_max / match_sc));
+				} else {
+					mapq = (int)(pen_cm * q_coef * (1.0f - x) * logf(r->score));
+				}
+			}
 			mapq -= (int)(4.343f * logf(r->n_sub + 1) + .499f);
 			mapq = mapq > 0 ? mapq : 0;
 			r->mapq = mapq < 60 ? mapq : 60;
+			if (has_dp && r->dp_max > r->dp_max2 && r->mapq == 0) r->mapq = 1;
 		} else r->mapq = 0;
 	}
 }
 
 /* ------------------------------------------------------------------ one read (aligner.py:193,215) */
 
+static int map_core(const orc_index *mi, const orc_opt_t *opt, int mid_occ, const char *seq, int qlen,
+                    orc_reg_t *regs_out, int cap, uint32_t *cig_out, int cig_cap, int *cig_total);
+
 int orc_map(const orc_index *mi, const orc_opt_t *opt, int mid_occ, const char *seq, int qlen,
             orc_reg_t *regs_out, int cap)
 {
+	return map_core(mi, opt, mid_occ, seq, qlen, regs_out, cap, 0, 0, 0);
+}
+
+int orc_map_cigar(const orc_index *mi, const orc_opt_t *opt, int mid_occ, const char *seq, int qlen,
+                  orc_reg_t *regs_out, int cap, uint32_t *cig_out, int cig_cap, int *cig_total)
+{
+	return map_core(mi, opt, mid_occ, seq, qlen, regs_out, cap, cig_out, cig_cap, cig_total);
+}
+
+static int map_core(const orc_index *mi, const orc_opt_t *opt, int mid_occ, const char *seq, int qlen,
+                    orc_reg_t *regs_out, int cap, uint32_t *cig_out, int cig_cap, int *cig_total)
+{
+	uint32_t **cigs = 0;
 	orc128_t *a;
 	uint64_t *u = 0;
 	int rep_len = 0, n_u = 0, n_regs, i;
@@ -854,11 +929,23 @@ int orc_map(const orc_index *mi, const orc_opt_t *opt, int mid_occ, const char *
 	if (a == 0 || n_u == 0) { free(a), free(u); return 0; }
 	regs = gen_regs(hash, qlen, n_u, u, a);
 	n_regs = n_u;
-	set_parent(opt->mask_level, n_regs, regs);
-	select_sub(opt->pri_ratio, mi->k * 2, opt->best_n, &n_regs, regs);
+	orc_set_parent(opt->mask_level, n_regs, regs, opt->a * 2 + opt->b);
+	orc_select_sub(opt->pri_ratio, mi->k * 2, opt->best_n, &n_regs, regs);
 	join_long(opt, qlen, &n_regs, regs, a);
-	set_mapq(n_regs, regs, opt->min_chain_score, rep_len);
+	if (opt->cigar)                                         /* mappy: MM_F_CIGAR is always set */
+		regs = orc_align_regs(mi, opt, qlen, seq, &n_regs, regs, a, cig_total ? &cigs : 0);
+	set_mapq(n_regs, regs, opt->min_chain_score, opt->a, rep_len);
 	for (i = 0; i < n_regs && i < cap; ++i) regs_out[i] = regs[i];
+	if (cig_total) {
+		int tot = 0, k;
+		for (i = 0; i < n_regs; ++i) {
+			for (k = 0; k < regs[i].n_cigar; ++k, ++tot)
+				if (cigs && tot < cig_cap) cig_out[tot] = cigs[i][k];
+			if (cigs) free(cigs[i]);
+		}
+		free(cigs);
+		*cig_total = tot;
+	}
 	free(regs), free(a), free(u);
 	return n_regs;
 }

@@ -33,7 +33,8 @@ extern "C" {
 
 typedef struct { uint64_t x, y; } orc128_t;
 
-/* one mapping region (subset of minimap2's mm_reg1_t that survives without DP) */
+/* one mapping region (minimap2's mm_reg1_t plus the fields of its mm_extra_t that the
+ * pipeline reads; the base-level fields stay 0 when base-level alignment is off) */
 typedef struct {
 	int32_t id, parent;      /* is_primary <=> id == parent (Appendix A.8)          */
 	int32_t rid;             /* contig index                                          */
@@ -44,9 +45,18 @@ typedef struct {
 	int32_t as;              /* offset of first anchor in the chained anchor array    */
 	int32_t mlen, blen;      /* chain-level match / block length (A.6)                */
 	int32_t subsc, n_sub;    /* best secondary score, number of sub-optimal hits      */
-	int32_t mapq;            /* chain-level MAPQ (A.7, "without DP" branch)           */
+	int32_t mapq;            /* MAPQ (A.7)                                            */
 	uint32_t hash;           /* tie-break hash used in the region sort (A.6)          */
+	/* ---- base-level alignment (A.6b) */
+	int32_t dp_score, dp_max, dp_max2;
+	int32_t n_ambi;          /* NM = blen - mlen + n_ambi (A.8)                       */
+	int32_t n_cigar;
+	int32_t flags;           /* ORC_REG_* bits                                        */
 } orc_reg_t;
+#define ORC_REG_HAS_DP     1   /* a CIGAR exists (r->p != 0)                  */
+#define ORC_REG_SPLIT_L    2   /* mm_reg1_t::split & 1                         */
+#define ORC_REG_SPLIT_R    4   /* mm_reg1_t::split & 2                         */
+#define ORC_REG_SPLIT_INV  8   /* mm_reg1_t::split_inv                         */
 
 typedef struct orc_index orc_index;
 
@@ -68,7 +78,17 @@ typedef struct {
 	int max_join_short;      /* 2000 */
 	int min_join_flank_sc;   /* 1000 */
 	float min_join_flank_ratio; /* 0.5f */
-	int a, b;                /* 2, 4 (only a*2+b is passed around; unused without DP) */
+	int a, b;                /* 2, 4 */
+	/* ---- base-level alignment (mappy always sets MM_F_CIGAR; A.1) */
+	int cigar;               /* 1: run it (what mappy does); 0: chain-level contract   */
+	int q, e, q2, e2;        /* 4, 2, 24, 1 */
+	int sc_ambi;             /* 1 */
+	int zdrop, zdrop_inv;    /* 400, 200 */
+	int end_bonus;           /* -1 */
+	int min_dp_max;          /* min_chain_score * a = 80 */
+	int min_ksw_len;         /* 200 */
+	float max_clip_ratio;    /* 1.0f */
+	int64_t max_sw_mat;      /* 100000000 */
 } orc_opt_t;
 
 void orc_opt_init(orc_opt_t *o);
@@ -106,10 +126,51 @@ int64_t orc_collect_seeds(const orc_index *mi, const orc_opt_t *opt, int mid_occ
 orc128_t *orc_chain_dp(const orc_opt_t *opt, int64_t n, orc128_t *a, int *n_u, uint64_t **u_out,
                        int32_t *f_out, int32_t *p_out, int32_t *v_out);
 
+/* ---- A.6b base-level alignment: ksw2's two-piece affine kernel ---- */
+#define ORC_EZ_SCORE_ONLY  0x01
+#define ORC_EZ_RIGHT       0x02   /* right-align gaps */
+#define ORC_EZ_GENERIC_SC  0x04
+#define ORC_EZ_APPROX_MAX  0x08
+#define ORC_EZ_APPROX_DROP 0x10
+#define ORC_EZ_EXTZ_ONLY   0x40   /* extension: stop at the maximum or the query end */
+#define ORC_EZ_REV_CIGAR   0x80
+typedef struct {
+	uint32_t max;
+	int zdropped;
+	int max_q, max_t;        /* cell of the maximum */
+	int mqe, mqe_t;          /* best score reaching the end of the query */
+	int mte, mte_q;          /* best score reaching the end of the target */
+	int score;               /* global alignment score */
+	int m_cigar, n_cigar;
+	int reach_end;
+	uint32_t *cigar;         /* len<<4 | op, op 0 M, 1 I, 2 D */
+} orc_extz_t;
+void orc_extz_reset(orc_extz_t *ez);
+void orc_gen_simple_mat(int m, int8_t *mat, int8_t a, int8_t b, int8_t sc_ambi);
+/* literal simulation of ksw_extd2_sse (see mm_ksw.c); sequences are codes 0..4 */
+void orc_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                   int8_t q, int8_t e, int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, orc_extz_t *ez);
+/* the same recurrence in absolute scores over the unbanded matrix (cross-check) */
+void orc_dp_clean(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat,
+                  int q, int e, int q2, int e2, int zdrop, int end_bonus, int flag, orc_extz_t *ez);
+int orc_local_score(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int q, int e);
+
+/* base-level alignment of all regions of one read (mm_align_skeleton + the second hierarchy
+ * pass of align_regs); regs is realloc'd when a Z-drop splits a region.  a[] are the chained
+ * anchors; seq the read (ASCII). */
+orc_reg_t *orc_align_regs(const orc_index *mi, const orc_opt_t *opt, int qlen, const char *seq,
+                          int *n_regs, orc_reg_t *regs, orc128_t *a, uint32_t ***cigars_out);
+/* contig bases as codes 0..4 (mm_idx_getseq) */
+int orc_index_getseq(const orc_index *mi, uint32_t rid, uint32_t st, uint32_t en, uint8_t *seq);
+
 /* ---- full per-read map: returns number of regions (all kept regions, primary and
  * secondary), writes at most cap ---- */
 int orc_map(const orc_index *mi, const orc_opt_t *opt, int mid_occ, const char *seq, int qlen,
             orc_reg_t *regs, int cap);
+
+/* same, also returning the CIGARs of the regions back to back (regs[i].n_cigar words each) */
+int orc_map_cigar(const orc_index *mi, const orc_opt_t *opt, int mid_occ, const char *seq, int qlen,
+                  orc_reg_t *regs, int cap, uint32_t *cig_out, int cig_cap, int *cig_total);
 
 /* ---- monica layer (aligner.py:194-263, 328-339) ---- */
 /* per-read decision codes */

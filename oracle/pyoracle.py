@@ -26,14 +26,30 @@ class Opt(C.Structure):
                 ("mask_level", C.c_float), ("pri_ratio", C.c_float), ("best_n", C.c_int),
                 ("max_join_long", C.c_int), ("max_join_short", C.c_int),
                 ("min_join_flank_sc", C.c_int), ("min_join_flank_ratio", C.c_float),
-                ("a", C.c_int), ("b", C.c_int)]
+                ("a", C.c_int), ("b", C.c_int),
+                ("cigar", C.c_int), ("q", C.c_int), ("e", C.c_int), ("q2", C.c_int), ("e2", C.c_int),
+                ("sc_ambi", C.c_int), ("zdrop", C.c_int), ("zdrop_inv", C.c_int), ("end_bonus", C.c_int),
+                ("min_dp_max", C.c_int), ("min_ksw_len", C.c_int), ("max_clip_ratio", C.c_float),
+                ("max_sw_mat", C.c_int64)]
+
+
+class Extz(C.Structure):
+    _fields_ = [("max", C.c_uint32), ("zdropped", C.c_int), ("max_q", C.c_int), ("max_t", C.c_int),
+                ("mqe", C.c_int), ("mqe_t", C.c_int), ("mte", C.c_int), ("mte_q", C.c_int),
+                ("score", C.c_int), ("m_cigar", C.c_int), ("n_cigar", C.c_int), ("reach_end", C.c_int),
+                ("cigar", C.POINTER(C.c_uint32))]
+
+
+EZ_RIGHT, EZ_APPROX_MAX, EZ_EXTZ_ONLY, EZ_REV_CIGAR = 0x02, 0x08, 0x40, 0x80
 
 
 REG_DTYPE = np.dtype([("id", "<i4"), ("parent", "<i4"), ("rid", "<i4"), ("rev", "<i4"),
                       ("rs", "<i4"), ("re", "<i4"), ("qs", "<i4"), ("qe", "<i4"),
                       ("score", "<i4"), ("score0", "<i4"), ("cnt", "<i4"), ("as", "<i4"),
                       ("mlen", "<i4"), ("blen", "<i4"), ("subsc", "<i4"), ("n_sub", "<i4"),
-                      ("mapq", "<i4"), ("hash", "<u4")])
+                      ("mapq", "<i4"), ("hash", "<u4"),
+                      ("dp_score", "<i4"), ("dp_max", "<i4"), ("dp_max2", "<i4"), ("n_ambi", "<i4"),
+                      ("n_cigar", "<i4"), ("flags", "<i4")])
 HIT_DTYPE = np.dtype([("rid", "<i4"), ("mapq", "<i4"), ("nm", "<i4"), ("mlen", "<i4")])
 A128_DTYPE = np.dtype([("x", "<u8"), ("y", "<u8")])
 
@@ -89,10 +105,56 @@ def lib():
         L.orc_best_hit.argtypes = [vp, i32]
         L.orc_classify_batch.restype = i64
         L.orc_classify_batch.argtypes = [vp, C.POINTER(Opt), i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, i64]
+        i8p = C.c_void_p
+        L.orc_gen_simple_mat.argtypes = [i32, i8p, C.c_int8, C.c_int8, C.c_int8]
+        L.orc_ksw_extd2.argtypes = [i32, vp, i32, vp, C.c_int8, i8p, C.c_int8, C.c_int8, C.c_int8, C.c_int8,
+                                    i32, i32, i32, i32, C.POINTER(Extz)]
+        L.orc_dp_clean.argtypes = [i32, vp, i32, vp, i8p, i32, i32, i32, i32, i32, i32, i32, C.POINTER(Extz)]
+        L.orc_local_score.restype = i32
+        L.orc_local_score.argtypes = [i32, vp, i32, vp, i8p, i32, i32]
+        L.orc_map_cigar.restype = i32
+        L.orc_map_cigar.argtypes = [vp, C.POINTER(Opt), i32, cp, i32, vp, i32, vp, i32, C.POINTER(i32)]
         L._libc = C.CDLL(None)
         L._libc.free.argtypes = [vp]
         _LIB = L
     return _LIB
+
+
+def simple_mat(a=2, b=4, sc_ambi=1):
+    mat = np.zeros(25, dtype=np.int8)
+    lib().orc_gen_simple_mat(5, mat.ctypes.data, a, b, sc_ambi)
+    return mat
+
+
+def _ez_result(ez):
+    cig = [(int(ez.cigar[i]) >> 4, "MID"[int(ez.cigar[i]) & 0xf]) for i in range(ez.n_cigar)]
+    out = dict(max=int(ez.max), zdropped=int(ez.zdropped), max_q=ez.max_q, max_t=ez.max_t, mqe=ez.mqe, mqe_t=ez.mqe_t,
+               mte=ez.mte, mte_q=ez.mte_q, score=ez.score, reach_end=ez.reach_end, cigar=cig)
+    if ez.cigar:
+        lib()._libc.free(C.cast(ez.cigar, C.c_void_p))
+    return out
+
+
+def ksw_extd2(query, target, w=751, zdrop=400, end_bonus=-1, flag=0, q=4, e=2, q2=24, e2=1, mat=None):
+    """The literal simulation of ksw2's kernel on code arrays (0..4)."""
+    mat = simple_mat() if mat is None else mat
+    qa = np.ascontiguousarray(query, dtype=np.uint8)
+    ta = np.ascontiguousarray(target, dtype=np.uint8)
+    ez = Extz()
+    lib().orc_ksw_extd2(len(qa), qa.ctypes.data, len(ta), ta.ctypes.data, 5, mat.ctypes.data, q, e, q2, e2,
+                        w, zdrop, end_bonus, flag, C.byref(ez))
+    return _ez_result(ez)
+
+
+def dp_clean(query, target, zdrop=400, end_bonus=-1, flag=0, q=4, e=2, q2=24, e2=1, mat=None):
+    """The same recurrence in absolute scores, unbanded."""
+    mat = simple_mat() if mat is None else mat
+    qa = np.ascontiguousarray(query, dtype=np.uint8)
+    ta = np.ascontiguousarray(target, dtype=np.uint8)
+    ez = Extz()
+    lib().orc_dp_clean(len(qa), qa.ctypes.data, len(ta), ta.ctypes.data, mat.ctypes.data, q, e, q2, e2,
+                       zdrop, end_bonus, flag, C.byref(ez))
+    return _ez_result(ez)
 
 
 def default_opt():
@@ -227,6 +289,25 @@ class Index:
             if n <= cap:
                 return out[:n].copy()
             cap = n
+
+    def map_cigar(self, seq):
+        """Regions of one read and their CIGARs [(len, op), ...] (base-level alignment on)."""
+        s = _b(seq)
+        cap, ccap = 64, 1 << 16
+        while True:
+            out = np.zeros(cap, dtype=REG_DTYPE)
+            cig = np.zeros(ccap, dtype=np.uint32)
+            tot = C.c_int(0)
+            n = lib().orc_map_cigar(self._h, C.byref(self.opt), self.mid_occ, s, len(s), out.ctypes.data, cap,
+                                    cig.ctypes.data, ccap, C.byref(tot))
+            if n <= cap and tot.value <= ccap:
+                break
+            cap, ccap = max(cap, n), max(ccap, tot.value)
+        regs, cigs, k = out[:n].copy(), [], 0
+        for r in regs:
+            cigs.append([(int(c) >> 4, "MID"[int(c) & 0xf]) for c in cig[k:k + r["n_cigar"]]])
+            k += r["n_cigar"]
+        return regs, cigs
 
     def classify(self, bases, offsets, min_mapq=60, n_threads=1):
         """bases: bytes/uint8 array of concatenated reads; offsets: int64[n+1]."""

@@ -30,6 +30,16 @@ def main():
     reads = [b[o[i]:o[i + 1]] for i in range(40)] + util.edge_reads_small(seqs, rng)
     bases, offsets = util.pack_reads(reads)
     oidx = pyoracle.Index.from_seqs(names, [s.tobytes() for s in seqs])
+    # ---- with base-level alignment (what mappy does): decisions, regions, CIGARs
+    dp_assign, dp_best, dp_nhits, dp_flat = oidx.classify(bases, offsets, 60)
+    dp_regs, dp_reg_cnt, dp_cig = [], [], []
+    for r in range(len(reads)):
+        g, cigs = oidx.map_cigar(bases[offsets[r]:offsets[r + 1]].tobytes())
+        dp_regs.append(g), dp_reg_cnt.append(len(g))
+        for c in cigs:
+            dp_cig.extend(l << 4 | "MID".index(op) for l, op in c)
+    # ---- chain level (base-level alignment off): every stage up to the chain-level regions
+    oidx.opt.cigar = 0
     assign, best, nhits, flat = oidx.classify(bases, offsets, 60)
     raw = bases.tobytes()
     mz_cnt, an_cnt, reg_cnt, regs, mz_first = [], [], [], [], []
@@ -52,9 +62,12 @@ def main():
         index_y_sum=np.uint64(int(iy.sum(dtype=np.uint64))), n_keys=np.int64(oidx.n_keys), n_occ=np.int64(oidx.n_minimizers),
         assign=assign, best=best, nhits=nhits, hits=flat,
         mz_cnt=np.array(mz_cnt), an_cnt=np.array(an_cnt), reg_cnt=np.array(reg_cnt), mz_first=np.array(mz_first, dtype=np.uint64),
+        dp_assign=dp_assign, dp_best=dp_best, dp_nhits=dp_nhits, dp_hits=dp_flat, dp_reg_cnt=np.array(dp_reg_cnt),
+        dp_regs=np.concatenate(dp_regs), dp_cigars=np.array(dp_cig, dtype=np.uint32),
         chain_f=np.concatenate(cf), chain_p=np.concatenate(cp), chain_v=np.concatenate(cv),
         regs=np.concatenate(regs) if regs else np.zeros(0, dtype=pyoracle.REG_DTYPE))
-    print("wrote small_case.npz:", len(reads), "reads,", int((assign >= 0).sum()), "classified")
+    print("wrote small_case.npz:", len(reads), "reads,", int((assign >= 0).sum()), "classified at the chain level,",
+          int((dp_assign >= 0).sum()), "with base-level alignment")
 
 
 if __name__ == "__main__":

@@ -242,14 +242,34 @@ def test_oracle_reproduces_golden_fixture(oracle):
     assert oidx.mid_occ == int(g["mid_occ"]) and oidx.n_keys == int(g["n_keys"]) and oidx.n_minimizers == int(g["n_occ"])
     ih, iy = oidx.dump()
     assert int(ih.sum(dtype=np.uint64)) == int(g["index_hash_sum"]) and int(iy.sum(dtype=np.uint64)) == int(g["index_y_sum"])
+    raw, offs = g["bases"].tobytes(), g["offsets"]
+    # ---- with base-level alignment (the default, as in mappy)
+    assign, best, nhits, flat = oidx.classify(g["bases"], g["offsets"], 60)
+    assert np.array_equal(assign, g["dp_assign"]) and np.array_equal(nhits, g["dp_nhits"])
+    for k in oracle.HIT_DTYPE.names:
+        assert np.array_equal(best[k], g["dp_best"][k]) and np.array_equal(flat[k], g["dp_hits"][k])
+    regs, cig, k, kc = g["dp_regs"], g["dp_cigars"], 0, 0
+    for r in range(len(offs) - 1):
+        got, cigs = oidx.map_cigar(raw[offs[r]:offs[r + 1]])
+        assert len(got) == g["dp_reg_cnt"][r]
+        for name in oracle.REG_DTYPE.names:
+            assert np.array_equal(got[name], regs[name][k:k + len(got)]), (r, name)
+        for c in cigs:
+            want = [(int(x) >> 4, "MID"[int(x) & 0xf]) for x in cig[kc:kc + len(c)]]
+            assert c == want, r
+            kc += len(c)
+        k += len(got)
+    assert kc == len(cig)
+    # ---- chain level
+    oidx.opt.cigar = 0
     assign, best, nhits, flat = oidx.classify(g["bases"], g["offsets"], 60)
     assert np.array_equal(assign, g["assign"]) and np.array_equal(nhits, g["nhits"])
     for k in oracle.HIT_DTYPE.names:
         assert np.array_equal(best[k], g["best"][k]) and np.array_equal(flat[k], g["hits"][k])
-    raw, offs, regs, k = g["bases"].tobytes(), g["offsets"], g["regs"], 0
+    regs, k = g["regs"], 0
     for r in range(len(offs) - 1):
         got = oidx.map(raw[offs[r]:offs[r + 1]])
         assert len(got) == g["reg_cnt"][r]
-        for name in oracle.REG_DTYPE.names:
+        for name in g["regs"].dtype.names:
             assert np.array_equal(got[name], regs[name][k:k + len(got)]), (r, name)
         k += len(got)
