@@ -51,7 +51,8 @@ typedef struct mnc_engine mnc_engine;
 typedef struct {
 	int32_t rid;    /* contig index; ctg = mnc_index_contig_name(rid) */
 	int32_t mapq;
-	int32_t nm;     /* NM := blen - mlen (chain-level contract) */
+	int32_t nm;     /* hit.NM = blen - mlen + n_ambi after base-level alignment (blen - mlen of the
+	                   chain under MNC_CONTRACT_CHAIN) */
 	int32_t mlen;
 } mnc_hit_t;
 
@@ -105,6 +106,15 @@ int  mnc_index_set_mid_occ(mnc_index *idx, int mid_occ);
  * created for an index on a device uploads the index tables to that device's HBM.
  */
 int  mnc_engine_create(mnc_index *idx, int device, mnc_engine **out);
+/* What index.map() computes before monica's gate (aligner.py:193-195, 215-217):
+ *   MNC_CONTRACT_DP     (default) minimap2's base-level alignment of every region, as mappy always
+ *                       runs it (MM_F_CIGAR): mapq from dp_max / dp_max2 and identity, NM and
+ *                       mlen from the CIGAR -- the values monica reads
+ *   MNC_CONTRACT_CHAIN  stop after chaining: chain-level MAPQ, NM := blen - mlen of the chain
+ *                       (the path BASELINE.json's north_star lists; ~10x faster, other numbers) */
+#define MNC_CONTRACT_DP    0
+#define MNC_CONTRACT_CHAIN 1
+int  mnc_engine_set_contract(mnc_engine *eng, int contract);
 void mnc_engine_destroy(mnc_engine *eng);
 void *mnc_engine_stream(mnc_engine *eng);                              /* hipStream_t */
 
@@ -162,7 +172,11 @@ int mnc_best_hit(const mnc_hit_t *hits, int n, int *best_index /* -1 = ambiguous
 #define MNC_STAGE_BACKTRACK   8   /* backtrack -> chain records                              */
 #define MNC_STAGE_REGIONS     9   /* regions, MAPQ, decision, counts                         */
 #define MNC_STAGE_GATHER      10  /* gated hit lists -> CSR (mnc_engine_fetch_hits)          */
-#define MNC_N_STAGES          11
+#define MNC_STAGE_DP_PLAN     11  /* chained anchors per region, DP windows, ksw2 segments   */
+#define MNC_STAGE_DP_ALIGN    12  /* ksw2-equivalent two-piece affine DP + backtrack         */
+#define MNC_STAGE_DP_STITCH   13  /* CIGAR merge / clean-up, mlen, blen, dp_max, Z-drop split */
+#define MNC_STAGE_DP_POST     14  /* second hierarchy pass, DP MAPQ, gate, decision          */
+#define MNC_N_STAGES          15
 int mnc_engine_set_profiling(mnc_engine *eng, int on);    /* HIP events around every stage */
 int mnc_engine_set_debug(mnc_engine *eng, int mode);      /* test switches, a bit mask: 2 stress build of the
                                                              chaining ring, 4 displacement bytes read from HBM */
@@ -185,10 +199,15 @@ int mnc_engine_get_counters(mnc_engine *eng, int64_t *c, int n);
 #define MNC_DUMP_REGS       8  /* mnc_reg_t per region                                          */
 #define MNC_DUMP_REG_OFFSETS 9 /* int64[n_reads+1]                                              */
 #define MNC_DUMP_REP_LEN    10 /* int32 per read                                                */
+#define MNC_DUMP_CIGARS     11 /* uint32 len<<4|op (0 M, 1 I, 2 D) of the dumped regions, back to back
+                                  (regs[i].n_cigar words each); MNC_CONTRACT_DP only              */
 typedef struct {
 	int32_t id, parent, rid, rev, rs, re, qs, qe, score, score0, cnt, as, mlen, blen,
 	        subsc, n_sub, mapq;
 	uint32_t hash;
+	/* base-level alignment (0 under MNC_CONTRACT_CHAIN): mm_extra_t's dp_score / dp_max / dp_max2 /
+	 * n_ambi / n_cigar; flags: 1 a CIGAR exists, 2 / 4 split left / right part, 8 split_inv */
+	int32_t dp_score, dp_max, dp_max2, n_ambi, n_cigar, flags;
 } mnc_reg_t;
 int mnc_engine_dump(mnc_engine *eng, int what, void *dst, int64_t cap_bytes, int64_t *n_bytes);
 

@@ -22,15 +22,19 @@ REG_DTYPE = np.dtype([("id", "<i4"), ("parent", "<i4"), ("rid", "<i4"), ("rev", 
                       ("rs", "<i4"), ("re", "<i4"), ("qs", "<i4"), ("qe", "<i4"),
                       ("score", "<i4"), ("score0", "<i4"), ("cnt", "<i4"), ("as", "<i4"),
                       ("mlen", "<i4"), ("blen", "<i4"), ("subsc", "<i4"), ("n_sub", "<i4"),
-                      ("mapq", "<i4"), ("hash", "<u4")])
+                      ("mapq", "<i4"), ("hash", "<u4"),
+                      ("dp_score", "<i4"), ("dp_max", "<i4"), ("dp_max2", "<i4"), ("n_ambi", "<i4"),
+                      ("n_cigar", "<i4"), ("flags", "<i4")])
 MZ_DTYPE = np.dtype([("hash", "<u4"), ("pos_strand", "<u4")])
 ANCHOR_DTYPE = np.dtype([("x", "<u8"), ("y", "<u8")])
 
-N_STAGES = 11
+N_STAGES = 15
 (STAGE_PACK, STAGE_SKETCH, STAGE_PARTITION, STAGE_PROBE, STAGE_COLLECT, STAGE_SORT, STAGE_SORT2, STAGE_CHAIN,
- STAGE_BACKTRACK, STAGE_REGIONS, STAGE_GATHER) = range(N_STAGES)
+ STAGE_BACKTRACK, STAGE_REGIONS, STAGE_GATHER, STAGE_DP_PLAN, STAGE_DP_ALIGN, STAGE_DP_STITCH,
+ STAGE_DP_POST) = range(N_STAGES)
 (DUMP_MINIMIZERS, DUMP_MZ_OFFSETS, DUMP_ANCHORS, DUMP_AN_OFFSETS, DUMP_CHAIN_F, DUMP_CHAIN_P,
- DUMP_CHAIN_V, DUMP_REGS, DUMP_REG_OFFSETS, DUMP_REP_LEN) = range(1, 11)
+ DUMP_CHAIN_V, DUMP_REGS, DUMP_REG_OFFSETS, DUMP_REP_LEN, DUMP_CIGARS) = range(1, 12)
+CONTRACT_DP, CONTRACT_CHAIN = 0, 1
 
 # every symbol include/monica_amd.h declares (checked by tests/test_capi.py)
 EXPORTS = [
@@ -41,7 +45,7 @@ EXPORTS = [
     "mnc_engine_create", "mnc_engine_destroy", "mnc_engine_stream",
     "mnc_classify_batch", "mnc_classify_device", "mnc_engine_sync", "mnc_engine_fetch_hits",
     "mnc_counts", "mnc_best_hit",
-    "mnc_engine_set_profiling", "mnc_engine_set_debug", "mnc_engine_get_timings", "mnc_stage_name", "mnc_stage_kernel",
+    "mnc_engine_set_profiling", "mnc_engine_set_debug", "mnc_engine_set_contract", "mnc_engine_get_timings", "mnc_stage_name", "mnc_stage_kernel",
     "mnc_engine_get_counters", "mnc_engine_dump",
     "mnc_fastq_open", "mnc_fastq_close", "mnc_fastq_next", "mnc_fastq_bases", "mnc_fastq_offsets",
     "mnc_fastq_quals", "mnc_fastq_title", "mnc_fastq_route",
@@ -120,6 +124,7 @@ def lib():
     sig("mnc_best_hit", i32, [vp, i32, C.POINTER(i32)])
     sig("mnc_engine_set_profiling", i32, [vp, i32])
     sig("mnc_engine_set_debug", i32, [vp, i32])
+    sig("mnc_engine_set_contract", i32, [vp, i32])
     sig("mnc_engine_get_timings", i32, [vp, vp, vp, i32])
     sig("mnc_stage_name", cp, [i32])
     sig("mnc_stage_kernel", cp, [i32])
@@ -316,6 +321,21 @@ class Engine:
 
     def set_profiling(self, on=True):
         check(lib().mnc_engine_set_profiling(self._h, 1 if on else 0))
+
+    def set_contract(self, contract):
+        """CONTRACT_DP (default): base-level alignment as mappy runs it; CONTRACT_CHAIN: stop after chaining."""
+        check(lib().mnc_engine_set_contract(self._h, int(contract)))
+
+    def cigars(self):
+        """CIGARs [(len, op), ...] of the regions of the last batch, in DUMP_REGS order."""
+        regs = self.dump(DUMP_REGS, REG_DTYPE)
+        words = self.dump(DUMP_CIGARS, np.uint32)
+        out, k = [], 0
+        for r in regs:
+            n = int(r["n_cigar"])
+            out.append([(int(c) >> 4, "MID"[int(c) & 0xf]) for c in words[k:k + n]])
+            k += n
+        return out
 
     def set_debug(self, mode=1):
         """mode 2 = stress build of the chaining kernel (every look-back through HBM)."""

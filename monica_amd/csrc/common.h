@@ -34,6 +34,12 @@ struct MapParams {
 	int max_join_short = 2000;
 	int min_join_flank_sc = 1000;
 	float min_join_flank_ratio = 0.5f;
+	// base-level alignment (mappy ORs MM_F_CIGAR in)
+	int a = 2, b = 4, q = 4, e = 2, q2 = 24, e2 = 1, sc_ambi = 1;
+	int zdrop = 400, zdrop_inv = 200, end_bonus = -1;
+	int min_dp_max = 80;              // min_chain_score * a
+	int min_ksw_len = 200;
+	long long max_sw_mat = 100000000;
 };
 
 // ---------------------------------------------------------------- HBM table

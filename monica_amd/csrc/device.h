@@ -82,7 +82,43 @@ struct ChainRec {
 	uint64_t x1, y1;   // last anchor
 	int32_t score, cnt;
 	int32_t mlen, blen;
-	int32_t as, pad;   // offset of the first anchor in the read's chained-anchor order
+	int32_t as, pad;   // as: read-local index of the chain's LAST anchor (p[] leads back from it); pad: rank
+};
+
+// ---------------------------------------------------------------- base-level alignment stage
+constexpr uint64_t SEED_LONG_JOIN = 1ULL << 40, SEED_IGNORE = 1ULL << 41, SEED_TANDEM = 1ULL << 42;
+constexpr int REG_HAS_DP = 1, REG_SPLIT_L = 2, REG_SPLIT_R = 4, REG_SPLIT_INV = 8;
+constexpr int EZ_RIGHT = 0x02, EZ_APPROX_MAX = 0x08, EZ_EXTZ_ONLY = 0x40, EZ_REV_CIGAR = 0x80;
+constexpr int DP_NEG_INF = -0x40000000;
+
+// one call of the two-piece affine kernel (ksw_extd2): left extension, a gap between two seeds,
+// right extension
+struct Seg {
+	int32_t read, reg;        // read ordinal; absolute region slot
+	int32_t kind;             // 0 left extension, 1 gap filling, 2 right extension
+	int32_t rid, rev;
+	int32_t ts, tlen;         // target interval [ts, ts + tlen) on the contig
+	int32_t qs, qlen;         // query interval on strand `rev` of the read
+	int32_t w, zdrop, flag;   // band, Z-drop, EZ_* flags
+	int32_t ai;               // gap filling: index (from as1) of the seed it ends at
+	int32_t big;              // direction bytes do not fit a normal workspace slot
+	// ---- results
+	int32_t n_cigar, zdropped, zdrop_code;
+	int32_t max, max_t, max_q, score, reach_end, mqe_t;
+	int64_t cig_off;          // first CIGAR word in the segment pool
+};
+
+// per region: what mm_align1 keeps between its steps
+struct RegDP {
+	int32_t read, order;      // order: position in the skeleton's region array (orig index << 8 | split depth)
+	int32_t first_seg, n_seg; // segments: [left], gap fills..., [right]
+	int32_t has_left, has_right;
+	int32_t as1, cnt1;        // after trimming bad ends
+	int32_t rs, qs, re, qe;   // first / last DP coordinate (seed mid-points)
+	int32_t rs0, qs0, re0, qe0;
+	int32_t n_cigar;          // region CIGAR (after the clean-up)
+	int32_t state;            // 0 unused, 1 planned this round, 2 done
+	int64_t cig_off;          // in the region pool
 };
 
 struct RegX { uint64_t x0, y0, x1, y1; };   // first / last anchor of a region
@@ -113,6 +149,7 @@ struct Batch {
 	float mask_level, pri_ratio, min_join_flank_ratio;
 	const int32_t *gap_lut;       // [GAP_LUT] (int)(dd*.01*avg_span) + (ilog2(dd)>>1), host-computed
 	const float *logf_lut;        // [logf_n] host libm logf(i)
+	const float *logf_a_lut;      // [logf_n] host libm logf((float)i / a): the DP branch of the MAPQ formula
 	int logf_n;
 	// ---- per base-slot arrays (capacity total_bases)
 	uint32_t *packed;             // 2-bit bases, 16 per word, first base in the top bits
@@ -153,6 +190,26 @@ struct Batch {
 	int64_t *counts;              // [n_genomes * 3] or null
 	int32_t *best_mlen;           // per read: mlen of the minimal gated hit (0 without one)
 	int64_t *stats;               // device counters (see mnc_engine_get_counters)
+	// ---- base-level alignment stage (contract MNC_CONTRACT_DP)
+	int contract;
+	const uint32_t *seq4;         // contig bases, 4 bits each
+	const int64_t *seq_off;       // [n_contigs + 1]
+	int sc_a, sc_b, gap_q, gap_e, gap_q2, gap_e2, sc_ambi, zdrop, zdrop_inv, end_bonus, min_dp_max, min_ksw_len;
+	long long max_sw_mat;
+	Anchor *ca;                   // chained anchors of the kept regions, squeezed, per read at an_off[r]
+	int32_t *ca_cnt;              // per read: anchors in ca
+	int32_t *chain_dst;           // per chain slot: first position in ca | LONG_JOIN bit 30, or -1
+	RegDP *regdp;                 // per region slot
+	Seg *segs;
+	int64_t seg_cap;
+	uint32_t *cig_seg, *cig_reg;  // CIGAR pools: per segment, per region
+	int64_t cig_seg_cap, cig_reg_cap;
+	unsigned long long *dp_ctr;   // [0] segments, [1] words in cig_seg, [2] words in cig_reg, [3] align queue,
+	                              // [4] overflow, [5] new regions this round, [6] big segments, [7] big queue
+	int32_t *work_list;           // region slots to plan / stitch this round
+	int32_t *next_list;           // region slots created by Z-drop splits (next round)
+	int32_t *big_list;            // segment indices for the large-workspace launch
+	int32_t *reg_cnt;             // per read: regions in the skeleton's array (kept + split tails)
 };
 
 // size classes of the row chaining kernel (anchors per LDS tile)

@@ -34,6 +34,22 @@ int chain_tail_prepare(size_t max_lds);
 // one, or with >= 65 536 bases, are sorted in HBM and take the sequential backtrack
 static const ChainClasses CHAIN_CLASSES = { 18, { 64, 128, 192, 256, 320, 384, 448, 512, 576, 640, 768, 896, 1024, 1280, 1536, 1792, 2048, 2560 } };
 void launch_regions(const Batch &B, void *regx, uint64_t *k64a, uint64_t *k64b, mnc_hit_t *gated, hipStream_t st);
+void launch_regions_post(const Batch &B, mnc_reg_t *work, void *regx, uint64_t *k64a, int32_t *tmp, mnc_hit_t *gated, hipStream_t st);
+// base-level alignment stage (k_align.hip)
+void launch_dp_gather(const Batch &B, hipStream_t st);
+void launch_dp_round(const Batch &B, int first, hipStream_t st);
+void launch_dp_round_end(const Batch &B, hipStream_t st);
+void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work, int state_max, long long p_max, int cig_max,
+                    long long big_state, long long big_p, long long big_cig, hipStream_t st);
+size_t dp_align_ws_bytes(long long state_max, long long p_max, long long cig_max);
+int dp_align_prepare(int lds_bytes);
+void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max, long long p_max, long long cig_max, int lds_bytes, int big_pass, hipStream_t st);
+void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_list, int n_wg, hipStream_t st);
+// workspace classes of the alignment kernel: a normal slot per workgroup, a few large ones
+constexpr int DP_LDS_BYTES = 16 * 1024;
+constexpr int DP_WG_SMALL = 2048, DP_WG_BIG = 8;
+constexpr long long DP_STATE_SMALL = 96 * 1024, DP_P_SMALL = 1 << 20, DP_CIG_SMALL = 4096;
+constexpr long long DP_STATE_BIG = 13 * 32768, DP_P_BIG = 256LL << 20, DP_CIG_BIG = 65536;
 void launch_gather_hits(const Batch &B, const mnc_hit_t *gated, const int64_t *hit_off, mnc_hit_t *out, hipStream_t st);
 
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
@@ -331,7 +347,7 @@ struct mnc_engine {
 	hipStream_t side[N_SIDE]{};
 	hipEvent_t ev_fork = nullptr, ev_join[N_SIDE]{};
 	// constant tables
-	Buf gap_lut, logf_lut;
+	Buf gap_lut, logf_lut, logf_a_lut;
 	int logf_n = 0;
 	// inputs / outputs for the host-buffer entry point
 	Buf in_bases, in_offsets, out_assign, out_best, out_nhits;
@@ -345,6 +361,10 @@ struct mnc_engine {
 	// per chain slot
 	Buf chains_tmp, regs, regx, k64a, k64b, tmp_i32, gated, hits_csr;
 	Buf stats, cls_count, cls_list;
+	// base-level alignment stage
+	int contract = MNC_CONTRACT_DP;
+	Buf ca, ca_cnt, chain_dst, regdp, segs, cig_seg, cig_reg, dp_ctr, work_a, work_b, big_list, reg_cnt, regs2, dp_ws, dp_ws_big;
+	size_t seg_cap_override = 0, cig_cap_override = 0;
 	int debug = 0;                           // bit mask (tests): 2 stress build of the chaining ring, 4 displacement bytes read from HBM
 	// last batch
 	Batch B{};
@@ -359,10 +379,12 @@ struct mnc_engine {
 	int64_t launches[MNC_N_STAGES]{};
 };
 
-static const char *STAGE_NAME[MNC_N_STAGES] = { "pack", "sketch", "partition", "probe", "collect", "offsets", "sort", "chain", "backtrack", "regions", "gather" };
+static const char *STAGE_NAME[MNC_N_STAGES] = { "pack", "sketch", "partition", "probe", "collect", "offsets", "sort", "chain", "backtrack", "regions", "gather",
+                                                "dp_plan", "dp_align", "dp_stitch", "dp_post" };
 static const char *STAGE_KERNEL[MNC_N_STAGES] = {
 	"mnc_pack_bases", "mnc_sketch_minimizers", "mnc_partition_queries", "mnc_probe_buckets", "mnc_collect_hits",
-	"mnc_bin_reads", "mnc_expand_sort", "mnc_chain_dp_ring", "mnc_chain_tail", "mnc_regions_decide", "mnc_gather_hits" };
+	"mnc_bin_reads", "mnc_expand_sort", "mnc_chain_dp_ring", "mnc_chain_tail", "mnc_regions_decide", "mnc_gather_hits",
+	"mnc_dp_plan", "mnc_dp_align", "mnc_dp_stitch", "mnc_regions_post" };
 
 extern "C" const char *mnc_stage_name(int s) { return s >= 0 && s < MNC_N_STAGES ? STAGE_NAME[s] : nullptr; }
 extern "C" const char *mnc_stage_kernel(int s) { return s >= 0 && s < MNC_N_STAGES ? STAGE_KERNEL[s] : nullptr; }
@@ -426,7 +448,8 @@ extern "C" void mnc_engine_destroy(mnc_engine *e)
 	if (!e) return;
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
-	Buf *all[] = { &e->gap_lut, &e->logf_lut, &e->in_bases, &e->in_offsets, &e->out_assign, &e->out_best, &e->out_nhits,
+	Buf *all[] = { &e->gap_lut, &e->logf_lut, &e->logf_a_lut, &e->ca, &e->ca_cnt, &e->chain_dst, &e->regdp, &e->segs, &e->cig_seg, &e->cig_reg, &e->dp_ctr,
+	               &e->work_a, &e->work_b, &e->big_list, &e->reg_cnt, &e->regs2, &e->dp_ws, &e->dp_ws_big, &e->in_bases, &e->in_offsets, &e->out_assign, &e->out_best, &e->out_nhits,
 	               &e->packed, &e->mz, &e->hits, &e->hist_tm, &e->q_off, &e->qrec, &e->bhits, &e->bhit_cnt, &e->ambig, &e->mz_cnt, &e->hit_cnt, &e->rep_len, &e->an_cnt, &e->an_off,
 	               &e->n_chain, &e->n_reg, &e->best_mlen, &e->hist_sums, &e->hist_offs, &e->scan_sums, &e->hit_off, &e->a, &e->f, &e->p, &e->v, &e->t, &e->u,
 	               &e->chains_tmp, &e->regs, &e->regx, &e->k64a, &e->k64b, &e->tmp_i32, &e->gated,
@@ -474,8 +497,14 @@ extern "C" int mnc_engine_create(mnc_index *idx, int device, mnc_engine **out)
 	e->logf_n = 1 << 21;
 	std::vector<float> lg((size_t)e->logf_n);
 	for (int i = 0; i < e->logf_n; ++i) lg[i] = logf((float)i);
+	// logf((float)dp_max / a) of the DP branch of the MAPQ formula (A.7), indexed by dp_max
+	std::vector<float> lga((size_t)e->logf_n);
+	for (int i = 0; i < e->logf_n; ++i) lga[i] = logf((float)i / idx->par.a);
 	rc = e->gap_lut.ensure(GAP_LUT * 4);
 	if (!rc) rc = e->logf_lut.ensure((size_t)e->logf_n * 4);
+	if (!rc) rc = e->logf_a_lut.ensure((size_t)e->logf_n * 4);
+	if (!rc) rc = e->dp_ctr.ensure(16 * 8);
+	if (!rc) rc = dp_align_prepare(DP_LDS_BYTES);
 	if (!rc) rc = e->stats.ensure(16 * 8);
 	if (!rc) rc = e->cls_count.ensure((MAX_CHAIN_CLASSES + 1) * 4 + 64);
 	if (!rc) rc = chain_tail_prepare(chain_tail_lds_bytes(CHAIN_CLASSES.nm[CHAIN_CLASSES.n - 1]));
@@ -483,6 +512,7 @@ extern "C" int mnc_engine_create(mnc_index *idx, int device, mnc_engine **out)
 	if (!rc) {
 		he = hipMemcpy(e->gap_lut.p, gap.data(), GAP_LUT * 4, hipMemcpyHostToDevice);
 		if (he == hipSuccess) he = hipMemcpy(e->logf_lut.p, lg.data(), (size_t)e->logf_n * 4, hipMemcpyHostToDevice);
+		if (he == hipSuccess) he = hipMemcpy(e->logf_a_lut.p, lga.data(), (size_t)e->logf_n * 4, hipMemcpyHostToDevice);
 		if (he == hipSuccess) he = hipMemset(e->stats.p, 0, 16 * 8);
 		if (he != hipSuccess) { set_error("table upload failed: %s", hipGetErrorString(he)); rc = MNC_ERR_HIP; }
 	}
@@ -513,6 +543,13 @@ extern "C" int mnc_engine_set_profiling(mnc_engine *e, int on)
 {
 	if (!e) return MNC_ERR_ARG;
 	e->profiling = on != 0;
+	return MNC_OK;
+}
+
+extern "C" int mnc_engine_set_contract(mnc_engine *e, int contract)
+{
+	if (!e || (contract != MNC_CONTRACT_DP && contract != MNC_CONTRACT_CHAIN)) return MNC_ERR_ARG;
+	e->contract = contract;
 	return MNC_OK;
 }
 
@@ -606,7 +643,11 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	B.max_iter = P.max_chain_iter, B.best_n = P.best_n, B.seed = P.seed, B.max_join_long = P.max_join_long;
 	B.max_join_short = P.max_join_short, B.min_join_flank_sc = P.min_join_flank_sc, B.mask_level = P.mask_level;
 	B.pri_ratio = P.pri_ratio, B.min_join_flank_ratio = P.min_join_flank_ratio;
-	B.gap_lut = e->gap_lut.as<int32_t>(), B.logf_lut = e->logf_lut.as<float>(), B.logf_n = e->logf_n;
+	B.gap_lut = e->gap_lut.as<int32_t>(), B.logf_lut = e->logf_lut.as<float>(), B.logf_a_lut = e->logf_a_lut.as<float>(), B.logf_n = e->logf_n;
+	B.contract = e->contract, B.seq4 = e->didx->seq4, B.seq_off = e->didx->seq_off;
+	B.sc_a = P.a, B.sc_b = P.b, B.gap_q = P.q, B.gap_e = P.e, B.gap_q2 = P.q2, B.gap_e2 = P.e2, B.sc_ambi = P.sc_ambi;
+	B.zdrop = P.zdrop, B.zdrop_inv = P.zdrop_inv, B.end_bonus = P.end_bonus, B.min_dp_max = P.min_dp_max, B.min_ksw_len = P.min_ksw_len;
+	B.max_sw_mat = P.max_sw_mat;
 	B.packed = e->packed.as<uint32_t>(), B.ambig = e->ambig.as<uint32_t>(), B.mz = e->mz.as<uint2>(), B.hits = e->hits.as<HitRec>();
 	B.mz_cnt = e->mz_cnt.as<int32_t>(), B.hit_cnt = e->hit_cnt.as<int32_t>(), B.rep_len = e->rep_len.as<int32_t>();
 	B.an_cnt = e->an_cnt.as<int64_t>(), B.an_off = e->an_off.as<int64_t>(), B.n_chain = e->n_chain.as<int32_t>(), B.n_reg = e->n_reg.as<int32_t>(), B.best_mlen = e->best_mlen.as<int32_t>();
@@ -744,7 +785,70 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 		launch_backtrack(B, lists + (size_t)CHAIN_CLASSES.n * n_reads, cls_count[CHAIN_CLASSES.n], e->side[k % mnc_engine::N_SIDE]);
 		if (int rc = join()) return rc;
 	}
-	{ StageTimer t(e, MNC_STAGE_REGIONS);   launch_regions(B, e->regx.p, e->k64a.as<uint64_t>(), e->k64b.as<uint64_t>(), e->gated.as<mnc_hit_t>(), st); }
+	if (e->contract == MNC_CONTRACT_DP) {
+		// ---- base-level alignment stage: buffers
+		size_t seg_cap = na / 2 + 1024, cig_cap = nb / 2 + (1u << 20);
+		if (e->seg_cap_override > seg_cap) seg_cap = e->seg_cap_override;
+		if (e->cig_cap_override > cig_cap) cig_cap = e->cig_cap_override;
+		int rc2 = MNC_OK;
+#define ENS2(buf, bytes) do { if (!rc2) rc2 = e->buf.ensure(bytes); } while (0)
+		ENS2(ca, na * sizeof(Anchor)); ENS2(ca_cnt, (nr + 1) * 4); ENS2(chain_dst, ns * 4); ENS2(regdp, ns * sizeof(RegDP));
+		ENS2(segs, seg_cap * sizeof(Seg)); ENS2(cig_seg, cig_cap * 4); ENS2(cig_reg, cig_cap * 4);
+		ENS2(work_a, ns * 4); ENS2(work_b, ns * 4); ENS2(big_list, seg_cap * 4); ENS2(reg_cnt, (nr + 1) * 4); ENS2(regs2, ns * sizeof(mnc_reg_t));
+		const size_t ws_small = dp_align_ws_bytes(DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL), ws_big = dp_align_ws_bytes(DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG);
+		ENS2(dp_ws, ws_small * DP_WG_SMALL); ENS2(dp_ws_big, ws_big * DP_WG_BIG);
+#undef ENS2
+		if (rc2) return rc2;
+		B.ca = e->ca.as<Anchor>(), B.ca_cnt = e->ca_cnt.as<int32_t>(), B.chain_dst = e->chain_dst.as<int32_t>(), B.regdp = e->regdp.as<RegDP>();
+		B.segs = e->segs.as<Seg>(), B.seg_cap = (int64_t)seg_cap, B.cig_seg = e->cig_seg.as<uint32_t>(), B.cig_reg = e->cig_reg.as<uint32_t>();
+		B.cig_seg_cap = B.cig_reg_cap = (int64_t)cig_cap, B.dp_ctr = e->dp_ctr.as<unsigned long long>();
+		B.big_list = e->big_list.as<int32_t>(), B.reg_cnt = e->reg_cnt.as<int32_t>();
+		int32_t *lists[2] = { e->work_a.as<int32_t>(), e->work_b.as<int32_t>() };
+		B.next_list = lists[0];                          // the regions kernel files every kept region here
+		HIP_TRY(hipMemsetAsync(e->dp_ctr.p, 0, 16 * 8, st));
+		{ StageTimer t(e, MNC_STAGE_REGIONS);   launch_regions(B, e->regx.p, e->k64a.as<uint64_t>(), e->k64b.as<uint64_t>(), e->gated.as<mnc_hit_t>(), st); }
+		{ StageTimer t(e, MNC_STAGE_DP_PLAN);   launch_dp_gather(B, st); }
+		unsigned max_work = (unsigned)ns;
+		for (int round = 0;; ++round) {
+			const int32_t *work = lists[round & 1];
+			int32_t *next = lists[(round + 1) & 1];
+			B.next_list = next;
+			launch_dp_round(B, round == 0, st);
+			if (round == 0) {
+				{ StageTimer t(e, MNC_STAGE_DP_PLAN);   launch_dp_plan(B, work, max_work, (int)DP_STATE_SMALL, DP_P_SMALL, (int)DP_CIG_SMALL, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, st); }
+				{
+					StageTimer t(e, MNC_STAGE_DP_ALIGN);
+					launch_dp_align(B, e->dp_ws.as<uint8_t>(), DP_WG_SMALL, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, st);
+					launch_dp_align(B, e->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 1, st);
+				}
+				{ StageTimer t(e, MNC_STAGE_DP_STITCH); launch_dp_stitch(B, work, next, 4096, st); }
+			} else {
+				launch_dp_plan(B, work, max_work, (int)DP_STATE_SMALL, DP_P_SMALL, (int)DP_CIG_SMALL, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, st);
+				launch_dp_align(B, e->dp_ws.as<uint8_t>(), DP_WG_SMALL, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, st);
+				launch_dp_align(B, e->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 1, st);
+				launch_dp_stitch(B, work, next, 4096, st);
+			}
+			launch_dp_round_end(B, st);
+			// Z-drop splits make new regions for the next round (rare); one small read-back per round
+			unsigned long long ctr[6] = {0};
+			HIP_TRY(hipMemcpyAsync(ctr, e->dp_ctr.p, sizeof(ctr), hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipStreamSynchronize(st));
+			if (ctr[4] != 0) {
+				if (ctr[4] >= 9) { set_error("a gap between two seeds is too large for the alignment workspace"); return MNC_ERR_UNSUPPORTED; }
+				e->seg_cap_override = na + 2 * ns + 1024;
+				e->cig_cap_override = cig_cap * 4;
+				*overflowed = true;
+				return MNC_OK;
+			}
+			if (ctr[5] == 0) break;
+			if (round > 256) { set_error("base-level alignment does not settle"); return MNC_ERR_HIP; }
+			max_work = (unsigned)ctr[5];
+		}
+		{ StageTimer t(e, MNC_STAGE_DP_POST); launch_regions_post(B, e->regs2.as<mnc_reg_t>(), e->regx.p, e->k64a.as<uint64_t>(), e->tmp_i32.as<int32_t>(), e->gated.as<mnc_hit_t>(), st); }
+	} else {
+		StageTimer t(e, MNC_STAGE_REGIONS);
+		launch_regions(B, e->regx.p, e->k64a.as<uint64_t>(), e->k64b.as<uint64_t>(), e->gated.as<mnc_hit_t>(), st);
+	}
 	HIP_TRY(hipGetLastError());
 	e->have_batch = true;
 	return MNC_OK;
@@ -942,6 +1046,26 @@ extern "C" int mnc_engine_dump(mnc_engine *e, int what, void *dst, int64_t cap_b
 		if (what == MNC_DUMP_REG_OFFSETS) return dump_offsets(c32, dst, cap_bytes, n_bytes);
 		for (size_t r = 0; r < nr; ++r) base[r] = an_off[r] / 3, cnt[r] = c32[r];
 		return dump_segments(B.regs, base, cnt, dst, cap_bytes, n_bytes);
+	}
+	case MNC_DUMP_CIGARS: {
+		if (B.contract != MNC_CONTRACT_DP) { set_error("CIGARs exist under MNC_CONTRACT_DP only"); return MNC_ERR_ARG; }
+		if (nr) HIP_TRY(hipMemcpy(c32.data(), B.n_reg, nr * 4, hipMemcpyDeviceToHost));
+		std::vector<uint32_t> out;
+		std::vector<RegDP> rd;
+		for (size_t r = 0; r < nr; ++r) {
+			if (c32[r] <= 0) continue;
+			rd.resize((size_t)c32[r]);
+			HIP_TRY(hipMemcpy(rd.data(), B.regdp + an_off[r] / 3, (size_t)c32[r] * sizeof(RegDP), hipMemcpyDeviceToHost));
+			for (int i = 0; i < c32[r]; ++i) {
+				const size_t o = out.size();
+				out.resize(o + (size_t)rd[i].n_cigar);
+				if (rd[i].n_cigar > 0) HIP_TRY(hipMemcpy(out.data() + o, B.cig_reg + rd[i].cig_off, (size_t)rd[i].n_cigar * 4, hipMemcpyDeviceToHost));
+			}
+		}
+		*n_bytes = (int64_t)out.size() * 4;
+		if (!dst || cap_bytes < *n_bytes) return MNC_ERR_RANGE;
+		if (!out.empty()) memcpy(dst, out.data(), out.size() * 4);
+		return MNC_OK;
 	}
 	case MNC_DUMP_REP_LEN:
 		*n_bytes = (int64_t)nr * 4;

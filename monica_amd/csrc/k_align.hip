@@ -1,0 +1,1061 @@
+// Stage kernels K8: base-level alignment of every region -- gfx950.
+//
+// Replaces mm_align_skeleton() / mm_align1() / ksw_extd2_sse() inside index.map(seq)
+// (monica/genomes/aligner.py:193, 215: mappy always sets MM_F_CIGAR), whose
+// results monica reads as hit.mapq / hit.NM / hit.mlen (aligner.py:194-195, 216-217).
+//
+//   mnc_dp_gather   thread / read: the anchors of the kept chains, squeezed together in `as` order
+//                   (mm_squeeze_a), LONG_JOIN flag on the first anchor of a fused chain
+//   mnc_dp_plan     thread / region: trim bad chain ends, flag seeds around long indels, DP window
+//                   from neighbouring seeds, the list of kernel calls ("segments": left extension,
+//                   one gap filling per >= min_ksw_len of seeds, right extension)
+//   mnc_dp_align    wave / segment from a work queue: ksw2's two-piece affine kernel in its
+//                   anti-diagonal difference form (u, v, x, y, x2, y2 as int8 in LDS, 64 cells per
+//                   step), the exact / approximate maximum, Z-drop, direction bytes to HBM, the
+//                   backtrack; gap fillings run minimap2's two passes (approximate first, exact
+//                   only when a walk over the CIGAR shows a large drop)
+//   mnc_dp_stitch   wave / region: CIGARs of the segments joined (a Z-drop ends the region and
+//                   its tail becomes a new region for the next round), indel left-alignment and
+//                   I/D merging (mm_fix_cigar), one walk giving mlen, blen, n_ambi, dp_max
+//                   (mm_update_extra)
+//
+// The kernel follows the SSE kernel's layout literally -- flat byte buffer, 16-lane rounding of
+// every anti-diagonal, in-place update, int8 wrap-around -- because at band edges ksw2 reads
+// cells outside the band whose contents only that layout defines; tests/ compare it with the
+// CPU oracle's simulation of the same layout, CIGAR for CIGAR.
+#include "device.h"
+
+namespace mnc {
+
+__device__ __forceinline__ void mem_order()
+{
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ int nt4_code(uint8_t c)
+{
+	switch (c) {
+	case 'A': case 'a': return 0;
+	case 'C': case 'c': return 1;
+	case 'G': case 'g': return 2;
+	case 'T': case 't': case 'U': case 'u': return 3;
+	default: return 4;
+	}
+}
+
+// base p of strand `rev` of a read (qseq0[rev][p] of mm_align_skeleton)
+__device__ __forceinline__ int qcode(const uint8_t *read, int qlen, int rev, int p)
+{
+	const int c = nt4_code(read[rev ? qlen - 1 - p : p]);
+	return rev ? (c < 4 ? 3 - c : 4) : c;
+}
+
+// base `pos` of contig `rid` (mm_idx_getseq)
+__device__ __forceinline__ int tcode(const Batch &B, int64_t contig_off, int pos)
+{
+	const int64_t o = contig_off + pos;
+	return (int)(B.seq4[o >> 3] >> ((o & 7) * 4) & 15u);
+}
+
+// ================================================================ gather: chained anchors, squeezed
+__global__ __launch_bounds__(64) void mnc_dp_gather(Batch B)
+{
+	const uint32_t rd = blockIdx.x * blockDim.x + threadIdx.x;
+	if (rd >= B.n_reads) return;
+	const int n = B.n_chain[rd];
+	if (n <= 0) return;
+	const int64_t a_off = B.an_off[rd], slot = a_off / 3;
+	const ChainRec *ch = B.chains_tmp + slot;
+	const Anchor *a = B.a + a_off;
+	const int32_t *p = B.p + a_off;
+	Anchor *ca = B.ca + a_off;
+	for (int c = 0; c < n; ++c) {
+		const int d = B.chain_dst[slot + c];
+		if (d < 0) continue;
+		const int dst = d & ((1 << 30) - 1), cnt = ch[c].cnt;
+		int j = ch[c].as;                                   // the chain's last anchor; p[] leads back
+		for (int k = cnt - 1; k >= 0; --k) {
+			Anchor x = a[j];
+			if (k == 0 && (d >> 30 & 1)) x.y |= SEED_LONG_JOIN;
+			ca[dst + k] = x;
+			j = p[j];
+		}
+	}
+}
+
+// ================================================================ plan: one region (mm_align1 up to the kernel calls)
+__device__ __forceinline__ int seed_gap(const Anchor *a, int i)
+{
+	return ((int32_t)a[i].y - (int32_t)a[i - 1].y) - ((int32_t)a[i].x - (int32_t)a[i - 1].x);
+}
+
+__device__ int collect_long_gaps(const Anchor *a, int cnt1, int min_gap, int32_t *K)
+{
+	int n = 0;
+	for (int i = 1; i < cnt1; ++i) {
+		const int gap = seed_gap(a, i);
+		if (gap < -min_gap || gap > min_gap) K[n++] = i;
+	}
+	return n <= 1 ? 0 : n;
+}
+
+__global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_list, int slot_state_max, long long slot_p_max, int slot_cig_max,
+                                                  long long big_state_max, long long big_p_max, long long big_cig_max)
+{
+	const unsigned long long n_work = B.dp_ctr[9];
+	const unsigned long long wi = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (wi >= n_work) return;
+	const int64_t rslot = work_list[wi];
+	mnc_reg_t r = B.regs[rslot];
+	RegDP d = B.regdp[rslot];
+	const uint32_t rd = (uint32_t)d.read;
+	const int64_t a_off = B.an_off[rd];
+	const int qlen = (int)(B.offsets[rd + 1] - B.offsets[rd]);
+	Anchor *a = B.ca + a_off;
+	const int n_a = B.ca_cnt[rd];
+	int32_t *K = B.t + a_off + r.as;                       // scratch: one int per anchor of the region
+	d.n_seg = 0, d.first_seg = 0, d.has_left = d.has_right = 0;
+	if (r.cnt == 0) { d.state = 2; B.regdp[rslot] = d; return; }
+	const int k2 = KMER >> 1;
+	const int rid = (int32_t)(a[r.as].x << 1 >> 33), rev = (int32_t)(a[r.as].x >> 63);
+	const int ref_len = (int)(B.seq_off[rid + 1] - B.seq_off[rid]);
+	const int bw = (int)(B.bw * 1.5 + 1.);
+	int as1 = r.as, cnt1 = r.cnt;
+
+	// ---- mm_fix_bad_ends
+	if (r.cnt >= 3) {
+		const int min_match = B.min_sc * 2;
+		int m, l;
+		m = l = (int)(a[r.as].y >> 32 & 0xff);
+		for (int i = r.as + 1; i < r.as + r.cnt - 1; ++i) {
+			const int q_span = (int)(a[i].y >> 32 & 0xff);
+			if (a[i].y & SEED_LONG_JOIN) break;
+			const int lr = (int32_t)a[i].x - (int32_t)a[i - 1].x, lq = (int32_t)a[i].y - (int32_t)a[i - 1].y;
+			const int mn = lr < lq ? lr : lq, mx = lr > lq ? lr : lq;
+			if (mx - mn > l >> 1) as1 = i;
+			l += mn;
+			m += mn < q_span ? mn : q_span;
+			if (l >= B.bw << 1 || (m >= min_match && m >= B.bw) || m >= r.mlen >> 1) break;
+		}
+		cnt1 = r.as + r.cnt - as1;
+		m = l = (int)(a[r.as + r.cnt - 1].y >> 32 & 0xff);
+		for (int i = r.as + r.cnt - 2; i > as1; --i) {
+			const int q_span = (int)(a[i + 1].y >> 32 & 0xff);
+			if (a[i + 1].y & SEED_LONG_JOIN) break;
+			const int lr = (int32_t)a[i + 1].x - (int32_t)a[i].x, lq = (int32_t)a[i + 1].y - (int32_t)a[i].y;
+			const int mn = lr < lq ? lr : lq, mx = lr > lq ? lr : lq;
+			if (mx - mn > l >> 1) cnt1 = i + 1 - as1;
+			l += mn;
+			m += mn < q_span ? mn : q_span;
+			if (l >= B.bw << 1 || (m >= min_match && m >= B.bw) || m >= r.mlen >> 1) break;
+		}
+	}
+	Anchor *b = a + as1;
+	// ---- mm_filter_bad_seeds(as1, cnt1, a, 10, 40, max_gap >> 1, 10)
+	{
+		const int n = collect_long_gaps(b, cnt1, 10, K);
+		if (n > 0) {
+			const int diff_thres = 40, max_ext_len = B.max_gap >> 1, max_ext_cnt = 10;
+			int mx = 0, max_st = -1, max_en = -1;
+			for (int k = 0;; ++k) {
+				int gap, l, n_ins = 0, n_del = 0, max_diff = 0, max_diff_l = -1;
+				if (k == n || k >= max_en) {
+					if (max_en > 0)
+						for (int i = K[max_st]; i < K[max_en]; ++i) b[i].y |= SEED_IGNORE;
+					mx = 0, max_st = max_en = -1;
+					if (k == n) break;
+				}
+				const int i = K[k];
+				gap = seed_gap(b, i);
+				if (gap > 0) n_ins += gap; else n_del += -gap;
+				const int qs_ = (int32_t)b[i - 1].y, rs_ = (int32_t)b[i - 1].x;
+				for (l = k + 1; l < n && l <= k + max_ext_cnt; ++l) {
+					const int j = K[l];
+					if ((int32_t)b[j].y - qs_ > max_ext_len || (int32_t)b[j].x - rs_ > max_ext_len) break;
+					gap = seed_gap(b, j);
+					if (gap > 0) n_ins += gap; else n_del += -gap;
+					const int diff = n_ins + n_del - abs(n_ins - n_del);
+					if (max_diff < diff) max_diff = diff, max_diff_l = l;
+				}
+				if (max_diff > diff_thres && max_diff > mx) mx = max_diff, max_st = k, max_en = max_diff_l;
+			}
+		}
+	}
+	// ---- mm_filter_bad_seeds_alt(as1, cnt1, a, 30, max_gap >> 1)
+	{
+		const int n = collect_long_gaps(b, cnt1, 30, K);
+		const int max_ext = B.max_gap >> 1;
+		for (int k = 0; k < n;) {
+			const int i = K[k];
+			int l, gap1 = seed_gap(b, i), re1 = (int32_t)b[i].x, qe1 = (int32_t)b[i].y;
+			gap1 = gap1 > 0 ? gap1 : -gap1;
+			for (l = k + 1; l < n; ++l) {
+				const int j = K[l];
+				if ((int32_t)b[j].y - qe1 > max_ext || (int32_t)b[j].x - re1 > max_ext) break;
+				int gap2 = seed_gap(b, j);
+				const int q_span_pre = (int)(b[j - 1].y >> 32 & 0xff);
+				const int rs2 = (int32_t)b[j - 1].x + q_span_pre, qs2 = (int32_t)b[j - 1].y + q_span_pre;
+				const int m = rs2 - re1 < qs2 - qe1 ? rs2 - re1 : qs2 - qe1;
+				gap2 = gap2 > 0 ? gap2 : -gap2;
+				if (m > gap1 + gap2) break;
+				re1 = (int32_t)b[j].x, qe1 = (int32_t)b[j].y, gap1 = gap2;
+			}
+			if (l > k + 1) {
+				const int end = K[l - 1];
+				for (int j = K[k]; j < end; ++j) b[j].y |= SEED_IGNORE;
+				b[end].y |= SEED_LONG_JOIN;
+			}
+			k = l;
+		}
+	}
+	// ---- DP window
+	int rs = (int32_t)b[0].x - k2, qs = (int32_t)b[0].y - k2;
+	int re = (int32_t)b[cnt1 - 1].x - k2, qe = (int32_t)b[cnt1 - 1].y - k2;
+	int rs0 = (int32_t)a[r.as].x + 1 - (int32_t)(a[r.as].y >> 32 & 0xff);
+	int qs0 = (int32_t)a[r.as].y + 1 - (int32_t)(a[r.as].y >> 32 & 0xff);
+	if (rs0 < 0) rs0 = 0;
+	int rs1 = 0, qs1 = 0, l;
+	for (int i = r.as - 1, c = 0; i >= 0 && a[i].x >> 32 == a[r.as].x >> 32; --i) {
+		const int x = (int32_t)a[i].x + 1 - (int32_t)(a[i].y >> 32 & 0xff);
+		const int y = (int32_t)a[i].y + 1 - (int32_t)(a[i].y >> 32 & 0xff);
+		if (x < rs0 && y < qs0) {
+			if (++c > B.min_cnt) {
+				l = rs0 - x > qs0 - y ? rs0 - x : qs0 - y;
+				rs1 = rs0 - l, qs1 = qs0 - l;
+				if (rs1 < 0) rs1 = 0;
+				break;
+			}
+		}
+	}
+	if (qs > 0 && rs > 0) {
+		l = qs < B.max_gap ? qs : B.max_gap;
+		qs1 = qs1 > qs - l ? qs1 : qs - l;
+		qs0 = qs0 < qs1 ? qs0 : qs1;
+		l += l * B.sc_a > B.gap_q ? (l * B.sc_a - B.gap_q) / B.gap_e : 0;
+		l = l < B.max_gap ? l : B.max_gap;
+		l = l < rs ? l : rs;
+		rs1 = rs1 > rs - l ? rs1 : rs - l;
+		rs0 = rs0 < rs1 ? rs0 : rs1;
+		rs0 = rs0 < rs ? rs0 : rs;
+	} else rs0 = rs, qs0 = qs;
+	int re0 = (int32_t)a[r.as + r.cnt - 1].x + 1, qe0 = (int32_t)a[r.as + r.cnt - 1].y + 1;
+	int re1 = ref_len, qe1 = qlen;
+	for (int i = r.as + r.cnt, c = 0; i < n_a && a[i].x >> 32 == a[r.as].x >> 32; ++i) {
+		const int x = (int32_t)a[i].x + 1 - (int32_t)(a[i].y >> 32 & 0xff);
+		const int y = (int32_t)a[i].y + 1 - (int32_t)(a[i].y >> 32 & 0xff);
+		if (x > re0 && y > qe0) {
+			if (++c > B.min_cnt) {
+				l = x - re0 > y - qe0 ? x - re0 : y - qe0;
+				re1 = re0 + l, qe1 = qe0 + l;
+				break;
+			}
+		}
+	}
+	if (qe < qlen && re < ref_len) {
+		l = qlen - qe < B.max_gap ? qlen - qe : B.max_gap;
+		qe1 = qe1 < qe + l ? qe1 : qe + l;
+		qe0 = qe0 > qe1 ? qe0 : qe1;
+		l += l * B.sc_a > B.gap_q ? (l * B.sc_a - B.gap_q) / B.gap_e : 0;
+		l = l < B.max_gap ? l : B.max_gap;
+		l = l < ref_len - re ? l : ref_len - re;
+		re1 = re1 < re + l ? re1 : re + l;
+		re0 = re0 > re1 ? re0 : re1;
+	} else re0 = re, qe0 = qe;
+	d.as1 = as1, d.cnt1 = cnt1, d.rs = rs, d.qs = qs, d.re = re, d.qe = qe;
+	d.rs0 = rs0, d.qs0 = qs0, d.re0 = re0, d.qe0 = qe0;
+
+	// ---- segments: count, allocate, fill
+	const bool left = qs > 0 && rs > 0;
+	int n_fill = 0;
+	{
+		int prs = rs, pqs = qs;
+		for (int i = 1; i < cnt1; ++i) {
+			if ((b[i].y & (SEED_IGNORE | SEED_TANDEM)) && i != cnt1 - 1) continue;
+			const int cre = (int32_t)b[i].x - k2, cqe = (int32_t)b[i].y - k2;
+			if (i == cnt1 - 1 || (b[i].y & SEED_LONG_JOIN) || (cqe - pqs >= B.min_ksw_len && cre - prs >= B.min_ksw_len)) ++n_fill, prs = cre, pqs = cqe;
+		}
+	}
+	// the last gap filling ends at the last seed: the right extension starts from (re, qe) above
+	const bool right = qe < qe0 && re < re0;
+	const int n_seg = (left ? 1 : 0) + n_fill + (right ? 1 : 0);
+	d.n_seg = n_seg, d.has_left = left, d.has_right = right, d.state = 1;
+	if (n_seg > 0) {
+		const unsigned long long s0 = atomicAdd(&B.dp_ctr[0], (unsigned long long)n_seg);
+		d.first_seg = (int32_t)s0;
+		if ((long long)(s0 + n_seg) > B.seg_cap) {
+			atomicMax(&B.dp_ctr[4], 1ULL);                          // overflow: the batch is redone with more room
+			d.n_seg = 0, d.has_left = d.has_right = 0;
+		} else {
+			Seg *sg = B.segs + s0;
+			auto emit = [&](Seg g) {
+				g.read = (int32_t)rd, g.reg = (int32_t)rslot, g.rid = rid, g.rev = rev;
+				g.n_cigar = 0, g.zdropped = 0, g.zdrop_code = 0, g.max = 0, g.max_t = g.max_q = -1, g.score = DP_NEG_INF, g.reach_end = 0, g.mqe_t = -1, g.cig_off = 0;
+				// workspace class
+				const long long T = (g.tlen + 15) / 16 * 16, Q = (g.qlen + 15) / 16 * 16 + 32;
+				long long nc = g.qlen < g.tlen ? g.qlen : g.tlen;
+				const int wb = g.w < 0 ? (g.tlen > g.qlen ? g.tlen : g.qlen) : g.w;
+				nc = ((nc < wb + 1 ? nc : wb + 1) + 15) / 16 + 1;
+				const long long p_bytes = ((long long)(g.qlen + g.tlen - 1) * nc + 1) * 16;
+				g.big = (12 * T + Q > slot_state_max || p_bytes > slot_p_max || g.qlen + g.tlen + 8 > slot_cig_max) ? 1 : 0;
+				if ((long long)g.tlen * g.qlen > B.max_sw_mat) g.big = 0;      // not aligned at all (ksw_reset_extz + zdropped)
+				else if (12 * T + Q > big_state_max || p_bytes > big_p_max || g.qlen + g.tlen + 8 > big_cig_max) {
+					g.big = 2;                                              // beyond even the large workspace: the batch fails
+					atomicMax(&B.dp_ctr[4], 9ULL);
+				}
+				if (g.big == 1) {
+					const unsigned long long bi = atomicAdd(&B.dp_ctr[6], 1ULL);
+					B.big_list[bi] = (int32_t)(sg - B.segs);
+				}
+				*sg++ = g;
+			};
+			if (left) {
+				Seg g;
+				g.kind = 0, g.ts = rs0, g.tlen = rs - rs0, g.qs = qs0, g.qlen = qs - qs0, g.w = bw;
+				g.zdrop = (r.flags & REG_SPLIT_INV) ? B.zdrop_inv : B.zdrop;
+				g.flag = EZ_EXTZ_ONLY | EZ_RIGHT | EZ_REV_CIGAR, g.ai = 0;
+				emit(g);
+			}
+			int prs = rs, pqs = qs;
+			for (int i = 1; i < cnt1; ++i) {
+				if ((b[i].y & (SEED_IGNORE | SEED_TANDEM)) && i != cnt1 - 1) continue;
+				const int cre = (int32_t)b[i].x - k2, cqe = (int32_t)b[i].y - k2;
+				if (i == cnt1 - 1 || (b[i].y & SEED_LONG_JOIN) || (cqe - pqs >= B.min_ksw_len && cre - prs >= B.min_ksw_len)) {
+					Seg g;
+					g.kind = 1, g.ts = prs, g.tlen = cre - prs, g.qs = pqs, g.qlen = cqe - pqs;
+					g.w = (b[i].y & SEED_LONG_JOIN) ? (cqe - pqs > cre - prs ? cqe - pqs : cre - prs) : bw;
+					g.zdrop = B.zdrop, g.flag = EZ_APPROX_MAX, g.ai = i;
+					emit(g);
+					prs = cre, pqs = cqe;
+				}
+			}
+			if (right) {
+				Seg g;
+				g.kind = 2, g.ts = re, g.tlen = re0 - re, g.qs = qe, g.qlen = qe0 - qe, g.w = bw;
+				g.zdrop = B.zdrop, g.flag = EZ_EXTZ_ONLY, g.ai = cnt1 - 1;
+				emit(g);
+			}
+		}
+	}
+	B.regdp[rslot] = d;
+}
+
+// ================================================================ align: ksw_extd2 on one wave
+struct Ez {
+	int32_t max, zdropped, max_q, max_t, mqe, mqe_t, score, reach_end, n_cigar;
+};
+
+__device__ __forceinline__ bool apply_zdrop(Ez &ez, int H, int r, int t, int zdrop, int e)
+{
+	if (H > ez.max) {
+		ez.max = H, ez.max_t = t, ez.max_q = r - t;
+	} else if (t >= ez.max_t && r - t >= ez.max_q) {
+		const int tl = t - ez.max_t, ql = (r - t) - ez.max_q;
+		const int l = tl > ql ? tl - ql : ql - tl;
+		if (zdrop >= 0 && ez.max - H > zdrop + l * e) { ez.zdropped = 1; return true; }
+	}
+	return false;
+}
+
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+	for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(v, d); v = v > o ? v : o; }
+	return v;
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+	for (int d = 32; d > 0; d >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)v, d); v = v < o ? v : o; }
+	return v;
+}
+
+#define I8(v) ((int)(int8_t)(v))
+
+// One call of the kernel on sequences already laid out in `mem` (sf = target codes, qr = the
+// query reversed), exactly as ksw_extd2_sse works on its buffer.  `cig` receives the CIGAR the
+// way ksw_backtrack pushes it (reversed unless EZ_REV_CIGAR asks for that order).
+__device__ void ksw_wave(int qlen, int tlen, int8_t *mem, int32_t *H, uint8_t *p, uint32_t *cig,
+                         int q, int e, int q2, int e2, int sc_mch, int sc_mis, int sc_N,
+                         int w, int zdrop, int end_bonus, int flag, Ez &ez)
+{
+	const int lane = threadIdx.x;
+	const bool approx_max = (flag & EZ_APPROX_MAX) != 0, right = (flag & EZ_RIGHT) != 0;
+	ez.max = 0, ez.zdropped = 0, ez.max_q = ez.max_t = ez.mqe_t = -1, ez.mqe = ez.score = DP_NEG_INF, ez.reach_end = 0, ez.n_cigar = 0;
+	const int qe = q + e;
+	if (w < 0) w = tlen > qlen ? tlen : qlen;
+	const int wl = w, wr = w;
+	const int tlen_ = (tlen + 15) / 16, qlen_ = (qlen + 15) / 16;
+	int n_col_ = qlen < tlen ? qlen : tlen;
+	n_col_ = ((n_col_ < w + 1 ? n_col_ : w + 1) + 15) / 16 + 1;
+	const int ncol = n_col_ * 16;
+	int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+	const int T = tlen_ * 16;
+	int8_t *u = mem, *v = u + T, *x = v + T, *y = x + T, *x2 = y + T, *y2 = x2 + T, *s = y2 + T;
+	uint8_t *sf = (uint8_t*)(s + T), *qr = sf + T;
+	(void)qlen_;
+	// u, v, x, y = -q - e ; x2, y2 = -q2 - e2 ; s = 0 ; H = -inf  (sf / qr were filled by the caller)
+	for (int i = lane; i < 4 * T; i += 64) u[i] = (int8_t)(-q - e);
+	for (int i = lane; i < 2 * T; i += 64) x2[i] = (int8_t)(-q2 - e2);
+	for (int i = lane; i < T; i += 64) s[i] = 0;
+	if (!approx_max) for (int i = lane; i < T; i += 64) H[i] = DP_NEG_INF;
+	mem_order();
+
+	int last_st = -1, last_en = -1, H0 = 0, last_H0_t = 0;
+	const int n_r = qlen + tlen - 1;
+	for (int r = 0; r < n_r; ++r) {
+		int st = 0, en = tlen - 1;
+		if (st < r - qlen + 1) st = r - qlen + 1;
+		if (en > r) en = r;
+		if (st < (r - wr + 1) >> 1) st = (r - wr + 1) >> 1;
+		if (en > (r + wl) >> 1) en = (r + wl) >> 1;
+		if (st > en) { ez.zdropped = 1; break; }
+		const int st0 = st, en0 = en;
+		st = st / 16 * 16, en = (en + 16) / 16 * 16 - 1;
+		int x1, x21, v1;
+		if (st > 0) {
+			if (st - 1 >= last_st && st - 1 <= last_en) x1 = x[st - 1], x21 = x2[st - 1], v1 = v[st - 1];
+			else x1 = -q - e, x21 = -q2 - e2, v1 = -q - e;
+		} else {
+			x1 = -q - e, x21 = -q2 - e2;
+			v1 = r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
+		}
+		mem_order();
+		if (en >= r && lane == 0) {
+			y[r] = (int8_t)(-q - e), y2[r] = (int8_t)(-q2 - e2);
+			u[r] = (int8_t)(r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2);
+		}
+		// scores: 16-lane strides from st0, all loads before all stores
+		{
+			const uint8_t *qrr = qr + (qlen - 1 - r);
+			const int n16 = (en0 - st0) / 16 + 1;
+			for (int c0 = 0; c0 < n16 * 16; c0 += 64) {
+				const int i = c0 + lane;
+				int sc = 0;
+				const bool act = i < n16 * 16;
+				if (act) {
+					const int sq = sf[st0 + i], sq2 = qrr[st0 + i];
+					sc = (sq == 4 || sq2 == 4) ? sc_N : sq == sq2 ? sc_mch : sc_mis;
+				}
+				mem_order();
+				if (act) s[st0 + i] = (int8_t)sc;
+			}
+		}
+		mem_order();
+		// core: chunks of 64 lanes from the top; a chunk reads [t-1] of the chunk below before that is updated
+		uint8_t *pr = p + (size_t)r * ncol;
+		for (int c0 = (en - st) / 64 * 64; c0 >= 0; c0 -= 64) {
+			const int t = st + c0 + lane;
+			const bool act = t <= en;
+			int z = 0, xt1 = 0, vt1 = 0, x2t1 = 0, ut = 0, yt = 0, y2t = 0;
+			if (act) {
+				z = s[t];
+				xt1 = t > st ? (int)x[t - 1] : x1;
+				vt1 = t > st ? (int)v[t - 1] : v1;
+				x2t1 = t > st ? (int)x2[t - 1] : x21;
+				ut = u[t], yt = y[t], y2t = y2[t];
+			}
+			mem_order();
+			if (act) {
+				int a = I8(xt1 + vt1), b = I8(yt + ut), a2 = I8(x2t1 + vt1), b2 = I8(y2t + ut), d, tmp;
+				if (!right) {
+					d = a > z ? 1 : 0;  z = z > a ? z : a;
+					d = b > z ? 2 : d;  z = z > b ? z : b;
+					d = a2 > z ? 3 : d; z = z > a2 ? z : a2;
+					d = b2 > z ? 4 : d; z = z > b2 ? z : b2;
+				} else {
+					d = z > a ? 0 : 1;  z = z > a ? z : a;
+					d = z > b ? d : 2;  z = z > b ? z : b;
+					d = z > a2 ? d : 3; z = z > a2 ? z : a2;
+					d = z > b2 ? d : 4; z = z > b2 ? z : b2;
+				}
+				z = z < sc_mch ? z : sc_mch;
+				u[t] = (int8_t)(z - vt1), v[t] = (int8_t)(z - ut);
+				tmp = I8(z - q), a = I8(a - tmp), b = I8(b - tmp);
+				tmp = I8(z - q2), a2 = I8(a2 - tmp), b2 = I8(b2 - tmp);
+				if (!right) {
+					x[t] = (int8_t)((a > 0 ? a : 0) - qe);          d |= a > 0 ? 0x08 : 0;
+					y[t] = (int8_t)((b > 0 ? b : 0) - qe);          d |= b > 0 ? 0x10 : 0;
+					x2[t] = (int8_t)((a2 > 0 ? a2 : 0) - (q2 + e2)); d |= a2 > 0 ? 0x20 : 0;
+					y2[t] = (int8_t)((b2 > 0 ? b2 : 0) - (q2 + e2)); d |= b2 > 0 ? 0x40 : 0;
+				} else {
+					x[t] = (int8_t)((0 > a ? 0 : a) - qe);          d |= 0 > a ? 0 : 0x08;
+					y[t] = (int8_t)((0 > b ? 0 : b) - qe);          d |= 0 > b ? 0 : 0x10;
+					x2[t] = (int8_t)((0 > a2 ? 0 : a2) - (q2 + e2)); d |= 0 > a2 ? 0 : 0x20;
+					y2[t] = (int8_t)((0 > b2 ? 0 : b2) - (q2 + e2)); d |= 0 > b2 ? 0 : 0x40;
+				}
+				pr[t - st] = (uint8_t)d;
+			}
+			mem_order();
+		}
+		if (!approx_max) {
+			int max_H, max_t;
+			if (r > 0) {
+				// H[en0] first (from the old H[en0-1]); then H[t] += v[t] for t in [st0, en0); the maximum in
+				// the SSE scan's tie order: en0, four interleaved lanes over [st0, en1), the tail [en1, en0)
+				const int en1 = st0 + (en0 - st0) / 4 * 4;
+				const int h_en0 = en0 > 0 ? H[en0 - 1] + (int)u[en0] : H[en0] + (int)v[en0];
+				mem_order();
+				int best_h = DP_NEG_INF - 1;
+				unsigned best_rank = 0xffffffffu;
+				for (int c0 = 0; c0 < en0 - st0; c0 += 64) {
+					const int t = st0 + c0 + lane;
+					if (t < en0) {
+						const int h = H[t] + (int)v[t];
+						H[t] = h;
+						const unsigned rank = t < en1 ? 1u + ((unsigned)(t - st0) & 3u) * 0x1000000u + ((unsigned)(t - st0) >> 2)
+						                              : 1u + 4u * 0x1000000u + (unsigned)(t - en1);
+						if (h > best_h || (h == best_h && rank < best_rank)) best_h = h, best_rank = rank;
+					}
+				}
+				if (lane == 0) {
+					H[en0] = h_en0;
+					if (h_en0 > best_h || (h_en0 == best_h)) best_h = h_en0, best_rank = 0;   // en0 comes first in the scan
+				}
+				const int mh = wave_max_i32(best_h);
+				const unsigned mr = wave_min_u32(best_h == mh ? best_rank : 0xffffffffu);
+				max_H = mh;
+				if (mr == 0) max_t = en0;
+				else if (mr < 1u + 4u * 0x1000000u) { const unsigned k = mr - 1u; max_t = st0 + (int)((k & 0xffffffu) * 4u + (k >> 24)); }
+				else max_t = en1 + (int)(mr - 1u - 4u * 0x1000000u);
+				mem_order();
+			} else {
+				if (lane == 0) H[0] = (int)v[0] - qe;
+				mem_order();
+				max_H = H[0], max_t = 0;
+			}
+			if (r - st0 == qlen - 1 && H[st0] > ez.mqe) ez.mqe = H[st0], ez.mqe_t = st0;
+			if (apply_zdrop(ez, max_H, r, max_t, zdrop, e2)) break;
+			if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = H[tlen - 1];
+		} else {
+			if (r > 0) {
+				if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
+					const int d0 = v[last_H0_t], d1 = u[last_H0_t + 1];
+					if (d0 > d1) H0 += d0;
+					else H0 += d1, ++last_H0_t;
+				} else if (last_H0_t >= st0 && last_H0_t <= en0) {
+					H0 += v[last_H0_t];
+				} else {
+					++last_H0_t, H0 += u[last_H0_t];
+				}
+			} else H0 = (int)v[0] - qe, last_H0_t = 0;
+			if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = H0;
+		}
+		last_st = st, last_en = en;
+	}
+	mem_order();
+	// ---- backtrack (ksw_backtrack, rotated layout): one lane walks, all lanes prefetch nothing yet
+	int i0 = -1, j0 = -1;
+	if (!ez.zdropped && !(flag & EZ_EXTZ_ONLY)) i0 = tlen - 1, j0 = qlen - 1;
+	else if (!ez.zdropped && (flag & EZ_EXTZ_ONLY) && ez.mqe + end_bonus > ez.max) ez.reach_end = 1, i0 = ez.mqe_t, j0 = qlen - 1;
+	else if (ez.max_t >= 0 && ez.max_q >= 0) i0 = ez.max_t, j0 = ez.max_q;
+	int n_cigar = 0;
+	if (i0 >= 0 && j0 >= 0 && lane == 0) {
+		int i = i0, j = j0, state = 0;
+		uint32_t cur = 0;                                     // op being grown: len << 4 | op, 0 = none
+		auto push = [&](uint32_t op, int len) {
+			if (cur != 0 && (cur & 0xf) == op) cur += (uint32_t)len << 4;
+			else { if (cur != 0) cig[n_cigar++] = cur; cur = (uint32_t)len << 4 | op; }
+		};
+		while (i >= 0 && j >= 0) {
+			const int r = i + j;
+			int st = 0, en = tlen - 1;
+			if (st < r - qlen + 1) st = r - qlen + 1;
+			if (en > r) en = r;
+			if (st < (r - wr + 1) >> 1) st = (r - wr + 1) >> 1;
+			if (en > (r + wl) >> 1) en = (r + wl) >> 1;
+			st = st / 16 * 16, en = (en + 16) / 16 * 16 - 1;    // off[r], off_end[r]
+			int force_state = -1;
+			if (i < st) force_state = 2;
+			if (i > en) force_state = 1;
+			const uint32_t tmp = force_state < 0 ? p[(size_t)r * ncol + (size_t)(i - st)] : 0;
+			if (state == 0) state = tmp & 7;
+			else if (!(tmp >> (state + 2) & 1)) state = 0;
+			if (state == 0) state = tmp & 7;
+			if (force_state >= 0) state = force_state;
+			if (state == 0) push(0, 1), --i, --j;
+			else if (state == 1 || state == 3) push(2, 1), --i;
+			else push(1, 1), --j;
+		}
+		if (i >= 0) push(2, i + 1);
+		if (j >= 0) push(1, j + 1);
+		if (cur != 0) cig[n_cigar++] = cur;
+		if (!(flag & EZ_REV_CIGAR))
+			for (int k = 0; k < n_cigar >> 1; ++k) { const uint32_t t2 = cig[k]; cig[k] = cig[n_cigar - 1 - k], cig[n_cigar - 1 - k] = t2; }
+	}
+	ez.n_cigar = __shfl(n_cigar, 0);
+	mem_order();
+}
+
+// mm_test_zdrop on a finished gap-filling CIGAR: 0 fine, 1 the score drops by more than zdrop, 2 and
+// the dropped stretch aligns to its own reverse complement.  One lane; sequences come from `mem`.
+__device__ int test_zdrop_lane0(const Batch &B, int qlen, int tlen, const uint8_t *sf, const uint8_t *qr, int n_cigar, const uint32_t *cig,
+                                int sc_mch, int sc_mis, int sc_N, int32_t *sw_H, int32_t *sw_E)
+{
+	int score = 0, mx = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0, max_zdrop = 0;
+	int pos00 = -1, pos01 = -1, pos10 = -1, pos11 = -1;
+	auto upd = [&](int sc, int ii, int jj) {
+		if (sc < mx) {
+			const int li = ii - max_i, lj = jj - max_j;
+			const int diff = li > lj ? li - lj : lj - li;
+			const int z = mx - sc - diff * B.gap_e;
+			if (z > max_zdrop) max_zdrop = z, pos00 = max_i, pos01 = ii + 1, pos10 = max_j, pos11 = jj + 1;
+		} else mx = sc, max_i = ii, max_j = jj;
+	};
+	for (int k = 0; k < n_cigar; ++k) {
+		const uint32_t op = cig[k] & 0xf, len = cig[k] >> 4;
+		if (op == 0) {
+			for (uint32_t l = 0; l < len; ++l) {
+				const int ct = sf[i + l], cq = qr[qlen - 1 - (j + (int)l)];
+				score += (ct == 4 || cq == 4) ? sc_N : ct == cq ? sc_mch : sc_mis;
+				upd(score, i + (int)l, j + (int)l);
+			}
+			i += len, j += len;
+		} else {
+			score -= B.gap_q + B.gap_e * (int)len;
+			if (op == 1) j += len; else i += len;
+			upd(score, i, j);
+		}
+	}
+	const int q_len = pos11 - pos10, t_len = pos01 - pos00;
+	if (max_zdrop > B.zdrop_inv && q_len < B.max_gap && t_len < B.max_gap) {
+		// ksw_ll_i16 of the reverse complement of the query stretch against the target stretch: the
+		// best local score with one affine gap cost (only the score matters here)
+		int best = 0;
+		for (int jj = 0; jj <= q_len; ++jj) sw_H[jj] = 0, sw_E[jj] = 0;
+		for (int ii = 0; ii < t_len; ++ii) {
+			int f = 0, diag = 0;
+			const int ct = sf[pos00 + ii];
+			for (int jj = 0; jj < q_len; ++jj) {
+				const int c0 = qr[qlen - 1 - (pos11 - jj - 1)];
+				const int cq = c0 >= 4 ? 4 : 3 - c0;
+				int h = diag + ((ct == 4 || cq == 4) ? sc_N : ct == cq ? sc_mch : sc_mis);
+				diag = sw_H[jj + 1];
+				h = h > sw_E[jj + 1] ? h : sw_E[jj + 1];
+				h = h > f ? h : f;
+				h = h > 0 ? h : 0;
+				sw_H[jj + 1] = h;
+				best = best > h ? best : h;
+				int t = h - (B.gap_q + B.gap_e);
+				t = t > 0 ? t : 0;
+				sw_E[jj + 1] = sw_E[jj + 1] - B.gap_e > t ? sw_E[jj + 1] - B.gap_e : t;
+				f = f - B.gap_e > t ? f - B.gap_e : t;
+			}
+		}
+		if (best > 32767) best = 32767;
+		if (best >= B.min_sc * B.sc_a && best >= B.min_dp_max) return 2;
+	}
+	return max_zdrop > B.zdrop ? 1 : 0;
+}
+
+// workspace of one workgroup: [state bytes | H | CIGAR scratch | local-SW rows | direction bytes]
+struct AlignWs { size_t state, h, cig, sw, p, total; };
+__host__ __device__ __forceinline__ AlignWs align_ws(long long state_max, long long p_max, long long cig_max)
+{
+	AlignWs w;
+	w.state = 0;
+	w.h = (size_t)(state_max + 255) / 256 * 256;
+	w.cig = w.h + (size_t)(state_max / 3 + 255) / 256 * 256;            // H: 4 T <= state / 3
+	w.sw = w.cig + (size_t)cig_max * 4;
+	w.p = w.sw + (size_t)cig_max * 8;
+	w.total = (w.p + (size_t)p_max + 4095) / 4096 * 4096;
+	return w;
+}
+
+__global__ __launch_bounds__(64) void mnc_dp_align(Batch B, uint8_t *ws_all, long long state_max, long long p_max, long long cig_max,
+                                                   int lds_bytes, int big_pass)
+{
+	extern __shared__ __align__(16) uint8_t smem[];
+	const int lane = threadIdx.x;
+	const AlignWs W = align_ws(state_max, p_max, cig_max);
+	uint8_t *ws = ws_all + (size_t)blockIdx.x * W.total;
+	const int sc_mch = B.sc_a, sc_mis = -B.sc_b, sc_N = -B.sc_ambi;
+	const unsigned long long n_seg = B.dp_ctr[0], n_big = B.dp_ctr[6];
+	for (;;) {
+		unsigned long long qi = 0;
+		if (lane == 0) qi = atomicAdd(&B.dp_ctr[big_pass ? 7 : 3], 1ULL);
+		qi = (unsigned long long)__shfl((long long)qi, 0);
+		if (qi >= (big_pass ? n_big : n_seg)) break;          // every wave reaches this: the queue is finite
+		const long long si = big_pass ? (long long)B.big_list[qi] : (long long)qi;
+		Seg g = B.segs[si];
+		if (!big_pass && g.big) continue;
+		Ez ez;
+		ez.max = 0, ez.zdropped = 0, ez.max_q = ez.max_t = ez.mqe_t = -1, ez.mqe = ez.score = DP_NEG_INF, ez.reach_end = 0, ez.n_cigar = 0;
+		int zdrop_code = 0;
+		uint32_t *cig = reinterpret_cast<uint32_t*>(ws + W.cig);
+		if (g.qlen <= 0 || g.tlen <= 0) {
+			// ksw_extd2 returns at once
+		} else if ((long long)g.tlen * g.qlen > B.max_sw_mat) {
+			ez.zdropped = 1;                                   // mm_align_pair: too large, treated as a Z-drop
+		} else {
+			const int T = (g.tlen + 15) / 16 * 16, Q = (g.qlen + 15) / 16 * 16 + 32;
+			const bool in_lds = 12 * T + Q <= lds_bytes;
+			int8_t *mem = in_lds ? reinterpret_cast<int8_t*>(smem) : reinterpret_cast<int8_t*>(ws + W.state);
+			int32_t *H = in_lds ? reinterpret_cast<int32_t*>(smem + (size_t)(8 * T + Q + 15) / 16 * 16) : reinterpret_cast<int32_t*>(ws + W.h);
+			uint8_t *sf = reinterpret_cast<uint8_t*>(mem) + 7 * (size_t)T, *qr = sf + T;
+			const uint8_t *read = B.bases + B.offsets[g.read];
+			const int rlen = (int)(B.offsets[g.read + 1] - B.offsets[g.read]);
+			const int64_t coff = B.seq_off[g.rid];
+			// target / reversed query; the left extension runs on both sequences reversed
+			for (int i = lane; i < T; i += 64) sf[i] = i < g.tlen ? (uint8_t)tcode(B, coff, g.kind == 0 ? g.ts + g.tlen - 1 - i : g.ts + i) : 0;
+			for (int i = lane; i < Q; i += 64) {
+				// qr[t] = query[qlen-1-t]; the left extension's query is itself the reverse of the read interval
+				qr[i] = i < g.qlen ? (uint8_t)qcode(read, rlen, g.rev, g.kind == 0 ? g.qs + i : g.qs + g.qlen - 1 - i) : 0;
+			}
+			mem_order();
+			ksw_wave(g.qlen, g.tlen, mem, H, ws + W.p, cig, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, sc_N,
+			         g.w, g.zdrop, g.kind == 1 ? -1 : B.end_bonus, g.flag, ez);
+			if (g.kind == 1) {
+				// the kernel's last 16-lane score store may spill into the first 15 target bytes (as in the
+				// SSE buffer, where those are dead by then): restore them for the walk and the second pass
+				if (lane < 16) sf[lane] = lane < g.tlen ? (uint8_t)tcode(B, coff, g.ts + lane) : 0;
+				mem_order();
+				if (lane == 0) zdrop_code = test_zdrop_lane0(B, g.qlen, g.tlen, sf, qr, ez.n_cigar, cig, sc_mch, sc_mis, sc_N,
+				                                              reinterpret_cast<int32_t*>(ws + W.sw), reinterpret_cast<int32_t*>(ws + W.sw) + cig_max);
+				zdrop_code = __shfl(zdrop_code, 0);
+				if (zdrop_code != 0)                             // second pass: exact maximum, real Z-drop
+					ksw_wave(g.qlen, g.tlen, mem, H, ws + W.p, cig, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, sc_N,
+					         g.w, zdrop_code == 2 ? B.zdrop_inv : B.zdrop, -1, 0, ez);
+			}
+		}
+		// results; the CIGAR goes to the segment pool
+		unsigned long long off = 0;
+		if (lane == 0 && ez.n_cigar > 0) off = atomicAdd(&B.dp_ctr[1], (unsigned long long)ez.n_cigar);
+		off = (unsigned long long)__shfl((long long)off, 0);
+		if (ez.n_cigar > 0) {
+			if ((long long)(off + ez.n_cigar) > B.cig_seg_cap) {
+				if (lane == 0) atomicMax(&B.dp_ctr[4], 2ULL);
+				ez.n_cigar = 0;
+			} else for (int k = lane; k < ez.n_cigar; k += 64) B.cig_seg[off + k] = cig[k];
+		}
+		if (lane == 0) {
+			Seg *o = B.segs + si;
+			o->n_cigar = ez.n_cigar, o->zdropped = ez.zdropped, o->zdrop_code = zdrop_code;
+			o->max = ez.max, o->max_t = ez.max_t, o->max_q = ez.max_q, o->score = ez.score, o->reach_end = ez.reach_end, o->mqe_t = ez.mqe_t;
+			o->cig_off = (int64_t)off;
+		}
+		mem_order();
+	}
+}
+
+// ================================================================ stitch: one region (the rest of mm_align1 + mm_update_extra)
+// LDS: the region's query and target codes (when they fit), the joined CIGAR is built in the
+// region pool.  One wave per region; lane 0 does the sequential bookkeeping, all lanes the walks.
+constexpr int ST_SEQ_MAX = 8 * 1024;                        // bytes of LDS per sequence
+constexpr int ST_CIG_MAX = 4096;                            // CIGAR words in LDS
+
+__device__ __forceinline__ void append_op(uint32_t *c, int &n, uint32_t word)
+{
+	if (n > 0 && (c[n - 1] & 0xf) == (word & 0xf)) c[n - 1] += word >> 4 << 4;
+	else c[n++] = word;
+}
+
+__global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work_list, int32_t *next_list)
+{
+	__shared__ uint8_t s_q[ST_SEQ_MAX], s_t[ST_SEQ_MAX];
+	__shared__ uint32_t s_c[ST_CIG_MAX];
+	const int lane = threadIdx.x;
+	const unsigned long long n_work = B.dp_ctr[9];
+	for (unsigned long long wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+		const int64_t rslot = work_list[wi];
+		mnc_reg_t r = B.regs[rslot];
+		RegDP d = B.regdp[rslot];
+		if (d.state != 1) continue;
+		const uint32_t rd = (uint32_t)d.read;
+		const int64_t a_off = B.an_off[rd];
+		const int qlen = (int)(B.offsets[rd + 1] - B.offsets[rd]);
+		const uint8_t *read = B.bases + B.offsets[rd];
+		const Anchor *a = B.ca + a_off;
+		const int rid = (int32_t)(a[r.as].x << 1 >> 33), rev = (int32_t)(a[r.as].x >> 63);
+		const int64_t coff = B.seq_off[rid];
+		const Seg *sg = B.segs + d.first_seg;
+		// ---- how many CIGAR words can the region need: all its segments', joined
+		long long total = 0;
+		for (int k = 0; k < d.n_seg; ++k) total += sg[k].n_cigar;
+		unsigned long long off = 0;
+		if (lane == 0 && total > 0) off = atomicAdd(&B.dp_ctr[2], (unsigned long long)total);
+		off = (unsigned long long)__shfl((long long)off, 0);
+		if ((long long)(off + total) > B.cig_reg_cap) {
+			if (lane == 0) atomicMax(&B.dp_ctr[4], 3ULL);
+			total = 0;
+			continue;
+		}
+		// the joined CIGAR is built in LDS when it fits, else in place in the pool
+		uint32_t *C = total <= ST_CIG_MAX ? s_c : B.cig_reg + off;
+		int n_c = 0, flags = r.flags, dp_score = 0;
+		int rs1 = d.rs, qs1 = d.qs, re1 = d.rs, qe1 = d.qs;
+		int split_at = -1, split_inv = 0;
+		// every value below is the same in all lanes; only the copies are shared out
+		auto append = [&](const Seg &g) {
+			if (g.n_cigar <= 0) return;
+			const uint32_t first = B.cig_seg[g.cig_off];
+			int start = 0;
+			if (n_c > 0 && (C[n_c - 1] & 0xf) == (first & 0xf)) {       // same operation across the boundary
+				mem_order();
+				if (lane == 0) C[n_c - 1] += first >> 4 << 4;
+				start = 1;
+			}
+			for (int c = start + lane; c < g.n_cigar; c += 64) C[n_c + c - start] = B.cig_seg[g.cig_off + c];
+			n_c += g.n_cigar - start;
+			mem_order();
+		};
+		{
+			int k = 0;
+			if (d.has_left) {
+				const Seg g = sg[k++];
+				if (g.n_cigar > 0) append(g), flags |= REG_HAS_DP, dp_score += g.max;
+				rs1 = d.rs - (g.reach_end ? g.mqe_t + 1 : g.max_t + 1);
+				qs1 = d.qs - (g.reach_end ? d.qs - d.qs0 : g.max_q + 1);
+			}
+			bool dropped = false;
+			const int n_fill = d.n_seg - d.has_left - d.has_right;
+			int prs = d.rs, pqs = d.qs;
+			for (int f = 0; f < n_fill; ++f) {
+				const Seg g = sg[k++];
+				re1 = g.ts + g.tlen, qe1 = g.qs + g.qlen;
+				if (g.n_cigar > 0) append(g), flags |= REG_HAS_DP;
+				if (g.zdropped) {
+					int j;
+					for (j = g.ai - 1; j >= 0; --j)
+						if ((int32_t)a[d.as1 + j].x <= prs + g.max_t) break;
+					dropped = true;
+					if (j < 0) j = 0;
+					dp_score += g.max;
+					re1 = prs + (g.max_t + 1), qe1 = pqs + (g.max_q + 1);
+					if (d.cnt1 - (j + 1) >= B.min_cnt) split_at = d.as1 + j + 1 - r.as, split_inv = g.zdrop_code == 2;
+					break;
+				} else dp_score += g.score;
+				prs = g.ts + g.tlen, pqs = g.qs + g.qlen;
+			}
+			if (!dropped && d.has_right) {
+				const Seg g = sg[d.n_seg - 1];
+				if (g.n_cigar > 0) append(g), flags |= REG_HAS_DP, dp_score += g.max;
+				re1 = d.re + (g.reach_end ? g.mqe_t + 1 : g.max_t + 1);
+				qe1 = d.qe + (g.reach_end ? d.qe0 - d.qe : g.max_q + 1);
+			}
+		}
+		mem_order();
+
+		// ---- a Z-drop splits the region: its tail is planned and aligned in the next round (mm_split_reg)
+		if (split_at > 0 && split_at < r.cnt) {
+			mnc_reg_t r2 = r;                                    // same values in every lane
+			r2.id = -1, r2.flags = REG_SPLIT_R | (split_inv ? REG_SPLIT_INV : 0);
+			r2.dp_score = r2.dp_max = r2.dp_max2 = r2.n_ambi = r2.n_cigar = 0;
+			r2.cnt = r.cnt - split_at;
+			r2.score = (int32_t)((double)__fmul_rn((float)r.score, __fdiv_rn((float)r2.cnt, (float)r.cnt)) + .499);
+			r2.as = r.as + split_at;
+			if (r.parent == r.id) r2.parent = -2;
+			r.cnt -= r2.cnt, r.score -= r2.score;
+			// coordinates and chain-level lengths of both parts (mm_reg_set_coor)
+			for (int part = 0; part < 2; ++part) {
+				mnc_reg_t &x = part ? r2 : r;
+				const Anchor f0 = a[x.as], l0 = a[x.as + x.cnt - 1];
+				const int q_span = (int)(f0.y >> 32 & 0xff);
+				x.rev = (int32_t)(f0.x >> 63), x.rid = (int32_t)(f0.x << 1 >> 33);
+				x.rs = (int32_t)f0.x + 1 > q_span ? (int32_t)f0.x + 1 - q_span : 0;
+				x.re = (int32_t)l0.x + 1;
+				if (!x.rev) x.qs = (int32_t)f0.y + 1 - q_span, x.qe = (int32_t)l0.y + 1;
+				else x.qs = qlen - ((int32_t)l0.y + 1), x.qe = qlen - ((int32_t)f0.y + 1 - q_span);
+				x.mlen = x.blen = q_span;
+				for (int i = x.as + 1; i < x.as + x.cnt; ++i) {
+					const int span = (int)(a[i].y >> 32 & 0xff);
+					const int tl = (int32_t)a[i].x - (int32_t)a[i - 1].x, ql = (int32_t)a[i].y - (int32_t)a[i - 1].y;
+					x.blen += tl > ql ? tl : ql;
+					x.mlen += tl > span && ql > span ? span : tl < ql ? tl : ql;
+				}
+			}
+			flags |= REG_SPLIT_L;
+			if (lane == 0) {
+				const int idx = atomicAdd(&B.reg_cnt[rd], 1);
+				const int64_t nslot = B.an_off[rd] / 3 + idx;
+				RegDP d2;
+				memset(&d2, 0, sizeof(d2));
+				d2.read = (int32_t)rd, d2.order = d.order + 1, d2.state = 1;
+				B.regs[nslot] = r2, B.regdp[nslot] = d2;
+				const unsigned long long ni = atomicAdd(&B.dp_ctr[5], 1ULL);
+				next_list[ni] = (int32_t)nslot;
+			}
+		}
+		r.rs = rs1, r.re = re1;
+		if (rev) r.qs = qlen - qe1, r.qe = qlen - qs1;
+		else r.qs = qs1, r.qe = qe1;
+		r.flags = flags, r.dp_score = dp_score;
+
+		if (flags & REG_HAS_DP) {
+			// ---- sequences of [qs1, qe1) x [rs1, re1) into LDS (or read in place when too long)
+			const int ql = qe1 - qs1, tl = re1 - rs1;
+			const bool in_lds = ql <= ST_SEQ_MAX && tl <= ST_SEQ_MAX;
+			if (in_lds) {
+				for (int i = lane; i < ql; i += 64) s_q[i] = (uint8_t)qcode(read, qlen, rev, qs1 + i);
+				for (int i = lane; i < tl; i += 64) s_t[i] = (uint8_t)tcode(B, coff, rs1 + i);
+			}
+			mem_order();
+			auto Q = [&](int i) -> int { return in_lds ? (int)s_q[i] : qcode(read, qlen, rev, qs1 + i); };
+			auto Tg = [&](int i) -> int { return in_lds ? (int)s_t[i] : tcode(B, coff, rs1 + i); };
+			int qshift = 0, tshift = 0;
+			// ---- mm_fix_cigar (lane 0)
+			if (lane == 0 && n_c > 1) {
+				int toff = 0, qoff = 0;
+				bool to_shrink = false;
+				for (int k = 0; k < n_c; ++k) {
+					const uint32_t op = C[k] & 0xf;
+					const int len = (int)(C[k] >> 4);
+					if (len == 0) to_shrink = true;
+					if (op == 0) toff += len, qoff += len;
+					else {
+						if (k > 0 && k < n_c - 1 && (C[k - 1] & 0xf) == 0 && (C[k + 1] & 0xf) == 0) {
+							int l;
+							const int prev_len = (int)(C[k - 1] >> 4);
+							if (op == 1) { for (l = 0; l < prev_len; ++l) if (Q(qoff - 1 - l) != Q(qoff + len - 1 - l)) break; }
+							else { for (l = 0; l < prev_len; ++l) if (Tg(toff - 1 - l) != Tg(toff + len - 1 - l)) break; }
+							if (l > 0) C[k - 1] -= (uint32_t)l << 4, C[k + 1] += (uint32_t)l << 4, qoff -= l, toff -= l;
+							if (l == prev_len) to_shrink = true;
+						}
+						if (op == 1) qoff += len; else toff += len;
+					}
+				}
+				for (int k = 0; k < n_c - 2; ++k) {
+					if ((C[k] & 0xf) > 0 && (C[k] & 0xf) + (C[k + 1] & 0xf) == 3) {
+						uint32_t s3[3] = { 0, 0, 0 };
+						int l;
+						for (l = k; l < n_c; ++l) {
+							const uint32_t op = C[l] & 0xf;
+							if (op == 1 || op == 2 || C[l] >> 4 == 0) s3[op] += C[l] >> 4;
+							else break;
+						}
+						if (s3[1] > 0 && s3[2] > 0 && l - k > 2) {
+							C[k] = s3[1] << 4 | 1, C[k + 1] = s3[2] << 4 | 2;
+							for (k += 2; k < l; ++k) C[k] &= 0xf;
+							to_shrink = true;
+						}
+						k = l;
+					}
+				}
+				if (to_shrink) {
+					int l = 0;
+					for (int k = 0; k < n_c; ++k) if (C[k] >> 4 != 0) C[l++] = C[k];
+					n_c = l;
+					l = 0;
+					for (int k = 0; k < n_c; ++k)
+						if (k == n_c - 1 || (C[k] & 0xf) != (C[k + 1] & 0xf)) C[l++] = C[k];
+						else C[k + 1] += C[k] >> 4 << 4;
+					n_c = l;
+				}
+				if ((C[0] & 0xf) == 1 || (C[0] & 0xf) == 2) {
+					const int l = (int)(C[0] >> 4);
+					if ((C[0] & 0xf) == 1) { if (r.rev) r.qe -= l; else r.qs += l; qshift = l; }
+					else r.rs += l, tshift = l;
+					--n_c;
+					for (int k = 0; k < n_c; ++k) C[k] = C[k + 1];
+				}
+			}
+			n_c = __shfl(n_c, 0), qshift = __shfl(qshift, 0), tshift = __shfl(tshift, 0);
+			r.qs = __shfl(r.qs, 0), r.qe = __shfl(r.qe, 0), r.rs = __shfl(r.rs, 0);
+			mem_order();
+			// ---- mm_update_extra: one walk; the lanes share each M run.  s := max(s + d, 0) per base
+			// is the map x -> max(x + a, b): a wave-wide scan of (a, b) pairs gives every prefix.
+			int s_run = 0, s_max = 0, mlen = 0, blen = 0, n_ambi = 0;
+			int toff = tshift, qoff = qshift;
+			for (int k = 0; k < n_c; ++k) {
+				const uint32_t op = C[k] & 0xf;
+				const int len = (int)(C[k] >> 4);
+				if (op == 0) {
+					int amb = 0, diff = 0;
+					for (int c0 = 0; c0 < len; c0 += 64) {
+						const int i = c0 + lane;
+						const bool act = i < len;
+						int dlt = 0;
+						if (act) {
+							const int cq = Q(qoff + i), ct = Tg(toff + i);
+							if (ct > 3 || cq > 3) ++amb, dlt = -B.sc_ambi;
+							else if (ct != cq) ++diff, dlt = -B.sc_b;
+							else dlt = B.sc_a;
+						}
+						// inclusive scan of f_i(x) = max(x + a_i, b_i), a_i = dlt, b_i = 0 (identity for idle lanes: a = 0, b = -inf)
+						int fa = act ? dlt : 0, fb = act ? 0 : DP_NEG_INF;
+						for (int sft = 1; sft < 64; sft <<= 1) {
+							const int pa = __shfl_up(fa, sft), pb = __shfl_up(fb, sft);
+							if (lane >= sft) {
+								// (earlier then later): x -> max(max(x + pa, pb) + fa, fb)
+								fb = pb + fa > fb ? pb + fa : fb;
+								fa = pa + fa;
+							}
+						}
+						const int sv = s_run + fa > fb ? s_run + fa : fb;      // s after base i
+						int mv = act ? sv : 0;
+						mv = wave_max_i32(mv);
+						s_max = s_max > mv ? s_max : mv;
+						s_run = __shfl(sv, 63);
+					}
+					amb = amb + 0;
+					// counts over the run
+					int ta = amb, td = diff;
+					for (int sft = 32; sft > 0; sft >>= 1) ta += __shfl_xor(ta, sft), td += __shfl_xor(td, sft);
+					blen += len - ta, mlen += len - (ta + td), n_ambi += ta;
+					toff += len, qoff += len;
+				} else {
+					int amb = 0;
+					for (int i = lane; i < len; i += 64) amb += (op == 1 ? Q(qoff + i) : Tg(toff + i)) > 3;
+					for (int sft = 32; sft > 0; sft >>= 1) amb += __shfl_xor(amb, sft);
+					blen += len - amb, n_ambi += amb;
+					s_run -= B.gap_q + B.gap_e * len;
+					if (s_run < 0) s_run = 0;
+					if (op == 1) qoff += len; else toff += len;
+				}
+			}
+			r.mlen = mlen, r.blen = blen, r.n_ambi += n_ambi, r.dp_max = s_max, r.n_cigar = n_c;
+		}
+		if (C == s_c) for (int k = lane; k < n_c; k += 64) B.cig_reg[off + k] = s_c[k];
+		if (lane == 0) {
+			d.state = 2, d.cig_off = (int64_t)off, d.n_cigar = n_c;
+			B.regs[rslot] = r, B.regdp[rslot] = d;
+		}
+		mem_order();
+	}
+}
+
+// ================================================================ round bookkeeping (one thread)
+__global__ void mnc_dp_round(Batch B, int first)
+{
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	if (first) B.dp_ctr[8] = 0;
+	B.dp_ctr[3] = B.dp_ctr[8];            // the align queue starts at this round's first segment
+	B.dp_ctr[9] = B.dp_ctr[5];            // regions to plan / stitch this round
+	B.dp_ctr[5] = 0;
+	B.dp_ctr[6] = 0, B.dp_ctr[7] = 0;
+}
+__global__ void mnc_dp_round_end(Batch B)
+{
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	B.dp_ctr[8] = B.dp_ctr[0];
+}
+
+// ================================================================ launches
+void launch_dp_gather(const Batch &B, hipStream_t st)
+{
+	if (B.n_reads) hipLaunchKernelGGL(mnc_dp_gather, dim3((B.n_reads + 63) / 64), dim3(64), 0, st, B);
+}
+void launch_dp_round(const Batch &B, int first, hipStream_t st) { hipLaunchKernelGGL(mnc_dp_round, dim3(1), dim3(1), 0, st, B, first); }
+void launch_dp_round_end(const Batch &B, hipStream_t st) { hipLaunchKernelGGL(mnc_dp_round_end, dim3(1), dim3(1), 0, st, B); }
+void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work, int state_max, long long p_max, int cig_max,
+                    long long big_state, long long big_p, long long big_cig, hipStream_t st)
+{
+	if (max_work) hipLaunchKernelGGL(mnc_dp_plan, dim3((max_work + 63) / 64), dim3(64), 0, st, B, work_list, state_max, p_max, cig_max, big_state, big_p, big_cig);
+}
+size_t dp_align_ws_bytes(long long state_max, long long p_max, long long cig_max) { return align_ws(state_max, p_max, cig_max).total; }
+int dp_align_prepare(int lds_bytes)
+{
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+	if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return MNC_ERR_HIP; }
+	return MNC_OK;
+}
+void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max, long long p_max, long long cig_max, int lds_bytes, int big_pass, hipStream_t st)
+{
+	hipLaunchKernelGGL(mnc_dp_align, dim3(n_wg), dim3(64), (size_t)lds_bytes, st, B, ws, state_max, p_max, cig_max, lds_bytes, big_pass);
+}
+void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_list, int n_wg, hipStream_t st)
+{
+	hipLaunchKernelGGL(mnc_dp_stitch, dim3(n_wg), dim3(64), 0, st, B, work_list, next_list);
+}
+
+} // namespace mnc

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64) void mnc_chain_backtrack(Batch B, const uint32_
 				c.mlen += tl > sp && ql > sp ? sp : tl < ql ? tl : ql;
 				prev = cur;
 			}
-			c.as = 0, c.pad = k;
+			c.as = v[n_v0], c.pad = k;
 			out[k++] = c;
 		} else n_v = n_v0;
 	}

@@ -506,7 +506,7 @@ __global__ __launch_bounds__(64) void mnc_chain_tail(Batch B, const uint32_t *li
 				ChainRec c;
 				const Anchor af = ga[A[3]], al = ga[sidx];
 				c.x0 = af.x, c.y0 = af.y, c.x1 = al.x, c.y1 = al.y;
-				c.score = score, c.cnt = (int)cnt, c.mlen = span + (int)A[1], c.blen = span + (int)A[2], c.as = 0, c.pad = kk;
+				c.score = score, c.cnt = (int)cnt, c.mlen = span + (int)A[1], c.blen = span + (int)A[2], c.as = (int)sidx, c.pad = kk;
 				out[kk] = c;
 			}
 			k += __popc(bits);
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(64) void mnc_chain_tail(Batch B, const uint32_t *li
 				ChainRec c;
 				const Anchor af = ga[first], al = ga[last];
 				c.x0 = af.x, c.y0 = af.y, c.x1 = al.x, c.y1 = al.y;
-				c.score = score, c.cnt = cnt, c.mlen = mlen, c.blen = blen, c.as = 0, c.pad = k;
+				c.score = score, c.cnt = cnt, c.mlen = mlen, c.blen = blen, c.as = last, c.pad = k;
 				out[k++] = c;
 			}
 		}

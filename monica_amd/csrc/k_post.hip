@@ -1,5 +1,5 @@
-// Stage kernel K6: chains -> regions -> hierarchy -> long-join -> chain-level MAPQ ->
-// monica's per-read decision and taxon counts -- gfx950.
+// Stage kernel K6: chains -> regions -> hierarchy -> long-join -> [base-level alignment, k_align.hip]
+// -> second hierarchy pass -> MAPQ -> monica's per-read decision and taxon counts -- gfx950.
 //
 // Replaces, for one index part: mm_gen_regs / mm_set_parent / mm_select_sub / mm_join_long /
 // mm_set_mapq inside index.map(seq) and the Python that
@@ -121,13 +121,173 @@ __device__ void sync_regs(int n_regs, RegP regs, I32P tmp)
 	}
 }
 
+// parent / secondary assignment, subsc, n_sub (mm_set_parent).  It runs twice when base-level
+// alignment is on (chain_post, then align_regs): on the second pass both regions carry a DP
+// result, dp_max2 of the parent is raised and a near-equal DP score counts as sub-optimal too.
+template <class RegP, class K64P, class I32P>
+__device__ __forceinline__ void set_parent(const Batch &B, int n_regs, RegP r, K64P cov, I32P w)
+{
+	if (n_regs <= 0) return;
+	const int sub_diff = B.sc_a * 2 + B.sc_b;
+	for (int i = 0; i < n_regs; ++i) r[i].id = i;
+	int k = 1;
+	w[0] = 0, r[0].parent = 0;
+	for (int i = 1; i < n_regs; ++i) {
+		const int si = r[i].qs, ei = r[i].qe;
+		int n_cov = 0, uncov_len = 0, j;
+		for (j = 0; j < k; ++j) {
+			const int pj = w[j];
+			int sj = r[pj].qs, ej = r[pj].qe;
+			if (ej <= si || sj >= ei) continue;
+			if (sj < si) sj = si;
+			if (ej > ei) ej = ei;
+			cov[n_cov++] = (uint64_t)(uint32_t)sj << 32 | (uint32_t)ej;
+		}
+		j = k;
+		if (n_cov > 0) {
+			int x = si;
+			sort_u64(cov, n_cov);
+			for (int jj = 0; jj < n_cov; ++jj) {
+				if ((int)(cov[jj] >> 32) > x) uncov_len += (int)(cov[jj] >> 32) - x;
+				x = (int32_t)cov[jj] > x ? (int32_t)cov[jj] : x;
+			}
+			if (ei > x) uncov_len += ei - x;
+			for (j = 0; j < k; ++j) {
+				const int pj = w[j];
+				const int sj = r[pj].qs, ej = r[pj].qe;
+				if (ej <= si || sj >= ei) continue;
+				const int mn = ej - sj < ei - si ? ej - sj : ei - si;
+				const int mx = ej - sj > ei - si ? ej - sj : ei - si;
+				const int ol = si < sj ? (ei < sj ? 0 : ei < ej ? ei - sj : ej - sj)
+				                       : (ej < si ? 0 : ej < ei ? ej - si : ei - si);
+				const float lhs = __fsub_rn(__fdiv_rn((float)ol, (float)mn), __fdiv_rn((float)uncov_len, (float)mx));
+				if (lhs > B.mask_level) {
+					int cnt_sub = 0;
+					r[i].parent = r[pj].parent;
+					r[pj].subsc = r[pj].subsc > r[i].score ? r[pj].subsc : r[i].score;
+					if (r[i].cnt >= r[pj].cnt) cnt_sub = 1;
+					if ((r[pj].flags & REG_HAS_DP) && (r[i].flags & REG_HAS_DP) &&
+					    (r[pj].rid != r[i].rid || r[pj].rs != r[i].rs || r[pj].re != r[i].re || ol != mn)) {   // not the same hit twice
+						const int sc = r[i].dp_max;
+						r[pj].dp_max2 = r[pj].dp_max2 > sc ? r[pj].dp_max2 : sc;
+						if (r[pj].dp_max - r[i].dp_max <= sub_diff) cnt_sub = 1;
+					}
+					if (cnt_sub) ++r[pj].n_sub;
+					break;
+				}
+			}
+		}
+		if (j == k) w[k++] = i, r[i].parent = i, r[i].n_sub = 0;
+	}
+}
+
+// keep primaries and the best secondaries (mm_select_sub); the in-place compaction reads r[p]
+// after earlier slots may have been overwritten.  `ex` travels with `r`.
+template <class RegP, class ExP, class I32P>
+__device__ __forceinline__ int select_sub(const Batch &B, int n_regs, RegP r, ExP ex, I32P tmp)
+{
+	if (!(B.pri_ratio > 0.0f) || n_regs <= 0) return n_regs;
+	const int min_diff = KMER * 2;
+	int k = 0, n_2nd = 0;
+	for (int i = 0; i < n_regs; ++i) {
+		const int p = r[i].parent;
+		if (p == i) {
+			r[k] = r[i], ex[k] = ex[i], ++k;
+		} else if (((float)r[i].score >= __fmul_rn((float)r[p].score, B.pri_ratio) || r[i].score + min_diff >= r[p].score) && n_2nd < B.best_n) {
+			if (!(r[i].qs == r[p].qs && r[i].qe == r[p].qe && r[i].rid == r[p].rid && r[i].rs == r[p].rs && r[i].re == r[p].re)) {
+				r[k] = r[i], ex[k] = ex[i], ++k, ++n_2nd;
+			}
+		}
+	}
+	if (k != n_regs) sync_regs(k, r, tmp);
+	return k;
+}
+
+// mm_set_mapq: the branch a region takes depends on whether it carries a DP result
+template <class RegP>
+__device__ __forceinline__ void set_mapq(const Batch &B, uint32_t rd, int n_regs, RegP r)
+{
+	long long sum_sc = 0;
+	for (int i = 0; i < n_regs; ++i) if (r[i].parent == r[i].id) sum_sc += r[i].score;
+	const float uniq_ratio = __fdiv_rn((float)sum_sc, (float)(sum_sc + (long long)B.rep_len[rd]));
+	for (int i = 0; i < n_regs; ++i) {
+		const mnc_reg_t x = r[i];
+		int mapq = 0;
+		if (x.parent == x.id) {
+			const bool has_dp = (x.flags & REG_HAS_DP) != 0;
+			const float pen_s1 = __fmul_rn(x.score > 100 ? 1.0f : __fmul_rn(0.01f, (float)x.score), uniq_ratio);
+			float pen_cm = x.cnt > 10 ? 1.0f : __fmul_rn(0.1f, (float)x.cnt);
+			pen_cm = pen_s1 < pen_cm ? pen_s1 : pen_cm;
+			const int subsc = x.subsc > B.min_sc ? x.subsc : B.min_sc;
+			const int ls = x.n_sub + 1 < B.logf_n ? x.n_sub + 1 : B.logf_n - 1;
+			if (has_dp && x.dp_max2 > 0 && x.dp_max > 0) {
+				// identity * pen_cm * 40 * (1 - x*x) * logf(dp_max / a); dp_max / a is a float division:
+				// its logf is not a table entry, so logf((float)dp_max / a) = logf(dp_max) - logf(a)
+				// would round differently -- the table is indexed by dp_max and holds logf((float)i / a)
+				const float identity = __fdiv_rn((float)x.mlen, (float)x.blen);
+				const float xr = __fdiv_rn(__fdiv_rn(__fmul_rn((float)x.dp_max2, (float)subsc), (float)x.dp_max), (float)x.score0);
+				const int li = x.dp_max < B.logf_n ? x.dp_max : B.logf_n - 1;
+				float q = __fmul_rn(__fmul_rn(__fmul_rn(__fmul_rn(identity, pen_cm), 40.0f), __fsub_rn(1.0f, __fmul_rn(xr, xr))), B.logf_a_lut[li]);
+				mapq = (int)q;
+				const float alt = __fadd_rn(__fdiv_rn(__fmul_rn(__fmul_rn(__fmul_rn(6.02f, identity), identity), (float)(x.dp_max - x.dp_max2)), (float)B.sc_a), .499f);
+				const int mapq_alt = (int)alt;
+				mapq = mapq < mapq_alt ? mapq : mapq_alt;
+			} else {
+				const float xr = __fdiv_rn((float)subsc, (float)x.score0);
+				if (has_dp) {
+					const float identity = __fdiv_rn((float)x.mlen, (float)x.blen);
+					const int li = x.dp_max < B.logf_n ? (x.dp_max > 0 ? x.dp_max : 0) : B.logf_n - 1;
+					float q = __fmul_rn(__fmul_rn(__fmul_rn(__fmul_rn(identity, pen_cm), 40.0f), __fsub_rn(1.0f, xr)), B.logf_a_lut[li]);
+					mapq = (int)q;
+				} else {
+					const int li = x.score < B.logf_n ? x.score : B.logf_n - 1;
+					float q = __fmul_rn(__fmul_rn(__fmul_rn(pen_cm, 40.0f), __fsub_rn(1.0f, xr)), B.logf_lut[li]);
+					mapq = (int)q;
+				}
+			}
+			mapq -= (int)__fadd_rn(__fmul_rn(4.343f, B.logf_lut[ls]), .499f);
+			mapq = mapq > 0 ? mapq : 0;
+			mapq = mapq < 60 ? mapq : 60;
+			if (has_dp && x.dp_max > x.dp_max2 && mapq == 0) mapq = 1;
+		}
+		r[i].mapq = mapq;
+	}
+}
+
+// monica: gate, best_hit, decision (aligner.py:216-233)
+template <class RegP>
+__device__ __forceinline__ void gate_and_decide(const Batch &B, int n_regs, RegP r, mnc_hit_t *gated,
+                                                int32_t &assign, mnc_hit_t &best, int32_t &nhits)
+{
+	int ties = 0;
+	for (int i = 0; i < n_regs; ++i) {
+		const mnc_reg_t x = r[i];
+		if (x.id == x.parent && x.mapq >= B.min_mapq) {
+			mnc_hit_t h;
+			h.rid = x.rid, h.mapq = x.mapq, h.nm = x.blen - x.mlen + x.n_ambi, h.mlen = x.mlen;
+			gated[nhits] = h;
+			if (nhits == 0) best = h, ties = 1;
+			else {
+				const long long l = (long long)h.nm * best.mlen, rr = (long long)best.nm * h.mlen;
+				if (l < rr) best = h, ties = 1;
+				else if (l == rr) best = h, ++ties;
+			}
+			++nhits;
+		}
+	}
+	if (nhits > 0) assign = (nhits == 1 || ties == 1) ? best.rid : MNC_AMBIGUOUS;   // best = the minimal hit, also when it is tied
+}
+
 // The work of one read on a workspace of n slots per array: `r`, `ex`, `ka`, `kb`, `w`, `tmp`
 // live in LDS for reads with few chains and in HBM scratch otherwise (the function is inlined
 // once per address space).  Returns the number of regions kept; fills assign / best / nhits.
+// With `chain_dst` (base-level alignment follows) it stops after long-join and tells every chain
+// where its anchors go in the squeezed anchor array of the read: position | LONG_JOIN flag (bit
+// 30) for a chain fused behind another one, -1 for a chain that is not kept.
 template <class RegP, class ExP, class K64P, class I32P>
 __device__ __forceinline__ int regions_of_read(const Batch &B, uint32_t rd, int qlen, int n, const ChainRec *ch,
                                                RegP r, ExP ex, K64P ka, K64P kb, I32P w, I32P tmp, mnc_hit_t *gated,
-                                               int32_t &assign, mnc_hit_t &best, int32_t &nhits)
+                                               int32_t &assign, mnc_hit_t &best, int32_t &nhits, int32_t *chain_dst)
 {
 	int n_regs = 0;
 	// ---------------- chains ordered by (first anchor x, rank); `as` = running anchor count
@@ -169,6 +329,8 @@ __device__ __forceinline__ int regions_of_read(const Batch &B, uint32_t rd, int 
 		x.hash = (uint32_t)ka[ci];
 		x.cnt = c.cnt, x.as = (int32_t)(kb[ci] >> 32), x.mlen = c.mlen, x.blen = c.blen;
 		x.subsc = 0, x.n_sub = 0, x.mapq = 0;
+		x.dp_score = ci, x.dp_max = x.dp_max2 = x.n_ambi = x.n_cigar = x.flags = 0;     // dp_score: the chain, until the end
+		if (chain_dst) chain_dst[ci] = -1;
 		RegX e;
 		e.x0 = c.x0, e.y0 = c.y0, e.x1 = c.x1, e.y1 = c.y1;
 		set_coor(x, e, qlen);
@@ -176,72 +338,12 @@ __device__ __forceinline__ int regions_of_read(const Batch &B, uint32_t rd, int 
 	}
 	n_regs = n;
 
-	// ---------------- parent / secondary, subsc, n_sub (mm_set_parent)
-	{
-		K64P cov = ka;
-		int k = 1;
-		w[0] = 0, r[0].parent = 0;
-		for (int i = 1; i < n_regs; ++i) {
-			const int si = r[i].qs, ei = r[i].qe;
-			int n_cov = 0, uncov_len = 0, j;
-			for (j = 0; j < k; ++j) {
-				const int pj = w[j];
-				int sj = r[pj].qs, ej = r[pj].qe;
-				if (ej <= si || sj >= ei) continue;
-				if (sj < si) sj = si;
-				if (ej > ei) ej = ei;
-				cov[n_cov++] = (uint64_t)(uint32_t)sj << 32 | (uint32_t)ej;
-			}
-			j = k;
-			if (n_cov > 0) {
-				int x = si;
-				sort_u64(cov, n_cov);
-				for (int jj = 0; jj < n_cov; ++jj) {
-					if ((int)(cov[jj] >> 32) > x) uncov_len += (int)(cov[jj] >> 32) - x;
-					x = (int32_t)cov[jj] > x ? (int32_t)cov[jj] : x;
-				}
-				if (ei > x) uncov_len += ei - x;
-				for (j = 0; j < k; ++j) {
-					const int pj = w[j];
-					const int sj = r[pj].qs, ej = r[pj].qe;
-					if (ej <= si || sj >= ei) continue;
-					const int mn = ej - sj < ei - si ? ej - sj : ei - si;
-					const int mx = ej - sj > ei - si ? ej - sj : ei - si;
-					const int ol = si < sj ? (ei < sj ? 0 : ei < ej ? ei - sj : ej - sj)
-					                       : (ej < si ? 0 : ej < ei ? ej - si : ei - si);
-					const float lhs = __fsub_rn(__fdiv_rn((float)ol, (float)mn), __fdiv_rn((float)uncov_len, (float)mx));
-					if (lhs > B.mask_level) {
-						r[i].parent = r[pj].parent;
-						r[pj].subsc = r[pj].subsc > r[i].score ? r[pj].subsc : r[i].score;
-						if (r[i].cnt >= r[pj].cnt) ++r[pj].n_sub;
-						break;
-					}
-				}
-			}
-			if (j == k) w[k++] = i, r[i].parent = i, r[i].n_sub = 0;
-		}
-	}
+	set_parent(B, n_regs, r, ka, w);
 
-	// ---------------- keep primaries and the best secondaries (mm_select_sub); the
-	// in-place compaction reads r[p] after earlier slots may have been overwritten
-	if (B.pri_ratio > 0.0f) {
-		const int min_diff = KMER * 2;
-		int k = 0, n_2nd = 0;
-		for (int i = 0; i < n_regs; ++i) {
-			const int p = r[i].parent;
-			if (p == i) {
-				r[k] = r[i], ex[k] = ex[i], ++k;
-			} else if (((float)r[i].score >= __fmul_rn((float)r[p].score, B.pri_ratio) || r[i].score + min_diff >= r[p].score) && n_2nd < B.best_n) {
-				if (!(r[i].qs == r[p].qs && r[i].qe == r[p].qe && r[i].rid == r[p].rid && r[i].rs == r[p].rs && r[i].re == r[p].re)) {
-					r[k] = r[i], ex[k] = ex[i], ++k, ++n_2nd;
-				}
-			}
-		}
-		if (k != n_regs) sync_regs(k, r, tmp);
-		n_regs = k;
-	}
+	n_regs = select_sub(B, n_regs, r, ex, tmp);
 
 	// ---------------- long-join of adjacent co-linear primaries (mm_join_long)
+	if (chain_dst && n_regs == 1) r[0].as = 0, chain_dst[r[0].dp_score] = 0;
 	if (n_regs >= 2) {
 		K64P aux = ka;
 		// squeeze: `as` becomes the running anchor count in original-`as` order
@@ -251,6 +353,7 @@ __device__ __forceinline__ int regions_of_read(const Batch &B, uint32_t rd, int 
 		for (int i = 0; i < n_regs; ++i) {
 			const int ri = (int32_t)(uint32_t)aux[i];
 			r[ri].as = as;
+			if (chain_dst) chain_dst[r[ri].dp_score] = as;
 			as += r[ri].cnt;
 		}
 		int n_aux = 0, n_drop = 0;
@@ -291,6 +394,7 @@ __device__ __forceinline__ int regions_of_read(const Batch &B, uint32_t rd, int 
 			r[i0] = r0, ex[i0] = e0;
 			r[i1].cnt = 0;
 			r[i1].parent = r0.id;
+			if (chain_dst) chain_dst[r1.dp_score] |= 1 << 30;        // MM_SEED_LONG_JOIN on its first anchor
 			++n_drop;
 		}
 		if (n_drop > 0) {
@@ -310,50 +414,10 @@ __device__ __forceinline__ int regions_of_read(const Batch &B, uint32_t rd, int 
 		}
 	}
 
-	// ---------------- chain-level MAPQ (mm_set_mapq, branch without base-level DP)
-	{
-		long long sum_sc = 0;
-		for (int i = 0; i < n_regs; ++i) if (r[i].parent == r[i].id) sum_sc += r[i].score;
-		const float uniq_ratio = __fdiv_rn((float)sum_sc, (float)(sum_sc + (long long)B.rep_len[rd]));
-		for (int i = 0; i < n_regs; ++i) {
-			const mnc_reg_t x = r[i];
-			int mapq = 0;
-			if (x.parent == x.id) {
-				const float pen_s1 = __fmul_rn(x.score > 100 ? 1.0f : __fmul_rn(0.01f, (float)x.score), uniq_ratio);
-				float pen_cm = x.cnt > 10 ? 1.0f : __fmul_rn(0.1f, (float)x.cnt);
-				pen_cm = pen_s1 < pen_cm ? pen_s1 : pen_cm;
-				const int subsc = x.subsc > B.min_sc ? x.subsc : B.min_sc;
-				const float xr = __fdiv_rn((float)subsc, (float)x.score0);
-				const int li = x.score < B.logf_n ? x.score : B.logf_n - 1;
-				const int ls = x.n_sub + 1 < B.logf_n ? x.n_sub + 1 : B.logf_n - 1;
-				float q = __fmul_rn(__fmul_rn(__fmul_rn(pen_cm, 40.0f), __fsub_rn(1.0f, xr)), B.logf_lut[li]);
-				mapq = (int)q;
-				mapq -= (int)__fadd_rn(__fmul_rn(4.343f, B.logf_lut[ls]), .499f);
-				mapq = mapq > 0 ? mapq : 0;
-				mapq = mapq < 60 ? mapq : 60;
-			}
-			r[i].mapq = mapq;
-		}
-	}
-
-	// ---------------- monica: gate, best_hit, decision (aligner.py:216-233)
-	int ties = 0;
-	for (int i = 0; i < n_regs; ++i) {
-		const mnc_reg_t x = r[i];
-		if (x.id == x.parent && x.mapq >= B.min_mapq) {
-			mnc_hit_t h;
-			h.rid = x.rid, h.mapq = x.mapq, h.nm = x.blen - x.mlen, h.mlen = x.mlen;
-			gated[nhits] = h;
-			if (nhits == 0) best = h, ties = 1;
-			else {
-				const long long l = (long long)h.nm * best.mlen, rr = (long long)best.nm * h.mlen;
-				if (l < rr) best = h, ties = 1;
-				else if (l == rr) best = h, ++ties;
-			}
-			++nhits;
-		}
-	}
-	if (nhits > 0) assign = (nhits == 1 || ties == 1) ? best.rid : MNC_AMBIGUOUS;   // best = the minimal hit, also when it is tied
+	for (int i = 0; i < n_regs; ++i) r[i].dp_score = 0;
+	if (chain_dst) return n_regs;                               // base-level alignment comes next (k_align.hip)
+	set_mapq(B, rd, n_regs, r);
+	gate_and_decide(B, n_regs, r, gated, assign, best, nhits);
 	return n_regs;
 }
 
@@ -368,6 +432,7 @@ __global__ __launch_bounds__(64) void mnc_regions_decide(Batch B, RegX *regx_all
 	__shared__ int32_t s_w[RG_LDS_CHAINS][64], s_tmp[RG_LDS_CHAINS][64];
 	const uint32_t rd = blockIdx.x * blockDim.x + threadIdx.x;
 	if (rd >= B.n_reads) return;
+	const bool dp = B.contract == MNC_CONTRACT_DP;
 	const int qlen = (int)(B.offsets[rd + 1] - B.offsets[rd]);
 	int32_t assign = MNC_UNMAPPED, nhits = 0;
 	mnc_hit_t best;
@@ -378,18 +443,115 @@ __global__ __launch_bounds__(64) void mnc_regions_decide(Batch B, RegX *regx_all
 		const int64_t slot = B.an_off[rd] / 3;
 		const ChainRec *ch = B.chains_tmp + slot;               // backtrack order (pad = rank)
 		mnc_hit_t *gated = gated_all + slot;
+		int32_t *chain_dst = dp ? B.chain_dst + slot : nullptr;
 		if (n <= RG_LDS_CHAINS) {
 			const int t = threadIdx.x;
 			n_regs = regions_of_read(B, rd, qlen, n, ch, Strided<mnc_reg_t>{&s_r[0][t]}, Strided<RegX>{&s_ex[0][t]},
 			                         Strided<uint64_t>{&s_ka[0][t]}, Strided<uint64_t>{&s_kb[0][t]},
-			                         Strided<int32_t>{&s_w[0][t]}, Strided<int32_t>{&s_tmp[0][t]}, gated, assign, best, nhits);
+			                         Strided<int32_t>{&s_w[0][t]}, Strided<int32_t>{&s_tmp[0][t]}, gated, assign, best, nhits, chain_dst);
 			mnc_reg_t *out = B.regs + slot;
 			for (int i = 0; i < n_regs; ++i) out[i] = s_r[i][t];
 		} else {
 			int32_t *w = B.tmp_i32 + slot * 4;                  // n ints each (4 per slot available)
 			n_regs = regions_of_read(B, rd, qlen, n, ch, B.regs + slot, regx_all + slot, k64a_all + slot, k64b_all + slot,
-			                         w, w + n, gated, assign, best, nhits);
+			                         w, w + n, gated, assign, best, nhits, chain_dst);
 		}
+		if (dp) {
+			// every kept region goes to the base-level alignment stage, in the order mm_align_skeleton
+			// walks them (a Z-drop split inserts its tail right behind its head: order = index << 8 | depth)
+			const mnc_reg_t *rg = B.regs + slot;
+			int total = 0;
+			for (int i = 0; i < n_regs; ++i) total += rg[i].cnt;
+			B.ca_cnt[rd] = total;
+			if (n_regs > 0) {
+				const unsigned long long w0 = atomicAdd(&B.dp_ctr[5], (unsigned long long)n_regs);
+				for (int i = 0; i < n_regs; ++i) {
+					RegDP d;
+					memset(&d, 0, sizeof(d));
+					d.read = (int32_t)rd, d.order = i << 8, d.state = 1;
+					B.regdp[slot + i] = d;
+					B.next_list[w0 + i] = (int32_t)(slot + i);
+				}
+			}
+		}
+	} else if (dp) B.ca_cnt[rd] = 0;
+	if (dp) { B.reg_cnt[rd] = n_regs; return; }
+	B.n_reg[rd] = n_regs;
+	B.assign[rd] = assign;
+	if (B.best) B.best[rd] = best;
+	B.nhits[rd] = nhits;
+	B.best_mlen[rd] = best.mlen;
+}
+
+// After the base-level alignment stage (k_align.hip): mm_filter_regs, mm_hit_sort, the second
+// mm_set_parent / mm_select_sub pass (align_regs), mm_set_mapq with the DP branch, then monica's
+// gate and decision.  One thread per read; the regions sit in the read's slots of B.regs in
+// arrival order (split tails appended), RegDP.order gives the skeleton's order.
+__global__ __launch_bounds__(64) void mnc_regions_post(Batch B, mnc_reg_t *work_all, RegX *regx_all, uint64_t *k64a_all,
+                                                       int32_t *tmp_all, mnc_hit_t *gated_all)
+{
+	const uint32_t rd = blockIdx.x * blockDim.x + threadIdx.x;
+	if (rd >= B.n_reads) return;
+	const int qlen = (int)(B.offsets[rd + 1] - B.offsets[rd]);
+	int32_t assign = MNC_UNMAPPED, nhits = 0;
+	mnc_hit_t best;
+	best.rid = best.mapq = best.nm = best.mlen = 0;
+	const int n0 = B.reg_cnt[rd];
+	int n_regs = 0;
+	if (n0 > 0) {
+		const int64_t slot = B.an_off[rd] / 3;
+		mnc_reg_t *src = B.regs + slot, *r = work_all + slot;
+		RegX *ex = regx_all + slot;                          // x0: CIGAR offset, x1: n_cigar -- travels with the region
+		uint64_t *ka = k64a_all + slot;
+		int32_t *w = tmp_all + slot * 4, *tmp = w + n0;
+		mnc_hit_t *gated = gated_all + slot;
+		// skeleton order
+		for (int i = 0; i < n0; ++i) w[i] = i;
+		for (int i = 1; i < n0; ++i) {
+			const int c = w[i], oc = B.regdp[slot + c].order;
+			int j = i - 1;
+			while (j >= 0 && B.regdp[slot + w[j]].order > oc) { w[j + 1] = w[j]; --j; }
+			w[j + 1] = c;
+		}
+		// mm_filter_regs
+		int k = 0;
+		for (int i = 0; i < n0; ++i) {
+			const mnc_reg_t x = src[w[i]];
+			bool flt = x.cnt < B.min_cnt;
+			if (x.flags & REG_HAS_DP) {
+				if (x.mlen < B.min_sc) flt = true;
+				else if (x.dp_max < B.min_dp_max) flt = true;
+				// max_clip_ratio = 1.0: (qs > qlen && qlen - qe > qlen) never holds
+			}
+			if (flt) continue;
+			RegX e;
+			e.x0 = (uint64_t)B.regdp[slot + w[i]].cig_off, e.y0 = 0, e.x1 = (uint64_t)(uint32_t)x.n_cigar, e.y1 = 0;
+			r[k] = x, ex[k] = e, ++k;
+		}
+		n_regs = k;
+		// mm_hit_sort: by DP score, hash as the tie-break (then position: a total order); descending
+		if (n_regs > 1) {
+			for (int i = 0; i < n_regs; ++i) {
+				const int sc = (r[i].flags & REG_HAS_DP) ? r[i].dp_max : r[i].score;
+				ka[i] = (uint64_t)(uint32_t)sc << 32 | r[i].hash;
+				tmp[i] = i;
+			}
+			for (int i = 1; i < n_regs; ++i) {
+				const int c = tmp[i];
+				const uint64_t kc = ka[c];
+				int j = i - 1;
+				while (j >= 0 && (ka[tmp[j]] < kc || (ka[tmp[j]] == kc && tmp[j] < c))) { tmp[j + 1] = tmp[j]; --j; }
+				tmp[j + 1] = c;
+			}
+			// permute through the source slots (free now)
+			for (int i = 0; i < n_regs; ++i) src[i] = r[tmp[i]], B.regdp[slot + i].cig_off = (int64_t)ex[tmp[i]].x0;
+			for (int i = 0; i < n_regs; ++i) { r[i] = src[i]; RegX e; e.x0 = (uint64_t)B.regdp[slot + i].cig_off, e.y0 = 0, e.x1 = (uint64_t)(uint32_t)src[i].n_cigar, e.y1 = 0; ex[i] = e; }
+		}
+		set_parent(B, n_regs, r, ka, w);
+		n_regs = select_sub(B, n_regs, r, ex, tmp);
+		set_mapq(B, rd, n_regs, r);
+		gate_and_decide(B, n_regs, r, gated, assign, best, nhits);
+		for (int i = 0; i < n_regs; ++i) src[i] = r[i], B.regdp[slot + i].cig_off = (int64_t)ex[i].x0, B.regdp[slot + i].n_cigar = r[i].n_cigar;
 	}
 	B.n_reg[rd] = n_regs;
 	B.assign[rd] = assign;
@@ -449,6 +611,15 @@ void launch_regions(const Batch &B, void *regx, uint64_t *k64a, uint64_t *k64b, 
 	if (B.n_reads == 0) return;
 	hipLaunchKernelGGL(mnc_regions_decide, dim3((B.n_reads + 63) / 64), dim3(64), 0, st, B,
 	                   reinterpret_cast<RegX*>(regx), k64a, k64b, gated);
+	if (B.counts && B.contract != MNC_CONTRACT_DP)
+		hipLaunchKernelGGL(mnc_count_taxa, dim3((B.n_reads + CT_READS - 1) / CT_READS), dim3(CT_THREADS), 0, st, B);
+}
+
+void launch_regions_post(const Batch &B, mnc_reg_t *work, void *regx, uint64_t *k64a, int32_t *tmp, mnc_hit_t *gated, hipStream_t st)
+{
+	if (B.n_reads == 0) return;
+	hipLaunchKernelGGL(mnc_regions_post, dim3((B.n_reads + 63) / 64), dim3(64), 0, st, B, work,
+	                   reinterpret_cast<RegX*>(regx), k64a, tmp, gated);
 	if (B.counts) hipLaunchKernelGGL(mnc_count_taxa, dim3((B.n_reads + CT_READS - 1) / CT_READS), dim3(CT_THREADS), 0, st, B);
 }
 

@@ -1,0 +1,106 @@
+"""GPU parity of the base-level alignment stage (csrc/k_align.hip) -- minimap2's
+mm_align_skeleton / ksw_extd2 as mappy always runs it (monica/genomes/aligner.py:193-195,
+215-217 read hit.mapq / hit.NM / hit.mlen from its result): every region field, every CIGAR,
+gated hits and decisions, bit for bit against the CPU oracle."""
+import numpy as np
+import pytest
+
+from monica_amd import synth
+import util
+from test_gpu_parity import _compare_dp, _world_from
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def world(capi, oracle):
+    names, seqs = util.small_genomes()
+    return _world_from(capi, oracle, names, seqs)
+
+
+def test_known_answers_on_the_gpu(capi, oracle, world):
+    g0, g1 = world["seqs"][0], world["seqs"][1]
+    one_sub = g0[5000:8000].copy()
+    one_sub[1500] = ord("A") if one_sub[1500] != ord("A") else ord("C")
+    with_n = g0[20000:24000].copy()
+    with_n[1500] = ord("N")
+    reads = [g0[5000:8000], util.revcomp(g0[5000:8000]), one_sub,
+             np.concatenate([g0[5000:6500], g0[6510:8000]]),                              # 10-base deletion
+             np.concatenate([g0[5000:6500], np.frombuffer(b"ACGTACGTAC", dtype=np.uint8), g0[6500:8000]]),
+             with_n,
+             np.concatenate([g0[100000:102500], g0[103500:106000]]),                      # 1 kb deletion: long-join
+             np.concatenate([g0[70000:72500], g1[90000:92500]])]                          # chimera
+    bases, offsets = util.pack_reads(reads)
+    assign, best, nhits = _compare_dp(capi, oracle, world, bases, offsets)
+    eng = world["eng"]
+    regs = eng.dump(capi.DUMP_REGS, capi.REG_DTYPE)
+    cigs = eng.cigars()
+    assert cigs[0] == [(3000, "M")] and cigs[1] == [(3000, "M")] and cigs[2] == [(3000, "M")]
+    assert (regs["mlen"][0], regs["blen"][0], regs["dp_max"][0], regs["mapq"][0]) == (3000, 3000, 6000, 60)
+    assert best["nm"][:6].tolist() == [0, 0, 1, 10, 10, 1] and best["mlen"][:3].tolist() == [3000, 3000, 2999]
+    assert cigs[3] == [(1499, "M"), (10, "D"), (1491, "M")]
+    assert cigs[6] == [(2500, "M"), (1000, "D"), (2500, "M")]
+    assert nhits[7] == 2
+
+
+def test_edge_reads(capi, oracle, world):
+    reads = util.edge_reads(world["seqs"], np.random.default_rng(7))
+    bases, offsets = util.pack_reads(reads)
+    _compare_dp(capi, oracle, world, bases, offsets)
+    _compare_dp(capi, oracle, world, bases, offsets, min_mapq=0)
+
+
+def test_noisy_reads(capi, oracle, world):
+    bases, offsets, truth = synth.reads(world["seqs"], 300, 5000, seed=0x5EED + 1)
+    assign, best, nhits = _compare_dp(capi, oracle, world, bases, offsets)
+    mapped = assign >= 0
+    assert mapped.sum() > 280 and (assign[mapped] == truth[mapped]).all()
+    assert (best["nm"][mapped] < 0.2 * best["mlen"][mapped]).all()
+    for rate in ((100, 50, 50), (800, 600, 600)):                    # 2 % and 20 % errors
+        b, o, _ = synth.reads(world["seqs"], 60, 3000, seed=31, sub=rate[0], ins=rate[1], dele=rate[2])
+        _compare_dp(capi, oracle, world, b, o, min_mapq=0)
+
+
+def test_zdrop_split_inversion_and_long_extensions(capi, oracle, world):
+    """A block of junk inside a read drops the score by more than zdrop in a gap filling: the
+    region is split there and its tail aligned as a region of its own.  An inverted block makes
+    the test answer "inversion" (lower Z-drop on the second pass and on the tail's left
+    extension).  Long junk flanks run the extension kernels until the Z-drop, past the band."""
+    g0, g1 = world["seqs"][0], world["seqs"][1]
+    rng = np.random.default_rng(21)
+    junk = lambda n: util.ACGT[rng.integers(0, 4, n)]
+    reads = [np.concatenate([g0[30000:32000], junk(700), g0[32700:34700]]),            # junk replaces 700 bases
+             np.concatenate([g0[40000:42000], util.revcomp(g0[42000:42700]), g0[42700:44700]]),   # inversion
+             np.concatenate([g1[50000:52000], junk(300), g1[52300:54000], junk(500), g1[54500:56500]]),
+             np.concatenate([junk(3000), g0[60000:63000], junk(3000)]),                  # flanks far longer than the band reach
+             np.concatenate([junk(1200), util.revcomp(g1[70000:72000])]),
+             np.concatenate([g0[80000:82000], junk(1500), g0[82000:84000]])]             # 1.5 kb insertion of junk
+    bases, offsets = util.pack_reads(reads)
+    _compare_dp(capi, oracle, world, bases, offsets, min_mapq=0)
+    regs = world["eng"].dump(capi.DUMP_REGS, capi.REG_DTYPE)
+    reg_off = world["eng"].dump(capi.DUMP_REG_OFFSETS, np.int64)
+    assert reg_off[1] - reg_off[0] >= 2 and (regs["flags"][reg_off[0]:reg_off[1]] & 6).any()   # really split
+    _compare_dp(capi, oracle, world, bases, offsets, min_mapq=60)
+
+
+def test_repetitive_index_with_secondaries(capi, oracle):
+    """Diverged copies: every read has secondaries whose DP scores set dp_max2 / n_sub of the
+    primary (the DP branch of the MAPQ formula), and some reads change hands after alignment."""
+    base = synth.genome(0x77, 120_000)
+    seqs = [base] + [synth.diverge(base, 0x78 + i, r) for i, r in enumerate((3000, 10_000, 30_000))] + [synth.genome(0x99, 80_000)]
+    names = [synth.contig_name(i) for i in range(5)]
+    w = _world_from(capi, oracle, names, seqs)
+    b, o, truth = synth.reads(seqs, 80, 4000, seed=41)
+    assign, best, nhits = _compare_dp(capi, oracle, w, b, o, min_mapq=0)
+    regs = w["eng"].dump(capi.DUMP_REGS, capi.REG_DTYPE)
+    assert (regs["dp_max2"] > 0).sum() > 40
+    _compare_dp(capi, oracle, w, b, o, min_mapq=60)
+
+
+def test_batch_shapes_and_tiny_reads(capi, oracle, world):
+    full, offs, _ = synth.reads(world["seqs"], 130, 1500, seed=77)
+    for n in (1, 2, 63, 64, 65, 130):
+        _compare_dp(capi, oracle, world, full[: offs[n]], offs[: n + 1])
+    reads = [world["seqs"][0][1000:1000 + L] for L in (0, 14, 15, 40, 60, 100, 150, 250, 400)]
+    bases, offsets = util.pack_reads(reads)
+    _compare_dp(capi, oracle, world, bases, offsets, min_mapq=0)

@@ -20,8 +20,49 @@ def world(capi, oracle):
     return dict(names=names, seqs=seqs, idx=idx, oidx=oidx, eng=eng)
 
 
-def _compare_batch(capi, oracle, world, bases, offsets, min_mapq=60):
+def _compare_dp(capi, oracle, world, bases, offsets, min_mapq=60):
+    """Base-level alignment on (the default contract, what mappy computes): every region field,
+    every CIGAR, gated hits and decisions against the oracle."""
     eng, oidx = world["eng"], world["oidx"]
+    eng.set_contract(capi.CONTRACT_DP)
+    oidx.opt.cigar = 1
+    n = len(offsets) - 1
+    assign, best, nhits = eng.classify(bases, offsets, min_mapq)
+    regs = eng.dump(capi.DUMP_REGS, capi.REG_DTYPE)
+    reg_off = eng.dump(capi.DUMP_REG_OFFSETS, np.int64)
+    cigs = eng.cigars()
+    hit_off, hits = eng.fetch_hits()
+    raw = bases.tobytes()
+    for r in range(n):
+        oregs, ocigs = oidx.map_cigar(raw[offsets[r]:offsets[r + 1]])
+        gr = regs[reg_off[r]:reg_off[r + 1]]
+        assert len(gr) == len(oregs), f"read {r}: region count {len(gr)} != {len(oregs)} after base-level alignment"
+        for name in capi.REG_DTYPE.names:
+            assert np.array_equal(gr[name], oregs[name]), f"read {r}: region field {name}: {gr[name]} != {oregs[name]}"
+        assert cigs[reg_off[r]:reg_off[r + 1]] == ocigs, f"read {r}: CIGAR"
+    oassign, obest, onh, oflat = oidx.classify(bases, offsets, min_mapq)
+    assert np.array_equal(assign, oassign)
+    assert np.array_equal(nhits, onh)
+    for name in capi.HIT_DTYPE.names:
+        assert np.array_equal(best[name], obest[name]), name
+        assert np.array_equal(hits[name], oflat[name]), name
+    assert np.array_equal(np.diff(hit_off), onh)
+    return assign, best, nhits
+
+
+def _compare_batch(capi, oracle, world, bases, offsets, min_mapq=60, dp=True):
+    """Stage by stage at the chain level, then -- with `dp` -- the complete path with base-level
+    alignment; returns the decisions of the latter (the default contract)."""
+    out = _compare_chain(capi, oracle, world, bases, offsets, min_mapq)
+    if dp:
+        out = _compare_dp(capi, oracle, world, bases, offsets, min_mapq)
+    return out
+
+
+def _compare_chain(capi, oracle, world, bases, offsets, min_mapq=60):
+    eng, oidx = world["eng"], world["oidx"]
+    eng.set_contract(capi.CONTRACT_CHAIN)
+    oidx.opt.cigar = 0
     n = len(offsets) - 1
     assign, best, nhits = eng.classify(bases, offsets, min_mapq)
     mz = eng.dump(capi.DUMP_MINIMIZERS, capi.MZ_DTYPE)
