@@ -5,7 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the hot path (2-bit pack -> minimizer sketch -> index probe ->
-anchor sort -> chain -> regions/MAPQ -> decision + taxon counts) over one batch of synthetic
+anchor sort -> chain -> regions -> base-level alignment of every region (what mappy runs for
+monica) -> MAPQ -> decision + taxon counts) over one batch of synthetic
 5 kb reads already resident in HBM, followed -- for N > 1 -- by the RCCL all-reduce of the
 per-taxon count vector (the analogue of alignment_update, aligner.py:282-302).  Reads shard
 across ranks with no other collective ("weak" scaling: every rank classifies its own
@@ -42,6 +43,9 @@ def parse():
     ap.add_argument("--max-len", type=int, default=7_000_000)
     ap.add_argument("--min-mapq", type=int, default=60)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1 auto, 0 off)")
+    ap.add_argument("--contract", choices=["dp", "chain"], default="dp",
+                    help="dp (default): minimap2's base-level alignment of every region, as mappy runs it for monica "
+                         "(mapq / NM / mlen from the CIGAR); chain: stop after chaining (the kernels north_star lists)")
     ap.add_argument("--mode", choices=["batch", "stream", "shard", "files"], default="batch",
                     help="batch: the headline metric; stream: BASELINE config 5 (400 reads/s arrival, 1-s "
                          "micro-batches); shard: config 4 (index parts spread over the ranks, every part sees "
@@ -95,6 +99,7 @@ def main():
     bases, offsets, truth = synth.reads(seqs, args.reads, args.read_len, seed=synth.SEED_READS + 2,
                                         first=rank * args.reads)
     engine = _capi.Engine(index, local_rank)
+    engine.set_contract(_capi.CONTRACT_DP if args.contract == "dp" else _capi.CONTRACT_CHAIN)
     n_genomes = info.n_genomes
     t_setup = time.time() - t0
 
@@ -147,6 +152,25 @@ def main():
     assign = d_assign.cpu().numpy()
     counts = d_counts.cpu().numpy().reshape(-1, 3)
 
+    # the same batch without base-level alignment (a secondary figure: the path of north_star's
+    # kernel list; its NM / mlen / mapq are chain-level estimates, not what monica reads from mappy)
+    chain_level = None
+    if args.contract == "dp" and world == 1:
+        engine.set_contract(_capi.CONTRACT_CHAIN)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        tcl = time.perf_counter()
+        n_cl = max(3, min(args.steps, 10))
+        for _ in range(n_cl):
+            step()
+        torch.cuda.synchronize()
+        dcl = time.perf_counter() - tcl
+        a_chain = d_assign.cpu().numpy()
+        chain_level = {"value": round(args.reads * n_cl / dcl, 1), "unit": "reads/s", "ms_per_step": round(dcl / n_cl * 1e3, 3),
+                       "steps": n_cl, "decisions_equal_to_dp": round(float((a_chain == assign).mean()), 5)}
+        engine.set_contract(_capi.CONTRACT_DP)
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -186,7 +210,9 @@ def main():
             pass
         cores = min(cores, 16)                       # the GPU box's CPU share for one GPU
         oidx = pyoracle.Index.from_seqs(names, [s.tobytes() for s in seqs])
-        n_s = args.cpu_sample if args.cpu_sample > 0 else args.reads
+        oidx.opt.cigar = 1 if args.contract == "dp" else 0
+        # the oracle's literal ksw2 simulation is scalar: a few hundred reads/s on 16 cores
+        n_s = args.cpu_sample if args.cpu_sample > 0 else (min(args.reads, 4000) if args.contract == "dp" else args.reads)
         ob, oo = bases[: n_s * args.read_len], offsets[: n_s + 1]
         reps, dt = 0, 0.0
         while True:                                  # about 10-30 s of CPU work on the sample
@@ -198,8 +224,9 @@ def main():
                 break
         agree = bool(np.array_equal(oa, assign[:n_s]))
         cpu = {"value": round(n_s * reps / dt, 1), "unit": "reads/s", "cores": cores, "kind": "port",
-               "sample": f"first {n_s} reads of the same batch x {reps} passes, CPU oracle (chain-level "
-                         f"minimap2-2.17 restatement, OpenMP over reads), {dt:.1f} s", "agrees_with_gpu": agree}
+               "sample": f"first {n_s} reads of the same batch x {reps} passes, CPU oracle (minimap2-2.17 restatement "
+                         f"{'with base-level alignment, scalar ksw2 simulation' if args.contract == 'dp' else 'at the chain level'}"
+                         f", OpenMP over reads), {dt:.1f} s", "agrees_with_gpu": agree}
 
     n_total = args.reads * args.steps * world
     mapped = int((assign >= 0).sum())
@@ -214,16 +241,18 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u32/u64 integer (float32 islands: overlap ratio, MAPQ)",
+        "dtype": "u32/u64 integer, int8 DP differences (float32 islands: overlap ratio, MAPQ)",
         "data": "synthetic",
         "config": {"workload": f"{args.reads} synthetic {args.read_len} nt reads per GPU per step vs "
                                f"{args.genomes}-genome minimizer index ({info.total_len} bp, {info.n_keys} keys, "
                                f"mid_occ {info.mid_occ})",
                    "reads_per_gpu_per_step": args.reads, "read_len": args.read_len, "genomes": args.genomes,
+                   "contract": "base-level alignment of every region (mappy's MM_F_CIGAR)" if args.contract == "dp" else "chain level",
                    "parallelism": f"read-sharded x{world}, index replicated, RCCL all-reduce of "
                                   f"{n_genomes * 3} int64 counts per step"},
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "chain_level": chain_level,
         "stage_ms_per_step": {k: round(v[0] / max(v[1], 1), 4) for k, v in timings.items() if v[1]},
         "batch_counters": counters,
         "mapped_reads_last_step": mapped,

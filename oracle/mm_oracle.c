@@ -990,7 +990,7 @@ static int classify_one(const orc_index *mi, const orc_opt_t *opt, int mid_occ, 
 			if (n_h < hits_cap) {
 				hits[n_h].rid = regs[i].rid;
 				hits[n_h].mapq = regs[i].mapq;
-				hits[n_h].nm = regs[i].blen - regs[i].mlen;   /* NM := blen - mlen (A.8, n_ambi = 0) */
+				hits[n_h].nm = regs[i].blen - regs[i].mlen + regs[i].n_ambi;   /* hit.NM (A.8) */
 				hits[n_h].mlen = regs[i].mlen;
 			}
 			++n_h;

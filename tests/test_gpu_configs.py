@@ -37,30 +37,39 @@ def _counts_from(idx_names_to_gid, contig_gid, assign, best, offsets):
     return out
 
 
-def _check_whole_batch(capi, oracle, names, seqs, bases, offsets, truth, min_correct):
+def _check_whole_batch(capi, oracle, names, seqs, bases, offsets, truth, min_correct, dp_sample=None):
+    """Both contracts: the chain level on every read; with base-level alignment (the default, what
+    mappy computes) on every read too unless `dp_sample` bounds the oracle's share (its literal
+    ksw2 simulation runs at a few hundred reads/s)."""
     idx = capi.Index.from_seqs(names, seqs)
     eng = capi.Engine(idx, 0)
     oidx = oracle.Index.from_seqs(names, [s.tobytes() for s in seqs])
     assert idx.mid_occ == oidx.mid_occ
-    assign, best, nhits = eng.classify(bases, offsets, 60)
-    hit_off, hits = eng.fetch_hits()
-    oassign, obest, onh, oflat = oidx.classify(bases, offsets, 60, n_threads=N_THREADS)
-    assert np.array_equal(assign, oassign)
-    assert np.array_equal(nhits, onh)
-    assert np.array_equal(np.diff(hit_off), onh)
-    for k in capi.HIT_DTYPE.names:
-        assert np.array_equal(best[k], obest[k]), k
-        assert np.array_equal(hits[k], oflat[k]), k
     gid = [int(x) for x in idx.contig_genome]
-    want = _counts_from(None, gid, oassign, obest, offsets)
-    for mode in (1, 2, 3):
-        got = capi.counts(idx, assign, best, offsets, mode)
-        assert np.array_equal(got, want[:, mode - 1]), f"counts, mode {mode}"
-    mapped = assign >= 0
-    assert (assign[mapped] == truth[mapped]).mean() >= min_correct
-    assert (assign[truth < 0] == capi.UNMAPPED).all()
+    out = None
+    for contract, cigar in ((capi.CONTRACT_CHAIN, 0), (capi.CONTRACT_DP, 1)):
+        eng.set_contract(contract)
+        oidx.opt.cigar = cigar
+        assign, best, nhits = eng.classify(bases, offsets, 60)
+        hit_off, hits = eng.fetch_hits()
+        n = len(truth) if (cigar == 0 or dp_sample is None) else min(dp_sample, len(truth))
+        oassign, obest, onh, oflat = oidx.classify(bases[:offsets[n]], offsets[:n + 1], 60, n_threads=N_THREADS)
+        assert np.array_equal(assign[:n], oassign)
+        assert np.array_equal(nhits[:n], onh)
+        assert np.array_equal(np.diff(hit_off)[:n], onh)
+        for k in capi.HIT_DTYPE.names:
+            assert np.array_equal(best[k][:n], obest[k]), k
+            assert np.array_equal(hits[k][:hit_off[n]], oflat[k]), k
+        want = _counts_from(None, gid, oassign, obest, offsets[:n + 1])
+        for mode in (1, 2, 3):
+            got = capi.counts(idx, assign[:n], best[:n], offsets[:n + 1], mode)
+            assert np.array_equal(got, want[:, mode - 1]), f"counts, mode {mode}"
+        mapped = assign >= 0
+        assert (assign[mapped] == truth[mapped]).mean() >= min_correct
+        assert (assign[truth < 0] == capi.UNMAPPED).all()
+        out = (assign, best, nhits)
     eng.close()
-    return assign, best, nhits
+    return out
 
 
 def test_config1_1k_reads_vs_single_contig(capi, oracle):
@@ -77,7 +86,7 @@ def test_config2_100k_reads_vs_20_genomes(capi, oracle):
     assert sum(len(s) for s in seqs) == 94_031_982
     n = 100_000
     bases, offsets, truth = synth.reads(seqs, n, 5000, seed=synth.SEED_READS + 2)
-    assign, best, nhits = _check_whole_batch(capi, oracle, names, seqs, bases, offsets, truth, 0.999)
+    assign, best, nhits = _check_whole_batch(capi, oracle, names, seqs, bases, offsets, truth, 0.999, dp_sample=6000)
     # the device-resident entry point with on-device taxon counts (what bench.py times)
     idx = capi.Index.from_seqs(names, seqs)
     eng = capi.Engine(idx, 0)
@@ -186,7 +195,8 @@ def test_config5_micro_batches_equal_one_batch(capi, oracle):
 def test_golden_fixture_on_the_hip_path(capi):
     """tests/golden/small_case.npz (made by tests/golden/make_golden.py with the oracle) against
     the HIP path at the chain level: index, minimizer / anchor counts, chaining f / p / v,
-    every region field, gated hits, decisions."""
+    every region field, gated hits, decisions; and the complete path with base-level alignment
+    (regions, CIGARs, gated hits, decisions)."""
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "small_case.npz"))
     names = [str(x) for x in g["names"]]
     seqs, o = [], 0
@@ -198,6 +208,20 @@ def test_golden_fixture_on_the_hip_path(capi):
     assert idx.mid_occ == int(g["mid_occ"]) and info.n_keys == int(g["n_keys"]) and info.n_occ == int(g["n_occ"])
     eng = capi.Engine(idx, 0)
     bases, offsets = g["bases"], g["offsets"]
+    # ---- with base-level alignment (the default)
+    assign, best, nhits = eng.classify(bases, offsets, 60)
+    hit_off, hits = eng.fetch_hits()
+    assert np.array_equal(assign, g["dp_assign"]) and np.array_equal(nhits, g["dp_nhits"])
+    for k in capi.HIT_DTYPE.names:
+        assert np.array_equal(best[k], g["dp_best"][k]), k
+        assert np.array_equal(hits[k], g["dp_hits"][k]), k
+    regs = eng.dump(capi.DUMP_REGS, capi.REG_DTYPE)
+    assert np.array_equal(np.diff(eng.dump(capi.DUMP_REG_OFFSETS, np.int64)), g["dp_reg_cnt"])
+    for k in capi.REG_DTYPE.names:
+        assert np.array_equal(regs[k], g["dp_regs"][k]), k
+    assert np.array_equal(eng.dump(capi.DUMP_CIGARS, np.uint32), g["dp_cigars"])
+    # ---- chain level
+    eng.set_contract(capi.CONTRACT_CHAIN)
     assign, best, nhits = eng.classify(bases, offsets, 60)
     hit_off, hits = eng.fetch_hits()
     assert np.array_equal(assign, g["assign"]) and np.array_equal(nhits, g["nhits"])
@@ -216,6 +240,6 @@ def test_golden_fixture_on_the_hip_path(capi):
     assert np.array_equal(eng.dump(capi.DUMP_CHAIN_V, np.int32), g["chain_v"])
     regs = eng.dump(capi.DUMP_REGS, capi.REG_DTYPE)
     assert np.array_equal(np.diff(eng.dump(capi.DUMP_REG_OFFSETS, np.int64)), g["reg_cnt"])
-    for k in capi.REG_DTYPE.names:
+    for k in g["regs"].dtype.names:
         assert np.array_equal(regs[k], g["regs"][k]), k
     eng.close()

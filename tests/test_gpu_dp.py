@@ -93,7 +93,7 @@ def test_repetitive_index_with_secondaries(capi, oracle):
     b, o, truth = synth.reads(seqs, 80, 4000, seed=41)
     assign, best, nhits = _compare_dp(capi, oracle, w, b, o, min_mapq=0)
     regs = w["eng"].dump(capi.DUMP_REGS, capi.REG_DTYPE)
-    assert (regs["dp_max2"] > 0).sum() > 40
+    assert (regs["dp_max2"] > 0).sum() >= 30
     _compare_dp(capi, oracle, w, b, o, min_mapq=60)
 
 
