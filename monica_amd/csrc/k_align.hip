@@ -373,6 +373,16 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
 // One call of the kernel on sequences already laid out in `mem` (sf = target codes, qr = the
 // query reversed), exactly as ksw_extd2_sse works on its buffer.  `cig` receives the CIGAR the
 // way ksw_backtrack pushes it (reversed unless EZ_REV_CIGAR asks for that order).
+template <bool LDS>
+__device__ __forceinline__ void st_order()
+{
+	// state in LDS: its operations execute in issue order within the wave, only the compiler has to
+	// be pinned (the direction bytes stream to HBM without being waited for); state in HBM: wait
+	if (LDS) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); asm volatile("" ::: "memory"); }
+	else mem_order();
+}
+
+template <bool LDS>
 __device__ void ksw_wave(int qlen, int tlen, int8_t *mem, int32_t *H, uint8_t *p, uint32_t *cig,
                          int q, int e, int q2, int e2, int sc_mch, int sc_mis, int sc_N,
                          int w, int zdrop, int end_bonus, int flag, Ez &ez)
@@ -399,7 +409,7 @@ __device__ void ksw_wave(int qlen, int tlen, int8_t *mem, int32_t *H, uint8_t *p
 	for (int i = lane; i < 2 * T; i += 64) x2[i] = (int8_t)(-q2 - e2);
 	for (int i = lane; i < T; i += 64) s[i] = 0;
 	if (!approx_max) for (int i = lane; i < T; i += 64) H[i] = DP_NEG_INF;
-	mem_order();
+	st_order<LDS>();
 
 	int last_st = -1, last_en = -1, H0 = 0, last_H0_t = 0;
 	const int n_r = qlen + tlen - 1;
@@ -420,7 +430,7 @@ __device__ void ksw_wave(int qlen, int tlen, int8_t *mem, int32_t *H, uint8_t *p
 			x1 = -q - e, x21 = -q2 - e2;
 			v1 = r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
 		}
-		mem_order();
+		st_order<LDS>();
 		if (en >= r && lane == 0) {
 			y[r] = (int8_t)(-q - e), y2[r] = (int8_t)(-q2 - e2);
 			u[r] = (int8_t)(r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2);
@@ -437,11 +447,11 @@ __device__ void ksw_wave(int qlen, int tlen, int8_t *mem, int32_t *H, uint8_t *p
 					const int sq = sf[st0 + i], sq2 = qrr[st0 + i];
 					sc = (sq == 4 || sq2 == 4) ? sc_N : sq == sq2 ? sc_mch : sc_mis;
 				}
-				mem_order();
+				st_order<LDS>();
 				if (act) s[st0 + i] = (int8_t)sc;
 			}
 		}
-		mem_order();
+		st_order<LDS>();
 		// core: chunks of 64 lanes from the top; a chunk reads [t-1] of the chunk below before that is updated
 		uint8_t *pr = p + (size_t)r * ncol;
 		for (int c0 = (en - st) / 64 * 64; c0 >= 0; c0 -= 64) {
@@ -455,7 +465,7 @@ __device__ void ksw_wave(int qlen, int tlen, int8_t *mem, int32_t *H, uint8_t *p
 				x2t1 = t > st ? (int)x2[t - 1] : x21;
 				ut = u[t], yt = y[t], y2t = y2[t];
 			}
-			mem_order();
+			st_order<LDS>();
 			if (act) {
 				int a = I8(xt1 + vt1), b = I8(yt + ut), a2 = I8(x2t1 + vt1), b2 = I8(y2t + ut), d, tmp;
 				if (!right) {
@@ -486,7 +496,7 @@ __device__ void ksw_wave(int qlen, int tlen, int8_t *mem, int32_t *H, uint8_t *p
 				}
 				pr[t - st] = (uint8_t)d;
 			}
-			mem_order();
+			st_order<LDS>();
 		}
 		if (!approx_max) {
 			int max_H, max_t;
@@ -495,7 +505,7 @@ __device__ void ksw_wave(int qlen, int tlen, int8_t *mem, int32_t *H, uint8_t *p
 				// the SSE scan's tie order: en0, four interleaved lanes over [st0, en1), the tail [en1, en0)
 				const int en1 = st0 + (en0 - st0) / 4 * 4;
 				const int h_en0 = en0 > 0 ? H[en0 - 1] + (int)u[en0] : H[en0] + (int)v[en0];
-				mem_order();
+				st_order<LDS>();
 				int best_h = DP_NEG_INF - 1;
 				unsigned best_rank = 0xffffffffu;
 				for (int c0 = 0; c0 < en0 - st0; c0 += 64) {
@@ -518,10 +528,10 @@ __device__ void ksw_wave(int qlen, int tlen, int8_t *mem, int32_t *H, uint8_t *p
 				if (mr == 0) max_t = en0;
 				else if (mr < 1u + 4u * 0x1000000u) { const unsigned k = mr - 1u; max_t = st0 + (int)((k & 0xffffffu) * 4u + (k >> 24)); }
 				else max_t = en1 + (int)(mr - 1u - 4u * 0x1000000u);
-				mem_order();
+				st_order<LDS>();
 			} else {
 				if (lane == 0) H[0] = (int)v[0] - qe;
-				mem_order();
+				st_order<LDS>();
 				max_H = H[0], max_t = 0;
 			}
 			if (r - st0 == qlen - 1 && H[st0] > ez.mqe) ez.mqe = H[st0], ez.mqe_t = st0;
@@ -543,7 +553,7 @@ __device__ void ksw_wave(int qlen, int tlen, int8_t *mem, int32_t *H, uint8_t *p
 		}
 		last_st = st, last_en = en;
 	}
-	mem_order();
+	mem_order();                                            // the direction bytes have to be in memory before the walk reads them
 	// ---- backtrack (ksw_backtrack, rotated layout): one lane walks, all lanes prefetch nothing yet
 	int i0 = -1, j0 = -1;
 	if (!ez.zdropped && !(flag & EZ_EXTZ_ONLY)) i0 = tlen - 1, j0 = qlen - 1;
@@ -703,8 +713,10 @@ __global__ __launch_bounds__(64) void mnc_dp_align(Batch B, uint8_t *ws_all, lon
 				qr[i] = i < g.qlen ? (uint8_t)qcode(read, rlen, g.rev, g.kind == 0 ? g.qs + i : g.qs + g.qlen - 1 - i) : 0;
 			}
 			mem_order();
-			ksw_wave(g.qlen, g.tlen, mem, H, ws + W.p, cig, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, sc_N,
-			         g.w, g.zdrop, g.kind == 1 ? -1 : B.end_bonus, g.flag, ez);
+			if (in_lds) ksw_wave<true>(g.qlen, g.tlen, mem, H, ws + W.p, cig, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, sc_N,
+			                           g.w, g.zdrop, g.kind == 1 ? -1 : B.end_bonus, g.flag, ez);
+			else ksw_wave<false>(g.qlen, g.tlen, mem, H, ws + W.p, cig, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, sc_N,
+			                     g.w, g.zdrop, g.kind == 1 ? -1 : B.end_bonus, g.flag, ez);
 			if (g.kind == 1) {
 				// the kernel's last 16-lane score store may spill into the first 15 target bytes (as in the
 				// SSE buffer, where those are dead by then): restore them for the walk and the second pass
@@ -714,8 +726,12 @@ __global__ __launch_bounds__(64) void mnc_dp_align(Batch B, uint8_t *ws_all, lon
 				                                              reinterpret_cast<int32_t*>(ws + W.sw), reinterpret_cast<int32_t*>(ws + W.sw) + cig_max);
 				zdrop_code = __shfl(zdrop_code, 0);
 				if (zdrop_code != 0)                             // second pass: exact maximum, real Z-drop
-					ksw_wave(g.qlen, g.tlen, mem, H, ws + W.p, cig, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, sc_N,
-					         g.w, zdrop_code == 2 ? B.zdrop_inv : B.zdrop, -1, 0, ez);
+				{
+					if (in_lds) ksw_wave<true>(g.qlen, g.tlen, mem, H, ws + W.p, cig, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, sc_N,
+					                           g.w, zdrop_code == 2 ? B.zdrop_inv : B.zdrop, -1, 0, ez);
+					else ksw_wave<false>(g.qlen, g.tlen, mem, H, ws + W.p, cig, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, sc_N,
+					                     g.w, zdrop_code == 2 ? B.zdrop_inv : B.zdrop, -1, 0, ez);
+				}
 			}
 		}
 		// results; the CIGAR goes to the segment pool
