@@ -173,10 +173,11 @@ int mnc_best_hit(const mnc_hit_t *hits, int n, int *best_index /* -1 = ambiguous
 #define MNC_STAGE_REGIONS     9   /* regions, MAPQ, decision, counts                         */
 #define MNC_STAGE_GATHER      10  /* gated hit lists -> CSR (mnc_engine_fetch_hits)          */
 #define MNC_STAGE_DP_PLAN     11  /* chained anchors per region, DP windows, ksw2 segments   */
-#define MNC_STAGE_DP_ALIGN    12  /* ksw2-equivalent two-piece affine DP + backtrack         */
+#define MNC_STAGE_DP_ALIGN    12  /* extensions, unusual gaps: ksw2's kernel in its own layout  */
 #define MNC_STAGE_DP_STITCH   13  /* CIGAR merge / clean-up, mlen, blen, dp_max, Z-drop split */
 #define MNC_STAGE_DP_POST     14  /* second hierarchy pass, DP MAPQ, gate, decision          */
-#define MNC_N_STAGES          15
+#define MNC_STAGE_DP_FILL     15  /* gap filling between seeds: banded two-piece affine DP       */
+#define MNC_N_STAGES          16
 int mnc_engine_set_profiling(mnc_engine *eng, int on);    /* HIP events around every stage */
 int mnc_engine_set_debug(mnc_engine *eng, int mode);      /* test switches, a bit mask: 2 stress build of the
                                                              chaining ring, 4 displacement bytes read from HBM */
@@ -185,7 +186,9 @@ int mnc_engine_get_timings(mnc_engine *eng, double *ms, int64_t *launches, int r
 const char *mnc_stage_name(int stage);
 const char *mnc_stage_kernel(int stage);                  /* kernel symbol, for rocprof matching */
 /* counters of the last batch: [0] minimizers, [1] probe hits, [2] anchors, [3] chains,
- * [4] regions, [5] gated hits, [6] reads with ambiguous bases, [7] table slot reads */
+ * [4] regions, [5] gated hits, [6] reads with ambiguous bases, [7] -; with n >= 12, of the base-level
+ * alignment stage (last round): [8] kernel calls (segments), [9] gap fillings given to the banded kernel's
+ * 32-lane tier, [10] those its 64-lane tier saw, [11] those it handed back to the literal kernel */
 int mnc_engine_get_counters(mnc_engine *eng, int64_t *c, int n);
 
 /* stage dumps of the last batch, for kernel-level parity tests */

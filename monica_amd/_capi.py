@@ -28,10 +28,10 @@ REG_DTYPE = np.dtype([("id", "<i4"), ("parent", "<i4"), ("rid", "<i4"), ("rev", 
 MZ_DTYPE = np.dtype([("hash", "<u4"), ("pos_strand", "<u4")])
 ANCHOR_DTYPE = np.dtype([("x", "<u8"), ("y", "<u8")])
 
-N_STAGES = 15
+N_STAGES = 16
 (STAGE_PACK, STAGE_SKETCH, STAGE_PARTITION, STAGE_PROBE, STAGE_COLLECT, STAGE_SORT, STAGE_SORT2, STAGE_CHAIN,
  STAGE_BACKTRACK, STAGE_REGIONS, STAGE_GATHER, STAGE_DP_PLAN, STAGE_DP_ALIGN, STAGE_DP_STITCH,
- STAGE_DP_POST) = range(N_STAGES)
+ STAGE_DP_POST, STAGE_DP_FILL) = range(N_STAGES)
 (DUMP_MINIMIZERS, DUMP_MZ_OFFSETS, DUMP_ANCHORS, DUMP_AN_OFFSETS, DUMP_CHAIN_F, DUMP_CHAIN_P,
  DUMP_CHAIN_V, DUMP_REGS, DUMP_REG_OFFSETS, DUMP_REP_LEN, DUMP_CIGARS) = range(1, 12)
 CONTRACT_DP, CONTRACT_CHAIN = 0, 1
@@ -349,9 +349,10 @@ class Engine:
         return {names[s]: (float(ms[s]), int(ln[s])) for s in range(N_STAGES)}
 
     def counters(self):
-        c = np.zeros(8, dtype=np.int64)
-        check(lib().mnc_engine_get_counters(self._h, c.ctypes.data, 8))
-        keys = ["minimizers", "probe_hits", "anchors", "chains", "regions", "gated_hits", "ambiguous_reads", "_"]
+        c = np.zeros(12, dtype=np.int64)
+        check(lib().mnc_engine_get_counters(self._h, c.ctypes.data, 12))
+        keys = ["minimizers", "probe_hits", "anchors", "chains", "regions", "gated_hits", "ambiguous_reads", "_",
+                "dp_segments", "dp_fill_tier1", "dp_fill_tier2", "dp_fill_handed_back"]
         return dict(zip(keys, (int(x) for x in c)))
 
     def dump(self, what, dtype):

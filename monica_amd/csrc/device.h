@@ -90,6 +90,7 @@ constexpr uint64_t SEED_LONG_JOIN = 1ULL << 40, SEED_IGNORE = 1ULL << 41, SEED_T
 constexpr int REG_HAS_DP = 1, REG_SPLIT_L = 2, REG_SPLIT_R = 4, REG_SPLIT_INV = 8;
 constexpr int EZ_RIGHT = 0x02, EZ_APPROX_MAX = 0x08, EZ_EXTZ_ONLY = 0x40, EZ_REV_CIGAR = 0x80;
 constexpr int DP_NEG_INF = -0x40000000;
+constexpr int FILL_MAX_LEN = 511;     // longest target / query of a gap filling the banded kernel (k_fill.hip) takes
 
 // one call of the two-piece affine kernel (ksw_extd2): left extension, a gap between two seeds,
 // right extension
@@ -205,10 +206,12 @@ struct Batch {
 	uint32_t *cig_seg, *cig_reg;  // CIGAR pools: per segment, per region
 	int64_t cig_seg_cap, cig_reg_cap;
 	unsigned long long *dp_ctr;   // [0] segments, [1] words in cig_seg, [2] words in cig_reg, [3] align queue,
-	                              // [4] overflow, [5] new regions this round, [6] big segments, [7] big queue
+	                              // [4] overflow, [5] new regions this round, [6] big segments, [7] big queue,
+	                              // [8] first segment of the round, [9] regions this round, [10..15] banded kernel
 	int32_t *work_list;           // region slots to plan / stitch this round
 	int32_t *next_list;           // region slots created by Z-drop splits (next round)
 	int32_t *big_list;            // segment indices for the large-workspace launch
+	int32_t *fill_list1, *fill_list2, *fill_fb;   // banded gap-filling kernel: 32-lane tier, 64-lane tier, handed back
 	int32_t *reg_cnt;             // per read: regions in the skeleton's array (kept + split tails)
 };
 

@@ -43,10 +43,16 @@ void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work,
                     long long big_state, long long big_p, long long big_cig, hipStream_t st);
 size_t dp_align_ws_bytes(long long state_max, long long p_max, long long cig_max);
 int dp_align_prepare(int lds_bytes);
-void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max, long long p_max, long long cig_max, int lds_bytes, int big_pass, hipStream_t st);
+void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max, long long p_max, long long cig_max,
+                     int lds_state, int lds_p, int lds_cig, int big_pass, hipStream_t st);
 void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_list, int n_wg, hipStream_t st);
+size_t dp_fill_p_slot();
+void launch_dp_fill(const Batch &B, int lanes, const int32_t *list, int ctr_n, int ctr_q, int32_t *next_list, int ctr_next,
+                    int32_t *fb_list, int ctr_fb, uint8_t *p_all, int n_wg, hipStream_t st);
+constexpr int DP_WG_FILL = 256 * 16;
 // workspace classes of the alignment kernel: a normal slot per workgroup, a few large ones
 constexpr int DP_LDS_BYTES = 16 * 1024;
+constexpr int DP_LDS0_STATE = 4 * 1024, DP_LDS0_P = 10 * 1024, DP_LDS0_CIG = 256;   // pass 0: 15 KB per workgroup
 constexpr int DP_WG_SMALL = 2048, DP_WG_BIG = 8;
 constexpr long long DP_STATE_SMALL = 96 * 1024, DP_P_SMALL = 1 << 20, DP_CIG_SMALL = 4096;
 constexpr long long DP_STATE_BIG = 13 * 32768, DP_P_BIG = 256LL << 20, DP_CIG_BIG = 65536;
@@ -364,6 +370,7 @@ struct mnc_engine {
 	// base-level alignment stage
 	int contract = MNC_CONTRACT_DP;
 	Buf ca, ca_cnt, chain_dst, regdp, segs, cig_seg, cig_reg, dp_ctr, work_a, work_b, big_list, reg_cnt, regs2, dp_ws, dp_ws_big;
+	Buf fill1, fill2, fill_fb, fill_p;
 	size_t seg_cap_override = 0, cig_cap_override = 0;
 	int debug = 0;                           // bit mask (tests): 2 stress build of the chaining ring, 4 displacement bytes read from HBM
 	// last batch
@@ -380,11 +387,11 @@ struct mnc_engine {
 };
 
 static const char *STAGE_NAME[MNC_N_STAGES] = { "pack", "sketch", "partition", "probe", "collect", "offsets", "sort", "chain", "backtrack", "regions", "gather",
-                                                "dp_plan", "dp_align", "dp_stitch", "dp_post" };
+                                                "dp_plan", "dp_align", "dp_stitch", "dp_post", "dp_fill" };
 static const char *STAGE_KERNEL[MNC_N_STAGES] = {
 	"mnc_pack_bases", "mnc_sketch_minimizers", "mnc_partition_queries", "mnc_probe_buckets", "mnc_collect_hits",
 	"mnc_bin_reads", "mnc_expand_sort", "mnc_chain_dp_ring", "mnc_chain_tail", "mnc_regions_decide", "mnc_gather_hits",
-	"mnc_dp_plan", "mnc_dp_align", "mnc_dp_stitch", "mnc_regions_post" };
+	"mnc_dp_plan", "mnc_dp_align", "mnc_dp_stitch", "mnc_regions_post", "mnc_dp_fill" };
 
 extern "C" const char *mnc_stage_name(int s) { return s >= 0 && s < MNC_N_STAGES ? STAGE_NAME[s] : nullptr; }
 extern "C" const char *mnc_stage_kernel(int s) { return s >= 0 && s < MNC_N_STAGES ? STAGE_KERNEL[s] : nullptr; }
@@ -449,7 +456,7 @@ extern "C" void mnc_engine_destroy(mnc_engine *e)
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
 	Buf *all[] = { &e->gap_lut, &e->logf_lut, &e->logf_a_lut, &e->ca, &e->ca_cnt, &e->chain_dst, &e->regdp, &e->segs, &e->cig_seg, &e->cig_reg, &e->dp_ctr,
-	               &e->work_a, &e->work_b, &e->big_list, &e->reg_cnt, &e->regs2, &e->dp_ws, &e->dp_ws_big, &e->in_bases, &e->in_offsets, &e->out_assign, &e->out_best, &e->out_nhits,
+	               &e->work_a, &e->work_b, &e->big_list, &e->reg_cnt, &e->regs2, &e->dp_ws, &e->dp_ws_big, &e->fill1, &e->fill2, &e->fill_fb, &e->fill_p, &e->in_bases, &e->in_offsets, &e->out_assign, &e->out_best, &e->out_nhits,
 	               &e->packed, &e->mz, &e->hits, &e->hist_tm, &e->q_off, &e->qrec, &e->bhits, &e->bhit_cnt, &e->ambig, &e->mz_cnt, &e->hit_cnt, &e->rep_len, &e->an_cnt, &e->an_off,
 	               &e->n_chain, &e->n_reg, &e->best_mlen, &e->hist_sums, &e->hist_offs, &e->scan_sums, &e->hit_off, &e->a, &e->f, &e->p, &e->v, &e->t, &e->u,
 	               &e->chains_tmp, &e->regs, &e->regx, &e->k64a, &e->k64b, &e->tmp_i32, &e->gated,
@@ -577,6 +584,22 @@ struct StageTimer {
 	StageTimer(mnc_engine *e_, int s_) : e(e_), s(s_) { if (e->profiling) (void)hipEventRecord(e->ev[s][0], e->stream); }
 	~StageTimer() { if (e->profiling) { (void)hipEventRecord(e->ev[s][1], e->stream); e->ev_used[s] = true; } }
 };
+}
+
+// the gap fillings the banded kernel takes: 32 lanes per segment, then 64 for those whose band
+// could not be proven wide enough
+static void align_fill(const Batch &B, mnc_engine *e, hipStream_t st)
+{
+	launch_dp_fill(B, 32, B.fill_list1, 10, 13, B.fill_list2, 11, B.fill_fb, 12, e->fill_p.as<uint8_t>(), DP_WG_FILL, st);
+	launch_dp_fill(B, 64, B.fill_list2, 11, 14, B.fill_fb, 12, B.fill_fb, 12, e->fill_p.as<uint8_t>(), DP_WG_FILL, st);
+}
+// everything else on the literal kernel: extensions and unusual gaps, the large ones, what the banded kernel handed back
+static void align_rest(const Batch &B, mnc_engine *e, hipStream_t st)
+{
+	// pass 0: the small all-in-LDS layout (extensions of most reads); what does not fit joins pass 2's list
+	launch_dp_align(B, e->dp_ws.as<uint8_t>(), 2 * DP_WG_SMALL, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS0_STATE, DP_LDS0_P, DP_LDS0_CIG, 0, st);
+	launch_dp_align(B, e->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 1, st);
+	launch_dp_align(B, e->dp_ws.as<uint8_t>(), DP_WG_SMALL, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, 0, 2, st);
 }
 
 // ---------------------------------------------------------------- one batch, device-resident
@@ -796,13 +819,15 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 		ENS2(segs, seg_cap * sizeof(Seg)); ENS2(cig_seg, cig_cap * 4); ENS2(cig_reg, cig_cap * 4);
 		ENS2(work_a, ns * 4); ENS2(work_b, ns * 4); ENS2(big_list, seg_cap * 4); ENS2(reg_cnt, (nr + 1) * 4); ENS2(regs2, ns * sizeof(mnc_reg_t));
 		const size_t ws_small = dp_align_ws_bytes(DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL), ws_big = dp_align_ws_bytes(DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG);
-		ENS2(dp_ws, ws_small * DP_WG_SMALL); ENS2(dp_ws_big, ws_big * DP_WG_BIG);
+		ENS2(dp_ws, ws_small * DP_WG_SMALL * 2); ENS2(dp_ws_big, ws_big * DP_WG_BIG);
+		ENS2(fill1, seg_cap * 4); ENS2(fill2, seg_cap * 4); ENS2(fill_fb, seg_cap * 4); ENS2(fill_p, dp_fill_p_slot() * DP_WG_FILL);
 #undef ENS2
 		if (rc2) return rc2;
 		B.ca = e->ca.as<Anchor>(), B.ca_cnt = e->ca_cnt.as<int32_t>(), B.chain_dst = e->chain_dst.as<int32_t>(), B.regdp = e->regdp.as<RegDP>();
 		B.segs = e->segs.as<Seg>(), B.seg_cap = (int64_t)seg_cap, B.cig_seg = e->cig_seg.as<uint32_t>(), B.cig_reg = e->cig_reg.as<uint32_t>();
 		B.cig_seg_cap = B.cig_reg_cap = (int64_t)cig_cap, B.dp_ctr = e->dp_ctr.as<unsigned long long>();
 		B.big_list = e->big_list.as<int32_t>(), B.reg_cnt = e->reg_cnt.as<int32_t>();
+		B.fill_list1 = e->fill1.as<int32_t>(), B.fill_list2 = e->fill2.as<int32_t>(), B.fill_fb = e->fill_fb.as<int32_t>();
 		int32_t *lists[2] = { e->work_a.as<int32_t>(), e->work_b.as<int32_t>() };
 		B.next_list = lists[0];                          // the regions kernel files every kept region here
 		HIP_TRY(hipMemsetAsync(e->dp_ctr.p, 0, 16 * 8, st));
@@ -817,15 +842,18 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 			if (round == 0) {
 				{ StageTimer t(e, MNC_STAGE_DP_PLAN);   launch_dp_plan(B, work, max_work, (int)DP_STATE_SMALL, DP_P_SMALL, (int)DP_CIG_SMALL, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, st); }
 				{
+					StageTimer t(e, MNC_STAGE_DP_FILL);
+					align_fill(B, e, st);
+				}
+				{
 					StageTimer t(e, MNC_STAGE_DP_ALIGN);
-					launch_dp_align(B, e->dp_ws.as<uint8_t>(), DP_WG_SMALL, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, st);
-					launch_dp_align(B, e->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 1, st);
+					align_rest(B, e, st);
 				}
 				{ StageTimer t(e, MNC_STAGE_DP_STITCH); launch_dp_stitch(B, work, next, 4096, st); }
 			} else {
 				launch_dp_plan(B, work, max_work, (int)DP_STATE_SMALL, DP_P_SMALL, (int)DP_CIG_SMALL, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, st);
-				launch_dp_align(B, e->dp_ws.as<uint8_t>(), DP_WG_SMALL, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, st);
-				launch_dp_align(B, e->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 1, st);
+				align_fill(B, e, st);
+				align_rest(B, e, st);
 				launch_dp_stitch(B, work, next, 4096, st);
 			}
 			launch_dp_round_end(B, st);
@@ -970,6 +998,12 @@ extern "C" int mnc_engine_get_counters(mnc_engine *e, int64_t *c, int n)
 	for (size_t r = 0; r < nr; ++r) c[0] += a[r], c[1] += b[r], c[3] += d[r], c[4] += g[r], c[5] += h[r], c[6] += amb[r] ? 1 : 0;
 	c[2] = e->last_total_anchors;
 	c[7] = 0;
+	if (n >= 12 && B.contract == MNC_CONTRACT_DP && e->dp_ctr.p) {
+		unsigned long long d[16];
+		HIP_TRY(hipMemcpy(d, e->dp_ctr.p, sizeof(d), hipMemcpyDeviceToHost));
+		c[8] = (int64_t)d[0], c[9] = (int64_t)d[10], c[10] = (int64_t)d[11], c[11] = (int64_t)d[12];
+
+	}
 	return MNC_OK;
 }
 

@@ -288,6 +288,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 			d.n_seg = 0, d.has_left = d.has_right = 0;
 		} else {
 			Seg *sg = B.segs + s0;
+			int n_tier[2] = { 0, 0 };
 			auto emit = [&](Seg g) {
 				g.read = (int32_t)rd, g.reg = (int32_t)rslot, g.rid = rid, g.rev = rev;
 				g.n_cigar = 0, g.zdropped = 0, g.zdrop_code = 0, g.max = 0, g.max_t = g.max_q = -1, g.score = DP_NEG_INF, g.reach_end = 0, g.mqe_t = -1, g.cig_off = 0;
@@ -306,6 +307,21 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 				if (g.big == 1) {
 					const unsigned long long bi = atomicAdd(&B.dp_ctr[6], 1ULL);
 					B.big_list[bi] = (int32_t)(sg - B.segs);
+				} else if (g.big == 0 && g.kind == 1 && g.w == bw && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= FILL_MAX_LEN && g.qlen <= FILL_MAX_LEN) {
+					// a gap between two seeds whose matrix the band never clips: the banded kernel of
+					// k_fill.hip, 32 lanes per segment when |tlen - qlen| leaves a band worth trying, else 64
+					const int ad = g.tlen > g.qlen ? g.tlen - g.qlen : g.qlen - g.tlen;
+					// the 32-lane tier only when its proof has a chance: the bound a band of that width leaves
+					// against what a read with ~10 % errors scores (~1.28 per base)
+					int tier = (62 - ad) / 2 >= 12 ? 1 : (126 - ad) / 2 >= 8 ? 2 : 0;
+					if (tier == 1) {
+						const int bb = (62 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
+						const int g1 = B.gap_q + B.gap_e * (bb + 1), g2 = B.gap_q2 + B.gap_e2 * (bb + 1);
+						const int U = B.sc_a * (mn - bb - 1) - 2 * (g1 < g2 ? g1 : g2);
+						if (U * 25 > mn * 32) tier = 2;                   // trying costs one unit, failing two more: worth it below even odds
+					}
+					if (tier) g.big = 3 + tier, ++n_tier[tier - 1];          // not for the literal kernel's first pass
+
 				}
 				*sg++ = g;
 			};
@@ -334,6 +350,14 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 				g.kind = 2, g.ts = re, g.tlen = re0 - re, g.qs = qe, g.qlen = qe0 - qe, g.w = bw;
 				g.zdrop = B.zdrop, g.flag = EZ_EXTZ_ONLY, g.ai = cnt1 - 1;
 				emit(g);
+			}
+			// the banded kernel's lists: one reservation per region and tier
+			for (int tier = 0; tier < 2; ++tier) {
+				if (n_tier[tier] == 0) continue;
+				unsigned long long fi = atomicAdd(&B.dp_ctr[10 + tier], (unsigned long long)n_tier[tier]);
+				int32_t *lst = tier == 0 ? B.fill_list1 : B.fill_list2;
+				for (int k = 0; k < n_seg; ++k)
+					if (B.segs[s0 + k].big == 4 + tier) lst[fi++] = (int32_t)(s0 + k);
 			}
 		}
 	}
@@ -370,6 +394,16 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
 
 #define I8(v) ((int)(int8_t)(v))
 
+// LDS pointers keep their address space in the type, so that the compiler emits ds_* instructions
+// (a generic pointer that may be LDS or HBM costs a flat access: several times the latency)
+typedef __attribute__((address_space(3))) int8_t *lds_i8p;
+typedef __attribute__((address_space(3))) uint8_t *lds_u8p;
+typedef __attribute__((address_space(3))) int32_t *lds_i32p;
+typedef __attribute__((address_space(3))) uint32_t *lds_u32p;
+template <class P> struct PtrTraits;
+template <> struct PtrTraits<int8_t*> { typedef uint8_t *u8; static constexpr bool lds = false; };
+template <> struct PtrTraits<lds_i8p> { typedef lds_u8p u8; static constexpr bool lds = true; };
+
 // One call of the kernel on sequences already laid out in `mem` (sf = target codes, qr = the
 // query reversed), exactly as ksw_extd2_sse works on its buffer.  `cig` receives the CIGAR the
 // way ksw_backtrack pushes it (reversed unless EZ_REV_CIGAR asks for that order).
@@ -382,11 +416,13 @@ __device__ __forceinline__ void st_order()
 	else mem_order();
 }
 
-template <bool LDS>
-__device__ void ksw_wave(int qlen, int tlen, int8_t *mem, int32_t *H, uint8_t *p, uint32_t *cig,
+template <class S8, class S32, class PP, class CP>
+__device__ void ksw_wave(int qlen, int tlen, S8 mem, S32 H, PP p, CP cig,
                          int q, int e, int q2, int e2, int sc_mch, int sc_mis, int sc_N,
                          int w, int zdrop, int end_bonus, int flag, Ez &ez)
 {
+	constexpr bool LDS = PtrTraits<S8>::lds;
+	typedef typename PtrTraits<S8>::u8 SU8;
 	const int lane = threadIdx.x;
 	const bool approx_max = (flag & EZ_APPROX_MAX) != 0, right = (flag & EZ_RIGHT) != 0;
 	ez.max = 0, ez.zdropped = 0, ez.max_q = ez.max_t = ez.mqe_t = -1, ez.mqe = ez.score = DP_NEG_INF, ez.reach_end = 0, ez.n_cigar = 0;
@@ -401,8 +437,8 @@ __device__ void ksw_wave(int qlen, int tlen, int8_t *mem, int32_t *H, uint8_t *p
 	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
 	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
 	const int T = tlen_ * 16;
-	int8_t *u = mem, *v = u + T, *x = v + T, *y = x + T, *x2 = y + T, *y2 = x2 + T, *s = y2 + T;
-	uint8_t *sf = (uint8_t*)(s + T), *qr = sf + T;
+	S8 u = mem, v = u + T, x = v + T, y = x + T, x2 = y + T, y2 = x2 + T, s = y2 + T;
+	SU8 sf = (SU8)(s + T), qr = sf + T;
 	(void)qlen_;
 	// u, v, x, y = -q - e ; x2, y2 = -q2 - e2 ; s = 0 ; H = -inf  (sf / qr were filled by the caller)
 	for (int i = lane; i < 4 * T; i += 64) u[i] = (int8_t)(-q - e);
@@ -437,7 +473,7 @@ __device__ void ksw_wave(int qlen, int tlen, int8_t *mem, int32_t *H, uint8_t *p
 		}
 		// scores: 16-lane strides from st0, all loads before all stores
 		{
-			const uint8_t *qrr = qr + (qlen - 1 - r);
+			SU8 qrr = qr + (qlen - 1 - r);
 			const int n16 = (en0 - st0) / 16 + 1;
 			for (int c0 = 0; c0 < n16 * 16; c0 += 64) {
 				const int i = c0 + lane;
@@ -453,7 +489,7 @@ __device__ void ksw_wave(int qlen, int tlen, int8_t *mem, int32_t *H, uint8_t *p
 		}
 		st_order<LDS>();
 		// core: chunks of 64 lanes from the top; a chunk reads [t-1] of the chunk below before that is updated
-		uint8_t *pr = p + (size_t)r * ncol;
+		PP pr = p + (size_t)r * ncol;
 		for (int c0 = (en - st) / 64 * 64; c0 >= 0; c0 -= 64) {
 			const int t = st + c0 + lane;
 			const bool act = t <= en;
@@ -599,7 +635,8 @@ __device__ void ksw_wave(int qlen, int tlen, int8_t *mem, int32_t *H, uint8_t *p
 
 // mm_test_zdrop on a finished gap-filling CIGAR: 0 fine, 1 the score drops by more than zdrop, 2 and
 // the dropped stretch aligns to its own reverse complement.  One lane; sequences come from `mem`.
-__device__ int test_zdrop_lane0(const Batch &B, int qlen, int tlen, const uint8_t *sf, const uint8_t *qr, int n_cigar, const uint32_t *cig,
+template <class SU8, class CP>
+__device__ int test_zdrop_lane0(const Batch &B, int qlen, int tlen, SU8 sf, SU8 qr, int n_cigar, CP cig,
                                 int sc_mch, int sc_mis, int sc_N, int32_t *sw_H, int32_t *sw_E)
 {
 	int score = 0, mx = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0, max_zdrop = 0;
@@ -672,77 +709,91 @@ __host__ __device__ __forceinline__ AlignWs align_ws(long long state_max, long l
 	return w;
 }
 
+// LDS of a workgroup: [state: lds_bytes | direction bytes: lds_p | CIGAR: lds_cig words].  Pass 0 runs
+// with a small all-in-LDS layout (many workgroups per CU: the kernel is a chain of LDS round
+// trips, only other waves hide them) and hands what does not fit to pass 2's list.
 __global__ __launch_bounds__(64) void mnc_dp_align(Batch B, uint8_t *ws_all, long long state_max, long long p_max, long long cig_max,
-                                                   int lds_bytes, int big_pass)
+                                                   int lds_bytes, int lds_p, int lds_cig, int big_pass)
 {
 	extern __shared__ __align__(16) uint8_t smem[];
 	const int lane = threadIdx.x;
 	const AlignWs W = align_ws(state_max, p_max, cig_max);
 	uint8_t *ws = ws_all + (size_t)blockIdx.x * W.total;
 	const int sc_mch = B.sc_a, sc_mis = -B.sc_b, sc_N = -B.sc_ambi;
-	const unsigned long long n_seg = B.dp_ctr[0], n_big = B.dp_ctr[6];
+	// pass 0: every segment of the round that is neither large nor the banded kernel's; 1: the large
+	// ones; 2: what the banded kernel handed back
+	const unsigned long long n_items = big_pass == 0 ? B.dp_ctr[0] : big_pass == 1 ? B.dp_ctr[6] : B.dp_ctr[12];
+	const int ctr_q = big_pass == 0 ? 3 : big_pass == 1 ? 7 : 15;
 	for (;;) {
 		unsigned long long qi = 0;
-		if (lane == 0) qi = atomicAdd(&B.dp_ctr[big_pass ? 7 : 3], 1ULL);
+		if (lane == 0) qi = atomicAdd(&B.dp_ctr[ctr_q], 1ULL);
 		qi = (unsigned long long)__shfl((long long)qi, 0);
-		if (qi >= (big_pass ? n_big : n_seg)) break;          // every wave reaches this: the queue is finite
-		const long long si = big_pass ? (long long)B.big_list[qi] : (long long)qi;
+		if (qi >= n_items) break;                              // every wave reaches this: the queue is finite
+		const long long si = big_pass == 0 ? (long long)qi : big_pass == 1 ? (long long)B.big_list[qi] : (long long)B.fill_fb[qi];
 		Seg g = B.segs[si];
-		if (!big_pass && g.big) continue;
+		if (big_pass == 0 && g.big) continue;
 		Ez ez;
 		ez.max = 0, ez.zdropped = 0, ez.max_q = ez.max_t = ez.mqe_t = -1, ez.mqe = ez.score = DP_NEG_INF, ez.reach_end = 0, ez.n_cigar = 0;
 		int zdrop_code = 0;
-		uint32_t *cig = reinterpret_cast<uint32_t*>(ws + W.cig);
+		unsigned long long off = 0;
 		if (g.qlen <= 0 || g.tlen <= 0) {
 			// ksw_extd2 returns at once
 		} else if ((long long)g.tlen * g.qlen > B.max_sw_mat) {
 			ez.zdropped = 1;                                   // mm_align_pair: too large, treated as a Z-drop
 		} else {
 			const int T = (g.tlen + 15) / 16 * 16, Q = (g.qlen + 15) / 16 * 16 + 32;
+			int ncw = g.qlen < g.tlen ? g.qlen : g.tlen;
+			{ const int wb = g.w < 0 ? (g.tlen > g.qlen ? g.tlen : g.qlen) : g.w; ncw = ((ncw < wb + 1 ? ncw : wb + 1) + 15) / 16 + 1; }
+			const long long p_bytes = ((long long)(g.qlen + g.tlen - 1) * ncw + 1) * 16;
 			const bool in_lds = 12 * T + Q <= lds_bytes;
-			int8_t *mem = in_lds ? reinterpret_cast<int8_t*>(smem) : reinterpret_cast<int8_t*>(ws + W.state);
-			int32_t *H = in_lds ? reinterpret_cast<int32_t*>(smem + (size_t)(8 * T + Q + 15) / 16 * 16) : reinterpret_cast<int32_t*>(ws + W.h);
-			uint8_t *sf = reinterpret_cast<uint8_t*>(mem) + 7 * (size_t)T, *qr = sf + T;
+			// small calls (the extensions of most reads) keep direction bytes and CIGAR in LDS as well
+			const bool all_lds = in_lds && p_bytes <= lds_p && g.qlen + g.tlen + 2 <= lds_cig;
+			if (big_pass == 0 && !all_lds) {                        // not for the small layout: pass 2 takes it
+				if (lane == 0) { const unsigned long long k = atomicAdd(&B.dp_ctr[12], 1ULL); B.fill_fb[k] = (int32_t)si; }
+				continue;
+			}
 			const uint8_t *read = B.bases + B.offsets[g.read];
 			const int rlen = (int)(B.offsets[g.read + 1] - B.offsets[g.read]);
 			const int64_t coff = B.seq_off[g.rid];
-			// target / reversed query; the left extension runs on both sequences reversed
-			for (int i = lane; i < T; i += 64) sf[i] = i < g.tlen ? (uint8_t)tcode(B, coff, g.kind == 0 ? g.ts + g.tlen - 1 - i : g.ts + i) : 0;
-			for (int i = lane; i < Q; i += 64) {
-				// qr[t] = query[qlen-1-t]; the left extension's query is itself the reverse of the read interval
-				qr[i] = i < g.qlen ? (uint8_t)qcode(read, rlen, g.rev, g.kind == 0 ? g.qs + i : g.qs + g.qlen - 1 - i) : 0;
-			}
-			mem_order();
-			if (in_lds) ksw_wave<true>(g.qlen, g.tlen, mem, H, ws + W.p, cig, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, sc_N,
-			                           g.w, g.zdrop, g.kind == 1 ? -1 : B.end_bonus, g.flag, ez);
-			else ksw_wave<false>(g.qlen, g.tlen, mem, H, ws + W.p, cig, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, sc_N,
-			                     g.w, g.zdrop, g.kind == 1 ? -1 : B.end_bonus, g.flag, ez);
-			if (g.kind == 1) {
-				// the kernel's last 16-lane score store may spill into the first 15 target bytes (as in the
-				// SSE buffer, where those are dead by then): restore them for the walk and the second pass
-				if (lane < 16) sf[lane] = lane < g.tlen ? (uint8_t)tcode(B, coff, g.ts + lane) : 0;
+			auto run = [&](auto mem, auto H, auto pbuf, auto cg) {
+				typedef typename PtrTraits<decltype(mem)>::u8 SU8;
+				SU8 sf = (SU8)(mem + 7 * (size_t)T), qr = sf + T;
+				// target / reversed query; the left extension runs on both sequences reversed
+				for (int i = lane; i < T; i += 64) sf[i] = i < g.tlen ? (uint8_t)tcode(B, coff, g.kind == 0 ? g.ts + g.tlen - 1 - i : g.ts + i) : 0;
+				for (int i = lane; i < Q; i += 64)
+					qr[i] = i < g.qlen ? (uint8_t)qcode(read, rlen, g.rev, g.kind == 0 ? g.qs + i : g.qs + g.qlen - 1 - i) : 0;
 				mem_order();
-				if (lane == 0) zdrop_code = test_zdrop_lane0(B, g.qlen, g.tlen, sf, qr, ez.n_cigar, cig, sc_mch, sc_mis, sc_N,
-				                                              reinterpret_cast<int32_t*>(ws + W.sw), reinterpret_cast<int32_t*>(ws + W.sw) + cig_max);
-				zdrop_code = __shfl(zdrop_code, 0);
-				if (zdrop_code != 0)                             // second pass: exact maximum, real Z-drop
-				{
-					if (in_lds) ksw_wave<true>(g.qlen, g.tlen, mem, H, ws + W.p, cig, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, sc_N,
-					                           g.w, zdrop_code == 2 ? B.zdrop_inv : B.zdrop, -1, 0, ez);
-					else ksw_wave<false>(g.qlen, g.tlen, mem, H, ws + W.p, cig, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, sc_N,
-					                     g.w, zdrop_code == 2 ? B.zdrop_inv : B.zdrop, -1, 0, ez);
+				ksw_wave(g.qlen, g.tlen, mem, H, pbuf, cg, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, sc_N,
+				         g.w, g.zdrop, g.kind == 1 ? -1 : B.end_bonus, g.flag, ez);
+				if (g.kind == 1) {
+					// the kernel's last 16-lane score store may spill into the first 15 target bytes (as in the
+					// SSE buffer, where those are dead by then): restore them for the walk and the second pass
+					if (lane < 16) sf[lane] = lane < g.tlen ? (uint8_t)tcode(B, coff, g.ts + lane) : 0;
+					mem_order();
+					if (lane == 0) zdrop_code = test_zdrop_lane0(B, g.qlen, g.tlen, sf, qr, ez.n_cigar, cg, sc_mch, sc_mis, sc_N,
+					                                              reinterpret_cast<int32_t*>(ws + W.sw), reinterpret_cast<int32_t*>(ws + W.sw) + cig_max);
+					zdrop_code = __shfl(zdrop_code, 0);
+					if (zdrop_code != 0)                             // second pass: exact maximum, real Z-drop
+						ksw_wave(g.qlen, g.tlen, mem, H, pbuf, cg, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, sc_N,
+						         g.w, zdrop_code == 2 ? B.zdrop_inv : B.zdrop, -1, 0, ez);
 				}
-			}
-		}
-		// results; the CIGAR goes to the segment pool
-		unsigned long long off = 0;
-		if (lane == 0 && ez.n_cigar > 0) off = atomicAdd(&B.dp_ctr[1], (unsigned long long)ez.n_cigar);
-		off = (unsigned long long)__shfl((long long)off, 0);
-		if (ez.n_cigar > 0) {
-			if ((long long)(off + ez.n_cigar) > B.cig_seg_cap) {
-				if (lane == 0) atomicMax(&B.dp_ctr[4], 2ULL);
-				ez.n_cigar = 0;
-			} else for (int k = lane; k < ez.n_cigar; k += 64) B.cig_seg[off + k] = cig[k];
+				// the CIGAR goes to the segment pool
+				if (lane == 0 && ez.n_cigar > 0) off = atomicAdd(&B.dp_ctr[1], (unsigned long long)ez.n_cigar);
+				off = (unsigned long long)__shfl((long long)off, 0);
+				if (ez.n_cigar > 0) {
+					if ((long long)(off + ez.n_cigar) > B.cig_seg_cap) {
+						if (lane == 0) atomicMax(&B.dp_ctr[4], 2ULL);
+						ez.n_cigar = 0;
+					} else for (int k = lane; k < ez.n_cigar; k += 64) B.cig_seg[off + k] = cg[k];
+				}
+			};
+			const size_t h_off = (size_t)(8 * T + Q + 15) / 16 * 16;
+			if (all_lds)
+				run((lds_i8p)smem, (lds_i32p)(smem + h_off), (lds_u8p)(smem + lds_bytes), (lds_u32p)(smem + lds_bytes + lds_p));
+			else if (in_lds)
+				run((lds_i8p)smem, (lds_i32p)(smem + h_off), ws + W.p, reinterpret_cast<uint32_t*>(ws + W.cig));
+			else
+				run(reinterpret_cast<int8_t*>(ws + W.state), reinterpret_cast<int32_t*>(ws + W.h), ws + W.p, reinterpret_cast<uint32_t*>(ws + W.cig));
 		}
 		if (lane == 0) {
 			Seg *o = B.segs + si;
@@ -1039,6 +1090,7 @@ __global__ void mnc_dp_round(Batch B, int first)
 	B.dp_ctr[9] = B.dp_ctr[5];            // regions to plan / stitch this round
 	B.dp_ctr[5] = 0;
 	B.dp_ctr[6] = 0, B.dp_ctr[7] = 0;
+	for (int k = 10; k < 16; ++k) B.dp_ctr[k] = 0;   // banded kernel: list lengths 10 / 11 / 12 (tier 1, tier 2, handed back), queues 13 / 14 / 15
 }
 __global__ void mnc_dp_round_end(Batch B)
 {
@@ -1065,9 +1117,11 @@ int dp_align_prepare(int lds_bytes)
 	if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return MNC_ERR_HIP; }
 	return MNC_OK;
 }
-void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max, long long p_max, long long cig_max, int lds_bytes, int big_pass, hipStream_t st)
+void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max, long long p_max, long long cig_max,
+                     int lds_state, int lds_p, int lds_cig, int big_pass, hipStream_t st)
 {
-	hipLaunchKernelGGL(mnc_dp_align, dim3(n_wg), dim3(64), (size_t)lds_bytes, st, B, ws, state_max, p_max, cig_max, lds_bytes, big_pass);
+	hipLaunchKernelGGL(mnc_dp_align, dim3(n_wg), dim3(64), (size_t)lds_state + lds_p + lds_cig * 4, st, B, ws, state_max, p_max, cig_max,
+	                   lds_state, lds_p, lds_cig, big_pass);
 }
 void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_list, int n_wg, hipStream_t st)
 {
