@@ -805,11 +805,42 @@ __global__ __launch_bounds__(64) void mnc_dp_align(Batch B, uint8_t *ws_all, lon
 	}
 }
 
+// ---- wave-wide scans with DPP (GFX9: row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143).
+// A lane that receives nothing keeps `old`: the identity of the operation.
+#define MNC_DPP(old, src, ctrl, rmask) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rmask), 0xf, false)
+__device__ __forceinline__ int dpp_incl_add(int v)
+{
+	v += MNC_DPP(0, v, 0x111, 0xf); v += MNC_DPP(0, v, 0x112, 0xf); v += MNC_DPP(0, v, 0x114, 0xf); v += MNC_DPP(0, v, 0x118, 0xf);
+	v += MNC_DPP(0, v, 0x142, 0xa); v += MNC_DPP(0, v, 0x143, 0xc);
+	return v;
+}
+__device__ __forceinline__ int dpp_max_all(int v)          // the maximum over the wave, in every lane
+{
+	const int lo = INT32_MIN;
+	int o;
+	o = MNC_DPP(lo, v, 0x111, 0xf); v = v > o ? v : o;  o = MNC_DPP(lo, v, 0x112, 0xf); v = v > o ? v : o;
+	o = MNC_DPP(lo, v, 0x114, 0xf); v = v > o ? v : o;  o = MNC_DPP(lo, v, 0x118, 0xf); v = v > o ? v : o;
+	o = MNC_DPP(lo, v, 0x142, 0xa); v = v > o ? v : o;  o = MNC_DPP(lo, v, 0x143, 0xc); v = v > o ? v : o;
+	return __builtin_amdgcn_readlane(v, 63);
+}
+// inclusive scan of maps x -> max(x + a, b) under composition "earlier, then later":
+// (a1, b1) then (a2, b2) = (a1 + a2, max(b1 + a2, b2)); identity (0, SC_NONE)
+constexpr int SC_NONE = -(1 << 28);
+__device__ __forceinline__ void dpp_scan_maps(int &a, int &b)
+{
+#define MNC_SCAN_STEP(ctrl, rmask) { const int pa = MNC_DPP(0, a, ctrl, rmask), pb = MNC_DPP(SC_NONE, b, ctrl, rmask); \
+	const int nb = pb + a > b ? pb + a : b; a = pa + a, b = nb; }
+	MNC_SCAN_STEP(0x111, 0xf) MNC_SCAN_STEP(0x112, 0xf) MNC_SCAN_STEP(0x114, 0xf) MNC_SCAN_STEP(0x118, 0xf)
+	MNC_SCAN_STEP(0x142, 0xa) MNC_SCAN_STEP(0x143, 0xc)
+#undef MNC_SCAN_STEP
+}
+
 // ================================================================ stitch: one region (the rest of mm_align1 + mm_update_extra)
 // LDS: the region's query and target codes (when they fit), the joined CIGAR is built in the
 // region pool.  One wave per region; lane 0 does the sequential bookkeeping, all lanes the walks.
 constexpr int ST_SEQ_MAX = 8 * 1024;                        // bytes of LDS per sequence
-constexpr int ST_CIG_MAX = 4096;                            // CIGAR words in LDS
+constexpr int ST_CIG_MAX = 2048;                            // CIGAR words in LDS
+constexpr int ST_EV_MAX = 4096;                             // score events buffered for one scan
 
 __device__ __forceinline__ void append_op(uint32_t *c, int &n, uint32_t word)
 {
@@ -821,6 +852,7 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 {
 	__shared__ uint8_t s_q[ST_SEQ_MAX], s_t[ST_SEQ_MAX];
 	__shared__ uint32_t s_c[ST_CIG_MAX];
+	__shared__ int16_t s_d[ST_EV_MAX];
 	const int lane = threadIdx.x;
 	const unsigned long long n_work = B.dp_ctr[9];
 	for (unsigned long long wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
@@ -853,18 +885,20 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 		int rs1 = d.rs, qs1 = d.qs, re1 = d.rs, qe1 = d.qs;
 		int split_at = -1, split_inv = 0;
 		// every value below is the same in all lanes; only the copies are shared out
+		const bool c_lds = total <= ST_CIG_MAX;
+		auto c_order = [&]() { if (c_lds) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); asm volatile("" ::: "memory"); } else mem_order(); };
 		auto append = [&](const Seg &g) {
 			if (g.n_cigar <= 0) return;
 			const uint32_t first = B.cig_seg[g.cig_off];
 			int start = 0;
 			if (n_c > 0 && (C[n_c - 1] & 0xf) == (first & 0xf)) {       // same operation across the boundary
-				mem_order();
+				c_order();
 				if (lane == 0) C[n_c - 1] += first >> 4 << 4;
 				start = 1;
 			}
 			for (int c = start + lane; c < g.n_cigar; c += 64) C[n_c + c - start] = B.cig_seg[g.cig_off + c];
 			n_c += g.n_cigar - start;
-			mem_order();
+			c_order();
 		};
 		{
 			int k = 0;
@@ -954,14 +988,66 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 			const bool in_lds = ql <= ST_SEQ_MAX && tl <= ST_SEQ_MAX;
 			if (in_lds) {
 				for (int i = lane; i < ql; i += 64) s_q[i] = (uint8_t)qcode(read, qlen, rev, qs1 + i);
-				for (int i = lane; i < tl; i += 64) s_t[i] = (uint8_t)tcode(B, coff, rs1 + i);
+				// eight target bases per word
+				const int64_t o0 = coff + rs1, w0 = o0 >> 3, w1 = (o0 + tl + 7) >> 3;
+				for (int64_t wd = w0 + lane; wd < w1; wd += 64) {
+					const uint32_t v = B.seq4[wd];
+#pragma unroll
+					for (int b8 = 0; b8 < 8; ++b8) {
+						const int64_t idx = wd * 8 + b8 - o0;
+						if (idx >= 0 && idx < tl) s_t[idx] = (uint8_t)(v >> (b8 * 4) & 15u);
+					}
+				}
 			}
-			mem_order();
+			c_order();
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 			auto Q = [&](int i) -> int { return in_lds ? (int)s_q[i] : qcode(read, qlen, rev, qs1 + i); };
 			auto Tg = [&](int i) -> int { return in_lds ? (int)s_t[i] : tcode(B, coff, rs1 + i); };
 			int qshift = 0, tshift = 0;
-			// ---- mm_fix_cigar (lane 0)
-			if (lane == 0 && n_c > 1) {
+			// ---- mm_fix_cigar.  Its common work -- sliding every indel between two M runs to the left
+			// as far as the bases repeat -- is independent per indel as long as no slide eats a whole
+			// M run: the lanes do it 64 operations at a time.  Anything else (an I next to a D, a
+			// leading gap, an M run eaten up) is rare and takes the sequential form on one lane.
+			bool rare = false;
+			if (n_c > 1) {
+				bool odd = (C[0] & 0xf) != 0;
+				int carry_q = 0, carry_t = 0;
+				for (int k0 = 0; k0 < n_c; k0 += 64) {
+					const int k = k0 + lane;
+					const uint32_t wd = k < n_c ? C[k] : 0;
+					const uint32_t op = wd & 0xf;
+					const int len = (int)(wd >> 4);
+					const int dq = k < n_c && op != 2 ? len : 0, dt = k < n_c && op != 1 ? len : 0;
+					const int iq = dpp_incl_add(dq), it = dpp_incl_add(dt);
+					const int qoff = carry_q + iq - dq, toff = carry_t + it - dt;
+					carry_q += __builtin_amdgcn_readlane(iq, 63), carry_t += __builtin_amdgcn_readlane(it, 63);
+					int sl = 0;
+					if (k < n_c) {
+						if (len == 0) odd = true;
+						if (op != 0) {
+							const uint32_t nx = k + 1 < n_c ? C[k + 1] : 0u, pv = k > 0 ? C[k - 1] : 1u;
+							if (k + 1 < n_c && (nx & 0xf) != 0) odd = true;          // I next to D
+							if (k > 0 && k < n_c - 1 && (pv & 0xf) == 0 && (nx & 0xf) == 0) {
+								const int prev_len = (int)(pv >> 4);
+								if (op == 1) { while (sl < prev_len && Q(qoff - 1 - sl) == Q(qoff + len - 1 - sl)) ++sl; }
+								else { while (sl < prev_len && Tg(toff - 1 - sl) == Tg(toff + len - 1 - sl)) ++sl; }
+								if (sl == prev_len) odd = true;
+							}
+						}
+						if (k < ST_EV_MAX) s_d[k] = (int16_t)sl; else if (sl) odd = true;
+					}
+				}
+				rare = __any(odd) != 0;
+				c_order();
+				if (!rare) {
+					for (int k = lane; k < n_c; k += 64) {
+						const int sl = k < ST_EV_MAX ? (int)s_d[k] : 0;
+						if (sl > 0) { atomicSub(&C[k - 1], (uint32_t)sl << 4); atomicAdd(&C[k + 1], (uint32_t)sl << 4); }
+					}
+				}
+				c_order();
+			}
+			if (rare && lane == 0) {
 				int toff = 0, qoff = 0;
 				bool to_shrink = false;
 				for (int k = 0; k < n_c; ++k) {
@@ -1018,58 +1104,64 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 			}
 			n_c = __shfl(n_c, 0), qshift = __shfl(qshift, 0), tshift = __shfl(tshift, 0);
 			r.qs = __shfl(r.qs, 0), r.qe = __shfl(r.qe, 0), r.rs = __shfl(r.rs, 0);
-			mem_order();
-			// ---- mm_update_extra: one walk; the lanes share each M run.  s := max(s + d, 0) per base
-			// is the map x -> max(x + a, b): a wave-wide scan of (a, b) pairs gives every prefix.
-			int s_run = 0, s_max = 0, mlen = 0, blen = 0, n_ambi = 0;
+			c_order();
+			// ---- mm_update_extra: s := max(s + d, 0) per base (and per gap) is the map x -> max(x + d, 0);
+			// the score events of the region are laid out in LDS and scanned 64 at a time
+			int s_run = 0, s_max = 0, mlen = 0, blen = 0, n_ambi = 0, ev = 0;
+			int c_amb = 0, c_diff = 0, c_gamb = 0;                    // per-lane counts (M columns; gap bases), summed at the end
+			auto flush = [&]() {
+				c_order();
+				for (int c0 = 0; c0 < ev; c0 += 64) {
+					const int i = c0 + lane;
+					const bool act = i < ev;
+					int fa = act ? (int)s_d[i] : 0, fb = act ? 0 : SC_NONE;
+					dpp_scan_maps(fa, fb);
+					const int sv = s_run + fa > fb ? s_run + fa : fb;
+					const int mv = dpp_max_all(act ? sv : 0);
+					s_max = s_max > mv ? s_max : mv;
+					s_run = __builtin_amdgcn_readlane(sv, 63);
+				}
+				ev = 0;
+				c_order();
+			};
 			int toff = tshift, qoff = qshift;
 			for (int k = 0; k < n_c; ++k) {
 				const uint32_t op = C[k] & 0xf;
 				const int len = (int)(C[k] >> 4);
 				if (op == 0) {
-					int amb = 0, diff = 0;
-					for (int c0 = 0; c0 < len; c0 += 64) {
-						const int i = c0 + lane;
-						const bool act = i < len;
-						int dlt = 0;
-						if (act) {
-							const int cq = Q(qoff + i), ct = Tg(toff + i);
-							if (ct > 3 || cq > 3) ++amb, dlt = -B.sc_ambi;
-							else if (ct != cq) ++diff, dlt = -B.sc_b;
+					for (int pos = 0; pos < len;) {
+						if (ev == ST_EV_MAX) flush();
+						const int take = len - pos < ST_EV_MAX - ev ? len - pos : ST_EV_MAX - ev;
+						for (int i = lane; i < take; i += 64) {
+							const int cq = Q(qoff + pos + i), ct = Tg(toff + pos + i);
+							int dlt;
+							if (ct > 3 || cq > 3) ++c_amb, dlt = -B.sc_ambi;
+							else if (ct != cq) ++c_diff, dlt = -B.sc_b;
 							else dlt = B.sc_a;
+							s_d[ev + i] = (int16_t)dlt;
 						}
-						// inclusive scan of f_i(x) = max(x + a_i, b_i), a_i = dlt, b_i = 0 (identity for idle lanes: a = 0, b = -inf)
-						int fa = act ? dlt : 0, fb = act ? 0 : DP_NEG_INF;
-						for (int sft = 1; sft < 64; sft <<= 1) {
-							const int pa = __shfl_up(fa, sft), pb = __shfl_up(fb, sft);
-							if (lane >= sft) {
-								// (earlier then later): x -> max(max(x + pa, pb) + fa, fb)
-								fb = pb + fa > fb ? pb + fa : fb;
-								fa = pa + fa;
-							}
-						}
-						const int sv = s_run + fa > fb ? s_run + fa : fb;      // s after base i
-						int mv = act ? sv : 0;
-						mv = wave_max_i32(mv);
-						s_max = s_max > mv ? s_max : mv;
-						s_run = __shfl(sv, 63);
+						ev += take, pos += take;
 					}
-					amb = amb + 0;
-					// counts over the run
-					int ta = amb, td = diff;
-					for (int sft = 32; sft > 0; sft >>= 1) ta += __shfl_xor(ta, sft), td += __shfl_xor(td, sft);
-					blen += len - ta, mlen += len - (ta + td), n_ambi += ta;
+					blen += len, mlen += len;
 					toff += len, qoff += len;
 				} else {
-					int amb = 0;
-					for (int i = lane; i < len; i += 64) amb += (op == 1 ? Q(qoff + i) : Tg(toff + i)) > 3;
-					for (int sft = 32; sft > 0; sft >>= 1) amb += __shfl_xor(amb, sft);
-					blen += len - amb, n_ambi += amb;
-					s_run -= B.gap_q + B.gap_e * len;
-					if (s_run < 0) s_run = 0;
+					for (int i = lane; i < len; i += 64) c_gamb += (op == 1 ? Q(qoff + i) : Tg(toff + i)) > 3;
+					blen += len;
+					if (ev == ST_EV_MAX) flush();
+					const int cost = B.gap_q + B.gap_e * len;
+					if (cost > 32767) {                                   // does not fit an event: applied directly
+						flush();
+						s_run = s_run - cost > 0 ? s_run - cost : 0;
+					} else {
+						if (lane == 0) s_d[ev] = (int16_t)-cost;
+						++ev;
+					}
 					if (op == 1) qoff += len; else toff += len;
 				}
 			}
+			flush();
+			for (int sft = 32; sft > 0; sft >>= 1) c_amb += __shfl_xor(c_amb, sft), c_diff += __shfl_xor(c_diff, sft), c_gamb += __shfl_xor(c_gamb, sft);
+			blen -= c_amb + c_gamb, mlen -= c_amb + c_diff, n_ambi = c_amb + c_gamb;
 			r.mlen = mlen, r.blen = blen, r.n_ambi += n_ambi, r.dp_max = s_max, r.n_cigar = n_c;
 		}
 		if (C == s_c) for (int k = lane; k < n_c; k += 64) B.cig_reg[off + k] = s_c[k];
