@@ -212,6 +212,9 @@ struct Batch {
 	int32_t *next_list;           // region slots created by Z-drop splits (next round)
 	int32_t *big_list;            // segment indices for the large-workspace launch
 	int32_t *fill_list1, *fill_list2, *fill_fb;   // banded gap-filling kernel: 32-lane tier, 64-lane tier, handed back
+	int32_t *fill_list3;                          // ... and the 128-cell tier
+	int32_t *ext_list1, *ext_list2;               // extension kernel: 32 / 64 lanes per segment
+	int32_t *gen_list;                            // the literal kernel's first pass
 	int32_t *reg_cnt;             // per read: regions in the skeleton's array (kept + split tails)
 };
 

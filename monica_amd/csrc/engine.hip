@@ -49,7 +49,8 @@ void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_li
 size_t dp_fill_p_slot();
 void launch_dp_fill(const Batch &B, int lanes, const int32_t *list, int ctr_n, int ctr_q, int32_t *next_list, int ctr_next,
                     int32_t *fb_list, int ctr_fb, uint8_t *p_all, int n_wg, hipStream_t st);
-constexpr int DP_WG_FILL = 256 * 16;
+void launch_dp_ext(const Batch &B, int lanes, const int32_t *list, int ctr_n, int ctr_q, int32_t *fb_list, int ctr_fb, uint8_t *p_all, int n_wg, hipStream_t st);
+constexpr int DP_WG_FILL = 256 * 16, DP_WG_EXT = 256 * 8;
 // workspace classes of the alignment kernel: a normal slot per workgroup, a few large ones
 constexpr int DP_LDS_BYTES = 16 * 1024;
 constexpr int DP_LDS0_STATE = 4 * 1024, DP_LDS0_P = 10 * 1024, DP_LDS0_CIG = 256;   // pass 0: 15 KB per workgroup
@@ -370,7 +371,7 @@ struct mnc_engine {
 	// base-level alignment stage
 	int contract = MNC_CONTRACT_DP;
 	Buf ca, ca_cnt, chain_dst, regdp, segs, cig_seg, cig_reg, dp_ctr, work_a, work_b, big_list, reg_cnt, regs2, dp_ws, dp_ws_big;
-	Buf fill1, fill2, fill_fb, fill_p;
+	Buf fill1, fill2, fill3, fill_fb, fill_p, ext1, ext2, ext_p, gen_list;
 	size_t seg_cap_override = 0, cig_cap_override = 0;
 	int debug = 0;                           // bit mask (tests): 2 stress build of the chaining ring, 4 displacement bytes read from HBM
 	// last batch
@@ -456,7 +457,7 @@ extern "C" void mnc_engine_destroy(mnc_engine *e)
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
 	Buf *all[] = { &e->gap_lut, &e->logf_lut, &e->logf_a_lut, &e->ca, &e->ca_cnt, &e->chain_dst, &e->regdp, &e->segs, &e->cig_seg, &e->cig_reg, &e->dp_ctr,
-	               &e->work_a, &e->work_b, &e->big_list, &e->reg_cnt, &e->regs2, &e->dp_ws, &e->dp_ws_big, &e->fill1, &e->fill2, &e->fill_fb, &e->fill_p, &e->in_bases, &e->in_offsets, &e->out_assign, &e->out_best, &e->out_nhits,
+	               &e->work_a, &e->work_b, &e->big_list, &e->reg_cnt, &e->regs2, &e->dp_ws, &e->dp_ws_big, &e->fill1, &e->fill2, &e->fill3, &e->fill_fb, &e->fill_p, &e->ext1, &e->ext2, &e->ext_p, &e->gen_list, &e->in_bases, &e->in_offsets, &e->out_assign, &e->out_best, &e->out_nhits,
 	               &e->packed, &e->mz, &e->hits, &e->hist_tm, &e->q_off, &e->qrec, &e->bhits, &e->bhit_cnt, &e->ambig, &e->mz_cnt, &e->hit_cnt, &e->rep_len, &e->an_cnt, &e->an_off,
 	               &e->n_chain, &e->n_reg, &e->best_mlen, &e->hist_sums, &e->hist_offs, &e->scan_sums, &e->hit_off, &e->a, &e->f, &e->p, &e->v, &e->t, &e->u,
 	               &e->chains_tmp, &e->regs, &e->regx, &e->k64a, &e->k64b, &e->tmp_i32, &e->gated,
@@ -510,7 +511,7 @@ extern "C" int mnc_engine_create(mnc_index *idx, int device, mnc_engine **out)
 	rc = e->gap_lut.ensure(GAP_LUT * 4);
 	if (!rc) rc = e->logf_lut.ensure((size_t)e->logf_n * 4);
 	if (!rc) rc = e->logf_a_lut.ensure((size_t)e->logf_n * 4);
-	if (!rc) rc = e->dp_ctr.ensure(16 * 8);
+	if (!rc) rc = e->dp_ctr.ensure(32 * 8);
 	if (!rc) rc = dp_align_prepare(DP_LDS_BYTES);
 	if (!rc) rc = e->stats.ensure(16 * 8);
 	if (!rc) rc = e->cls_count.ensure((MAX_CHAIN_CLASSES + 1) * 4 + 64);
@@ -586,19 +587,26 @@ struct StageTimer {
 };
 }
 
-// the gap fillings the banded kernel takes: 32 lanes per segment, then 64 for those whose band
-// could not be proven wide enough
-static void align_fill(const Batch &B, mnc_engine *e, hipStream_t st)
+// The kernel calls of a round run on four streams side by side -- they touch different segments --
+// and meet before the literal kernel's last pass, which takes what the others handed back:
+//   s0  gap fillings on the banded kernel: 32 lanes per segment, then 64, then 128 cells for those
+//       whose band could not be proven wide enough
+//   s1  the extensions of most regions (small matrices, their own kernel)
+//   s2  the literal kernel's first pass: unusual small calls
+//   s3  the few calls that need the large workspace
+static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream_t s1, hipStream_t s2, hipStream_t s3)
 {
-	launch_dp_fill(B, 32, B.fill_list1, 10, 13, B.fill_list2, 11, B.fill_fb, 12, e->fill_p.as<uint8_t>(), DP_WG_FILL, st);
-	launch_dp_fill(B, 64, B.fill_list2, 11, 14, B.fill_fb, 12, B.fill_fb, 12, e->fill_p.as<uint8_t>(), DP_WG_FILL, st);
+	launch_dp_fill(B, 32, B.fill_list1, 10, 13, B.fill_list2, 11, B.fill_fb, 12, e->fill_p.as<uint8_t>(), DP_WG_FILL, s0);
+	launch_dp_fill(B, 64, B.fill_list2, 11, 14, B.fill_list3, 22, B.fill_fb, 12, e->fill_p.as<uint8_t>(), DP_WG_FILL, s0);
+	launch_dp_fill(B, 128, B.fill_list3, 22, 23, B.fill_fb, 12, B.fill_fb, 12, e->fill_p.as<uint8_t>(), DP_WG_FILL / 2, s0);
+	launch_dp_ext(B, 32, B.ext_list1, 16, 18, B.fill_fb, 12, e->ext_p.as<uint8_t>(), DP_WG_EXT, s1);
+	launch_dp_ext(B, 64, B.ext_list2, 17, 19, B.fill_fb, 12, e->ext_p.as<uint8_t>(), DP_WG_EXT, s1);
+	launch_dp_align(B, e->dp_ws.as<uint8_t>(), 2 * DP_WG_SMALL, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS0_STATE, DP_LDS0_P, DP_LDS0_CIG, 0, s2);
+	launch_dp_align(B, e->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 1, s3);
 }
-// everything else on the literal kernel: extensions and unusual gaps, the large ones, what the banded kernel handed back
+// what the other kernels handed back, on the literal kernel
 static void align_rest(const Batch &B, mnc_engine *e, hipStream_t st)
 {
-	// pass 0: the small all-in-LDS layout (extensions of most reads); what does not fit joins pass 2's list
-	launch_dp_align(B, e->dp_ws.as<uint8_t>(), 2 * DP_WG_SMALL, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS0_STATE, DP_LDS0_P, DP_LDS0_CIG, 0, st);
-	launch_dp_align(B, e->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 1, st);
 	launch_dp_align(B, e->dp_ws.as<uint8_t>(), DP_WG_SMALL, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, 0, 2, st);
 }
 
@@ -820,17 +828,18 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 		ENS2(work_a, ns * 4); ENS2(work_b, ns * 4); ENS2(big_list, seg_cap * 4); ENS2(reg_cnt, (nr + 1) * 4); ENS2(regs2, ns * sizeof(mnc_reg_t));
 		const size_t ws_small = dp_align_ws_bytes(DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL), ws_big = dp_align_ws_bytes(DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG);
 		ENS2(dp_ws, ws_small * DP_WG_SMALL * 2); ENS2(dp_ws_big, ws_big * DP_WG_BIG);
-		ENS2(fill1, seg_cap * 4); ENS2(fill2, seg_cap * 4); ENS2(fill_fb, seg_cap * 4); ENS2(fill_p, dp_fill_p_slot() * DP_WG_FILL);
+		ENS2(fill1, seg_cap * 4); ENS2(fill2, seg_cap * 4); ENS2(fill3, seg_cap * 4); ENS2(fill_fb, seg_cap * 4); ENS2(fill_p, dp_fill_p_slot() * DP_WG_FILL); ENS2(ext1, seg_cap * 4); ENS2(ext2, seg_cap * 4); ENS2(gen_list, seg_cap * 4); ENS2(ext_p, dp_fill_p_slot() * DP_WG_EXT);
 #undef ENS2
 		if (rc2) return rc2;
 		B.ca = e->ca.as<Anchor>(), B.ca_cnt = e->ca_cnt.as<int32_t>(), B.chain_dst = e->chain_dst.as<int32_t>(), B.regdp = e->regdp.as<RegDP>();
 		B.segs = e->segs.as<Seg>(), B.seg_cap = (int64_t)seg_cap, B.cig_seg = e->cig_seg.as<uint32_t>(), B.cig_reg = e->cig_reg.as<uint32_t>();
 		B.cig_seg_cap = B.cig_reg_cap = (int64_t)cig_cap, B.dp_ctr = e->dp_ctr.as<unsigned long long>();
 		B.big_list = e->big_list.as<int32_t>(), B.reg_cnt = e->reg_cnt.as<int32_t>();
-		B.fill_list1 = e->fill1.as<int32_t>(), B.fill_list2 = e->fill2.as<int32_t>(), B.fill_fb = e->fill_fb.as<int32_t>();
+		B.fill_list1 = e->fill1.as<int32_t>(), B.fill_list2 = e->fill2.as<int32_t>(), B.fill_list3 = e->fill3.as<int32_t>(), B.fill_fb = e->fill_fb.as<int32_t>();
+		B.ext_list1 = e->ext1.as<int32_t>(), B.ext_list2 = e->ext2.as<int32_t>(), B.gen_list = e->gen_list.as<int32_t>();
 		int32_t *lists[2] = { e->work_a.as<int32_t>(), e->work_b.as<int32_t>() };
 		B.next_list = lists[0];                          // the regions kernel files every kept region here
-		HIP_TRY(hipMemsetAsync(e->dp_ctr.p, 0, 16 * 8, st));
+		HIP_TRY(hipMemsetAsync(e->dp_ctr.p, 0, 32 * 8, st));
 		{ StageTimer t(e, MNC_STAGE_REGIONS);   launch_regions(B, e->regx.p, e->k64a.as<uint64_t>(), e->k64b.as<uint64_t>(), e->gated.as<mnc_hit_t>(), st); }
 		{ StageTimer t(e, MNC_STAGE_DP_PLAN);   launch_dp_gather(B, st); }
 		unsigned max_work = (unsigned)ns;
@@ -842,8 +851,10 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 			if (round == 0) {
 				{ StageTimer t(e, MNC_STAGE_DP_PLAN);   launch_dp_plan(B, work, max_work, (int)DP_STATE_SMALL, DP_P_SMALL, (int)DP_CIG_SMALL, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, st); }
 				{
-					StageTimer t(e, MNC_STAGE_DP_FILL);
-					align_fill(B, e, st);
+					StageTimer t(e, MNC_STAGE_DP_FILL);               // the four streams, fork to join
+					if (int rcf = fork()) return rcf;
+					align_round(B, e, e->side[0], e->side[1], e->side[2], e->side[3]);
+					if (int rcj = join()) return rcj;
 				}
 				{
 					StageTimer t(e, MNC_STAGE_DP_ALIGN);
@@ -852,7 +863,9 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 				{ StageTimer t(e, MNC_STAGE_DP_STITCH); launch_dp_stitch(B, work, next, 4096, st); }
 			} else {
 				launch_dp_plan(B, work, max_work, (int)DP_STATE_SMALL, DP_P_SMALL, (int)DP_CIG_SMALL, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, st);
-				align_fill(B, e, st);
+				if (int rcf = fork()) return rcf;
+				align_round(B, e, e->side[0], e->side[1], e->side[2], e->side[3]);
+				if (int rcj = join()) return rcj;
 				align_rest(B, e, st);
 				launch_dp_stitch(B, work, next, 4096, st);
 			}
@@ -1002,6 +1015,7 @@ extern "C" int mnc_engine_get_counters(mnc_engine *e, int64_t *c, int n)
 		unsigned long long d[16];
 		HIP_TRY(hipMemcpy(d, e->dp_ctr.p, sizeof(d), hipMemcpyDeviceToHost));
 		c[8] = (int64_t)d[0], c[9] = (int64_t)d[10], c[10] = (int64_t)d[11], c[11] = (int64_t)d[12];
+
 
 	}
 	return MNC_OK;

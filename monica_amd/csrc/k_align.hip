@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 			d.n_seg = 0, d.has_left = d.has_right = 0;
 		} else {
 			Seg *sg = B.segs + s0;
-			int n_tier[2] = { 0, 0 };
+			int n_tier[6] = { 0, 0, 0, 0, 0, 0 };
 			auto emit = [&](Seg g) {
 				g.read = (int32_t)rd, g.reg = (int32_t)rslot, g.rid = rid, g.rev = rev;
 				g.n_cigar = 0, g.zdropped = 0, g.zdrop_code = 0, g.max = 0, g.max_t = g.max_q = -1, g.score = DP_NEG_INF, g.reach_end = 0, g.mqe_t = -1, g.cig_off = 0;
@@ -313,15 +313,35 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 					const int ad = g.tlen > g.qlen ? g.tlen - g.qlen : g.qlen - g.tlen;
 					// the 32-lane tier only when its proof has a chance: the bound a band of that width leaves
 					// against what a read with ~10 % errors scores (~1.28 per base)
-					int tier = (62 - ad) / 2 >= 12 ? 1 : (126 - ad) / 2 >= 8 ? 2 : 0;
+					int tier = (61 - ad) / 2 >= 12 ? 1 : (125 - ad) / 2 >= 8 ? 2 : 6;
 					if (tier == 1) {
-						const int bb = (62 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
+						const int bb = (61 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
 						const int g1 = B.gap_q + B.gap_e * (bb + 1), g2 = B.gap_q2 + B.gap_e2 * (bb + 1);
 						const int U = B.sc_a * (mn - bb - 1) - 2 * (g1 < g2 ? g1 : g2);
 						if (U * 25 > mn * 32) tier = 2;                   // trying costs one unit, failing two more: worth it below even odds
 					}
+					if (tier == 2) {                                      // and the 64-lane tier likewise, against the literal kernel
+						const int bb = (125 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
+						const int g1 = B.gap_q + B.gap_e * (bb + 1), g2 = B.gap_q2 + B.gap_e2 * (bb + 1);
+						const int U = B.sc_a * (mn - bb - 1) - 2 * (g1 < g2 ? g1 : g2);
+						if (U * 25 > mn * 32) tier = 6;                   // two cells per lane: a band of 128
+					}
+					if (tier == 6) {
+						const int bb = (253 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
+						const int g1 = B.gap_q + B.gap_e * (bb + 1), g2 = B.gap_q2 + B.gap_e2 * (bb + 1);
+						const int U = B.sc_a * (mn - bb - 1) - 2 * (g1 < g2 ? g1 : g2);
+						if (bb < 8 || U * 25 > mn * 32) tier = 0;
+					}
 					if (tier) g.big = 3 + tier, ++n_tier[tier - 1];          // not for the literal kernel's first pass
-
+				} else if (g.big == 0 && g.kind != 1 && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= g.w && g.qlen <= g.w &&
+				           g.tlen + g.qlen - 1 <= 2 * FILL_MAX_LEN && (g.tlen < g.qlen ? g.tlen : g.qlen) <= 64) {
+					// an extension whose matrix the band never clips and whose anti-diagonals fit a wave:
+					// the extension kernel of k_fill.hip (32 lanes per segment when they fit)
+					const int tier = (g.tlen < g.qlen ? g.tlen : g.qlen) <= 32 ? 3 : 4;
+					g.big = 3 + tier, ++n_tier[tier - 1];
+				}
+				if (g.big == 0) {                                          // the literal kernel's first pass
+					g.big = 8, ++n_tier[4];
 				}
 				*sg++ = g;
 			};
@@ -352,10 +372,10 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 				emit(g);
 			}
 			// the banded kernel's lists: one reservation per region and tier
-			for (int tier = 0; tier < 2; ++tier) {
+			for (int tier = 0; tier < 6; ++tier) {
 				if (n_tier[tier] == 0) continue;
-				unsigned long long fi = atomicAdd(&B.dp_ctr[10 + tier], (unsigned long long)n_tier[tier]);
-				int32_t *lst = tier == 0 ? B.fill_list1 : B.fill_list2;
+				unsigned long long fi = atomicAdd(&B.dp_ctr[tier < 2 ? 10 + tier : tier < 4 ? 14 + tier : tier == 4 ? 20 : 22], (unsigned long long)n_tier[tier]);
+				int32_t *lst = tier == 0 ? B.fill_list1 : tier == 1 ? B.fill_list2 : tier == 2 ? B.ext_list1 : tier == 3 ? B.ext_list2 : tier == 4 ? B.gen_list : B.fill_list3;
 				for (int k = 0; k < n_seg; ++k)
 					if (B.segs[s0 + k].big == 4 + tier) lst[fi++] = (int32_t)(s0 + k);
 			}
@@ -720,18 +740,17 @@ __global__ __launch_bounds__(64) void mnc_dp_align(Batch B, uint8_t *ws_all, lon
 	const AlignWs W = align_ws(state_max, p_max, cig_max);
 	uint8_t *ws = ws_all + (size_t)blockIdx.x * W.total;
 	const int sc_mch = B.sc_a, sc_mis = -B.sc_b, sc_N = -B.sc_ambi;
-	// pass 0: every segment of the round that is neither large nor the banded kernel's; 1: the large
+	// pass 0: the segments of the round that are neither large nor another kernel's; 1: the large
 	// ones; 2: what the banded kernel handed back
-	const unsigned long long n_items = big_pass == 0 ? B.dp_ctr[0] : big_pass == 1 ? B.dp_ctr[6] : B.dp_ctr[12];
-	const int ctr_q = big_pass == 0 ? 3 : big_pass == 1 ? 7 : 15;
+	const unsigned long long n_items = big_pass == 0 ? B.dp_ctr[20] : big_pass == 1 ? B.dp_ctr[6] : B.dp_ctr[12];
+	const int ctr_q = big_pass == 0 ? 21 : big_pass == 1 ? 7 : 15;
 	for (;;) {
 		unsigned long long qi = 0;
 		if (lane == 0) qi = atomicAdd(&B.dp_ctr[ctr_q], 1ULL);
 		qi = (unsigned long long)__shfl((long long)qi, 0);
 		if (qi >= n_items) break;                              // every wave reaches this: the queue is finite
-		const long long si = big_pass == 0 ? (long long)qi : big_pass == 1 ? (long long)B.big_list[qi] : (long long)B.fill_fb[qi];
+		const long long si = big_pass == 0 ? (long long)B.gen_list[qi] : big_pass == 1 ? (long long)B.big_list[qi] : (long long)B.fill_fb[qi];
 		Seg g = B.segs[si];
-		if (big_pass == 0 && g.big) continue;
 		Ez ez;
 		ez.max = 0, ez.zdropped = 0, ez.max_q = ez.max_t = ez.mqe_t = -1, ez.mqe = ez.score = DP_NEG_INF, ez.reach_end = 0, ez.n_cigar = 0;
 		int zdrop_code = 0;
@@ -1182,7 +1201,8 @@ __global__ void mnc_dp_round(Batch B, int first)
 	B.dp_ctr[9] = B.dp_ctr[5];            // regions to plan / stitch this round
 	B.dp_ctr[5] = 0;
 	B.dp_ctr[6] = 0, B.dp_ctr[7] = 0;
-	for (int k = 10; k < 16; ++k) B.dp_ctr[k] = 0;   // banded kernel: list lengths 10 / 11 / 12 (tier 1, tier 2, handed back), queues 13 / 14 / 15
+	for (int k = 10; k < 24; ++k) B.dp_ctr[k] = 0;   // banded kernel: list lengths 10 / 11 / 12 (tier 1, tier 2, handed back), queues 13 / 14 / 15;
+	                                                 // extension kernel: lists 16 / 17, queues 18 / 19; literal kernel's first pass: list 20, queue 21; banded kernel, 128 cells: list 22, queue 23
 }
 __global__ void mnc_dp_round_end(Batch B)
 {

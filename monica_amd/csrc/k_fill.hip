@@ -64,9 +64,12 @@ __host__ __device__ __forceinline__ int fill_gap(int l, int q, int e, int q2, in
 // band of half-width b around the diagonals 0 .. d (d = tlen - qlen): offsets i - j in [kmin, kmax]
 __host__ __device__ __forceinline__ void fill_band(int n, int m, int lanes, int &b, int &kmin, int &kmax)
 {
+	// kmin is kept even (one diagonal more below when needed): then the parity of the steps on which
+	// t0 advances is the same for every segment of a wave
 	const int d = n - m, ad = d < 0 ? -d : d;
-	b = (2 * lanes - 2 - ad) / 2;
+	b = (2 * lanes - 3 - ad) / 2;
 	kmin = (d < 0 ? d : 0) - b, kmax = (d > 0 ? d : 0) + b;
+	if (kmin & 1) --kmin;
 }
 
 // the best score any global path can have that leaves the band (see the header)
@@ -91,21 +94,23 @@ __host__ __device__ __forceinline__ int dp_band_bound(int n, int m, int kmin, in
 	return U;
 }
 
-// LANES = 32: two segments per wave; 64: one.  Proof failures go to `next_list` (the wider tier, or
-// the literal kernel), CIGARs whose walk shows a large score drop to `fb_list` (the literal kernel
+// LANES = 32: two segments per wave; 64: one; CPL cells per lane (64 x 2: a band of 128 cells for
+// the long gaps whose bound needs it).  Proof failures go to `next_list` (the wider tier, or the
+// literal kernel), CIGARs whose walk shows a large score drop to `fb_list` (the literal kernel
 // runs minimap2's exact second pass).
-template <int LANES>
+template <int LANES, int CPL>
 __global__ __launch_bounds__(64) void mnc_dp_fill(Batch B, const int32_t *list, int ctr_n, int ctr_q, int32_t *next_list, int ctr_next,
                                                   int32_t *fb_list, int ctr_fb, uint8_t *p_all)
 {
-	constexpr int SEGS = 64 / LANES;
+	constexpr int SEGS = 64 / LANES, W = LANES * CPL, ROWB = 64 * CPL;   // cells per segment and step; bytes per step of the wave
+	static_assert(CPL == 1 || LANES == 64, "several cells per lane: one segment per wave");
 	__shared__ uint8_t s_t[SEGS][FILL_MAX_LEN + 1], s_q[SEGS][FILL_MAX_LEN + 1];
-	__shared__ __align__(16) uint8_t s_win[SEGS][FILL_WIN * LANES];
+	__shared__ __align__(16) uint8_t s_win[SEGS][FILL_WIN * W];
 	__shared__ uint32_t s_cg[SEGS][2 * FILL_MAX_LEN + 2];
 	const int lane = threadIdx.x, sg = lane / LANES, L = lane % LANES, lead = sg * LANES;
 	const bool leader = L == 0;
 	const int a = B.sc_a, bmis = -B.sc_b, scN = -B.sc_ambi, q = B.gap_q, e = B.gap_e, q2 = B.gap_q2, e2 = B.gap_e2;
-	uint8_t *p_wave = p_all + (size_t)blockIdx.x * FILL_P_SLOT;
+	uint8_t *p_wave = p_all + (size_t)blockIdx.x * (FILL_P_SLOT * CPL);
 	const unsigned long long n_items = B.dp_ctr[ctr_n];
 	for (;;) {
 		unsigned long long q0 = 0;
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(64) void mnc_dp_fill(Batch B, const int32_t *list, 
 		}
 		const int n = g.tlen, m = g.qlen;
 		int b, kmin, kmax;
-		fill_band(n, m, LANES, b, kmin, kmax);
+		fill_band(n, m, W, b, kmin, kmax);
 		bool ok = has && n >= 1 && m >= 1 && n <= FILL_MAX_LEN && m <= FILL_MAX_LEN && b >= FILL_MIN_BAND;
 		// ---- sequences
 		if (ok) {
@@ -142,59 +147,78 @@ __global__ __launch_bounds__(64) void mnc_dp_fill(Batch B, const int32_t *list, 
 		const int rows = ok ? n + m - 1 : 0;
 		int max_rows = rows;
 		if (SEGS == 2) { const int o = __shfl_xor(max_rows, 32); max_rows = max_rows > o ? max_rows : o; }
-		// ---- forward: one anti-diagonal per step
-		int H1 = FILL_NEG, H2 = FILL_NEG, En = FILL_NEG, E2n = FILL_NEG, Fn = FILL_NEG, F2n = FILL_NEG, Sc = FILL_NEG;
-		uint8_t *prow = p_wave + lane;
-		for (int r = 0; r < max_rows; ++r, prow += 64) {
+		// ---- forward: one anti-diagonal per step; cell c = L + LANES * k of the band holds t = t0 + c
+		int H1[CPL], H2[CPL], En[CPL], E2n[CPL], Fn[CPL], F2n[CPL], Sc = FILL_NEG;
+#pragma unroll
+		for (int k = 0; k < CPL; ++k) H1[k] = H2[k] = En[k] = E2n[k] = Fn[k] = F2n[k] = FILL_NEG;
+		uint8_t *prow = p_wave + lead * CPL + L;
+		for (int r = 0; r < max_rows; ++r, prow += ROWB) {
 			const int t0 = (r + kmin + 1) >> 1;
-			// t0(r) = ceil((r + kmin) / 2) advances on the steps where r + kmin is odd: then the left
-			// neighbour sits one lane up, else the upper one one lane down.  Uniform over the wave.
-			// The two gap states that cross lanes this step: DPP wave shifts, one instruction each.
-			int sE, sE2, sF, sF2;
-			if (((r + kmin) & 1) == 0) {
-				sE = __builtin_amdgcn_update_dpp(FILL_NEG, En, 0x138, 0xf, 0xf, false);      // wave_shr:1
-				sE2 = __builtin_amdgcn_update_dpp(FILL_NEG, E2n, 0x138, 0xf, 0xf, false);
-				if (LANES == 32 && L == 0) sE = sE2 = FILL_NEG;                                // lane 32 got the other segment's
-				sF = Fn, sF2 = F2n;
-			} else {
-				sF = __builtin_amdgcn_update_dpp(FILL_NEG, Fn, 0x130, 0xf, 0xf, false);      // wave_shl:1
-				sF2 = __builtin_amdgcn_update_dpp(FILL_NEG, F2n, 0x130, 0xf, 0xf, false);
-				if (LANES == 32 && L == LANES - 1) sF = sF2 = FILL_NEG;
-				sE = En, sE2 = E2n;
-			}
-			const int t = t0 + L, j = r - t;
-			const bool act = r < rows && t >= 0 && j >= 0 && t < n && j < m && 2 * t - r <= kmax;
-			int Hn = FILL_NEG, nEn = FILL_NEG, nE2n = FILL_NEG, nFn = FILL_NEG, nF2n = FILL_NEG;
-			if (act) {
-				const int ct = s_t[sg][t], cq = s_q[sg][j];
-				const int sc = (ct == 4 || cq == 4) ? scN : ct == cq ? a : bmis;
-				int hd = H2;
-				if (t == 0 || j == 0) {                              // virtual row / column: gaps from the corner
-					hd = t == 0 && j == 0 ? 0 : -fill_gap(t == 0 ? j : t, q, e, q2, e2);
-					if (t == 0) { const int hb = -fill_gap(j + 1, q, e, q2, e2); sE = hb - q - e, sE2 = hb - q2 - e2; }
-					if (j == 0) { const int hb = -fill_gap(t + 1, q, e, q2, e2); sF = hb - q - e, sF2 = hb - q2 - e2; }
+			// t0(r) = ceil((r + kmin) / 2) advances on the odd steps (kmin is even): then the left
+			// neighbour is the next cell of the band, else the upper one the previous cell.  Uniform over
+			// the wave.  The two gap states that cross cells this step: DPP wave shifts, one instruction
+			// each (and a readlane where a lane's second cell follows the last lane's first).
+			int sE[CPL], sE2[CPL], sF[CPL], sF2[CPL];
+			if ((r & 1) == 0) {                                   // kmin is even
+#pragma unroll
+				for (int k = 0; k < CPL; ++k) {
+					sE[k] = __builtin_amdgcn_update_dpp(FILL_NEG, En[k], 0x138, 0xf, 0xf, false);      // wave_shr:1
+					sE2[k] = __builtin_amdgcn_update_dpp(FILL_NEG, E2n[k], 0x138, 0xf, 0xf, false);
+					if (L == 0) {                                      // (lane 32 of a two-segment wave got the other segment's)
+						if (k == 0) sE[k] = sE2[k] = FILL_NEG;
+						else sE[k] = __builtin_amdgcn_readlane(En[k > 0 ? k - 1 : 0], 63), sE2[k] = __builtin_amdgcn_readlane(E2n[k > 0 ? k - 1 : 0], 63);
+					}
+					sF[k] = Fn[k], sF2[k] = F2n[k];
 				}
-				int z = hd + sc, d;
-				d = sE > z ? 1 : 0;  z = z > sE ? z : sE;
-				d = sF > z ? 2 : d;  z = z > sF ? z : sF;
-				d = sE2 > z ? 3 : d; z = z > sE2 ? z : sE2;
-				d = sF2 > z ? 4 : d; z = z > sF2 ? z : sF2;
-				Hn = z;
-				const int o1 = z - q, o2 = z - q2;
-				d |= sE > o1 ? 0x08 : 0;  nEn = (sE > o1 ? sE : o1) - e;
-				d |= sF > o1 ? 0x10 : 0;  nFn = (sF > o1 ? sF : o1) - e;
-				d |= sE2 > o2 ? 0x20 : 0; nE2n = (sE2 > o2 ? sE2 : o2) - e2;
-				d |= sF2 > o2 ? 0x40 : 0; nF2n = (sF2 > o2 ? sF2 : o2) - e2;
-				*prow = (uint8_t)d;
-				if (r == rows - 1) Sc = Hn;                          // the corner: the global score
+			} else {
+#pragma unroll
+				for (int k = 0; k < CPL; ++k) {
+					sF[k] = __builtin_amdgcn_update_dpp(FILL_NEG, Fn[k], 0x130, 0xf, 0xf, false);      // wave_shl:1
+					sF2[k] = __builtin_amdgcn_update_dpp(FILL_NEG, F2n[k], 0x130, 0xf, 0xf, false);
+					if (L == LANES - 1) {
+						if (k == CPL - 1) sF[k] = sF2[k] = FILL_NEG;
+						else sF[k] = __builtin_amdgcn_readlane(Fn[k + 1 < CPL ? k + 1 : k], 0), sF2[k] = __builtin_amdgcn_readlane(F2n[k + 1 < CPL ? k + 1 : k], 0);
+					}
+					sE[k] = En[k], sE2[k] = E2n[k];
+				}
 			}
-			H2 = H1, H1 = Hn, En = nEn, E2n = nE2n, Fn = nFn, F2n = nF2n;
+#pragma unroll
+			for (int k = 0; k < CPL; ++k) {
+				const int t = t0 + L + LANES * k, j = r - t;
+				const bool act = r < rows && t >= 0 && j >= 0 && t < n && j < m && 2 * t - r <= kmax;
+				int Hn = FILL_NEG, nEn = FILL_NEG, nE2n = FILL_NEG, nFn = FILL_NEG, nF2n = FILL_NEG;
+				if (act) {
+					const int ct = s_t[sg][t], cq = s_q[sg][j];
+					const int sc = (ct == 4 || cq == 4) ? scN : ct == cq ? a : bmis;
+					int hd = H2[k], vE = sE[k], vE2 = sE2[k], vF = sF[k], vF2 = sF2[k];
+					if (t == 0 || j == 0) {                            // virtual row / column: gaps from the corner
+						hd = t == 0 && j == 0 ? 0 : -fill_gap(t == 0 ? j : t, q, e, q2, e2);
+						if (t == 0) { const int hb = -fill_gap(j + 1, q, e, q2, e2); vE = hb - q - e, vE2 = hb - q2 - e2; }
+						if (j == 0) { const int hb = -fill_gap(t + 1, q, e, q2, e2); vF = hb - q - e, vF2 = hb - q2 - e2; }
+					}
+					int z = hd + sc, d;
+					d = vE > z ? 1 : 0;  z = z > vE ? z : vE;
+					d = vF > z ? 2 : d;  z = z > vF ? z : vF;
+					d = vE2 > z ? 3 : d; z = z > vE2 ? z : vE2;
+					d = vF2 > z ? 4 : d; z = z > vF2 ? z : vF2;
+					Hn = z;
+					const int o1 = z - q, o2 = z - q2;
+					d |= vE > o1 ? 0x08 : 0;  nEn = (vE > o1 ? vE : o1) - e;
+					d |= vF > o1 ? 0x10 : 0;  nFn = (vF > o1 ? vF : o1) - e;
+					d |= vE2 > o2 ? 0x20 : 0; nE2n = (vE2 > o2 ? vE2 : o2) - e2;
+					d |= vF2 > o2 ? 0x40 : 0; nF2n = (vF2 > o2 ? vF2 : o2) - e2;
+					prow[LANES * k] = (uint8_t)d;
+					if (r == rows - 1) Sc = Hn;                        // the corner: the global score
+				}
+				H2[k] = H1[k], H1[k] = Hn, En[k] = nEn, E2n[k] = nE2n, Fn[k] = nFn, F2n[k] = nF2n;
+			}
 		}
 		// ---- the proof: every path that leaves the band scores at most U
 		int S = FILL_NEG;
 		{
-			const int lc = ok ? n - 1 - ((rows - 1 + kmin + 1) >> 1) : 0;
-			S = __shfl(Sc, lead + (lc < 0 ? 0 : lc >= LANES ? LANES - 1 : lc));
+			int lc = ok ? n - 1 - ((rows - 1 + kmin + 1) >> 1) : 0;
+			lc = lc < 0 ? 0 : lc >= W ? W - 1 : lc;
+			S = __shfl(Sc, lead + lc % LANES);
 			const int U = dp_band_bound(n, m, kmin, kmax, a, q, e, q2, e2);
 			if (ok && !(S > U)) ok = false;
 		}
@@ -207,11 +231,14 @@ __global__ __launch_bounds__(64) void mnc_dp_fill(Batch B, const int32_t *list, 
 		for (;;) {
 			const int seg_r = __shfl(walking ? bi + bj : -1, lead), seg_wlo = __shfl(wlo, lead);
 			if (!__any(seg_r >= 0)) break;
-			if (seg_r >= 0 && seg_r < seg_wlo) {                   // refill: rows [lo, lo + FILL_WIN), 16 bytes per lane
+			if (seg_r >= 0 && seg_r < seg_wlo) {                   // refill: rows [lo, lo + FILL_WIN), 16 bytes per lane and cell
 				const int lo = seg_r - (FILL_WIN - 1) > 0 ? seg_r - (FILL_WIN - 1) : 0;
-				const int byte0 = L * 16, row = lo + byte0 / LANES, col = byte0 % LANES;
-				const uint4 v = *reinterpret_cast<const uint4*>(p_wave + (size_t)row * 64 + lead + col);
-				*reinterpret_cast<uint4*>(&s_win[sg][byte0]) = v;
+#pragma unroll
+				for (int k = 0; k < CPL; ++k) {
+					const int byte0 = (L + LANES * k) * 16, row = lo + byte0 / W, col = byte0 % W;
+					const uint4 v = *reinterpret_cast<const uint4*>(p_wave + (size_t)row * ROWB + lead * CPL + col);
+					*reinterpret_cast<uint4*>(&s_win[sg][byte0]) = v;
+				}
 				wlo = lo;
 			}
 			fill_order();
@@ -220,8 +247,8 @@ __global__ __launch_bounds__(64) void mnc_dp_fill(Batch B, const int32_t *list, 
 					const int r = bi + bj;
 					if (r < wlo) break;
 					const int idx = bi - ((r + kmin + 1) >> 1);
-					if (idx < 0 || idx >= LANES || 2 * bi - r > kmax) { walking = false, to_next = true; break; }   // cannot happen after the proof
-					const uint32_t tmp = s_win[sg][(r - wlo) * LANES + idx];
+					if (idx < 0 || idx >= W || 2 * bi - r > kmax) { walking = false, to_next = true; break; }   // cannot happen after the proof
+					const uint32_t tmp = s_win[sg][(r - wlo) * W + idx];
 					if (state == 0) state = tmp & 7;
 					else if (!(tmp >> (state + 2) & 1)) state = 0;
 					if (state == 0) state = tmp & 7;
@@ -298,12 +325,232 @@ __global__ __launch_bounds__(64) void mnc_dp_fill(Batch B, const int32_t *list, 
 	}
 }
 
+// ================================================================ extensions
+// The left and right extension of a region (ksw_extd2 with KSW_EZ_EXTZ_ONLY): from the corner
+// outwards until the Z-drop, reporting the best cell (or the end of the query).  For the flanks of
+// most reads the matrix is small and the band (751) never clips it, so the kernel's result is the
+// plain two-piece affine DP's; an anti-diagonal has at most min(qlen, tlen) cells: one lane each
+// (32 lanes: two segments per wave).  Beyond what the gap-filling kernel does, every step finds
+// the maximum of its anti-diagonal in the SSE scan's tie order (the last cell first, then four
+// interleaved lanes, then the tail: DPP max-reduce of (H, rank) keys), updates the best cell or
+// tests the Z-drop against it, and tracks the best score in the query's last row.  The left
+// extension runs on reversed sequences with gaps right-aligned (ties go to the later candidate).
+template <int LANES>
+__global__ __launch_bounds__(64) void mnc_dp_ext(Batch B, const int32_t *list, int ctr_n, int ctr_q, int32_t *fb_list, int ctr_fb, uint8_t *p_all)
+{
+	constexpr int SEGS = 64 / LANES, SEQ = 2 * FILL_MAX_LEN + 2;
+	__shared__ uint8_t s_t[SEGS][SEQ], s_q[SEGS][SEQ];
+	__shared__ __align__(16) uint8_t s_win[SEGS][FILL_WIN * LANES];
+	__shared__ uint32_t s_cg[SEGS][SEQ];
+	const int lane = threadIdx.x, sg = lane / LANES, L = lane % LANES, lead = sg * LANES;
+	const bool leader = L == 0;
+	const int a = B.sc_a, bmis = -B.sc_b, scN = -B.sc_ambi, q = B.gap_q, e = B.gap_e, q2 = B.gap_q2, e2 = B.gap_e2;
+	uint8_t *p_wave = p_all + (size_t)blockIdx.x * FILL_P_SLOT;
+	const unsigned long long n_items = B.dp_ctr[ctr_n];
+	for (;;) {
+		unsigned long long q0 = 0;
+		if (lane == 0) q0 = atomicAdd(&B.dp_ctr[ctr_q], (unsigned long long)SEGS);
+		q0 = (unsigned long long)__shfl((long long)q0, 0);
+		if (q0 >= n_items) break;                              // every wave gets here: the queue is finite
+		const bool has = q0 + sg < n_items;
+		const long long si = has ? (long long)list[q0 + sg] : -1;
+		struct { int32_t tlen, qlen, ts, qs, read, rid, rev, kind, zdrop, flag; } g = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+		if (has) {
+			const Seg *gs = B.segs + si;
+			g.tlen = gs->tlen, g.qlen = gs->qlen, g.ts = gs->ts, g.qs = gs->qs, g.read = gs->read, g.rid = gs->rid, g.rev = gs->rev;
+			g.kind = gs->kind, g.zdrop = gs->zdrop, g.flag = gs->flag;
+		}
+		const int n = g.tlen, m = g.qlen;
+		const int mn = n < m ? n : m;
+		const bool ok = has && n >= 1 && m >= 1 && mn <= LANES && n + m - 1 <= 2 * FILL_MAX_LEN;
+		const int rgt = (g.flag & EZ_RIGHT) ? 1 : 0;          // gaps right-aligned: a later candidate wins a tie
+		if (ok) {
+			const uint8_t *read = B.bases + B.offsets[g.read];
+			const int rlen = (int)(B.offsets[g.read + 1] - B.offsets[g.read]);
+			const int64_t coff = B.seq_off[g.rid];
+			const bool rv = g.kind == 0;                          // the left extension: both sequences reversed
+			for (int i = L; i < n; i += LANES) {
+				const int64_t o = coff + (rv ? g.ts + n - 1 - i : g.ts + i);
+				s_t[sg][i] = (uint8_t)(B.seq4[o >> 3] >> ((o & 7) * 4) & 15u);
+			}
+			for (int i = L; i < m; i += LANES) {
+				const int pq = rv ? g.qs + m - 1 - i : g.qs + i;
+				const int c = fill_nt4(read[g.rev ? rlen - 1 - pq : pq]);
+				s_q[sg][i] = (uint8_t)(g.rev ? (c < 4 ? 3 - c : 4) : c);
+			}
+		}
+		fill_order();
+		const int rows = ok ? n + m - 1 : 0;
+		int max_rows = rows;
+		if (SEGS == 2) { const int o = __shfl_xor(max_rows, 32); max_rows = max_rows > o ? max_rows : o; }
+		// per-segment state of ksw_extz_t (the same value in every lane of the segment)
+		int ez_max = 0, ez_max_t = -1, ez_max_q = -1, ez_mqe = DP_NEG_INF, ez_mqe_t = -1, zdropped = 0;
+		int H1 = FILL_NEG, H2 = FILL_NEG, En = FILL_NEG, E2n = FILL_NEG, Fn = FILL_NEG, F2n = FILL_NEG;
+		uint8_t *prow = p_wave + lane;
+		for (int r = 0; r < max_rows; ++r, prow += 64) {
+			if (__all(zdropped || r >= rows)) break;
+			// lane L holds t = st0 + L, st0 = max(0, r - m + 1): while r < m the upper neighbour and the
+			// diagonal one sit one lane down; from r = m on the left neighbour sits one lane up (and the
+			// diagonal one, from r = m + 1 on)
+			const int uE = __builtin_amdgcn_update_dpp(FILL_NEG, En, 0x138, 0xf, 0xf, false), uE2 = __builtin_amdgcn_update_dpp(FILL_NEG, E2n, 0x138, 0xf, 0xf, false);
+			const int uH = __builtin_amdgcn_update_dpp(FILL_NEG, H2, 0x138, 0xf, 0xf, false);
+			const int dF = __builtin_amdgcn_update_dpp(FILL_NEG, Fn, 0x130, 0xf, 0xf, false), dF2 = __builtin_amdgcn_update_dpp(FILL_NEG, F2n, 0x130, 0xf, 0xf, false);
+			const int dH = __builtin_amdgcn_update_dpp(FILL_NEG, H2, 0x130, 0xf, 0xf, false);
+			const bool lo = L == 0, hi = L == LANES - 1;
+			int sE, sE2, sF, sF2, hd;
+			if (r < m) sE = lo ? FILL_NEG : uE, sE2 = lo ? FILL_NEG : uE2, sF = Fn, sF2 = F2n, hd = lo ? FILL_NEG : uH;
+			else sE = En, sE2 = E2n, sF = hi ? FILL_NEG : dF, sF2 = hi ? FILL_NEG : dF2, hd = r == m ? H2 : (hi ? FILL_NEG : dH);
+			const int st0 = r - m + 1 > 0 ? r - m + 1 : 0, en0 = r < n - 1 ? r : n - 1;
+			const int t = st0 + L, j = r - t;
+			const bool act = !zdropped && r < rows && t <= en0;
+			int Hn = FILL_NEG, nEn = FILL_NEG, nE2n = FILL_NEG, nFn = FILL_NEG, nF2n = FILL_NEG;
+			if (act) {
+				const int ct = s_t[sg][t], cq = s_q[sg][j];
+				const int sc = (ct == 4 || cq == 4) ? scN : ct == cq ? a : bmis;
+				if (t == 0 || j == 0) {
+					hd = t == 0 && j == 0 ? 0 : -fill_gap(t == 0 ? j : t, q, e, q2, e2);
+					if (t == 0) { const int hb = -fill_gap(j + 1, q, e, q2, e2); sE = hb - q - e, sE2 = hb - q2 - e2; }
+					if (j == 0) { const int hb = -fill_gap(t + 1, q, e, q2, e2); sF = hb - q - e, sF2 = hb - q2 - e2; }
+				}
+				int z = hd + sc, d;
+				d = sE + rgt > z ? 1 : 0;  z = z > sE ? z : sE;
+				d = sF + rgt > z ? 2 : d;  z = z > sF ? z : sF;
+				d = sE2 + rgt > z ? 3 : d; z = z > sE2 ? z : sE2;
+				d = sF2 + rgt > z ? 4 : d; z = z > sF2 ? z : sF2;
+				Hn = z;
+				const int o1 = z - q, o2 = z - q2;
+				d |= sE + rgt > o1 ? 0x08 : 0;  nEn = (sE > o1 ? sE : o1) - e;
+				d |= sF + rgt > o1 ? 0x10 : 0;  nFn = (sF > o1 ? sF : o1) - e;
+				d |= sE2 + rgt > o2 ? 0x20 : 0; nE2n = (sE2 > o2 ? sE2 : o2) - e2;
+				d |= sF2 + rgt > o2 ? 0x40 : 0; nF2n = (sF2 > o2 ? sF2 : o2) - e2;
+				*prow = (uint8_t)d;
+			}
+			H2 = H1, H1 = Hn, En = nEn, E2n = nE2n, Fn = nFn, F2n = nF2n;
+			// ---- the maximum of the anti-diagonal, ties in the SSE scan's order
+			unsigned long long key = 0;
+			if (act) {
+				const int en1 = st0 + (en0 - st0) / 4 * 4;
+				const unsigned rank = t == en0 ? 0u : t < en1 ? 1u + ((unsigned)(t - st0) & 3u) * 0x1000000u + ((unsigned)(t - st0) >> 2)
+				                                            : 1u + 4u * 0x1000000u + (unsigned)(t - en1);
+				key = (unsigned long long)(unsigned)(Hn + (1 << 30)) << 32 | (0xffffffffu - rank);
+			}
+			{
+				// max-reduce inside the segment: rows of 16 lanes, then across them
+#define MNC_KMAX(ctrl, rmask) { const unsigned lo32 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)key, ctrl, rmask, 0xf, false), \
+	hi32 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(key >> 32), ctrl, rmask, 0xf, false); \
+	const unsigned long long o = (unsigned long long)hi32 << 32 | lo32; key = key > o ? key : o; }
+				MNC_KMAX(0x111, 0xf) MNC_KMAX(0x112, 0xf) MNC_KMAX(0x114, 0xf) MNC_KMAX(0x118, 0xf) MNC_KMAX(0x142, 0xa)
+				if (LANES == 64) MNC_KMAX(0x143, 0xc)
+#undef MNC_KMAX
+			}
+			const unsigned long long kseg = (unsigned long long)__shfl((long long)key, lead + LANES - 1);
+			const int h_lead = __shfl(Hn, lead);                   // H of the cell in the query's last row, when there is one
+			if (!zdropped && r < rows) {
+				const int max_H = (int)(unsigned)(kseg >> 32) - (1 << 30);
+				const unsigned mr = 0xffffffffu - (unsigned)kseg;
+				const int en1 = st0 + (en0 - st0) / 4 * 4;
+				int max_t;
+				if (mr == 0) max_t = en0;
+				else if (mr < 1u + 4u * 0x1000000u) { const unsigned k = mr - 1u; max_t = st0 + (int)((k & 0xffffffu) * 4u + (k >> 24)); }
+				else max_t = en1 + (int)(mr - 1u - 4u * 0x1000000u);
+				if (r - st0 == m - 1 && h_lead > ez_mqe) ez_mqe = h_lead, ez_mqe_t = st0;
+				// ksw_apply_zdrop
+				if (max_H > ez_max) ez_max = max_H, ez_max_t = max_t, ez_max_q = r - max_t;
+				else if (max_t >= ez_max_t && r - max_t >= ez_max_q) {
+					const int tl = max_t - ez_max_t, ql = (r - max_t) - ez_max_q;
+					const int l = tl > ql ? tl - ql : ql - tl;
+					if (g.zdrop >= 0 && ez_max - max_H > g.zdrop + l * e2) zdropped = 1;
+				}
+			}
+		}
+		// ---- where the backtrack starts
+		int bi = -1, bj = -1, reach_end = 0;
+		if (ok) {
+			if (!zdropped && ez_mqe + B.end_bonus > ez_max) reach_end = 1, bi = ez_mqe_t, bj = m - 1;
+			else if (ez_max_t >= 0 && ez_max_q >= 0) bi = ez_max_t, bj = ez_max_q;
+		}
+		fill_order_mem();
+		int state = 0, n_c = 0, wlo = 1 << 30;
+		uint32_t cur = 0;
+		bool walking = ok && bi >= 0 && bj >= 0, bad = false;
+		for (;;) {
+			const int seg_r = __shfl(walking ? bi + bj : -1, lead), seg_wlo = __shfl(wlo, lead);
+			if (!__any(seg_r >= 0)) break;
+			if (seg_r >= 0 && seg_r < seg_wlo) {
+				const int lo = seg_r - (FILL_WIN - 1) > 0 ? seg_r - (FILL_WIN - 1) : 0;
+				const int byte0 = L * 16, row = lo + byte0 / LANES, col = byte0 % LANES;
+				const uint4 v = *reinterpret_cast<const uint4*>(p_wave + (size_t)row * 64 + lead + col);
+				*reinterpret_cast<uint4*>(&s_win[sg][byte0]) = v;
+				wlo = lo;
+			}
+			fill_order();
+			if (leader && walking) {
+				while (bi >= 0 && bj >= 0) {
+					const int r = bi + bj;
+					if (r < wlo) break;
+					const int idx = bi - (r - m + 1 > 0 ? r - m + 1 : 0);
+					if (idx < 0 || idx >= LANES) { walking = false, bad = true; break; }
+					const uint32_t tmp = s_win[sg][(r - wlo) * LANES + idx];
+					if (state == 0) state = tmp & 7;
+					else if (!(tmp >> (state + 2) & 1)) state = 0;
+					if (state == 0) state = tmp & 7;
+					uint32_t op;
+					if (state == 0) op = 0, --bi, --bj;
+					else if (state == 1 || state == 3) op = 2, --bi;
+					else op = 1, --bj;
+					if (cur != 0 && (cur & 0xf) == op) cur += 1u << 4;
+					else { if (cur != 0) s_cg[sg][n_c++] = cur; cur = 1u << 4 | op; }
+				}
+				if (walking && (bi < 0 || bj < 0)) {
+					if (bi >= 0) { if (cur != 0 && (cur & 0xf) == 2) cur += (uint32_t)(bi + 1) << 4; else { if (cur != 0) s_cg[sg][n_c++] = cur; cur = (uint32_t)(bi + 1) << 4 | 2; } }
+					if (bj >= 0) { if (cur != 0 && (cur & 0xf) == 1) cur += (uint32_t)(bj + 1) << 4; else { if (cur != 0) s_cg[sg][n_c++] = cur; cur = (uint32_t)(bj + 1) << 4 | 1; } }
+					if (cur != 0) s_cg[sg][n_c++] = cur;
+					walking = false;
+				}
+			}
+			fill_order();
+		}
+		const bool s_bad = __shfl((int)(bad || (has && !ok)), lead) != 0;
+		const int s_nc = __shfl(n_c, lead);
+		if (has && s_bad) {
+			if (leader) { const unsigned long long k = atomicAdd(&B.dp_ctr[ctr_fb], 1ULL); fb_list[k] = (int32_t)si; }
+		} else if (has) {
+			unsigned long long off = 0;
+			if (leader && s_nc > 0) off = atomicAdd(&B.dp_ctr[1], (unsigned long long)s_nc);
+			off = (unsigned long long)__shfl((long long)off, lead);
+			int wrote = s_nc;
+			if ((long long)(off + s_nc) > B.cig_seg_cap) {
+				if (leader) atomicMax(&B.dp_ctr[4], 2ULL);
+				wrote = 0;
+			} else {
+				// ksw_backtrack leaves the CIGAR last operation first; KSW_EZ_REV_CIGAR keeps that order
+				const bool keep = (g.flag & EZ_REV_CIGAR) != 0;
+				for (int k = L; k < s_nc; k += LANES) B.cig_seg[off + k] = s_cg[sg][keep ? k : s_nc - 1 - k];
+			}
+			if (leader) {
+				Seg *o = B.segs + si;
+				o->n_cigar = wrote, o->zdropped = zdropped, o->zdrop_code = 0;
+				o->max = ez_max, o->max_t = ez_max_t, o->max_q = ez_max_q, o->score = DP_NEG_INF, o->reach_end = reach_end, o->mqe_t = ez_mqe_t;
+				o->cig_off = (int64_t)off;
+			}
+		}
+		fill_order_mem();
+	}
+}
+
 size_t dp_fill_p_slot() { return FILL_P_SLOT; }
 void launch_dp_fill(const Batch &B, int lanes, const int32_t *list, int ctr_n, int ctr_q, int32_t *next_list, int ctr_next,
                     int32_t *fb_list, int ctr_fb, uint8_t *p_all, int n_wg, hipStream_t st)
 {
-	if (lanes == 32) hipLaunchKernelGGL(mnc_dp_fill<32>, dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all);
-	else hipLaunchKernelGGL(mnc_dp_fill<64>, dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all);
+	if (lanes == 32) hipLaunchKernelGGL((mnc_dp_fill<32, 1>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all);
+	else if (lanes == 64) hipLaunchKernelGGL((mnc_dp_fill<64, 1>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all);
+	else hipLaunchKernelGGL((mnc_dp_fill<64, 2>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all);
+}
+
+void launch_dp_ext(const Batch &B, int lanes, const int32_t *list, int ctr_n, int ctr_q, int32_t *fb_list, int ctr_fb, uint8_t *p_all, int n_wg, hipStream_t st)
+{
+	if (lanes == 32) hipLaunchKernelGGL(mnc_dp_ext<32>, dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, fb_list, ctr_fb, p_all);
+	else hipLaunchKernelGGL(mnc_dp_ext<64>, dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, fb_list, ctr_fb, p_all);
 }
 
 } // namespace mnc

@@ -9,8 +9,9 @@ The reference uses exactly this surface (monica/genomes/aligner.py):
 
 `Aligner.map` is the per-read slow path kept for fidelity; `Aligner.map_batch` is what
 `monica_amd.aligner.aligner` uses: one C-ABI call per micro-batch, all compute on the GPU.
-Hits follow the chain-level contract of DESIGN.md section 1 (no base-level DP):
-`NM := blen - mlen`, MAPQ from the chain-level branch of minimap2's formula.
+Hits carry what mappy computes with its always-on base-level alignment (MM_F_CIGAR): `mapq` from
+the DP branch of minimap2's formula, `mlen` / `blen` / `NM = blen - mlen + n_ambi` from the CIGAR
+(the restatement is unpinned against the real library, see there).
 """
 import os
 import threading
@@ -80,11 +81,11 @@ def default_device():
 
 
 class Hit:
-    """The attributes of a mappy alignment that exist without base-level alignment."""
+    """The attributes of a mappy alignment."""
     __slots__ = ("ctg", "ctg_len", "r_st", "r_en", "q_st", "q_en", "strand", "mapq", "mlen", "blen", "NM",
-                 "is_primary", "score", "n_anchors")
+                 "is_primary", "score", "n_anchors", "cigar")
 
-    def __init__(self, reg, index):
+    def __init__(self, reg, index, cigar=None):
         rid = int(reg["rid"])
         self.ctg = index.contig_names[rid]
         self.ctg_len = index.contig_lens[rid]
@@ -93,10 +94,15 @@ class Hit:
         self.strand = -1 if reg["rev"] else 1
         self.mapq = int(reg["mapq"])
         self.mlen, self.blen = int(reg["mlen"]), int(reg["blen"])
-        self.NM = self.blen - self.mlen
+        self.NM = self.blen - self.mlen + int(reg["n_ambi"])
+        self.cigar = [[l, "MID".index(op)] for l, op in cigar] if cigar else []      # mappy: [[length, op], ...]
         self.is_primary = bool(reg["id"] == reg["parent"])
         self.score = int(reg["score"])
         self.n_anchors = int(reg["cnt"])
+
+    @property
+    def cigar_str(self):
+        return "".join(f"{l}{'MID'[op]}" for l, op in self.cigar)
 
     def __repr__(self):
         return (f"{self.q_st}\t{self.q_en}\t{'+' if self.strand > 0 else '-'}\t{self.ctg}\t{self.ctg_len}\t"
@@ -210,5 +216,6 @@ class Aligner:
         eng = self.engine()
         eng.classify(np.frombuffer(b, dtype=np.uint8), np.array([0, len(b)], dtype=np.int64), 0)
         regs = eng.dump(_capi.DUMP_REGS, _capi.REG_DTYPE)
-        for reg in regs:
-            yield Hit(reg, self._index)
+        cigs = eng.cigars()
+        for reg, cig in zip(regs, cigs):
+            yield Hit(reg, self._index, cig)
