@@ -199,6 +199,28 @@ def main():
                     "traffic": traffic, "algorithmic_bytes_per_launch": int(algo_bytes),
                     "avg_launch_ms": round(probe_ms / probe_n, 4), "launches": probe_n}
 
+    # the probe STAGE: partition + probe + collect, the same algorithmic bytes
+    # (the stage's useful work: queries in, one table slot per query, hits out) over the three
+    # kernels' time; `traffic` = their HBM bytes from the PMC passes, when profiles/ holds them
+    roofline_stage = None
+    try:
+        st_ms = sum(timings[k][0] / max(timings[k][1], 1) for k in ("partition", "probe", "collect"))
+        if st_ms > 0:
+            ach = algo_bytes / (st_ms / 1e3) / 1e9
+            st_traffic = None
+            try:
+                with open(args.traffic_json) as f:
+                    tj = json.load(f)
+                if tj.get("reads") == args.reads and tj.get("read_len") == args.read_len:
+                    st_traffic = tj.get("stage_hbm_bytes_per_launch")
+            except Exception:
+                pass
+            roofline_stage = {"bound": "hbm", "kernels": ["mnc_partition_queries (+ scans)", "mnc_probe_buckets", "mnc_collect_hits"],
+                              "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                              "traffic": st_traffic, "algorithmic_bytes_per_launch": int(algo_bytes), "ms": round(st_ms, 4)}
+    except Exception:
+        pass
+
     # ---------------------------------------------------------------- CPU baseline (oracle, bounded sample)
     cpu = None
     if world == 1 and args.cpu_sample != 0:
@@ -251,6 +273,7 @@ def main():
                    "parallelism": f"read-sharded x{world}, index replicated, RCCL all-reduce of "
                                   f"{n_genomes * 3} int64 counts per step"},
         "roofline": roofline,
+        "roofline_stage": roofline_stage,
         "cpu_baseline": cpu,
         "chain_level": chain_level,
         "stage_ms_per_step": {k: round(v[0] / max(v[1], 1), 4) for k, v in timings.items() if v[1]},

@@ -267,6 +267,24 @@ int mnc_hitmap_update(mnc_hitmap *hm, const mnc_fastq *fq, const mnc_index *idx,
 int mnc_hitmap_n_names(const mnc_hitmap *hm);
 const char *mnc_hitmap_name(const mnc_hitmap *hm, int id);
 
+/* ---------------------------------------------------------------- collectives (RCCL over xGMI)
+ * The cross-process forms of monica's two merges, on a caller-supplied ncclComm_t and HIP stream
+ * (librccl.so is opened on first use; the library does not link it):
+ *   mnc_allreduce_counts     <- Counter.update in alignment_update (aligner.py:286-298) when the reads
+ *                               of a batch are sharded over GPUs: int64 sum of the count table
+ *                               (n = n_genomes * 3 for the table mnc_classify_device fills), in place
+ *   mnc_allgather_summaries  <- the hits carried between index parts (aligner.py:91-103, 196-203,
+ *                               218-223) when the parts live on different GPUs: every rank's per-read
+ *                               summary block {hits, nm, mlen, contig, tied} (20 B per read), in rank
+ *                               order; the merge itself is mnc_best_hit's rule per read
+ * mnc_comm_* make / free a communicator through this ABI alone (ncclGetUniqueId on one rank, the
+ * 128 bytes handed to the others by any means, ncclCommInitRank on all). */
+int mnc_comm_unique_id(void *id128);
+int mnc_comm_init_rank(const void *id128, int n_ranks, int rank, void **comm);
+int mnc_comm_destroy(void *comm);
+int mnc_allreduce_counts(int64_t *d_counts, int n, void *comm, void *stream);
+int mnc_allgather_summaries(const void *d_send, void *d_recv, size_t bytes_per_rank, void *comm, void *stream);
+
 /* page-locked host memory for batch buffers (plain malloc when no GPU is present) */
 void *mnc_host_alloc(size_t bytes);
 void mnc_host_free(void *p);

@@ -45,7 +45,8 @@ EXPORTS = [
     "mnc_engine_create", "mnc_engine_destroy", "mnc_engine_stream",
     "mnc_classify_batch", "mnc_classify_device", "mnc_engine_sync", "mnc_engine_fetch_hits",
     "mnc_counts", "mnc_best_hit",
-    "mnc_engine_set_profiling", "mnc_engine_set_debug", "mnc_engine_set_contract", "mnc_engine_get_timings", "mnc_stage_name", "mnc_stage_kernel",
+    "mnc_engine_set_profiling", "mnc_engine_set_debug", "mnc_engine_set_contract",
+    "mnc_comm_unique_id", "mnc_comm_init_rank", "mnc_comm_destroy", "mnc_allreduce_counts", "mnc_allgather_summaries", "mnc_engine_get_timings", "mnc_stage_name", "mnc_stage_kernel",
     "mnc_engine_get_counters", "mnc_engine_dump",
     "mnc_fastq_open", "mnc_fastq_close", "mnc_fastq_next", "mnc_fastq_bases", "mnc_fastq_offsets",
     "mnc_fastq_quals", "mnc_fastq_title", "mnc_fastq_route",
@@ -125,6 +126,11 @@ def lib():
     sig("mnc_engine_set_profiling", i32, [vp, i32])
     sig("mnc_engine_set_debug", i32, [vp, i32])
     sig("mnc_engine_set_contract", i32, [vp, i32])
+    sig("mnc_comm_unique_id", i32, [vp])
+    sig("mnc_comm_init_rank", i32, [vp, i32, i32, C.POINTER(vp)])
+    sig("mnc_comm_destroy", i32, [vp])
+    sig("mnc_allreduce_counts", i32, [vp, i32, vp, vp])
+    sig("mnc_allgather_summaries", i32, [vp, vp, C.c_size_t, vp, vp])
     sig("mnc_engine_get_timings", i32, [vp, vp, vp, i32])
     sig("mnc_stage_name", cp, [i32])
     sig("mnc_stage_kernel", cp, [i32])
@@ -163,6 +169,42 @@ def check(code):
 
 def _b(s):
     return s if isinstance(s, (bytes, bytearray)) else str(s).encode()
+
+
+class Comm:
+    """An RCCL communicator made through the C-ABI (`mnc_comm_*`): rank 0 calls `Comm.unique_id()`,
+    hands the 128 bytes to the other ranks by any means, every rank constructs `Comm(id, n, rank)`
+    with its device current."""
+
+    def __init__(self, unique_id, n_ranks, rank):
+        h = C.c_void_p()
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        check(lib().mnc_comm_init_rank(buf, int(n_ranks), int(rank), C.byref(h)))
+        self._h, self.n_ranks, self.rank = h, int(n_ranks), int(rank)
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * 128)()
+        check(lib().mnc_comm_unique_id(buf))
+        return bytes(buf)
+
+    def allreduce_counts(self, d_counts_ptr, n, stream=None):
+        check(lib().mnc_allreduce_counts(C.c_void_p(d_counts_ptr), int(n), self._h, C.c_void_p(stream or 0)))
+
+    def allgather_summaries(self, d_send_ptr, d_recv_ptr, bytes_per_rank, stream=None):
+        check(lib().mnc_allgather_summaries(C.c_void_p(d_send_ptr), C.c_void_p(d_recv_ptr), int(bytes_per_rank), self._h,
+                                            C.c_void_p(stream or 0)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mnc_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def device_count():

@@ -492,7 +492,6 @@ __global__ __launch_bounds__(64) void mnc_regions_post(Batch B, mnc_reg_t *work_
 {
 	const uint32_t rd = blockIdx.x * blockDim.x + threadIdx.x;
 	if (rd >= B.n_reads) return;
-	const int qlen = (int)(B.offsets[rd + 1] - B.offsets[rd]);
 	int32_t assign = MNC_UNMAPPED, nhits = 0;
 	mnc_hit_t best;
 	best.rid = best.mapq = best.nm = best.mlen = 0;

@@ -45,8 +45,42 @@ def shard_bounds(n, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def allreduce_counts(counts):
+class PipeGroup:
+    """A process group over `multiprocessing` pipes (a star around rank 0) with the two collectives
+    this path needs.  For hosts without torch.distributed / RCCL -- the same reductions a C caller
+    gets from `mnc_allreduce_counts` / `mnc_allgather_summaries` -- and for tests of the merge
+    rules with real processes."""
+
+    def __init__(self, rank, world, conns):
+        """conns: on rank 0 a list of world - 1 connections (to ranks 1..), else [the connection to rank 0]."""
+        self.rank, self.world, self.conns = rank, world, conns
+
+    @staticmethod
+    def make(world):
+        """Connections for `world` processes: element r goes to rank r's constructor."""
+        import multiprocessing as mp
+        pairs = [mp.Pipe() for _ in range(world - 1)]
+        return [[a for a, _ in pairs]] + [[b] for _, b in pairs]
+
+    def all_gather(self, t):
+        if self.rank == 0:
+            parts = [t] + [torch.from_numpy(c.recv()) for c in self.conns]
+            for c in self.conns:
+                c.send([p.cpu().numpy() for p in parts])
+            return parts
+        self.conns[0].send(t.cpu().numpy())
+        return [torch.from_numpy(a) for a in self.conns[0].recv()]
+
+    def all_reduce_sum(self, t):
+        total = sum(self.all_gather(t))
+        t.copy_(total.to(t.device))
+        return t
+
+
+def allreduce_counts(counts, group=None):
     """Sum the per-genome count table over ranks, in place (torch tensor)."""
+    if group is not None:
+        return group.all_reduce_sum(counts)
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     return counts
@@ -96,9 +130,11 @@ def merge_summaries(stacked):
     return assign.to(torch.int32), nm.to(torch.int32), ml.to(torch.int32), total.to(torch.int32)
 
 
-def gather_and_merge(summary):
+def gather_and_merge(summary, group=None):
     """All-gather the per-part summaries (rank order = part order) and merge them."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if group is not None:
+        stacked = torch.stack([p.to(summary.device) for p in group.all_gather(summary.contiguous())])
+    elif dist.is_initialized() and dist.get_world_size() > 1:
         parts = [torch.empty_like(summary) for _ in range(dist.get_world_size())]
         dist.all_gather(parts, summary.contiguous())
         stacked = torch.stack(parts)

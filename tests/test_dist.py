@@ -111,3 +111,41 @@ def test_world_size_2_gloo(oracle):
     assert got_counts.sum() == sum(1 for w in want if w >= 0)
     assert got_counts.tolist() == [sum(1 for w in want if w == g) for g in range(4)]
     assert sum(1 for w in want if w >= 0) > 90
+
+
+def _pipe_worker(rank, world, conns, q):
+    sys.path.insert(0, ROOT)
+    g = mdist.PipeGroup(rank, world, conns)
+    rng = np.random.default_rng(5)                       # every rank draws the same table, takes its rows
+    n = 500
+    summ = torch.zeros((world, n, 5), dtype=torch.int32)
+    summ[:, :, 0] = torch.from_numpy(rng.integers(0, 3, (world, n)).astype(np.int32))
+    summ[:, :, 1] = torch.from_numpy(rng.integers(0, 6, (world, n)).astype(np.int32))
+    summ[:, :, 2] = torch.from_numpy(rng.integers(1, 12, (world, n)).astype(np.int32))
+    summ[:, :, 3] = torch.where(summ[:, :, 0] > 0, torch.from_numpy(rng.integers(0, 50, (world, n)).astype(np.int32)), torch.tensor(-1, dtype=torch.int32))
+    summ[:, :, 4] = torch.from_numpy((rng.random((world, n)) < 0.1).astype(np.int32)) * (summ[:, :, 0] > 1).to(torch.int32)
+    merged = mdist.gather_and_merge(summ[rank], group=g)
+    counts = torch.arange(12, dtype=torch.int64) * (rank + 1)
+    mdist.allreduce_counts(counts, group=g)
+    q.put((rank, [m.numpy() for m in merged], counts.numpy(), summ.numpy()))
+
+
+def test_world_size_3_without_torch_distributed():
+    """The same two reductions over plain pipes (no gloo, no RCCL): what a host that drives the
+    C-ABI's mnc_allreduce_counts / mnc_allgather_summaries itself has to reproduce."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    conns = mdist.PipeGroup.make(world)
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, conns[r], q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=120) for _ in range(world)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = [m.numpy() for m in mdist.merge_summaries(torch.from_numpy(got[0][3]))]
+    for rank, merged, counts, _ in got:
+        for a, b in zip(merged, want):
+            assert np.array_equal(a, b), rank
+        assert counts.tolist() == [k * (1 + 2 + 3) for k in range(12)]

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Average rocprofv3 PMC counters per kernel launch (separate --pmc passes, as the MI355X guide
+prescribes) and write profiles/<tag>_pmc_hbm_counters.json + profiles/probe_traffic.json."""
+import collections, csv, glob, json, os, sys
+
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in glob.glob(os.path.join(root, "gpurun_out", f"pmc_{tag}_*")):
+    if not os.path.isdir(d):
+        continue
+    for f in glob.glob(os.path.join(d, "**", "out_counter_collection.csv"), recursive=True):
+        per = collections.defaultdict(dict)
+        for r in csv.DictReader(open(f)):
+            key = (r["Dispatch_Id"], r["Kernel_Name"].split("(")[0])
+            per[key][r["Counter_Name"]] = per[key].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        for (_, k), cs in per.items():
+            for c, v in cs.items():
+                agg[k][c].append(v)
+out = {k: {c: {"avg_per_launch": sum(v) / len(v), "launches": len(v)} for c, v in cs.items()} for k, cs in agg.items()}
+json.dump(out, open(os.path.join(root, "profiles", f"{tag}_pmc_hbm_counters.json"), "w"), indent=1)
+
+
+def hbm(kernel):          # FETCH_SIZE / WRITE_SIZE are in KiB; FETCH doubled (gfx950 correction for coalesced streams)
+    k = [x for x in out if x.endswith(kernel)]
+    if not k:
+        return None
+    c = out[k[0]]
+    return (2 * c["FETCH_SIZE"]["avg_per_launch"] + c["WRITE_SIZE"]["avg_per_launch"]) * 1024
+
+
+probe = hbm("mnc_probe_buckets")
+stage = [hbm(k) for k in ("mnc_partition_queries", "mnc_probe_buckets", "mnc_collect_hits")]
+if probe:
+    pk = [x for x in out if x.endswith("mnc_probe_buckets")][0]
+    json.dump({"kernel": "mnc_probe_buckets", "reads": 100000, "read_len": 5000, "hbm_bytes_per_launch": int(probe),
+               "stage_hbm_bytes_per_launch": int(sum(x for x in stage if x)),
+               "fetch_size_kib": out[pk]["FETCH_SIZE"]["avg_per_launch"], "write_size_kib": out[pk]["WRITE_SIZE"]["avg_per_launch"],
+               "tcc_hit": out[pk].get("TCC_HIT_sum", {}).get("avg_per_launch"), "tcc_miss": out[pk].get("TCC_MISS_sum", {}).get("avg_per_launch"),
+               "note": f"{tag}: separate rocprofv3 --pmc passes of bench.py --steps 2 --warmup 1 --contract chain (tools/prof_r02.sh); "
+                       "FETCH_SIZE/WRITE_SIZE in KiB; FETCH doubled per the guide's gfx950 correction for coalesced streams; "
+                       "stage = partition + probe + collect"},
+              open(os.path.join(root, "profiles", "probe_traffic.json"), "w"), indent=1)
+    print("probe HBM bytes/launch", int(probe), "stage", int(sum(x for x in stage if x)))
+ks = glob.glob(os.path.join(root, "gpurun_out", f"prof_{tag}", "**", "out_kernel_stats.csv"), recursive=True)
+if ks:
+    import shutil
+    shutil.copy(ks[0], os.path.join(root, "profiles", f"{tag}_kernel_stats.csv"))
+b = os.path.join(root, "gpurun_out", f"prof_{tag}_bench_under_rocprof.json")
+if os.path.exists(b):
+    import shutil
+    shutil.copy(b, os.path.join(root, "profiles", f"{tag}_bench_under_rocprof.json"))
