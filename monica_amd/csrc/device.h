@@ -214,6 +214,7 @@ struct Batch {
 	int32_t *fill_list1, *fill_list2, *fill_fb;   // banded gap-filling kernel: 32-lane tier, 64-lane tier, handed back
 	int32_t *fill_list3;                          // ... and the 128-cell tier
 	int32_t *ext_list1, *ext_list2;               // extension kernel: 32 / 64 lanes per segment
+	int32_t *ext_list3, *ext_list4;               // ... 128 / 256 cells (two / four per lane)
 	int32_t *gen_list;                            // the literal kernel's first pass
 	int32_t *reg_cnt;             // per read: regions in the skeleton's array (kept + split tails)
 };

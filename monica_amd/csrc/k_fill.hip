@@ -103,7 +103,6 @@ __global__ __launch_bounds__(64) void mnc_dp_fill(Batch B, const int32_t *list, 
                                                   int32_t *fb_list, int ctr_fb, uint8_t *p_all)
 {
 	constexpr int SEGS = 64 / LANES, W = LANES * CPL, ROWB = 64 * CPL;   // cells per segment and step; bytes per step of the wave
-	static_assert(CPL == 1 || LANES == 64, "several cells per lane: one segment per wave");
 	__shared__ uint8_t s_t[SEGS][FILL_MAX_LEN + 1], s_q[SEGS][FILL_MAX_LEN + 1];
 	__shared__ __align__(16) uint8_t s_win[SEGS][FILL_WIN * W];
 	__shared__ uint32_t s_cg[SEGS][2 * FILL_MAX_LEN + 2];
@@ -164,10 +163,13 @@ __global__ __launch_bounds__(64) void mnc_dp_fill(Batch B, const int32_t *list, 
 				for (int k = 0; k < CPL; ++k) {
 					sE[k] = __builtin_amdgcn_update_dpp(FILL_NEG, En[k], 0x138, 0xf, 0xf, false);      // wave_shr:1
 					sE2[k] = __builtin_amdgcn_update_dpp(FILL_NEG, E2n[k], 0x138, 0xf, 0xf, false);
-					if (L == 0) {                                      // (lane 32 of a two-segment wave got the other segment's)
-						if (k == 0) sE[k] = sE2[k] = FILL_NEG;
-						else sE[k] = __builtin_amdgcn_readlane(En[k > 0 ? k - 1 : 0], 63), sE2[k] = __builtin_amdgcn_readlane(E2n[k > 0 ? k - 1 : 0], 63);
-					}
+					// the first lane of a segment: nothing below its first cell; its next cells follow the last
+					// lane's previous ones (lane 32 of a two-segment wave got the other segment's)
+					if (k > 0) {
+						const int pe = LANES == 64 ? __builtin_amdgcn_readlane(En[k > 0 ? k - 1 : 0], 63) : __shfl(En[k > 0 ? k - 1 : 0], lead + LANES - 1);
+						const int pe2 = LANES == 64 ? __builtin_amdgcn_readlane(E2n[k > 0 ? k - 1 : 0], 63) : __shfl(E2n[k > 0 ? k - 1 : 0], lead + LANES - 1);
+						if (L == 0) sE[k] = pe, sE2[k] = pe2;
+					} else if (L == 0) sE[k] = sE2[k] = FILL_NEG;
 					sF[k] = Fn[k], sF2[k] = F2n[k];
 				}
 			} else {
@@ -175,10 +177,11 @@ __global__ __launch_bounds__(64) void mnc_dp_fill(Batch B, const int32_t *list, 
 				for (int k = 0; k < CPL; ++k) {
 					sF[k] = __builtin_amdgcn_update_dpp(FILL_NEG, Fn[k], 0x130, 0xf, 0xf, false);      // wave_shl:1
 					sF2[k] = __builtin_amdgcn_update_dpp(FILL_NEG, F2n[k], 0x130, 0xf, 0xf, false);
-					if (L == LANES - 1) {
-						if (k == CPL - 1) sF[k] = sF2[k] = FILL_NEG;
-						else sF[k] = __builtin_amdgcn_readlane(Fn[k + 1 < CPL ? k + 1 : k], 0), sF2[k] = __builtin_amdgcn_readlane(F2n[k + 1 < CPL ? k + 1 : k], 0);
-					}
+					if (k < CPL - 1) {
+						const int nf = LANES == 64 ? __builtin_amdgcn_readlane(Fn[k + 1 < CPL ? k + 1 : k], 0) : __shfl(Fn[k + 1 < CPL ? k + 1 : k], lead);
+						const int nf2 = LANES == 64 ? __builtin_amdgcn_readlane(F2n[k + 1 < CPL ? k + 1 : k], 0) : __shfl(F2n[k + 1 < CPL ? k + 1 : k], lead);
+						if (L == LANES - 1) sF[k] = nf, sF2[k] = nf2;
+					} else if (L == LANES - 1) sF[k] = sF2[k] = FILL_NEG;
 					sE[k] = En[k], sE2[k] = E2n[k];
 				}
 			}
@@ -335,17 +338,18 @@ __global__ __launch_bounds__(64) void mnc_dp_fill(Batch B, const int32_t *list, 
 // interleaved lanes, then the tail: DPP max-reduce of (H, rank) keys), updates the best cell or
 // tests the Z-drop against it, and tracks the best score in the query's last row.  The left
 // extension runs on reversed sequences with gaps right-aligned (ties go to the later candidate).
-template <int LANES>
+template <int LANES, int CPL>
 __global__ __launch_bounds__(64) void mnc_dp_ext(Batch B, const int32_t *list, int ctr_n, int ctr_q, int32_t *fb_list, int ctr_fb, uint8_t *p_all)
 {
-	constexpr int SEGS = 64 / LANES, SEQ = 2 * FILL_MAX_LEN + 2;
+	constexpr int SEGS = 64 / LANES, W = LANES * CPL, ROWB = 64 * CPL, SEQ = 2 * FILL_MAX_LEN + 2;
+	static_assert(CPL == 1 || LANES == 64, "several cells per lane: one segment per wave");
 	__shared__ uint8_t s_t[SEGS][SEQ], s_q[SEGS][SEQ];
-	__shared__ __align__(16) uint8_t s_win[SEGS][FILL_WIN * LANES];
+	__shared__ __align__(16) uint8_t s_win[SEGS][FILL_WIN * W];
 	__shared__ uint32_t s_cg[SEGS][SEQ];
 	const int lane = threadIdx.x, sg = lane / LANES, L = lane % LANES, lead = sg * LANES;
 	const bool leader = L == 0;
 	const int a = B.sc_a, bmis = -B.sc_b, scN = -B.sc_ambi, q = B.gap_q, e = B.gap_e, q2 = B.gap_q2, e2 = B.gap_e2;
-	uint8_t *p_wave = p_all + (size_t)blockIdx.x * FILL_P_SLOT;
+	uint8_t *p_wave = p_all + (size_t)blockIdx.x * (FILL_P_SLOT * CPL);
 	const unsigned long long n_items = B.dp_ctr[ctr_n];
 	for (;;) {
 		unsigned long long q0 = 0;
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(64) void mnc_dp_ext(Batch B, const int32_t *list, i
 		}
 		const int n = g.tlen, m = g.qlen;
 		const int mn = n < m ? n : m;
-		const bool ok = has && n >= 1 && m >= 1 && mn <= LANES && n + m - 1 <= 2 * FILL_MAX_LEN;
+		const bool ok = has && n >= 1 && m >= 1 && mn <= W && n + m - 1 <= 2 * FILL_MAX_LEN;
 		const int rgt = (g.flag & EZ_RIGHT) ? 1 : 0;          // gaps right-aligned: a later candidate wins a tie
 		if (ok) {
 			const uint8_t *read = B.bases + B.offsets[g.read];
@@ -385,54 +389,72 @@ __global__ __launch_bounds__(64) void mnc_dp_ext(Batch B, const int32_t *list, i
 		if (SEGS == 2) { const int o = __shfl_xor(max_rows, 32); max_rows = max_rows > o ? max_rows : o; }
 		// per-segment state of ksw_extz_t (the same value in every lane of the segment)
 		int ez_max = 0, ez_max_t = -1, ez_max_q = -1, ez_mqe = DP_NEG_INF, ez_mqe_t = -1, zdropped = 0;
-		int H1 = FILL_NEG, H2 = FILL_NEG, En = FILL_NEG, E2n = FILL_NEG, Fn = FILL_NEG, F2n = FILL_NEG;
-		uint8_t *prow = p_wave + lane;
-		for (int r = 0; r < max_rows; ++r, prow += 64) {
+		int H1[CPL], H2[CPL], En[CPL], E2n[CPL], Fn[CPL], F2n[CPL];
+#pragma unroll
+		for (int k = 0; k < CPL; ++k) H1[k] = H2[k] = En[k] = E2n[k] = Fn[k] = F2n[k] = FILL_NEG;
+		uint8_t *prow = p_wave + lead * CPL + L;
+		for (int r = 0; r < max_rows; ++r, prow += ROWB) {
 			if (__all(zdropped || r >= rows)) break;
-			// lane L holds t = st0 + L, st0 = max(0, r - m + 1): while r < m the upper neighbour and the
-			// diagonal one sit one lane down; from r = m on the left neighbour sits one lane up (and the
-			// diagonal one, from r = m + 1 on)
-			const int uE = __builtin_amdgcn_update_dpp(FILL_NEG, En, 0x138, 0xf, 0xf, false), uE2 = __builtin_amdgcn_update_dpp(FILL_NEG, E2n, 0x138, 0xf, 0xf, false);
-			const int uH = __builtin_amdgcn_update_dpp(FILL_NEG, H2, 0x138, 0xf, 0xf, false);
-			const int dF = __builtin_amdgcn_update_dpp(FILL_NEG, Fn, 0x130, 0xf, 0xf, false), dF2 = __builtin_amdgcn_update_dpp(FILL_NEG, F2n, 0x130, 0xf, 0xf, false);
-			const int dH = __builtin_amdgcn_update_dpp(FILL_NEG, H2, 0x130, 0xf, 0xf, false);
-			const bool lo = L == 0, hi = L == LANES - 1;
-			int sE, sE2, sF, sF2, hd;
-			if (r < m) sE = lo ? FILL_NEG : uE, sE2 = lo ? FILL_NEG : uE2, sF = Fn, sF2 = F2n, hd = lo ? FILL_NEG : uH;
-			else sE = En, sE2 = E2n, sF = hi ? FILL_NEG : dF, sF2 = hi ? FILL_NEG : dF2, hd = r == m ? H2 : (hi ? FILL_NEG : dH);
+			// cell c = L + LANES * k holds t = st0 + c, st0 = max(0, r - m + 1): while r < m the upper
+			// neighbour and the diagonal one are the previous cell; from r = m on the left neighbour is the
+			// next cell (and the diagonal one, from r = m + 1 on)
 			const int st0 = r - m + 1 > 0 ? r - m + 1 : 0, en0 = r < n - 1 ? r : n - 1;
-			const int t = st0 + L, j = r - t;
-			const bool act = !zdropped && r < rows && t <= en0;
-			int Hn = FILL_NEG, nEn = FILL_NEG, nE2n = FILL_NEG, nFn = FILL_NEG, nF2n = FILL_NEG;
-			if (act) {
-				const int ct = s_t[sg][t], cq = s_q[sg][j];
-				const int sc = (ct == 4 || cq == 4) ? scN : ct == cq ? a : bmis;
-				if (t == 0 || j == 0) {
-					hd = t == 0 && j == 0 ? 0 : -fill_gap(t == 0 ? j : t, q, e, q2, e2);
-					if (t == 0) { const int hb = -fill_gap(j + 1, q, e, q2, e2); sE = hb - q - e, sE2 = hb - q2 - e2; }
-					if (j == 0) { const int hb = -fill_gap(t + 1, q, e, q2, e2); sF = hb - q - e, sF2 = hb - q2 - e2; }
-				}
-				int z = hd + sc, d;
-				d = sE + rgt > z ? 1 : 0;  z = z > sE ? z : sE;
-				d = sF + rgt > z ? 2 : d;  z = z > sF ? z : sF;
-				d = sE2 + rgt > z ? 3 : d; z = z > sE2 ? z : sE2;
-				d = sF2 + rgt > z ? 4 : d; z = z > sF2 ? z : sF2;
-				Hn = z;
-				const int o1 = z - q, o2 = z - q2;
-				d |= sE + rgt > o1 ? 0x08 : 0;  nEn = (sE > o1 ? sE : o1) - e;
-				d |= sF + rgt > o1 ? 0x10 : 0;  nFn = (sF > o1 ? sF : o1) - e;
-				d |= sE2 + rgt > o2 ? 0x20 : 0; nE2n = (sE2 > o2 ? sE2 : o2) - e2;
-				d |= sF2 + rgt > o2 ? 0x40 : 0; nF2n = (sF2 > o2 ? sF2 : o2) - e2;
-				*prow = (uint8_t)d;
-			}
-			H2 = H1, H1 = Hn, En = nEn, E2n = nE2n, Fn = nFn, F2n = nF2n;
-			// ---- the maximum of the anti-diagonal, ties in the SSE scan's order
+			const int en1 = st0 + (en0 - st0) / 4 * 4;
 			unsigned long long key = 0;
-			if (act) {
-				const int en1 = st0 + (en0 - st0) / 4 * 4;
-				const unsigned rank = t == en0 ? 0u : t < en1 ? 1u + ((unsigned)(t - st0) & 3u) * 0x1000000u + ((unsigned)(t - st0) >> 2)
-				                                            : 1u + 4u * 0x1000000u + (unsigned)(t - en1);
-				key = (unsigned long long)(unsigned)(Hn + (1 << 30)) << 32 | (0xffffffffu - rank);
+			int h_first = FILL_NEG;
+			int sE_[CPL], sE2_[CPL], sF_[CPL], sF2_[CPL], hd_[CPL];
+#pragma unroll
+			for (int k = 0; k < CPL; ++k) {
+				int uE = __builtin_amdgcn_update_dpp(FILL_NEG, En[k], 0x138, 0xf, 0xf, false), uE2 = __builtin_amdgcn_update_dpp(FILL_NEG, E2n[k], 0x138, 0xf, 0xf, false);
+				int uH = __builtin_amdgcn_update_dpp(FILL_NEG, H2[k], 0x138, 0xf, 0xf, false);
+				int dF = __builtin_amdgcn_update_dpp(FILL_NEG, Fn[k], 0x130, 0xf, 0xf, false), dF2 = __builtin_amdgcn_update_dpp(FILL_NEG, F2n[k], 0x130, 0xf, 0xf, false);
+				int dH = __builtin_amdgcn_update_dpp(FILL_NEG, H2[k], 0x130, 0xf, 0xf, false);
+				if (L == 0) {
+					if (k == 0) uE = uE2 = uH = FILL_NEG;
+					else uE = __builtin_amdgcn_readlane(En[k > 0 ? k - 1 : 0], 63), uE2 = __builtin_amdgcn_readlane(E2n[k > 0 ? k - 1 : 0], 63), uH = __builtin_amdgcn_readlane(H2[k > 0 ? k - 1 : 0], 63);
+				}
+				if (L == LANES - 1) {
+					if (k == CPL - 1) dF = dF2 = dH = FILL_NEG;
+					else dF = __builtin_amdgcn_readlane(Fn[k + 1 < CPL ? k + 1 : k], 0), dF2 = __builtin_amdgcn_readlane(F2n[k + 1 < CPL ? k + 1 : k], 0), dH = __builtin_amdgcn_readlane(H2[k + 1 < CPL ? k + 1 : k], 0);
+				}
+				sE_[k] = r < m ? uE : En[k], sE2_[k] = r < m ? uE2 : E2n[k];
+				sF_[k] = r < m ? Fn[k] : dF, sF2_[k] = r < m ? F2n[k] : dF2;
+				hd_[k] = r < m ? uH : r == m ? H2[k] : dH;
+			}
+#pragma unroll
+			for (int k = 0; k < CPL; ++k) {
+				int sE = sE_[k], sE2 = sE2_[k], sF = sF_[k], sF2 = sF2_[k], hd = hd_[k];
+				const int t = st0 + L + LANES * k, j = r - t;
+				const bool act = !zdropped && r < rows && t <= en0;
+				int Hn = FILL_NEG, nEn = FILL_NEG, nE2n = FILL_NEG, nFn = FILL_NEG, nF2n = FILL_NEG;
+				if (act) {
+					const int ct = s_t[sg][t], cq = s_q[sg][j];
+					const int sc = (ct == 4 || cq == 4) ? scN : ct == cq ? a : bmis;
+					if (t == 0 || j == 0) {
+						hd = t == 0 && j == 0 ? 0 : -fill_gap(t == 0 ? j : t, q, e, q2, e2);
+						if (t == 0) { const int hb = -fill_gap(j + 1, q, e, q2, e2); sE = hb - q - e, sE2 = hb - q2 - e2; }
+						if (j == 0) { const int hb = -fill_gap(t + 1, q, e, q2, e2); sF = hb - q - e, sF2 = hb - q2 - e2; }
+					}
+					int z = hd + sc, d;
+					d = sE + rgt > z ? 1 : 0;  z = z > sE ? z : sE;
+					d = sF + rgt > z ? 2 : d;  z = z > sF ? z : sF;
+					d = sE2 + rgt > z ? 3 : d; z = z > sE2 ? z : sE2;
+					d = sF2 + rgt > z ? 4 : d; z = z > sF2 ? z : sF2;
+					Hn = z;
+					const int o1 = z - q, o2 = z - q2;
+					d |= sE + rgt > o1 ? 0x08 : 0;  nEn = (sE > o1 ? sE : o1) - e;
+					d |= sF + rgt > o1 ? 0x10 : 0;  nFn = (sF > o1 ? sF : o1) - e;
+					d |= sE2 + rgt > o2 ? 0x20 : 0; nE2n = (sE2 > o2 ? sE2 : o2) - e2;
+					d |= sF2 + rgt > o2 ? 0x40 : 0; nF2n = (sF2 > o2 ? sF2 : o2) - e2;
+					prow[LANES * k] = (uint8_t)d;
+					// the maximum of the anti-diagonal, ties in the SSE scan's order
+					const unsigned rank = t == en0 ? 0u : t < en1 ? 1u + ((unsigned)(t - st0) & 3u) * 0x1000000u + ((unsigned)(t - st0) >> 2)
+					                                            : 1u + 4u * 0x1000000u + (unsigned)(t - en1);
+					const unsigned long long kk = (unsigned long long)(unsigned)(Hn + (1 << 30)) << 32 | (0xffffffffu - rank);
+					key = key > kk ? key : kk;
+				}
+				if (k == 0) h_first = Hn;
+				H2[k] = H1[k], H1[k] = Hn, En[k] = nEn, E2n[k] = nE2n, Fn[k] = nFn, F2n[k] = nF2n;
 			}
 			{
 				// max-reduce inside the segment: rows of 16 lanes, then across them
@@ -444,11 +466,10 @@ __global__ __launch_bounds__(64) void mnc_dp_ext(Batch B, const int32_t *list, i
 #undef MNC_KMAX
 			}
 			const unsigned long long kseg = (unsigned long long)__shfl((long long)key, lead + LANES - 1);
-			const int h_lead = __shfl(Hn, lead);                   // H of the cell in the query's last row, when there is one
+			const int h_lead = __shfl(h_first, lead);              // H of the cell in the query's last row, when there is one
 			if (!zdropped && r < rows) {
 				const int max_H = (int)(unsigned)(kseg >> 32) - (1 << 30);
 				const unsigned mr = 0xffffffffu - (unsigned)kseg;
-				const int en1 = st0 + (en0 - st0) / 4 * 4;
 				int max_t;
 				if (mr == 0) max_t = en0;
 				else if (mr < 1u + 4u * 0x1000000u) { const unsigned k = mr - 1u; max_t = st0 + (int)((k & 0xffffffu) * 4u + (k >> 24)); }
@@ -478,9 +499,12 @@ __global__ __launch_bounds__(64) void mnc_dp_ext(Batch B, const int32_t *list, i
 			if (!__any(seg_r >= 0)) break;
 			if (seg_r >= 0 && seg_r < seg_wlo) {
 				const int lo = seg_r - (FILL_WIN - 1) > 0 ? seg_r - (FILL_WIN - 1) : 0;
-				const int byte0 = L * 16, row = lo + byte0 / LANES, col = byte0 % LANES;
-				const uint4 v = *reinterpret_cast<const uint4*>(p_wave + (size_t)row * 64 + lead + col);
-				*reinterpret_cast<uint4*>(&s_win[sg][byte0]) = v;
+#pragma unroll
+				for (int k = 0; k < CPL; ++k) {
+					const int byte0 = (L + LANES * k) * 16, row = lo + byte0 / W, col = byte0 % W;
+					const uint4 v = *reinterpret_cast<const uint4*>(p_wave + (size_t)row * ROWB + lead * CPL + col);
+					*reinterpret_cast<uint4*>(&s_win[sg][byte0]) = v;
+				}
 				wlo = lo;
 			}
 			fill_order();
@@ -489,8 +513,8 @@ __global__ __launch_bounds__(64) void mnc_dp_ext(Batch B, const int32_t *list, i
 					const int r = bi + bj;
 					if (r < wlo) break;
 					const int idx = bi - (r - m + 1 > 0 ? r - m + 1 : 0);
-					if (idx < 0 || idx >= LANES) { walking = false, bad = true; break; }
-					const uint32_t tmp = s_win[sg][(r - wlo) * LANES + idx];
+					if (idx < 0 || idx >= W) { walking = false, bad = true; break; }
+					const uint32_t tmp = s_win[sg][(r - wlo) * W + idx];
 					if (state == 0) state = tmp & 7;
 					else if (!(tmp >> (state + 2) & 1)) state = 0;
 					if (state == 0) state = tmp & 7;
@@ -549,8 +573,10 @@ void launch_dp_fill(const Batch &B, int lanes, const int32_t *list, int ctr_n, i
 
 void launch_dp_ext(const Batch &B, int lanes, const int32_t *list, int ctr_n, int ctr_q, int32_t *fb_list, int ctr_fb, uint8_t *p_all, int n_wg, hipStream_t st)
 {
-	if (lanes == 32) hipLaunchKernelGGL(mnc_dp_ext<32>, dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, fb_list, ctr_fb, p_all);
-	else hipLaunchKernelGGL(mnc_dp_ext<64>, dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, fb_list, ctr_fb, p_all);
+	if (lanes == 32) hipLaunchKernelGGL((mnc_dp_ext<32, 1>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, fb_list, ctr_fb, p_all);
+	else if (lanes == 64) hipLaunchKernelGGL((mnc_dp_ext<64, 1>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, fb_list, ctr_fb, p_all);
+	else if (lanes == 128) hipLaunchKernelGGL((mnc_dp_ext<64, 2>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, fb_list, ctr_fb, p_all);
+	else hipLaunchKernelGGL((mnc_dp_ext<64, 4>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, fb_list, ctr_fb, p_all);
 }
 
 } // namespace mnc
