@@ -100,6 +100,8 @@ def main():
                                         first=rank * args.reads)
     engine = _capi.Engine(index, local_rank)
     engine.set_contract(_capi.CONTRACT_DP if args.contract == "dp" else _capi.CONTRACT_CHAIN)
+    if os.environ.get("MNC_FILL_PRED"):
+        engine.set_debug(int(os.environ["MNC_FILL_PRED"]) << 8)
     n_genomes = info.n_genomes
     t_setup = time.time() - t0
 

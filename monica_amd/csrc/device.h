@@ -193,6 +193,7 @@ struct Batch {
 	int64_t *stats;               // device counters (see mnc_engine_get_counters)
 	// ---- base-level alignment stage (contract MNC_CONTRACT_DP)
 	int contract;
+	int fill_pred;                // a gap filling tries the 32-lane tier when its bound is below fill_pred / 25 per base
 	const uint32_t *seq4;         // contig bases, 4 bits each
 	const int64_t *seq_off;       // [n_contigs + 1]
 	int sc_a, sc_b, gap_q, gap_e, gap_q2, gap_e2, sc_ambi, zdrop, zdrop_inv, end_bonus, min_dp_max, min_ksw_len;

@@ -677,6 +677,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	B.max_join_short = P.max_join_short, B.min_join_flank_sc = P.min_join_flank_sc, B.mask_level = P.mask_level;
 	B.pri_ratio = P.pri_ratio, B.min_join_flank_ratio = P.min_join_flank_ratio;
 	B.gap_lut = e->gap_lut.as<int32_t>(), B.logf_lut = e->logf_lut.as<float>(), B.logf_a_lut = e->logf_a_lut.as<float>(), B.logf_n = e->logf_n;
+	B.fill_pred = (e->debug >> 8 & 0xff) ? (e->debug >> 8 & 0xff) : 34;     // tuning knob: debug bits 8-15
 	B.contract = e->contract, B.seq4 = e->didx->seq4, B.seq_off = e->didx->seq_off;
 	B.sc_a = P.a, B.sc_b = P.b, B.gap_q = P.q, B.gap_e = P.e, B.gap_q2 = P.q2, B.gap_e2 = P.e2, B.sc_ambi = P.sc_ambi;
 	B.zdrop = P.zdrop, B.zdrop_inv = P.zdrop_inv, B.end_bonus = P.end_bonus, B.min_dp_max = P.min_dp_max, B.min_ksw_len = P.min_ksw_len;

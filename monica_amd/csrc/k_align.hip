@@ -318,7 +318,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 						const int bb = (61 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
 						const int g1 = B.gap_q + B.gap_e * (bb + 1), g2 = B.gap_q2 + B.gap_e2 * (bb + 1);
 						const int U = B.sc_a * (mn - bb - 1) - 2 * (g1 < g2 ? g1 : g2);
-						if (U * 25 > mn * 32) tier = 2;                   // trying costs one unit, failing two more: worth it below even odds
+						if (U * 25 > mn * B.fill_pred) tier = 2;          // trying costs one unit, failing two more: worth it below even odds
 					}
 					if (tier == 2) {                                      // and the 64-lane tier likewise, against the literal kernel
 						const int bb = (125 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
