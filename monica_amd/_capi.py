@@ -207,6 +207,18 @@ class Comm:
             pass
 
 
+def pinned_array(a):
+    """A copy of `a` in page-locked host memory (mnc_host_alloc), as the FASTQ reader's batches are."""
+    a = np.ascontiguousarray(a)
+    L = lib()
+    L.mnc_host_alloc.restype = C.c_void_p
+    L.mnc_host_alloc.argtypes = [C.c_size_t]
+    p = L.mnc_host_alloc(max(a.nbytes, 1))
+    out = np.frombuffer((C.c_uint8 * max(a.nbytes, 1)).from_address(p), dtype=np.uint8)[:a.nbytes].view(a.dtype).reshape(a.shape)
+    out[...] = a
+    return out                                          # (freed with the process)
+
+
 def device_count():
     n = C.c_int(0)
     check(lib().mnc_device_count(C.byref(n)))

@@ -340,3 +340,29 @@ def test_fastq_reader_against_the_transcribed_biopython_rules(tmp_path):
         assert got_err == want_err, (case, text, got_err, want_err)
         if want is not None:
             assert got == want, (case, text)
+
+
+def test_decisions_agree_with_real_mappy_when_it_is_installed():
+    """PARITY UNPINNED: this image has no mappy, so the restatement cannot be checked against the
+    real library here.  Where mappy 2.17 is installed next to a GPU this measures the agreement
+    of the gated (ctg, NM, mlen) lists on a synthetic world (monica/genomes/aligner.py:193-195)."""
+    mappy = pytest.importorskip("mappy")
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU as well")
+    from monica_amd import mappy_compat, synth
+    import tempfile
+    names, seqs = synth.genome_set(4, min_len=150_000, max_len=250_000)
+    with tempfile.TemporaryDirectory() as d:
+        fa = os.path.join(d, "db.fna")
+        synth.write_fasta(fa, names, seqs)
+        theirs = mappy.Aligner(fn_idx_in=fa, preset="map-ont", best_n=15)
+        ours = mappy_compat.Aligner(fn_idx_in=fa, preset="map-ont", best_n=15)
+        bases, offsets, truth = synth.reads(seqs, 300, 4000, seed=77)
+        raw, same = bases.tobytes(), 0
+        for r in range(300):
+            s = raw[offsets[r]:offsets[r + 1]].decode()
+            a = sorted((h.ctg, h.NM, h.mlen) for h in theirs.map(s) if h.is_primary and h.mapq >= 60)
+            b = sorted((h.ctg, h.NM, h.mlen) for h in ours.map(s) if h.is_primary and h.mapq >= 60)
+            same += a == b
+        assert same >= 285, f"only {same}/300 gated hit lists equal mappy's"
