@@ -313,21 +313,21 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 					const int ad = g.tlen > g.qlen ? g.tlen - g.qlen : g.qlen - g.tlen;
 					// the 32-lane tier only when its proof has a chance: the bound a band of that width leaves
 					// against what a read with ~10 % errors scores (~1.28 per base)
-					int tier = (61 - ad) / 2 >= 12 ? 1 : (125 - ad) / 2 >= 8 ? 2 : 6;
+					int tier = (62 - ad) / 2 >= 12 ? 1 : (126 - ad) / 2 >= 8 ? 2 : 6;
 					if (tier == 1) {
-						const int bb = (61 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
+						const int bb = (62 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
 						const int g1 = B.gap_q + B.gap_e * (bb + 1), g2 = B.gap_q2 + B.gap_e2 * (bb + 1);
 						const int U = B.sc_a * (mn - bb - 1) - 2 * (g1 < g2 ? g1 : g2);
 						if (U * 25 > mn * B.fill_pred) tier = 2;          // trying costs one unit, failing two more: worth it below even odds
 					}
 					if (tier == 2) {                                      // and the 64-lane tier likewise, against the literal kernel
-						const int bb = (125 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
+						const int bb = (126 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
 						const int g1 = B.gap_q + B.gap_e * (bb + 1), g2 = B.gap_q2 + B.gap_e2 * (bb + 1);
 						const int U = B.sc_a * (mn - bb - 1) - 2 * (g1 < g2 ? g1 : g2);
 						if (U * 25 > mn * 32) tier = 6;                   // two cells per lane: a band of 128
 					}
 					if (tier == 6) {
-						const int bb = (253 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
+						const int bb = (254 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
 						const int g1 = B.gap_q + B.gap_e * (bb + 1), g2 = B.gap_q2 + B.gap_e2 * (bb + 1);
 						const int U = B.sc_a * (mn - bb - 1) - 2 * (g1 < g2 ? g1 : g2);
 						if (bb < 8 || U * 25 > mn * 32) tier = 0;

@@ -31,6 +31,7 @@ namespace mnc {
 constexpr int FILL_NEG = -(1 << 28);
 constexpr int FILL_WIN = 16;                            // rows of direction bytes held in LDS by the backtrack
 constexpr int FILL_MIN_BAND = 8;                        // narrower bands are not worth a try
+constexpr int FILL_CIG_MAX = 384;                       // CIGAR operations of a gap filling kept in LDS
 constexpr size_t FILL_P_SLOT = (size_t)(2 * FILL_MAX_LEN + FILL_WIN) * 64;   // direction bytes of one wave
 
 __device__ __forceinline__ void fill_order()
@@ -61,15 +62,17 @@ __host__ __device__ __forceinline__ int fill_gap(int l, int q, int e, int q2, in
 	return g1 < g2 ? g1 : g2;
 }
 
-// band of half-width b around the diagonals 0 .. d (d = tlen - qlen): offsets i - j in [kmin, kmax]
-__host__ __device__ __forceinline__ void fill_band(int n, int m, int lanes, int &b, int &kmin, int &kmax)
+// band around the diagonals 0 .. d (d = tlen - qlen): the 2 * cells offsets i - j in [kmin, kmax] -- on
+// an even anti-diagonal the cells hold the even offsets kmin .. kmax - 1, on an odd one the odd offsets
+// kmin + 1 .. kmax (kmin even, so that the parity of a step means the same for every segment of a
+// wave): every lane is inside the band on every step.  b = what is left on the narrower side.
+__host__ __device__ __forceinline__ void fill_band(int n, int m, int cells, int &b, int &kmin, int &kmax)
 {
-	// kmin is kept even (one diagonal more below when needed): then the parity of the steps on which
-	// t0 advances is the same for every segment of a wave
 	const int d = n - m, ad = d < 0 ? -d : d;
-	b = (2 * lanes - 3 - ad) / 2;
-	kmin = (d < 0 ? d : 0) - b, kmax = (d > 0 ? d : 0) + b;
+	b = (2 * cells - 2 - ad) / 2;
+	kmin = (d < 0 ? d : 0) - b;
 	if (kmin & 1) --kmin;
+	kmax = kmin + 2 * cells - 1;
 }
 
 // the best score any global path can have that leaves the band (see the header)
@@ -94,6 +97,74 @@ __host__ __device__ __forceinline__ int dp_band_bound(int n, int m, int kmin, in
 	return U;
 }
 
+// One anti-diagonal of the banded fill.  ODD = 0: t0 stays, the upper neighbour is the previous
+// cell of the band; 1: t0 advances, the left neighbour is the next cell.  `H` holds H of the same
+// cells two steps back (same parity) and receives this step's.
+template <int LANES, int CPL, int ODD>
+__device__ __forceinline__ void fill_step(const int n, const int m, const int rows, const int kmin, const int a, const int bmis, const int scN,
+                                          const int q, const int e, const int q2, const int e2, const uint8_t *st, const uint8_t *sq,
+                                          int r, int L, int (&H)[CPL], int (&En)[CPL], int (&E2n)[CPL],
+                                          int (&Fn)[CPL], int (&F2n)[CPL], int &Sc, uint8_t *prow)
+{
+	const int t0 = (r + kmin + 1) >> 1;
+	int sE[CPL], sE2[CPL], sF[CPL], sF2[CPL];
+	if (!ODD) {
+#pragma unroll
+		for (int k = 0; k < CPL; ++k) {
+			sE[k] = __builtin_amdgcn_update_dpp(FILL_NEG, En[k], 0x138, 0xf, 0xf, false);      // wave_shr:1
+			sE2[k] = __builtin_amdgcn_update_dpp(FILL_NEG, E2n[k], 0x138, 0xf, 0xf, false);
+			if (k > 0) {
+				const int pe = __builtin_amdgcn_readlane(En[k > 0 ? k - 1 : 0], 63), pe2 = __builtin_amdgcn_readlane(E2n[k > 0 ? k - 1 : 0], 63);
+				if (L == 0) sE[k] = pe, sE2[k] = pe2;
+			} else if (LANES == 32 && L == 0) sE[k] = sE2[k] = FILL_NEG;                      // lane 32 got the other segment's
+			sF[k] = Fn[k], sF2[k] = F2n[k];
+		}
+	} else {
+#pragma unroll
+		for (int k = 0; k < CPL; ++k) {
+			sF[k] = __builtin_amdgcn_update_dpp(FILL_NEG, Fn[k], 0x130, 0xf, 0xf, false);      // wave_shl:1
+			sF2[k] = __builtin_amdgcn_update_dpp(FILL_NEG, F2n[k], 0x130, 0xf, 0xf, false);
+			if (k < CPL - 1) {
+				const int nf = __builtin_amdgcn_readlane(Fn[k + 1 < CPL ? k + 1 : k], 0), nf2 = __builtin_amdgcn_readlane(F2n[k + 1 < CPL ? k + 1 : k], 0);
+				if (L == LANES - 1) sF[k] = nf, sF2[k] = nf2;
+			} else if (LANES == 32 && L == LANES - 1) sF[k] = sF2[k] = FILL_NEG;
+			sE[k] = En[k], sE2[k] = E2n[k];
+		}
+	}
+#pragma unroll
+	for (int k = 0; k < CPL; ++k) {
+		// Every lane computes on every step: a cell outside the matrix holds garbage that no cell
+		// inside ever reads (its upper / left / diagonal neighbours are inside too, or the virtual
+		// row / column below replaces them), and the band has no inside edge to guard (fill_band).
+		const int t = t0 + L + LANES * k, j = r - t;
+		const bool act = r < rows && (unsigned)t < (unsigned)n && (unsigned)j < (unsigned)m;
+		const int tc = t < 0 ? 0 : t > FILL_MAX_LEN ? FILL_MAX_LEN : t, jc = j < 0 ? 0 : j > FILL_MAX_LEN ? FILL_MAX_LEN : j;
+		const int ct = st[tc], cq = sq[jc];
+		const int sc = (ct == 4 || cq == 4) ? scN : ct == cq ? a : bmis;
+		int hd = H[k], vE = sE[k], vE2 = sE2[k], vF = sF[k], vF2 = sF2[k];
+		if (t == 0 || j == 0) {                                  // virtual row / column: gaps from the corner
+			hd = t == 0 && j == 0 ? 0 : -fill_gap(t == 0 ? j : t, q, e, q2, e2);
+			if (t == 0) { const int hb = -fill_gap(j + 1, q, e, q2, e2); vE = hb - q - e, vE2 = hb - q2 - e2; }
+			if (j == 0) { const int hb = -fill_gap(t + 1, q, e, q2, e2); vF = hb - q - e, vF2 = hb - q2 - e2; }
+		}
+		int z = hd + sc, d;
+		d = vE > z ? 1 : 0;  z = z > vE ? z : vE;
+		d = vF > z ? 2 : d;  z = z > vF ? z : vF;
+		d = vE2 > z ? 3 : d; z = z > vE2 ? z : vE2;
+		d = vF2 > z ? 4 : d; z = z > vF2 ? z : vF2;
+		const int o1 = z - q, o2 = z - q2;
+		d |= vE > o1 ? 0x08 : 0;  En[k] = (vE > o1 ? vE : o1) - e;
+		d |= vF > o1 ? 0x10 : 0;  Fn[k] = (vF > o1 ? vF : o1) - e;
+		d |= vE2 > o2 ? 0x20 : 0; E2n[k] = (vE2 > o2 ? vE2 : o2) - e2;
+		d |= vF2 > o2 ? 0x40 : 0; F2n[k] = (vF2 > o2 ? vF2 : o2) - e2;
+		if (act) {
+			prow[LANES * k] = (uint8_t)d;
+			if (r == rows - 1) Sc = z;                          // the corner: the global score
+		}
+		H[k] = z;
+	}
+}
+
 // LANES = 32: two segments per wave; 64: one; CPL cells per lane (64 x 2: a band of 128 cells for
 // the long gaps whose bound needs it).  Proof failures go to `next_list` (the wider tier, or the
 // literal kernel), CIGARs whose walk shows a large score drop to `fb_list` (the literal kernel
@@ -105,7 +176,7 @@ __global__ __launch_bounds__(64) void mnc_dp_fill(Batch B, const int32_t *list, 
 	constexpr int SEGS = 64 / LANES, W = LANES * CPL, ROWB = 64 * CPL;   // cells per segment and step; bytes per step of the wave
 	__shared__ uint8_t s_t[SEGS][FILL_MAX_LEN + 1], s_q[SEGS][FILL_MAX_LEN + 1];
 	__shared__ __align__(16) uint8_t s_win[SEGS][FILL_WIN * W];
-	__shared__ uint32_t s_cg[SEGS][2 * FILL_MAX_LEN + 2];
+	__shared__ uint32_t s_cg[SEGS][FILL_CIG_MAX];            // a gap filling's CIGAR: a few dozen operations (beyond: handed on)
 	const int lane = threadIdx.x, sg = lane / LANES, L = lane % LANES, lead = sg * LANES;
 	const bool leader = L == 0;
 	const int a = B.sc_a, bmis = -B.sc_b, scN = -B.sc_ambi, q = B.gap_q, e = B.gap_e, q2 = B.gap_q2, e2 = B.gap_e2;
@@ -151,71 +222,19 @@ __global__ __launch_bounds__(64) void mnc_dp_fill(Batch B, const int32_t *list, 
 #pragma unroll
 		for (int k = 0; k < CPL; ++k) H1[k] = H2[k] = En[k] = E2n[k] = Fn[k] = F2n[k] = FILL_NEG;
 		uint8_t *prow = p_wave + lead * CPL + L;
-		for (int r = 0; r < max_rows; ++r, prow += ROWB) {
-			const int t0 = (r + kmin + 1) >> 1;
-			// t0(r) = ceil((r + kmin) / 2) advances on the odd steps (kmin is even): then the left
-			// neighbour is the next cell of the band, else the upper one the previous cell.  Uniform over
-			// the wave.  The two gap states that cross cells this step: DPP wave shifts, one instruction
-			// each (and a readlane where a lane's second cell follows the last lane's first).
-			int sE[CPL], sE2[CPL], sF[CPL], sF2[CPL];
-			if ((r & 1) == 0) {                                   // kmin is even
+		// two steps per iteration: an even one (the upper neighbour is the previous cell) and an odd one
+		// (the left neighbour is the next cell); H of two steps back is the register of the same parity
+		const uint8_t *st = &s_t[sg][0], *sq = &s_q[sg][0];
+		int Heven[CPL], Hodd[CPL];
 #pragma unroll
-				for (int k = 0; k < CPL; ++k) {
-					sE[k] = __builtin_amdgcn_update_dpp(FILL_NEG, En[k], 0x138, 0xf, 0xf, false);      // wave_shr:1
-					sE2[k] = __builtin_amdgcn_update_dpp(FILL_NEG, E2n[k], 0x138, 0xf, 0xf, false);
-					// the first lane of a segment: nothing below its first cell; its next cells follow the last
-					// lane's previous ones (lane 32 of a two-segment wave got the other segment's)
-					if (k > 0) {
-						const int pe = LANES == 64 ? __builtin_amdgcn_readlane(En[k > 0 ? k - 1 : 0], 63) : __shfl(En[k > 0 ? k - 1 : 0], lead + LANES - 1);
-						const int pe2 = LANES == 64 ? __builtin_amdgcn_readlane(E2n[k > 0 ? k - 1 : 0], 63) : __shfl(E2n[k > 0 ? k - 1 : 0], lead + LANES - 1);
-						if (L == 0) sE[k] = pe, sE2[k] = pe2;
-					} else if (L == 0) sE[k] = sE2[k] = FILL_NEG;
-					sF[k] = Fn[k], sF2[k] = F2n[k];
-				}
-			} else {
-#pragma unroll
-				for (int k = 0; k < CPL; ++k) {
-					sF[k] = __builtin_amdgcn_update_dpp(FILL_NEG, Fn[k], 0x130, 0xf, 0xf, false);      // wave_shl:1
-					sF2[k] = __builtin_amdgcn_update_dpp(FILL_NEG, F2n[k], 0x130, 0xf, 0xf, false);
-					if (k < CPL - 1) {
-						const int nf = LANES == 64 ? __builtin_amdgcn_readlane(Fn[k + 1 < CPL ? k + 1 : k], 0) : __shfl(Fn[k + 1 < CPL ? k + 1 : k], lead);
-						const int nf2 = LANES == 64 ? __builtin_amdgcn_readlane(F2n[k + 1 < CPL ? k + 1 : k], 0) : __shfl(F2n[k + 1 < CPL ? k + 1 : k], lead);
-						if (L == LANES - 1) sF[k] = nf, sF2[k] = nf2;
-					} else if (L == LANES - 1) sF[k] = sF2[k] = FILL_NEG;
-					sE[k] = En[k], sE2[k] = E2n[k];
-				}
-			}
-#pragma unroll
-			for (int k = 0; k < CPL; ++k) {
-				const int t = t0 + L + LANES * k, j = r - t;
-				const bool act = r < rows && t >= 0 && j >= 0 && t < n && j < m && 2 * t - r <= kmax;
-				int Hn = FILL_NEG, nEn = FILL_NEG, nE2n = FILL_NEG, nFn = FILL_NEG, nF2n = FILL_NEG;
-				if (act) {
-					const int ct = s_t[sg][t], cq = s_q[sg][j];
-					const int sc = (ct == 4 || cq == 4) ? scN : ct == cq ? a : bmis;
-					int hd = H2[k], vE = sE[k], vE2 = sE2[k], vF = sF[k], vF2 = sF2[k];
-					if (t == 0 || j == 0) {                            // virtual row / column: gaps from the corner
-						hd = t == 0 && j == 0 ? 0 : -fill_gap(t == 0 ? j : t, q, e, q2, e2);
-						if (t == 0) { const int hb = -fill_gap(j + 1, q, e, q2, e2); vE = hb - q - e, vE2 = hb - q2 - e2; }
-						if (j == 0) { const int hb = -fill_gap(t + 1, q, e, q2, e2); vF = hb - q - e, vF2 = hb - q2 - e2; }
-					}
-					int z = hd + sc, d;
-					d = vE > z ? 1 : 0;  z = z > vE ? z : vE;
-					d = vF > z ? 2 : d;  z = z > vF ? z : vF;
-					d = vE2 > z ? 3 : d; z = z > vE2 ? z : vE2;
-					d = vF2 > z ? 4 : d; z = z > vF2 ? z : vF2;
-					Hn = z;
-					const int o1 = z - q, o2 = z - q2;
-					d |= vE > o1 ? 0x08 : 0;  nEn = (vE > o1 ? vE : o1) - e;
-					d |= vF > o1 ? 0x10 : 0;  nFn = (vF > o1 ? vF : o1) - e;
-					d |= vE2 > o2 ? 0x20 : 0; nE2n = (vE2 > o2 ? vE2 : o2) - e2;
-					d |= vF2 > o2 ? 0x40 : 0; nF2n = (vF2 > o2 ? vF2 : o2) - e2;
-					prow[LANES * k] = (uint8_t)d;
-					if (r == rows - 1) Sc = Hn;                        // the corner: the global score
-				}
-				H2[k] = H1[k], H1[k] = Hn, En[k] = nEn, E2n[k] = nE2n, Fn[k] = nFn, F2n[k] = nF2n;
-			}
+		for (int k = 0; k < CPL; ++k) Heven[k] = Hodd[k] = FILL_NEG;
+		(void)H1; (void)H2;
+		int r = 0;
+		for (; r + 1 < max_rows; r += 2, prow += 2 * ROWB) {
+			fill_step<LANES, CPL, 0>(n, m, rows, kmin, a, bmis, scN, q, e, q2, e2, st, sq, r, L, Heven, En, E2n, Fn, F2n, Sc, prow);
+			fill_step<LANES, CPL, 1>(n, m, rows, kmin, a, bmis, scN, q, e, q2, e2, st, sq, r + 1, L, Hodd, En, E2n, Fn, F2n, Sc, prow + ROWB);
 		}
+		if (r < max_rows) fill_step<LANES, CPL, 0>(n, m, rows, kmin, a, bmis, scN, q, e, q2, e2, st, sq, r, L, Heven, En, E2n, Fn, F2n, Sc, prow);
 		// ---- the proof: every path that leaves the band scores at most U
 		int S = FILL_NEG;
 		{
@@ -250,7 +269,7 @@ __global__ __launch_bounds__(64) void mnc_dp_fill(Batch B, const int32_t *list, 
 					const int r = bi + bj;
 					if (r < wlo) break;
 					const int idx = bi - ((r + kmin + 1) >> 1);
-					if (idx < 0 || idx >= W || 2 * bi - r > kmax) { walking = false, to_next = true; break; }   // cannot happen after the proof
+					if (idx < 0 || idx >= W) { walking = false, to_next = true; break; }   // cannot happen after the proof
 					const uint32_t tmp = s_win[sg][(r - wlo) * W + idx];
 					if (state == 0) state = tmp & 7;
 					else if (!(tmp >> (state + 2) & 1)) state = 0;
@@ -260,7 +279,13 @@ __global__ __launch_bounds__(64) void mnc_dp_fill(Batch B, const int32_t *list, 
 					else if (state == 1 || state == 3) op = 2, --bi;
 					else op = 1, --bj;
 					if (cur != 0 && (cur & 0xf) == op) cur += 1u << 4;
-					else { if (cur != 0) s_cg[sg][n_c++] = cur; cur = 1u << 4 | op; }
+					else {
+						if (cur != 0) {
+							if (n_c >= FILL_CIG_MAX - 4) { walking = false, to_fb = true; break; }   // more operations than the scratch holds
+							s_cg[sg][n_c++] = cur;
+						}
+						cur = 1u << 4 | op;
+					}
 				}
 				if (walking && (bi < 0 || bj < 0)) {
 					if (bi >= 0) { if (cur != 0 && (cur & 0xf) == 2) cur += (uint32_t)(bi + 1) << 4; else { if (cur != 0) s_cg[sg][n_c++] = cur; cur = (uint32_t)(bi + 1) << 4 | 2; } }
@@ -271,8 +296,25 @@ __global__ __launch_bounds__(64) void mnc_dp_fill(Batch B, const int32_t *list, 
 			}
 			fill_order();
 		}
-		// ---- mm_test_zdrop: a walk over the CIGAR (stored last operation first)
-		if (leader && ok && !to_next) {
+		// ---- mm_test_zdrop: a walk over the CIGAR (stored last operation first).  The drop it looks for
+		// is at most the sum of all the negative steps of the walk -- b per mismatch, q + e len per gap --
+		// and the number of mismatches follows from the score: S = a (M columns - mm) - b mm - (two-piece
+		// gap costs).  Below the threshold the answer is 0 without touching the sequences (an ambiguous
+		// base scores -1 and loosens the count: (a + 1) x <= a M - S - G2 for x columns that do not match).
+		bool walk = leader && ok && !to_next && !to_fb;
+		if (walk) {
+			int mcols = 0, g1 = 0, g2 = 0;
+			for (int k = 0; k < n_c; ++k) {
+				const uint32_t op = s_cg[sg][k] & 0xf;
+				const int len = (int)(s_cg[sg][k] >> 4);
+				if (op == 0) mcols += len;
+				else g1 += q + e * len, g2 += fill_gap(len, q, e, q2, e2);
+			}
+			const int lost = a * mcols - S - g2;                   // >= (a + 1) per column that does not match
+			const int neg = (-bmis) * (lost / (a + 1)) + g1;
+			if (neg <= (B.zdrop_inv < B.zdrop ? B.zdrop_inv : B.zdrop)) walk = false;
+		}
+		if (walk) {
 			int score = 0, mx = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0, max_zdrop = 0;
 			for (int k = n_c - 1; k >= 0; --k) {
 				const uint32_t op = s_cg[sg][k] & 0xf;
