@@ -1147,7 +1147,9 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 				c_order();
 			};
 			int toff = tshift, qoff = qshift;
-			for (int k = 0; k < n_c; ++k) {
+			// one operation at a time, the lanes sharing its bases: long M runs, gaps too costly for an event
+			auto seq_ops = [&](int k_lo, int k_hi) {
+			for (int k = k_lo; k < k_hi; ++k) {
 				const uint32_t op = C[k] & 0xf;
 				const int len = (int)(C[k] >> 4);
 				if (op == 0) {
@@ -1180,6 +1182,41 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 					}
 					if (op == 1) qoff += len; else toff += len;
 				}
+			}
+			};
+			// 64 operations at a time, one lane each: offsets by prefix sums, every lane lays out its
+			// operation's events (an M run: one per base; a gap: one) and counts
+			for (int k0 = 0; k0 < n_c; k0 += 64) {
+				const int k = k0 + lane, k1 = k0 + 64 < n_c ? k0 + 64 : n_c;
+				const uint32_t wd = k < n_c ? C[k] : 0;
+				const uint32_t op = wd & 0xf;
+				const int len = (int)(wd >> 4);
+				const int cost = B.gap_q + B.gap_e * len;
+				const int dq = k < n_c && op != 2 ? len : 0, dt = k < n_c && op != 1 ? len : 0, dev = k >= n_c ? 0 : op == 0 ? len : 1;
+				const int iq = dpp_incl_add(dq), it = dpp_incl_add(dt), ie = dpp_incl_add(dev);
+				const int tot_ev = __builtin_amdgcn_readlane(ie, 63);
+				const int big = dpp_max_all(k < n_c ? (op == 0 ? len : cost > 32767 ? 1 << 20 : 0) : 0);
+				if (big > 256 || tot_ev > ST_EV_MAX) { seq_ops(k0, k1); continue; }
+				if (ev + tot_ev > ST_EV_MAX) flush();
+				if (k < n_c) {
+					const int qo = qoff + iq - dq, to = toff + it - dt, eo = ev + ie - dev;
+					if (op == 0) {
+						for (int i = 0; i < len; ++i) {
+							const int cq = Q(qo + i), ct = Tg(to + i);
+							int dlt;
+							if (ct > 3 || cq > 3) ++c_amb, dlt = -B.sc_ambi;
+							else if (ct != cq) ++c_diff, dlt = -B.sc_b;
+							else dlt = B.sc_a;
+							s_d[eo + i] = (int16_t)dlt;
+						}
+					} else {
+						for (int i = 0; i < len; ++i) c_gamb += (op == 1 ? Q(qo + i) : Tg(to + i)) > 3;
+						s_d[eo] = (int16_t)-cost;
+					}
+				}
+				blen += __builtin_amdgcn_readlane(dpp_incl_add(k < n_c ? len : 0), 63);
+				mlen += __builtin_amdgcn_readlane(dpp_incl_add(k < n_c && op == 0 ? len : 0), 63);
+				qoff += __builtin_amdgcn_readlane(iq, 63), toff += __builtin_amdgcn_readlane(it, 63), ev += tot_ev;
 			}
 			flush();
 			for (int sft = 32; sft > 0; sft >>= 1) c_amb += __shfl_xor(c_amb, sft), c_diff += __shfl_xor(c_diff, sft), c_gamb += __shfl_xor(c_gamb, sft);
