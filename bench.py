@@ -109,8 +109,8 @@ def main():
                                         first=first_read)
     engine = _capi.Engine(index, local_rank)
     engine.set_contract(_capi.CONTRACT_DP if args.contract == "dp" else _capi.CONTRACT_CHAIN)
-    if os.environ.get("MNC_FILL_PRED"):
-        engine.set_debug(int(os.environ["MNC_FILL_PRED"]) << 8)
+    if os.environ.get("MNC_FILL_PRED") or os.environ.get("MNC_DP_SERIAL"):
+        engine.set_debug(int(os.environ.get("MNC_FILL_PRED", "0")) << 8 | (0x10000 if os.environ.get("MNC_DP_SERIAL") else 0))
     n_genomes = info.n_genomes
     t_setup = time.time() - t0
 

@@ -373,7 +373,7 @@ struct mnc_engine {
 	Buf ca, ca_cnt, chain_dst, regdp, segs, cig_seg, cig_reg, dp_ctr, work_a, work_b, big_list, reg_cnt, regs2, dp_ws, dp_ws_big;
 	Buf fill1, fill2, fill3, fill_fb, fill_p, ext1, ext2, ext3, ext4, ext_p, gen_list;
 	size_t seg_cap_override = 0, cig_cap_override = 0;
-	int debug = 0;                           // bit mask (tests): 2 stress build of the chaining ring, 4 displacement bytes read from HBM
+	int debug = 0;                           // bit mask (tests): 2 stress build of the chaining ring, 4 displacement bytes read from HBM, 0x10000 alignment kernels one at a time (with stage timers)
 	// last batch
 	Batch B{};
 	bool have_batch = false;
@@ -856,7 +856,8 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 				{
 					StageTimer t(e, MNC_STAGE_DP_FILL);               // the four streams, fork to join
 					if (int rcf = fork()) return rcf;
-					align_round(B, e, e->side[0], e->side[1], e->side[2], e->side[3]);
+					if (e->debug & 0x10000) align_round(B, e, e->side[0], e->side[0], e->side[0], e->side[0]);   // profiling: one kernel at a time
+					else align_round(B, e, e->side[0], e->side[1], e->side[2], e->side[3]);
 					if (int rcj = join()) return rcj;
 				}
 				{
@@ -867,7 +868,8 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 			} else {
 				launch_dp_plan(B, work, max_work, (int)DP_STATE_SMALL, DP_P_SMALL, (int)DP_CIG_SMALL, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, st);
 				if (int rcf = fork()) return rcf;
-				align_round(B, e, e->side[0], e->side[1], e->side[2], e->side[3]);
+				if (e->debug & 0x10000) align_round(B, e, e->side[0], e->side[0], e->side[0], e->side[0]);
+				else align_round(B, e, e->side[0], e->side[1], e->side[2], e->side[3]);
 				if (int rcj = join()) return rcj;
 				align_rest(B, e, st);
 				launch_dp_stitch(B, work, next, 4096, st);

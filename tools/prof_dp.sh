@@ -1,6 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r02}
+[ -n "${SERIAL:-}" ] && export MNC_DP_SERIAL=1
 timeout 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o out --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 > $R/gpurun_out/prof_$TAG.log 2>&1
 cd $R && python3 - <<PY
 import csv, glob, collections
