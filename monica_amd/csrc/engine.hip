@@ -47,8 +47,10 @@ void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max,
                      int lds_state, int lds_p, int lds_cig, int big_pass, hipStream_t st);
 void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_list, int n_wg, hipStream_t st);
 size_t dp_fill_p_slot();
+size_t dp_fillp_slot();
+size_t dp_fillp_cig_slot();
 void launch_dp_fill(const Batch &B, int lanes, const int32_t *list, int ctr_n, int ctr_q, int32_t *next_list, int ctr_next,
-                    int32_t *fb_list, int ctr_fb, uint8_t *p_all, int n_wg, hipStream_t st);
+                    int32_t *fb_list, int ctr_fb, uint8_t *p_all, uint32_t *cig_all, int n_wg, hipStream_t st);
 void launch_dp_ext(const Batch &B, int lanes, const int32_t *list, int ctr_n, int ctr_q, int32_t *fb_list, int ctr_fb, uint8_t *p_all, int n_wg, hipStream_t st);
 constexpr int DP_WG_FILL = 256 * 16, DP_WG_EXT = 256 * 8;
 // workspace classes of the alignment kernel: a normal slot per workgroup, a few large ones
@@ -371,7 +373,7 @@ struct mnc_engine {
 	// base-level alignment stage
 	int contract = MNC_CONTRACT_DP;
 	Buf ca, ca_cnt, chain_dst, regdp, segs, cig_seg, cig_reg, dp_ctr, work_a, work_b, big_list, reg_cnt, regs2, dp_ws, dp_ws_big;
-	Buf fill1, fill2, fill3, fill_fb, fill_p, ext1, ext2, ext3, ext4, ext_p, gen_list;
+	Buf fill1, fill2, fill3, fill_fb, fill_p, fill_cig, ext1, ext2, ext3, ext4, ext_p, gen_list;
 	size_t seg_cap_override = 0, cig_cap_override = 0;
 	int debug = 0;                           // bit mask (tests): 2 stress build of the chaining ring, 4 displacement bytes read from HBM, 0x10000 alignment kernels one at a time (with stage timers)
 	// last batch
@@ -457,7 +459,7 @@ extern "C" void mnc_engine_destroy(mnc_engine *e)
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
 	Buf *all[] = { &e->gap_lut, &e->logf_lut, &e->logf_a_lut, &e->ca, &e->ca_cnt, &e->chain_dst, &e->regdp, &e->segs, &e->cig_seg, &e->cig_reg, &e->dp_ctr,
-	               &e->work_a, &e->work_b, &e->big_list, &e->reg_cnt, &e->regs2, &e->dp_ws, &e->dp_ws_big, &e->fill1, &e->fill2, &e->fill3, &e->fill_fb, &e->fill_p, &e->ext1, &e->ext2, &e->ext3, &e->ext4, &e->ext_p, &e->gen_list, &e->in_bases, &e->in_offsets, &e->out_assign, &e->out_best, &e->out_nhits,
+	               &e->work_a, &e->work_b, &e->big_list, &e->reg_cnt, &e->regs2, &e->dp_ws, &e->dp_ws_big, &e->fill1, &e->fill2, &e->fill3, &e->fill_fb, &e->fill_p, &e->fill_cig, &e->ext1, &e->ext2, &e->ext3, &e->ext4, &e->ext_p, &e->gen_list, &e->in_bases, &e->in_offsets, &e->out_assign, &e->out_best, &e->out_nhits,
 	               &e->packed, &e->mz, &e->hits, &e->hist_tm, &e->q_off, &e->qrec, &e->bhits, &e->bhit_cnt, &e->ambig, &e->mz_cnt, &e->hit_cnt, &e->rep_len, &e->an_cnt, &e->an_off,
 	               &e->n_chain, &e->n_reg, &e->best_mlen, &e->hist_sums, &e->hist_offs, &e->scan_sums, &e->hit_off, &e->a, &e->f, &e->p, &e->v, &e->t, &e->u,
 	               &e->chains_tmp, &e->regs, &e->regx, &e->k64a, &e->k64b, &e->tmp_i32, &e->gated,
@@ -596,9 +598,9 @@ struct StageTimer {
 //   s3  the few calls that need the large workspace
 static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream_t s1, hipStream_t s2, hipStream_t s3)
 {
-	launch_dp_fill(B, 32, B.fill_list1, 10, 13, B.fill_list2, 11, B.fill_fb, 12, e->fill_p.as<uint8_t>(), DP_WG_FILL, s0);
-	launch_dp_fill(B, 64, B.fill_list2, 11, 14, B.fill_list3, 22, B.fill_fb, 12, e->fill_p.as<uint8_t>(), DP_WG_FILL, s0);
-	launch_dp_fill(B, 128, B.fill_list3, 22, 23, B.fill_fb, 12, B.fill_fb, 12, e->fill_p.as<uint8_t>(), DP_WG_FILL / 2, s0);
+	launch_dp_fill(B, 32, B.fill_list1, 10, 13, B.fill_list2, 11, B.fill_fb, 12, e->fill_p.as<uint8_t>(), e->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
+	launch_dp_fill(B, 64, B.fill_list2, 11, 14, B.fill_list3, 22, B.fill_fb, 12, e->fill_p.as<uint8_t>(), e->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
+	launch_dp_fill(B, 128, B.fill_list3, 22, 23, B.fill_fb, 12, B.fill_fb, 12, e->fill_p.as<uint8_t>(), e->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
 	launch_dp_ext(B, 32, B.ext_list1, 16, 18, B.fill_fb, 12, e->ext_p.as<uint8_t>(), DP_WG_EXT, s1);
 	launch_dp_ext(B, 64, B.ext_list2, 17, 19, B.fill_fb, 12, e->ext_p.as<uint8_t>(), DP_WG_EXT, s1);
 	launch_dp_ext(B, 128, B.ext_list3, 24, 26, B.fill_fb, 12, e->ext_p.as<uint8_t>(), DP_WG_EXT / 2, s1);
@@ -831,7 +833,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 		ENS2(work_a, ns * 4); ENS2(work_b, ns * 4); ENS2(big_list, seg_cap * 4); ENS2(reg_cnt, (nr + 1) * 4); ENS2(regs2, ns * sizeof(mnc_reg_t));
 		const size_t ws_small = dp_align_ws_bytes(DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL), ws_big = dp_align_ws_bytes(DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG);
 		ENS2(dp_ws, ws_small * DP_WG_SMALL * 2); ENS2(dp_ws_big, ws_big * DP_WG_BIG);
-		ENS2(fill1, seg_cap * 4); ENS2(fill2, seg_cap * 4); ENS2(fill3, seg_cap * 4); ENS2(fill_fb, seg_cap * 4); ENS2(fill_p, dp_fill_p_slot() * DP_WG_FILL); ENS2(ext1, seg_cap * 4); ENS2(ext2, seg_cap * 4); ENS2(ext3, seg_cap * 4); ENS2(ext4, seg_cap * 4); ENS2(gen_list, seg_cap * 4); ENS2(ext_p, dp_fill_p_slot() * DP_WG_EXT);
+		ENS2(fill1, seg_cap * 4); ENS2(fill2, seg_cap * 4); ENS2(fill3, seg_cap * 4); ENS2(fill_fb, seg_cap * 4); ENS2(fill_p, dp_fillp_slot() * DP_WG_FILL); ENS2(fill_cig, dp_fillp_cig_slot() * DP_WG_FILL); ENS2(ext1, seg_cap * 4); ENS2(ext2, seg_cap * 4); ENS2(ext3, seg_cap * 4); ENS2(ext4, seg_cap * 4); ENS2(gen_list, seg_cap * 4); ENS2(ext_p, dp_fill_p_slot() * DP_WG_EXT);
 #undef ENS2
 		if (rc2) return rc2;
 		B.ca = e->ca.as<Anchor>(), B.ca_cnt = e->ca_cnt.as<int32_t>(), B.chain_dst = e->chain_dst.as<int32_t>(), B.regdp = e->regdp.as<RegDP>();

@@ -371,257 +371,305 @@ __global__ __launch_bounds__(64) void mnc_dp_fill(Batch B, const int32_t *list, 
 }
 
 // ================================================================ the same fill, two cells per lane and instruction
-// Scores of a gap filling stay within +-2^12 (at most 511 matches of 2; at least -4 per base and one
-// long gap), so a cell fits 16 bits with three spare: the kernel keeps (score << 3 | tag) in the halves
-// of a register and runs the recurrence on VOP3P pairs (v_pk_add/sub/max_i16).  The tag makes the
-// maximum itself pick ksw2's winner among equal scores -- H 4..7, E 3, F 2, E2 1, F2 0: the first of
-// ksw2's comparison chain wins a tie -- and likewise "a gap is opened rather than extended on a tie"
-// (the opening candidate carries H's tag).  The direction byte is those tags (decoded by the walk).
+// Scores of a gap filling span less than 2^12 (at most 511 matches of 2; at least -4 per base and one
+// long gap), so a cell fits 16 bits with four spare: the kernel keeps ((score + bias) << 4 | tag) in the
+// halves of a register and runs the recurrence on VOP3P pairs (v_pk_add/sub/max_i16).  The tag makes
+// the maximum itself pick ksw2's winner among equal scores -- H 15, E 7, F 3, E2 1, F2 0: the first of
+// ksw2's comparison chain wins a tie -- and likewise "a gap is opened rather than extended on a tie":
+// the opening candidate carries H's tag, and the bit that tells it from the extending one is bit 3, 2,
+// 1, 0 for E, F, E2, F2, so the four flags of the direction byte are one bit-field insert each.
 // Cell c = 2 L + h of the band: lane L, half h; the neighbour cells' gap states are a DPP move of the
 // neighbouring lane and one v_alignbit.  The virtual row and column only touch the band during its
 // first max(-kmin, kmax) steps: those run a variant of the step with the overrides, the rest without.
-// Bases are one-hot (A 1, C 2, G 4, T 8): a pair matches when the AND is non-zero; a segment with
-// an ambiguous base goes to the literal kernel.
+// A segment with an ambiguous base goes to the literal kernel.
 typedef short pk_s16 __attribute__((ext_vector_type(2)));
 typedef unsigned short pk_u16 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_adds(uint32_t x, uint32_t y) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(pk_s16, x), __builtin_bit_cast(pk_s16, y))); }
 __device__ __forceinline__ uint32_t pk_subs(uint32_t x, uint32_t y) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(pk_s16, x), __builtin_bit_cast(pk_s16, y))); }
 __device__ __forceinline__ uint32_t pk_maxs(uint32_t x, uint32_t y) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(pk_s16, x), __builtin_bit_cast(pk_s16, y))); }
-__device__ __forceinline__ uint32_t pk_minu(uint32_t x, uint32_t y) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(pk_u16, x), __builtin_bit_cast(pk_u16, y))); }
+__device__ __forceinline__ uint32_t pk_subsu(uint32_t x, uint32_t y) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(pk_u16, x), __builtin_bit_cast(pk_u16, y))); }
 __device__ __forceinline__ uint32_t pk_madu(uint32_t x, uint32_t y, uint32_t z) { return __builtin_bit_cast(uint32_t, (pk_u16)(__builtin_bit_cast(pk_u16, x) * __builtin_bit_cast(pk_u16, y) + __builtin_bit_cast(pk_u16, z))); }
 __device__ __forceinline__ uint32_t pk_rep(int v) { return ((uint32_t)v & 0xffffu) * 0x10001u; }
 __device__ __forceinline__ uint32_t pk_bfi(uint32_t mask, uint32_t x, uint32_t y) { return (x & mask) | (y & ~mask); }
 
 constexpr uint32_t PK_NEG = 0x80008000u;
-struct PkConst { uint32_t kmatch, kmis, q8, q28, e8, e28; };
+constexpr uint32_t PK_TAG_H = 0x000f000fu, PK_TAG_E = 0x00070007u, PK_TAG_F = 0x00030003u, PK_TAG_E2 = 0x00010001u;   // F2: 0
+struct PkConst { uint32_t kmatch, kmis, q8, q28, e8, e28; int bias; };
+
+// the span of the scores a band of `cells` can hold, and the bias that centres it in 12 bits
+__host__ __device__ __forceinline__ bool fillp_bias(int cells, int a, int bmis_abs, int q, int e, int q2, int e2, int &bias)
+{
+	const int hi = a * FILL_MAX_LEN, lo = -(bmis_abs * FILL_MAX_LEN + fill_gap(2 * cells + 2, q, e, q2, e2) + (q + e > q2 + e2 ? q + e : q2 + e2));
+	bias = -(hi + lo) / 2;
+	return hi + bias < 2040 && lo + bias > -2040;
+}
 
 template <int LANES, int ODD, bool EDGE>
 __device__ __forceinline__ void fillp_step(const PkConst &K, const int r, const int L, const int rows_m1, const uint8_t *st, const uint8_t *sq,
                                            const int q, const int e, const int q2, const int e2,
                                            int &t_lo, int &tn, int &jn, uint32_t &T2, uint32_t &Q2, uint32_t &Hs,
-                                           uint32_t &E, uint32_t &E2, uint32_t &F, uint32_t &F2, uint32_t &Sc, uint8_t *prow)
+                                           uint32_t &E, uint32_t &E2, uint32_t &F, uint32_t &F2, uint32_t &Sc,
+                                           uint32_t &nb1, uint32_t &nb2, uint32_t &acc)
 {
 	constexpr int SHR = LANES == 16 ? 0x111 : 0x138, SHL = LANES == 16 ? 0x101 : 0x130;   // row_shr:1 / wave_shr:1
 	uint32_t vE, vE2, vF, vF2;
+	// nb1 / nb2 receive the neighbouring lane's register; the lane at the band's edge has no source and
+	// keeps what they held: PK_NEG, from before the loop
 	if (!ODD) {
-		uint32_t pe = (uint32_t)__builtin_amdgcn_update_dpp((int)PK_NEG, (int)E, SHR, 0xf, 0xf, false);
-		uint32_t pe2 = (uint32_t)__builtin_amdgcn_update_dpp((int)PK_NEG, (int)E2, SHR, 0xf, 0xf, false);
-		if (LANES == 32 && L == 0) pe = pe2 = PK_NEG;                 // lane 32 got the other segment's
-		vE = __builtin_amdgcn_alignbit(E, pe, 16), vE2 = __builtin_amdgcn_alignbit(E2, pe2, 16);
+		nb1 = (uint32_t)__builtin_amdgcn_update_dpp((int)nb1, (int)E, SHR, 0xf, 0xf, false);
+		nb2 = (uint32_t)__builtin_amdgcn_update_dpp((int)nb2, (int)E2, SHR, 0xf, 0xf, false);
+		if (LANES == 32 && L == 0) nb1 = nb2 = PK_NEG;               // lane 32 got the other segment's
+		vE = __builtin_amdgcn_alignbit(E, nb1, 16), vE2 = __builtin_amdgcn_alignbit(E2, nb2, 16);
 		vF = F, vF2 = F2;
-		Q2 = Q2 << 16 | sq[jn], ++jn;
+		Q2 = __builtin_amdgcn_perm(Q2, (uint32_t)sq[jn], 0x05040100u), ++jn;   // (old low half -> high, the new base -> low)
 	} else {
-		uint32_t nf = (uint32_t)__builtin_amdgcn_update_dpp((int)PK_NEG, (int)F, SHL, 0xf, 0xf, false);
-		uint32_t nf2 = (uint32_t)__builtin_amdgcn_update_dpp((int)PK_NEG, (int)F2, SHL, 0xf, 0xf, false);
-		if (LANES == 32 && L == LANES - 1) nf = nf2 = PK_NEG;
-		vF = __builtin_amdgcn_alignbit(nf, F, 16), vF2 = __builtin_amdgcn_alignbit(nf2, F2, 16);
+		nb1 = (uint32_t)__builtin_amdgcn_update_dpp((int)nb1, (int)F, SHL, 0xf, 0xf, false);
+		nb2 = (uint32_t)__builtin_amdgcn_update_dpp((int)nb2, (int)F2, SHL, 0xf, 0xf, false);
+		if (LANES == 32 && L == LANES - 1) nb1 = nb2 = PK_NEG;
+		vF = __builtin_amdgcn_alignbit(nb1, F, 16), vF2 = __builtin_amdgcn_alignbit(nb2, F2, 16);
 		vE = E, vE2 = E2;
-		T2 = __builtin_amdgcn_alignbit((uint32_t)st[tn], T2, 16), ++tn;
+		T2 = __builtin_amdgcn_perm((uint32_t)st[tn], T2, 0x05040302u), ++tn;   // (old high half -> low, the new base -> high)
 		if (EDGE) ++t_lo;
 	}
 	uint32_t hd = Hs;
 	if (EDGE) {
 		// the virtual row / column: gaps from the corner.  Cell (0, j) sits on step r = j, cell (t, 0) on r = t:
 		// the same three numbers for both, by the step alone
-		const int hb = -fill_gap(r + 1, q, e, q2, e2);
-		const uint32_t h0 = pk_rep(((r == 0 ? 0 : -fill_gap(r, q, e, q2, e2)) << 3) | 4);
-		const uint32_t g1 = pk_rep((hb - q - e) << 3), g2 = pk_rep((hb - q2 - e2) << 3);
+		const int hb = -fill_gap(r + 1, q, e, q2, e2) + K.bias;
+		const uint32_t h0 = pk_rep(((r == 0 ? 0 : -fill_gap(r, q, e, q2, e2)) + K.bias) << 4) | PK_TAG_H;
+		const uint32_t g1 = pk_rep((hb - q - e) << 4), g2 = pk_rep((hb - q2 - e2) << 4);
 		const uint32_t mt = t_lo == 0 ? 0x0000ffffu : t_lo == -1 ? 0xffff0000u : 0u;
 		const uint32_t mj = t_lo == r ? 0x0000ffffu : t_lo == r - 1 ? 0xffff0000u : 0u;
 		hd = pk_bfi(mt | mj, h0, hd);
-		vE = pk_bfi(mt, g1 | 0x00030003u, vE), vE2 = pk_bfi(mt, g2 | 0x00010001u, vE2);
-		vF = pk_bfi(mj, g1 | 0x00020002u, vF), vF2 = pk_bfi(mj, g2, vF2);
+		vE = pk_bfi(mt, g1 | PK_TAG_E, vE), vE2 = pk_bfi(mt, g2 | PK_TAG_E2, vE2);
+		vF = pk_bfi(mj, g1 | PK_TAG_F, vF), vF2 = pk_bfi(mj, g2, vF2);
 	}
-	const uint32_t sc = pk_madu(pk_minu(T2 & Q2, 0x00010001u), K.kmatch, K.kmis);
+	const uint32_t sc = pk_madu(pk_subsu(0x00010001u, T2 ^ Q2), K.kmatch, K.kmis);   // 1 - min(1, x): the bases are equal
 	uint32_t z = pk_adds(hd, sc);
 	z = pk_maxs(z, vE), z = pk_maxs(z, vF), z = pk_maxs(z, vE2), z = pk_maxs(z, vF2);
-	const uint32_t zt = z | 0x00040004u;
+	const uint32_t zt = z | PK_TAG_H;
 	const uint32_t o1 = pk_subs(zt, K.q8), o2 = pk_subs(zt, K.q28);
 	const uint32_t mE = pk_maxs(vE, o1), mF = pk_maxs(vF, o1), mE2 = pk_maxs(vE2, o2), mF2 = pk_maxs(vF2, o2);
-	E = (pk_subs(mE, K.e8) & 0xfff8fff8u) | 0x00030003u;
-	F = (pk_subs(mF, K.e8) & 0xfff8fff8u) | 0x00020002u;
-	E2 = (pk_subs(mE2, K.e28) & 0xfff8fff8u) | 0x00010001u;
-	F2 = pk_subs(mF2, K.e28) & 0xfff8fff8u;
-	uint32_t d = z & 0x00070007u;
-	d = (mE & 0x00040004u) << 1 | d;
-	d = (mF & 0x00040004u) << 2 | d;
-	d = (mE2 & 0x00040004u) << 3 | d;
-	d = (mF2 & 0x00040004u) << 4 | d;
-	*reinterpret_cast<uint16_t*>(prow) = (uint16_t)__builtin_amdgcn_perm(d, d, 0x0c0c0200u);
+	E = pk_subs(mE, K.e8) & 0xfff7fff7u;                       // tag 15 or 7 -> 7
+	F = pk_subs(mF, K.e8) & 0xfff3fff3u;                       // 15 or 3 -> 3
+	E2 = pk_subs(mE2, K.e28) & 0xfff1fff1u;
+	F2 = pk_subs(mF2, K.e28) & 0xfff0fff0u;
+	// direction byte: bits 4-7 the winner's tag, bits 3 / 2 / 1 / 0 "E / F / E2 / F2 was opened"
+	uint32_t d = pk_bfi(0x00080008u, mE, pk_bfi(0x00040004u, mF, pk_bfi(0x00020002u, mE2, mF2 & 0x00010001u)));
+	d |= (z & 0x000f000fu) << 4;
+	// two steps' direction bytes per register: (even step: cells 2 L, 2 L + 1; odd step: likewise)
+	acc = ODD ? __builtin_amdgcn_perm(d, acc, 0x06040100u) : __builtin_amdgcn_perm(d, d, 0x0c0c0200u);
 	Sc = r == rows_m1 ? zt : Sc;
 	Hs = zt;
 }
 
+// A wave takes FILLP_G x SEGS segments at a time: FILLP_G forward passes (SEGS segments side by side, as
+// above), their direction bytes kept in the wave's slot of HBM -- per 16 steps a lane stores the 32
+// bytes of its two cells, so a walk that stays near one diagonal reads a line many times -- and then
+// ONE walk phase in which every lane backtracks a segment of its own: a walk is a few dozen
+// instructions per CIGAR column whatever the number of active lanes, and with 4 of 64 it used to cost
+// as much issue time as the fill itself.
+constexpr int FILLP_G = 16;
+constexpr int FILLP_BLOCKS = (2 * FILL_MAX_LEN + 15) / 16 + 1;           // 16-step blocks of direction bytes per pass
+constexpr size_t FILLP_PASS_BYTES = (size_t)FILLP_BLOCKS * 64 * 32;
+constexpr size_t FILLP_SLOT = FILLP_G * FILLP_PASS_BYTES;
+
 template <int LANES>
 __global__ __launch_bounds__(64) void mnc_dp_fillp(Batch B, const int32_t *list, int ctr_n, int ctr_q, int32_t *next_list, int ctr_next,
-                                                   int32_t *fb_list, int ctr_fb, uint8_t *p_all)
+                                                   int32_t *fb_list, int ctr_fb, uint8_t *p_all, uint32_t *cig_all)
 {
-	constexpr int SEGS = 64 / LANES, W = 2 * LANES, ROWB = 128, PAD = 2 * W, SEQ = FILL_MAX_LEN + 1 + 4 * W;
-	constexpr int CIG = LANES == 16 ? 192 : FILL_CIG_MAX;
-	__shared__ uint8_t s_t[SEGS][SEQ], s_q[SEGS][SEQ];        // one-hot bases at [PAD + i]; what lies around them feeds cells outside the matrix only
-	__shared__ __align__(16) uint8_t s_win[SEGS][FILL_WIN * W];
-	__shared__ uint32_t s_cg[SEGS][CIG];
+	constexpr int SEGS = 64 / LANES, W = 2 * LANES, PAD = 2 * W, SEQ = FILL_MAX_LEN + 1 + 4 * W, NSEG = FILLP_G * SEGS;
+	__shared__ uint8_t s_t[SEGS][SEQ], s_q[SEGS][SEQ];        // bases at [PAD + i]; what lies around them feeds cells outside the matrix only
+	__shared__ __align__(16) uint8_t s_chunk[64][32];         // the walk: the 32 direction bytes a lane is reading from
+	__shared__ int32_t s_n[64], s_m[64], s_kmin[64], s_S[64], s_si[64], s_state[64];   // per segment of the group; state 0 none, 1 walk, 2 next tier, 3 literal kernel
 	const int lane = threadIdx.x, sg = lane / LANES, L = lane % LANES, lead = sg * LANES;
 	const bool leader = L == 0;
 	const int a = B.sc_a, bmis = -B.sc_b, q = B.gap_q, e = B.gap_e, q2 = B.gap_q2, e2 = B.gap_e2;
 	PkConst K;
-	K.kmatch = pk_rep((a - bmis) << 3), K.kmis = pk_rep(bmis << 3), K.q8 = pk_rep(q << 3), K.q28 = pk_rep(q2 << 3), K.e8 = pk_rep(e << 3), K.e28 = pk_rep(e2 << 3);
-	uint8_t *p_wave = p_all + (size_t)blockIdx.x * (2 * FILL_P_SLOT);
+	K.kmatch = pk_rep((a - bmis) << 4), K.kmis = pk_rep(bmis << 4), K.q8 = pk_rep(q << 4), K.q28 = pk_rep(q2 << 4), K.e8 = pk_rep(e << 4), K.e28 = pk_rep(e2 << 4);
+	const bool fits = fillp_bias(W, a, -bmis > B.sc_ambi ? -bmis : B.sc_ambi, q, e, q2, e2, K.bias);
+	uint8_t *p_wave = p_all + (size_t)blockIdx.x * FILLP_SLOT;
+	uint32_t *cg = cig_all + ((size_t)blockIdx.x * 64 + lane) * FILL_CIG_MAX;
 	const unsigned long long n_items = B.dp_ctr[ctr_n];
 	const unsigned long long segmask = LANES == 64 ? ~0ULL : ((1ULL << (LANES & 63)) - 1) << lead;
+	const int thr = B.zdrop_inv < B.zdrop ? B.zdrop_inv : B.zdrop;
 	for (;;) {
 		unsigned long long q0 = 0;
-		if (lane == 0) q0 = atomicAdd(&B.dp_ctr[ctr_q], (unsigned long long)SEGS);
+		if (lane == 0) q0 = atomicAdd(&B.dp_ctr[ctr_q], (unsigned long long)NSEG);
 		q0 = (unsigned long long)__shfl((long long)q0, 0);
 		if (q0 >= n_items) break;                              // every wave gets here: the queue is finite
-		const bool has = q0 + sg < n_items;
-		const long long si = has ? (long long)list[q0 + sg] : -1;
-		struct { int32_t tlen, qlen, ts, qs, read, rid, rev; } g = { 0, 0, 0, 0, 0, 0, 0 };
-		if (has) {
-			const Seg *gs = B.segs + si;
-			g.tlen = gs->tlen, g.qlen = gs->qlen, g.ts = gs->ts, g.qs = gs->qs, g.read = gs->read, g.rid = gs->rid, g.rev = gs->rev;
-		}
-		const int n = g.tlen, m = g.qlen;
-		int b, kmin, kmax;
-		fill_band(n, m, W, b, kmin, kmax);
-		bool ok = has && n >= 1 && m >= 1 && n <= FILL_MAX_LEN && m <= FILL_MAX_LEN && b >= FILL_MIN_BAND;
-		// ---- sequences
-		bool ambiguous = false;
-		if (ok) {
-			const uint8_t *read = B.bases + B.offsets[g.read];
-			const int rlen = (int)(B.offsets[g.read + 1] - B.offsets[g.read]);
-			const int64_t coff = B.seq_off[g.rid] + g.ts;
-#pragma unroll 1
-			for (int i = L; i < n; i += LANES) {
-				const int64_t o = coff + i;
-				const uint32_t c = B.seq4[o >> 3] >> ((o & 7) * 4) & 15u;
-				ambiguous |= c > 3;
-				s_t[sg][PAD + i] = (uint8_t)(1u << (c & 3));
-			}
-#pragma unroll 1
-			for (int i = L; i < m; i += LANES) {
-				const int pq = g.qs + i;
-				const int c = fill_nt4(read[g.rev ? rlen - 1 - pq : pq]);
-				ambiguous |= c > 3;
-				s_q[sg][PAD + i] = (uint8_t)(1u << ((g.rev ? 3 - c : c) & 3));
-			}
-		}
-		const bool seg_amb = (__ballot(ambiguous) & segmask) != 0;
-		bool to_fb = ok && seg_amb;                             // the literal kernel scores an ambiguous base
-		ok = ok && !seg_amb;
+		s_state[lane] = 0;
 		fill_order();
-		const int rows = ok ? n + m - 1 : 0;
-		int max_rows = rows, edge_rows = ok ? ((-kmin > kmax ? -kmin : kmax) + 3) & ~1 : 0;
+		// ================================================ forward passes
+		for (int u = 0; u < FILLP_G; ++u) {
+			if (q0 + (unsigned long long)u * SEGS >= n_items) break;
+			const unsigned long long item = q0 + (unsigned long long)u * SEGS + sg;
+			const bool has = item < n_items;
+			const long long si = has ? (long long)list[item] : -1;
+			struct { int32_t tlen, qlen, ts, qs, read, rid, rev; } g = { 0, 0, 0, 0, 0, 0, 0 };
+			if (has) {
+				const Seg *gs = B.segs + si;
+				g.tlen = gs->tlen, g.qlen = gs->qlen, g.ts = gs->ts, g.qs = gs->qs, g.read = gs->read, g.rid = gs->rid, g.rev = gs->rev;
+			}
+			const int n = g.tlen, m = g.qlen;
+			int b, kmin, kmax;
+			fill_band(n, m, W, b, kmin, kmax);
+			bool ok = has && fits && n >= 1 && m >= 1 && n <= FILL_MAX_LEN && m <= FILL_MAX_LEN && b >= FILL_MIN_BAND;
+			bool ambiguous = false;
+			if (ok) {
+				const uint8_t *read = B.bases + B.offsets[g.read];
+				const int rlen = (int)(B.offsets[g.read + 1] - B.offsets[g.read]);
+				const int64_t coff = B.seq_off[g.rid] + g.ts;
+#pragma unroll 1
+				for (int i = L; i < n; i += LANES) {
+					const int64_t o = coff + i;
+					const uint32_t c = B.seq4[o >> 3] >> ((o & 7) * 4) & 15u;
+					ambiguous |= c > 3;
+					s_t[sg][PAD + i] = (uint8_t)(c & 3);
+				}
+#pragma unroll 1
+				for (int i = L; i < m; i += LANES) {
+					const int pq = g.qs + i;
+					const int c = fill_nt4(read[g.rev ? rlen - 1 - pq : pq]);
+					ambiguous |= c > 3;
+					s_q[sg][PAD + i] = (uint8_t)((g.rev ? 3 - c : c) & 3);
+				}
+			}
+			const bool seg_amb = (__ballot(ambiguous) & segmask) != 0;
+			const bool to_fb = ok && seg_amb;                       // the literal kernel scores an ambiguous base
+			ok = ok && !seg_amb;
+			fill_order();
+			const int rows = ok ? n + m - 1 : 0;
+			int max_rows = (rows + 15) & ~15, edge_rows = ok ? ((-kmin > kmax ? -kmin : kmax) + 2 + 15) & ~15 : 0;
 #pragma unroll
-		for (int sft = LANES; sft < 64; sft <<= 1) {
-			const int o = __shfl_xor(max_rows, sft), oe = __shfl_xor(edge_rows, sft);
-			max_rows = max_rows > o ? max_rows : o, edge_rows = edge_rows > oe ? edge_rows : oe;
+			for (int sft = LANES; sft < 64; sft <<= 1) {
+				const int o = __shfl_xor(max_rows, sft), oe = __shfl_xor(edge_rows, sft);
+				max_rows = max_rows > o ? max_rows : o, edge_rows = edge_rows > oe ? edge_rows : oe;
+			}
+			max_rows = __builtin_amdgcn_readfirstlane(max_rows), edge_rows = __builtin_amdgcn_readfirstlane(edge_rows);
+			if (edge_rows > max_rows) edge_rows = max_rows;
+			const int kmin_run = ok ? kmin : -2 * W;                // a segment that sits out: indices inside the arrays all the same
+			// one anti-diagonal per step; cells 2 L, 2 L + 1 of the band hold t = t0 + 2 L (+ 1)
+			const uint8_t *st = &s_t[sg][0], *sq = &s_q[sg][0];
+			int t_lo = (kmin_run >> 1) + 2 * L;
+			uint32_t T2 = (uint32_t)st[PAD + t_lo] | (uint32_t)st[PAD + t_lo + 1] << 16;
+			uint32_t Q2 = (uint32_t)sq[PAD - t_lo - 1] | (uint32_t)sq[PAD - t_lo - 2] << 16;
+			int tn = PAD + t_lo + 2, jn = PAD - t_lo;
+			uint32_t He = PK_NEG | PK_TAG_H, Ho = He, E = PK_NEG | PK_TAG_E, F = PK_NEG | PK_TAG_F, E2 = PK_NEG | PK_TAG_E2, F2 = PK_NEG, Sc = PK_NEG;
+			uint32_t nbe1 = PK_NEG, nbe2 = PK_NEG, nbf1 = PK_NEG, nbf2 = PK_NEG;
+			const int rows_m1 = rows - 1;
+			uint4 *pblk = reinterpret_cast<uint4*>(p_wave + (size_t)u * FILLP_PASS_BYTES + lane * 32);
+			int r = 0;
+			for (; r < edge_rows; r += 16, pblk += 2048 / 16) {
+				uint32_t acc[8];
+#pragma unroll
+				for (int k = 0; k < 8; ++k) {
+					fillp_step<LANES, 0, true>(K, r + 2 * k, L, rows_m1, st, sq, q, e, q2, e2, t_lo, tn, jn, T2, Q2, He, E, E2, F, F2, Sc, nbe1, nbe2, acc[k]);
+					fillp_step<LANES, 1, true>(K, r + 2 * k + 1, L, rows_m1, st, sq, q, e, q2, e2, t_lo, tn, jn, T2, Q2, Ho, E, E2, F, F2, Sc, nbf1, nbf2, acc[k]);
+				}
+				pblk[0] = make_uint4(acc[0], acc[1], acc[2], acc[3]), pblk[1] = make_uint4(acc[4], acc[5], acc[6], acc[7]);
+			}
+			for (; r < max_rows; r += 16, pblk += 2048 / 16) {
+				uint32_t acc[8];
+#pragma unroll
+				for (int k = 0; k < 8; ++k) {
+					fillp_step<LANES, 0, false>(K, r + 2 * k, L, rows_m1, st, sq, q, e, q2, e2, t_lo, tn, jn, T2, Q2, He, E, E2, F, F2, Sc, nbe1, nbe2, acc[k]);
+					fillp_step<LANES, 1, false>(K, r + 2 * k + 1, L, rows_m1, st, sq, q, e, q2, e2, t_lo, tn, jn, T2, Q2, Ho, E, E2, F, F2, Sc, nbf1, nbf2, acc[k]);
+				}
+				pblk[0] = make_uint4(acc[0], acc[1], acc[2], acc[3]), pblk[1] = make_uint4(acc[4], acc[5], acc[6], acc[7]);
+			}
+			// the proof: every path that leaves the band scores at most U
+			int S = FILL_NEG;
+			{
+				int lc = ok ? n - 1 - ((rows - 1 + kmin + 1) >> 1) : 0;
+				lc = lc < 0 ? 0 : lc >= W ? W - 1 : lc;
+				const uint32_t v = (uint32_t)__shfl((int)Sc, lead + (lc >> 1));
+				S = ((int)(int16_t)(lc & 1 ? v >> 16 : v & 0xffffu) >> 4) - K.bias;
+				const int U = dp_band_bound(n, m, kmin, kmax, a, q, e, q2, e2);
+				if (ok && !(S > U)) ok = false;
+			}
+			if (leader && has) {
+				const int w = u * SEGS + sg;
+				s_n[w] = n, s_m[w] = m, s_kmin[w] = kmin, s_S[w] = S, s_si[w] = (int32_t)si;
+				s_state[w] = ok ? 1 : to_fb ? 3 : 2;
+			}
+			fill_order();                                          // the next pass overwrites the sequences
 		}
-		max_rows = __builtin_amdgcn_readfirstlane(max_rows), edge_rows = __builtin_amdgcn_readfirstlane(edge_rows);
-		if (!ok) kmin = -2 * W;                                // a segment that sits out: indices inside the arrays all the same
-		// ---- forward: one anti-diagonal per step; cells 2 L, 2 L + 1 of the band hold t = t0 + 2 L (+ 1)
-		const uint8_t *st = &s_t[sg][0], *sq = &s_q[sg][0];
-		int t_lo = (kmin >> 1) + 2 * L;
-		uint32_t T2 = (uint32_t)st[PAD + t_lo] | (uint32_t)st[PAD + t_lo + 1] << 16;
-		uint32_t Q2 = (uint32_t)sq[PAD - t_lo - 1] | (uint32_t)sq[PAD - t_lo - 2] << 16;
-		int tn = PAD + t_lo + 2, jn = PAD - t_lo;
-		uint32_t He = PK_NEG | 0x00040004u, Ho = He, E = PK_NEG | 0x00030003u, F = PK_NEG | 0x00020002u, E2 = PK_NEG | 0x00010001u, F2 = PK_NEG, Sc = PK_NEG;
-		const int rows_m1 = rows - 1;
-		uint8_t *prow = p_wave + 2 * lane;
-		int r = 0;
-		for (; r < edge_rows; r += 2, prow += 2 * ROWB) {
-			fillp_step<LANES, 0, true>(K, r, L, rows_m1, st, sq, q, e, q2, e2, t_lo, tn, jn, T2, Q2, He, E, E2, F, F2, Sc, prow);
-			fillp_step<LANES, 1, true>(K, r + 1, L, rows_m1, st, sq, q, e, q2, e2, t_lo, tn, jn, T2, Q2, Ho, E, E2, F, F2, Sc, prow + ROWB);
-		}
-		for (; r < max_rows; r += 2, prow += 2 * ROWB) {
-			fillp_step<LANES, 0, false>(K, r, L, rows_m1, st, sq, q, e, q2, e2, t_lo, tn, jn, T2, Q2, He, E, E2, F, F2, Sc, prow);
-			fillp_step<LANES, 1, false>(K, r + 1, L, rows_m1, st, sq, q, e, q2, e2, t_lo, tn, jn, T2, Q2, Ho, E, E2, F, F2, Sc, prow + ROWB);
-		}
-		// ---- the proof: every path that leaves the band scores at most U
-		int S = FILL_NEG;
+		fill_order_mem();                                      // the direction bytes are in memory before the walks read them
+		// ================================================ one walk per lane
+		int state_w = lane < NSEG ? s_state[lane] : 0;
+		const int n = s_n[lane], m = s_m[lane], kmin = s_kmin[lane], S = s_S[lane];
+		const long long si = s_si[lane];
+		int n_c = 0;
 		{
-			int lc = ok ? n - 1 - ((rows - 1 + kmin + 1) >> 1) : 0;
-			lc = lc < 0 ? 0 : lc >= W ? W - 1 : lc;
-			const uint32_t v = (uint32_t)__shfl((int)Sc, lead + (lc >> 1));
-			S = (int)(int16_t)(lc & 1 ? v >> 16 : v & 0xffffu) >> 3;
-			const int U = dp_band_bound(n, m, kmin, kmax, a, q, e, q2, e2);
-			if (ok && !(S > U)) ok = false;
-		}
-		bool to_next = has && !ok && !to_fb;
-		fill_order_mem();                                      // the direction bytes are in memory before the walk reads them
-		// ---- backtrack through a window of FILL_WIN rows held in LDS
-		int bi = n - 1, bj = m - 1, state = 0, n_c = 0, wlo = rows;
-		uint32_t cur = 0;
-		bool walking = ok;
-		for (;;) {
-			const int seg_r = __shfl(walking ? bi + bj : -1, lead), seg_wlo = __shfl(wlo, lead);
-			if (!__any(seg_r >= 0)) break;
-			if (seg_r >= 0 && seg_r < seg_wlo) {                   // refill: rows [lo, lo + FILL_WIN), 32 bytes per lane
-				const int lo = seg_r - (FILL_WIN - 1) > 0 ? seg_r - (FILL_WIN - 1) : 0;
-				const int byte0 = L * 32, row = lo + byte0 / W, col = byte0 % W;
-				const uint4 *src = reinterpret_cast<const uint4*>(p_wave + (size_t)row * ROWB + sg * W + col);
-				const uint4 v0 = src[0], v1 = src[1];
-				*reinterpret_cast<uint4*>(&s_win[sg][byte0]) = v0;
-				*reinterpret_cast<uint4*>(&s_win[sg][byte0 + 16]) = v1;
-				wlo = lo;
-			}
-			fill_order();
-			if (leader && walking) {
-				while (bi >= 0 && bj >= 0) {
-					const int r = bi + bj;
-					if (r < wlo) break;
-					const int idx = bi - ((r + kmin + 1) >> 1);
-					if (idx < 0 || idx >= W) { walking = false, to_next = true; break; }   // cannot happen after the proof
-					const uint32_t raw = s_win[sg][(r - wlo) * W + idx];
-					// tag 4..7: H; 3 E; 2 F; 1 E2; 0 F2 -- and bits 3..6 say "opened" where ksw2's say "extended"
-					const uint32_t tmp = ((raw & 7u) >= 4u ? 0u : 4u - (raw & 7u)) | (~raw & 0x78u);
-					if (state == 0) state = tmp & 7;
-					else if (!(tmp >> (state + 2) & 1)) state = 0;
-					if (state == 0) state = tmp & 7;
-					uint32_t op;
-					if (state == 0) op = 0, --bi, --bj;
-					else if (state == 1 || state == 3) op = 2, --bi;
-					else op = 1, --bj;
-					if (cur != 0 && (cur & 0xf) == op) cur += 1u << 4;
-					else {
-						if (cur != 0) {
-							if (n_c >= CIG - 4) { walking = false, to_fb = true; break; }   // more operations than the scratch holds
-							s_cg[sg][n_c++] = cur;
-						}
-						cur = 1u << 4 | op;
+			const uint8_t *pu = p_wave + (size_t)(lane / SEGS) * FILLP_PASS_BYTES + (lane % SEGS) * LANES * 32;
+			int bi = n - 1, bj = m - 1, state = 0, cid = -1, mcols = 0, g1 = 0, g2 = 0;
+			uint32_t cur = 0;
+			bool walking = state_w == 1;
+			while (walking && bi >= 0 && bj >= 0) {
+				const int r = bi + bj, idx = bi - ((r + kmin + 1) >> 1);
+				if (idx < 0 || idx >= W) { state_w = 2; walking = false; break; }   // cannot happen after the proof
+				const int c = (r >> 4) * 64 + (idx >> 1);
+				if (c != cid) {
+					const uint4 *src = reinterpret_cast<const uint4*>(pu + (size_t)c * 32);
+					const uint4 v0 = src[0], v1 = src[1];
+					*reinterpret_cast<uint4*>(&s_chunk[lane][0]) = v0, *reinterpret_cast<uint4*>(&s_chunk[lane][16]) = v1;
+					cid = c;
+				}
+				const uint32_t raw = s_chunk[lane][(r & 15) * 2 + (idx & 1)];
+				// bits 4-7: the winner's tag (H 15, E 7, F 3, E2 1, F2 0); bits 3 / 2 / 1 / 0: E / F / E2 / F2 was opened here
+				if (state != 0 && (raw >> (4 - state) & 1u)) state = 0;
+				if (state == 0) { const uint32_t tag = raw >> 4; state = tag >= 8u ? 0 : tag == 7u ? 1 : tag == 3u ? 2 : tag == 1u ? 3 : 4; }
+				uint32_t op;
+				if (state == 0) op = 0, --bi, --bj;
+				else if (state == 1 || state == 3) op = 2, --bi;
+				else op = 1, --bj;
+				if (cur != 0 && (cur & 0xf) == op) cur += 1u << 4;
+				else {
+					if (cur != 0) {
+						if (n_c >= FILL_CIG_MAX - 4) { state_w = 3; walking = false; break; }   // more operations than the scratch holds
+						const int len = (int)(cur >> 4);
+						if ((cur & 0xf) == 0) mcols += len; else g1 += q + e * len, g2 += fill_gap(len, q, e, q2, e2);
+						cg[n_c++] = cur;
 					}
-				}
-				if (walking && (bi < 0 || bj < 0)) {
-					if (bi >= 0) { if (cur != 0 && (cur & 0xf) == 2) cur += (uint32_t)(bi + 1) << 4; else { if (cur != 0) s_cg[sg][n_c++] = cur; cur = (uint32_t)(bi + 1) << 4 | 2; } }
-					if (bj >= 0) { if (cur != 0 && (cur & 0xf) == 1) cur += (uint32_t)(bj + 1) << 4; else { if (cur != 0) s_cg[sg][n_c++] = cur; cur = (uint32_t)(bj + 1) << 4 | 1; } }
-					if (cur != 0) s_cg[sg][n_c++] = cur;
-					walking = false;
+					cur = 1u << 4 | op;
 				}
 			}
-			fill_order();
-		}
-		// ---- mm_test_zdrop (see mnc_dp_fill): skipped when the score bounds the drop below the threshold
-		bool walk = leader && ok && !to_next && !to_fb;
-		if (walk) {
-			int mcols = 0, g1 = 0, g2 = 0;
-			for (int k = 0; k < n_c; ++k) {
-				const uint32_t op = s_cg[sg][k] & 0xf;
-				const int len = (int)(s_cg[sg][k] >> 4);
-				if (op == 0) mcols += len;
-				else g1 += q + e * len, g2 += fill_gap(len, q, e, q2, e2);
+			if (walking) {
+				auto push = [&](uint32_t w) {
+					const int len = (int)(w >> 4);
+					if ((w & 0xf) == 0) mcols += len; else g1 += q + e * len, g2 += fill_gap(len, q, e, q2, e2);
+					cg[n_c++] = w;
+				};
+				if (bi >= 0) { if (cur != 0 && (cur & 0xf) == 2) cur += (uint32_t)(bi + 1) << 4; else { if (cur != 0) push(cur); cur = (uint32_t)(bi + 1) << 4 | 2; } }
+				if (bj >= 0) { if (cur != 0 && (cur & 0xf) == 1) cur += (uint32_t)(bj + 1) << 4; else { if (cur != 0) push(cur); cur = (uint32_t)(bj + 1) << 4 | 1; } }
+				if (cur != 0) push(cur);
+				// mm_test_zdrop: the drop it looks for is at most the sum of the negative steps of the walk -- b per
+				// mismatch, q + e len per gap -- and the number of mismatches follows from the score:
+				// S = a (M columns - mm) - b mm - (two-piece gap costs).  Above the threshold: the literal kernel's
+				const int lost = a * mcols - S - g2;
+				const int neg = (-bmis) * (lost / (a - bmis)) + g1;
+				if (neg > thr) state_w = 4;
 			}
-			const int lost = a * mcols - S - g2;                   // = (a + b) per mismatch
-			const int neg = (-bmis) * (lost / (a + 1)) + g1;
-			if (neg <= (B.zdrop_inv < B.zdrop ? B.zdrop_inv : B.zdrop)) walk = false;
 		}
-		if (walk) {
+		fill_order_mem();                                      // a lane reads its CIGAR back below
+		if (state_w == 4) {
+			// the walk over the CIGAR (stored last operation first), bases from memory: rare
+			const Seg *gs = B.segs + si;
+			const uint8_t *read = B.bases + B.offsets[gs->read];
+			const int rlen = (int)(B.offsets[gs->read + 1] - B.offsets[gs->read]), rev = gs->rev, qs = gs->qs;
+			const int64_t coff = B.seq_off[gs->rid] + gs->ts;
 			int score = 0, mx = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0, max_zdrop = 0;
 			for (int k = n_c - 1; k >= 0; --k) {
-				const uint32_t op = s_cg[sg][k] & 0xf;
-				const int len = (int)(s_cg[sg][k] >> 4);
+				const uint32_t w = cg[k], op = w & 0xf;
+				const int len = (int)(w >> 4);
 				if (op == 0) {
 					for (int l = 0; l < len; ++l) {
-						score += (st[PAD + i + l] & sq[PAD + j + l]) ? a : bmis;
+						const int64_t o = coff + i + l;
+						const int ct = (int)(B.seq4[o >> 3] >> ((o & 7) * 4) & 15u), pq = qs + j + l;
+						int cq = fill_nt4(read[rev ? rlen - 1 - pq : pq]);
+						if (rev) cq = 3 - cq;
+						score += ct == cq ? a : bmis;
 						if (score < mx) {
 							const int li = i + l - max_i, lj = j + l - max_j;
 							const int z = mx - score - (li > lj ? li - lj : lj - li) * e;
@@ -640,27 +688,28 @@ __global__ __launch_bounds__(64) void mnc_dp_fillp(Batch B, const int32_t *list,
 				}
 			}
 			// above the smaller threshold the answer may be 1 or 2: the literal kernel decides and reruns
-			if (max_zdrop > (B.zdrop_inv < B.zdrop ? B.zdrop_inv : B.zdrop)) to_fb = true;
+			state_w = max_zdrop > thr ? 3 : 1;
 		}
-		const bool s_next = __shfl((int)to_next, lead) != 0, s_fb = __shfl((int)to_fb, lead) != 0;
-		const int s_nc = __shfl(n_c, lead);
-		if (has && (s_next || s_fb)) {
-			if (leader) {
-				if (s_fb) { const unsigned long long k = atomicAdd(&B.dp_ctr[ctr_fb], 1ULL); fb_list[k] = (int32_t)si; }
-				else { const unsigned long long k = atomicAdd(&B.dp_ctr[ctr_next], 1ULL); next_list[k] = (int32_t)si; }
-			}
-		} else if (has) {
-			unsigned long long off = 0;
-			if (leader) off = atomicAdd(&B.dp_ctr[1], (unsigned long long)s_nc);
-			off = (unsigned long long)__shfl((long long)off, lead);
-			int wrote = s_nc;
-			if ((long long)(off + s_nc) > B.cig_seg_cap) {
-				if (leader) atomicMax(&B.dp_ctr[4], 2ULL);
-				wrote = 0;
-			} else for (int k = L; k < s_nc; k += LANES) B.cig_seg[off + k] = s_cg[sg][s_nc - 1 - k];
-			if (leader) {
+		// ================================================ results
+		if (state_w == 2) { const unsigned long long k = atomicAdd(&B.dp_ctr[ctr_next], 1ULL); next_list[k] = (int32_t)si; }
+		if (state_w == 3) { const unsigned long long k = atomicAdd(&B.dp_ctr[ctr_fb], 1ULL); fb_list[k] = (int32_t)si; }
+		{
+			const int mine = state_w == 1 ? n_c : 0;
+			int incl = mine;
+#pragma unroll
+			for (int sft = 1; sft < 64; sft <<= 1) { const int o = __shfl_up(incl, sft); if (lane >= sft) incl += o; }
+			const int total = __shfl(incl, 63);
+			unsigned long long base = 0;
+			if (lane == 0 && total > 0) base = atomicAdd(&B.dp_ctr[1], (unsigned long long)total);
+			base = (unsigned long long)__shfl((long long)base, 0);
+			if ((long long)(base + total) > B.cig_seg_cap) {
+				if (lane == 0) atomicMax(&B.dp_ctr[4], 2ULL);
+				if (state_w == 1) { Seg *o = B.segs + si; o->n_cigar = 0, o->zdropped = 0, o->zdrop_code = 0, o->cig_off = 0; }
+			} else if (state_w == 1) {
+				const unsigned long long off = base + (unsigned long long)(incl - mine);
+				for (int k = 0; k < n_c; ++k) B.cig_seg[off + k] = cg[n_c - 1 - k];
 				Seg *o = B.segs + si;
-				o->n_cigar = wrote, o->zdropped = 0, o->zdrop_code = 0;
+				o->n_cigar = n_c, o->zdropped = 0, o->zdrop_code = 0;
 				o->max = 0, o->max_t = -1, o->max_q = -1, o->score = S, o->reach_end = 0, o->mqe_t = -1;
 				o->cig_off = (int64_t)off;
 			}
@@ -903,14 +952,16 @@ __global__ __launch_bounds__(64) void mnc_dp_ext(Batch B, const int32_t *list, i
 	}
 }
 
-size_t dp_fill_p_slot() { return 2 * FILL_P_SLOT; }
+size_t dp_fill_p_slot() { return FILL_P_SLOT; }
+size_t dp_fillp_slot() { return FILLP_SLOT; }
+size_t dp_fillp_cig_slot() { return (size_t)64 * FILL_CIG_MAX * 4; }
 void launch_dp_fill(const Batch &B, int lanes, const int32_t *list, int ctr_n, int ctr_q, int32_t *next_list, int ctr_next,
-                    int32_t *fb_list, int ctr_fb, uint8_t *p_all, int n_wg, hipStream_t st)
+                    int32_t *fb_list, int ctr_fb, uint8_t *p_all, uint32_t *cig_all, int n_wg, hipStream_t st)
 {
 	// `lanes` = cells of the band
-	if (lanes == 32) hipLaunchKernelGGL((mnc_dp_fillp<16>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all);
-	else if (lanes == 64) hipLaunchKernelGGL((mnc_dp_fillp<32>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all);
-	else hipLaunchKernelGGL((mnc_dp_fillp<64>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all);
+	if (lanes == 32) hipLaunchKernelGGL((mnc_dp_fillp<16>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all, cig_all);
+	else if (lanes == 64) hipLaunchKernelGGL((mnc_dp_fillp<32>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all, cig_all);
+	else hipLaunchKernelGGL((mnc_dp_fillp<64>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all, cig_all);
 }
 
 void launch_dp_ext(const Batch &B, int lanes, const int32_t *list, int ctr_n, int ctr_q, int32_t *fb_list, int ctr_fb, uint8_t *p_all, int n_wg, hipStream_t st)
