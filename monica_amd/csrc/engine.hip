@@ -49,6 +49,9 @@ void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_li
 size_t dp_fill_p_slot();
 size_t dp_fillp_slot();
 size_t dp_fillp_cig_slot();
+size_t dp_extp_slot();
+size_t dp_extp_cig_slot();
+void launch_dp_extp(const Batch &B, int cells, int rgt, const int32_t *list, int ctr_n, int ctr_q, uint8_t *p_all, uint32_t *cig_all, int n_wg, hipStream_t st);
 void launch_dp_fill(const Batch &B, int lanes, const int32_t *list, int ctr_n, int ctr_q, int32_t *next_list, int ctr_next,
                     int32_t *fb_list, int ctr_fb, uint8_t *p_all, uint32_t *cig_all, int n_wg, hipStream_t st);
 void launch_dp_ext(const Batch &B, int lanes, const int32_t *list, int ctr_n, int ctr_q, int32_t *fb_list, int ctr_fb, uint8_t *p_all, int n_wg, hipStream_t st);
@@ -373,7 +376,7 @@ struct mnc_engine {
 	// base-level alignment stage
 	int contract = MNC_CONTRACT_DP;
 	Buf ca, ca_cnt, chain_dst, regdp, segs, cig_seg, cig_reg, dp_ctr, work_a, work_b, big_list, reg_cnt, regs2, dp_ws, dp_ws_big;
-	Buf fill1, fill2, fill3, fill_fb, fill_p, fill_cig, ext1, ext2, ext3, ext4, ext_p, gen_list;
+	Buf fill1, fill2, fill3, fill_fb, fill_p, fill_cig, extp, extp_p, extp_cig, ext1, ext2, ext3, ext4, ext_p, gen_list;
 	size_t seg_cap_override = 0, cig_cap_override = 0;
 	int debug = 0;                           // bit mask (tests): 2 stress build of the chaining ring, 4 displacement bytes read from HBM, 0x10000 alignment kernels one at a time (with stage timers)
 	// last batch
@@ -459,7 +462,7 @@ extern "C" void mnc_engine_destroy(mnc_engine *e)
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
 	Buf *all[] = { &e->gap_lut, &e->logf_lut, &e->logf_a_lut, &e->ca, &e->ca_cnt, &e->chain_dst, &e->regdp, &e->segs, &e->cig_seg, &e->cig_reg, &e->dp_ctr,
-	               &e->work_a, &e->work_b, &e->big_list, &e->reg_cnt, &e->regs2, &e->dp_ws, &e->dp_ws_big, &e->fill1, &e->fill2, &e->fill3, &e->fill_fb, &e->fill_p, &e->fill_cig, &e->ext1, &e->ext2, &e->ext3, &e->ext4, &e->ext_p, &e->gen_list, &e->in_bases, &e->in_offsets, &e->out_assign, &e->out_best, &e->out_nhits,
+	               &e->work_a, &e->work_b, &e->big_list, &e->reg_cnt, &e->regs2, &e->dp_ws, &e->dp_ws_big, &e->fill1, &e->fill2, &e->fill3, &e->fill_fb, &e->fill_p, &e->fill_cig, &e->extp, &e->extp_p, &e->extp_cig, &e->ext1, &e->ext2, &e->ext3, &e->ext4, &e->ext_p, &e->gen_list, &e->in_bases, &e->in_offsets, &e->out_assign, &e->out_best, &e->out_nhits,
 	               &e->packed, &e->mz, &e->hits, &e->hist_tm, &e->q_off, &e->qrec, &e->bhits, &e->bhit_cnt, &e->ambig, &e->mz_cnt, &e->hit_cnt, &e->rep_len, &e->an_cnt, &e->an_off,
 	               &e->n_chain, &e->n_reg, &e->best_mlen, &e->hist_sums, &e->hist_offs, &e->scan_sums, &e->hit_off, &e->a, &e->f, &e->p, &e->v, &e->t, &e->u,
 	               &e->chains_tmp, &e->regs, &e->regx, &e->k64a, &e->k64b, &e->tmp_i32, &e->gated,
@@ -513,7 +516,7 @@ extern "C" int mnc_engine_create(mnc_index *idx, int device, mnc_engine **out)
 	rc = e->gap_lut.ensure(GAP_LUT * 4);
 	if (!rc) rc = e->logf_lut.ensure((size_t)e->logf_n * 4);
 	if (!rc) rc = e->logf_a_lut.ensure((size_t)e->logf_n * 4);
-	if (!rc) rc = e->dp_ctr.ensure(32 * 8);
+	if (!rc) rc = e->dp_ctr.ensure(64 * 8);
 	if (!rc) rc = dp_align_prepare(DP_LDS_BYTES);
 	if (!rc) rc = e->stats.ensure(16 * 8);
 	if (!rc) rc = e->cls_count.ensure((MAX_CHAIN_CLASSES + 1) * 4 + 64);
@@ -601,6 +604,8 @@ static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream
 	launch_dp_fill(B, 32, B.fill_list1, 10, 13, B.fill_list2, 11, B.fill_fb, 12, e->fill_p.as<uint8_t>(), e->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
 	launch_dp_fill(B, 64, B.fill_list2, 11, 14, B.fill_list3, 22, B.fill_fb, 12, e->fill_p.as<uint8_t>(), e->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
 	launch_dp_fill(B, 128, B.fill_list3, 22, 23, B.fill_fb, 12, B.fill_fb, 12, e->fill_p.as<uint8_t>(), e->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
+	for (int i = 0; i < 8; ++i)
+		launch_dp_extp(B, 32 << (i >> 1), i & 1, B.extp_list + (int64_t)i * B.seg_cap, 32 + i, 40 + i, e->extp_p.as<uint8_t>(), e->extp_cig.as<uint32_t>(), DP_WG_EXT, s1);
 	launch_dp_ext(B, 32, B.ext_list1, 16, 18, B.fill_fb, 12, e->ext_p.as<uint8_t>(), DP_WG_EXT, s1);
 	launch_dp_ext(B, 64, B.ext_list2, 17, 19, B.fill_fb, 12, e->ext_p.as<uint8_t>(), DP_WG_EXT, s1);
 	launch_dp_ext(B, 128, B.ext_list3, 24, 26, B.fill_fb, 12, e->ext_p.as<uint8_t>(), DP_WG_EXT / 2, s1);
@@ -833,7 +838,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 		ENS2(work_a, ns * 4); ENS2(work_b, ns * 4); ENS2(big_list, seg_cap * 4); ENS2(reg_cnt, (nr + 1) * 4); ENS2(regs2, ns * sizeof(mnc_reg_t));
 		const size_t ws_small = dp_align_ws_bytes(DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL), ws_big = dp_align_ws_bytes(DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG);
 		ENS2(dp_ws, ws_small * DP_WG_SMALL * 2); ENS2(dp_ws_big, ws_big * DP_WG_BIG);
-		ENS2(fill1, seg_cap * 4); ENS2(fill2, seg_cap * 4); ENS2(fill3, seg_cap * 4); ENS2(fill_fb, seg_cap * 4); ENS2(fill_p, dp_fillp_slot() * DP_WG_FILL); ENS2(fill_cig, dp_fillp_cig_slot() * DP_WG_FILL); ENS2(ext1, seg_cap * 4); ENS2(ext2, seg_cap * 4); ENS2(ext3, seg_cap * 4); ENS2(ext4, seg_cap * 4); ENS2(gen_list, seg_cap * 4); ENS2(ext_p, dp_fill_p_slot() * DP_WG_EXT);
+		ENS2(fill1, seg_cap * 4); ENS2(fill2, seg_cap * 4); ENS2(fill3, seg_cap * 4); ENS2(fill_fb, seg_cap * 4); ENS2(fill_p, dp_fillp_slot() * DP_WG_FILL); ENS2(fill_cig, dp_fillp_cig_slot() * DP_WG_FILL); ENS2(extp, seg_cap * 4 * 8); ENS2(extp_p, dp_extp_slot() * DP_WG_EXT); ENS2(extp_cig, dp_extp_cig_slot() * DP_WG_EXT); ENS2(ext1, seg_cap * 4); ENS2(ext2, seg_cap * 4); ENS2(ext3, seg_cap * 4); ENS2(ext4, seg_cap * 4); ENS2(gen_list, seg_cap * 4); ENS2(ext_p, dp_fill_p_slot() * DP_WG_EXT);
 #undef ENS2
 		if (rc2) return rc2;
 		B.ca = e->ca.as<Anchor>(), B.ca_cnt = e->ca_cnt.as<int32_t>(), B.chain_dst = e->chain_dst.as<int32_t>(), B.regdp = e->regdp.as<RegDP>();
@@ -841,10 +846,10 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 		B.cig_seg_cap = B.cig_reg_cap = (int64_t)cig_cap, B.dp_ctr = e->dp_ctr.as<unsigned long long>();
 		B.big_list = e->big_list.as<int32_t>(), B.reg_cnt = e->reg_cnt.as<int32_t>();
 		B.fill_list1 = e->fill1.as<int32_t>(), B.fill_list2 = e->fill2.as<int32_t>(), B.fill_list3 = e->fill3.as<int32_t>(), B.fill_fb = e->fill_fb.as<int32_t>();
-		B.ext_list1 = e->ext1.as<int32_t>(), B.ext_list2 = e->ext2.as<int32_t>(), B.ext_list3 = e->ext3.as<int32_t>(), B.ext_list4 = e->ext4.as<int32_t>(), B.gen_list = e->gen_list.as<int32_t>();
+		B.ext_list1 = e->ext1.as<int32_t>(), B.ext_list2 = e->ext2.as<int32_t>(), B.ext_list3 = e->ext3.as<int32_t>(), B.ext_list4 = e->ext4.as<int32_t>(), B.gen_list = e->gen_list.as<int32_t>(), B.extp_list = e->extp.as<int32_t>();
 		int32_t *lists[2] = { e->work_a.as<int32_t>(), e->work_b.as<int32_t>() };
 		B.next_list = lists[0];                          // the regions kernel files every kept region here
-		HIP_TRY(hipMemsetAsync(e->dp_ctr.p, 0, 32 * 8, st));
+		HIP_TRY(hipMemsetAsync(e->dp_ctr.p, 0, 64 * 8, st));
 		{ StageTimer t(e, MNC_STAGE_REGIONS);   launch_regions(B, e->regx.p, e->k64a.as<uint64_t>(), e->k64b.as<uint64_t>(), e->gated.as<mnc_hit_t>(), st); }
 		{ StageTimer t(e, MNC_STAGE_DP_PLAN);   launch_dp_gather(B, st); }
 		unsigned max_work = (unsigned)ns;

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 			d.n_seg = 0, d.has_left = d.has_right = 0;
 		} else {
 			Seg *sg = B.segs + s0;
-			int n_tier[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+			int n_tier[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 			auto emit = [&](Seg g) {
 				g.read = (int32_t)rd, g.reg = (int32_t)rslot, g.rid = rid, g.rev = rev;
 				g.n_cigar = 0, g.zdropped = 0, g.zdrop_code = 0, g.max = 0, g.max_t = g.max_q = -1, g.score = DP_NEG_INF, g.reach_end = 0, g.mqe_t = -1, g.cig_off = 0;
@@ -334,9 +334,14 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 					}
 					if (tier) g.big = 3 + tier, ++n_tier[tier - 1];          // not for the literal kernel's first pass
 				} else if (g.big == 0 && g.kind != 1 && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= g.w && g.qlen <= g.w &&
+				           g.tlen + g.qlen - 1 <= 2 * FILL_MAX_LEN && g.qlen <= 256) {
+					// an extension whose matrix the band never clips, one cell per query base: the packed
+					// extension kernel of k_fill.hip (tiers 8..15: by query length, right / left)
+					const int tier = 8 + 2 * (g.qlen <= 32 ? 0 : g.qlen <= 64 ? 1 : g.qlen <= 128 ? 2 : 3) + ((g.flag & EZ_RIGHT) ? 1 : 0);
+					g.big = 4 + tier, ++n_tier[tier];
+				} else if (g.big == 0 && g.kind != 1 && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= g.w && g.qlen <= g.w &&
 				           g.tlen + g.qlen - 1 <= 2 * FILL_MAX_LEN && (g.tlen < g.qlen ? g.tlen : g.qlen) <= 256) {
-					// an extension whose matrix the band never clips and whose anti-diagonals fit a wave (up to
-					// four cells per lane): the extension kernel of k_fill.hip
+					// ... or with anti-diagonals that fit a wave (up to four cells per lane): the step-by-step one
 					const int mn = g.tlen < g.qlen ? g.tlen : g.qlen;
 					const int tier = mn <= 32 ? 3 : mn <= 64 ? 4 : mn <= 128 ? 7 : 8;
 					g.big = 3 + tier, ++n_tier[tier - 1];
@@ -373,11 +378,12 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 				emit(g);
 			}
 			// the banded kernel's lists: one reservation per region and tier
-			for (int tier = 0; tier < 8; ++tier) {
+			for (int tier = 0; tier < 16; ++tier) {
 				if (n_tier[tier] == 0) continue;
-				const int ci = tier < 2 ? 10 + tier : tier < 4 ? 14 + tier : tier == 4 ? 20 : tier == 5 ? 22 : 18 + tier;   // 6 -> 24, 7 -> 25
+				const int ci = tier >= 8 ? 24 + tier : tier < 2 ? 10 + tier : tier < 4 ? 14 + tier : tier == 4 ? 20 : tier == 5 ? 22 : 18 + tier;   // 6 -> 24, 7 -> 25; 8.. -> 32..
 				unsigned long long fi = atomicAdd(&B.dp_ctr[ci], (unsigned long long)n_tier[tier]);
-				int32_t *lst = tier == 0 ? B.fill_list1 : tier == 1 ? B.fill_list2 : tier == 2 ? B.ext_list1 : tier == 3 ? B.ext_list2 : tier == 4 ? B.gen_list
+				int32_t *lst = tier >= 8 ? B.extp_list + (int64_t)(tier - 8) * B.seg_cap
+				             : tier == 0 ? B.fill_list1 : tier == 1 ? B.fill_list2 : tier == 2 ? B.ext_list1 : tier == 3 ? B.ext_list2 : tier == 4 ? B.gen_list
 				             : tier == 5 ? B.fill_list3 : tier == 6 ? B.ext_list3 : B.ext_list4;
 				for (int k = 0; k < n_seg; ++k)
 					if (B.segs[s0 + k].big == 4 + tier) lst[fi++] = (int32_t)(s0 + k);
@@ -1241,7 +1247,7 @@ __global__ void mnc_dp_round(Batch B, int first)
 	B.dp_ctr[9] = B.dp_ctr[5];            // regions to plan / stitch this round
 	B.dp_ctr[5] = 0;
 	B.dp_ctr[6] = 0, B.dp_ctr[7] = 0;
-	for (int k = 10; k < 28; ++k) B.dp_ctr[k] = 0;   // banded kernel: list lengths 10 / 11 / 12 (tier 1, tier 2, handed back), queues 13 / 14 / 15;
+	for (int k = 10; k < 48; ++k) B.dp_ctr[k] = 0;   // banded kernel: list lengths 10 / 11 / 12 (tier 1, tier 2, handed back), queues 13 / 14 / 15;
 	                                                 // extension kernel: lists 16 / 17, queues 18 / 19; literal kernel's first pass: list 20, queue 21; banded kernel, 128 cells: list 22, queue 23; extension kernel, 128 / 256 cells: lists 24 / 25, queues 26 / 27
 }
 __global__ void mnc_dp_round_end(Batch B)

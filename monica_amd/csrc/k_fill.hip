@@ -952,6 +952,409 @@ __global__ __launch_bounds__(64) void mnc_dp_ext(Batch B, const int32_t *list, i
 	}
 }
 
+// ================================================================ extensions, two cells per lane and instruction
+// The same packed arithmetic for the extensions.  Cell c of a segment is QUERY base c for the whole
+// run and holds target base t = r - c on step r: the upper neighbour is the cell itself one step
+// back, the left and the diagonal ones are cell c - 1 (one / two steps back), the same on every
+// step; the virtual column enters at cell 0 on every step, the virtual row at cell c = r.  A lane
+// holds 2 CPL consecutive cells, so the shift by one cell is one DPP move and CPL v_alignbit.
+//
+// What ksw2 does per anti-diagonal -- the maximum, the best cell so far, the Z-drop test -- is not
+// done per step: every cell keeps its own best H and the step it first reached it (packed), the best
+// cell of the matrix follows at the end (first step, then the SSE scan's order within it), and
+// the score of the query's last row (mqe) is cell m - 1's own best.  That is ksw2's result when its
+// Z-drop never fires; every 16 steps the kernel checks a bound that rules the Z-drop out until the
+// next check (best so far - maximum of this anti-diagonal <= zdrop - what 16 steps can change), and
+// a segment that fails it goes to the step-by-step kernel above.  RGT: gaps right-aligned (the left
+// extension, KSW_EZ_RIGHT): the later candidate wins a tie, so the tags are the other way round.
+constexpr int EXTP_G = 16;
+constexpr int EXTP_CIG_MAX = 1024;
+constexpr int EXTP_ROWS = 2 * FILL_MAX_LEN;                 // n + m - 1 at most
+
+template <int RGT> struct ExtpTag {
+	static constexpr uint32_t H = RGT ? 0u : 0x000f000fu, E = RGT ? 0x00010001u : 0x00070007u, F = 0x00030003u,
+	                          E2 = RGT ? 0x00070007u : 0x00010001u, F2 = RGT ? 0x000f000fu : 0u;
+};
+
+__host__ __device__ __forceinline__ bool extp_bias(int cells, int a, int bmis_abs, int q, int e, int q2, int e2, int &bias)
+{
+	const int hi = a * cells, lo = -(bmis_abs * cells + fill_gap(EXTP_ROWS + 32, q, e, q2, e2) + (q + e > q2 + e2 ? q + e : q2 + e2));
+	bias = -(hi + lo) / 2;
+	// cells that have not started hold what grew from the initial value: still below every real score
+	return hi + bias < 2040 && lo + bias > -2040 && lo + bias > -2048 + a * cells + 16;
+}
+
+template <int LANES, int CPL, int RGT, bool EDGE, bool LIVE>
+__device__ __forceinline__ void extp_step(const PkConst &K, const int r, const int L, const int rows, const uint8_t *st, int &tn,
+                                          const int q, const int e, const int q2, const int e2, const uint32_t colmask,
+                                          uint32_t (&T)[CPL], const uint32_t (&Q)[CPL], uint32_t (&H1)[CPL], uint32_t (&H2)[CPL],
+                                          uint32_t (&E)[CPL], uint32_t (&E2)[CPL], uint32_t (&F)[CPL], uint32_t (&F2)[CPL],
+                                          uint32_t (&best)[CPL], uint32_t (&bestR)[CPL], uint32_t &nbH, uint32_t &nbF, uint32_t &nbF2,
+                                          uint32_t (&acc)[CPL], const int odd)
+{
+	typedef ExtpTag<RGT> TG;
+	constexpr int SHR = LANES == 16 ? 0x111 : 0x138;           // row_shr:1 / wave_shr:1
+	// the target bases move up one cell
+	{
+		const uint32_t nc = st[tn];
+		++tn;
+#pragma unroll
+		for (int k = CPL - 1; k > 0; --k) T[k] = __builtin_amdgcn_alignbit(T[k], T[k - 1], 16);
+		T[0] = __builtin_amdgcn_perm(T[0], nc, 0x05040100u);
+	}
+	// H two steps back, F and F2 one step back, of the cell below
+	nbH = (uint32_t)__builtin_amdgcn_update_dpp((int)nbH, (int)H2[CPL - 1], SHR, 0xf, 0xf, false);
+	nbF = (uint32_t)__builtin_amdgcn_update_dpp((int)nbF, (int)F[CPL - 1], SHR, 0xf, 0xf, false);
+	nbF2 = (uint32_t)__builtin_amdgcn_update_dpp((int)nbF2, (int)F2[CPL - 1], SHR, 0xf, 0xf, false);
+	uint32_t hd[CPL], vF[CPL], vF2[CPL];
+#pragma unroll
+	for (int k = CPL - 1; k > 0; --k)
+		hd[k] = __builtin_amdgcn_alignbit(H2[k], H2[k - 1], 16), vF[k] = __builtin_amdgcn_alignbit(F[k], F[k - 1], 16), vF2[k] = __builtin_amdgcn_alignbit(F2[k], F2[k - 1], 16);
+	hd[0] = __builtin_amdgcn_alignbit(H2[0], nbH, 16), vF[0] = __builtin_amdgcn_alignbit(F[0], nbF, 16), vF2[0] = __builtin_amdgcn_alignbit(F2[0], nbF2, 16);
+	// the virtual column at cell 0 (t = r), and on the first steps the virtual row at cell c = r (t = 0)
+	const int hb = -fill_gap(r + 1, q, e, q2, e2) + K.bias;
+	const uint32_t h0 = pk_rep(((r == 0 ? 0 : -fill_gap(r, q, e, q2, e2)) + K.bias) << 4) | TG::H;
+	const uint32_t g1 = pk_rep((hb - q - e) << 4), g2 = pk_rep((hb - q2 - e2) << 4);
+	hd[0] = pk_bfi(colmask, h0, hd[0]), vF[0] = pk_bfi(colmask, g1 | TG::F, vF[0]), vF2[0] = pk_bfi(colmask, g2 | TG::F2, vF2[0]);
+	uint32_t vE[CPL], vE2[CPL];
+#pragma unroll
+	for (int k = 0; k < CPL; ++k) vE[k] = E[k], vE2[k] = E2[k];
+	if (EDGE) {
+		// `r` is a multiple of 2 CPL plus a constant in the unrolled block: register and half are static
+		const uint32_t rowmask = L == r / (2 * CPL) ? ((odd & 1) ? 0xffff0000u : 0x0000ffffu) : 0u;
+		const int ks = (odd >> 1) % CPL;
+#pragma unroll
+		for (int k = 0; k < CPL; ++k)
+			if (k == ks) hd[k] = pk_bfi(rowmask, h0, hd[k]), vE[k] = pk_bfi(rowmask, g1 | TG::E, vE[k]), vE2[k] = pk_bfi(rowmask, g2 | TG::E2, vE2[k]);
+	}
+	const uint32_t Rpk = pk_rep(r);
+#pragma unroll
+	for (int k = 0; k < CPL; ++k) {
+		const uint32_t sc = pk_madu(pk_subsu(0x00010001u, T[k] ^ Q[k]), K.kmatch, K.kmis);
+		uint32_t z = pk_adds(hd[k], sc);
+		z = pk_maxs(z, vE[k]), z = pk_maxs(z, vF[k]), z = pk_maxs(z, vE2[k]), z = pk_maxs(z, vF2[k]);
+		const uint32_t zt = RGT ? (z & 0xfff0fff0u) : (z | 0x000f000fu);
+		const uint32_t o1 = pk_subs(zt, K.q8), o2 = pk_subs(zt, K.q28);
+		const uint32_t mE = pk_maxs(vE[k], o1), mF = pk_maxs(vF[k], o1), mE2 = pk_maxs(vE2[k], o2), mF2 = pk_maxs(vF2[k], o2);
+		uint32_t d;
+		if (RGT) {
+			E[k] = pk_subs(mE, K.e8) | TG::E, F[k] = pk_subs(mF, K.e8) | TG::F, E2[k] = pk_subs(mE2, K.e28) | TG::E2, F2[k] = pk_subs(mF2, K.e28) | TG::F2;
+			d = pk_bfi(0x00010001u, mE, pk_bfi(0x00020002u, mF, pk_bfi(0x00040004u, mE2, mF2 & 0x00080008u)));   // "extended"
+		} else {
+			E[k] = pk_subs(mE, K.e8) & 0xfff7fff7u, F[k] = pk_subs(mF, K.e8) & 0xfff3fff3u, E2[k] = pk_subs(mE2, K.e28) & 0xfff1fff1u, F2[k] = pk_subs(mF2, K.e28) & 0xfff0fff0u;
+			d = pk_bfi(0x00080008u, mE, pk_bfi(0x00040004u, mF, pk_bfi(0x00020002u, mE2, mF2 & 0x00010001u)));   // "opened"
+		}
+		d |= (z & 0x000f000fu) << 4;
+		acc[k] = (odd & 1) ? __builtin_amdgcn_perm(d, acc[k], 0x06040100u) : __builtin_amdgcn_perm(d, d, 0x0c0c0200u);
+		// every cell's best H and the step it first reached it
+		const uint32_t zl = LIVE ? (r < rows ? zt : PK_NEG) : zt;
+		const uint32_t nb = pk_maxs(best[k], zl), chg = nb ^ best[k];
+		const uint32_t msk = __builtin_bit_cast(uint32_t, (pk_u16)(__builtin_bit_cast(pk_u16, pk_subsu(chg, 0x00010001u)) - __builtin_bit_cast(pk_u16, chg)));   // 0xffff where it changed
+		bestR[k] = pk_bfi(msk, Rpk, bestR[k]), best[k] = nb;
+		H2[k] = H1[k], H1[k] = zt;
+	}
+}
+
+template <int LANES> __device__ __forceinline__ int seg_max_i32(int v)
+{
+#pragma unroll
+	for (int sft = 1; sft < LANES; sft <<= 1) { const int o = __shfl_xor(v, sft); v = v > o ? v : o; }
+	return v;
+}
+template <int LANES> __device__ __forceinline__ unsigned seg_min_u32(unsigned v)
+{
+#pragma unroll
+	for (int sft = 1; sft < LANES; sft <<= 1) { const unsigned o = (unsigned)__shfl_xor((int)v, sft); v = v < o ? v : o; }
+	return v;
+}
+__device__ __forceinline__ int pk_half(uint32_t v, int h) { return (int)(int16_t)(h ? v >> 16 : v & 0xffffu); }
+
+template <int LANES, int CPL, int RGT>
+__global__ __launch_bounds__(64) void mnc_dp_extp(Batch B, const int32_t *list, int ctr_n, int ctr_q, uint8_t *p_all, uint32_t *cig_all)
+{
+	constexpr int SEGS = 64 / LANES, WC = 2 * CPL * LANES, PAD = WC + 2, SEQ = PAD + EXTP_ROWS + 48, NSEG = EXTP_G * SEGS;
+	constexpr bool LIVE = SEGS > 1;
+	constexpr size_t PASS_BYTES = (size_t)FILLP_BLOCKS * 64 * 32 * CPL;
+	typedef ExtpTag<RGT> TG;
+	__shared__ uint8_t s_t[SEGS][SEQ], s_q[SEGS][WC];
+	__shared__ __align__(16) uint8_t s_chunk[64][32];
+	__shared__ int32_t s_n[64], s_m[64], s_bi[64], s_bj[64], s_si[64], s_state[64], s_max[64], s_maxt[64], s_maxq[64], s_mqet[64], s_reach[64], s_keep[64];
+	const int lane = threadIdx.x, sg = lane / LANES, L = lane % LANES, lead = sg * LANES;
+	const bool leader = L == 0;
+	const int a = B.sc_a, bmis = -B.sc_b, q = B.gap_q, e = B.gap_e, q2 = B.gap_q2, e2 = B.gap_e2;
+	PkConst K;
+	K.kmatch = pk_rep((a - bmis) << 4), K.kmis = pk_rep(bmis << 4), K.q8 = pk_rep(q << 4), K.q28 = pk_rep(q2 << 4), K.e8 = pk_rep(e << 4), K.e28 = pk_rep(e2 << 4);
+	const bool fits = extp_bias(WC, a, -bmis > B.sc_ambi ? -bmis : B.sc_ambi, q, e, q2, e2, K.bias);
+	const int slack = 2 * q + 16 * e + 8 * a + 8 * (-bmis);    // what 16 steps can add to the best score so far and take from the anti-diagonal's maximum
+	uint8_t *p_wave = p_all + (size_t)blockIdx.x * (EXTP_G * PASS_BYTES);
+	uint32_t *cg = cig_all + ((size_t)blockIdx.x * 64 + lane) * EXTP_CIG_MAX;
+	const unsigned long long n_items = B.dp_ctr[ctr_n];
+	const unsigned long long segmask = LANES == 64 ? ~0ULL : ((1ULL << (LANES & 63)) - 1) << lead;
+	const uint32_t colmask = L == 0 ? 0x0000ffffu : 0u;
+	// few segments: smaller groups, so that every workgroup has some
+	int g_eff = (int)((n_items + (unsigned long long)gridDim.x * SEGS - 1) / ((unsigned long long)gridDim.x * SEGS));
+	g_eff = g_eff < 1 ? 1 : g_eff > EXTP_G ? EXTP_G : g_eff;
+	for (;;) {
+		unsigned long long q0 = 0;
+		if (lane == 0) q0 = atomicAdd(&B.dp_ctr[ctr_q], (unsigned long long)(g_eff * SEGS));
+		q0 = (unsigned long long)__shfl((long long)q0, 0);
+		if (q0 >= n_items) break;                              // every wave gets here: the queue is finite
+		s_state[lane] = 0;
+		fill_order();
+		for (int u = 0; u < g_eff; ++u) {
+			if (q0 + (unsigned long long)u * SEGS >= n_items) break;
+			const unsigned long long item = q0 + (unsigned long long)u * SEGS + sg;
+			const bool has = item < n_items;
+			const long long si = has ? (long long)list[item] : -1;
+			struct { int32_t tlen, qlen, ts, qs, read, rid, rev, kind, zdrop, flag; } g = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+			if (has) {
+				const Seg *gs = B.segs + si;
+				g.tlen = gs->tlen, g.qlen = gs->qlen, g.ts = gs->ts, g.qs = gs->qs, g.read = gs->read, g.rid = gs->rid, g.rev = gs->rev;
+				g.kind = gs->kind, g.zdrop = gs->zdrop, g.flag = gs->flag;
+			}
+			const int n = g.tlen, m = g.qlen;
+			bool ok = has && fits && n >= 1 && m >= 1 && m <= WC && n + m - 1 <= EXTP_ROWS && ((g.flag & EZ_RIGHT) != 0) == (RGT != 0);
+			const int rows = ok ? n + m - 1 : 0;
+			int max_rows = rows, edge_rows = ok ? (m + 15) & ~15 : 0;
+#pragma unroll
+			for (int sft = LANES; sft < 64; sft <<= 1) {
+				const int o = __shfl_xor(max_rows, sft), oe = __shfl_xor(edge_rows, sft);
+				max_rows = max_rows > o ? max_rows : o, edge_rows = edge_rows > oe ? edge_rows : oe;
+			}
+			max_rows = __builtin_amdgcn_readfirstlane(max_rows), edge_rows = __builtin_amdgcn_readfirstlane(edge_rows);
+			// ---- sequences: target bases at [PAD + t] (beyond the end: a base that matches nothing), query bases in registers
+			bool ambiguous = false;
+			if (ok) {
+				const uint8_t *read = B.bases + B.offsets[g.read];
+				const int rlen = (int)(B.offsets[g.read + 1] - B.offsets[g.read]);
+				const int64_t coff = B.seq_off[g.rid];
+				const bool rv = g.kind == 0;                          // the left extension: both sequences reversed
+#pragma unroll 1
+				for (int i = L; i < n; i += LANES) {
+					const int64_t o = coff + (rv ? g.ts + n - 1 - i : g.ts + i);
+					const uint32_t c = B.seq4[o >> 3] >> ((o & 7) * 4) & 15u;
+					ambiguous |= c > 3;
+					s_t[sg][PAD + i] = (uint8_t)(c & 3);
+				}
+#pragma unroll 1
+				for (int i = n + L; i < max_rows + 16; i += LANES) s_t[sg][PAD + i] = 4;
+#pragma unroll 1
+				for (int i = L; i < WC; i += LANES) {
+					int c = 5;
+					if (i < m) {
+						const int pq = rv ? g.qs + m - 1 - i : g.qs + i;
+						c = fill_nt4(read[g.rev ? rlen - 1 - pq : pq]);
+						ambiguous |= c > 3;
+						c = (g.rev ? 3 - c : c) & 3;
+					}
+					s_q[sg][i] = (uint8_t)c;
+				}
+			}
+			const bool seg_amb = (__ballot(ambiguous) & segmask) != 0;
+			ok = ok && !seg_amb;                                   // the step-by-step kernel scores an ambiguous base
+			fill_order();
+			const uint8_t *st = &s_t[sg][0];
+			uint32_t T[CPL], Q[CPL], H1[CPL], H2[CPL], E[CPL], E2[CPL], F[CPL], F2[CPL], best[CPL], bestR[CPL];
+#pragma unroll
+			for (int k = 0; k < CPL; ++k) {
+				const int c0 = 2 * CPL * L + 2 * k;
+				Q[k] = (uint32_t)s_q[sg][c0] | (uint32_t)s_q[sg][c0 + 1] << 16;
+				T[k] = (uint32_t)st[PAD - 1 - c0] | (uint32_t)st[PAD - 2 - c0] << 16;
+				H1[k] = H2[k] = PK_NEG | TG::H, E[k] = PK_NEG | TG::E, E2[k] = PK_NEG | TG::E2, F[k] = PK_NEG | TG::F, F2[k] = PK_NEG | TG::F2;
+				best[k] = PK_NEG | TG::H, bestR[k] = 0;
+			}
+			int tn = PAD - 2 * CPL * L;
+			uint32_t nbH = PK_NEG, nbF = PK_NEG, nbF2 = PK_NEG;
+			bool suspect = false;
+			uint4 *pblk = reinterpret_cast<uint4*>(p_wave + (size_t)u * PASS_BYTES + (size_t)lane * 32 * CPL);
+			for (int r = 0; r < max_rows; r += 16, pblk += 64 * 32 * CPL / 16) {
+				uint32_t acc[8][CPL] = {};
+				if (r < edge_rows) {
+#pragma unroll
+					for (int k = 0; k < 16; ++k)
+						if (r + k < max_rows) extp_step<LANES, CPL, RGT, true, LIVE>(K, r + k, L, rows, st, tn, q, e, q2, e2, colmask, T, Q, H1, H2, E, E2, F, F2, best, bestR, nbH, nbF, nbF2, acc[k >> 1], k);
+				} else {
+#pragma unroll
+					for (int k = 0; k < 16; ++k)
+						if (r + k < max_rows) extp_step<LANES, CPL, RGT, false, LIVE>(K, r + k, L, rows, st, tn, q, e, q2, e2, colmask, T, Q, H1, H2, E, E2, F, F2, best, bestR, nbH, nbF, nbF2, acc[k >> 1], k);
+				}
+#pragma unroll
+				for (int k = 0; k < CPL; ++k)
+					pblk[2 * k] = make_uint4(acc[0][k], acc[1][k], acc[2][k], acc[3][k]), pblk[2 * k + 1] = make_uint4(acc[4][k], acc[5][k], acc[6][k], acc[7][k]);
+				// ---- can the Z-drop fire before the next check?  best so far against this anti-diagonal's maximum
+				const int rl = r + 15 < max_rows - 1 ? r + 15 : max_rows - 1;
+				int gv = -(1 << 20), av = -(1 << 20);
+#pragma unroll
+				for (int k = 0; k < CPL; ++k)
+#pragma unroll
+					for (int h = 0; h < 2; ++h) {
+						const int c = 2 * CPL * L + 2 * k + h;
+						if (c < m) {
+							const int bv = pk_half(best[k], h) >> 4, hv = pk_half(H1[k], h) >> 4;
+							gv = gv > bv ? gv : bv;
+							if ((unsigned)(rl - c) < (unsigned)n) av = av > hv ? av : hv;
+						}
+					}
+				gv = seg_max_i32<LANES>(gv) - K.bias, av = seg_max_i32<LANES>(av) - K.bias;
+				gv = gv > 0 ? gv : 0;
+				if (ok && g.zdrop >= 0 && rl < rows && gv - av > g.zdrop - slack) suspect = true;
+			}
+			// ---- the best cell: the first step that reached the best score, then the SSE scan's order on that step
+			int ez_max = 0, ez_max_t = -1, ez_max_q = -1, ez_mqe = DP_NEG_INF, ez_mqe_t = -1;
+			{
+				int gb = -(1 << 20);
+#pragma unroll
+				for (int k = 0; k < CPL; ++k)
+#pragma unroll
+					for (int h = 0; h < 2; ++h) { const int bv = pk_half(best[k], h); if (2 * CPL * L + 2 * k + h < m && bv > gb) gb = bv; }
+				gb = seg_max_i32<LANES>(gb);
+				const int gmax = (gb >> 4) - K.bias;
+				if (ok && gmax > 0) {
+					unsigned rmin = 0xffffffffu;
+#pragma unroll
+					for (int k = 0; k < CPL; ++k)
+#pragma unroll
+						for (int h = 0; h < 2; ++h)
+							if (2 * CPL * L + 2 * k + h < m && pk_half(best[k], h) == gb) { const unsigned rr = (h ? bestR[k] >> 16 : bestR[k] & 0xffffu); rmin = rmin < rr ? rmin : rr; }
+					rmin = seg_min_u32<LANES>(rmin);
+					const int rr = (int)rmin, st0 = rr - m + 1 > 0 ? rr - m + 1 : 0, en0 = rr < n - 1 ? rr : n - 1, en1 = st0 + (en0 - st0) / 4 * 4;
+					unsigned key = 0xffffffffu;
+#pragma unroll
+					for (int k = 0; k < CPL; ++k)
+#pragma unroll
+						for (int h = 0; h < 2; ++h) {
+							const int c = 2 * CPL * L + 2 * k + h;
+							if (c < m && pk_half(best[k], h) == gb && (h ? bestR[k] >> 16 : bestR[k] & 0xffffu) == rmin) {
+								const int t = rr - c;
+								const unsigned rank = t == en0 ? 0u : t < en1 ? 256u * (1u + ((unsigned)(t - st0) & 3u)) + ((unsigned)(t - st0) >> 2) : 256u * 5u + (unsigned)(t - en1);
+								const unsigned kk = rank << 10 | (unsigned)t;
+								key = key < kk ? key : kk;
+							}
+						}
+					key = seg_min_u32<LANES>(key);
+					ez_max = gmax, ez_max_t = (int)(key & 1023u), ez_max_q = rr - ez_max_t;
+				}
+				// the query's last row: cell m - 1
+				const int cm = ok ? m - 1 : 0, src = lead + cm / (2 * CPL), km = cm % (2 * CPL) / 2;
+				uint32_t bq = 0, bqr = 0;
+#pragma unroll
+				for (int k = 0; k < CPL; ++k) {
+					const uint32_t x = (uint32_t)__shfl((int)best[k], src), y = (uint32_t)__shfl((int)bestR[k], src);
+					if (k == km) bq = x, bqr = y;
+				}
+				if (ok) ez_mqe = (pk_half(bq, cm & 1) >> 4) - K.bias, ez_mqe_t = (int)((cm & 1) ? bqr >> 16 : bqr & 0xffffu) - cm;
+			}
+			if (leader && has) {
+				const int w = u * SEGS + sg;
+				int bi = -1, bj = -1, reach_end = 0;
+				if (ok && !suspect) {
+					if (ez_mqe + B.end_bonus > ez_max) reach_end = 1, bi = ez_mqe_t, bj = m - 1;
+					else if (ez_max_t >= 0 && ez_max_q >= 0) bi = ez_max_t, bj = ez_max_q;
+				}
+				s_n[w] = n, s_m[w] = m, s_bi[w] = bi, s_bj[w] = bj, s_si[w] = (int32_t)si, s_keep[w] = (g.flag & EZ_REV_CIGAR) != 0;
+				s_max[w] = ez_max, s_maxt[w] = ez_max_t, s_maxq[w] = ez_max_q, s_mqet[w] = ez_mqe_t, s_reach[w] = reach_end;
+				s_state[w] = ok && !suspect ? 1 : 2;
+			}
+			fill_order();
+		}
+		fill_order_mem();                                      // the direction bytes are in memory before the walks read them
+		// ================================================ one walk per lane
+		int state_w = lane < g_eff * SEGS ? s_state[lane] : 0;
+		const int n = s_n[lane], m = s_m[lane];
+		const long long si = s_si[lane];
+		int n_c = 0;
+		if (state_w == 1) {
+			const uint8_t *pu = p_wave + (size_t)(lane / SEGS) * PASS_BYTES;
+			const int slot = lane % SEGS;
+			int bi = s_bi[lane], bj = s_bj[lane], state = 0, cid = -1;
+			uint32_t cur = 0;
+			bool walking = bi >= 0 && bj >= 0, bad = false;
+			while (walking && bi >= 0 && bj >= 0) {
+				const int r = bi + bj;
+				const int c = ((r >> 4) * 64 + slot * LANES + bj / (2 * CPL)) * CPL + bj % (2 * CPL) / 2;
+				if (c != cid) {
+					const uint4 *src = reinterpret_cast<const uint4*>(pu + (size_t)c * 32);
+					const uint4 v0 = src[0], v1 = src[1];
+					*reinterpret_cast<uint4*>(&s_chunk[lane][0]) = v0, *reinterpret_cast<uint4*>(&s_chunk[lane][16]) = v1;
+					cid = c;
+				}
+				const uint32_t raw = s_chunk[lane][(r & 15) * 2 + (bj & 1)], tag = raw >> 4;
+				if (RGT) {
+					if (state != 0 && !(raw >> (state - 1) & 1u)) state = 0;     // not extended here: opened
+					if (state == 0) state = tag == 0u ? 0 : tag == 1u ? 1 : tag == 3u ? 2 : tag == 7u ? 3 : 4;
+				} else {
+					if (state != 0 && (raw >> (4 - state) & 1u)) state = 0;
+					if (state == 0) state = tag >= 8u ? 0 : tag == 7u ? 1 : tag == 3u ? 2 : tag == 1u ? 3 : 4;
+				}
+				uint32_t op;
+				if (state == 0) op = 0, --bi, --bj;
+				else if (state == 1 || state == 3) op = 2, --bi;
+				else op = 1, --bj;
+				if (cur != 0 && (cur & 0xf) == op) cur += 1u << 4;
+				else {
+					if (cur != 0) {
+						if (n_c >= EXTP_CIG_MAX - 4) { bad = true; break; }
+						cg[n_c++] = cur;
+					}
+					cur = 1u << 4 | op;
+				}
+			}
+			if (bad) state_w = 2;
+			else if (walking) {
+				if (bi >= 0) { if (cur != 0 && (cur & 0xf) == 2) cur += (uint32_t)(bi + 1) << 4; else { if (cur != 0) cg[n_c++] = cur; cur = (uint32_t)(bi + 1) << 4 | 2; } }
+				if (bj >= 0) { if (cur != 0 && (cur & 0xf) == 1) cur += (uint32_t)(bj + 1) << 4; else { if (cur != 0) cg[n_c++] = cur; cur = (uint32_t)(bj + 1) << 4 | 1; } }
+				if (cur != 0) cg[n_c++] = cur;
+			}
+		}
+		fill_order_mem();                                      // a lane reads its CIGAR back below
+		if (state_w == 2) {
+			// to the step-by-step kernel, by the length of its anti-diagonals
+			const int mn = n < m ? n : m;
+			const int ci = mn <= 32 ? 16 : mn <= 64 ? 17 : mn <= 128 ? 24 : 25;
+			int32_t *lst = mn <= 32 ? B.ext_list1 : mn <= 64 ? B.ext_list2 : mn <= 128 ? B.ext_list3 : B.ext_list4;
+			if (mn <= 256) { const unsigned long long k = atomicAdd(&B.dp_ctr[ci], 1ULL); lst[k] = (int32_t)si; }
+			else { const unsigned long long k = atomicAdd(&B.dp_ctr[12], 1ULL); B.fill_fb[k] = (int32_t)si; }
+		}
+		{
+			const int mine = state_w == 1 ? n_c : 0;
+			int incl = mine;
+#pragma unroll
+			for (int sft = 1; sft < 64; sft <<= 1) { const int o = __shfl_up(incl, sft); if (lane >= sft) incl += o; }
+			const int total = __shfl(incl, 63);
+			unsigned long long base = 0;
+			if (lane == 0 && total > 0) base = atomicAdd(&B.dp_ctr[1], (unsigned long long)total);
+			base = (unsigned long long)__shfl((long long)base, 0);
+			const bool over = (long long)(base + total) > B.cig_seg_cap;
+			if (over && lane == 0) atomicMax(&B.dp_ctr[4], 2ULL);
+			if (state_w == 1) {
+				const unsigned long long off = base + (unsigned long long)(incl - mine);
+				// ksw_backtrack leaves the CIGAR last operation first; KSW_EZ_REV_CIGAR keeps that order
+				const bool keep = s_keep[lane] != 0;
+				if (!over) for (int k = 0; k < n_c; ++k) B.cig_seg[off + k] = cg[keep ? k : n_c - 1 - k];
+				Seg *o = B.segs + si;
+				o->n_cigar = over ? 0 : n_c, o->zdropped = 0, o->zdrop_code = 0;
+				o->max = s_max[lane], o->max_t = s_maxt[lane], o->max_q = s_maxq[lane], o->score = DP_NEG_INF, o->reach_end = s_reach[lane], o->mqe_t = s_mqet[lane];
+				o->cig_off = (int64_t)off;
+			}
+		}
+		fill_order_mem();
+	}
+}
+
+size_t dp_extp_slot() { return (size_t)EXTP_G * FILLP_BLOCKS * 64 * 32 * 2; }
+size_t dp_extp_cig_slot() { return (size_t)64 * EXTP_CIG_MAX * 4; }
+// `cells`: 32 / 64 / 128 / 256 query bases at most; rgt: the left extensions (gaps right-aligned)
+void launch_dp_extp(const Batch &B, int cells, int rgt, const int32_t *list, int ctr_n, int ctr_q, uint8_t *p_all, uint32_t *cig_all, int n_wg, hipStream_t st)
+{
+#define MNC_EXTP(LN, CP) do { if (rgt) hipLaunchKernelGGL((mnc_dp_extp<LN, CP, 1>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, p_all, cig_all); \
+	else hipLaunchKernelGGL((mnc_dp_extp<LN, CP, 0>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, p_all, cig_all); } while (0)
+	if (cells == 32) MNC_EXTP(16, 1);
+	else if (cells == 64) MNC_EXTP(32, 1);
+	else if (cells == 128) MNC_EXTP(64, 1);
+	else MNC_EXTP(64, 2);
+#undef MNC_EXTP
+}
+
 size_t dp_fill_p_slot() { return FILL_P_SLOT; }
 size_t dp_fillp_slot() { return FILLP_SLOT; }
 size_t dp_fillp_cig_slot() { return (size_t)64 * FILL_CIG_MAX * 4; }
