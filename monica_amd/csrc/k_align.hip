@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 			d.n_seg = 0, d.has_left = d.has_right = 0;
 		} else {
 			Seg *sg = B.segs + s0;
-			int n_tier[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+			int n_tier[17] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 			auto emit = [&](Seg g) {
 				g.read = (int32_t)rd, g.reg = (int32_t)rslot, g.rid = rid, g.rev = rev;
 				g.n_cigar = 0, g.zdropped = 0, g.zdrop_code = 0, g.max = 0, g.max_t = g.max_q = -1, g.score = DP_NEG_INF, g.reach_end = 0, g.mqe_t = -1, g.cig_off = 0;
@@ -346,8 +346,11 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 					const int tier = mn <= 32 ? 3 : mn <= 64 ? 4 : mn <= 128 ? 7 : 8;
 					g.big = 3 + tier, ++n_tier[tier - 1];
 				}
-				if (g.big == 0) {                                          // the literal kernel's first pass
-					g.big = 8, ++n_tier[4];
+				if (g.big == 0) {
+					// the literal kernel: its first pass with everything in LDS, or from the start on its own list
+					const bool all_lds = 12 * T + Q <= B.lds0_state && p_bytes <= B.lds0_p && g.qlen + g.tlen + 2 <= B.lds0_cig;
+					if (all_lds) g.big = 8, ++n_tier[4];
+					else g.big = 20, ++n_tier[16];
 				}
 				*sg++ = g;
 			};
@@ -378,11 +381,11 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 				emit(g);
 			}
 			// the banded kernel's lists: one reservation per region and tier
-			for (int tier = 0; tier < 16; ++tier) {
+			for (int tier = 0; tier < 17; ++tier) {
 				if (n_tier[tier] == 0) continue;
-				const int ci = tier >= 8 ? 24 + tier : tier < 2 ? 10 + tier : tier < 4 ? 14 + tier : tier == 4 ? 20 : tier == 5 ? 22 : 18 + tier;   // 6 -> 24, 7 -> 25; 8.. -> 32..
+				const int ci = tier == 16 ? 28 : tier >= 8 ? 24 + tier : tier < 2 ? 10 + tier : tier < 4 ? 14 + tier : tier == 4 ? 20 : tier == 5 ? 22 : 18 + tier;   // 6 -> 24, 7 -> 25; 8.. -> 32..
 				unsigned long long fi = atomicAdd(&B.dp_ctr[ci], (unsigned long long)n_tier[tier]);
-				int32_t *lst = tier >= 8 ? B.extp_list + (int64_t)(tier - 8) * B.seg_cap
+				int32_t *lst = tier == 16 ? B.mid_list : tier >= 8 ? B.extp_list + (int64_t)(tier - 8) * B.seg_cap
 				             : tier == 0 ? B.fill_list1 : tier == 1 ? B.fill_list2 : tier == 2 ? B.ext_list1 : tier == 3 ? B.ext_list2 : tier == 4 ? B.gen_list
 				             : tier == 5 ? B.fill_list3 : tier == 6 ? B.ext_list3 : B.ext_list4;
 				for (int k = 0; k < n_seg; ++k)
@@ -749,16 +752,16 @@ __global__ __launch_bounds__(64) void mnc_dp_align(Batch B, uint8_t *ws_all, lon
 	const AlignWs W = align_ws(state_max, p_max, cig_max);
 	uint8_t *ws = ws_all + (size_t)blockIdx.x * W.total;
 	const int sc_mch = B.sc_a, sc_mis = -B.sc_b, sc_N = -B.sc_ambi;
-	// pass 0: the segments of the round that are neither large nor another kernel's; 1: the large
-	// ones; 2: what the banded kernel handed back
-	const unsigned long long n_items = big_pass == 0 ? B.dp_ctr[20] : big_pass == 1 ? B.dp_ctr[6] : B.dp_ctr[12];
-	const int ctr_q = big_pass == 0 ? 21 : big_pass == 1 ? 7 : 15;
+	// pass 0: the segments of the round that are neither large nor another kernel's and fit the LDS
+	// layout; 3: those that do not; 1: the large ones; 2: what the banded kernels handed back
+	const unsigned long long n_items = big_pass == 0 ? B.dp_ctr[20] : big_pass == 1 ? B.dp_ctr[6] : big_pass == 3 ? B.dp_ctr[28] : B.dp_ctr[12];
+	const int ctr_q = big_pass == 0 ? 21 : big_pass == 1 ? 7 : big_pass == 3 ? 29 : 15;
 	for (;;) {
 		unsigned long long qi = 0;
 		if (lane == 0) qi = atomicAdd(&B.dp_ctr[ctr_q], 1ULL);
 		qi = (unsigned long long)__shfl((long long)qi, 0);
 		if (qi >= n_items) break;                              // every wave reaches this: the queue is finite
-		const long long si = big_pass == 0 ? (long long)B.gen_list[qi] : big_pass == 1 ? (long long)B.big_list[qi] : (long long)B.fill_fb[qi];
+		const long long si = big_pass == 0 ? (long long)B.gen_list[qi] : big_pass == 1 ? (long long)B.big_list[qi] : big_pass == 3 ? (long long)B.mid_list[qi] : (long long)B.fill_fb[qi];
 		Seg g = B.segs[si];
 		Ez ez;
 		ez.max = 0, ez.zdropped = 0, ez.max_q = ez.max_t = ez.mqe_t = -1, ez.mqe = ez.score = DP_NEG_INF, ez.reach_end = 0, ez.n_cigar = 0;
