@@ -182,10 +182,54 @@ def main():
                        "steps": n_cl, "decisions_equal_to_dp": round(float((a_chain == assign).mean()), 5)}
         engine.set_contract(_capi.CONTRACT_DP)
 
+    # the alignment kernels one at a time (they share the chip in the timed steps): HIP events around
+    # each launch, on the stream it runs on -- the dominant kernel's own duration for `roofline`
+    dp_kernel_ms = None
+    if args.contract == "dp" and world == 1:
+        base_debug = int(os.environ.get("MNC_FILL_PRED", "0")) << 8
+        engine.set_debug(base_debug | 0x10000)
+        engine.set_profiling(True)
+        engine.timings(reset=True)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        tk = engine.timings()
+        engine.set_profiling(False)
+        engine.set_debug(base_debug | (0x10000 if os.environ.get("MNC_DP_SERIAL") else 0))
+        dp_kernel_ms = {k: tk[k][0] / max(tk[k][1], 1) for k in ("dp_fill_t1", "dp_fill_t2", "dp_fill_t3", "dp_ext", "dp_stitch") if k in tk}
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
+
+    # ---------------------------------------------------------------- roofline of the dominant kernel
+    # With base-level alignment the batch is bound by the gap-filling kernel mnc_dp_fillp<16> (32-cell
+    # band): 16-bit pair arithmetic on the vector ALU, neither HBM nor MFMA.  Its roof is the vector
+    # issue rate of the instructions it is made of (v_pk_max/add/sub_i16, v_perm, v_alignbit, DPP moves):
+    # one wave64 instruction per 4 cycles and SIMD, measured with 8 waves per SIMD by
+    # tools/micro/valu_rate.hip (profiles/r02_valu_issue_rates.json: 4.1-4.2 cycles; the guide's 2-cycle
+    # figure is v_fma_f32's) -> 256 CUs x 4 SIMDs x 2.4 GHz / 4.  One step of the kernel updates the 128
+    # band cells of a wave (4 segments x 32) in `FILLP_INSTR_PER_STEP` vector instructions (its ISA): the
+    # roof is that many cell updates/s.  Algorithmic work per launch = the anti-diagonals of the gap
+    # fillings given to this tier (counter dp_fill_steps_t1) x 32 cells.
+    VALU_PEAK = 256 * 4 * 2.4e9 / 4
+    FILLP_INSTR_PER_STEP = 597 / 16                      # vector instructions of the unrolled 16-step block (llvm-objdump)
+    roofline_dp = None
+    if dp_kernel_ms and dp_kernel_ms.get("dp_fill_t1", 0) > 0 and counters.get("dp_fill_steps_t1", 0) > 0:
+        cells = counters["dp_fill_steps_t1"] * 32
+        t_s = dp_kernel_ms["dp_fill_t1"] / 1e3
+        instr_per_cell = FILLP_INSTR_PER_STEP / 128
+        peak = VALU_PEAK / instr_per_cell / 1e9
+        ach = cells / t_s / 1e9
+        roofline_dp = {"bound": "valu", "kernel": "mnc_dp_fillp<16>", "achieved": round(ach, 2), "peak": round(peak, 1),
+                       "unit": "Gcell/s", "frac": round(ach / peak, 4), "traffic": None,
+                       "algorithmic_cells_per_launch": int(cells), "avg_launch_ms": round(dp_kernel_ms["dp_fill_t1"], 4),
+                       "vector_instructions_per_cell": round(instr_per_cell, 4),
+                       "bound_note": "int16 pair arithmetic on the vector ALU: the roof is the VALU issue rate (6.144e11 wave64 "
+                                     "instructions/s, measured: profiles/r02_valu_issue_rates.json), not HBM (the kernel writes 1 byte per cell: "
+                                     f"{cells / t_s / 1e9:.0f} GB/s) and not MFMA",
+                       "kernels_one_at_a_time_ms": {k: round(v, 4) for k, v in dp_kernel_ms.items()}}
 
     # ---------------------------------------------------------------- roofline of the probe kernel
     probe_ms, probe_n = timings["probe"]
@@ -301,7 +345,8 @@ def main():
                    "contract": "base-level alignment of every region (mappy's MM_F_CIGAR)" if args.contract == "dp" else "chain level",
                    "parallelism": f"read-sharded x{world}, index replicated, RCCL all-reduce of "
                                   f"{n_genomes * 3} int64 counts per step"},
-        "roofline": roofline,
+        "roofline": roofline_dp if roofline_dp else roofline,
+        "roofline_probe": roofline,
         "roofline_stage": roofline_stage,
         "cpu_baseline": cpu,
         "chain_level": chain_level,

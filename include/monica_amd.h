@@ -177,10 +177,16 @@ int mnc_best_hit(const mnc_hit_t *hits, int n, int *best_index /* -1 = ambiguous
 #define MNC_STAGE_DP_STITCH   13  /* CIGAR merge / clean-up, mlen, blen, dp_max, Z-drop split */
 #define MNC_STAGE_DP_POST     14  /* second hierarchy pass, DP MAPQ, gate, decision          */
 #define MNC_STAGE_DP_FILL     15  /* gap filling between seeds: banded two-piece affine DP       */
-#define MNC_N_STAGES          16
+#define MNC_STAGE_DP_FILL_T1  16  /* the next four only with debug bit 0x10000 (kernels one at a time):  */
+#define MNC_STAGE_DP_FILL_T2  17  /*   the banded gap-filling kernel's 32- / 64- / 128-cell launches     */
+#define MNC_STAGE_DP_FILL_T3  18
+#define MNC_STAGE_DP_EXT      19  /*   all the extension kernels                                         */
+#define MNC_N_STAGES          20
 int mnc_engine_set_profiling(mnc_engine *eng, int on);    /* HIP events around every stage */
 int mnc_engine_set_debug(mnc_engine *eng, int mode);      /* test switches, a bit mask: 2 stress build of the
-                                                             chaining ring, 4 displacement bytes read from HBM */
+                                                             chaining ring, 4 displacement bytes read from HBM,
+                                                             0x10000 the alignment kernels one at a time (per-kernel
+                                                             timers), bits 8-15 a tuning value for the tier choice */
 /* accumulated since the last reset: ms[MNC_N_STAGES], launches[MNC_N_STAGES] */
 int mnc_engine_get_timings(mnc_engine *eng, double *ms, int64_t *launches, int reset);
 const char *mnc_stage_name(int stage);
@@ -188,7 +194,9 @@ const char *mnc_stage_kernel(int stage);                  /* kernel symbol, for 
 /* counters of the last batch: [0] minimizers, [1] probe hits, [2] anchors, [3] chains,
  * [4] regions, [5] gated hits, [6] reads with ambiguous bases, [7] -; with n >= 12, of the base-level
  * alignment stage (last round): [8] kernel calls (segments), [9] gap fillings given to the banded kernel's
- * 32-lane tier, [10] those its 64-lane tier saw, [11] those it handed back to the literal kernel */
+ * 32-cell tier, [10] those its 64-cell tier saw, [11] those handed back to the literal kernel; with
+ * n >= 16: [12] / [13] / [14] anti-diagonals (steps) of the gap fillings the 32- / 64- / 128-cell tier
+ * ran, [15] anti-diagonal steps x query bases of the extensions given to the packed extension kernel */
 int mnc_engine_get_counters(mnc_engine *eng, int64_t *c, int n);
 
 /* stage dumps of the last batch, for kernel-level parity tests */

@@ -393,11 +393,11 @@ struct mnc_engine {
 };
 
 static const char *STAGE_NAME[MNC_N_STAGES] = { "pack", "sketch", "partition", "probe", "collect", "offsets", "sort", "chain", "backtrack", "regions", "gather",
-                                                "dp_plan", "dp_align", "dp_stitch", "dp_post", "dp_fill" };
+                                                "dp_plan", "dp_align", "dp_stitch", "dp_post", "dp_fill", "dp_fill_t1", "dp_fill_t2", "dp_fill_t3", "dp_ext" };
 static const char *STAGE_KERNEL[MNC_N_STAGES] = {
 	"mnc_pack_bases", "mnc_sketch_minimizers", "mnc_partition_queries", "mnc_probe_buckets", "mnc_collect_hits",
 	"mnc_bin_reads", "mnc_expand_sort", "mnc_chain_dp_ring", "mnc_chain_tail", "mnc_regions_decide", "mnc_gather_hits",
-	"mnc_dp_plan", "mnc_dp_align", "mnc_dp_stitch", "mnc_regions_post", "mnc_dp_fill" };
+	"mnc_dp_plan", "mnc_dp_align", "mnc_dp_stitch", "mnc_regions_post", "mnc_dp_fillp", "mnc_dp_fillp<16>", "mnc_dp_fillp<32>", "mnc_dp_fillp<64>", "mnc_dp_extp" };
 
 extern "C" const char *mnc_stage_name(int s) { return s >= 0 && s < MNC_N_STAGES ? STAGE_NAME[s] : nullptr; }
 extern "C" const char *mnc_stage_kernel(int s) { return s >= 0 && s < MNC_N_STAGES ? STAGE_KERNEL[s] : nullptr; }
@@ -601,15 +601,23 @@ struct StageTimer {
 //   s3  the few calls that need the large workspace
 static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream_t s1, hipStream_t s2, hipStream_t s3)
 {
+	// per-kernel timers: only when everything runs on one stream (debug bit 0x10000)
+	const bool timed = e->profiling && s0 == s1;
+	auto mark = [&](int stage, int which) { if (timed) { (void)hipEventRecord(e->ev[stage][which], s0); if (which) e->ev_used[stage] = true; } };
+	mark(MNC_STAGE_DP_FILL_T1, 0);
 	launch_dp_fill(B, 32, B.fill_list1, 10, 13, B.fill_list2, 11, B.fill_fb, 12, e->fill_p.as<uint8_t>(), e->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
+	mark(MNC_STAGE_DP_FILL_T1, 1), mark(MNC_STAGE_DP_FILL_T2, 0);
 	launch_dp_fill(B, 64, B.fill_list2, 11, 14, B.fill_list3, 22, B.fill_fb, 12, e->fill_p.as<uint8_t>(), e->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
+	mark(MNC_STAGE_DP_FILL_T2, 1), mark(MNC_STAGE_DP_FILL_T3, 0);
 	launch_dp_fill(B, 128, B.fill_list3, 22, 23, B.fill_fb, 12, B.fill_fb, 12, e->fill_p.as<uint8_t>(), e->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
+	mark(MNC_STAGE_DP_FILL_T3, 1), mark(MNC_STAGE_DP_EXT, 0);
 	for (int i = 0; i < 8; ++i)
 		launch_dp_extp(B, 32 << (i >> 1), i & 1, B.extp_list + (int64_t)i * B.seg_cap, 32 + i, 40 + i, e->extp_p.as<uint8_t>(), e->extp_cig.as<uint32_t>(), DP_WG_EXT, s1);
 	launch_dp_ext(B, 32, B.ext_list1, 16, 18, B.fill_fb, 12, e->ext_p.as<uint8_t>(), DP_WG_EXT, s1);
 	launch_dp_ext(B, 64, B.ext_list2, 17, 19, B.fill_fb, 12, e->ext_p.as<uint8_t>(), DP_WG_EXT, s1);
 	launch_dp_ext(B, 128, B.ext_list3, 24, 26, B.fill_fb, 12, e->ext_p.as<uint8_t>(), DP_WG_EXT / 2, s1);
 	launch_dp_ext(B, 256, B.ext_list4, 25, 27, B.fill_fb, 12, e->ext_p.as<uint8_t>(), DP_WG_EXT / 4, s1);
+	mark(MNC_STAGE_DP_EXT, 1);
 	// the literal kernel's lists known at planning time, beside the banded kernels (`s2`: the batch's own stream,
 	// idle between fork and join: the side streams share hardware queues among themselves)
 	launch_dp_align(B, e->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 1, s2);
@@ -1029,9 +1037,10 @@ extern "C" int mnc_engine_get_counters(mnc_engine *e, int64_t *c, int n)
 	c[2] = e->last_total_anchors;
 	c[7] = 0;
 	if (n >= 12 && B.contract == MNC_CONTRACT_DP && e->dp_ctr.p) {
-		unsigned long long d[16];
+		unsigned long long d[64];
 		HIP_TRY(hipMemcpy(d, e->dp_ctr.p, sizeof(d), hipMemcpyDeviceToHost));
 		c[8] = (int64_t)d[0], c[9] = (int64_t)d[10], c[10] = (int64_t)d[11], c[11] = (int64_t)d[12];
+		if (n >= 16) c[12] = (int64_t)d[48], c[13] = (int64_t)d[49], c[14] = (int64_t)d[50], c[15] = (int64_t)d[51];
 
 
 	}

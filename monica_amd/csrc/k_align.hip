@@ -289,6 +289,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 		} else {
 			Seg *sg = B.segs + s0;
 			int n_tier[17] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+			unsigned long long work[4] = { 0, 0, 0, 0 };             // anti-diagonals given to the banded tiers; steps x cells of the packed extensions
 			auto emit = [&](Seg g) {
 				g.read = (int32_t)rd, g.reg = (int32_t)rslot, g.rid = rid, g.rev = rev;
 				g.n_cigar = 0, g.zdropped = 0, g.zdrop_code = 0, g.max = 0, g.max_t = g.max_q = -1, g.score = DP_NEG_INF, g.reach_end = 0, g.mqe_t = -1, g.cig_off = 0;
@@ -333,12 +334,14 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 						if (bb < 8 || U * 25 > mn * 32) tier = 0;
 					}
 					if (tier) g.big = 3 + tier, ++n_tier[tier - 1];          // not for the literal kernel's first pass
+					if (tier) work[tier == 1 ? 0 : tier == 2 ? 1 : 2] += (unsigned long long)(g.tlen + g.qlen - 1);
 				} else if (g.big == 0 && g.kind != 1 && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= g.w && g.qlen <= g.w &&
 				           g.tlen + g.qlen - 1 <= 2 * FILL_MAX_LEN && g.qlen <= 256) {
 					// an extension whose matrix the band never clips, one cell per query base: the packed
 					// extension kernel of k_fill.hip (tiers 8..15: by query length, right / left)
 					const int tier = 8 + 2 * (g.qlen <= 32 ? 0 : g.qlen <= 64 ? 1 : g.qlen <= 128 ? 2 : 3) + ((g.flag & EZ_RIGHT) ? 1 : 0);
 					g.big = 4 + tier, ++n_tier[tier];
+					work[3] += (unsigned long long)(g.tlen + g.qlen - 1) * g.qlen;
 				} else if (g.big == 0 && g.kind != 1 && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= g.w && g.qlen <= g.w &&
 				           g.tlen + g.qlen - 1 <= 2 * FILL_MAX_LEN && (g.tlen < g.qlen ? g.tlen : g.qlen) <= 256) {
 					// ... or with anti-diagonals that fit a wave (up to four cells per lane): the step-by-step one
@@ -380,6 +383,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 				g.zdrop = B.zdrop, g.flag = EZ_EXTZ_ONLY, g.ai = cnt1 - 1;
 				emit(g);
 			}
+			for (int k = 0; k < 4; ++k) if (work[k]) atomicAdd(&B.dp_ctr[48 + k], work[k]);
 			// the banded kernel's lists: one reservation per region and tier
 			for (int tier = 0; tier < 17; ++tier) {
 				if (n_tier[tier] == 0) continue;
@@ -1250,7 +1254,8 @@ __global__ void mnc_dp_round(Batch B, int first)
 	B.dp_ctr[9] = B.dp_ctr[5];            // regions to plan / stitch this round
 	B.dp_ctr[5] = 0;
 	B.dp_ctr[6] = 0, B.dp_ctr[7] = 0;
-	for (int k = 10; k < 48; ++k) B.dp_ctr[k] = 0;   // banded kernel: list lengths 10 / 11 / 12 (tier 1, tier 2, handed back), queues 13 / 14 / 15;
+	for (int k = 10; k < 48; ++k) B.dp_ctr[k] = 0;
+	if (first) for (int k = 48; k < 52; ++k) B.dp_ctr[k] = 0;   // banded kernel: list lengths 10 / 11 / 12 (tier 1, tier 2, handed back), queues 13 / 14 / 15;
 	                                                 // extension kernel: lists 16 / 17, queues 18 / 19; literal kernel's first pass: list 20, queue 21; banded kernel, 128 cells: list 22, queue 23; extension kernel, 128 / 256 cells: lists 24 / 25, queues 26 / 27
 }
 __global__ void mnc_dp_round_end(Batch B)

@@ -393,6 +393,13 @@ __device__ __forceinline__ uint32_t pk_rep(int v) { return ((uint32_t)v & 0xffff
 __device__ __forceinline__ uint32_t pk_bfi(uint32_t mask, uint32_t x, uint32_t y) { return (x & mask) | (y & ~mask); }
 
 constexpr uint32_t PK_NEG = 0x80008000u;
+// x = tag(E) ^ tag(F) ^ tag(E2) ^ tag(F2) with tags 15 (opened) or 7 / 3 / 1 / 0: bit 0 = 1 ^ d, bit 1 = c ^ d,
+// bit 2 = 1 ^ b ^ c ^ d, bit 3 = a ^ b ^ c ^ d for a, b, c, d = "E, F, E2, F2 opened".  Returns a << 3 | b << 2 | c << 1 | d.
+__device__ __forceinline__ uint32_t fillp_opened(uint32_t x)
+{
+	const uint32_t d = (x & 1u) ^ 1u, c = (x >> 1 & 1u) ^ d, b = (x >> 2 & 1u) ^ 1u ^ c ^ d, a = (x >> 3 & 1u) ^ b ^ c ^ d;
+	return a << 3 | b << 2 | c << 1 | d;
+}
 constexpr uint32_t PK_TAG_H = 0x000f000fu, PK_TAG_E = 0x00070007u, PK_TAG_F = 0x00030003u, PK_TAG_E2 = 0x00010001u;   // F2: 0
 struct PkConst { uint32_t kmatch, kmis, q8, q28, e8, e28; int bias; };
 
@@ -454,9 +461,10 @@ __device__ __forceinline__ void fillp_step(const PkConst &K, const int r, const 
 	F = pk_subs(mF, K.e8) & 0xfff3fff3u;                       // 15 or 3 -> 3
 	E2 = pk_subs(mE2, K.e28) & 0xfff1fff1u;
 	F2 = pk_subs(mF2, K.e28) & 0xfff0fff0u;
-	// direction byte: bits 4-7 the winner's tag, bits 3 / 2 / 1 / 0 "E / F / E2 / F2 was opened"
-	uint32_t d = pk_bfi(0x00080008u, mE, pk_bfi(0x00040004u, mF, pk_bfi(0x00020002u, mE2, mF2 & 0x00010001u)));
-	d |= (z & 0x000f000fu) << 4;
+	// direction byte: bits 0-3 the winner's tag; bits 4-7 the XOR of the four gap states' tags (15 where a gap
+	// was opened, else 7 / 3 / 1 / 0 for E / F / E2 / F2), from which the walk solves the four "opened" bits:
+	// three cheap instructions instead of four field inserts (fillp_opened)
+	const uint32_t d = pk_bfi(0x000f000fu, z, (mE ^ mF ^ mE2 ^ mF2) << 4);
 	// two steps' direction bytes per register: (even step: cells 2 L, 2 L + 1; odd step: likewise)
 	acc = ODD ? __builtin_amdgcn_perm(d, acc, 0x06040100u) : __builtin_amdgcn_perm(d, d, 0x0c0c0200u);
 	Sc = r == rows_m1 ? zt : Sc;
@@ -617,9 +625,9 @@ __global__ __launch_bounds__(64) void mnc_dp_fillp(Batch B, const int32_t *list,
 					cid = c;
 				}
 				const uint32_t raw = s_chunk[lane][(r & 15) * 2 + (idx & 1)];
-				// bits 4-7: the winner's tag (H 15, E 7, F 3, E2 1, F2 0); bits 3 / 2 / 1 / 0: E / F / E2 / F2 was opened here
-				if (state != 0 && (raw >> (4 - state) & 1u)) state = 0;
-				if (state == 0) { const uint32_t tag = raw >> 4; state = tag >= 8u ? 0 : tag == 7u ? 1 : tag == 3u ? 2 : tag == 1u ? 3 : 4; }
+				// bits 0-3: the winner's tag (H 15, E 7, F 3, E2 1, F2 0); bits 4-7: which gap states were opened here (fillp_opened)
+				if (state != 0 && (fillp_opened(raw >> 4) >> (4 - state) & 1u)) state = 0;
+				if (state == 0) { const uint32_t tag = raw & 15u; state = tag >= 8u ? 0 : tag == 7u ? 1 : tag == 3u ? 2 : tag == 1u ? 3 : 4; }
 				uint32_t op;
 				if (state == 0) op = 0, --bi, --bj;
 				else if (state == 1 || state == 3) op = 2, --bi;
@@ -971,6 +979,13 @@ constexpr int EXTP_G = 16;
 constexpr int EXTP_CIG_MAX = 1024;
 constexpr int EXTP_ROWS = 2 * FILL_MAX_LEN;                 // n + m - 1 at most
 
+// right-aligned gaps: x = XOR of the tags 1 / 3 / 7 / 15 (E / F / E2 / F2 extended) or 0 (opened): bit 3 = d, bit 2 = c ^ d,
+// bit 1 = b ^ c ^ d, bit 0 = a ^ b ^ c ^ d.  Returns d << 3 | c << 2 | b << 1 | a ("extended" bits, E lowest).
+__device__ __forceinline__ uint32_t extp_extended(uint32_t x)
+{
+	const uint32_t d = x >> 3 & 1u, c = (x >> 2 & 1u) ^ d, b = (x >> 1 & 1u) ^ c ^ d, a = (x & 1u) ^ b ^ c ^ d;
+	return d << 3 | c << 2 | b << 1 | a;
+}
 template <int RGT> struct ExtpTag {
 	static constexpr uint32_t H = RGT ? 0u : 0x000f000fu, E = RGT ? 0x00010001u : 0x00070007u, F = 0x00030003u,
 	                          E2 = RGT ? 0x00070007u : 0x00010001u, F2 = RGT ? 0x000f000fu : 0u;
@@ -1039,12 +1054,12 @@ __device__ __forceinline__ void extp_step(const PkConst &K, const int r, const i
 		uint32_t d;
 		if (RGT) {
 			E[k] = pk_subs(mE, K.e8) | TG::E, F[k] = pk_subs(mF, K.e8) | TG::F, E2[k] = pk_subs(mE2, K.e28) | TG::E2, F2[k] = pk_subs(mF2, K.e28) | TG::F2;
-			d = pk_bfi(0x00010001u, mE, pk_bfi(0x00020002u, mF, pk_bfi(0x00040004u, mE2, mF2 & 0x00080008u)));   // "extended"
+			d = mE ^ mF ^ mE2 ^ mF2;                                // tags 1 / 3 / 7 / 15 where extended, 0 where opened: extp_extended
 		} else {
 			E[k] = pk_subs(mE, K.e8) & 0xfff7fff7u, F[k] = pk_subs(mF, K.e8) & 0xfff3fff3u, E2[k] = pk_subs(mE2, K.e28) & 0xfff1fff1u, F2[k] = pk_subs(mF2, K.e28) & 0xfff0fff0u;
-			d = pk_bfi(0x00080008u, mE, pk_bfi(0x00040004u, mF, pk_bfi(0x00020002u, mE2, mF2 & 0x00010001u)));   // "opened"
+			d = mE ^ mF ^ mE2 ^ mF2;                                // fillp_opened
 		}
-		d |= (z & 0x000f000fu) << 4;
+		d = pk_bfi(0x000f000fu, z, d << 4);                          // bits 0-3 the winner's tag, bits 4-7 the XOR
 		acc[k] = (odd & 1) ? __builtin_amdgcn_perm(d, acc[k], 0x06040100u) : __builtin_amdgcn_perm(d, d, 0x0c0c0200u);
 		// every cell's best H and the step it first reached it
 		const uint32_t zl = LIVE ? (r < rows ? zt : PK_NEG) : zt;
@@ -1278,12 +1293,12 @@ __global__ __launch_bounds__(64) void mnc_dp_extp(Batch B, const int32_t *list, 
 					*reinterpret_cast<uint4*>(&s_chunk[lane][0]) = v0, *reinterpret_cast<uint4*>(&s_chunk[lane][16]) = v1;
 					cid = c;
 				}
-				const uint32_t raw = s_chunk[lane][(r & 15) * 2 + (bj & 1)], tag = raw >> 4;
+				const uint32_t raw = s_chunk[lane][(r & 15) * 2 + (bj & 1)], tag = raw & 15u;
 				if (RGT) {
-					if (state != 0 && !(raw >> (state - 1) & 1u)) state = 0;     // not extended here: opened
+					if (state != 0 && !(extp_extended(raw >> 4) >> (state - 1) & 1u)) state = 0;     // not extended here: opened
 					if (state == 0) state = tag == 0u ? 0 : tag == 1u ? 1 : tag == 3u ? 2 : tag == 7u ? 3 : 4;
 				} else {
-					if (state != 0 && (raw >> (4 - state) & 1u)) state = 0;
+					if (state != 0 && (fillp_opened(raw >> 4) >> (4 - state) & 1u)) state = 0;
 					if (state == 0) state = tag >= 8u ? 0 : tag == 7u ? 1 : tag == 3u ? 2 : tag == 1u ? 3 : 4;
 				}
 				uint32_t op;

@@ -1,0 +1,59 @@
+// Issue rate of the vector instructions the alignment kernels are made of, on gfx950: cycles per wave64
+// instruction and SIMD with 1, 2, 4, 8 waves per SIMD.  hipcc --offload-arch=gfx950 -O3 valu_rate.hip -o valu_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+
+#define REP16(x) x x x x x x x x x x x x x x x x
+template <int OP>
+__global__ __launch_bounds__(64) void k(uint32_t *out, int iters, uint32_t seed)
+{
+	uint32_t a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+	const uint32_t b = seed * 2654435761u | 0x00010001u;
+	for (int i = 0; i < iters; ++i) {
+#define ONE(INS) asm volatile(INS : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+		if (OP == 0) { REP16(ONE("v_add_u32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_add_u32 %3, %3, %8\n v_add_u32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_add_u32 %7, %7, %8")) }
+		if (OP == 1) { REP16(ONE("v_pk_max_i16 %0, %0, %8\n v_pk_max_i16 %1, %1, %8\n v_pk_max_i16 %2, %2, %8\n v_pk_max_i16 %3, %3, %8\n v_pk_max_i16 %4, %4, %8\n v_pk_max_i16 %5, %5, %8\n v_pk_max_i16 %6, %6, %8\n v_pk_max_i16 %7, %7, %8")) }
+		if (OP == 2) { REP16(ONE("v_pk_add_i16 %0, %0, %8 clamp\n v_pk_add_i16 %1, %1, %8 clamp\n v_pk_add_i16 %2, %2, %8 clamp\n v_pk_add_i16 %3, %3, %8 clamp\n v_pk_add_i16 %4, %4, %8 clamp\n v_pk_add_i16 %5, %5, %8 clamp\n v_pk_add_i16 %6, %6, %8 clamp\n v_pk_add_i16 %7, %7, %8 clamp")) }
+		if (OP == 3) { REP16(ONE("v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %1, %1, %8, %8\n v_fma_f32 %2, %2, %8, %8\n v_fma_f32 %3, %3, %8, %8\n v_fma_f32 %4, %4, %8, %8\n v_fma_f32 %5, %5, %8, %8\n v_fma_f32 %6, %6, %8, %8\n v_fma_f32 %7, %7, %8, %8")) }
+		if (OP == 4) { REP16(ONE("v_perm_b32 %0, %0, %8, %8\n v_perm_b32 %1, %1, %8, %8\n v_perm_b32 %2, %2, %8, %8\n v_perm_b32 %3, %3, %8, %8\n v_perm_b32 %4, %4, %8, %8\n v_perm_b32 %5, %5, %8, %8\n v_perm_b32 %6, %6, %8, %8\n v_perm_b32 %7, %7, %8, %8")) }
+		if (OP == 5) { REP16(ONE("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %4, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %6, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %6 row_shr:1 row_mask:0xf bank_mask:0xf")) }
+		if (OP == 6) { REP16(ONE("v_and_b32 %0, %0, %8\n v_or_b32 %1, %1, %8\n v_and_b32 %2, %2, %8\n v_or_b32 %3, %3, %8\n v_alignbit_b32 %4, %4, %8, 16\n v_alignbit_b32 %5, %5, %8, 16\n v_xor_b32 %6, %6, %8\n v_xor_b32 %7, %7, %8")) }
+		if (OP == 7) { REP16(ONE("v_pk_fma_f16 %0, %0, %8, %8\n v_pk_fma_f16 %1, %1, %8, %8\n v_pk_fma_f16 %2, %2, %8, %8\n v_pk_fma_f16 %3, %3, %8, %8\n v_pk_fma_f16 %4, %4, %8, %8\n v_pk_fma_f16 %5, %5, %8, %8\n v_pk_fma_f16 %6, %6, %8, %8\n v_pk_fma_f16 %7, %7, %8, %8")) }
+		if (OP == 8) { REP16(ONE("v_max_i32 %0, %0, %8\n v_max_i32 %1, %1, %8\n v_max_i32 %2, %2, %8\n v_max_i32 %3, %3, %8\n v_max_i32 %4, %4, %8\n v_max_i32 %5, %5, %8\n v_max_i32 %6, %6, %8\n v_max_i32 %7, %7, %8")) }
+		if (OP == 9) { REP16(ONE("v_pk_mad_u16 %0, %0, %8, %8\n v_pk_mad_u16 %1, %1, %8, %8\n v_pk_mad_u16 %2, %2, %8, %8\n v_pk_mad_u16 %3, %3, %8, %8\n v_pk_mad_u16 %4, %4, %8, %8\n v_pk_mad_u16 %5, %5, %8, %8\n v_pk_mad_u16 %6, %6, %8, %8\n v_pk_mad_u16 %7, %7, %8, %8")) }
+		if (OP == 10) { REP16(ONE("v_max_f32 %0, %0, %8\n v_max_f32 %1, %1, %8\n v_max_f32 %2, %2, %8\n v_max_f32 %3, %3, %8\n v_max_f32 %4, %4, %8\n v_max_f32 %5, %5, %8\n v_max_f32 %6, %6, %8\n v_max_f32 %7, %7, %8")) }
+		if (OP == 11) { REP16(ONE("v_pk_max_f16 %0, %0, %8\n v_pk_max_f16 %1, %1, %8\n v_pk_max_f16 %2, %2, %8\n v_pk_max_f16 %3, %3, %8\n v_pk_max_f16 %4, %4, %8\n v_pk_max_f16 %5, %5, %8\n v_pk_max_f16 %6, %6, %8\n v_pk_max_f16 %7, %7, %8")) }
+	}
+	out[blockIdx.x * 64 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+}
+
+template <int OP> double run(uint32_t *d, int waves_per_simd, int iters)
+{
+	const int n_wg = 256 * 4 * waves_per_simd;
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0), hipEventCreate(&e1);
+	hipLaunchKernelGGL(k<OP>, dim3(n_wg), dim3(64), 0, 0, d, 10, 1u);
+	hipDeviceSynchronize();
+	hipEventRecord(e0, 0);
+	hipLaunchKernelGGL(k<OP>, dim3(n_wg), dim3(64), 0, 0, d, iters, 1u);
+	hipEventRecord(e1, 0);
+	hipEventSynchronize(e1);
+	float ms = 0;
+	hipEventElapsedTime(&ms, e0, e1);
+	const double instr_per_simd = (double)waves_per_simd * iters * 16 * 8;
+	return ms * 1e-3 * 2.4e9 / instr_per_simd;            // cycles per wave64 instruction and SIMD, at 2.4 GHz
+}
+
+int main()
+{
+	uint32_t *d;
+	hipMalloc(&d, 256 * 4 * 8 * 64 * 4);
+	const char *names[] = { "v_add_u32", "v_pk_max_i16", "v_pk_add_i16 clamp", "v_fma_f32", "v_perm_b32", "v_mov_b32_dpp row_shr:1", "and/or/alignbit/xor mix", "v_pk_fma_f16", "v_max_i32", "v_pk_mad_u16", "v_max_f32", "v_pk_max_f16" };
+	printf("{\n");
+#define ROW(OP) printf(" \"%s\": {\"1\": %.2f, \"2\": %.2f, \"4\": %.2f, \"8\": %.2f}%s\n", names[OP], run<OP>(d, 1, 4000), run<OP>(d, 2, 4000), run<OP>(d, 4, 2000), run<OP>(d, 8, 1000), OP == 11 ? "" : ",");
+	ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(5) ROW(6) ROW(7) ROW(8) ROW(9) ROW(10) ROW(11)
+	printf("}\n");
+	return 0;
+}

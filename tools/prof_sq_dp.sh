@@ -1,7 +1,8 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r02sq}
-for c in "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD"; do
+export MNC_DP_SERIAL=1
+for c in "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" "SQ_INST_CYCLES_VMEM SQ_WAVE_CYCLES"; do
   tag=$(echo $c | tr ' ' '_')
   timeout 300 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/sq_${TAG}_$tag -o out --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-sample 0 > $R/gpurun_out/sq_${TAG}_$tag.log 2>&1
 done
