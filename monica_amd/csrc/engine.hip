@@ -45,7 +45,7 @@ size_t dp_align_ws_bytes(long long state_max, long long p_max, long long cig_max
 int dp_align_prepare(int lds_bytes);
 void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max, long long p_max, long long cig_max,
                      int lds_state, int lds_p, int lds_cig, int big_pass, hipStream_t st);
-void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_list, int n_wg, hipStream_t st);
+void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_list, int max_read_len, int n_wg, hipStream_t st);
 size_t dp_fill_p_slot();
 size_t dp_fillp_slot();
 size_t dp_fillp_cig_slot();
@@ -378,6 +378,7 @@ struct mnc_engine {
 	Buf ca, ca_cnt, chain_dst, regdp, segs, cig_seg, cig_reg, dp_ctr, work_a, work_b, big_list, reg_cnt, regs2, dp_ws, dp_ws_big;
 	Buf fill1, fill2, fill3, fill_fb, fill_p, fill_cig, extp, extp_p, extp_cig, mid_list, dp_ws_mid, ext1, ext2, ext3, ext4, ext_p, gen_list;
 	size_t seg_cap_override = 0, cig_cap_override = 0;
+	int cur_max_read_len = 0;                // of the batch being classified (sizes the stitch kernel's LDS)
 	int debug = 0;                           // bit mask (tests): 2 stress build of the chaining ring, 4 displacement bytes read from HBM, 0x10000 alignment kernels one at a time (with stage timers)
 	// last batch
 	Batch B{};
@@ -884,7 +885,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 					StageTimer t(e, MNC_STAGE_DP_ALIGN);
 					align_rest(B, e, st);
 				}
-				{ StageTimer t(e, MNC_STAGE_DP_STITCH); launch_dp_stitch(B, work, next, 4096, st); }
+				{ StageTimer t(e, MNC_STAGE_DP_STITCH); launch_dp_stitch(B, work, next, e->cur_max_read_len > 0 ? e->cur_max_read_len : 8192, 4096, st); }
 			} else {
 				launch_dp_plan(B, work, max_work, (int)DP_STATE_SMALL, DP_P_SMALL, (int)DP_CIG_SMALL, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, st);
 				if (int rcf = fork()) return rcf;
@@ -892,7 +893,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 				else align_round(B, e, e->side[0], e->side[1], st, e->side[3]);
 				if (int rcj = join()) return rcj;
 				align_rest(B, e, st);
-				launch_dp_stitch(B, work, next, 4096, st);
+				launch_dp_stitch(B, work, next, e->cur_max_read_len > 0 ? e->cur_max_read_len : 8192, 4096, st);
 			}
 			launch_dp_round_end(B, st);
 			// Z-drop splits make new regions for the next round (rare); one small read-back per round
@@ -937,6 +938,7 @@ extern "C" int mnc_classify_device(mnc_engine *e, const uint8_t *d_bases, const 
 		return MNC_OK;
 	}
 	bool overflowed = false;
+	e->cur_max_read_len = max_read_len;
 	int rc = classify_once(e, d_bases, d_offsets, n_reads, total_bases, min_mapq, d_assign, d_best, d_nhits, d_counts, &overflowed);
 	if (!rc && overflowed)                          // denser sketch than budgeted: redo with exact room
 		rc = classify_once(e, d_bases, d_offsets, n_reads, total_bases, min_mapq, d_assign, d_best, d_nhits, d_counts, &overflowed);

@@ -873,9 +873,9 @@ __device__ __forceinline__ void dpp_scan_maps(int &a, int &b)
 // ================================================================ stitch: one region (the rest of mm_align1 + mm_update_extra)
 // LDS: the region's query and target codes (when they fit), the joined CIGAR is built in the
 // region pool.  One wave per region; lane 0 does the sequential bookkeeping, all lanes the walks.
-constexpr int ST_SEQ_MAX = 8 * 1024;                        // bytes of LDS per sequence
-constexpr int ST_CIG_MAX = 2048;                            // CIGAR words in LDS
-constexpr int ST_EV_MAX = 4096;                             // score events buffered for one scan
+constexpr int ST_CIG_MAX = 1024;                            // CIGAR words in LDS
+constexpr int ST_EV_MAX = 2048;                             // score events (one byte each) buffered for one scan
+constexpr int ST_EV_LIM = 127;                              // a gap that costs more is applied directly
 
 __device__ __forceinline__ void append_op(uint32_t *c, int &n, uint32_t word)
 {
@@ -883,11 +883,14 @@ __device__ __forceinline__ void append_op(uint32_t *c, int &n, uint32_t word)
 	else c[n++] = word;
 }
 
-__global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work_list, int32_t *next_list)
+__global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work_list, int32_t *next_list, int seq_q_max, int seq_t_max)
 {
-	__shared__ uint8_t s_q[ST_SEQ_MAX], s_t[ST_SEQ_MAX];
-	__shared__ uint32_t s_c[ST_CIG_MAX];
-	__shared__ int16_t s_d[ST_EV_MAX];
+	// LDS (dynamic: the sequences are sized for the batch's longest read, so that many regions share a CU):
+	// [joined CIGAR | score events | query codes | target codes]
+	extern __shared__ __align__(16) uint8_t st_smem[];
+	uint32_t *s_c = reinterpret_cast<uint32_t*>(st_smem);
+	int8_t *s_d = reinterpret_cast<int8_t*>(st_smem + ST_CIG_MAX * 4);
+	uint8_t *s_q = st_smem + ST_CIG_MAX * 4 + ST_EV_MAX, *s_t = s_q + seq_q_max;
 	const int lane = threadIdx.x;
 	const unsigned long long n_work = B.dp_ctr[9];
 	for (unsigned long long wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
@@ -903,9 +906,22 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 		const int rid = (int32_t)(a[r.as].x << 1 >> 33), rev = (int32_t)(a[r.as].x >> 63);
 		const int64_t coff = B.seq_off[rid];
 		const Seg *sg = B.segs + d.first_seg;
-		// ---- how many CIGAR words can the region need: all its segments', joined
+		// ---- which segments are joined: all of them, or up to the first gap filling that Z-dropped; how many
+		// CIGAR words that is at most.  One segment per lane, 64 at a time.
+		const int n_fill = d.n_seg - d.has_left - d.has_right;
+		int stop = d.n_seg;
+		bool dropped = false;
 		long long total = 0;
-		for (int k = 0; k < d.n_seg; ++k) total += sg[k].n_cigar;
+		for (int k0 = 0; k0 < d.n_seg && !dropped; k0 += 64) {
+			const int k = k0 + lane;
+			const bool in = k < d.n_seg;
+			int nc = in ? sg[k].n_cigar : 0;
+			const bool zd = in && k >= d.has_left && k < d.has_left + n_fill && sg[k].zdropped != 0;
+			const unsigned long long bz = __ballot(zd);
+			if (bz) dropped = true, stop = k0 + __ffsll((long long)bz);       // the Z-dropped one is the last joined
+			if (k >= stop) nc = 0;
+			total += __builtin_amdgcn_readlane(dpp_incl_add(nc), 63);
+		}
 		unsigned long long off = 0;
 		if (lane == 0 && total > 0) off = atomicAdd(&B.dp_ctr[2], (unsigned long long)total);
 		off = (unsigned long long)__shfl((long long)off, 0);
@@ -922,52 +938,68 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 		// every value below is the same in all lanes; only the copies are shared out
 		const bool c_lds = total <= ST_CIG_MAX;
 		auto c_order = [&]() { if (c_lds) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); asm volatile("" ::: "memory"); } else mem_order(); };
-		auto append = [&](const Seg &g) {
-			if (g.n_cigar <= 0) return;
-			const uint32_t first = B.cig_seg[g.cig_off];
-			int start = 0;
-			if (n_c > 0 && (C[n_c - 1] & 0xf) == (first & 0xf)) {       // same operation across the boundary
-				c_order();
-				if (lane == 0) C[n_c - 1] += first >> 4 << 4;
-				start = 1;
-			}
-			for (int c = start + lane; c < g.n_cigar; c += 64) C[n_c + c - start] = B.cig_seg[g.cig_off + c];
-			n_c += g.n_cigar - start;
-			c_order();
-		};
+		if (total > 0) flags |= REG_HAS_DP;
 		{
-			int k = 0;
+			// the join: a segment whose first operation equals the last one before it adds its length there
+			// and starts one word later.  Offsets by a prefix sum, all copies at once, then the additions.
+			int carry_lo = -1;                                   // operation of the last word so far
+			for (int k0 = 0; k0 < stop; k0 += 64) {
+				const int k = k0 + lane;
+				const bool in = k < stop;
+				const int nk = in ? sg[k].n_cigar : 0;
+				const int64_t ok = in ? sg[k].cig_off : 0;
+				const uint32_t first = nk > 0 ? B.cig_seg[ok] : 0u, last = nk > 0 ? B.cig_seg[ok + nk - 1] : 0u;
+				// score: the extensions add their best score, a gap filling its global score (its best one if it Z-dropped)
+				int term = 0;
+				if (in) {
+					const bool is_fill = k >= d.has_left && k < d.has_left + n_fill;
+					if (!is_fill) term = nk > 0 ? sg[k].max : 0;
+					else term = sg[k].zdropped ? sg[k].max : sg[k].score;
+				}
+				dp_score += __builtin_amdgcn_readlane(dpp_incl_add(term), 63);
+				const unsigned long long ne = __ballot(nk > 0);
+				const unsigned long long below = ne & ((1ULL << lane) - 1ULL);
+				const int prev = below ? 63 - __clzll((long long)below) : -1;
+				const int lo_prev_lane = __shfl((int)(last & 0xf), prev < 0 ? 0 : prev);
+				const int lo_prev = prev < 0 ? carry_lo : lo_prev_lane;
+				const int mk = nk > 0 && lo_prev >= 0 && (int)(first & 0xf) == lo_prev ? 1 : 0;
+				const int cnt = nk - mk;
+				const int incl = dpp_incl_add(cnt);
+				const int dst = n_c + incl - cnt;
+				for (int j = 0; j < 64 && k0 + j < stop; ++j) {
+					const int nj = __shfl(nk, j);
+					if (nj == 0) continue;
+					const int mj = __shfl(mk, j), dj = __shfl(dst, j);
+					const int64_t oj = (int64_t)__shfl((long long)ok, j);
+					for (int c = mj + lane; c < nj; c += 64) C[dj + c - mj] = B.cig_seg[oj + c];
+				}
+				c_order();
+				if (mk) atomicAdd(&C[dst - 1], first >> 4 << 4);
+				c_order();
+				n_c += __builtin_amdgcn_readlane(incl, 63);
+				if (ne) carry_lo = __shfl((int)(last & 0xf), 63 - __clzll((long long)ne));
+			}
 			if (d.has_left) {
-				const Seg g = sg[k++];
-				if (g.n_cigar > 0) append(g), flags |= REG_HAS_DP, dp_score += g.max;
+				const Seg g = sg[0];
 				rs1 = d.rs - (g.reach_end ? g.mqe_t + 1 : g.max_t + 1);
 				qs1 = d.qs - (g.reach_end ? d.qs - d.qs0 : g.max_q + 1);
 			}
-			bool dropped = false;
-			const int n_fill = d.n_seg - d.has_left - d.has_right;
-			int prs = d.rs, pqs = d.qs;
-			for (int f = 0; f < n_fill; ++f) {
-				const Seg g = sg[k++];
-				re1 = g.ts + g.tlen, qe1 = g.qs + g.qlen;
-				if (g.n_cigar > 0) append(g), flags |= REG_HAS_DP;
-				if (g.zdropped) {
-					int j;
-					for (j = g.ai - 1; j >= 0; --j)
-						if ((int32_t)a[d.as1 + j].x <= prs + g.max_t) break;
-					dropped = true;
-					if (j < 0) j = 0;
-					dp_score += g.max;
-					re1 = prs + (g.max_t + 1), qe1 = pqs + (g.max_q + 1);
-					if (d.cnt1 - (j + 1) >= B.min_cnt) split_at = d.as1 + j + 1 - r.as, split_inv = g.zdrop_code == 2;
-					break;
-				} else dp_score += g.score;
-				prs = g.ts + g.tlen, pqs = g.qs + g.qlen;
-			}
-			if (!dropped && d.has_right) {
-				const Seg g = sg[d.n_seg - 1];
-				if (g.n_cigar > 0) append(g), flags |= REG_HAS_DP, dp_score += g.max;
-				re1 = d.re + (g.reach_end ? g.mqe_t + 1 : g.max_t + 1);
-				qe1 = d.qe + (g.reach_end ? d.qe0 - d.qe : g.max_q + 1);
+			if (dropped) {
+				const Seg g = sg[stop - 1];
+				const int prs = g.ts, pqs = g.qs;                    // a gap filling starts where the one before it ended
+				int j;
+				for (j = g.ai - 1; j >= 0; --j)
+					if ((int32_t)a[d.as1 + j].x <= prs + g.max_t) break;
+				if (j < 0) j = 0;
+				re1 = prs + (g.max_t + 1), qe1 = pqs + (g.max_q + 1);
+				if (d.cnt1 - (j + 1) >= B.min_cnt) split_at = d.as1 + j + 1 - r.as, split_inv = g.zdrop_code == 2;
+			} else {
+				if (n_fill > 0) { const Seg g = sg[d.has_left + n_fill - 1]; re1 = g.ts + g.tlen, qe1 = g.qs + g.qlen; }
+				if (d.has_right) {
+					const Seg g = sg[d.n_seg - 1];
+					re1 = d.re + (g.reach_end ? g.mqe_t + 1 : g.max_t + 1);
+					qe1 = d.qe + (g.reach_end ? d.qe0 - d.qe : g.max_q + 1);
+				}
 			}
 		}
 		mem_order();
@@ -1020,7 +1052,7 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 		if (flags & REG_HAS_DP) {
 			// ---- sequences of [qs1, qe1) x [rs1, re1) into LDS (or read in place when too long)
 			const int ql = qe1 - qs1, tl = re1 - rs1;
-			const bool in_lds = ql <= ST_SEQ_MAX && tl <= ST_SEQ_MAX;
+			const bool in_lds = ql <= seq_q_max && tl <= seq_t_max;
 			if (in_lds) {
 				for (int i = lane; i < ql; i += 64) s_q[i] = (uint8_t)qcode(read, qlen, rev, qs1 + i);
 				// eight target bases per word
@@ -1069,7 +1101,7 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 								if (sl == prev_len) odd = true;
 							}
 						}
-						if (k < ST_EV_MAX) s_d[k] = (int16_t)sl; else if (sl) odd = true;
+						if (k < ST_EV_MAX && sl <= ST_EV_LIM) s_d[k] = (int8_t)sl; else if (sl) odd = true;
 					}
 				}
 				rare = __any(odd) != 0;
@@ -1175,7 +1207,7 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 							if (ct > 3 || cq > 3) ++c_amb, dlt = -B.sc_ambi;
 							else if (ct != cq) ++c_diff, dlt = -B.sc_b;
 							else dlt = B.sc_a;
-							s_d[ev + i] = (int16_t)dlt;
+							s_d[ev + i] = (int8_t)dlt;
 						}
 						ev += take, pos += take;
 					}
@@ -1186,11 +1218,11 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 					blen += len;
 					if (ev == ST_EV_MAX) flush();
 					const int cost = B.gap_q + B.gap_e * len;
-					if (cost > 32767) {                                   // does not fit an event: applied directly
+					if (cost > ST_EV_LIM) {                               // does not fit an event: applied directly
 						flush();
 						s_run = s_run - cost > 0 ? s_run - cost : 0;
 					} else {
-						if (lane == 0) s_d[ev] = (int16_t)-cost;
+						if (lane == 0) s_d[ev] = (int8_t)-cost;
 						++ev;
 					}
 					if (op == 1) qoff += len; else toff += len;
@@ -1208,7 +1240,7 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 				const int dq = k < n_c && op != 2 ? len : 0, dt = k < n_c && op != 1 ? len : 0, dev = k >= n_c ? 0 : op == 0 ? len : 1;
 				const int iq = dpp_incl_add(dq), it = dpp_incl_add(dt), ie = dpp_incl_add(dev);
 				const int tot_ev = __builtin_amdgcn_readlane(ie, 63);
-				const int big = dpp_max_all(k < n_c ? (op == 0 ? len : cost > 32767 ? 1 << 20 : 0) : 0);
+				const int big = dpp_max_all(k < n_c ? (op == 0 ? len : cost > ST_EV_LIM ? 1 << 20 : 0) : 0);
 				if (big > 256 || tot_ev > ST_EV_MAX) { seq_ops(k0, k1); continue; }
 				if (ev + tot_ev > ST_EV_MAX) flush();
 				if (k < n_c) {
@@ -1220,11 +1252,11 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 							if (ct > 3 || cq > 3) ++c_amb, dlt = -B.sc_ambi;
 							else if (ct != cq) ++c_diff, dlt = -B.sc_b;
 							else dlt = B.sc_a;
-							s_d[eo + i] = (int16_t)dlt;
+							s_d[eo + i] = (int8_t)dlt;
 						}
 					} else {
 						for (int i = 0; i < len; ++i) c_gamb += (op == 1 ? Q(qo + i) : Tg(to + i)) > 3;
-						s_d[eo] = (int16_t)-cost;
+						s_d[eo] = (int8_t)-cost;
 					}
 				}
 				blen += __builtin_amdgcn_readlane(dpp_incl_add(k < n_c ? len : 0), 63);
@@ -1289,9 +1321,16 @@ void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max,
 	hipLaunchKernelGGL(mnc_dp_align, dim3(n_wg), dim3(64), (size_t)lds_state + lds_p + lds_cig * 4, st, B, ws, state_max, p_max, cig_max,
 	                   lds_state, lds_p, lds_cig, big_pass);
 }
-void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_list, int n_wg, hipStream_t st)
+void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_list, int max_read_len, int n_wg, hipStream_t st)
 {
-	hipLaunchKernelGGL(mnc_dp_stitch, dim3(n_wg), dim3(64), 0, st, B, work_list, next_list);
+	// query codes of a whole read; a region's target span is longer by its deletions: a quarter more
+	int q_max = (max_read_len + 63) / 64 * 64, t_max = (max_read_len + max_read_len / 4 + 127) / 64 * 64;
+	if (q_max > 16384) q_max = 16384;
+	if (t_max > 20480) t_max = 20480;
+	if (q_max < 256) q_max = 256;
+	if (t_max < 320) t_max = 320;
+	const size_t lds = (size_t)ST_CIG_MAX * 4 + ST_EV_MAX + q_max + t_max;
+	hipLaunchKernelGGL(mnc_dp_stitch, dim3(n_wg), dim3(64), lds, st, B, work_list, next_list, q_max, t_max);
 }
 
 } // namespace mnc
