@@ -222,8 +222,16 @@ def main():
         instr_per_cell = FILLP_INSTR_PER_STEP / 128
         peak = VALU_PEAK / instr_per_cell / 1e9
         ach = cells / t_s / 1e9
+        fill_traffic = None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(args.traffic_json)), "fill_traffic.json")) as f:
+                tj = json.load(f)
+            if tj.get("reads") == args.reads and tj.get("read_len") == args.read_len:
+                fill_traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
         roofline_dp = {"bound": "valu", "kernel": "mnc_dp_fillp<16>", "achieved": round(ach, 2), "peak": round(peak, 1),
-                       "unit": "Gcell/s", "frac": round(ach / peak, 4), "traffic": None,
+                       "unit": "Gcell/s", "frac": round(ach / peak, 4), "traffic": fill_traffic,
                        "algorithmic_cells_per_launch": int(cells), "avg_launch_ms": round(dp_kernel_ms["dp_fill_t1"], 4),
                        "vector_instructions_per_cell": round(instr_per_cell, 4),
                        "bound_note": "int16 pair arithmetic on the vector ALU: the roof is the VALU issue rate (6.144e11 wave64 "

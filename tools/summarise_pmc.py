@@ -42,6 +42,18 @@ if probe:
                        "stage = partition + probe + collect"},
               open(os.path.join(root, "profiles", "probe_traffic.json"), "w"), indent=1)
     print("probe HBM bytes/launch", int(probe), "stage", int(sum(x for x in stage if x)))
+# the dominant kernel with base-level alignment: the 32-cell tier of the banded gap-filling kernel
+fk = [x for x in out if "mnc_dp_fillp<16>" in x]
+if fk and "FETCH_SIZE" in out[fk[0]] and "WRITE_SIZE" in out[fk[0]]:
+    c = out[fk[0]]
+    json.dump({"kernel": "mnc_dp_fillp<16>", "reads": 100000, "read_len": 5000,
+               "hbm_bytes_per_launch": int((2 * c["FETCH_SIZE"]["avg_per_launch"] + c["WRITE_SIZE"]["avg_per_launch"]) * 1024),
+               "fetch_size_kib": c["FETCH_SIZE"]["avg_per_launch"], "write_size_kib": c["WRITE_SIZE"]["avg_per_launch"],
+               "sq_insts_valu": c.get("SQ_INSTS_VALU", {}).get("avg_per_launch"), "sq_busy_cycles": c.get("SQ_BUSY_CYCLES", {}).get("avg_per_launch"),
+               "note": f"{tag}: separate rocprofv3 --pmc passes of bench.py --steps 1 --warmup 1 with MNC_DP_SERIAL=1 (the alignment "
+                       "kernels one at a time); FETCH doubled per the guide's gfx950 correction"},
+              open(os.path.join(root, "profiles", "fill_traffic.json"), "w"), indent=1)
+    print("fill kernel HBM bytes/launch", int((2 * c["FETCH_SIZE"]["avg_per_launch"] + c["WRITE_SIZE"]["avg_per_launch"]) * 1024))
 ks = glob.glob(os.path.join(root, "gpurun_out", f"prof_{tag}", "**", "out_kernel_stats.csv"), recursive=True)
 if ks:
     import shutil
