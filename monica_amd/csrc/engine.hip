@@ -1043,6 +1043,7 @@ extern "C" int mnc_engine_get_counters(mnc_engine *e, int64_t *c, int n)
 		HIP_TRY(hipMemcpy(d, e->dp_ctr.p, sizeof(d), hipMemcpyDeviceToHost));
 		c[8] = (int64_t)d[0], c[9] = (int64_t)d[10], c[10] = (int64_t)d[11], c[11] = (int64_t)d[12];
 		if (n >= 16) c[12] = (int64_t)d[48], c[13] = (int64_t)d[49], c[14] = (int64_t)d[50], c[15] = (int64_t)d[51];
+		if (n >= 24) for (int i = 0; i < 8; ++i) c[16 + i] = (int64_t)d[52 + i];
 
 
 	}

@@ -308,6 +308,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 				if (g.big == 1) {
 					const unsigned long long bi = atomicAdd(&B.dp_ctr[6], 1ULL);
 					B.big_list[bi] = (int32_t)(sg - B.segs);
+					atomicAdd(&B.dp_ctr[56 + (g.kind == 1 ? 0 : 1)], 1ULL); atomicAdd(&B.dp_ctr[58], (unsigned long long)(g.tlen + g.qlen)); atomicMax(&B.dp_ctr[59], (unsigned long long)(g.tlen > g.qlen ? g.tlen : g.qlen));
 				} else if (g.big == 0 && g.kind == 1 && g.w == bw && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= FILL_MAX_LEN && g.qlen <= FILL_MAX_LEN) {
 					// a gap between two seeds whose matrix the band never clips: the banded kernel of
 					// k_fill.hip, 32 lanes per segment when |tlen - qlen| leaves a band worth trying, else 64
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 					// the literal kernel: its first pass with everything in LDS, or from the start on its own list
 					const bool all_lds = 12 * T + Q <= B.lds0_state && p_bytes <= B.lds0_p && g.qlen + g.tlen + 2 <= B.lds0_cig;
 					if (all_lds) g.big = 8, ++n_tier[4];
-					else g.big = 20, ++n_tier[16];
+					else { g.big = 20, ++n_tier[16]; atomicAdd(&B.dp_ctr[52 + (g.kind == 1 ? 0 : 1)], 1ULL); atomicAdd(&B.dp_ctr[54], (unsigned long long)(g.tlen + g.qlen)); atomicMax(&B.dp_ctr[55], (unsigned long long)(g.tlen > g.qlen ? g.tlen : g.qlen)); }
 				}
 				*sg++ = g;
 			};
@@ -1287,7 +1288,7 @@ __global__ void mnc_dp_round(Batch B, int first)
 	B.dp_ctr[5] = 0;
 	B.dp_ctr[6] = 0, B.dp_ctr[7] = 0;
 	for (int k = 10; k < 48; ++k) B.dp_ctr[k] = 0;
-	if (first) for (int k = 48; k < 52; ++k) B.dp_ctr[k] = 0;   // banded kernel: list lengths 10 / 11 / 12 (tier 1, tier 2, handed back), queues 13 / 14 / 15;
+	if (first) for (int k = 48; k < 64; ++k) B.dp_ctr[k] = 0;   // banded kernel: list lengths 10 / 11 / 12 (tier 1, tier 2, handed back), queues 13 / 14 / 15;
 	                                                 // extension kernel: lists 16 / 17, queues 18 / 19; literal kernel's first pass: list 20, queue 21; banded kernel, 128 cells: list 22, queue 23; extension kernel, 128 / 256 cells: lists 24 / 25, queues 26 / 27
 }
 __global__ void mnc_dp_round_end(Batch B)
