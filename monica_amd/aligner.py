@@ -162,10 +162,13 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
     t_engine = time.perf_counter()
     engine = index.engine()
     t_engine = time.perf_counter() - t_engine
+    t_open = time.perf_counter()
     reader = _capi.FastqReader(sample)
+    t_open = time.perf_counter() - t_open
 
-    clock = TIMINGS.setdefault(sample_name, dict.fromkeys(("parse", "classify", "carry", "route", "count", "engine"), 0.0))
+    clock = TIMINGS.setdefault(sample_name, dict.fromkeys(("parse", "classify", "carry", "route", "count", "engine", "open", "close", "remove"), 0.0))
     clock["engine"] += t_engine
+    clock["open"] += t_open
 
     def classify_next():
         t0 = time.perf_counter()
@@ -235,7 +238,9 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
                         first[u] = ordinal[np.argmax(name[mapped] == u)]
             seen_reads += reader.n
     finally:
+        t0 = time.perf_counter()
         reader.close()
+        clock["close"] += time.perf_counter() - t0
     sample_alignment = dict()
     for u in sorted(np.flatnonzero(first >= 0), key=lambda u: first[u]):
         tax_unit, accession, _ = decoded[u]
@@ -243,7 +248,9 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
     if os.path.exists(carried_file):
         os.remove(carried_file)
     print(f"{sample} done")
+    t0 = time.perf_counter()
     os.remove(sample)
+    clock["remove"] += time.perf_counter() - t0
     return sample_alignment, sample_name
 
 

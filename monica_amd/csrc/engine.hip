@@ -403,18 +403,30 @@ static const char *STAGE_KERNEL[MNC_N_STAGES] = {
 extern "C" const char *mnc_stage_name(int s) { return s >= 0 && s < MNC_N_STAGES ? STAGE_NAME[s] : nullptr; }
 extern "C" const char *mnc_stage_kernel(int s) { return s >= 0 && s < MNC_N_STAGES ? STAGE_KERNEL[s] : nullptr; }
 
-// page-locked host buffers for the batch readers (hostio.cpp); plain malloc without a GPU
+// page-locked host buffers for the batch readers (hostio.cpp); plain malloc without a GPU.  Locking a
+// gigabyte of pages takes ~0.1 s, as long as classifying the reads in it: freed buffers are kept
+// (up to PINNED_KEEP bytes) and handed out again.
 static std::mutex g_pinned_mu;
-static std::vector<void*> g_pinned;
+struct PinnedBuf { void *p; size_t bytes; bool in_use; };
+static std::vector<PinnedBuf> g_pinned;
+constexpr size_t PINNED_KEEP = 6ull << 30;
 
 extern "C" void *mnc_host_alloc(size_t bytes)
 {
 	if (bytes == 0) bytes = 1;
+	{
+		std::lock_guard<std::mutex> g(g_pinned_mu);
+		size_t best = g_pinned.size();
+		for (size_t i = 0; i < g_pinned.size(); ++i)             // the smallest kept buffer that is large enough (and not wasteful)
+			if (!g_pinned[i].in_use && g_pinned[i].bytes >= bytes && g_pinned[i].bytes <= 2 * bytes + (1u << 20) &&
+			    (best == g_pinned.size() || g_pinned[i].bytes < g_pinned[best].bytes)) best = i;
+		if (best != g_pinned.size()) { g_pinned[best].in_use = true; return g_pinned[best].p; }
+	}
 	int c = 0;
 	void *p = nullptr;
 	if (hipGetDeviceCount(&c) == hipSuccess && c > 0 && hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p) {
 		std::lock_guard<std::mutex> g(g_pinned_mu);
-		g_pinned.push_back(p);
+		g_pinned.push_back({ p, bytes, true });
 		return p;
 	}
 	(void)hipGetLastError();
@@ -427,10 +439,15 @@ extern "C" void mnc_host_free(void *p)
 	{
 		std::lock_guard<std::mutex> g(g_pinned_mu);
 		for (size_t i = 0; i < g_pinned.size(); ++i)
-			if (g_pinned[i] == p) {
-				g_pinned[i] = g_pinned.back();
-				g_pinned.pop_back();
-				(void)hipHostFree(p);
+			if (g_pinned[i].p == p) {
+				g_pinned[i].in_use = false;
+				size_t kept = 0;
+				for (const PinnedBuf &b : g_pinned) if (!b.in_use) kept += b.bytes;
+				if (kept > PINNED_KEEP) {                            // over the budget: this one goes back to the system
+					g_pinned[i] = g_pinned.back();
+					g_pinned.pop_back();
+					(void)hipHostFree(p);
+				}
 				return;
 			}
 	}

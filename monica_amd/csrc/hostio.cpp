@@ -21,6 +21,10 @@
 #include <sys/stat.h>
 #include <algorithm>
 #include <unistd.h>
+#include <omp.h>
+#include <mutex>
+#include <vector>
+#include <string>
 #include <unordered_map>
 
 using namespace mnc;
@@ -29,38 +33,140 @@ namespace {
 
 constexpr size_t IO_CHUNK = 8u << 20;
 
+// Giving a gigabyte back to the system and asking for it again per file costs ~0.1 s of page work each
+// way: the readers' large buffers are kept (up to CACHE_KEEP bytes) and handed to the next reader.
+struct BigCache {
+	std::mutex mu;
+	std::vector<std::pair<char*, size_t>> kept;
+	size_t kept_bytes = 0;
+	static constexpr size_t CACHE_KEEP = 6ull << 30, BIG = 16u << 20;
+	char *take(size_t need, size_t *got)
+	{
+		std::lock_guard<std::mutex> g(mu);
+		size_t best = kept.size();
+		for (size_t i = 0; i < kept.size(); ++i)
+			if (kept[i].second >= need && (best == kept.size() || kept[i].second < kept[best].second)) best = i;
+		if (best == kept.size()) return nullptr;
+		char *p = kept[best].first;
+		*got = kept[best].second;
+		kept_bytes -= kept[best].second;
+		kept[best] = kept.back(), kept.pop_back();
+		return p;
+	}
+	void give(char *p, size_t bytes)
+	{
+		if (!p) return;
+		{
+			std::lock_guard<std::mutex> g(mu);
+			if (bytes >= BIG && kept_bytes + bytes <= CACHE_KEEP) { kept.push_back({ p, bytes }), kept_bytes += bytes; return; }
+		}
+		free(p);
+	}
+};
+BigCache g_big;
+
 struct LineReader {
 	int fd = -1;
-	std::vector<char> buf;
+	char *data = nullptr;       // raw buffer (no zero-filling when it grows: a batch holds a gigabyte)
+	size_t cap = 0;
 	size_t lo = 0, hi = 0;
-	bool eof = false;
+	bool eof = false, seekable = false;
 	int err = 0;                // errno of a failed read(): reported as MNC_ERR_IO, never taken for the end of the file
+
+	bool grow(size_t need)
+	{
+		if (need <= cap) return true;
+		size_t nc = cap + cap / 2;
+		if (nc < need) nc = need;
+		size_t got = 0;
+		if (char *c = g_big.take(nc, &got)) {                      // a kept buffer: move what is held
+			if (hi > lo) memcpy(c + lo, data + lo, hi - lo);
+			g_big.give(data, cap);
+			data = c, cap = got;
+			return true;
+		}
+		char *np_ = (char*)realloc(data, nc);
+		if (!np_) return false;
+		data = np_, cap = nc;
+		return true;
+	}
+	void release() { g_big.give(data, cap); data = nullptr, cap = 0, lo = hi = 0; }
+	void compact() { if (lo > 0) { memmove(data, data + lo, hi - lo); hi -= lo, lo = 0; } }
 
 	// next line without its terminator; false at end of file.  `raw_len` = bytes consumed
 	bool next(const char *&p, size_t &len)
 	{
 		for (;;) {
-			const char *nl = hi > lo ? (const char*)memchr(buf.data() + lo, '\n', hi - lo) : nullptr;
+			const char *nl = hi > lo ? (const char*)memchr(data + lo, '\n', hi - lo) : nullptr;
 			if (nl) {
-				p = buf.data() + lo;
+				p = data + lo;
 				len = (size_t)(nl - p);
 				lo += len + 1;
 				return true;
 			}
 			if (eof) {
 				if (hi == lo) return false;
-				p = buf.data() + lo, len = hi - lo, lo = hi;
+				p = data + lo, len = hi - lo, lo = hi;
 				return true;
 			}
 			// refill: keep the partial line, append a chunk
-			if (lo > 0) { memmove(buf.data(), buf.data() + lo, hi - lo); hi -= lo, lo = 0; }
-			if (buf.size() < hi + IO_CHUNK) buf.resize(hi + IO_CHUNK);
+			compact();
+			if (!grow(hi + IO_CHUNK)) { err = ENOMEM; eof = true; return false; }
 			ssize_t n;
-			do n = read(fd, buf.data() + hi, IO_CHUNK); while (n < 0 && errno == EINTR);
+			do n = read(fd, data + hi, IO_CHUNK); while (n < 0 && errno == EINTR);
 			if (n < 0) { err = errno ? errno : EIO; eof = true; return false; }
 			if (n == 0) eof = true;
 			hi += (size_t)n;
 		}
+	}
+
+	// have `want` bytes after `lo` (or everything up to the end of the file): slices of a regular file
+	// are read by several threads at once
+	bool fill(size_t want)
+	{
+		if (hi - lo >= want || eof) return true;
+		compact();
+		if (!grow(want + IO_CHUNK)) { err = ENOMEM; return false; }
+		const off_t pos = seekable ? lseek(fd, 0, SEEK_CUR) : (off_t)-1;
+		struct stat sb;
+		if (pos >= 0 && fstat(fd, &sb) == 0 && sb.st_size > pos) {
+			const size_t n = std::min<size_t>(want - hi, (size_t)(sb.st_size - pos));
+			const size_t slice = 16u << 20;
+			const int64_t n_slices = (int64_t)((n + slice - 1) / slice);
+			int fail = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(io_threads())
+			for (int64_t k = 0; k < n_slices; ++k) {
+				size_t done = 0;
+				const size_t len = std::min(slice, n - (size_t)k * slice);
+				while (done < len) {
+					const ssize_t r = pread(fd, data + hi + (size_t)k * slice + done, len - done, pos + (off_t)((size_t)k * slice + done));
+					if (r < 0 && errno == EINTR) continue;
+					if (r <= 0) {
+#pragma omp atomic write
+						fail = r < 0 ? (errno ? errno : EIO) : EIO;
+						break;
+					}
+					done += (size_t)r;
+				}
+			}
+			if (fail) { err = fail; eof = true; return false; }
+			hi += n;
+			if (lseek(fd, pos + (off_t)n, SEEK_SET) < 0) { err = errno ? errno : EIO; eof = true; return false; }
+		}
+		while (hi - lo < want && !eof) {                          // the rest (or all of it, from a pipe)
+			if (!grow(hi + IO_CHUNK)) { err = ENOMEM; return false; }
+			ssize_t n;
+			do n = read(fd, data + hi, std::min(IO_CHUNK, want - (hi - lo) + 1)); while (n < 0 && errno == EINTR);
+			if (n < 0) { err = errno ? errno : EIO; eof = true; return false; }
+			if (n == 0) eof = true;
+			hi += (size_t)n;
+		}
+		return true;
+	}
+	static int io_threads()
+	{
+		int t = omp_get_max_threads();
+		return t < 1 ? 1 : t > 16 ? 16 : t;
 	}
 };
 
@@ -82,7 +188,13 @@ struct HostBuf {               // growable byte buffer, optionally page-locked
 		if (need <= cap) return true;
 		size_t nc = cap ? cap : (1u << 20);
 		while (nc < need) nc += nc / 2 + (1u << 20);
-		uint8_t *np_ = pinned ? (uint8_t*)mnc_host_alloc(nc) : (uint8_t*)malloc(nc);
+		uint8_t *np_ = nullptr;
+		if (pinned) np_ = (uint8_t*)mnc_host_alloc(nc);
+		else {
+			size_t got = 0;
+			np_ = (uint8_t*)g_big.take(nc, &got);
+			if (np_) nc = got; else np_ = (uint8_t*)malloc(nc);
+		}
 		if (!np_) return false;
 		if (keep) memcpy(np_, p, keep);
 		release();
@@ -91,7 +203,7 @@ struct HostBuf {               // growable byte buffer, optionally page-locked
 	}
 	void release()
 	{
-		if (p) { if (pinned) mnc_host_free(p); else free(p); }
+		if (p) { if (pinned) mnc_host_free(p); else g_big.give((char*)p, cap); }
 		p = nullptr, cap = 0;
 	}
 };
@@ -111,6 +223,7 @@ struct mnc_fastq {
 	std::string titles;
 	std::vector<uint64_t> title_off;  // n + 1
 	std::vector<uint32_t> id_len, id_off;   // seq_record.id = first word of the title
+	std::vector<size_t> nl;          // the four-line fast path: line ends of the buffered text
 };
 
 static int fq_io_fail(const mnc_fastq *fq)
@@ -135,7 +248,9 @@ extern "C" int mnc_fastq_open(const char *path, mnc_fastq **out)
 	fq->path = path;
 	{
 		struct stat sb;
-		fq->file_size = fstat(fd, &sb) == 0 ? (int64_t)sb.st_size : 0;
+		const bool ok = fstat(fd, &sb) == 0;
+		fq->file_size = ok ? (int64_t)sb.st_size : 0;
+		fq->in.seekable = ok && S_ISREG(sb.st_mode) && lseek(fd, 0, SEEK_CUR) >= 0;
 	}
 	fq->bases.pinned = true;
 	fq->offsets.push_back(0);
@@ -148,9 +263,142 @@ extern "C" void mnc_fastq_close(mnc_fastq *fq)
 {
 	if (!fq) return;
 	if (fq->in.fd >= 0) close(fq->in.fd);
+	fq->in.release();
 	fq->bases.release();
 	fq->quals.release();
 	delete fq;
+}
+
+// ---------------------------------------------------------------- the four-line fast path
+// A batch of records that each take exactly four lines (title, sequence, '+' line, qualities -- what
+// every basecaller writes) is found and copied by all host threads at once: line ends by slices of
+// the buffered text, then per record the checks under which the general parser below (Biopython's
+// FastqGeneralIterator, which allows wrapped sequences) reads the same four lines the same way --
+// '@' first, '+' third with an empty or equal caption, equal lengths, a next line that starts
+// with '@'.  Anything else -- including what the general parser reports as an error -- leaves the
+// state untouched and is parsed (or reported) by the general parser.
+static int fastq_next_fast(mnc_fastq *fq, uint32_t max_reads, uint64_t max_bases, bool *handled)
+{
+	*handled = false;
+	LineReader &in = fq->in;
+	if (!fq->have_pending || !in.seekable || max_reads == 0) return MNC_OK;
+	{
+		uint64_t want = 2 * max_bases + (uint64_t)max_reads * 512 + (1u << 20);
+		const uint64_t left = (uint64_t)fq->file_size + (1u << 20);       // never more than the file
+		if (want > left) want = left;
+		if (!in.fill((size_t)want)) return in.err == ENOMEM ? (set_error("out of host memory"), MNC_ERR_NOMEM) : MNC_OK;   // an I/O error: the general parser reports it
+	}
+	const char *base = in.data + in.lo;
+	const size_t avail = in.hi - in.lo;
+	if (avail == 0) return MNC_OK;
+	const int T = LineReader::io_threads();
+	// ---- line ends
+	std::vector<std::vector<size_t>> part((size_t)T);
+#pragma omp parallel num_threads(T)
+	{
+		const int t = omp_get_thread_num(), nt = omp_get_num_threads();
+		const size_t a = avail * (size_t)t / (size_t)nt, b = avail * (size_t)(t + 1) / (size_t)nt;
+		std::vector<size_t> &v = part[(size_t)t];
+		v.reserve((b - a) / 1024 + 16);
+		const char *p = base + a, *e = base + b;
+		while (p < e) {
+			const char *q = (const char*)memchr(p, '\n', (size_t)(e - p));
+			if (!q) break;
+			v.push_back((size_t)(q - base));
+			p = q + 1;
+		}
+	}
+	std::vector<size_t> &nl = fq->nl;
+	nl.clear();
+	for (const auto &v : part) nl.insert(nl.end(), v.begin(), v.end());
+	bool open_end = false;                                        // the file ends without a line terminator
+	if (in.eof && (nl.empty() || nl.back() != avail - 1)) nl.push_back(avail), open_end = true;
+	const size_t n_lines = nl.size();
+	auto line = [&](size_t i, const char *&p, size_t &len) { const size_t s0 = i ? nl[i - 1] + 1 : 0; p = base + s0, len = nl[i] - s0; };
+	// lines of the buffer: seq0 plus0 qual0 title1 seq1 ... (title0 is the pending line)
+	size_t R;
+	if (in.eof) {
+		if (n_lines % 4 != 3) return MNC_OK;                      // not whole four-line records to the end
+		R = (n_lines + 1) / 4;
+	} else R = n_lines / 4;                                       // only records whose next title is in the buffer
+	if (R > max_reads) R = max_reads;
+	if (R == 0) return MNC_OK;
+	std::vector<uint32_t> slen(R);
+	int bad = 0;
+#pragma omp parallel for schedule(static) num_threads(T) reduction(|:bad)
+	for (int64_t r = 0; r < (int64_t)R; ++r) {
+		const char *tp, *sp, *pp, *qp;
+		size_t tl, sl, pl, ql;
+		if (r == 0) tp = fq->pending.data(), tl = fq->pending.size(); else line((size_t)(4 * r - 1), tp, tl);
+		line((size_t)(4 * r), sp, sl), line((size_t)(4 * r + 1), pp, pl), line((size_t)(4 * r + 2), qp, ql);
+		if (tl == 0 || tp[0] != '@' || pl == 0 || pp[0] != '+') { bad |= 1; continue; }
+		const size_t t_len = rstrip_len(tp + 1, tl - 1), c_len = rstrip_len(pp + 1, pl - 1);
+		if (c_len > 0 && (c_len != t_len || memcmp(pp + 1, tp + 1, t_len) != 0)) { bad |= 1; continue; }
+		const size_t s_len = rstrip_len(sp, sl), q_len = rstrip_len(qp, ql);
+		if (s_len != q_len || s_len > 0xffffffffu) { bad |= 1; continue; }
+		if (memchr(sp, ' ', s_len) || memchr(sp, '\t', s_len)) { bad |= 1; continue; }
+		for (size_t i = 0; i < q_len; ++i) if ((uint8_t)qp[i] < 33 || (uint8_t)qp[i] > 126) { bad |= 1; break; }
+		if ((size_t)(4 * r + 3) < n_lines) {
+			const char *np_; size_t nl_;
+			line((size_t)(4 * r + 3), np_, nl_);
+			if (nl_ == 0 || np_[0] != '@') bad |= 1;
+		}
+		slen[(size_t)r] = (uint32_t)s_len;
+	}
+	if (bad) return MNC_OK;
+	// ---- how many records: the batch ends with the record that reaches max_bases
+	size_t n = 0;
+	{
+		uint64_t nb = 0;
+		while (n < R) { nb += slen[n]; ++n; if (nb >= max_bases) break; }
+	}
+	fq->offsets.resize(n + 1), fq->title_off.resize(n + 1), fq->id_len.resize(n), fq->id_off.resize(n);
+	std::vector<uint32_t> tlen(n);
+	fq->offsets[0] = 0, fq->title_off[0] = 0;
+	for (size_t r = 0; r < n; ++r) {
+		const char *tp; size_t tl;
+		if (r == 0) tp = fq->pending.data(), tl = fq->pending.size(); else line(4 * r - 1, tp, tl);
+		tlen[r] = (uint32_t)rstrip_len(tp + 1, tl - 1);
+		fq->offsets[r + 1] = fq->offsets[r] + slen[r];
+		fq->title_off[r + 1] = fq->title_off[r] + tlen[r];
+	}
+	const int64_t nb = fq->offsets[n];
+	if (!fq->bases.ensure((size_t)nb + 64, 0) || !fq->quals.ensure((size_t)nb + 64, 0)) { set_error("out of host memory"); return MNC_ERR_NOMEM; }
+	fq->titles.resize((size_t)fq->title_off[n]);
+#pragma omp parallel for schedule(static) num_threads(T)
+	for (int64_t r = 0; r < (int64_t)n; ++r) {
+		const char *tp, *sp, *qp;
+		size_t tl, sl, ql;
+		if (r == 0) tp = fq->pending.data(), tl = fq->pending.size(); else line((size_t)(4 * r - 1), tp, tl);
+		line((size_t)(4 * r), sp, sl), line((size_t)(4 * r + 2), qp, ql);
+		(void)tl, (void)sl, (void)ql;
+		const size_t s_len = slen[(size_t)r], t_len = tlen[(size_t)r];
+		memcpy(fq->bases.p + fq->offsets[(size_t)r], sp, s_len);
+		memcpy(fq->quals.p + fq->offsets[(size_t)r], qp, s_len);
+		char *t = &fq->titles[(size_t)fq->title_off[(size_t)r]];
+		memcpy(t, tp + 1, t_len);
+		size_t a = 0;
+		while (a < t_len && (t[a] == ' ' || (t[a] >= 9 && t[a] <= 13))) ++a;
+		size_t b = a;
+		while (b < t_len && !(t[b] == ' ' || (t[b] >= 9 && t[b] <= 13))) ++b;
+		fq->id_len[(size_t)r] = (uint32_t)(b - a), fq->id_off[(size_t)r] = (uint32_t)a;
+	}
+	fq->n = (uint32_t)n;
+	// ---- what was consumed: through the title of the next record, which becomes the pending line
+	if (4 * n - 1 < n_lines) {
+		const char *tp; size_t tl;
+		line(4 * n - 1, tp, tl);
+		fq->pending.assign(tp, tl);
+		fq->have_pending = true;
+		const size_t end = nl[4 * n - 1];
+		in.lo += (open_end && 4 * n - 1 == n_lines - 1) ? end : end + 1;
+	} else {
+		fq->have_pending = false;
+		in.lo = in.hi;
+		fq->done = true;
+	}
+	*handled = true;
+	return MNC_OK;
 }
 
 extern "C" int mnc_fastq_next(mnc_fastq *fq, uint32_t max_reads, uint64_t max_bases, uint32_t *n_reads)
@@ -175,6 +423,11 @@ extern "C" int mnc_fastq_next(mnc_fastq *fq, uint32_t max_reads, uint64_t max_ba
 		}
 		fq->pending.assign(p, len);
 		fq->have_pending = true;
+	}
+	{
+		bool handled = false;
+		if (int rc = fastq_next_fast(fq, max_reads, max_bases, &handled)) return rc;
+		if (handled) { *n_reads = fq->n; return MNC_OK; }
 	}
 	int64_t nb = 0;
 	if (!fq->bases.p && fq->file_size > 0) {
@@ -283,68 +536,116 @@ extern "C" int mnc_fastq_title(const mnc_fastq *fq, uint32_t r, const char **tit
 	return MNC_OK;
 }
 
-namespace {
-struct OutFile {
-	FILE *f = nullptr;
-	std::string buf;
-	int flush()
-	{
-		if (f && !buf.empty()) {
-			if (fwrite(buf.data(), 1, buf.size(), f) != buf.size()) return MNC_ERR_IO;
-			buf.clear();
-		}
-		return MNC_OK;
-	}
-};
-}
-
 extern "C" int mnc_fastq_route(const mnc_fastq *fq, const uint8_t *dest, const int32_t *label,
                                const char *const *labels, int n_labels, const char *const *paths)
 {
 	if (!fq || !dest || !paths) return MNC_ERR_ARG;
-	OutFile out[4];
-	int rc = MNC_OK;
-	for (uint32_t r = 0; r < fq->n && rc == MNC_OK; ++r) {
+	// arguments first: a destination without a path, a label out of range
+	for (uint32_t r = 0; r < fq->n; ++r) {
 		const uint8_t d = dest[r];
-		if (!d) continue;
-		const char *t = fq->titles.data() + fq->title_off[r];
-		const size_t t_len = (size_t)(fq->title_off[r + 1] - fq->title_off[r]);
-		const int64_t o = fq->offsets[r], l = fq->offsets[r + 1] - o;
-		for (int k = 0; k < 4; ++k) {
-			if (!(d >> k & 1)) continue;
-			OutFile &of = out[k];
-			if (!of.f) {
-				if (!paths[k]) { set_error("read %u is routed to a file that was not given", r); rc = MNC_ERR_ARG; break; }
-				of.f = fopen(paths[k], "ab");
-				if (!of.f) { set_error("cannot open %s: %s", paths[k], strerror(errno)); rc = MNC_ERR_IO; break; }
+		for (int k = 0; k < 4; ++k) if ((d >> k & 1) && !paths[k]) { set_error("read %u is routed to a file that was not given", r); return MNC_ERR_ARG; }
+		if ((d >> 2 & 1) && label && label[r] >= 0 && (!labels || label[r] >= n_labels)) { set_error("label %d of read %u is out of range", label[r], r); return MNC_ERR_ARG; }
+	}
+	// Every record's length in its file is known before it is written (title, two lines of the read's
+	// length, six more characters, the label in front of a mapped record's title): offsets by a prefix
+	// sum, the files grown once, and every host thread formats its slice of the batch through a small
+	// buffer and writes it in place (pwrite) -- the order in each file is the reads' order.
+	const int T = std::max(1, std::min(LineReader::io_threads(), (int)(fq->n / 2048 + 1)));
+	auto rec_len = [&](uint32_t r, int k) -> size_t {
+		const size_t t_len = (size_t)(fq->title_off[r + 1] - fq->title_off[r]), l = (size_t)(fq->offsets[r + 1] - fq->offsets[r]);
+		size_t head = t_len;
+		if (k == 2 && label && label[r] >= 0) {
+			const char *id = labels[label[r]];
+			const size_t idl = strlen(id);
+			const char *tt = fq->titles.data() + fq->title_off[r];
+			if (t_len == 0) head = idl;
+			else if (!(fq->id_len[r] == idl && memcmp(tt + fq->id_off[r], id, idl) == 0)) head = idl + 1 + t_len;
+		}
+		return 1 + head + 1 + l + 3 + l + 1;
+	};
+	std::vector<size_t> slice_bytes((size_t)T * 4, 0);
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+	for (int t = 0; t < T; ++t) {
+		const uint32_t r0 = (uint32_t)((uint64_t)fq->n * (uint64_t)t / (uint64_t)T), r1 = (uint32_t)((uint64_t)fq->n * (uint64_t)(t + 1) / (uint64_t)T);
+		for (uint32_t r = r0; r < r1; ++r)
+			for (int k = 0; k < 4; ++k)
+				if (dest[r] >> k & 1) slice_bytes[(size_t)t * 4 + k] += rec_len(r, k);
+	}
+	int fds[4] = { -1, -1, -1, -1 };
+	off_t start[4] = { 0, 0, 0, 0 };
+	size_t total[4] = { 0, 0, 0, 0 };
+	int rc = MNC_OK;
+	for (int k = 0; k < 4 && rc == MNC_OK; ++k) {
+		for (int t = 0; t < T; ++t) total[k] += slice_bytes[(size_t)t * 4 + k];
+		if (total[k] == 0) continue;
+		fds[k] = open(paths[k], O_WRONLY | O_CREAT, 0666);
+		struct stat sb;
+		if (fds[k] < 0 || fstat(fds[k], &sb) != 0) { set_error("cannot open %s: %s", paths[k], strerror(errno)); rc = MNC_ERR_IO; break; }
+		start[k] = sb.st_size;                                // append: the new records follow what the file holds
+	}
+	int fail[4] = { 0, 0, 0, 0 };
+	if (rc == MNC_OK) {
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+		for (int t = 0; t < T; ++t) {
+			const uint32_t r0 = (uint32_t)((uint64_t)fq->n * (uint64_t)t / (uint64_t)T), r1 = (uint32_t)((uint64_t)fq->n * (uint64_t)(t + 1) / (uint64_t)T);
+			off_t pos[4];
+			std::string buf[4];
+			for (int k = 0; k < 4; ++k) {
+				pos[k] = start[k];
+				for (int u = 0; u < t; ++u) pos[k] += (off_t)slice_bytes[(size_t)u * 4 + k];
 			}
-			std::string &b = of.buf;
-			b.push_back('@');
-			if (k == 2 && label && label[r] >= 0) {           // seq_record.id = tax_unit
-				if (!labels || label[r] >= n_labels) { set_error("label %d of read %u is out of range", label[r], r); rc = MNC_ERR_ARG; break; }
-				const char *id = labels[label[r]];
-				const size_t idl = strlen(id);
-				if (t_len == 0) b.append(id, idl);
-				else if (fq->id_len[r] == idl && memcmp(t + fq->id_off[r], id, idl) == 0) b.append(t, t_len);
-				else { b.append(id, idl); b.push_back(' '); b.append(t, t_len); }
-			} else b.append(t, t_len);
-			b.push_back('\n');
-			b.append((const char*)fq->bases.p + o, (size_t)l);
-			b.append("\n+\n", 3);
-			b.append((const char*)fq->quals.p + o, (size_t)l);
-			b.push_back('\n');
-			if (b.size() > (4u << 20)) { rc = of.flush(); if (rc) { set_error("write to %s failed", paths[k]); break; } }
+			auto flush = [&](int k) {
+				std::string &b = buf[k];
+				size_t done = 0;
+				while (done < b.size()) {
+					const ssize_t w = pwrite(fds[k], b.data() + done, b.size() - done, pos[k] + (off_t)done);
+					if (w < 0 && errno == EINTR) continue;
+					if (w <= 0) {
+#pragma omp atomic write
+						fail[k] = errno ? errno : EIO;
+						break;
+					}
+					done += (size_t)w;
+				}
+				pos[k] += (off_t)b.size();
+				b.clear();
+			};
+			for (uint32_t r = r0; r < r1; ++r) {
+				const uint8_t d = dest[r];
+				if (!d) continue;
+				const char *tt = fq->titles.data() + fq->title_off[r];
+				const size_t t_len = (size_t)(fq->title_off[r + 1] - fq->title_off[r]);
+				const int64_t o = fq->offsets[r], l = fq->offsets[r + 1] - o;
+				for (int k = 0; k < 4; ++k) {
+					if (!(d >> k & 1)) continue;
+					std::string &b = buf[k];
+					b.push_back('@');
+					if (k == 2 && label && label[r] >= 0) {           // seq_record.id = tax_unit
+						const char *id = labels[label[r]];
+						const size_t idl = strlen(id);
+						if (t_len == 0) b.append(id, idl);
+						else if (fq->id_len[r] == idl && memcmp(tt + fq->id_off[r], id, idl) == 0) b.append(tt, t_len);
+						else { b.append(id, idl); b.push_back(' '); b.append(tt, t_len); }
+					} else b.append(tt, t_len);
+					b.push_back('\n');
+					b.append((const char*)fq->bases.p + o, (size_t)l);
+					b.append("\n+\n", 3);
+					b.append((const char*)fq->quals.p + o, (size_t)l);
+					b.push_back('\n');
+					if (b.size() > (2u << 20)) flush(k);
+				}
+			}
+			for (int k = 0; k < 4; ++k) if (!buf[k].empty()) flush(k);
 		}
 	}
 	for (int k = 0; k < 4; ++k) {
-		if (!out[k].f) continue;
-		if (rc == MNC_OK && out[k].flush() != MNC_OK) { set_error("write to %s failed", paths[k]); rc = MNC_ERR_IO; }
-		if (fclose(out[k].f) != 0 && rc == MNC_OK) { set_error("write to %s failed", paths[k]); rc = MNC_ERR_IO; }
+		if (fds[k] < 0) continue;
+		if (close(fds[k]) != 0 && !fail[k]) fail[k] = errno ? errno : EIO;
+		if (rc == MNC_OK && fail[k]) { set_error("write to %s failed: %s", paths[k], strerror(fail[k])); rc = MNC_ERR_IO; }
 	}
 	return rc;
 }
 
-// ---------------------------------------------------------------- hits carried across index parts
 namespace {
 struct HitState { int32_t hits, nm, mlen, name, tied; };
 }

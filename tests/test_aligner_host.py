@@ -136,6 +136,52 @@ def test_route_writes_what_seqio_write_would(tmp_path):
     rd.close()
 
 
+def test_many_records_parse_and_route_on_all_host_threads(tmp_path):
+    """Large batches take the four-line fast path of the reader and the sliced, in-place writes of
+    the router: both must give what the record-by-record forms give."""
+    from monica_amd import _capi
+    rng = np.random.default_rng(5)
+    n = 9000
+    recs = []
+    for r in range(n):
+        l = int(rng.integers(0, 60))
+        seq = rng.choice(list(b"ACGTN"), l).astype(np.uint8).tobytes() if l else b""
+        qual = rng.integers(33, 127, l).astype(np.uint8).tobytes() if l else b""
+        title = (b"Genus_a" if r % 7 == 0 else b"r%d" % r) + (b" ch=%d" % (r % 512) if r % 3 else b"")
+        recs.append((title, seq, qual))
+    text = b"".join(b"@" + t + b"\n" + s_ + b"\n+" + (t if i % 11 == 0 else b"") + b"\n" + q + b"\n" for i, (t, s_, q) in enumerate(recs))
+    src = tmp_path / "big.fastq"
+    src.write_bytes(text[:-1])                                     # no line terminator at the end of the file
+    assert list(_fastq_general_iterator(text)) == recs
+    got = []
+    for b in fastq.read_batches(str(src), max_reads=4000):
+        got += [(b.headers[i].encode(), b.seq(i), b.qual(i)) for i in range(len(b))]
+    assert got == recs
+    rd = _capi.FastqReader(str(src))
+    assert rd.next() == n
+    dest = rng.choice([0, _capi.TO_UNMAPPED, _capi.TO_AMBIGUOUS, _capi.TO_MAPPED, _capi.TO_MAPPED | _capi.TO_FOCUS], n).astype(np.uint8)
+    label = np.where(dest & _capi.TO_MAPPED, rng.integers(0, 2, n), -1).astype(np.int32)
+    labels = ["Genus_a", "Genus_b"]
+    paths = [str(tmp_path / k) for k in ("u.fq", "a.fq", "m.fq", "f.fq")]
+    (tmp_path / "m.fq").write_bytes(b"@old\nA\n+\nI\n")
+    rd.route(dest, label, labels, paths)
+    rd.close()
+    want = {k: b"" for k in range(4)}
+    want[2] = b"@old\nA\n+\nI\n"
+    for r, (t, s_, q) in enumerate(recs):
+        for k in range(4):
+            if not (dest[r] >> k) & 1:
+                continue
+            head = t
+            if k == 2 and label[r] >= 0:
+                lab = labels[label[r]].encode()
+                first = t.split(None, 1)[0] if t.split() else b""
+                head = lab if not t else (t if first == lab else lab + b" " + t)
+            want[k] += b"@" + head + b"\n" + s_ + b"\n+\n" + q + b"\n"
+    for k in range(4):
+        assert open(paths[k], "rb").read() == want[k], k
+
+
 def test_hitmap_is_sample_hits_with_best_hit(tmp_path):
     """Extending per-id lists part by part and reducing them with best_hit equals the carried summary."""
     import numpy as np
@@ -332,7 +378,7 @@ def test_fastq_reader_against_the_transcribed_biopython_rules(tmp_path):
             want, want_err = None, str(e)
         try:
             got = []
-            for b in fastq.read_batches(str(p), max_reads=int(rng.integers(1, 5))):
+            for b in fastq.read_batches(str(p), max_reads=int(rng.integers(1, 5)), max_bases=int(rng.choice([1, 7, 50, 1 << 29]))):
                 got += [(b.headers[i].encode(), b.seq(i), b.qual(i)) for i in range(len(b))]
             got_err = None
         except ValueError as e:
