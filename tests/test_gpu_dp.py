@@ -104,3 +104,23 @@ def test_batch_shapes_and_tiny_reads(capi, oracle, world):
     reads = [world["seqs"][0][1000:1000 + L] for L in (0, 14, 15, 40, 60, 100, 150, 250, 400)]
     bases, offsets = util.pack_reads(reads)
     _compare_dp(capi, oracle, world, bases, offsets, min_mapq=0)
+
+
+def test_long_reads_and_mixed_lengths(capi, oracle, world):
+    """Reads far longer than the usual 5 kb: more than 64 kernel calls per region (the join works through
+    them 64 at a time), regions whose bases do not fit the stitch kernel's LDS (read in place from HBM),
+    next to short reads in the same batch; low and high error rates."""
+    seqs = world["seqs"]
+    rng = np.random.default_rng(77)
+    reads = []
+    for L, (sub, ins, dele) in ((30_000, (400, 300, 300)), (70_000, (200, 150, 150)), (18_000, (600, 450, 450)), (45_000, (0, 0, 0))):
+        b, o, _ = synth.reads(seqs, 1, L, seed=int(rng.integers(1, 1 << 30)), sub=sub, ins=ins, dele=dele)
+        reads.append(b[o[0]:o[1]])
+    short_b, short_o, _ = synth.reads(seqs, 6, 1200, seed=5)
+    reads += [short_b[short_o[i]:short_o[i + 1]] for i in range(6)]
+    reads.append(util.revcomp(seqs[1][10_000:60_000]))
+    bases, offsets = util.pack_reads(reads)
+    assign, best, nhits = _compare_dp(capi, oracle, world, bases, offsets, min_mapq=0)
+    assert (assign[:4] >= 0).all() and assign[-1] == 1
+    regs = world["eng"].dump(capi.DUMP_REGS, capi.REG_DTYPE)
+    assert regs["n_cigar"].max() > 1024 and (regs["qe"] - regs["qs"]).max() > 40_000
