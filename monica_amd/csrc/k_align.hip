@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 			d.n_seg = 0, d.has_left = d.has_right = 0;
 		} else {
 			Seg *sg = B.segs + s0;
-			int n_tier[17] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+			int n_tier[19] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 			unsigned long long work[4] = { 0, 0, 0, 0 };             // anti-diagonals given to the banded tiers; steps x cells of the packed extensions
 			auto emit = [&](Seg g) {
 				g.read = (int32_t)rd, g.reg = (int32_t)rslot, g.rid = rid, g.rev = rev;
@@ -305,7 +305,24 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 					g.big = 2;                                              // beyond even the large workspace: the batch fails
 					atomicMax(&B.dp_ctr[4], 9ULL);
 				}
-				if (g.big == 1) {
+				bool lfill = false;
+				if (g.big <= 1 && g.kind == 1 && g.w == bw && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= 2047 && g.qlen <= 2047 &&
+				    (g.tlen > FILL_MAX_LEN || g.qlen > FILL_MAX_LEN) && (long long)g.tlen * g.qlen <= B.max_sw_mat) {
+					// a longer gap between two seeds (512 .. 2047 bases): the banded kernel's int32 form, 128 cells when
+					// the bound has a chance there, else 256
+					const int ad = g.tlen > g.qlen ? g.tlen - g.qlen : g.qlen - g.tlen, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
+					int tier = 0;
+					{
+						const int bb = (254 - ad) / 2;
+						const int g1 = B.gap_q + B.gap_e * (bb + 1), g2 = B.gap_q2 + B.gap_e2 * (bb + 1);
+						const int U = B.sc_a * (mn - bb - 1) - 2 * (g1 < g2 ? g1 : g2);
+						if (bb >= 8 && U * 25 <= mn * 32) tier = 17;
+					}
+					if (!tier && (510 - ad) / 2 >= 8) tier = 18;
+					if (tier) g.big = 4 + tier, ++n_tier[tier], lfill = true;
+				}
+				if (lfill) {
+				} else if (g.big == 1) {
 					const unsigned long long bi = atomicAdd(&B.dp_ctr[6], 1ULL);
 					B.big_list[bi] = (int32_t)(sg - B.segs);
 					atomicAdd(&B.dp_ctr[56 + (g.kind == 1 ? 0 : 1)], 1ULL); atomicAdd(&B.dp_ctr[58], (unsigned long long)(g.tlen + g.qlen)); atomicMax(&B.dp_ctr[59], (unsigned long long)(g.tlen > g.qlen ? g.tlen : g.qlen));
@@ -386,11 +403,11 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 			}
 			for (int k = 0; k < 4; ++k) if (work[k]) atomicAdd(&B.dp_ctr[48 + k], work[k]);
 			// the banded kernel's lists: one reservation per region and tier
-			for (int tier = 0; tier < 17; ++tier) {
+			for (int tier = 0; tier < 19; ++tier) {
 				if (n_tier[tier] == 0) continue;
-				const int ci = tier == 16 ? 28 : tier >= 8 ? 24 + tier : tier < 2 ? 10 + tier : tier < 4 ? 14 + tier : tier == 4 ? 20 : tier == 5 ? 22 : 18 + tier;   // 6 -> 24, 7 -> 25; 8.. -> 32..
+				const int ci = tier >= 17 ? 13 + tier : tier == 16 ? 28 : tier >= 8 ? 24 + tier : tier < 2 ? 10 + tier : tier < 4 ? 14 + tier : tier == 4 ? 20 : tier == 5 ? 22 : 18 + tier;   // 6 -> 24, 7 -> 25; 8.. -> 32..
 				unsigned long long fi = atomicAdd(&B.dp_ctr[ci], (unsigned long long)n_tier[tier]);
-				int32_t *lst = tier == 16 ? B.mid_list : tier >= 8 ? B.extp_list + (int64_t)(tier - 8) * B.seg_cap
+				int32_t *lst = tier == 17 ? B.lfill_list1 : tier == 18 ? B.lfill_list2 : tier == 16 ? B.mid_list : tier >= 8 ? B.extp_list + (int64_t)(tier - 8) * B.seg_cap
 				             : tier == 0 ? B.fill_list1 : tier == 1 ? B.fill_list2 : tier == 2 ? B.ext_list1 : tier == 3 ? B.ext_list2 : tier == 4 ? B.gen_list
 				             : tier == 5 ? B.fill_list3 : tier == 6 ? B.ext_list3 : B.ext_list4;
 				for (int k = 0; k < n_seg; ++k)
@@ -1288,6 +1305,7 @@ __global__ void mnc_dp_round(Batch B, int first)
 	B.dp_ctr[5] = 0;
 	B.dp_ctr[6] = 0, B.dp_ctr[7] = 0;
 	for (int k = 10; k < 48; ++k) B.dp_ctr[k] = 0;
+	B.dp_ctr[60] = B.dp_ctr[61] = 0;
 	if (first) for (int k = 48; k < 64; ++k) B.dp_ctr[k] = 0;   // banded kernel: list lengths 10 / 11 / 12 (tier 1, tier 2, handed back), queues 13 / 14 / 15;
 	                                                 // extension kernel: lists 16 / 17, queues 18 / 19; literal kernel's first pass: list 20, queue 21; banded kernel, 128 cells: list 22, queue 23; extension kernel, 128 / 256 cells: lists 24 / 25, queues 26 / 27
 }

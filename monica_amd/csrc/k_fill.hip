@@ -100,7 +100,7 @@ __host__ __device__ __forceinline__ int dp_band_bound(int n, int m, int kmin, in
 // One anti-diagonal of the banded fill.  ODD = 0: t0 stays, the upper neighbour is the previous
 // cell of the band; 1: t0 advances, the left neighbour is the next cell.  `H` holds H of the same
 // cells two steps back (same parity) and receives this step's.
-template <int LANES, int CPL, int ODD>
+template <int LANES, int CPL, int ODD, int MAXLEN>
 __device__ __forceinline__ void fill_step(const int n, const int m, const int rows, const int kmin, const int a, const int bmis, const int scN,
                                           const int q, const int e, const int q2, const int e2, const uint8_t *st, const uint8_t *sq,
                                           int r, int L, int (&H)[CPL], int (&En)[CPL], int (&E2n)[CPL],
@@ -138,7 +138,7 @@ __device__ __forceinline__ void fill_step(const int n, const int m, const int ro
 		// row / column below replaces them), and the band has no inside edge to guard (fill_band).
 		const int t = t0 + L + LANES * k, j = r - t;
 		const bool act = r < rows && (unsigned)t < (unsigned)n && (unsigned)j < (unsigned)m;
-		const int tc = t < 0 ? 0 : t > FILL_MAX_LEN ? FILL_MAX_LEN : t, jc = j < 0 ? 0 : j > FILL_MAX_LEN ? FILL_MAX_LEN : j;
+		const int tc = t < 0 ? 0 : t > MAXLEN ? MAXLEN : t, jc = j < 0 ? 0 : j > MAXLEN ? MAXLEN : j;
 		const int ct = st[tc], cq = sq[jc];
 		const int sc = (ct == 4 || cq == 4) ? scN : ct == cq ? a : bmis;
 		int hd = H[k], vE = sE[k], vE2 = sE2[k], vF = sF[k], vF2 = sF2[k];
@@ -165,22 +165,24 @@ __device__ __forceinline__ void fill_step(const int n, const int m, const int ro
 	}
 }
 
-// LANES = 32: two segments per wave; 64: one; CPL cells per lane (64 x 2: a band of 128 cells for
-// the long gaps whose bound needs it).  Proof failures go to `next_list` (the wider tier, or the
-// literal kernel), CIGARs whose walk shows a large score drop to `fb_list` (the literal kernel
-// runs minimap2's exact second pass).
-template <int LANES, int CPL>
+// The int32 form of the banded kernel (one cell per lane and register, absolute 32-bit scores, the
+// ambiguity score included): what the packed kernel below cannot hold -- gaps between seeds of more
+// than 511 bases, whose scores outgrow 12 bits.  64 lanes x CPL cells (a band of 128 or 256 cells),
+// sequences up to MAXLEN.  Proof failures go to `next_list` (the wider tier, or the literal kernel),
+// CIGARs whose walk shows a large score drop to `fb_list` (the literal kernel runs minimap2's exact
+// second pass).
+template <int LANES, int CPL, int MAXLEN, int CIGMAX>
 __global__ __launch_bounds__(64) void mnc_dp_fill(Batch B, const int32_t *list, int ctr_n, int ctr_q, int32_t *next_list, int ctr_next,
                                                   int32_t *fb_list, int ctr_fb, uint8_t *p_all)
 {
 	constexpr int SEGS = 64 / LANES, W = LANES * CPL, ROWB = 64 * CPL;   // cells per segment and step; bytes per step of the wave
-	__shared__ uint8_t s_t[SEGS][FILL_MAX_LEN + 1], s_q[SEGS][FILL_MAX_LEN + 1];
+	__shared__ uint8_t s_t[SEGS][MAXLEN + 1], s_q[SEGS][MAXLEN + 1];
 	__shared__ __align__(16) uint8_t s_win[SEGS][FILL_WIN * W];
-	__shared__ uint32_t s_cg[SEGS][FILL_CIG_MAX];            // a gap filling's CIGAR: a few dozen operations (beyond: handed on)
+	__shared__ uint32_t s_cg[SEGS][CIGMAX];                  // the gap filling's CIGAR (beyond: handed on)
 	const int lane = threadIdx.x, sg = lane / LANES, L = lane % LANES, lead = sg * LANES;
 	const bool leader = L == 0;
 	const int a = B.sc_a, bmis = -B.sc_b, scN = -B.sc_ambi, q = B.gap_q, e = B.gap_e, q2 = B.gap_q2, e2 = B.gap_e2;
-	uint8_t *p_wave = p_all + (size_t)blockIdx.x * (FILL_P_SLOT * CPL);
+	uint8_t *p_wave = p_all + (size_t)blockIdx.x * ((size_t)(2 * MAXLEN + FILL_WIN) * 64 * CPL);
 	const unsigned long long n_items = B.dp_ctr[ctr_n];
 	for (;;) {
 		unsigned long long q0 = 0;
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(64) void mnc_dp_fill(Batch B, const int32_t *list, 
 		const int n = g.tlen, m = g.qlen;
 		int b, kmin, kmax;
 		fill_band(n, m, W, b, kmin, kmax);
-		bool ok = has && n >= 1 && m >= 1 && n <= FILL_MAX_LEN && m <= FILL_MAX_LEN && b >= FILL_MIN_BAND;
+		bool ok = has && n >= 1 && m >= 1 && n <= MAXLEN && m <= MAXLEN && b >= FILL_MIN_BAND;
 		// ---- sequences
 		if (ok) {
 			const uint8_t *read = B.bases + B.offsets[g.read];
@@ -231,10 +233,10 @@ __global__ __launch_bounds__(64) void mnc_dp_fill(Batch B, const int32_t *list, 
 		(void)H1; (void)H2;
 		int r = 0;
 		for (; r + 1 < max_rows; r += 2, prow += 2 * ROWB) {
-			fill_step<LANES, CPL, 0>(n, m, rows, kmin, a, bmis, scN, q, e, q2, e2, st, sq, r, L, Heven, En, E2n, Fn, F2n, Sc, prow);
-			fill_step<LANES, CPL, 1>(n, m, rows, kmin, a, bmis, scN, q, e, q2, e2, st, sq, r + 1, L, Hodd, En, E2n, Fn, F2n, Sc, prow + ROWB);
+			fill_step<LANES, CPL, 0, MAXLEN>(n, m, rows, kmin, a, bmis, scN, q, e, q2, e2, st, sq, r, L, Heven, En, E2n, Fn, F2n, Sc, prow);
+			fill_step<LANES, CPL, 1, MAXLEN>(n, m, rows, kmin, a, bmis, scN, q, e, q2, e2, st, sq, r + 1, L, Hodd, En, E2n, Fn, F2n, Sc, prow + ROWB);
 		}
-		if (r < max_rows) fill_step<LANES, CPL, 0>(n, m, rows, kmin, a, bmis, scN, q, e, q2, e2, st, sq, r, L, Heven, En, E2n, Fn, F2n, Sc, prow);
+		if (r < max_rows) fill_step<LANES, CPL, 0, MAXLEN>(n, m, rows, kmin, a, bmis, scN, q, e, q2, e2, st, sq, r, L, Heven, En, E2n, Fn, F2n, Sc, prow);
 		// ---- the proof: every path that leaves the band scores at most U
 		int S = FILL_NEG;
 		{
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(64) void mnc_dp_fill(Batch B, const int32_t *list, 
 					if (cur != 0 && (cur & 0xf) == op) cur += 1u << 4;
 					else {
 						if (cur != 0) {
-							if (n_c >= FILL_CIG_MAX - 4) { walking = false, to_fb = true; break; }   // more operations than the scratch holds
+							if (n_c >= CIGMAX - 4) { walking = false, to_fb = true; break; }   // more operations than the scratch holds
 							s_cg[sg][n_c++] = cur;
 						}
 						cur = 1u << 4 | op;
@@ -1370,6 +1372,15 @@ void launch_dp_extp(const Batch &B, int cells, int rgt, const int32_t *list, int
 #undef MNC_EXTP
 }
 
+constexpr int LFILL_MAX_LEN = 2047, LFILL_CIG_MAX = 1024;
+size_t dp_lfill_p_slot() { return (size_t)(2 * LFILL_MAX_LEN + FILL_WIN) * 64 * 4; }
+// gaps between seeds of 512 .. 2047 bases: the int32 banded kernel, 128 cells, then 256
+void launch_dp_lfill(const Batch &B, int cells, const int32_t *list, int ctr_n, int ctr_q, int32_t *next_list, int ctr_next,
+                     int32_t *fb_list, int ctr_fb, uint8_t *p_all, int n_wg, hipStream_t st)
+{
+	if (cells == 128) hipLaunchKernelGGL((mnc_dp_fill<64, 2, LFILL_MAX_LEN, LFILL_CIG_MAX>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all);
+	else hipLaunchKernelGGL((mnc_dp_fill<64, 4, LFILL_MAX_LEN, LFILL_CIG_MAX>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all);
+}
 size_t dp_fill_p_slot() { return FILL_P_SLOT; }
 size_t dp_fillp_slot() { return FILLP_SLOT; }
 size_t dp_fillp_cig_slot() { return (size_t)64 * FILL_CIG_MAX * 4; }
