@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 			d.n_seg = 0, d.has_left = d.has_right = 0;
 		} else {
 			Seg *sg = B.segs + s0;
-			int n_tier[19] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+			int n_tier[20] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 			unsigned long long work[4] = { 0, 0, 0, 0 };             // anti-diagonals given to the banded tiers; steps x cells of the packed extensions
 			auto emit = [&](Seg g) {
 				g.read = (int32_t)rd, g.reg = (int32_t)rslot, g.rid = rid, g.rev = rev;
@@ -367,6 +367,10 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 					const int tier = mn <= 32 ? 3 : mn <= 64 ? 4 : mn <= 128 ? 7 : 8;
 					g.big = 3 + tier, ++n_tier[tier - 1];
 				}
+				if (g.big == 0 && g.kind != 1 && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= g.w && g.qlen <= g.w &&
+				    g.tlen + g.qlen - 1 <= 2 * 1535 && (g.tlen < g.qlen ? g.tlen : g.qlen) <= 512) {
+					g.big = 4 + 19, ++n_tier[19];                           // a longer extension: the step-by-step kernel, eight cells per lane
+				}
 				if (g.big == 0) {
 					// the literal kernel: its first pass with everything in LDS, or from the start on its own list
 					const bool all_lds = 12 * T + Q <= B.lds0_state && p_bytes <= B.lds0_p && g.qlen + g.tlen + 2 <= B.lds0_cig;
@@ -403,11 +407,11 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 			}
 			for (int k = 0; k < 4; ++k) if (work[k]) atomicAdd(&B.dp_ctr[48 + k], work[k]);
 			// the banded kernel's lists: one reservation per region and tier
-			for (int tier = 0; tier < 19; ++tier) {
+			for (int tier = 0; tier < 20; ++tier) {
 				if (n_tier[tier] == 0) continue;
-				const int ci = tier >= 17 ? 13 + tier : tier == 16 ? 28 : tier >= 8 ? 24 + tier : tier < 2 ? 10 + tier : tier < 4 ? 14 + tier : tier == 4 ? 20 : tier == 5 ? 22 : 18 + tier;   // 6 -> 24, 7 -> 25; 8.. -> 32..
+				const int ci = tier == 19 ? 62 : tier >= 17 ? 13 + tier : tier == 16 ? 28 : tier >= 8 ? 24 + tier : tier < 2 ? 10 + tier : tier < 4 ? 14 + tier : tier == 4 ? 20 : tier == 5 ? 22 : 18 + tier;   // 6 -> 24, 7 -> 25; 8.. -> 32..
 				unsigned long long fi = atomicAdd(&B.dp_ctr[ci], (unsigned long long)n_tier[tier]);
-				int32_t *lst = tier == 17 ? B.lfill_list1 : tier == 18 ? B.lfill_list2 : tier == 16 ? B.mid_list : tier >= 8 ? B.extp_list + (int64_t)(tier - 8) * B.seg_cap
+				int32_t *lst = tier == 19 ? B.lext_list : tier == 17 ? B.lfill_list1 : tier == 18 ? B.lfill_list2 : tier == 16 ? B.mid_list : tier >= 8 ? B.extp_list + (int64_t)(tier - 8) * B.seg_cap
 				             : tier == 0 ? B.fill_list1 : tier == 1 ? B.fill_list2 : tier == 2 ? B.ext_list1 : tier == 3 ? B.ext_list2 : tier == 4 ? B.gen_list
 				             : tier == 5 ? B.fill_list3 : tier == 6 ? B.ext_list3 : B.ext_list4;
 				for (int k = 0; k < n_seg; ++k)
@@ -1305,7 +1309,7 @@ __global__ void mnc_dp_round(Batch B, int first)
 	B.dp_ctr[5] = 0;
 	B.dp_ctr[6] = 0, B.dp_ctr[7] = 0;
 	for (int k = 10; k < 48; ++k) B.dp_ctr[k] = 0;
-	B.dp_ctr[60] = B.dp_ctr[61] = 0;
+	B.dp_ctr[60] = B.dp_ctr[61] = B.dp_ctr[62] = B.dp_ctr[63] = 0;
 	if (first) for (int k = 48; k < 64; ++k) B.dp_ctr[k] = 0;   // banded kernel: list lengths 10 / 11 / 12 (tier 1, tier 2, handed back), queues 13 / 14 / 15;
 	                                                 // extension kernel: lists 16 / 17, queues 18 / 19; literal kernel's first pass: list 20, queue 21; banded kernel, 128 cells: list 22, queue 23; extension kernel, 128 / 256 cells: lists 24 / 25, queues 26 / 27
 }

@@ -503,15 +503,18 @@ __global__ __launch_bounds__(64) void mnc_dp_fillp(Batch B, const int32_t *list,
 	const unsigned long long n_items = B.dp_ctr[ctr_n];
 	const unsigned long long segmask = LANES == 64 ? ~0ULL : ((1ULL << (LANES & 63)) - 1) << lead;
 	const int thr = B.zdrop_inv < B.zdrop ? B.zdrop_inv : B.zdrop;
+	// few segments (a micro-batch): fewer forward passes per group, so that every workgroup has some
+	int g_eff = (int)((n_items + (unsigned long long)gridDim.x * SEGS - 1) / ((unsigned long long)gridDim.x * SEGS));
+	g_eff = g_eff < 1 ? 1 : g_eff > FILLP_G ? FILLP_G : g_eff;
 	for (;;) {
 		unsigned long long q0 = 0;
-		if (lane == 0) q0 = atomicAdd(&B.dp_ctr[ctr_q], (unsigned long long)NSEG);
+		if (lane == 0) q0 = atomicAdd(&B.dp_ctr[ctr_q], (unsigned long long)(g_eff * SEGS));
 		q0 = (unsigned long long)__shfl((long long)q0, 0);
 		if (q0 >= n_items) break;                              // every wave gets here: the queue is finite
 		s_state[lane] = 0;
 		fill_order();
 		// ================================================ forward passes
-		for (int u = 0; u < FILLP_G; ++u) {
+		for (int u = 0; u < g_eff; ++u) {
 			if (q0 + (unsigned long long)u * SEGS >= n_items) break;
 			const unsigned long long item = q0 + (unsigned long long)u * SEGS + sg;
 			const bool has = item < n_items;
@@ -607,7 +610,7 @@ __global__ __launch_bounds__(64) void mnc_dp_fillp(Batch B, const int32_t *list,
 		}
 		fill_order_mem();                                      // the direction bytes are in memory before the walks read them
 		// ================================================ one walk per lane
-		int state_w = lane < NSEG ? s_state[lane] : 0;
+		int state_w = lane < g_eff * SEGS ? s_state[lane] : 0;
 		const int n = s_n[lane], m = s_m[lane], kmin = s_kmin[lane], S = s_S[lane];
 		const long long si = s_si[lane];
 		int n_c = 0;
@@ -738,10 +741,10 @@ __global__ __launch_bounds__(64) void mnc_dp_fillp(Batch B, const int32_t *list,
 // interleaved lanes, then the tail: DPP max-reduce of (H, rank) keys), updates the best cell or
 // tests the Z-drop against it, and tracks the best score in the query's last row.  The left
 // extension runs on reversed sequences with gaps right-aligned (ties go to the later candidate).
-template <int LANES, int CPL>
+template <int LANES, int CPL, int MAXLEN>
 __global__ __launch_bounds__(64) void mnc_dp_ext(Batch B, const int32_t *list, int ctr_n, int ctr_q, int32_t *fb_list, int ctr_fb, uint8_t *p_all)
 {
-	constexpr int SEGS = 64 / LANES, W = LANES * CPL, ROWB = 64 * CPL, SEQ = 2 * FILL_MAX_LEN + 2;
+	constexpr int SEGS = 64 / LANES, W = LANES * CPL, ROWB = 64 * CPL, SEQ = 2 * MAXLEN + 2;
 	static_assert(CPL == 1 || LANES == 64, "several cells per lane: one segment per wave");
 	__shared__ uint8_t s_t[SEGS][SEQ], s_q[SEGS][SEQ];
 	__shared__ __align__(16) uint8_t s_win[SEGS][FILL_WIN * W];
@@ -749,7 +752,7 @@ __global__ __launch_bounds__(64) void mnc_dp_ext(Batch B, const int32_t *list, i
 	const int lane = threadIdx.x, sg = lane / LANES, L = lane % LANES, lead = sg * LANES;
 	const bool leader = L == 0;
 	const int a = B.sc_a, bmis = -B.sc_b, scN = -B.sc_ambi, q = B.gap_q, e = B.gap_e, q2 = B.gap_q2, e2 = B.gap_e2;
-	uint8_t *p_wave = p_all + (size_t)blockIdx.x * (FILL_P_SLOT * CPL);
+	uint8_t *p_wave = p_all + (size_t)blockIdx.x * ((size_t)(2 * MAXLEN + FILL_WIN) * 64 * CPL);
 	const unsigned long long n_items = B.dp_ctr[ctr_n];
 	for (;;) {
 		unsigned long long q0 = 0;
@@ -766,7 +769,7 @@ __global__ __launch_bounds__(64) void mnc_dp_ext(Batch B, const int32_t *list, i
 		}
 		const int n = g.tlen, m = g.qlen;
 		const int mn = n < m ? n : m;
-		const bool ok = has && n >= 1 && m >= 1 && mn <= W && n + m - 1 <= 2 * FILL_MAX_LEN;
+		const bool ok = has && n >= 1 && m >= 1 && mn <= W && n + m - 1 <= 2 * MAXLEN;
 		const int rgt = (g.flag & EZ_RIGHT) ? 1 : 0;          // gaps right-aligned: a later candidate wins a tie
 		if (ok) {
 			const uint8_t *read = B.bases + B.offsets[g.read];
@@ -1381,6 +1384,13 @@ void launch_dp_lfill(const Batch &B, int cells, const int32_t *list, int ctr_n, 
 	if (cells == 128) hipLaunchKernelGGL((mnc_dp_fill<64, 2, LFILL_MAX_LEN, LFILL_CIG_MAX>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all);
 	else hipLaunchKernelGGL((mnc_dp_fill<64, 4, LFILL_MAX_LEN, LFILL_CIG_MAX>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all);
 }
+constexpr int LEXT_MAX_LEN = 1535;
+size_t dp_lext_p_slot() { return (size_t)(2 * LEXT_MAX_LEN + FILL_WIN) * 64 * 8; }
+// extensions of 257 .. 512 bases on the shorter side: the step-by-step kernel with eight cells per lane
+void launch_dp_lext(const Batch &B, const int32_t *list, int ctr_n, int ctr_q, int32_t *fb_list, int ctr_fb, uint8_t *p_all, int n_wg, hipStream_t st)
+{
+	hipLaunchKernelGGL((mnc_dp_ext<64, 8, LEXT_MAX_LEN>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, fb_list, ctr_fb, p_all);
+}
 size_t dp_fill_p_slot() { return FILL_P_SLOT; }
 size_t dp_fillp_slot() { return FILLP_SLOT; }
 size_t dp_fillp_cig_slot() { return (size_t)64 * FILL_CIG_MAX * 4; }
@@ -1395,10 +1405,10 @@ void launch_dp_fill(const Batch &B, int lanes, const int32_t *list, int ctr_n, i
 
 void launch_dp_ext(const Batch &B, int lanes, const int32_t *list, int ctr_n, int ctr_q, int32_t *fb_list, int ctr_fb, uint8_t *p_all, int n_wg, hipStream_t st)
 {
-	if (lanes == 32) hipLaunchKernelGGL((mnc_dp_ext<32, 1>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, fb_list, ctr_fb, p_all);
-	else if (lanes == 64) hipLaunchKernelGGL((mnc_dp_ext<64, 1>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, fb_list, ctr_fb, p_all);
-	else if (lanes == 128) hipLaunchKernelGGL((mnc_dp_ext<64, 2>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, fb_list, ctr_fb, p_all);
-	else hipLaunchKernelGGL((mnc_dp_ext<64, 4>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, fb_list, ctr_fb, p_all);
+	if (lanes == 32) hipLaunchKernelGGL((mnc_dp_ext<32, 1, FILL_MAX_LEN>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, fb_list, ctr_fb, p_all);
+	else if (lanes == 64) hipLaunchKernelGGL((mnc_dp_ext<64, 1, FILL_MAX_LEN>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, fb_list, ctr_fb, p_all);
+	else if (lanes == 128) hipLaunchKernelGGL((mnc_dp_ext<64, 2, FILL_MAX_LEN>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, fb_list, ctr_fb, p_all);
+	else hipLaunchKernelGGL((mnc_dp_ext<64, 4, FILL_MAX_LEN>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, fb_list, ctr_fb, p_all);
 }
 
 } // namespace mnc

@@ -8,5 +8,5 @@ idx = max(i for i, r in enumerate(rows) if "mnc_pack_bases" in r["Kernel_Name"])
 t0 = int(rows[idx]["Start_Timestamp"])
 for r in rows[idx:]:
     s, e = (int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - t0) / 1e6
-    if e - s > 0.15:
+    if e - s > float(sys.argv[2] if len(sys.argv) > 2 else 0.15):
         print(f"{s:8.2f} {e:8.2f} {e - s:7.2f}  {r['Kernel_Name'].split('(')[0][:60]}  grid={r.get('Grid_Size','')} q={r.get('Queue_Id','')}")
