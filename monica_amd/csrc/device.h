@@ -89,6 +89,7 @@ struct ChainRec {
 constexpr uint64_t SEED_LONG_JOIN = 1ULL << 40, SEED_IGNORE = 1ULL << 41, SEED_TANDEM = 1ULL << 42;
 constexpr int REG_HAS_DP = 1, REG_SPLIT_L = 2, REG_SPLIT_R = 4, REG_SPLIT_INV = 8;
 constexpr int EZ_RIGHT = 0x02, EZ_APPROX_MAX = 0x08, EZ_EXTZ_ONLY = 0x40, EZ_REV_CIGAR = 0x80;
+constexpr int SEG_NEEDS_BIG_WS = 0x10000;                 // Seg.flag, ours: the literal kernel needs its large workspace for this call
 constexpr int DP_NEG_INF = -0x40000000;
 constexpr int FILL_MAX_LEN = 511;     // longest target / query of a gap filling the banded kernel (k_fill.hip) takes
 
@@ -193,6 +194,7 @@ struct Batch {
 	int64_t *stats;               // device counters (see mnc_engine_get_counters)
 	// ---- base-level alignment stage (contract MNC_CONTRACT_DP)
 	int contract;
+	int debug_route;              // test switch: 1 no packed extension kernel, 2 no packed gap-filling kernel, 4 no long tiers
 	int fill_pred;                // a gap filling tries the 32-lane tier when its bound is below fill_pred / 25 per base
 	const uint32_t *seq4;         // contig bases, 4 bits each
 	const int64_t *seq_off;       // [n_contigs + 1]
@@ -218,6 +220,7 @@ struct Batch {
 	int32_t *ext_list3, *ext_list4;               // ... 128 / 256 cells (two / four per lane)
 	int32_t *gen_list;                            // the literal kernel's first pass
 	int32_t *lfill_list1, *lfill_list2;           // gaps of 512 .. 2047 bases, int32 banded kernel (128 / 256 cells): lengths dp_ctr[30] / [31], queues [60] / [61]
+	int32_t *bigfb_list;                          // calls the banded kernel hands back that need the literal kernel's large workspace: length dp_ctr[56], queue [57]
 	int32_t *lext_list;                           // extensions of 257 .. 512 bases on the shorter side (step-by-step kernel, 8 cells per lane): length dp_ctr[62], queue [63]
 	int32_t *mid_list;                            // the literal kernel, segments its first pass' LDS layout cannot hold: lengths dp_ctr[28], queue [29]
 	int lds0_state, lds0_p, lds0_cig;             // that layout

@@ -64,7 +64,7 @@ constexpr int DP_WG_FILL = 256 * 16, DP_WG_EXT = 256 * 8;
 // workspace classes of the alignment kernel: a normal slot per workgroup, a few large ones
 constexpr int DP_LDS_BYTES = 16 * 1024;
 constexpr int DP_LDS0_STATE = 4 * 1024, DP_LDS0_P = 10 * 1024, DP_LDS0_CIG = 256;   // pass 0: 15 KB per workgroup
-constexpr int DP_WG_SMALL = 2048, DP_WG_BIG = 24, DP_WG_MID = 2048, DP_WG_LFILL = 1024, DP_WG_LEXT = 512;
+constexpr int DP_WG_SMALL = 2048, DP_WG_BIG = 8, DP_WG_MID = 512, DP_WG_LFILL = 1024, DP_WG_LEXT = 512;
 constexpr long long DP_STATE_SMALL = 96 * 1024, DP_P_SMALL = 1 << 20, DP_CIG_SMALL = 4096;
 constexpr long long DP_STATE_BIG = 13 * 32768, DP_P_BIG = 256LL << 20, DP_CIG_BIG = 65536;
 void launch_gather_hits(const Batch &B, const mnc_hit_t *gated, const int64_t *hit_off, mnc_hit_t *out, hipStream_t st);
@@ -195,6 +195,32 @@ struct Buf {
 	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 	template <class T> T *as() const { return reinterpret_cast<T*>(p); }
 };
+
+// The alignment kernels' scratch -- direction bytes of the persistent workgroups, CIGAR scratch, the
+// literal kernel's workspaces: ~30 GB whatever the batch -- exists once per device and is lent to one
+// engine at a time for the alignment stage of its batch (the kernels fill the chip: two engines
+// would not run them faster side by side).  monica's thread pool makes an engine per thread.
+struct SharedWs {
+	std::mutex mu;
+	int refs = 0;
+	Buf fill_p, fill_cig, extp_p, extp_cig, ext_p, lfill_p, lext_p, dp_ws, dp_ws_mid, dp_ws_big;
+	void release() { for (Buf *b : { &fill_p, &fill_cig, &extp_p, &extp_cig, &ext_p, &lfill_p, &lext_p, &dp_ws, &dp_ws_mid, &dp_ws_big }) b->release(); }
+};
+static std::mutex g_ws_mu;
+static SharedWs *g_ws[64];
+static SharedWs *shared_ws(int device, int add_ref)
+{
+	std::lock_guard<std::mutex> g(g_ws_mu);
+	if (device < 0 || device >= 64) return nullptr;
+	if (!g_ws[device]) g_ws[device] = new SharedWs();
+	SharedWs *w = g_ws[device];
+	w->refs += add_ref;
+	if (w->refs == 0 && add_ref < 0) {                       // the last engine of the device is gone
+		std::lock_guard<std::mutex> h(w->mu);
+		w->release();
+	}
+	return w;
+}
 
 // ================================================================ index residency
 static int check_device(int device)
@@ -380,8 +406,9 @@ struct mnc_engine {
 	Buf stats, cls_count, cls_list;
 	// base-level alignment stage
 	int contract = MNC_CONTRACT_DP;
-	Buf ca, ca_cnt, chain_dst, regdp, segs, cig_seg, cig_reg, dp_ctr, work_a, work_b, big_list, reg_cnt, regs2, dp_ws, dp_ws_big;
-	Buf fill1, fill2, fill3, fill_fb, fill_p, fill_cig, extp, extp_p, extp_cig, mid_list, dp_ws_mid, lfill1, lfill2, lfill_p, lext, lext_p, ext1, ext2, ext3, ext4, ext_p, gen_list;
+	Buf ca, ca_cnt, chain_dst, regdp, segs, cig_seg, cig_reg, dp_ctr, work_a, work_b, big_list, reg_cnt, regs2;
+	SharedWs *ws = nullptr;                  // the device's alignment scratch (held during the alignment stage only)
+	Buf fill1, fill2, fill3, fill_fb, extp, mid_list, lfill1, lfill2, lext, bigfb, ext1, ext2, ext3, ext4, gen_list;
 	size_t seg_cap_override = 0, cig_cap_override = 0;
 	int cur_max_read_len = 0;                // of the batch being classified (sizes the stitch kernel's LDS)
 	int debug = 0;                           // bit mask (tests): 2 stress build of the chaining ring, 4 displacement bytes read from HBM, 0x10000 alignment kernels one at a time (with stage timers)
@@ -485,12 +512,13 @@ extern "C" void mnc_engine_destroy(mnc_engine *e)
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
 	Buf *all[] = { &e->gap_lut, &e->logf_lut, &e->logf_a_lut, &e->ca, &e->ca_cnt, &e->chain_dst, &e->regdp, &e->segs, &e->cig_seg, &e->cig_reg, &e->dp_ctr,
-	               &e->work_a, &e->work_b, &e->big_list, &e->reg_cnt, &e->regs2, &e->dp_ws, &e->dp_ws_big, &e->fill1, &e->fill2, &e->fill3, &e->fill_fb, &e->fill_p, &e->fill_cig, &e->extp, &e->extp_p, &e->extp_cig, &e->mid_list, &e->dp_ws_mid, &e->lfill1, &e->lfill2, &e->lfill_p, &e->lext, &e->lext_p, &e->ext1, &e->ext2, &e->ext3, &e->ext4, &e->ext_p, &e->gen_list, &e->in_bases, &e->in_offsets, &e->out_assign, &e->out_best, &e->out_nhits,
+	               &e->work_a, &e->work_b, &e->big_list, &e->reg_cnt, &e->regs2, &e->fill1, &e->fill2, &e->fill3, &e->fill_fb, &e->extp, &e->mid_list, &e->lfill1, &e->lfill2, &e->lext, &e->bigfb, &e->ext1, &e->ext2, &e->ext3, &e->ext4, &e->gen_list, &e->in_bases, &e->in_offsets, &e->out_assign, &e->out_best, &e->out_nhits,
 	               &e->packed, &e->mz, &e->hits, &e->hist_tm, &e->q_off, &e->qrec, &e->bhits, &e->bhit_cnt, &e->ambig, &e->mz_cnt, &e->hit_cnt, &e->rep_len, &e->an_cnt, &e->an_off,
 	               &e->n_chain, &e->n_reg, &e->best_mlen, &e->hist_sums, &e->hist_offs, &e->scan_sums, &e->hit_off, &e->a, &e->f, &e->p, &e->v, &e->t, &e->u,
 	               &e->chains_tmp, &e->regs, &e->regx, &e->k64a, &e->k64b, &e->tmp_i32, &e->gated,
 	               &e->hits_csr, &e->stats, &e->cls_count, &e->cls_list };
 	for (Buf *b : all) b->release();
+	if (e->ws) { (void)shared_ws(e->device, -1); e->ws = nullptr; }
 	for (int s = 0; s < MNC_N_STAGES; ++s) for (int k = 0; k < 2; ++k) if (e->ev[s][k]) (void)hipEventDestroy(e->ev[s][k]);
 	for (int k = 0; k < mnc_engine::N_SIDE; ++k) {
 		if (e->side[k]) (void)hipStreamDestroy(e->side[k]);
@@ -510,6 +538,7 @@ extern "C" int mnc_engine_create(mnc_index *idx, int device, mnc_engine **out)
 	mnc_engine *e = new (std::nothrow) mnc_engine;
 	if (!e) return MNC_ERR_NOMEM;
 	e->idx = idx, e->device = device;
+	e->ws = shared_ws(device, +1);
 	int rc = index_upload(idx, device, &e->didx);
 	if (rc) { delete e; return rc; }
 	hipError_t he = hipSetDevice(device);
@@ -628,34 +657,35 @@ static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream
 	const bool timed = e->profiling && s0 == s1;
 	auto mark = [&](int stage, int which) { if (timed) { (void)hipEventRecord(e->ev[stage][which], s0); if (which) e->ev_used[stage] = true; } };
 	mark(MNC_STAGE_DP_FILL_T1, 0);
-	launch_dp_fill(B, 32, B.fill_list1, 10, 13, B.fill_list2, 11, B.fill_fb, 12, e->fill_p.as<uint8_t>(), e->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
+	launch_dp_fill(B, 32, B.fill_list1, 10, 13, B.fill_list2, 11, B.fill_fb, 12, e->ws->fill_p.as<uint8_t>(), e->ws->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
 	mark(MNC_STAGE_DP_FILL_T1, 1), mark(MNC_STAGE_DP_FILL_T2, 0);
-	launch_dp_fill(B, 64, B.fill_list2, 11, 14, B.fill_list3, 22, B.fill_fb, 12, e->fill_p.as<uint8_t>(), e->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
+	launch_dp_fill(B, 64, B.fill_list2, 11, 14, B.fill_list3, 22, B.fill_fb, 12, e->ws->fill_p.as<uint8_t>(), e->ws->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
 	mark(MNC_STAGE_DP_FILL_T2, 1), mark(MNC_STAGE_DP_FILL_T3, 0);
-	launch_dp_fill(B, 128, B.fill_list3, 22, 23, B.fill_fb, 12, B.fill_fb, 12, e->fill_p.as<uint8_t>(), e->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
+	launch_dp_fill(B, 128, B.fill_list3, 22, 23, B.fill_fb, 12, B.fill_fb, 12, e->ws->fill_p.as<uint8_t>(), e->ws->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
 	// the long gaps last on this stream: a thousand single waves, beside whatever the other streams still run
-	launch_dp_lfill(B, 128, B.lfill_list1, 30, 60, B.lfill_list2, 31, B.fill_fb, 12, e->lfill_p.as<uint8_t>(), DP_WG_LFILL, s0);
-	launch_dp_lfill(B, 256, B.lfill_list2, 31, 61, B.fill_fb, 12, B.fill_fb, 12, e->lfill_p.as<uint8_t>(), DP_WG_LFILL, s0);
+	launch_dp_lfill(B, 128, B.lfill_list1, 30, 60, B.lfill_list2, 31, B.fill_fb, 12, e->ws->lfill_p.as<uint8_t>(), DP_WG_LFILL, s0);
+	launch_dp_lfill(B, 256, B.lfill_list2, 31, 61, B.fill_fb, 12, B.fill_fb, 12, e->ws->lfill_p.as<uint8_t>(), DP_WG_LFILL, s0);
 	mark(MNC_STAGE_DP_FILL_T3, 1), mark(MNC_STAGE_DP_EXT, 0);
 	for (int i = 0; i < 8; ++i)
-		launch_dp_extp(B, 32 << (i >> 1), i & 1, B.extp_list + (int64_t)i * B.seg_cap, 32 + i, 40 + i, e->extp_p.as<uint8_t>(), e->extp_cig.as<uint32_t>(), DP_WG_EXT, s1);
-	launch_dp_ext(B, 32, B.ext_list1, 16, 18, B.fill_fb, 12, e->ext_p.as<uint8_t>(), DP_WG_EXT, s1);
-	launch_dp_ext(B, 64, B.ext_list2, 17, 19, B.fill_fb, 12, e->ext_p.as<uint8_t>(), DP_WG_EXT, s1);
-	launch_dp_ext(B, 128, B.ext_list3, 24, 26, B.fill_fb, 12, e->ext_p.as<uint8_t>(), DP_WG_EXT / 2, s1);
-	launch_dp_ext(B, 256, B.ext_list4, 25, 27, B.fill_fb, 12, e->ext_p.as<uint8_t>(), DP_WG_EXT / 4, s1);
+		launch_dp_extp(B, 32 << (i >> 1), i & 1, B.extp_list + (int64_t)i * B.seg_cap, 32 + i, 40 + i, e->ws->extp_p.as<uint8_t>(), e->ws->extp_cig.as<uint32_t>(), DP_WG_EXT, s1);
+	launch_dp_ext(B, 32, B.ext_list1, 16, 18, B.fill_fb, 12, e->ws->ext_p.as<uint8_t>(), DP_WG_EXT, s1);
+	launch_dp_ext(B, 64, B.ext_list2, 17, 19, B.fill_fb, 12, e->ws->ext_p.as<uint8_t>(), DP_WG_EXT, s1);
+	launch_dp_ext(B, 128, B.ext_list3, 24, 26, B.fill_fb, 12, e->ws->ext_p.as<uint8_t>(), DP_WG_EXT / 2, s1);
+	launch_dp_ext(B, 256, B.ext_list4, 25, 27, B.fill_fb, 12, e->ws->ext_p.as<uint8_t>(), DP_WG_EXT / 4, s1);
 	mark(MNC_STAGE_DP_EXT, 1);
 	// the literal kernel's lists known at planning time, beside the banded kernels (`s2`: the batch's own stream,
 	// idle between fork and join: the side streams share hardware queues among themselves)
-	launch_dp_lext(B, B.lext_list, 62, 63, B.fill_fb, 12, e->lext_p.as<uint8_t>(), DP_WG_LEXT, s2);
-	launch_dp_align(B, e->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 1, s2);
-	launch_dp_align(B, e->dp_ws_mid.as<uint8_t>(), DP_WG_MID, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, 0, 3, s2);
-	launch_dp_align(B, e->dp_ws.as<uint8_t>(), 2 * DP_WG_SMALL, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS0_STATE, DP_LDS0_P, DP_LDS0_CIG, 0, s2);
+	launch_dp_lext(B, B.lext_list, 62, 63, B.fill_fb, 12, e->ws->lext_p.as<uint8_t>(), DP_WG_LEXT, s2);
+	launch_dp_align(B, e->ws->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 1, s2);
+	launch_dp_align(B, e->ws->dp_ws_mid.as<uint8_t>(), DP_WG_MID, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, 0, 3, s2);
+	launch_dp_align(B, e->ws->dp_ws.as<uint8_t>(), 2 * DP_WG_SMALL, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS0_STATE, DP_LDS0_P, DP_LDS0_CIG, 0, s2);
 	(void)s3;
 }
 // what the other kernels handed back, on the literal kernel
 static void align_rest(const Batch &B, mnc_engine *e, hipStream_t st)
 {
-	launch_dp_align(B, e->dp_ws.as<uint8_t>(), DP_WG_SMALL, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, 0, 2, st);
+	launch_dp_align(B, e->ws->dp_ws.as<uint8_t>(), DP_WG_SMALL, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, 0, 2, st);
+	launch_dp_align(B, e->ws->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 4, st);
 }
 
 // ---------------------------------------------------------------- one batch, device-resident
@@ -723,6 +753,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	B.max_join_short = P.max_join_short, B.min_join_flank_sc = P.min_join_flank_sc, B.mask_level = P.mask_level;
 	B.pri_ratio = P.pri_ratio, B.min_join_flank_ratio = P.min_join_flank_ratio;
 	B.gap_lut = e->gap_lut.as<int32_t>(), B.logf_lut = e->logf_lut.as<float>(), B.logf_a_lut = e->logf_a_lut.as<float>(), B.logf_n = e->logf_n;
+	B.debug_route = e->debug >> 17 & 15;
 	B.fill_pred = (e->debug >> 8 & 0xff) ? (e->debug >> 8 & 0xff) : 34;     // tuning knob: debug bits 8-15
 	B.contract = e->contract, B.seq4 = e->didx->seq4, B.seq_off = e->didx->seq_off;
 	B.sc_a = P.a, B.sc_b = P.b, B.gap_q = P.q, B.gap_e = P.e, B.gap_q2 = P.q2, B.gap_e2 = P.e2, B.sc_ambi = P.sc_ambi;
@@ -867,17 +898,22 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	}
 	if (e->contract == MNC_CONTRACT_DP) {
 		// ---- base-level alignment stage: buffers
-		size_t seg_cap = na / 2 + 1024, cig_cap = nb / 2 + (1u << 20);
+		// room for the segments: ~23 per 5 kb read with 10 % errors is one per 17 anchors; one per 6, and
+		// the batch is redone with the worst case if that overflows (`seg_cap_override`)
+		size_t seg_cap = na / 6 + 4096, cig_cap = nb / 2 + (1u << 20);
 		if (e->seg_cap_override > seg_cap) seg_cap = e->seg_cap_override;
 		if (e->cig_cap_override > cig_cap) cig_cap = e->cig_cap_override;
 		int rc2 = MNC_OK;
 #define ENS2(buf, bytes) do { if (!rc2) rc2 = e->buf.ensure(bytes); } while (0)
+#define ENSW(buf, bytes) do { if (!rc2) rc2 = e->ws->buf.ensure(bytes); } while (0)
+		// the device's alignment scratch is this engine's from here to the end of the stage
+		std::unique_lock<std::mutex> ws_hold(e->ws->mu);
 		ENS2(ca, na * sizeof(Anchor)); ENS2(ca_cnt, (nr + 1) * 4); ENS2(chain_dst, ns * 4); ENS2(regdp, ns * sizeof(RegDP));
 		ENS2(segs, seg_cap * sizeof(Seg)); ENS2(cig_seg, cig_cap * 4); ENS2(cig_reg, cig_cap * 4);
 		ENS2(work_a, ns * 4); ENS2(work_b, ns * 4); ENS2(big_list, seg_cap * 4); ENS2(reg_cnt, (nr + 1) * 4); ENS2(regs2, ns * sizeof(mnc_reg_t));
 		const size_t ws_small = dp_align_ws_bytes(DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL), ws_big = dp_align_ws_bytes(DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG);
-		ENS2(dp_ws, ws_small * DP_WG_SMALL * 2); ENS2(dp_ws_big, ws_big * DP_WG_BIG); ENS2(dp_ws_mid, ws_small * DP_WG_MID); ENS2(mid_list, seg_cap * 4); ENS2(lfill1, seg_cap * 4); ENS2(lfill2, seg_cap * 4); ENS2(lfill_p, dp_lfill_p_slot() * DP_WG_LFILL); ENS2(lext, seg_cap * 4); ENS2(lext_p, dp_lext_p_slot() * DP_WG_LEXT);
-		ENS2(fill1, seg_cap * 4); ENS2(fill2, seg_cap * 4); ENS2(fill3, seg_cap * 4); ENS2(fill_fb, seg_cap * 4); ENS2(fill_p, dp_fillp_slot() * DP_WG_FILL); ENS2(fill_cig, dp_fillp_cig_slot() * DP_WG_FILL); ENS2(extp, seg_cap * 4 * 8); ENS2(extp_p, dp_extp_slot() * DP_WG_EXT); ENS2(extp_cig, dp_extp_cig_slot() * DP_WG_EXT); ENS2(ext1, seg_cap * 4); ENS2(ext2, seg_cap * 4); ENS2(ext3, seg_cap * 4); ENS2(ext4, seg_cap * 4); ENS2(gen_list, seg_cap * 4); ENS2(ext_p, dp_fill_p_slot() * DP_WG_EXT);
+		ENSW(dp_ws, ws_small * DP_WG_SMALL * 2); ENSW(dp_ws_big, ws_big * DP_WG_BIG); ENSW(dp_ws_mid, ws_small * DP_WG_MID); ENS2(mid_list, seg_cap * 4); ENS2(lfill1, seg_cap * 4); ENS2(lfill2, seg_cap * 4); ENSW(lfill_p, dp_lfill_p_slot() * DP_WG_LFILL); ENS2(lext, seg_cap * 4); ENS2(bigfb, seg_cap * 4); ENSW(lext_p, dp_lext_p_slot() * DP_WG_LEXT);
+		ENS2(fill1, seg_cap * 4); ENS2(fill2, seg_cap * 4); ENS2(fill3, seg_cap * 4); ENS2(fill_fb, seg_cap * 4); ENSW(fill_p, dp_fillp_slot() * DP_WG_FILL); ENSW(fill_cig, dp_fillp_cig_slot() * DP_WG_FILL); ENS2(extp, seg_cap * 4 * 8); ENSW(extp_p, dp_extp_slot() * DP_WG_EXT); ENSW(extp_cig, dp_extp_cig_slot() * DP_WG_EXT); ENS2(ext1, seg_cap * 4); ENS2(ext2, seg_cap * 4); ENS2(ext3, seg_cap * 4); ENS2(ext4, seg_cap * 4); ENS2(gen_list, seg_cap * 4); ENSW(ext_p, dp_fill_p_slot() * DP_WG_EXT);
 #undef ENS2
 		if (rc2) return rc2;
 		B.ca = e->ca.as<Anchor>(), B.ca_cnt = e->ca_cnt.as<int32_t>(), B.chain_dst = e->chain_dst.as<int32_t>(), B.regdp = e->regdp.as<RegDP>();
@@ -885,7 +921,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 		B.cig_seg_cap = B.cig_reg_cap = (int64_t)cig_cap, B.dp_ctr = e->dp_ctr.as<unsigned long long>();
 		B.big_list = e->big_list.as<int32_t>(), B.reg_cnt = e->reg_cnt.as<int32_t>();
 		B.fill_list1 = e->fill1.as<int32_t>(), B.fill_list2 = e->fill2.as<int32_t>(), B.fill_list3 = e->fill3.as<int32_t>(), B.fill_fb = e->fill_fb.as<int32_t>();
-		B.ext_list1 = e->ext1.as<int32_t>(), B.ext_list2 = e->ext2.as<int32_t>(), B.ext_list3 = e->ext3.as<int32_t>(), B.ext_list4 = e->ext4.as<int32_t>(), B.gen_list = e->gen_list.as<int32_t>(), B.extp_list = e->extp.as<int32_t>(), B.mid_list = e->mid_list.as<int32_t>(), B.lfill_list1 = e->lfill1.as<int32_t>(), B.lfill_list2 = e->lfill2.as<int32_t>(), B.lext_list = e->lext.as<int32_t>();
+		B.ext_list1 = e->ext1.as<int32_t>(), B.ext_list2 = e->ext2.as<int32_t>(), B.ext_list3 = e->ext3.as<int32_t>(), B.ext_list4 = e->ext4.as<int32_t>(), B.gen_list = e->gen_list.as<int32_t>(), B.extp_list = e->extp.as<int32_t>(), B.mid_list = e->mid_list.as<int32_t>(), B.lfill_list1 = e->lfill1.as<int32_t>(), B.lfill_list2 = e->lfill2.as<int32_t>(), B.lext_list = e->lext.as<int32_t>(), B.bigfb_list = e->bigfb.as<int32_t>();
 		B.lds0_state = DP_LDS0_STATE, B.lds0_p = DP_LDS0_P, B.lds0_cig = DP_LDS0_CIG;
 		int32_t *lists[2] = { e->work_a.as<int32_t>(), e->work_b.as<int32_t>() };
 		B.next_list = lists[0];                          // the regions kernel files every kept region here
@@ -1069,7 +1105,6 @@ extern "C" int mnc_engine_get_counters(mnc_engine *e, int64_t *c, int n)
 		HIP_TRY(hipMemcpy(d, e->dp_ctr.p, sizeof(d), hipMemcpyDeviceToHost));
 		c[8] = (int64_t)d[0], c[9] = (int64_t)d[10], c[10] = (int64_t)d[11], c[11] = (int64_t)d[12];
 		if (n >= 16) c[12] = (int64_t)d[48], c[13] = (int64_t)d[49], c[14] = (int64_t)d[50], c[15] = (int64_t)d[51];
-		if (n >= 24) for (int i = 0; i < 8; ++i) c[16 + i] = (int64_t)d[52 + i];
 
 
 	}

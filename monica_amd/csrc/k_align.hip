@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 					atomicMax(&B.dp_ctr[4], 9ULL);
 				}
 				bool lfill = false;
-				if (g.big <= 1 && g.kind == 1 && g.w == bw && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= 2047 && g.qlen <= 2047 &&
+				if (!(B.debug_route & 4) && g.big <= 1 && g.kind == 1 && g.w == bw && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= 2047 && g.qlen <= 2047 &&
 				    (g.tlen > FILL_MAX_LEN || g.qlen > FILL_MAX_LEN) && (long long)g.tlen * g.qlen <= B.max_sw_mat) {
 					// a longer gap between two seeds (512 .. 2047 bases): the banded kernel's int32 form, 128 cells when
 					// the bound has a chance there, else 256
@@ -319,14 +319,16 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 						if (bb >= 8 && U * 25 <= mn * 32) tier = 17;
 					}
 					if (!tier && (510 - ad) / 2 >= 8) tier = 18;
-					if (tier) g.big = 4 + tier, ++n_tier[tier], lfill = true;
+					if (tier) {
+						if (g.big == 1) g.flag |= SEG_NEEDS_BIG_WS;           // should the banded kernel hand it back
+						g.big = 4 + tier, ++n_tier[tier], lfill = true;
+					}
 				}
 				if (lfill) {
 				} else if (g.big == 1) {
 					const unsigned long long bi = atomicAdd(&B.dp_ctr[6], 1ULL);
 					B.big_list[bi] = (int32_t)(sg - B.segs);
-					atomicAdd(&B.dp_ctr[56 + (g.kind == 1 ? 0 : 1)], 1ULL); atomicAdd(&B.dp_ctr[58], (unsigned long long)(g.tlen + g.qlen)); atomicMax(&B.dp_ctr[59], (unsigned long long)(g.tlen > g.qlen ? g.tlen : g.qlen));
-				} else if (g.big == 0 && g.kind == 1 && g.w == bw && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= FILL_MAX_LEN && g.qlen <= FILL_MAX_LEN) {
+				} else if (!(B.debug_route & 2) && g.big == 0 && g.kind == 1 && g.w == bw && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= FILL_MAX_LEN && g.qlen <= FILL_MAX_LEN) {
 					// a gap between two seeds whose matrix the band never clips: the banded kernel of
 					// k_fill.hip, 32 lanes per segment when |tlen - qlen| leaves a band worth trying, else 64
 					const int ad = g.tlen > g.qlen ? g.tlen - g.qlen : g.qlen - g.tlen;
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 					}
 					if (tier) g.big = 3 + tier, ++n_tier[tier - 1];          // not for the literal kernel's first pass
 					if (tier) work[tier == 1 ? 0 : tier == 2 ? 1 : 2] += (unsigned long long)(g.tlen + g.qlen - 1);
-				} else if (g.big == 0 && g.kind != 1 && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= g.w && g.qlen <= g.w &&
+				} else if (!(B.debug_route & 1) && g.big == 0 && g.kind != 1 && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= g.w && g.qlen <= g.w &&
 				           g.tlen + g.qlen - 1 <= 2 * FILL_MAX_LEN && g.qlen <= 256) {
 					// an extension whose matrix the band never clips, one cell per query base: the packed
 					// extension kernel of k_fill.hip (tiers 8..15: by query length, right / left)
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 					const int tier = mn <= 32 ? 3 : mn <= 64 ? 4 : mn <= 128 ? 7 : 8;
 					g.big = 3 + tier, ++n_tier[tier - 1];
 				}
-				if (g.big == 0 && g.kind != 1 && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= g.w && g.qlen <= g.w &&
+				if (!(B.debug_route & 8) && g.big == 0 && g.kind != 1 && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= g.w && g.qlen <= g.w &&
 				    g.tlen + g.qlen - 1 <= 2 * 1535 && (g.tlen < g.qlen ? g.tlen : g.qlen) <= 512) {
 					g.big = 4 + 19, ++n_tier[19];                           // a longer extension: the step-by-step kernel, eight cells per lane
 				}
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 					// the literal kernel: its first pass with everything in LDS, or from the start on its own list
 					const bool all_lds = 12 * T + Q <= B.lds0_state && p_bytes <= B.lds0_p && g.qlen + g.tlen + 2 <= B.lds0_cig;
 					if (all_lds) g.big = 8, ++n_tier[4];
-					else { g.big = 20, ++n_tier[16]; atomicAdd(&B.dp_ctr[52 + (g.kind == 1 ? 0 : 1)], 1ULL); atomicAdd(&B.dp_ctr[54], (unsigned long long)(g.tlen + g.qlen)); atomicMax(&B.dp_ctr[55], (unsigned long long)(g.tlen > g.qlen ? g.tlen : g.qlen)); }
+					else g.big = 20, ++n_tier[16];
 				}
 				*sg++ = g;
 			};
@@ -780,14 +782,14 @@ __global__ __launch_bounds__(64) void mnc_dp_align(Batch B, uint8_t *ws_all, lon
 	const int sc_mch = B.sc_a, sc_mis = -B.sc_b, sc_N = -B.sc_ambi;
 	// pass 0: the segments of the round that are neither large nor another kernel's and fit the LDS
 	// layout; 3: those that do not; 1: the large ones; 2: what the banded kernels handed back
-	const unsigned long long n_items = big_pass == 0 ? B.dp_ctr[20] : big_pass == 1 ? B.dp_ctr[6] : big_pass == 3 ? B.dp_ctr[28] : B.dp_ctr[12];
-	const int ctr_q = big_pass == 0 ? 21 : big_pass == 1 ? 7 : big_pass == 3 ? 29 : 15;
+	const unsigned long long n_items = big_pass == 0 ? B.dp_ctr[20] : big_pass == 1 ? B.dp_ctr[6] : big_pass == 3 ? B.dp_ctr[28] : big_pass == 4 ? B.dp_ctr[56] : B.dp_ctr[12];
+	const int ctr_q = big_pass == 0 ? 21 : big_pass == 1 ? 7 : big_pass == 3 ? 29 : big_pass == 4 ? 57 : 15;
 	for (;;) {
 		unsigned long long qi = 0;
 		if (lane == 0) qi = atomicAdd(&B.dp_ctr[ctr_q], 1ULL);
 		qi = (unsigned long long)__shfl((long long)qi, 0);
 		if (qi >= n_items) break;                              // every wave reaches this: the queue is finite
-		const long long si = big_pass == 0 ? (long long)B.gen_list[qi] : big_pass == 1 ? (long long)B.big_list[qi] : big_pass == 3 ? (long long)B.mid_list[qi] : (long long)B.fill_fb[qi];
+		const long long si = big_pass == 0 ? (long long)B.gen_list[qi] : big_pass == 1 ? (long long)B.big_list[qi] : big_pass == 3 ? (long long)B.mid_list[qi] : big_pass == 4 ? (long long)B.bigfb_list[qi] : (long long)B.fill_fb[qi];
 		Seg g = B.segs[si];
 		Ez ez;
 		ez.max = 0, ez.zdropped = 0, ez.max_q = ez.max_t = ez.mqe_t = -1, ez.mqe = ez.score = DP_NEG_INF, ez.reach_end = 0, ez.n_cigar = 0;
@@ -807,6 +809,12 @@ __global__ __launch_bounds__(64) void mnc_dp_align(Batch B, uint8_t *ws_all, lon
 			const bool all_lds = in_lds && p_bytes <= lds_p && g.qlen + g.tlen + 2 <= lds_cig;
 			if (big_pass == 0 && !all_lds) {                        // not for the small layout: pass 2 takes it
 				if (lane == 0) { const unsigned long long k = atomicAdd(&B.dp_ctr[12], 1ULL); B.fill_fb[k] = (int32_t)si; }
+				continue;
+			}
+			if (!all_lds && ((!in_lds && 12LL * T + Q > state_max) || p_bytes > p_max || g.qlen + g.tlen + 8 > cig_max)) {
+				// a call that does not fit this launch's workspace slot must never get here (mnc_dp_plan sorts them);
+				// should one, the batch fails instead of writing past the slot
+				if (lane == 0) atomicMax(&B.dp_ctr[4], 9ULL);
 				continue;
 			}
 			const uint8_t *read = B.bases + B.offsets[g.read];
@@ -1309,7 +1317,7 @@ __global__ void mnc_dp_round(Batch B, int first)
 	B.dp_ctr[5] = 0;
 	B.dp_ctr[6] = 0, B.dp_ctr[7] = 0;
 	for (int k = 10; k < 48; ++k) B.dp_ctr[k] = 0;
-	B.dp_ctr[60] = B.dp_ctr[61] = B.dp_ctr[62] = B.dp_ctr[63] = 0;
+	B.dp_ctr[56] = B.dp_ctr[57] = B.dp_ctr[60] = B.dp_ctr[61] = B.dp_ctr[62] = B.dp_ctr[63] = 0;
 	if (first) for (int k = 48; k < 64; ++k) B.dp_ctr[k] = 0;   // banded kernel: list lengths 10 / 11 / 12 (tier 1, tier 2, handed back), queues 13 / 14 / 15;
 	                                                 // extension kernel: lists 16 / 17, queues 18 / 19; literal kernel's first pass: list 20, queue 21; banded kernel, 128 cells: list 22, queue 23; extension kernel, 128 / 256 cells: lists 24 / 25, queues 26 / 27
 }

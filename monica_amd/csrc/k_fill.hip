@@ -349,7 +349,9 @@ __global__ __launch_bounds__(64) void mnc_dp_fill(Batch B, const int32_t *list, 
 		const int s_nc = __shfl(n_c, lead);
 		if (has && (s_next || s_fb)) {
 			if (leader) {
-				if (s_fb) { const unsigned long long k = atomicAdd(&B.dp_ctr[ctr_fb], 1ULL); fb_list[k] = (int32_t)si; }
+				const bool literal = s_fb || next_list == fb_list;      // the last tier hands everything to the literal kernel
+				if (literal && (B.segs[si].flag & SEG_NEEDS_BIG_WS)) { const unsigned long long k = atomicAdd(&B.dp_ctr[56], 1ULL); B.bigfb_list[k] = (int32_t)si; }
+				else if (literal) { const unsigned long long k = atomicAdd(&B.dp_ctr[ctr_fb], 1ULL); fb_list[k] = (int32_t)si; }
 				else { const unsigned long long k = atomicAdd(&B.dp_ctr[ctr_next], 1ULL); next_list[k] = (int32_t)si; }
 			}
 		} else if (has) {

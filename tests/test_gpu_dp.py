@@ -124,3 +124,35 @@ def test_long_reads_and_mixed_lengths(capi, oracle, world):
     assert (assign[:4] >= 0).all() and assign[-1] == 1
     regs = world["eng"].dump(capi.DUMP_REGS, capi.REG_DTYPE)
     assert regs["n_cigar"].max() > 1024 and (regs["qe"] - regs["qs"]).max() > 40_000
+
+
+def test_engines_on_threads_share_the_device_workspace(capi, oracle, world):
+    """monica's thread pool: one engine per thread on the same index; the alignment scratch of the device
+    is lent to one engine at a time.  Every thread must get what a single engine gets."""
+    import threading
+    batches = [synth.reads(world["seqs"], 150, 3000, seed=900 + i) for i in range(4)]
+    want = []
+    for b, o, _ in batches:
+        a, best, nh = world["eng"].classify(b, o, 60)
+        want.append((a.copy(), best.copy(), nh.copy()))
+    got, errs = [None] * 4, []
+
+    def run(i):
+        try:
+            eng = capi.Engine(world["idx"], 0)
+            for _ in range(3):
+                a, best, nh = eng.classify(batches[i][0], batches[i][1], 60)
+            got[i] = (a.copy(), best.copy(), nh.copy())
+            eng.close()
+        except Exception as e:                                   # noqa: BLE001
+            errs.append(e)
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for i in range(4):
+        assert np.array_equal(got[i][0], want[i][0]) and np.array_equal(got[i][2], want[i][2])
+        for name in capi.HIT_DTYPE.names:
+            assert np.array_equal(got[i][1][name], want[i][1][name])
