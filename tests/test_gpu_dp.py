@@ -156,3 +156,21 @@ def test_engines_on_threads_share_the_device_workspace(capi, oracle, world):
         assert np.array_equal(got[i][0], want[i][0]) and np.array_equal(got[i][2], want[i][2])
         for name in capi.HIT_DTYPE.names:
             assert np.array_equal(got[i][1][name], want[i][1][name])
+
+
+def test_results_do_not_depend_on_scheduling(capi, world):
+    """Which workgroup takes which kernel call differs from run to run (atomic work queues): the regions
+    and CIGARs of a batch full of Z-drops, long gaps and hand-backs between kernels must not."""
+    b, o, _ = synth.reads(world["seqs"], 60, 3000, seed=31, sub=800, ins=600, dele=600)
+    eng = world["eng"]
+    eng.set_contract(capi.CONTRACT_DP)
+    first = None
+    for _ in range(8):
+        eng.classify(b, o, 0)
+        now = (eng.dump(capi.DUMP_REGS, capi.REG_DTYPE), eng.dump(capi.DUMP_REG_OFFSETS, np.int64), eng.dump(capi.DUMP_CIGARS, np.uint32))
+        if first is None:
+            first = now
+        else:
+            assert np.array_equal(now[1], first[1]) and np.array_equal(now[2], first[2])
+            for name in capi.REG_DTYPE.names:
+                assert np.array_equal(now[0][name], first[0][name]), name
