@@ -52,8 +52,7 @@ size_t dp_fillp_cig_slot();
 size_t dp_lfill_p_slot();
 size_t dp_lext_p_slot();
 void launch_dp_lext(const Batch &B, const int32_t *list, int ctr_n, int ctr_q, int32_t *fb_list, int ctr_fb, uint8_t *p_all, int n_wg, hipStream_t st);
-void launch_dp_lfill(const Batch &B, int cells, const int32_t *list, int ctr_n, int ctr_q, int32_t *next_list, int ctr_next,
-                     int32_t *fb_list, int ctr_fb, uint8_t *p_all, int n_wg, hipStream_t st);
+void launch_dp_lfill(const Batch &B, const int32_t *list, int ctr_n, int ctr_q, int32_t *fb_list, int ctr_fb, uint8_t *p_all, int n_wg, hipStream_t st);
 size_t dp_extp_slot();
 size_t dp_extp_cig_slot();
 void launch_dp_extp(const Batch &B, int cells, int rgt, const int32_t *list, int ctr_n, int ctr_q, uint8_t *p_all, uint32_t *cig_all, int n_wg, hipStream_t st);
@@ -64,7 +63,7 @@ constexpr int DP_WG_FILL = 256 * 16, DP_WG_EXT = 256 * 8;
 // workspace classes of the alignment kernel: a normal slot per workgroup, a few large ones
 constexpr int DP_LDS_BYTES = 16 * 1024;
 constexpr int DP_LDS0_STATE = 4 * 1024, DP_LDS0_P = 10 * 1024, DP_LDS0_CIG = 256;   // pass 0: 15 KB per workgroup
-constexpr int DP_WG_SMALL = 2048, DP_WG_BIG = 8, DP_WG_MID = 512, DP_WG_LFILL = 1024, DP_WG_LEXT = 512;
+constexpr int DP_WG_SMALL = 2048, DP_WG_BIG = 8, DP_WG_MID = 512, DP_WG_LFILL = 2048, DP_WG_LEXT = 512;
 constexpr long long DP_STATE_SMALL = 96 * 1024, DP_P_SMALL = 1 << 20, DP_CIG_SMALL = 4096;
 constexpr long long DP_STATE_BIG = 13 * 32768, DP_P_BIG = 256LL << 20, DP_CIG_BIG = 65536;
 void launch_gather_hits(const Batch &B, const mnc_hit_t *gated, const int64_t *hit_off, mnc_hit_t *out, hipStream_t st);
@@ -408,7 +407,7 @@ struct mnc_engine {
 	int contract = MNC_CONTRACT_DP;
 	Buf ca, ca_cnt, chain_dst, regdp, segs, cig_seg, cig_reg, dp_ctr, work_a, work_b, big_list, reg_cnt, regs2;
 	SharedWs *ws = nullptr;                  // the device's alignment scratch (held during the alignment stage only)
-	Buf fill1, fill2, fill3, fill_fb, extp, mid_list, lfill1, lfill2, lext, bigfb, ext1, ext2, ext3, ext4, gen_list;
+	Buf fill1, fill2, fill3, fill_fb, extp, mid_list, lfill, lext, bigfb, ext1, ext2, ext3, ext4, gen_list;
 	size_t seg_cap_override = 0, cig_cap_override = 0;
 	int cur_max_read_len = 0;                // of the batch being classified (sizes the stitch kernel's LDS)
 	int debug = 0;                           // bit mask (tests): 2 stress build of the chaining ring, 4 displacement bytes read from HBM, 0x10000 alignment kernels one at a time (with stage timers)
@@ -512,7 +511,7 @@ extern "C" void mnc_engine_destroy(mnc_engine *e)
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
 	Buf *all[] = { &e->gap_lut, &e->logf_lut, &e->logf_a_lut, &e->ca, &e->ca_cnt, &e->chain_dst, &e->regdp, &e->segs, &e->cig_seg, &e->cig_reg, &e->dp_ctr,
-	               &e->work_a, &e->work_b, &e->big_list, &e->reg_cnt, &e->regs2, &e->fill1, &e->fill2, &e->fill3, &e->fill_fb, &e->extp, &e->mid_list, &e->lfill1, &e->lfill2, &e->lext, &e->bigfb, &e->ext1, &e->ext2, &e->ext3, &e->ext4, &e->gen_list, &e->in_bases, &e->in_offsets, &e->out_assign, &e->out_best, &e->out_nhits,
+	               &e->work_a, &e->work_b, &e->big_list, &e->reg_cnt, &e->regs2, &e->fill1, &e->fill2, &e->fill3, &e->fill_fb, &e->extp, &e->mid_list, &e->lfill, &e->lext, &e->bigfb, &e->ext1, &e->ext2, &e->ext3, &e->ext4, &e->gen_list, &e->in_bases, &e->in_offsets, &e->out_assign, &e->out_best, &e->out_nhits,
 	               &e->packed, &e->mz, &e->hits, &e->hist_tm, &e->q_off, &e->qrec, &e->bhits, &e->bhit_cnt, &e->ambig, &e->mz_cnt, &e->hit_cnt, &e->rep_len, &e->an_cnt, &e->an_off,
 	               &e->n_chain, &e->n_reg, &e->best_mlen, &e->hist_sums, &e->hist_offs, &e->scan_sums, &e->hit_off, &e->a, &e->f, &e->p, &e->v, &e->t, &e->u,
 	               &e->chains_tmp, &e->regs, &e->regx, &e->k64a, &e->k64b, &e->tmp_i32, &e->gated,
@@ -542,7 +541,13 @@ extern "C" int mnc_engine_create(mnc_index *idx, int device, mnc_engine **out)
 	int rc = index_upload(idx, device, &e->didx);
 	if (rc) { delete e; return rc; }
 	hipError_t he = hipSetDevice(device);
-	if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+	if (he == hipSuccess) {
+		// the batch's own stream carries the latency-bound kernels (a few long calls on single waves) beside the
+		// chip-filling ones of the side streams: its workgroups go first when wave slots come free
+		int least = 0, greatest = 0;
+		if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+		he = hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, greatest);
+	}
 	for (int k = 0; k < mnc_engine::N_SIDE && he == hipSuccess; ++k) {
 		he = hipStreamCreateWithFlags(&e->side[k], hipStreamNonBlocking);
 		if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming);
@@ -656,15 +661,16 @@ static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream
 	// per-kernel timers: only when everything runs on one stream (debug bit 0x10000)
 	const bool timed = e->profiling && s0 == s1;
 	auto mark = [&](int stage, int which) { if (timed) { (void)hipEventRecord(e->ev[stage][which], s0); if (which) e->ev_used[stage] = true; } };
+	// the long gaps first, on the batch's own stream: single waves (one call each, ~2 ms) that are on the chip
+	// before the persistent workgroups of the gap-filling tiers take the wave slots
+	if (s2 != s0) launch_dp_lfill(B, B.lfill_list, 31, 61, B.fill_fb, 12, e->ws->lfill_p.as<uint8_t>(), DP_WG_LFILL, s2);
 	mark(MNC_STAGE_DP_FILL_T1, 0);
 	launch_dp_fill(B, 32, B.fill_list1, 10, 13, B.fill_list2, 11, B.fill_fb, 12, e->ws->fill_p.as<uint8_t>(), e->ws->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
 	mark(MNC_STAGE_DP_FILL_T1, 1), mark(MNC_STAGE_DP_FILL_T2, 0);
 	launch_dp_fill(B, 64, B.fill_list2, 11, 14, B.fill_list3, 22, B.fill_fb, 12, e->ws->fill_p.as<uint8_t>(), e->ws->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
 	mark(MNC_STAGE_DP_FILL_T2, 1), mark(MNC_STAGE_DP_FILL_T3, 0);
 	launch_dp_fill(B, 128, B.fill_list3, 22, 23, B.fill_fb, 12, B.fill_fb, 12, e->ws->fill_p.as<uint8_t>(), e->ws->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
-	// the long gaps last on this stream: a thousand single waves, beside whatever the other streams still run
-	launch_dp_lfill(B, 128, B.lfill_list1, 30, 60, B.lfill_list2, 31, B.fill_fb, 12, e->ws->lfill_p.as<uint8_t>(), DP_WG_LFILL, s0);
-	launch_dp_lfill(B, 256, B.lfill_list2, 31, 61, B.fill_fb, 12, B.fill_fb, 12, e->ws->lfill_p.as<uint8_t>(), DP_WG_LFILL, s0);
+	if (s2 == s0) launch_dp_lfill(B, B.lfill_list, 31, 61, B.fill_fb, 12, e->ws->lfill_p.as<uint8_t>(), DP_WG_LFILL, s0);   // one kernel at a time (profiling)
 	mark(MNC_STAGE_DP_FILL_T3, 1), mark(MNC_STAGE_DP_EXT, 0);
 	for (int i = 0; i < 8; ++i)
 		launch_dp_extp(B, 32 << (i >> 1), i & 1, B.extp_list + (int64_t)i * B.seg_cap, 32 + i, 40 + i, e->ws->extp_p.as<uint8_t>(), e->ws->extp_cig.as<uint32_t>(), DP_WG_EXT, s1);
@@ -912,7 +918,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 		ENS2(segs, seg_cap * sizeof(Seg)); ENS2(cig_seg, cig_cap * 4); ENS2(cig_reg, cig_cap * 4);
 		ENS2(work_a, ns * 4); ENS2(work_b, ns * 4); ENS2(big_list, seg_cap * 4); ENS2(reg_cnt, (nr + 1) * 4); ENS2(regs2, ns * sizeof(mnc_reg_t));
 		const size_t ws_small = dp_align_ws_bytes(DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL), ws_big = dp_align_ws_bytes(DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG);
-		ENSW(dp_ws, ws_small * DP_WG_SMALL * 2); ENSW(dp_ws_big, ws_big * DP_WG_BIG); ENSW(dp_ws_mid, ws_small * DP_WG_MID); ENS2(mid_list, seg_cap * 4); ENS2(lfill1, seg_cap * 4); ENS2(lfill2, seg_cap * 4); ENSW(lfill_p, dp_lfill_p_slot() * DP_WG_LFILL); ENS2(lext, seg_cap * 4); ENS2(bigfb, seg_cap * 4); ENSW(lext_p, dp_lext_p_slot() * DP_WG_LEXT);
+		ENSW(dp_ws, ws_small * DP_WG_SMALL * 2); ENSW(dp_ws_big, ws_big * DP_WG_BIG); ENSW(dp_ws_mid, ws_small * DP_WG_MID); ENS2(mid_list, seg_cap * 4); ENS2(lfill, seg_cap * 4); ENSW(lfill_p, dp_lfill_p_slot() * DP_WG_LFILL); ENS2(lext, seg_cap * 4); ENS2(bigfb, seg_cap * 4); ENSW(lext_p, dp_lext_p_slot() * DP_WG_LEXT);
 		ENS2(fill1, seg_cap * 4); ENS2(fill2, seg_cap * 4); ENS2(fill3, seg_cap * 4); ENS2(fill_fb, seg_cap * 4); ENSW(fill_p, dp_fillp_slot() * DP_WG_FILL); ENSW(fill_cig, dp_fillp_cig_slot() * DP_WG_FILL); ENS2(extp, seg_cap * 4 * 8); ENSW(extp_p, dp_extp_slot() * DP_WG_EXT); ENSW(extp_cig, dp_extp_cig_slot() * DP_WG_EXT); ENS2(ext1, seg_cap * 4); ENS2(ext2, seg_cap * 4); ENS2(ext3, seg_cap * 4); ENS2(ext4, seg_cap * 4); ENS2(gen_list, seg_cap * 4); ENSW(ext_p, dp_fill_p_slot() * DP_WG_EXT);
 #undef ENS2
 		if (rc2) return rc2;
@@ -921,7 +927,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 		B.cig_seg_cap = B.cig_reg_cap = (int64_t)cig_cap, B.dp_ctr = e->dp_ctr.as<unsigned long long>();
 		B.big_list = e->big_list.as<int32_t>(), B.reg_cnt = e->reg_cnt.as<int32_t>();
 		B.fill_list1 = e->fill1.as<int32_t>(), B.fill_list2 = e->fill2.as<int32_t>(), B.fill_list3 = e->fill3.as<int32_t>(), B.fill_fb = e->fill_fb.as<int32_t>();
-		B.ext_list1 = e->ext1.as<int32_t>(), B.ext_list2 = e->ext2.as<int32_t>(), B.ext_list3 = e->ext3.as<int32_t>(), B.ext_list4 = e->ext4.as<int32_t>(), B.gen_list = e->gen_list.as<int32_t>(), B.extp_list = e->extp.as<int32_t>(), B.mid_list = e->mid_list.as<int32_t>(), B.lfill_list1 = e->lfill1.as<int32_t>(), B.lfill_list2 = e->lfill2.as<int32_t>(), B.lext_list = e->lext.as<int32_t>(), B.bigfb_list = e->bigfb.as<int32_t>();
+		B.ext_list1 = e->ext1.as<int32_t>(), B.ext_list2 = e->ext2.as<int32_t>(), B.ext_list3 = e->ext3.as<int32_t>(), B.ext_list4 = e->ext4.as<int32_t>(), B.gen_list = e->gen_list.as<int32_t>(), B.extp_list = e->extp.as<int32_t>(), B.mid_list = e->mid_list.as<int32_t>(), B.lfill_list = e->lfill.as<int32_t>(), B.lext_list = e->lext.as<int32_t>(), B.bigfb_list = e->bigfb.as<int32_t>();
 		B.lds0_state = DP_LDS0_STATE, B.lds0_p = DP_LDS0_P, B.lds0_cig = DP_LDS0_CIG;
 		int32_t *lists[2] = { e->work_a.as<int32_t>(), e->work_b.as<int32_t>() };
 		B.next_list = lists[0];                          // the regions kernel files every kept region here

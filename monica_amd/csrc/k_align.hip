@@ -308,17 +308,11 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 				bool lfill = false;
 				if (!(B.debug_route & 4) && g.big <= 1 && g.kind == 1 && g.w == bw && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= 2047 && g.qlen <= 2047 &&
 				    (g.tlen > FILL_MAX_LEN || g.qlen > FILL_MAX_LEN) && (long long)g.tlen * g.qlen <= B.max_sw_mat) {
-					// a longer gap between two seeds (512 .. 2047 bases): the banded kernel's int32 form, 128 cells when
-					// the bound has a chance there, else 256
-					const int ad = g.tlen > g.qlen ? g.tlen - g.qlen : g.qlen - g.tlen, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
-					int tier = 0;
-					{
-						const int bb = (254 - ad) / 2;
-						const int g1 = B.gap_q + B.gap_e * (bb + 1), g2 = B.gap_q2 + B.gap_e2 * (bb + 1);
-						const int U = B.sc_a * (mn - bb - 1) - 2 * (g1 < g2 ? g1 : g2);
-						if (bb >= 8 && U * 25 <= mn * 32) tier = 17;
-					}
-					if (!tier && (510 - ad) / 2 >= 8) tier = 18;
+					// a longer gap between two seeds (512 .. 2047 bases): the banded kernel's int32 form, a band of 256
+					// cells (one launch, early, beside the packed tiers: a narrower first try would put its failures
+					// behind them)
+					const int ad = g.tlen > g.qlen ? g.tlen - g.qlen : g.qlen - g.tlen;
+					const int tier = (510 - ad) / 2 >= 8 ? 18 : 0;
 					if (tier) {
 						if (g.big == 1) g.flag |= SEG_NEEDS_BIG_WS;           // should the banded kernel hand it back
 						g.big = 4 + tier, ++n_tier[tier], lfill = true;
@@ -413,7 +407,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 				if (n_tier[tier] == 0) continue;
 				const int ci = tier == 19 ? 62 : tier >= 17 ? 13 + tier : tier == 16 ? 28 : tier >= 8 ? 24 + tier : tier < 2 ? 10 + tier : tier < 4 ? 14 + tier : tier == 4 ? 20 : tier == 5 ? 22 : 18 + tier;   // 6 -> 24, 7 -> 25; 8.. -> 32..
 				unsigned long long fi = atomicAdd(&B.dp_ctr[ci], (unsigned long long)n_tier[tier]);
-				int32_t *lst = tier == 19 ? B.lext_list : tier == 17 ? B.lfill_list1 : tier == 18 ? B.lfill_list2 : tier == 16 ? B.mid_list : tier >= 8 ? B.extp_list + (int64_t)(tier - 8) * B.seg_cap
+				int32_t *lst = tier == 19 ? B.lext_list : tier == 18 ? B.lfill_list : tier == 16 ? B.mid_list : tier >= 8 ? B.extp_list + (int64_t)(tier - 8) * B.seg_cap
 				             : tier == 0 ? B.fill_list1 : tier == 1 ? B.fill_list2 : tier == 2 ? B.ext_list1 : tier == 3 ? B.ext_list2 : tier == 4 ? B.gen_list
 				             : tier == 5 ? B.fill_list3 : tier == 6 ? B.ext_list3 : B.ext_list4;
 				for (int k = 0; k < n_seg; ++k)

@@ -1379,12 +1379,10 @@ void launch_dp_extp(const Batch &B, int cells, int rgt, const int32_t *list, int
 
 constexpr int LFILL_MAX_LEN = 2047, LFILL_CIG_MAX = 1024;
 size_t dp_lfill_p_slot() { return (size_t)(2 * LFILL_MAX_LEN + FILL_WIN) * 64 * 4; }
-// gaps between seeds of 512 .. 2047 bases: the int32 banded kernel, 128 cells, then 256
-void launch_dp_lfill(const Batch &B, int cells, const int32_t *list, int ctr_n, int ctr_q, int32_t *next_list, int ctr_next,
-                     int32_t *fb_list, int ctr_fb, uint8_t *p_all, int n_wg, hipStream_t st)
+// gaps between seeds of 512 .. 2047 bases: the int32 banded kernel with a band of 256 cells
+void launch_dp_lfill(const Batch &B, const int32_t *list, int ctr_n, int ctr_q, int32_t *fb_list, int ctr_fb, uint8_t *p_all, int n_wg, hipStream_t st)
 {
-	if (cells == 128) hipLaunchKernelGGL((mnc_dp_fill<64, 2, LFILL_MAX_LEN, LFILL_CIG_MAX>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all);
-	else hipLaunchKernelGGL((mnc_dp_fill<64, 4, LFILL_MAX_LEN, LFILL_CIG_MAX>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all);
+	hipLaunchKernelGGL((mnc_dp_fill<64, 4, LFILL_MAX_LEN, LFILL_CIG_MAX>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, fb_list, ctr_fb, fb_list, ctr_fb, p_all);
 }
 constexpr int LEXT_MAX_LEN = 1535;
 size_t dp_lext_p_slot() { return (size_t)(2 * LEXT_MAX_LEN + FILL_WIN) * 64 * 8; }
