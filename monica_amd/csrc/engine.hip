@@ -682,10 +682,10 @@ static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream
 	// the literal kernel's lists known at planning time, beside the banded kernels (`s2`: the batch's own stream,
 	// idle between fork and join: the side streams share hardware queues among themselves)
 	launch_dp_lext(B, B.lext_list, 62, 63, B.fill_fb, 12, e->ws->lext_p.as<uint8_t>(), DP_WG_LEXT, s2);
-	launch_dp_align(B, e->ws->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 1, s2);
-	launch_dp_align(B, e->ws->dp_ws_mid.as<uint8_t>(), DP_WG_MID, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, 0, 3, s2);
+	// the literal kernel's long calls on a stream of their own (`s3`: the side stream whose hardware queue no other uses)
+	launch_dp_align(B, e->ws->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 1, s3);
+	launch_dp_align(B, e->ws->dp_ws_mid.as<uint8_t>(), DP_WG_MID, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, 0, 3, s3);
 	launch_dp_align(B, e->ws->dp_ws.as<uint8_t>(), 2 * DP_WG_SMALL, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS0_STATE, DP_LDS0_P, DP_LDS0_CIG, 0, s2);
-	(void)s3;
 }
 // what the other kernels handed back, on the literal kernel
 static void align_rest(const Batch &B, mnc_engine *e, hipStream_t st)
@@ -946,7 +946,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 					StageTimer t(e, MNC_STAGE_DP_FILL);               // the four streams, fork to join
 					if (int rcf = fork()) return rcf;
 					if (e->debug & 0x10000) align_round(B, e, e->side[0], e->side[0], e->side[0], e->side[0]);   // profiling: one kernel at a time
-					else align_round(B, e, e->side[0], e->side[1], st, e->side[3]);
+					else align_round(B, e, e->side[0], e->side[1], st, e->side[2]);
 					if (int rcj = join()) return rcj;
 				}
 				{
@@ -958,7 +958,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 				launch_dp_plan(B, work, max_work, (int)DP_STATE_SMALL, DP_P_SMALL, (int)DP_CIG_SMALL, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, st);
 				if (int rcf = fork()) return rcf;
 				if (e->debug & 0x10000) align_round(B, e, e->side[0], e->side[0], e->side[0], e->side[0]);
-				else align_round(B, e, e->side[0], e->side[1], st, e->side[3]);
+				else align_round(B, e, e->side[0], e->side[1], st, e->side[2]);
 				if (int rcj = join()) return rcj;
 				align_rest(B, e, st);
 				launch_dp_stitch(B, work, next, e->cur_max_read_len > 0 ? e->cur_max_read_len : 8192, 4096, st);

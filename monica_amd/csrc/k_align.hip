@@ -776,6 +776,7 @@ __global__ __launch_bounds__(64) void mnc_dp_align(Batch B, uint8_t *ws_all, lon
 	const int sc_mch = B.sc_a, sc_mis = -B.sc_b, sc_N = -B.sc_ambi;
 	// pass 0: the segments of the round that are neither large nor another kernel's and fit the LDS
 	// layout; 3: those that do not; 1: the large ones; 2: what the banded kernels handed back
+	if (big_pass != 0) __builtin_amdgcn_s_setprio(3);         // a few long calls on single waves beside chip-filling kernels: first in line for issue
 	const unsigned long long n_items = big_pass == 0 ? B.dp_ctr[20] : big_pass == 1 ? B.dp_ctr[6] : big_pass == 3 ? B.dp_ctr[28] : big_pass == 4 ? B.dp_ctr[56] : B.dp_ctr[12];
 	const int ctr_q = big_pass == 0 ? 21 : big_pass == 1 ? 7 : big_pass == 3 ? 29 : big_pass == 4 ? 57 : 15;
 	for (;;) {

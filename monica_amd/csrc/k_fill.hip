@@ -184,6 +184,9 @@ __global__ __launch_bounds__(64) void mnc_dp_fill(Batch B, const int32_t *list, 
 	const int a = B.sc_a, bmis = -B.sc_b, scN = -B.sc_ambi, q = B.gap_q, e = B.gap_e, q2 = B.gap_q2, e2 = B.gap_e2;
 	uint8_t *p_wave = p_all + (size_t)blockIdx.x * ((size_t)(2 * MAXLEN + FILL_WIN) * 64 * CPL);
 	const unsigned long long n_items = B.dp_ctr[ctr_n];
+	// a long call is one wave's serial work for milliseconds, beside chip-filling kernels that have four waves on
+	// every SIMD: with equal priority it would get a fifth of the issue slots and five times the latency
+	if (MAXLEN > FILL_MAX_LEN) __builtin_amdgcn_s_setprio(3);
 	for (;;) {
 		unsigned long long q0 = 0;
 		if (lane == 0) q0 = atomicAdd(&B.dp_ctr[ctr_q], (unsigned long long)SEGS);
@@ -756,6 +759,9 @@ __global__ __launch_bounds__(64) void mnc_dp_ext(Batch B, const int32_t *list, i
 	const int a = B.sc_a, bmis = -B.sc_b, scN = -B.sc_ambi, q = B.gap_q, e = B.gap_e, q2 = B.gap_q2, e2 = B.gap_e2;
 	uint8_t *p_wave = p_all + (size_t)blockIdx.x * ((size_t)(2 * MAXLEN + FILL_WIN) * 64 * CPL);
 	const unsigned long long n_items = B.dp_ctr[ctr_n];
+	// a long call is one wave's serial work for milliseconds, beside chip-filling kernels that have four waves on
+	// every SIMD: with equal priority it would get a fifth of the issue slots and five times the latency
+	if (MAXLEN > FILL_MAX_LEN) __builtin_amdgcn_s_setprio(3);
 	for (;;) {
 		unsigned long long q0 = 0;
 		if (lane == 0) q0 = atomicAdd(&B.dp_ctr[ctr_q], (unsigned long long)SEGS);
