@@ -497,6 +497,7 @@ __global__ __launch_bounds__(64) void mnc_dp_fillp(Batch B, const int32_t *list,
 	__shared__ uint8_t s_t[SEGS][SEQ], s_q[SEGS][SEQ];        // bases at [PAD + i]; what lies around them feeds cells outside the matrix only
 	__shared__ __align__(16) uint8_t s_chunk[64][32];         // the walk: the 32 direction bytes a lane is reading from
 	__shared__ int32_t s_n[64], s_m[64], s_kmin[64], s_S[64], s_si[64], s_state[64];   // per segment of the group; state 0 none, 1 walk, 2 next tier, 3 literal kernel
+	__shared__ int32_t s_item[64];                             // the group's segments, shortest first
 	const int lane = threadIdx.x, sg = lane / LANES, L = lane % LANES, lead = sg * LANES;
 	const bool leader = L == 0;
 	const int a = B.sc_a, bmis = -B.sc_b, q = B.gap_q, e = B.gap_e, q2 = B.gap_q2, e2 = B.gap_e2;
@@ -517,13 +518,28 @@ __global__ __launch_bounds__(64) void mnc_dp_fillp(Batch B, const int32_t *list,
 		q0 = (unsigned long long)__shfl((long long)q0, 0);
 		if (q0 >= n_items) break;                              // every wave gets here: the queue is finite
 		s_state[lane] = 0;
+		// the group's segments in the order of their lengths: the SEGS segments of a pass run as many steps as the
+		// longest of them, and neighbours in this order differ by a few steps instead of by up to a hundred
+		{
+			int my_si = -1, my_rows = INT32_MAX;
+			if (lane < g_eff * SEGS && q0 + lane < n_items) {
+				my_si = list[q0 + lane];
+				const Seg *gs = B.segs + my_si;
+				my_rows = gs->tlen + gs->qlen;
+			}
+			int rank = 0;
+			for (int j = 0; j < 64; ++j) {
+				const int rj = __shfl(my_rows, j);
+				rank += (rj < my_rows || (rj == my_rows && j < lane)) ? 1 : 0;
+			}
+			s_item[rank] = my_si;
+		}
 		fill_order();
 		// ================================================ forward passes
 		for (int u = 0; u < g_eff; ++u) {
 			if (q0 + (unsigned long long)u * SEGS >= n_items) break;
-			const unsigned long long item = q0 + (unsigned long long)u * SEGS + sg;
-			const bool has = item < n_items;
-			const long long si = has ? (long long)list[item] : -1;
+			const long long si = s_item[u * SEGS + sg];
+			const bool has = si >= 0;
 			struct { int32_t tlen, qlen, ts, qs, read, rid, rev; } g = { 0, 0, 0, 0, 0, 0, 0 };
 			if (has) {
 				const Seg *gs = B.segs + si;
