@@ -1,29 +1,32 @@
-// Stage kernel K8b: gap filling between two seeds, the common case of the base-level alignment
-// stage -- gfx950.
+// Stage kernels K8b / K8c: gap filling between two seeds and the extensions, the common cases of
+// the base-level alignment stage -- gfx950.
 //
 // Replaces the first (approximate-maximum) pass of mm_align1's gap filling: ksw_extd2_sse as a
 // GLOBAL alignment of ~200 x 200 bases with a band (1.5 bw + 1 = 751) that never clips such a
-// matrix, then mm_test_zdrop on its CIGAR (monica/genomes/aligner.py:193, 215).
+// matrix, then mm_test_zdrop on its CIGAR; and the left / right extension calls of the same
+// function (monica/genomes/aligner.py:193, 215).
 //
 // ksw2 fills the whole matrix because its band is wider than the matrix.  The alignment it
-// reports lies close to the main diagonal, so this kernel fills only a diagonal band and then
-// PROVES that the band held the answer: a path that leaves a band of half-width b around the
+// reports lies close to the main diagonal, so the gap-filling kernels fill only a diagonal band and
+// then PROVE that the band held the answer: a path that leaves a band of half-width b around the
 // diagonals 0 .. tlen - qlen has at least b + 1 gap bases more than it needs in each direction,
 // which bounds its score by U = a (matches left) - gap(b + 1 ...) (dp_band_bound); when the
 // banded score is strictly above U, every co-optimal path lies inside the band, every value on
 // them equals the full matrix's, and the backtrack takes the same turns (ties are between
-// co-optimal paths, all inside).  Otherwise the segment goes to the next tier: 64 lanes instead
-// of 32 per segment, then the literal kernel of k_align.hip (also for a CIGAR whose walk shows
-// a Z-drop: that needs the exact second pass).
+// co-optimal paths, all inside).  Otherwise the segment goes to the next, wider tier and in the end
+// to the literal kernel of k_align.hip (also a CIGAR whose walk shows a Z-drop: that needs the
+// exact second pass).
 //
-// A segment is one half-wave (or one wave): lane L holds cell t = t0(r) + L of anti-diagonal r
-// (t = target index, t0 advances every other step), absolute int32 scores, two-piece affine
-// gaps.  A cell needs H of the same lane two steps back (the diagonal), the gap states its upper
-// neighbour produced (lane L - 1 or L, by the parity of the step) and those of its left
-// neighbour (lane L or L + 1): all state is in registers, two values cross lanes per step.
-// Direction bytes (which of H / E / F / E2 / F2 wins, with ksw2's priority; "the next cell's
-// gap state extends this one" x 4) stream to HBM, 32 (64) contiguous bytes per segment and
-// step; the backtrack walks them through a 16-row window in LDS that the whole half-wave refills.
+// In this file, in order:
+//   mnc_dp_fill<64, 4, 2047>   the band in int32, one cell per lane and register -- the round's first
+//                              form of the kernel, kept for gaps of 512 .. 2047 bases (256-cell band)
+//   mnc_dp_fillp<16|32|64>     the same band on packed 16-bit pairs (32 / 64 / 128 cells): the
+//                              batch's dominant kernel; 16 forward passes per wave, one walk per lane
+//   mnc_dp_ext<LANES, CPL>     extensions step by step: full anti-diagonals, the maximum of each in
+//                              the SSE scan's tie order, ksw_apply_zdrop -- what the packed extension
+//                              kernel hands back, and extensions of 257 .. 512 bases (8 cells per lane)
+//   mnc_dp_extp<LANES, CPL, RGT>  extensions on packed pairs, one cell per query base
+// Direction bytes stream to HBM; scores, gap states and sequences stay in registers / LDS.
 #include "device.h"
 
 namespace mnc {
