@@ -681,7 +681,9 @@ static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream
 	mark(MNC_STAGE_DP_EXT, 1);
 	// the literal kernel's lists known at planning time, beside the banded kernels (`s2`: the batch's own stream,
 	// idle between fork and join: the side streams share hardware queues among themselves)
-	launch_dp_lext(B, B.lext_list, 62, 63, B.fill_fb, 12, e->ws->lext_p.as<uint8_t>(), DP_WG_LEXT, s2);
+	// the long extensions: beside the long gaps in a micro-batch (on the stream of the literal kernel, which has little to do there), behind them
+	// on the batch's stream otherwise (the extension stream is busy to the end)
+	launch_dp_lext(B, B.lext_list, 62, 63, B.fill_fb, 12, e->ws->lext_p.as<uint8_t>(), DP_WG_LEXT, B.n_reads < 4096 ? s3 : s2);
 	// the literal kernel's long calls on a stream of their own (`s3`: the side stream whose hardware queue no other uses)
 	launch_dp_align(B, e->ws->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 1, s3);
 	launch_dp_align(B, e->ws->dp_ws_mid.as<uint8_t>(), DP_WG_MID, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, 0, 3, s3);
