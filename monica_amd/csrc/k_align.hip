@@ -1254,9 +1254,67 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 				}
 			}
 			};
+			// The usual CIGAR (hundreds of short operations): every lane takes a contiguous share of the operations
+			// and composes their maps one after the other in registers -- x -> max(x + A, Bv) after an event d is
+			// A += d, Bv = max(Bv + d, 0), and the largest value on the way is max(x + MA, MB) with the running
+			// maxima of A and Bv -- then ONE scan over the 64 lane maps gives every lane the score it starts from.
+			// No event array, no scan per 64 events.  A CIGAR with few or very long operations (a clean read:
+			// "5000M") would leave most lanes idle: it takes the event form below.
+			bool lane_form = n_c >= 128;
+			if (lane_form) {
+				int longest = 0;
+				for (int k = lane; k < n_c; k += 64) { const int len = (int)(C[k] >> 4); longest = longest > len ? longest : len; }
+				lane_form = dpp_max_all(longest) <= 384;
+			}
+			if (lane_form) {
+				const int per = (n_c + 63) / 64;
+				const int k_lo = lane * per < n_c ? lane * per : n_c, k_hi = k_lo + per < n_c ? k_lo + per : n_c;
+				int dq = 0, dt = 0;
+				for (int k = k_lo; k < k_hi; ++k) {
+					const uint32_t wd = C[k], op = wd & 0xf;
+					const int len = (int)(wd >> 4);
+					if (op != 2) dq += len;
+					if (op != 1) dt += len;
+				}
+				int qo = qshift + dpp_incl_add(dq) - dq, to = tshift + dpp_incl_add(dt) - dt;
+				int A = 0, Bv = SC_NONE, MA = SC_NONE, MB = SC_NONE, my_blen = 0, my_mlen = 0;
+				for (int k = k_lo; k < k_hi; ++k) {
+					const uint32_t wd = C[k], op = wd & 0xf;
+					const int len = (int)(wd >> 4);
+					my_blen += len;
+					if (op == 0) {
+						my_mlen += len;
+						for (int i = 0; i < len; ++i) {
+							const int cq = Q(qo + i), ct = Tg(to + i);
+							int dlt;
+							if (ct > 3 || cq > 3) ++c_amb, dlt = -B.sc_ambi;
+							else if (ct != cq) ++c_diff, dlt = -B.sc_b;
+							else dlt = B.sc_a;
+							A += dlt, Bv = Bv + dlt > 0 ? Bv + dlt : 0;
+							MA = MA > A ? MA : A, MB = MB > Bv ? MB : Bv;
+						}
+						qo += len, to += len;
+					} else {
+						for (int i = 0; i < len; ++i) c_gamb += (op == 1 ? Q(qo + i) : Tg(to + i)) > 3;
+						const int dlt = -(B.gap_q + B.gap_e * len);
+						A += dlt, Bv = Bv + dlt > 0 ? Bv + dlt : 0;
+						MA = MA > A ? MA : A, MB = MB > Bv ? MB : Bv;
+						if (op == 1) qo += len; else to += len;
+					}
+				}
+				// the score every lane starts from: the lanes before it, composed, applied to 0
+				int fa = A, fb = Bv;
+				dpp_scan_maps(fa, fb);
+				const int x_out = fa > fb ? fa : fb;                                 // max(0 + fa, fb)
+				int x_in = __shfl_up(x_out, 1);
+				if (lane == 0) x_in = 0;
+				const int top = k_lo < k_hi ? (x_in + MA > MB ? x_in + MA : MB) : 0;
+				s_max = dpp_max_all(top > 0 ? top : 0);
+				blen = __builtin_amdgcn_readlane(dpp_incl_add(my_blen), 63), mlen = __builtin_amdgcn_readlane(dpp_incl_add(my_mlen), 63);
+			}
 			// 64 operations at a time, one lane each: offsets by prefix sums, every lane lays out its
 			// operation's events (an M run: one per base; a gap: one) and counts
-			for (int k0 = 0; k0 < n_c; k0 += 64) {
+			for (int k0 = 0; k0 < n_c && !lane_form; k0 += 64) {
 				const int k = k0 + lane, k1 = k0 + 64 < n_c ? k0 + 64 : n_c;
 				const uint32_t wd = k < n_c ? C[k] : 0;
 				const uint32_t op = wd & 0xf;
@@ -1288,7 +1346,7 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 				mlen += __builtin_amdgcn_readlane(dpp_incl_add(k < n_c && op == 0 ? len : 0), 63);
 				qoff += __builtin_amdgcn_readlane(iq, 63), toff += __builtin_amdgcn_readlane(it, 63), ev += tot_ev;
 			}
-			flush();
+			if (!lane_form) flush();
 			for (int sft = 32; sft > 0; sft >>= 1) c_amb += __shfl_xor(c_amb, sft), c_diff += __shfl_xor(c_diff, sft), c_gamb += __shfl_xor(c_gamb, sft);
 			blen -= c_amb + c_gamb, mlen -= c_amb + c_diff, n_ambi = c_amb + c_gamb;
 			r.mlen = mlen, r.blen = blen, r.n_ambi += n_ambi, r.dp_max = s_max, r.n_cigar = n_c;
