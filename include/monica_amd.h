@@ -186,7 +186,10 @@ int mnc_engine_set_profiling(mnc_engine *eng, int on);    /* HIP events around e
 int mnc_engine_set_debug(mnc_engine *eng, int mode);      /* test switches, a bit mask: 2 stress build of the
                                                              chaining ring, 4 displacement bytes read from HBM,
                                                              0x10000 the alignment kernels one at a time (per-kernel
-                                                             timers), bits 8-15 a tuning value for the tier choice */
+                                                             timers), bits 8-15 a tuning value for the tier choice,
+                                                             0x20000 / 0x40000 / 0x80000 / 0x100000 without the packed
+                                                             extension / packed gap-filling / long-gap / long-extension
+                                                             kernels (their calls go to the next kernel in line) */
 /* accumulated since the last reset: ms[MNC_N_STAGES], launches[MNC_N_STAGES] */
 int mnc_engine_get_timings(mnc_engine *eng, double *ms, int64_t *launches, int reset);
 const char *mnc_stage_name(int stage);

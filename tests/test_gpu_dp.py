@@ -174,3 +174,25 @@ def test_results_do_not_depend_on_scheduling(capi, world):
             assert np.array_equal(now[1], first[1]) and np.array_equal(now[2], first[2])
             for name in capi.REG_DTYPE.names:
                 assert np.array_equal(now[0][name], first[0][name]), name
+
+
+@pytest.mark.parametrize("route", [0x20000, 0x40000, 0x80000 | 0x100000, 0x20000 | 0x40000 | 0x80000 | 0x100000])
+def test_every_kernel_family_can_be_taken_out(capi, oracle, world, route):
+    """The alignment stage sorts its kernel calls over several kernels (packed gap filling, packed extensions, the
+    long-call kernels, the step-by-step extension kernel, ksw2's kernel literally).  With a family switched off its
+    calls go to the next kernel in line -- in the end all of them to the literal one -- and nothing may change."""
+    reads = [synth.reads(world["seqs"], 40, 3000, seed=31, sub=800, ins=600, dele=600), synth.reads(world["seqs"], 60, 5000, seed=0x5EED + 9)]
+    g0 = world["seqs"][0]
+    rng = np.random.default_rng(3)
+    junk = lambda n: util.ACGT[rng.integers(0, 4, n)]
+    extra = [np.concatenate([junk(900), g0[60000:63000], junk(700)]), np.concatenate([g0[100000:102500], g0[103500:106000]]),
+             np.concatenate([g0[30000:32000], junk(700), g0[32700:34700]])]
+    eng = world["eng"]
+    try:
+        eng.set_debug(route)
+        for b, o, _ in reads:
+            _compare_dp(capi, oracle, world, b, o, min_mapq=0)
+        b, o = util.pack_reads(extra)
+        _compare_dp(capi, oracle, world, b, o, min_mapq=0)
+    finally:
+        eng.set_debug(0)
