@@ -202,6 +202,13 @@ const char *mnc_stage_kernel(int stage);                  /* kernel symbol, for 
  * ran, [15] anti-diagonal steps x query bases of the extensions given to the packed extension kernel */
 int mnc_engine_get_counters(mnc_engine *eng, int64_t *c, int n);
 
+/* Test hooks of the index residency: the device tables (hash-and-displace perfect hash per table region) are built
+ * on the device; `on` = 1 makes the next upload of this index use the host form of the same construction instead;
+ * mnc_engine_dump_tables copies what the engine's device holds ([region_bits, disp_bits] int32, salts, displacement
+ * bytes, presence filter, table slots) so that the two can be compared. */
+int mnc_index_set_host_tables(mnc_index *idx, int on);
+int mnc_engine_dump_tables(mnc_engine *eng, void *dst, int64_t cap_bytes, int64_t *n_bytes);
+
 /* stage dumps of the last batch, for kernel-level parity tests */
 #define MNC_DUMP_MINIMIZERS 1  /* u32 pairs {hash, pos<<1|strand} in read order                    */
 #define MNC_DUMP_MZ_OFFSETS 2  /* int64[n_reads+1]                                              */

@@ -45,7 +45,7 @@ EXPORTS = [
     "mnc_engine_create", "mnc_engine_destroy", "mnc_engine_stream",
     "mnc_classify_batch", "mnc_classify_device", "mnc_engine_sync", "mnc_engine_fetch_hits",
     "mnc_counts", "mnc_best_hit",
-    "mnc_engine_set_profiling", "mnc_engine_set_debug", "mnc_engine_set_contract",
+    "mnc_engine_set_profiling", "mnc_engine_set_debug", "mnc_engine_set_contract", "mnc_index_set_host_tables", "mnc_engine_dump_tables",
     "mnc_comm_unique_id", "mnc_comm_init_rank", "mnc_comm_destroy", "mnc_allreduce_counts", "mnc_allgather_summaries", "mnc_engine_get_timings", "mnc_stage_name", "mnc_stage_kernel",
     "mnc_engine_get_counters", "mnc_engine_dump",
     "mnc_fastq_open", "mnc_fastq_close", "mnc_fastq_next", "mnc_fastq_bases", "mnc_fastq_offsets",
@@ -125,6 +125,8 @@ def lib():
     sig("mnc_best_hit", i32, [vp, i32, C.POINTER(i32)])
     sig("mnc_engine_set_profiling", i32, [vp, i32])
     sig("mnc_engine_set_debug", i32, [vp, i32])
+    sig("mnc_index_set_host_tables", i32, [vp, i32])
+    sig("mnc_engine_dump_tables", i32, [vp, vp, C.c_int64, vp])
     sig("mnc_engine_set_contract", i32, [vp, i32])
     sig("mnc_comm_unique_id", i32, [vp])
     sig("mnc_comm_init_rank", i32, [vp, i32, i32, C.POINTER(vp)])
@@ -394,6 +396,16 @@ class Engine:
     def set_debug(self, mode=1):
         """mode 2 = stress build of the chaining kernel (every look-back through HBM)."""
         check(lib().mnc_engine_set_debug(self._h, int(mode)))
+
+    def dump_tables(self):
+        """The device tables of this engine's index as bytes (test hook)."""
+        n = C.c_int64(0)
+        rc = lib().mnc_engine_dump_tables(self._h, None, 0, C.byref(n))
+        if rc not in (OK, ERR_RANGE):
+            check(rc)
+        buf = np.zeros(n.value, dtype=np.uint8)
+        check(lib().mnc_engine_dump_tables(self._h, buf.ctypes.data, len(buf), C.byref(n)))
+        return buf
 
     def timings(self, reset=False):
         ms = np.zeros(N_STAGES, dtype=np.float64)

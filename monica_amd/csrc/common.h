@@ -101,6 +101,7 @@ struct mnc_index {
 	// device residency
 	std::mutex dev_mutex;
 	std::deque<mnc::DeviceIndex> dev;   // a deque: engines keep pointers to its elements
+	bool host_tables = false;           // test switch: build the device tables with the host form (mnc_index_set_host_tables)
 };
 
 namespace mnc {

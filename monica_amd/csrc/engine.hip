@@ -236,6 +236,26 @@ static int check_device(int device)
 	return MNC_OK;
 }
 
+int index_tables_on_device(const std::vector<uint32_t> &keys, const std::vector<uint64_t> &key_off, const std::vector<uint32_t> &reg_count,
+                           int region_bits, int disp_bits, TableSlot *d_table, uint8_t *d_disp, uint32_t *d_salt, uint32_t *d_filter,
+                           const uint64_t *d_positions);
+
+// the rest of the index (occurrence words, genome of a contig, contig bases) next to tables that are on the device already
+static int index_upload_rest(mnc_index *idx, DeviceIndex &d)
+{
+	auto upload = [&](void **dst, const void *src, size_t bytes, size_t spare = 0) -> int {
+		HIP_TRY(hipMalloc(dst, bytes + spare ? bytes + spare : 8));
+		if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+		return MNC_OK;
+	};
+	int urc = MNC_OK;
+	if (!d.positions) urc = upload((void**)&d.positions, idx->pos.data(), idx->pos.size() * 8, 8);   // one spare word behind the positions
+	if (!urc) urc = upload((void**)&d.contig_genome, idx->contig_genome.data(), idx->contig_genome.size() * 4);
+	if (!urc) urc = upload((void**)&d.seq4, idx->seq4.data(), idx->seq4.size() * 4, 16);
+	if (!urc) urc = upload((void**)&d.seq_off, idx->seq_off.data(), idx->seq_off.size() * 8);
+	return urc;
+}
+
 int index_upload(mnc_index *idx, int device, DeviceIndex **out)
 {
 	std::lock_guard<std::mutex> lk(idx->dev_mutex);
@@ -243,12 +263,38 @@ int index_upload(mnc_index *idx, int device, DeviceIndex **out)
 	if (idx->keys.empty()) { set_error("empty index"); return MNC_ERR_FORMAT; }
 	HIP_TRY(hipSetDevice(device));
 	// ---- regions: PB_N blocks of R slots (load <= 0.5), perfectly hashed by hash-and-displace
-	std::vector<std::vector<uint32_t>> reg(PB_N);       // key indices per region
-	for (size_t i = 0; i < idx->keys.size(); ++i) reg[pb_bucket(idx->keys[i])].push_back((uint32_t)i);
+	std::vector<uint32_t> reg_count(PB_N, 0);
+	for (size_t i = 0; i < idx->keys.size(); ++i) ++reg_count[pb_bucket(idx->keys[i])];
 	size_t biggest = 0;
-	for (auto &v : reg) biggest = std::max(biggest, v.size());
+	for (uint32_t c : reg_count) biggest = std::max(biggest, (size_t)c);
 	int region_bits = 6;
 	while ((1ULL << region_bits) < biggest * 2) ++region_bits;
+	// ---- the construction on the device (k_index.hip): the same tables in a few milliseconds; the host form below
+	// takes over when a region does not fit that kernel (or needs larger regions)
+	if (!idx->host_tables && region_bits <= 28) {
+		DeviceIndex d;
+		d.device = device, d.region_bits = region_bits, d.disp_bits = std::max(0, region_bits - 3);
+		const size_t Rd = (size_t)1 << d.region_bits, NBd = (size_t)1 << d.disp_bits;
+		bool ok = hipMalloc((void**)&d.filter, (size_t)PB_N * PF_WORDS * 4) == hipSuccess && hipMalloc((void**)&d.disp, (size_t)PB_N * NBd) == hipSuccess &&
+		          hipMalloc((void**)&d.salt, PB_N * 4) == hipSuccess && hipMalloc((void**)&d.table, (size_t)PB_N * Rd * sizeof(TableSlot)) == hipSuccess &&
+		          hipMalloc((void**)&d.positions, idx->pos.size() * 8 + 8) == hipSuccess &&
+		          hipMemcpy(d.positions, idx->pos.data(), idx->pos.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+		int trc = ok ? index_tables_on_device(idx->keys, idx->key_off, reg_count, d.region_bits, d.disp_bits, d.table, d.disp, d.salt, d.filter, d.positions) : 1;
+		if (trc == 0) trc = index_upload_rest(idx, d) == MNC_OK ? 0 : -1;
+		if (trc == 0) {
+			d.bytes = (int64_t)((size_t)PB_N * Rd * sizeof(TableSlot) + (size_t)PB_N * PF_WORDS * 4 + (size_t)PB_N * NBd + (idx->pos.size() + 1) * 8 +
+			                    idx->contig_genome.size() * 4 + idx->seq4.size() * 4 + idx->seq_off.size() * 8);
+			idx->dev.push_back(d);
+			*out = &idx->dev.back();
+			return MNC_OK;
+		}
+		(void)hipGetLastError();
+		void *parts[] = { d.filter, d.disp, d.salt, d.table, d.positions, d.contig_genome, d.seq4, d.seq_off };
+		for (void *q : parts) if (q) (void)hipFree(q);
+		if (trc < 0) { set_error("index upload failed"); return MNC_ERR_NOMEM; }
+	}
+	std::vector<std::vector<uint32_t>> reg(PB_N);       // key indices per region
+	for (size_t i = 0; i < idx->keys.size(); ++i) reg[pb_bucket(idx->keys[i])].push_back((uint32_t)i);
 	int disp_bits = 0;
 	size_t R = 0, NB = 0;
 	std::vector<TableSlot> tab;
@@ -592,6 +638,38 @@ extern "C" int mnc_engine_create(mnc_index *idx, int device, mnc_engine **out)
 }
 
 extern "C" void *mnc_engine_stream(mnc_engine *e) { return e ? (void*)e->stream : nullptr; }
+
+extern "C" int mnc_index_set_host_tables(mnc_index *idx, int on)
+{
+	if (!idx) return MNC_ERR_ARG;
+	std::lock_guard<std::mutex> lk(idx->dev_mutex);
+	idx->host_tables = on != 0;
+	return MNC_OK;
+}
+
+// the device tables of an engine's index, for tests: [region_bits, disp_bits] int32, salt[PB_N], displacement bytes,
+// presence filter words, table slots
+extern "C" int mnc_engine_dump_tables(mnc_engine *e, void *dst, int64_t cap_bytes, int64_t *n_bytes)
+{
+	if (!e || !n_bytes || !e->didx) return MNC_ERR_ARG;
+	HIP_TRY(hipSetDevice(e->device));
+	const DeviceIndex &d = *e->didx;
+	const size_t R = (size_t)1 << d.region_bits, NB = (size_t)1 << d.disp_bits;
+	const size_t sz[] = { 8, PB_N * 4, (size_t)PB_N * NB, (size_t)PB_N * PF_WORDS * 4, (size_t)PB_N * R * sizeof(TableSlot) };
+	*n_bytes = (int64_t)(sz[0] + sz[1] + sz[2] + sz[3] + sz[4]);
+	if (!dst || cap_bytes < *n_bytes) return MNC_ERR_RANGE;
+	uint8_t *o = (uint8_t*)dst;
+	const int32_t hdr[2] = { d.region_bits, d.disp_bits };
+	memcpy(o, hdr, 8), o += 8;
+	HIP_TRY(hipMemcpy(o, d.salt, sz[1], hipMemcpyDeviceToHost));
+	o += sz[1];
+	HIP_TRY(hipMemcpy(o, d.disp, sz[2], hipMemcpyDeviceToHost));
+	o += sz[2];
+	HIP_TRY(hipMemcpy(o, d.filter, sz[3], hipMemcpyDeviceToHost));
+	o += sz[3];
+	HIP_TRY(hipMemcpy(o, d.table, sz[4], hipMemcpyDeviceToHost));
+	return MNC_OK;
+}
 
 extern "C" int mnc_engine_sync(mnc_engine *e)
 {

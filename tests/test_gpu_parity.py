@@ -350,3 +350,16 @@ def test_chain_ring_stress_build(capi, oracle, world):
     finally:
         eng.set_debug(0)
     _compare_batch(capi, oracle, world, eb, eo)
+
+
+@pytest.mark.gpu
+def test_device_built_tables_equal_the_host_form(capi):
+    """The device tables of an index (per-region hash-and-displace perfect hash, displacement bytes, salts,
+    presence filter) are built on the device; the host form of the same construction is the reference."""
+    for n, lo, hi in ((4, 200_000, 300_000), (3, 1_500_000, 2_500_000)):
+        names, seqs = util.small_genomes(n, lo, hi)
+        a = capi.Index.from_seqs(names, seqs)
+        b = capi.Index.from_seqs(names, seqs)
+        capi.check(capi.lib().mnc_index_set_host_tables(b._h, 1))
+        ta, tb = capi.Engine(a, 0).dump_tables(), capi.Engine(b, 0).dump_tables()
+        assert len(ta) == len(tb) and np.array_equal(ta, tb)
