@@ -344,7 +344,7 @@ def main():
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
-        "dtype": "u32/u64 integer, int8 DP differences (float32 islands: overlap ratio, MAPQ)",
+        "dtype": "u32/u64 integer; int16 pairs in the alignment kernels (int32 / int8 in the long-call and literal ones); float32 islands: overlap ratio, MAPQ",
         "data": "synthetic",
         "config": {"workload": f"{args.reads} synthetic {args.read_len} nt reads per GPU per step vs "
                                f"{args.genomes}-genome minimizer index ({info.total_len} bp, {info.n_keys} keys, "
