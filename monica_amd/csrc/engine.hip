@@ -728,12 +728,15 @@ struct StageTimer {
 }
 
 // The kernel calls of a round run on four streams side by side -- they touch different segments --
-// and meet before the literal kernel's last pass, which takes what the others handed back:
-//   s0  gap fillings on the banded kernel: 32 lanes per segment, then 64, then 128 cells for those
-//       whose band could not be proven wide enough
-//   s1  the extensions of most regions (small matrices, their own kernel)
-//   s2  the literal kernel's first pass: unusual small calls
-//   s3  the few calls that need the large workspace
+// and meet before the literal kernel's last passes, which take what the others handed back:
+//   s0  gap fillings on the packed banded kernel: 32 cells per segment, then 64, then 128 for those whose band
+//       could not be proven wide enough
+//   s1  the extensions: the packed kernel (by query length and side), then the step-by-step kernel for what it
+//       handed back
+//   s2  (the batch's own stream) the long gaps first, the long extensions, the literal kernel's small calls
+//   s3  (the side stream with a hardware queue of its own) the literal kernel's few long calls
+// The chip-filling kernels (s0, s1) are bound by vector issue; the others are serial work on single waves that
+// fills the gaps.  With debug bit 0x10000 all four are the same stream (one kernel at a time, per-kernel timers).
 static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream_t s1, hipStream_t s2, hipStream_t s3)
 {
 	// per-kernel timers: only when everything runs on one stream (debug bit 0x10000)
@@ -757,10 +760,8 @@ static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream
 	launch_dp_ext(B, 128, B.ext_list3, 24, 26, B.fill_fb, 12, e->ws->ext_p.as<uint8_t>(), DP_WG_EXT / 2, s1);
 	launch_dp_ext(B, 256, B.ext_list4, 25, 27, B.fill_fb, 12, e->ws->ext_p.as<uint8_t>(), DP_WG_EXT / 4, s1);
 	mark(MNC_STAGE_DP_EXT, 1);
-	// the literal kernel's lists known at planning time, beside the banded kernels (`s2`: the batch's own stream,
-	// idle between fork and join: the side streams share hardware queues among themselves)
-	// the long extensions: beside the long gaps in a micro-batch (on the stream of the literal kernel, which has little to do there), behind them
-	// on the batch's stream otherwise (the extension stream is busy to the end)
+	// the long extensions: beside the long gaps in a micro-batch (on the stream of the literal kernel, which has little
+	// to do there), behind them on the batch's stream otherwise
 	launch_dp_lext(B, B.lext_list, 62, 63, B.fill_fb, 12, e->ws->lext_p.as<uint8_t>(), DP_WG_LEXT, B.n_reads < 4096 ? s3 : s2);
 	// the literal kernel's long calls on a stream of their own (`s3`: the side stream whose hardware queue no other uses)
 	launch_dp_align(B, e->ws->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 1, s3);
