@@ -199,7 +199,9 @@ const char *mnc_stage_kernel(int stage);                  /* kernel symbol, for 
  * alignment stage (last round): [8] kernel calls (segments), [9] gap fillings given to the banded kernel's
  * 32-cell tier, [10] those its 64-cell tier saw, [11] those handed back to the literal kernel; with
  * n >= 16: [12] / [13] / [14] anti-diagonals (steps) of the gap fillings the 32- / 64- / 128-cell tier
- * ran, [15] anti-diagonal steps x query bases of the extensions given to the packed extension kernel */
+ * ran, [15] anti-diagonal steps x query bases of the extensions given to the packed extension kernel; with n >= 24
+ * (last round): [16] / [17] calls planned for the literal kernel's large / small workspace, [18] long gaps (int32 banded
+ * kernel), [19] those handed back that need the large workspace, [20] long extensions, [21] gap fillings the 128-cell tier saw */
 int mnc_engine_get_counters(mnc_engine *eng, int64_t *c, int n);
 
 /* Test hooks of the index residency: the device tables (hash-and-displace perfect hash per table region) are built

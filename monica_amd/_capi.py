@@ -415,11 +415,12 @@ class Engine:
         return {names[s]: (float(ms[s]), int(ln[s])) for s in range(N_STAGES)}
 
     def counters(self):
-        c = np.zeros(16, dtype=np.int64)
-        check(lib().mnc_engine_get_counters(self._h, c.ctypes.data, 16))
+        c = np.zeros(24, dtype=np.int64)
+        check(lib().mnc_engine_get_counters(self._h, c.ctypes.data, 24))
         keys = ["minimizers", "probe_hits", "anchors", "chains", "regions", "gated_hits", "ambiguous_reads", "_",
                 "dp_segments", "dp_fill_tier1", "dp_fill_tier2", "dp_fill_handed_back",
-                "dp_fill_steps_t1", "dp_fill_steps_t2", "dp_fill_steps_t3", "dp_ext_cell_steps"]
+                "dp_fill_steps_t1", "dp_fill_steps_t2", "dp_fill_steps_t3", "dp_ext_cell_steps",
+                "dp_literal_big", "dp_literal_mid", "dp_long_gaps", "dp_literal_big_handed_back", "dp_long_extensions", "dp_fill_tier3"]
         return dict(zip(keys, (int(x) for x in c)))
 
     def dump(self, what, dtype):

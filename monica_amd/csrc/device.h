@@ -220,6 +220,7 @@ struct Batch {
 	int32_t *ext_list3, *ext_list4;               // ... 128 / 256 cells (two / four per lane)
 	int32_t *gen_list;                            // the literal kernel's first pass
 	int32_t *lfill_list;                          // gaps of 512 .. 2047 bases, int32 banded kernel (256 cells): length dp_ctr[31], queue [61]
+	int32_t *huge_list;                           // the few calls beyond the large workspace's slots (literal kernel, pass 5): length dp_ctr[58], queue [59]
 	int32_t *bigfb_list;                          // calls the banded kernel hands back that need the literal kernel's large workspace: length dp_ctr[56], queue [57]
 	int32_t *lext_list;                           // extensions of 257 .. 512 bases on the shorter side (step-by-step kernel, 8 cells per lane): length dp_ctr[62], queue [63]
 	int32_t *mid_list;                            // the literal kernel, segments its first pass' LDS layout cannot hold: lengths dp_ctr[28], queue [29]

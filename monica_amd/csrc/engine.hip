@@ -40,7 +40,7 @@ void launch_dp_gather(const Batch &B, hipStream_t st);
 void launch_dp_round(const Batch &B, int first, hipStream_t st);
 void launch_dp_round_end(const Batch &B, hipStream_t st);
 void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work, int state_max, long long p_max, int cig_max,
-                    long long big_state, long long big_p, long long big_cig, hipStream_t st);
+                    long long big_state, long long big_p, long long big_cig, long long huge_state, long long huge_p, long long huge_cig, hipStream_t st);
 size_t dp_align_ws_bytes(long long state_max, long long p_max, long long cig_max);
 int dp_align_prepare(int lds_bytes);
 void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max, long long p_max, long long cig_max,
@@ -63,9 +63,10 @@ constexpr int DP_WG_FILL = 256 * 16, DP_WG_EXT = 256 * 8;
 // workspace classes of the alignment kernel: a normal slot per workgroup, a few large ones
 constexpr int DP_LDS_BYTES = 16 * 1024;
 constexpr int DP_LDS0_STATE = 4 * 1024, DP_LDS0_P = 10 * 1024, DP_LDS0_CIG = 256;   // pass 0: 15 KB per workgroup
-constexpr int DP_WG_SMALL = 2048, DP_WG_BIG = 8, DP_WG_MID = 512, DP_WG_LFILL = 2048, DP_WG_LEXT = 512;
+constexpr int DP_WG_SMALL = 2048, DP_WG_BIG = 768, DP_WG_HUGE = 8, DP_WG_MID = 512, DP_WG_LFILL = 2048, DP_WG_LEXT = 512;
 constexpr long long DP_STATE_SMALL = 96 * 1024, DP_P_SMALL = 1 << 20, DP_CIG_SMALL = 4096;
-constexpr long long DP_STATE_BIG = 13 * 32768, DP_P_BIG = 256LL << 20, DP_CIG_BIG = 65536;
+constexpr long long DP_STATE_BIG = 13 * 32768, DP_P_BIG = 8LL << 20, DP_CIG_BIG = 65536;       // 768 slots of 9 MB: any extension (max_gap 5000 on both sides: 7.7 MB of direction bytes)
+constexpr long long DP_STATE_HUGE = 13 * 32768, DP_P_HUGE = 256LL << 20, DP_CIG_HUGE = 65536;   // and 8 of 257 MB for anything up to max_sw_mat
 void launch_gather_hits(const Batch &B, const mnc_hit_t *gated, const int64_t *hit_off, mnc_hit_t *out, hipStream_t st);
 
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
@@ -202,8 +203,8 @@ struct Buf {
 struct SharedWs {
 	std::mutex mu;
 	int refs = 0;
-	Buf fill_p, fill_cig, extp_p, extp_cig, ext_p, lfill_p, lext_p, dp_ws, dp_ws_mid, dp_ws_big;
-	void release() { for (Buf *b : { &fill_p, &fill_cig, &extp_p, &extp_cig, &ext_p, &lfill_p, &lext_p, &dp_ws, &dp_ws_mid, &dp_ws_big }) b->release(); }
+	Buf fill_p, fill_cig, extp_p, extp_cig, ext_p, lfill_p, lext_p, dp_ws, dp_ws_mid, dp_ws_big, dp_ws_huge;
+	void release() { for (Buf *b : { &fill_p, &fill_cig, &extp_p, &extp_cig, &ext_p, &lfill_p, &lext_p, &dp_ws, &dp_ws_mid, &dp_ws_big, &dp_ws_huge }) b->release(); }
 };
 static std::mutex g_ws_mu;
 static SharedWs *g_ws[64];
@@ -451,7 +452,7 @@ struct mnc_engine {
 	Buf stats, cls_count, cls_list;
 	// base-level alignment stage
 	int contract = MNC_CONTRACT_DP;
-	Buf ca, ca_cnt, chain_dst, regdp, segs, cig_seg, cig_reg, dp_ctr, work_a, work_b, big_list, reg_cnt, regs2;
+	Buf ca, ca_cnt, chain_dst, regdp, segs, cig_seg, cig_reg, dp_ctr, work_a, work_b, big_list, huge_list, reg_cnt, regs2;
 	SharedWs *ws = nullptr;                  // the device's alignment scratch (held during the alignment stage only)
 	Buf fill1, fill2, fill3, fill_fb, extp, mid_list, lfill, lext, bigfb, ext1, ext2, ext3, ext4, gen_list;
 	size_t seg_cap_override = 0, cig_cap_override = 0;
@@ -557,7 +558,7 @@ extern "C" void mnc_engine_destroy(mnc_engine *e)
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
 	Buf *all[] = { &e->gap_lut, &e->logf_lut, &e->logf_a_lut, &e->ca, &e->ca_cnt, &e->chain_dst, &e->regdp, &e->segs, &e->cig_seg, &e->cig_reg, &e->dp_ctr,
-	               &e->work_a, &e->work_b, &e->big_list, &e->reg_cnt, &e->regs2, &e->fill1, &e->fill2, &e->fill3, &e->fill_fb, &e->extp, &e->mid_list, &e->lfill, &e->lext, &e->bigfb, &e->ext1, &e->ext2, &e->ext3, &e->ext4, &e->gen_list, &e->in_bases, &e->in_offsets, &e->out_assign, &e->out_best, &e->out_nhits,
+	               &e->work_a, &e->work_b, &e->big_list, &e->huge_list, &e->reg_cnt, &e->regs2, &e->fill1, &e->fill2, &e->fill3, &e->fill_fb, &e->extp, &e->mid_list, &e->lfill, &e->lext, &e->bigfb, &e->ext1, &e->ext2, &e->ext3, &e->ext4, &e->gen_list, &e->in_bases, &e->in_offsets, &e->out_assign, &e->out_best, &e->out_nhits,
 	               &e->packed, &e->mz, &e->hits, &e->hist_tm, &e->q_off, &e->qrec, &e->bhits, &e->bhit_cnt, &e->ambig, &e->mz_cnt, &e->hit_cnt, &e->rep_len, &e->an_cnt, &e->an_off,
 	               &e->n_chain, &e->n_reg, &e->best_mlen, &e->hist_sums, &e->hist_offs, &e->scan_sums, &e->hit_off, &e->a, &e->f, &e->p, &e->v, &e->t, &e->u,
 	               &e->chains_tmp, &e->regs, &e->regx, &e->k64a, &e->k64b, &e->tmp_i32, &e->gated,
@@ -766,6 +767,7 @@ static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream
 	// the literal kernel's long calls on a stream of their own (`s3`: the side stream whose hardware queue no other uses)
 	launch_dp_align(B, e->ws->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 1, s3);
 	launch_dp_align(B, e->ws->dp_ws_mid.as<uint8_t>(), DP_WG_MID, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, 0, 3, s3);
+	launch_dp_align(B, e->ws->dp_ws_huge.as<uint8_t>(), DP_WG_HUGE, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE, DP_LDS_BYTES, 0, 0, 5, s3);
 	launch_dp_align(B, e->ws->dp_ws.as<uint8_t>(), 2 * DP_WG_SMALL, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS0_STATE, DP_LDS0_P, DP_LDS0_CIG, 0, s2);
 }
 // what the other kernels handed back, on the literal kernel
@@ -998,15 +1000,15 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 		ENS2(ca, na * sizeof(Anchor)); ENS2(ca_cnt, (nr + 1) * 4); ENS2(chain_dst, ns * 4); ENS2(regdp, ns * sizeof(RegDP));
 		ENS2(segs, seg_cap * sizeof(Seg)); ENS2(cig_seg, cig_cap * 4); ENS2(cig_reg, cig_cap * 4);
 		ENS2(work_a, ns * 4); ENS2(work_b, ns * 4); ENS2(big_list, seg_cap * 4); ENS2(reg_cnt, (nr + 1) * 4); ENS2(regs2, ns * sizeof(mnc_reg_t));
-		const size_t ws_small = dp_align_ws_bytes(DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL), ws_big = dp_align_ws_bytes(DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG);
-		ENSW(dp_ws, ws_small * DP_WG_SMALL * 2); ENSW(dp_ws_big, ws_big * DP_WG_BIG); ENSW(dp_ws_mid, ws_small * DP_WG_MID); ENS2(mid_list, seg_cap * 4); ENS2(lfill, seg_cap * 4); ENSW(lfill_p, dp_lfill_p_slot() * DP_WG_LFILL); ENS2(lext, seg_cap * 4); ENS2(bigfb, seg_cap * 4); ENSW(lext_p, dp_lext_p_slot() * DP_WG_LEXT);
+		const size_t ws_small = dp_align_ws_bytes(DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL), ws_big = dp_align_ws_bytes(DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG), ws_huge = dp_align_ws_bytes(DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE);
+		ENSW(dp_ws, ws_small * DP_WG_SMALL * 2); ENSW(dp_ws_big, ws_big * DP_WG_BIG); ENSW(dp_ws_huge, ws_huge * DP_WG_HUGE); ENS2(huge_list, seg_cap * 4); ENSW(dp_ws_mid, ws_small * DP_WG_MID); ENS2(mid_list, seg_cap * 4); ENS2(lfill, seg_cap * 4); ENSW(lfill_p, dp_lfill_p_slot() * DP_WG_LFILL); ENS2(lext, seg_cap * 4); ENS2(bigfb, seg_cap * 4); ENSW(lext_p, dp_lext_p_slot() * DP_WG_LEXT);
 		ENS2(fill1, seg_cap * 4); ENS2(fill2, seg_cap * 4); ENS2(fill3, seg_cap * 4); ENS2(fill_fb, seg_cap * 4); ENSW(fill_p, dp_fillp_slot() * DP_WG_FILL); ENSW(fill_cig, dp_fillp_cig_slot() * DP_WG_FILL); ENS2(extp, seg_cap * 4 * 8); ENSW(extp_p, dp_extp_slot() * DP_WG_EXT); ENSW(extp_cig, dp_extp_cig_slot() * DP_WG_EXT); ENS2(ext1, seg_cap * 4); ENS2(ext2, seg_cap * 4); ENS2(ext3, seg_cap * 4); ENS2(ext4, seg_cap * 4); ENS2(gen_list, seg_cap * 4); ENSW(ext_p, dp_fill_p_slot() * DP_WG_EXT);
 #undef ENS2
 		if (rc2) return rc2;
 		B.ca = e->ca.as<Anchor>(), B.ca_cnt = e->ca_cnt.as<int32_t>(), B.chain_dst = e->chain_dst.as<int32_t>(), B.regdp = e->regdp.as<RegDP>();
 		B.segs = e->segs.as<Seg>(), B.seg_cap = (int64_t)seg_cap, B.cig_seg = e->cig_seg.as<uint32_t>(), B.cig_reg = e->cig_reg.as<uint32_t>();
 		B.cig_seg_cap = B.cig_reg_cap = (int64_t)cig_cap, B.dp_ctr = e->dp_ctr.as<unsigned long long>();
-		B.big_list = e->big_list.as<int32_t>(), B.reg_cnt = e->reg_cnt.as<int32_t>();
+		B.big_list = e->big_list.as<int32_t>(), B.huge_list = e->huge_list.as<int32_t>(), B.reg_cnt = e->reg_cnt.as<int32_t>();
 		B.fill_list1 = e->fill1.as<int32_t>(), B.fill_list2 = e->fill2.as<int32_t>(), B.fill_list3 = e->fill3.as<int32_t>(), B.fill_fb = e->fill_fb.as<int32_t>();
 		B.ext_list1 = e->ext1.as<int32_t>(), B.ext_list2 = e->ext2.as<int32_t>(), B.ext_list3 = e->ext3.as<int32_t>(), B.ext_list4 = e->ext4.as<int32_t>(), B.gen_list = e->gen_list.as<int32_t>(), B.extp_list = e->extp.as<int32_t>(), B.mid_list = e->mid_list.as<int32_t>(), B.lfill_list = e->lfill.as<int32_t>(), B.lext_list = e->lext.as<int32_t>(), B.bigfb_list = e->bigfb.as<int32_t>();
 		B.lds0_state = DP_LDS0_STATE, B.lds0_p = DP_LDS0_P, B.lds0_cig = DP_LDS0_CIG;
@@ -1022,7 +1024,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 			B.next_list = next;
 			launch_dp_round(B, round == 0, st);
 			if (round == 0) {
-				{ StageTimer t(e, MNC_STAGE_DP_PLAN);   launch_dp_plan(B, work, max_work, (int)DP_STATE_SMALL, DP_P_SMALL, (int)DP_CIG_SMALL, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, st); }
+				{ StageTimer t(e, MNC_STAGE_DP_PLAN);   launch_dp_plan(B, work, max_work, (int)DP_STATE_SMALL, DP_P_SMALL, (int)DP_CIG_SMALL, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE, st); }
 				{
 					StageTimer t(e, MNC_STAGE_DP_FILL);               // the four streams, fork to join
 					if (int rcf = fork()) return rcf;
@@ -1036,7 +1038,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 				}
 				{ StageTimer t(e, MNC_STAGE_DP_STITCH); launch_dp_stitch(B, work, next, e->cur_max_read_len > 0 ? e->cur_max_read_len : 8192, 4096, st); }
 			} else {
-				launch_dp_plan(B, work, max_work, (int)DP_STATE_SMALL, DP_P_SMALL, (int)DP_CIG_SMALL, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, st);
+				launch_dp_plan(B, work, max_work, (int)DP_STATE_SMALL, DP_P_SMALL, (int)DP_CIG_SMALL, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE, st);
 				if (int rcf = fork()) return rcf;
 				if (e->debug & 0x10000) align_round(B, e, e->side[0], e->side[0], e->side[0], e->side[0]);
 				else align_round(B, e, e->side[0], e->side[1], st, e->side[2]);
@@ -1192,6 +1194,7 @@ extern "C" int mnc_engine_get_counters(mnc_engine *e, int64_t *c, int n)
 		HIP_TRY(hipMemcpy(d, e->dp_ctr.p, sizeof(d), hipMemcpyDeviceToHost));
 		c[8] = (int64_t)d[0], c[9] = (int64_t)d[10], c[10] = (int64_t)d[11], c[11] = (int64_t)d[12];
 		if (n >= 16) c[12] = (int64_t)d[48], c[13] = (int64_t)d[49], c[14] = (int64_t)d[50], c[15] = (int64_t)d[51];
+		if (n >= 24) c[16] = (int64_t)d[6], c[17] = (int64_t)d[28], c[18] = (int64_t)d[31], c[19] = (int64_t)d[56], c[20] = (int64_t)d[62], c[21] = (int64_t)d[22];
 
 
 	}

@@ -101,7 +101,8 @@ __device__ int collect_long_gaps(const Anchor *a, int cnt1, int min_gap, int32_t
 }
 
 __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_list, int slot_state_max, long long slot_p_max, int slot_cig_max,
-                                                  long long big_state_max, long long big_p_max, long long big_cig_max)
+                                                  long long big_state_max, long long big_p_max, long long big_cig_max,
+                                                  long long huge_state_max, long long huge_p_max, long long huge_cig_max)
 {
 	const unsigned long long n_work = B.dp_ctr[9];
 	const unsigned long long wi = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -302,8 +303,11 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 				g.big = (12 * T + Q > slot_state_max || p_bytes > slot_p_max || g.qlen + g.tlen + 8 > slot_cig_max) ? 1 : 0;
 				if ((long long)g.tlen * g.qlen > B.max_sw_mat) g.big = 0;      // not aligned at all (ksw_reset_extz + zdropped)
 				else if (12 * T + Q > big_state_max || p_bytes > big_p_max || g.qlen + g.tlen + 8 > big_cig_max) {
-					g.big = 2;                                              // beyond even the large workspace: the batch fails
-					atomicMax(&B.dp_ctr[4], 9ULL);
+					g.big = 3;                                              // the few largest: a class of their own, a handful of very large slots
+					if (12 * T + Q > huge_state_max || p_bytes > huge_p_max || g.qlen + g.tlen + 8 > huge_cig_max) {
+						g.big = 2;                                          // beyond even those: the batch fails
+						atomicMax(&B.dp_ctr[4], 9ULL);
+					}
 				}
 				bool lfill = false;
 				if (!(B.debug_route & 4) && g.big <= 1 && g.kind == 1 && g.w == bw && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= 2047 && g.qlen <= 2047 &&
@@ -319,9 +323,16 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 					}
 				}
 				if (lfill) {
+				} else if (!(B.debug_route & 8) && g.big == 1 && g.kind != 1 && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= g.w && g.qlen <= g.w &&
+				           g.tlen + g.qlen - 1 <= 2 * 1535 && (g.tlen < g.qlen ? g.tlen : g.qlen) <= 512) {
+					g.flag |= SEG_NEEDS_BIG_WS;                             // a longer extension (below) that would need the large workspace
+					g.big = 4 + 19, ++n_tier[19];
 				} else if (g.big == 1) {
 					const unsigned long long bi = atomicAdd(&B.dp_ctr[6], 1ULL);
 					B.big_list[bi] = (int32_t)(sg - B.segs);
+				} else if (g.big == 3) {
+					const unsigned long long bi = atomicAdd(&B.dp_ctr[58], 1ULL);
+					B.huge_list[bi] = (int32_t)(sg - B.segs);
 				} else if (!(B.debug_route & 2) && g.big == 0 && g.kind == 1 && g.w == bw && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= FILL_MAX_LEN && g.qlen <= FILL_MAX_LEN) {
 					// a gap between two seeds whose matrix the band never clips: the banded kernel of
 					// k_fill.hip, 32 lanes per segment when |tlen - qlen| leaves a band worth trying, else 64
@@ -775,16 +786,17 @@ __global__ __launch_bounds__(64) void mnc_dp_align(Batch B, uint8_t *ws_all, lon
 	uint8_t *ws = ws_all + (size_t)blockIdx.x * W.total;
 	const int sc_mch = B.sc_a, sc_mis = -B.sc_b, sc_N = -B.sc_ambi;
 	// pass 0: the segments of the round that are neither large nor another kernel's and fit the LDS
-	// layout; 3: those that do not; 1: the large ones; 2: what the banded kernels handed back
+	// layout; 3: those that do not; 1: the large ones; 5: the few largest; 2: what the banded kernels handed back (4: those
+	// of them that need the large workspace)
 	if (big_pass != 0) __builtin_amdgcn_s_setprio(3);         // a few long calls on single waves beside chip-filling kernels: first in line for issue
-	const unsigned long long n_items = big_pass == 0 ? B.dp_ctr[20] : big_pass == 1 ? B.dp_ctr[6] : big_pass == 3 ? B.dp_ctr[28] : big_pass == 4 ? B.dp_ctr[56] : B.dp_ctr[12];
-	const int ctr_q = big_pass == 0 ? 21 : big_pass == 1 ? 7 : big_pass == 3 ? 29 : big_pass == 4 ? 57 : 15;
+	const unsigned long long n_items = big_pass == 0 ? B.dp_ctr[20] : big_pass == 1 ? B.dp_ctr[6] : big_pass == 3 ? B.dp_ctr[28] : big_pass == 4 ? B.dp_ctr[56] : big_pass == 5 ? B.dp_ctr[58] : B.dp_ctr[12];
+	const int ctr_q = big_pass == 0 ? 21 : big_pass == 1 ? 7 : big_pass == 3 ? 29 : big_pass == 4 ? 57 : big_pass == 5 ? 59 : 15;
 	for (;;) {
 		unsigned long long qi = 0;
 		if (lane == 0) qi = atomicAdd(&B.dp_ctr[ctr_q], 1ULL);
 		qi = (unsigned long long)__shfl((long long)qi, 0);
 		if (qi >= n_items) break;                              // every wave reaches this: the queue is finite
-		const long long si = big_pass == 0 ? (long long)B.gen_list[qi] : big_pass == 1 ? (long long)B.big_list[qi] : big_pass == 3 ? (long long)B.mid_list[qi] : big_pass == 4 ? (long long)B.bigfb_list[qi] : (long long)B.fill_fb[qi];
+		const long long si = big_pass == 0 ? (long long)B.gen_list[qi] : big_pass == 1 ? (long long)B.big_list[qi] : big_pass == 3 ? (long long)B.mid_list[qi] : big_pass == 4 ? (long long)B.bigfb_list[qi] : big_pass == 5 ? (long long)B.huge_list[qi] : (long long)B.fill_fb[qi];
 		Seg g = B.segs[si];
 		Ez ez;
 		ez.max = 0, ez.zdropped = 0, ez.max_q = ez.max_t = ez.mqe_t = -1, ez.mqe = ez.score = DP_NEG_INF, ez.reach_end = 0, ez.n_cigar = 0;
@@ -1370,7 +1382,7 @@ __global__ void mnc_dp_round(Batch B, int first)
 	B.dp_ctr[5] = 0;
 	B.dp_ctr[6] = 0, B.dp_ctr[7] = 0;
 	for (int k = 10; k < 48; ++k) B.dp_ctr[k] = 0;
-	B.dp_ctr[56] = B.dp_ctr[57] = B.dp_ctr[60] = B.dp_ctr[61] = B.dp_ctr[62] = B.dp_ctr[63] = 0;
+	B.dp_ctr[56] = B.dp_ctr[57] = B.dp_ctr[58] = B.dp_ctr[59] = B.dp_ctr[60] = B.dp_ctr[61] = B.dp_ctr[62] = B.dp_ctr[63] = 0;
 	if (first) for (int k = 48; k < 64; ++k) B.dp_ctr[k] = 0;   // banded kernel: list lengths 10 / 11 / 12 (tier 1, tier 2, handed back), queues 13 / 14 / 15;
 	                                                 // extension kernel: lists 16 / 17, queues 18 / 19; literal kernel's first pass: list 20, queue 21; banded kernel, 128 cells: list 22, queue 23; extension kernel, 128 / 256 cells: lists 24 / 25, queues 26 / 27
 }
@@ -1388,9 +1400,10 @@ void launch_dp_gather(const Batch &B, hipStream_t st)
 void launch_dp_round(const Batch &B, int first, hipStream_t st) { hipLaunchKernelGGL(mnc_dp_round, dim3(1), dim3(1), 0, st, B, first); }
 void launch_dp_round_end(const Batch &B, hipStream_t st) { hipLaunchKernelGGL(mnc_dp_round_end, dim3(1), dim3(1), 0, st, B); }
 void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work, int state_max, long long p_max, int cig_max,
-                    long long big_state, long long big_p, long long big_cig, hipStream_t st)
+                    long long big_state, long long big_p, long long big_cig, long long huge_state, long long huge_p, long long huge_cig, hipStream_t st)
 {
-	if (max_work) hipLaunchKernelGGL(mnc_dp_plan, dim3((max_work + 63) / 64), dim3(64), 0, st, B, work_list, state_max, p_max, cig_max, big_state, big_p, big_cig);
+	if (max_work) hipLaunchKernelGGL(mnc_dp_plan, dim3((max_work + 63) / 64), dim3(64), 0, st, B, work_list, state_max, p_max, cig_max, big_state, big_p, big_cig,
+	                                 huge_state, huge_p, huge_cig);
 }
 size_t dp_align_ws_bytes(long long state_max, long long p_max, long long cig_max) { return align_ws(state_max, p_max, cig_max).total; }
 int dp_align_prepare(int lds_bytes)

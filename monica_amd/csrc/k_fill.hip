@@ -967,7 +967,8 @@ __global__ __launch_bounds__(64) void mnc_dp_ext(Batch B, const int32_t *list, i
 		const bool s_bad = __shfl((int)(bad || (has && !ok)), lead) != 0;
 		const int s_nc = __shfl(n_c, lead);
 		if (has && s_bad) {
-			if (leader) { const unsigned long long k = atomicAdd(&B.dp_ctr[ctr_fb], 1ULL); fb_list[k] = (int32_t)si; }
+			if (leader && (g.flag & SEG_NEEDS_BIG_WS)) { const unsigned long long k = atomicAdd(&B.dp_ctr[56], 1ULL); B.bigfb_list[k] = (int32_t)si; }
+			else if (leader) { const unsigned long long k = atomicAdd(&B.dp_ctr[ctr_fb], 1ULL); fb_list[k] = (int32_t)si; }
 		} else if (has) {
 			unsigned long long off = 0;
 			if (leader && s_nc > 0) off = atomicAdd(&B.dp_ctr[1], (unsigned long long)s_nc);

@@ -1,0 +1,17 @@
+"""Stage times and tier counters of one batch at a given error rate (sub, ins, del in 1e-4)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from monica_amd import _capi, synth
+sub, ins, dele, n = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 30000
+names, seqs = synth.genome_set(20, min_len=2_000_000, max_len=7_000_000)
+index = _capi.Index.from_seqs(names, seqs)
+eng = _capi.Engine(index, 0)
+bases, offsets, truth = synth.reads(seqs, n, 5000, seed=778, sub=sub, ins=ins, dele=dele)
+eng.classify(bases, offsets, 60)
+eng.set_profiling(True); eng.timings(reset=True)
+t = time.time(); a, best, nh = eng.classify(bases, offsets, 60); dt = time.time() - t
+tm = eng.timings(); c = eng.counters()
+print("error %.1f %%: %d reads in %.3f s = %.0f reads/s; mapped %d" % ((sub + ins + dele) / 100, n, dt, n / dt, int((a >= 0).sum())))
+print({k: round(v[0], 2) for k, v in tm.items() if v[1]})
+print({k: v for k, v in c.items() if k.startswith("dp_")})
