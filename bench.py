@@ -327,6 +327,29 @@ def main():
         end_to_end = {"value": round(args.reads * n_e2e / de, 1), "unit": "reads/s", "ms_per_batch": round(de / n_e2e * 1e3, 3),
                       "what": "mnc_classify_batch on page-locked host buffers: H2D of 5 000 ASCII bytes per read, kernels, D2H",
                       "equal_to_resident": bool(np.array_equal(e_assign, assign))}
+        # ... and as monica's thread pool drives it (aligner.py:65-111: one sample per thread): two engines of the same
+        # device on two host threads, one's copies behind the other's kernels
+        import threading
+        engine_b = _capi.Engine(index, local_rank)
+        engine_b.set_contract(_capi.CONTRACT_DP if args.contract == "dp" else _capi.CONTRACT_CHAIN)
+        hb_b = _capi.pinned_array(bases)
+        engine_b.classify(hb_b, offsets, args.min_mapq)
+        outs = [None, None]
+
+        def drive(k, eng, buf):
+            for _ in range(n_e2e):
+                outs[k] = eng.classify(buf, offsets, args.min_mapq)[0]
+        th = [threading.Thread(target=drive, args=(0, engine, hb)), threading.Thread(target=drive, args=(1, engine_b, hb_b))]
+        te = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        de2 = time.perf_counter() - te
+        end_to_end["two_engines"] = {"value": round(2 * args.reads * n_e2e / de2, 1), "unit": "reads/s",
+                                     "ms_per_batch": round(de2 / (2 * n_e2e) * 1e3, 3),
+                                     "equal_to_resident": bool(np.array_equal(outs[0], assign) and np.array_equal(outs[1], assign))}
+        del engine_b
 
     if args.scaling == "strong":
         n_total = args.total_reads * args.steps

@@ -89,6 +89,9 @@ int  mnc_index_build_mem(int n_seq, const char *const *names, const char *const 
                          const int64_t *lens, int k, int w, mnc_index **out);
 int  mnc_index_save(const mnc_index *idx, const char *path);
 int  mnc_index_load(const char *path, mnc_index **out);
+/* minimap2's own index format ("MMI\2", what mappy writes at aligner.py:45-46): mnc_index_load reads either format;
+ * this writes it, so that an index built here can be handed to mappy / minimap2 as well */
+int  mnc_index_save_mmi(const mnc_index *idx, const char *path);
 void mnc_index_free(mnc_index *idx);
 int  mnc_index_info(const mnc_index *idx, mnc_index_info_t *info);
 const char *mnc_index_contig_name(const mnc_index *idx, int rid);      /* hit.ctg, aligner.py:195 */

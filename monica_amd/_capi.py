@@ -39,7 +39,7 @@ CONTRACT_DP, CONTRACT_CHAIN = 0, 1
 # every symbol include/monica_amd.h declares (checked by tests/test_capi.py)
 EXPORTS = [
     "mnc_strerror", "mnc_last_error", "mnc_device_count", "mnc_device_name",
-    "mnc_index_build", "mnc_index_build_mem", "mnc_index_save", "mnc_index_load", "mnc_index_free",
+    "mnc_index_build", "mnc_index_build_mem", "mnc_index_save", "mnc_index_save_mmi", "mnc_index_load", "mnc_index_free",
     "mnc_index_info", "mnc_index_contig_name", "mnc_index_contig_len", "mnc_index_contig_genome",
     "mnc_index_genome_name", "mnc_index_genome_len", "mnc_index_dump", "mnc_index_set_mid_occ",
     "mnc_engine_create", "mnc_engine_destroy", "mnc_engine_stream",
@@ -104,6 +104,7 @@ def lib():
     sig("mnc_index_build", i32, [cp, cp, i32, i32, pp])
     sig("mnc_index_build_mem", i32, [i32, C.POINTER(cp), C.POINTER(cp), C.POINTER(i64), i32, i32, pp])
     sig("mnc_index_save", i32, [vp, cp])
+    sig("mnc_index_save_mmi", i32, [vp, cp])
     sig("mnc_index_load", i32, [cp, pp])
     sig("mnc_index_free", None, [vp])
     sig("mnc_index_info", i32, [vp, C.POINTER(IndexInfo)])
@@ -268,8 +269,10 @@ class Index:
         check(lib().mnc_index_load(_b(path), C.byref(h)))
         return cls(h)
 
-    def save(self, path):
-        check(lib().mnc_index_save(self._h, _b(path)))
+    def save(self, path, mmi=False):
+        """This library's own file (loads without a sort), or -- `mmi=True` -- minimap2's format, the one mappy writes at
+        aligner.py:45-46; `load` reads either."""
+        check((lib().mnc_index_save_mmi if mmi else lib().mnc_index_save)(self._h, _b(path)))
 
     def info(self):
         info = IndexInfo()

@@ -354,12 +354,156 @@ extern "C" int mnc_index_save(const mnc_index *idx, const char *path)
 	return MNC_OK;
 }
 
+
+// ---------------------------------------------------------------- minimap2's index file
+// The file mappy writes at aligner.py:45-46 (`fn_idx_out`) and reads at aligner.py:59: "MMI\2",
+// u32 {w, k, b, n_seq, flag}; per sequence u8 name length, name, u32 length; per bucket (2^b of them,
+// bucket = hash & (2^b - 1)) i32 n + n occurrence words of its repeated minimizers, u32 size + size
+// pairs {key = hash >> b << 1 | singleton, value = the occurrence word | offset << 32 | count}; then
+// the bases, 4 bits each, 8 per u32 (SURVEY.md A.3 -- stated there from the published format of
+// minimap2 2.17; no file written by minimap2 itself was at hand to check it against).
+namespace {
+constexpr int MMI_NO_SEQ = 2, MMI_HPC = 1;
+struct MmiHead { uint32_t w, k, b, n_seq, flag; };
+}
+
+extern "C" int mnc_index_save_mmi(const mnc_index *idx, const char *path)
+{
+	if (!idx || !path) return MNC_ERR_ARG;
+	for (auto &s : idx->contig_name)
+		if (s.size() > 255) { set_error("contig name longer than 255 bytes: the .mmi format cannot hold it"); return MNC_ERR_UNSUPPORTED; }
+	FILE *f = fopen(path, "wb");
+	if (!f) { set_error("cannot create %s", path); return MNC_ERR_IO; }
+	const int b = 14;
+	const MmiHead h = { (uint32_t)idx->w, (uint32_t)idx->k, (uint32_t)b, (uint32_t)idx->contig_name.size(), 0u };
+	bool ok = fwrite("MMI\2", 1, 4, f) == 4 && put(f, &h, 1);
+	for (size_t i = 0; ok && i < idx->contig_name.size(); ++i) {
+		const uint8_t l = (uint8_t)idx->contig_name[i].size();
+		const uint32_t len = (uint32_t)idx->contig_len[i];
+		ok = put(f, &l, 1) && put(f, idx->contig_name[i].data(), l) && put(f, &len, 1);
+	}
+	// keys by bucket (ascending hash inside one)
+	const size_t nb = (size_t)1 << b, nk = idx->keys.size();
+	std::vector<uint32_t> start(nb + 1, 0), order(nk);
+	for (size_t i = 0; i < nk; ++i) ++start[(idx->keys[i] & (nb - 1)) + 1];
+	for (size_t i = 0; i < nb; ++i) start[i + 1] += start[i];
+	{
+		std::vector<uint32_t> cur(start.begin(), start.end() - 1);
+		for (size_t i = 0; i < nk; ++i) order[cur[idx->keys[i] & (nb - 1)]++] = (uint32_t)i;
+	}
+	std::vector<uint64_t> p, kv;
+	for (size_t bi = 0; ok && bi < nb; ++bi) {
+		p.clear(), kv.clear();
+		for (uint32_t o = start[bi]; o < start[bi + 1]; ++o) {
+			const size_t i = order[o];
+			const uint64_t cnt = idx->key_off[i + 1] - idx->key_off[i], hi = (uint64_t)(idx->keys[i] >> b) << 1;
+			if (cnt == 1) kv.push_back(hi | 1), kv.push_back(idx->pos[idx->key_off[i]]);
+			else {
+				kv.push_back(hi), kv.push_back((uint64_t)p.size() << 32 | cnt);
+				p.insert(p.end(), idx->pos.begin() + (ptrdiff_t)idx->key_off[i], idx->pos.begin() + (ptrdiff_t)idx->key_off[i + 1]);
+			}
+		}
+		const int32_t n = (int32_t)p.size();
+		const uint32_t size = (uint32_t)(kv.size() / 2);
+		ok = put(f, &n, 1) && put(f, p.data(), p.size()) && put(f, &size, 1) && put(f, kv.data(), kv.size());
+	}
+	ok = ok && put(f, idx->seq4.data(), (size_t)(idx->total_len + 7) / 8);
+	ok = (fclose(f) == 0) && ok;
+	if (!ok) { set_error("short write to %s", path); return MNC_ERR_IO; }
+	return MNC_OK;
+}
+
+static int load_mmi(FILE *f, const char *path, int64_t file_size, mnc_index **out)
+{
+	auto bad = [&](const char *what) { set_error("%s is truncated or damaged (%s)", path, what); return MNC_ERR_FORMAT; };
+	MmiHead h;
+	if (!get(f, &h, 1)) return bad("header");
+	if (h.b < 1 || h.b > 28 || h.n_seq == 0 || (int64_t)h.n_seq * 5 > file_size) return bad("header");
+	if (h.flag & MMI_HPC) { set_error("%s: homopolymer-compressed indexes are not supported", path); return MNC_ERR_UNSUPPORTED; }
+	if (h.flag & MMI_NO_SEQ) { set_error("%s holds no sequences: base-level alignment needs them", path); return MNC_ERR_UNSUPPORTED; }
+	if (int e = check_kw((int)h.k, (int)h.w)) return e;
+	mnc_index *idx = new (std::nothrow) mnc_index;
+	if (!idx) return MNC_ERR_NOMEM;
+	int rc = MNC_OK;
+	try {
+		idx->k = (int)h.k, idx->w = (int)h.w;
+		int64_t total = 0;
+		for (uint32_t i = 0; i < h.n_seq && !rc; ++i) {
+			uint8_t l;
+			char name[256];
+			uint32_t len;
+			if (!get(f, &l, 1) || !get(f, name, l) || !get(f, &len, 1) || len > 0x7fffffffu) { rc = bad("sequence table"); break; }
+			idx->contig_name.emplace_back(name, l);
+			idx->contig_len.push_back((int64_t)len);
+			total += len;
+		}
+		std::vector<std::pair<uint64_t, uint64_t>> pairs;
+		std::vector<uint64_t> p, kv;
+		const int64_t rest_min = (total + 7) / 8 * 4;
+		for (uint64_t bi = 0; bi < (1ull << h.b) && !rc; ++bi) {
+			int32_t n;
+			uint32_t size;
+			if (!get(f, &n, 1) || n < 0 || (int64_t)n * 8 > file_size) { rc = bad("bucket"); break; }
+			p.resize((size_t)n);
+			if (!get(f, p.data(), p.size()) || !get(f, &size, 1) || (int64_t)size * 16 > file_size) { rc = bad("bucket"); break; }
+			kv.resize((size_t)size * 2);
+			if (!get(f, kv.data(), kv.size())) { rc = bad("bucket"); break; }
+			for (uint32_t j = 0; j < size; ++j) {
+				const uint64_t key = kv[2 * j], val = kv[2 * j + 1];
+				const uint64_t hash = (key >> 1) << h.b | bi;
+				if (hash >= (1ull << 30)) { rc = bad("minimizer beyond 2k bits"); break; }
+				if (key & 1) pairs.emplace_back(hash, val);
+				else {
+					const uint64_t off = val >> 32, cnt = (uint32_t)val;
+					if (cnt < 2 || off + cnt > (uint64_t)n) { rc = bad("occurrence list"); break; }
+					for (uint64_t t = 0; t < cnt; ++t) pairs.emplace_back(hash, p[off + t]);
+				}
+			}
+		}
+		if (!rc) {
+			const int64_t here = (int64_t)ftello(f);
+			if (here < 0 || file_size - here < rest_min) rc = bad("sequences");
+		}
+		if (!rc) {
+			idx->seq_off.assign((size_t)h.n_seq + 1, 0);
+			for (uint32_t i = 0; i < h.n_seq; ++i) idx->seq_off[i + 1] = idx->seq_off[i] + idx->contig_len[i];
+			idx->seq4.assign((size_t)(total + 7) / 8 + 1, 0u);
+			if (!get(f, idx->seq4.data(), (size_t)(total + 7) / 8)) rc = bad("sequences");
+		}
+		for (size_t i = 0; !rc && i < pairs.size(); ++i) {
+			const uint64_t rid = pairs[i].second >> 32, ps = (uint32_t)pairs[i].second >> 1;
+			if (rid >= h.n_seq || (int64_t)ps >= idx->contig_len[rid]) rc = bad("occurrence word");
+		}
+		if (!rc && pairs.empty()) rc = bad("no minimizer");
+		if (!rc) {
+			index_finalize(idx, pairs);                 // sorts, groups and derives mid_occ as mappy does on loading
+			for (size_t k = 0; !rc && k < idx->keys.size(); ++k)    // an occurrence listed twice under one minimizer: not minimap2's
+				for (uint64_t o = idx->key_off[k] + 1; o < idx->key_off[k + 1]; ++o)
+					if (idx->pos[o] == idx->pos[o - 1]) { rc = bad("duplicate occurrence"); break; }
+		}
+	} catch (const std::bad_alloc &) { rc = MNC_ERR_NOMEM; }
+	if (rc) { delete idx; return rc; }
+	*out = idx;
+	return MNC_OK;
+}
+
 extern "C" int mnc_index_load(const char *path, mnc_index **out)
 {
 	if (!path || !out) return MNC_ERR_ARG;
 	*out = nullptr;
 	FILE *f = fopen(path, "rb");
 	if (!f) { set_error("cannot open %s", path); return MNC_ERR_IO; }
+	{   // minimap2's own format (what an installation that ran the reference holds)?
+		char m4[4];
+		if (fread(m4, 1, 4, f) == 4 && memcmp(m4, "MMI\2", 4) == 0) {
+			struct stat sb;
+			if (fstat(fileno(f), &sb) != 0) { fclose(f); set_error("cannot stat %s", path); return MNC_ERR_IO; }
+			const int rc = load_mmi(f, path, (int64_t)sb.st_size, out);
+			fclose(f);
+			return rc;
+		}
+		rewind(f);
+	}
 	FileHeader h;
 	if (!get(f, &h, 1) || memcmp(h.magic, MAGIC, 8) != 0 || h.n_contigs <= 0 || h.n_keys <= 0 ||
 	    h.n_occ < h.n_keys || h.names_bytes <= 0) {

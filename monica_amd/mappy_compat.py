@@ -110,6 +110,11 @@ class Hit:
                 f"tp:A:{'P' if self.is_primary else 'S'}")
 
 
+# What `fn_idx_out` writes: "native" (this library's file: loads without sorting) or "mmi" (minimap2's format, as
+# mappy writes it at aligner.py:45-46 -- for an installation that also runs the reference).  Both load.
+INDEX_FILE_FORMAT = "native"
+
+
 class Aligner:
     """Index handle with mappy's constructor and truthiness."""
 
@@ -130,6 +135,9 @@ class Aligner:
                 raise ValueError("fn_idx_in or seq is required")
             elif self._is_index_file(fn_idx_in):
                 self._index = _load_index_cached(fn_idx_in)
+            elif INDEX_FILE_FORMAT == "mmi" and fn_idx_out:
+                self._index = _capi.Index.build(fn_idx_in, None, kk, ww)
+                self._index.save(fn_idx_out, mmi=True)
             else:
                 self._index = _capi.Index.build(fn_idx_in, fn_idx_out, kk, ww)
         except (_capi.MncError, OSError, ValueError) as e:      # mappy: a falsy Aligner, no exception
@@ -140,7 +148,8 @@ class Aligner:
     def _is_index_file(path):
         try:
             with open(path, "rb") as f:
-                return f.read(6) == b"MNCIDX"
+                head = f.read(6)
+                return head == b"MNCIDX" or head[:4] == b"MMI\x02"       # this library's file, or minimap2's own
         except OSError:
             return False
 

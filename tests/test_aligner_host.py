@@ -412,3 +412,45 @@ def test_decisions_agree_with_real_mappy_when_it_is_installed():
             b = sorted((h.ctg, h.NM, h.mlen) for h in ours.map(s) if h.is_primary and h.mapq >= 60)
             same += a == b
         assert same >= 285, f"only {same}/300 gated hit lists equal mappy's"
+
+
+def test_indexer_can_write_minimap2s_own_format(tmp_path, monkeypatch):
+    """aligner.py:45-46 writes `indexN.mmi` through mappy; with `mappy_compat.INDEX_FILE_FORMAT = "mmi"` the files are
+    minimap2's format (readable by the reference's installation too), and `index_loader` (aligner.py:56-62) loads both."""
+    from monica_amd import mappy_compat, synth
+    import util
+    names, seqs = util.small_genomes(2, 60_000, 80_000)
+    dbs = tmp_path / "databases"
+    dbs.mkdir()
+    synth.write_fasta(str(dbs / "database0.fna.gz"), names, seqs)
+    native = aligner.indexer(str(dbs), str(tmp_path / "native"))
+    monkeypatch.setattr(mappy_compat, "INDEX_FILE_FORMAT", "mmi")
+    mmi = aligner.indexer(str(dbs), str(tmp_path / "mmi"))
+    assert [os.path.basename(p) for p in native + mmi] == ["index0.mmi", "index0.mmi"]
+    assert open(native[0], "rb").read(6) == b"MNCIDX" and open(mmi[0], "rb").read(4) == b"MMI\x02"
+    a, b = aligner.index_loader(native[0]), aligner.index_loader(mmi[0])
+    assert a and b and a.seq_names == b.seq_names == names
+    ha, ya = a.index.dump()
+    hb, yb = b.index.dump()
+    assert np.array_equal(ha, hb) and np.array_equal(ya, yb) and a.index.mid_occ == b.index.mid_occ
+
+
+def test_index_files_interoperate_with_real_mappy_when_it_is_installed(tmp_path):
+    """UNPINNED here (no mappy in this image): where mappy 2.17 is installed, an index it wrote loads as the index this
+    library builds from the same FASTA, and an index this library wrote in the .mmi format loads in mappy
+    (aligner.py:45-46, 59)."""
+    mappy = pytest.importorskip("mappy")
+    from monica_amd import mappy_compat, synth
+    names, seqs = synth.genome_set(3, min_len=80_000, max_len=120_000)
+    fa = str(tmp_path / "db.fna")
+    synth.write_fasta(fa, names, seqs)
+    theirs_path, ours_path = str(tmp_path / "theirs.mmi"), str(tmp_path / "ours.mmi")
+    assert mappy.Aligner(fn_idx_in=fa, preset="map-ont", best_n=15, fn_idx_out=theirs_path)
+    ours = mappy_compat.Aligner(fn_idx_in=fa, preset="map-ont", best_n=15)
+    ours.index.save(ours_path, mmi=True)
+    loaded = mappy_compat.Aligner(fn_idx_in=theirs_path)
+    assert loaded and loaded.seq_names == ours.seq_names
+    for x, y in zip(loaded.index.dump(), ours.index.dump()):
+        assert np.array_equal(x, y)
+    back = mappy.Aligner(fn_idx_in=ours_path)
+    assert back and list(back.seq_names) == ours.seq_names

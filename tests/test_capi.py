@@ -197,3 +197,90 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "pyoracle" not in text and "liborc" not in text and "mm_oracle" not in text, f
+
+
+# ---------------------------------------------------------------- minimap2's index file (.mmi)
+def write_mmi_by_the_published_layout(path, names, seqs, h, y, b=14, descending=False):
+    """A second statement of the format, independent of the library's writer: "MMI\\2", u32 w k b n_seq
+    flag; per sequence u8 name length + name + u32 length; per bucket i32 n + n words, u32 size + size (key, value)
+    pairs; 4-bit bases, 8 per u32.  Entries go out in ascending or descending key order: a loader must not care."""
+    import struct
+    code = np.full(256, 4, dtype=np.uint32)
+    for k, c in enumerate("ACGT"):
+        code[ord(c)] = code[ord(c.lower())] = k
+    code[ord("U")] = code[ord("u")] = 3
+    with open(path, "wb") as f:
+        f.write(b"MMI\x02" + struct.pack("<5I", 10, 15, b, len(names), 0))
+        for nm, s in zip(names, seqs):
+            f.write(struct.pack("<B", len(nm)) + nm.encode() + struct.pack("<I", len(s)))
+        bucket = (h & np.uint64((1 << b) - 1)).astype(np.int64)
+        order = np.lexsort((y, h, bucket))
+        hb, hh, yy = bucket[order], h[order], y[order]
+        starts = np.searchsorted(hb, np.arange((1 << b) + 1))
+        for bi in range(1 << b):
+            lo, hi = starts[bi], starts[bi + 1]
+            keys, first, counts = np.unique(hh[lo:hi], return_index=True, return_counts=True)
+            p, kv = [], []
+            for kx, fx, cx in zip(keys, first, counts):
+                key = int(kx) >> b << 1
+                if cx == 1:
+                    kv.append((key | 1, int(yy[lo + fx])))
+                else:
+                    kv.append((key, len(p) << 32 | int(cx)))
+                    p.extend(int(v) for v in yy[lo + fx: lo + fx + cx])
+            if descending:
+                kv.reverse()
+            f.write(struct.pack("<i", len(p)) + struct.pack(f"<{len(p)}Q", *p))
+            f.write(struct.pack("<I", len(kv)) + b"".join(struct.pack("<2Q", *e) for e in kv))
+        cat = np.concatenate([code[np.frombuffer(s.tobytes(), dtype=np.uint8)] for s in seqs])
+        cat = np.concatenate([cat, np.zeros(-len(cat) % 8, dtype=np.uint32)]).reshape(-1, 8)
+        words = (cat << (np.arange(8, dtype=np.uint32) * 4)).sum(axis=1).astype(np.uint32)
+        f.write(words.tobytes())
+
+
+def test_mmi_files_load_and_round_trip(capi, world, tmp_path):
+    """aligner.py:45-46 / 59: mappy writes and reads minimap2's .mmi.  An index saved in that format, and one laid out by
+    the test from the published description, load as the same index (same native file, byte for byte)."""
+    names, seqs, idx, oidx = world
+    native = tmp_path / "a.idx"
+    idx.save(str(native))
+    mmi = tmp_path / "a.mmi"
+    idx.save(str(mmi), mmi=True)
+    assert open(mmi, "rb").read(4) == b"MMI\x02"
+    back = capi.Index.load(str(mmi))
+    assert back.info().mid_occ == idx.info().mid_occ and list(back.contig_names) == list(idx.contig_names)
+    back.save(str(tmp_path / "b.idx"))
+    assert open(tmp_path / "b.idx", "rb").read() == open(native, "rb").read()
+    h, y = idx.dump()
+    for desc in (False, True):
+        other = tmp_path / f"by_hand_{int(desc)}.mmi"
+        write_mmi_by_the_published_layout(str(other), names, seqs, h, y, descending=desc)
+        if not desc:
+            assert open(other, "rb").read() == open(mmi, "rb").read()         # the library's writer: ascending keys
+        again = capi.Index.load(str(other))
+        again.save(str(tmp_path / "c.idx"))
+        assert open(tmp_path / "c.idx", "rb").read() == open(native, "rb").read()
+
+
+def test_damaged_mmi_files_are_refused(capi, world, tmp_path):
+    import struct
+    names, seqs, idx, _ = world
+    good = tmp_path / "g.mmi"
+    idx.save(str(good), mmi=True)
+    blob = open(good, "rb").read()
+    cases = {"cut in the buckets": blob[: len(blob) // 2], "cut in the sequences": blob[:-8], "cut in the header": blob[:16],
+             "hpc flag": blob[:20] + struct.pack("<I", 1) + blob[24:], "no sequences flag": blob[:20] + struct.pack("<I", 2) + blob[24:],
+             "other k": blob[:8] + struct.pack("<I", 19) + blob[12:], "no sequence": blob[:16] + struct.pack("<I", 0) + blob[20:]}
+    for what, data in cases.items():
+        p = tmp_path / "bad.mmi"
+        p.write_bytes(data)
+        with pytest.raises(capi.MncError):
+            capi.Index.load(str(p))
+    # an occurrence word that points past its contig
+    h, y = idx.dump()
+    y2 = y.copy()
+    y2[0] = np.uint64(int(y2[0]) & 0xffffffff00000000 | 0x7ffffffe)
+    p = tmp_path / "bad2.mmi"
+    write_mmi_by_the_published_layout(str(p), names, seqs, h, y2)
+    with pytest.raises(capi.MncError):
+        capi.Index.load(str(p))
