@@ -92,15 +92,24 @@ private:
 };
 } // namespace
 
-static void contig_minimizers(const char *s, int64_t len, int w, int k, uint32_t rid,
+// The minimizers of one contig whose k-mers end in [lo, hi): what the scan of the whole contig reports there.  The
+// state of the scan (ring of the last w records, the minimum = the right-most smallest of them, the run of valid bases
+// compared with w + k) is a function of the last 2 w + k bases, so a scan started SKETCH_WARM bases early is in the same
+// state from `lo` on; a record is reported at the latest when it leaves the window, w bases after it, so the scan runs
+// that much past `hi` (what it reports outside [lo, hi) belongs to the neighbours; only the contig's true end flushes).
+constexpr int64_t SKETCH_WARM = 64, SKETCH_SEG = 1 << 18;
+static void contig_minimizers(const char *s, int64_t len, int64_t lo, int64_t hi, int w, int k, uint32_t rid,
                               std::vector<std::pair<uint64_t, uint64_t>> &out)
 {
 	const uint32_t mask = (uint32_t)((1ULL << 2 * k) - 1);
 	const int top = 2 * (k - 1);
 	uint32_t fw = 0, rv = 0;
 	int run = 0;
-	WindowMin win(w, out);
-	for (int64_t i = 0; i < len; ++i) {
+	std::vector<std::pair<uint64_t, uint64_t>> all;
+	const bool whole = lo == 0 && hi >= len;
+	WindowMin win(w, whole ? out : all);
+	const int64_t from = std::max<int64_t>(0, lo - SKETCH_WARM), to = std::min(len, hi + w + 2);
+	for (int64_t i = from; i < to; ++i) {
 		int c = base_code((unsigned char)s[i]);
 		Rec cur{NONE, NONE};
 		if (c < 4) {
@@ -116,7 +125,12 @@ static void contig_minimizers(const char *s, int64_t len, int w, int k, uint32_t
 		} else run = 0;
 		win.push(cur, run, k);
 	}
-	win.flush();
+	if (to == len) win.flush();
+	if (!whole)
+		for (auto &pr : all) {
+			const int64_t pos = (int64_t)((uint32_t)pr.second >> 1);
+			if (pos >= lo && pos < hi) out.push_back(pr);
+		}
 }
 
 // contig bases -> 4-bit codes.  Words shared by two contigs are written by one thread only:
@@ -245,21 +259,22 @@ extern "C" int mnc_index_build_mem(int n_seq, const char *const *names, const ch
 			idx->contig_name.emplace_back(names[i]);
 			idx->contig_len.push_back(lens[i]);
 		}
-		// contigs are independent: sketch them on the host threads, longest first
-		std::vector<std::vector<std::pair<uint64_t, uint64_t>>> per(n_seq);
-		std::vector<int> order(n_seq);
-		for (int i = 0; i < n_seq; ++i) order[i] = i;
-		std::sort(order.begin(), order.end(), [&](int a, int b) { return lens[a] != lens[b] ? lens[a] > lens[b] : a < b; });
+		// pieces of contigs are independent (contig_minimizers): sketch them on all host threads
+		struct Piece { int contig; int64_t lo, hi; };
+		std::vector<Piece> pieces;
+		for (int i = 0; i < n_seq; ++i)
+			for (int64_t lo = 0; lo == 0 || lo < lens[i]; lo += SKETCH_SEG) pieces.push_back({ i, lo, lo + SKETCH_SEG >= lens[i] ? lens[i] : lo + SKETCH_SEG });
+		std::vector<std::vector<std::pair<uint64_t, uint64_t>>> per(pieces.size());
 		bool oom = false;
 		idx->seq_off.assign((size_t)n_seq + 1, 0);
 		for (int i = 0; i < n_seq; ++i) idx->seq_off[i + 1] = idx->seq_off[i] + lens[i];
 		idx->seq4.assign((size_t)(idx->seq_off[n_seq] + 7) / 8 + 1, 0u);
 #pragma omp parallel for schedule(dynamic, 1)
-		for (int j = 0; j < n_seq; ++j) {
-			const int i = order[j];
+		for (size_t j = 0; j < pieces.size(); ++j) {
+			const Piece &pc = pieces[j];
 			try {
-				per[i].reserve((size_t)(lens[i] / 5 + 16));
-				contig_minimizers(seqs[i], lens[i], w, k, (uint32_t)i, per[i]);
+				per[j].reserve((size_t)((pc.hi - pc.lo) / 5 + 16));
+				contig_minimizers(seqs[pc.contig], lens[pc.contig], pc.lo, pc.hi, w, k, (uint32_t)pc.contig, per[j]);
 			} catch (const std::bad_alloc &) { oom = true; }
 		}
 		pack_contigs(idx, seqs, lens, n_seq);

@@ -284,3 +284,35 @@ def test_damaged_mmi_files_are_refused(capi, world, tmp_path):
     write_mmi_by_the_published_layout(str(p), names, seqs, h, y2)
     with pytest.raises(capi.MncError):
         capi.Index.load(str(p))
+
+
+def test_contigs_sketched_in_pieces_equal_the_whole_scan(capi, oracle):
+    """aligner.py:45: the index builder sketches long contigs in pieces on all host threads (csrc/index.cpp:
+    contig_minimizers).  Ambiguous bases, homopolymer runs and short tandem repeats -- everywhere, so also around the
+    piece boundaries at multiples of 2^18 -- must give the minimizers of the oracle's one scan per contig."""
+    rng = np.random.default_rng(41)
+    seqs = []
+    for n in (900_000, 262_144, 262_150, 300):
+        s = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n)
+        for _ in range(n // 150):                                     # runs of N, of one base, of a 2- or 3-mer
+            at, kind = int(rng.integers(0, n)), int(rng.integers(0, 4))
+            ln = int(rng.integers(1, 60))
+            if kind == 0:
+                s[at:at + int(rng.integers(1, 4))] = ord("N")
+            elif kind == 1:
+                s[at:at + ln] = s[at]
+            else:
+                unit = s[at:at + kind].copy()
+                reps = np.tile(unit, ln // kind + 1)[: len(s[at:at + ln])]
+                s[at:at + ln] = reps
+        for b in range(1 << 18, n, 1 << 18):                          # and the boundaries themselves
+            s[b - 30:b - 28] = ord("N")
+            s[b + 3:b + 40] = ord("A")
+        seqs.append(s)
+    names = [f"Genus{i}_species{i}:ACC{i:06d}.1" for i in range(len(seqs))]
+    idx = capi.Index.from_seqs(names, seqs)
+    oidx = oracle.Index.from_seqs(names, [s.tobytes() for s in seqs])
+    h, y = idx.dump()
+    oh, oy = oidx.dump()
+    assert len(h) == len(oh) and np.array_equal(h, oh) and np.array_equal(y, oy)
+    assert idx.info().mid_occ == oidx.mid_occ
