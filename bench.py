@@ -109,8 +109,9 @@ def main():
                                         first=first_read)
     engine = _capi.Engine(index, local_rank)
     engine.set_contract(_capi.CONTRACT_DP if args.contract == "dp" else _capi.CONTRACT_CHAIN)
-    if os.environ.get("MNC_FILL_PRED") or os.environ.get("MNC_DP_SERIAL"):
-        engine.set_debug(int(os.environ.get("MNC_FILL_PRED", "0")) << 8 | (0x10000 if os.environ.get("MNC_DP_SERIAL") else 0))
+    if os.environ.get("MNC_FILL_PRED") or os.environ.get("MNC_DP_SERIAL") or os.environ.get("MNC_DEBUG_BITS"):
+        engine.set_debug(int(os.environ.get("MNC_FILL_PRED", "0")) << 8 | (0x10000 if os.environ.get("MNC_DP_SERIAL") else 0) |
+                         int(os.environ.get("MNC_DEBUG_BITS", "0"), 0))
     n_genomes = info.n_genomes
     t_setup = time.time() - t0
 

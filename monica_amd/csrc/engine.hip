@@ -32,7 +32,10 @@ int chain_tail_prepare(size_t max_lds);
 
 // LDS tile sizes (anchors per read) of the sort and backtrack kernels; reads above the last
 // one, or with >= 65 536 bases, are sorted in HBM and take the sequential backtrack
-static const ChainClasses CHAIN_CLASSES = { 18, { 64, 128, 192, 256, 320, 384, 448, 512, 576, 640, 768, 896, 1024, 1280, 1536, 1792, 2048, 2560 } };
+// anchors per read: ~390 for a 5 kb read; the classes reach reads of ~100 kb (8192 anchors: 128 KB of LDS for the sort's tile,
+// 135 KB for two reads of the backtrack), longer ones take the forms that work in HBM
+static const ChainClasses CHAIN_CLASSES = { 22, { 64, 128, 192, 256, 320, 384, 448, 512, 576, 640, 768, 896, 1024, 1280, 1536, 1792, 2048, 2560,
+                                                  3072, 4096, 6144, 8192 } };
 void launch_regions(const Batch &B, void *regx, uint64_t *k64a, uint64_t *k64b, mnc_hit_t *gated, hipStream_t st);
 void launch_regions_post(const Batch &B, mnc_reg_t *work, void *regx, uint64_t *k64a, int32_t *tmp, mnc_hit_t *gated, hipStream_t st);
 // base-level alignment stage (k_align.hip)
@@ -457,7 +460,7 @@ struct mnc_engine {
 	Buf fill1, fill2, fill3, fill_fb, extp, mid_list, lfill, lext, bigfb, ext1, ext2, ext3, ext4, gen_list;
 	size_t seg_cap_override = 0, cig_cap_override = 0;
 	int cur_max_read_len = 0;                // of the batch being classified (sizes the stitch kernel's LDS)
-	int debug = 0;                           // bit mask (tests): 2 stress build of the chaining ring, 4 displacement bytes read from HBM, 0x10000 alignment kernels one at a time (with stage timers)
+	int debug = 0;                           // bit mask (tests): 2 stress build of the chaining ring, 4 displacement bytes read from HBM, 0x10000 alignment kernels one at a time (with stage timers), 0x200000 the stitch kernel reads bases in place (its form for regions beyond its LDS)
 	// last batch
 	Batch B{};
 	bool have_batch = false;
@@ -1036,7 +1039,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 					StageTimer t(e, MNC_STAGE_DP_ALIGN);
 					align_rest(B, e, st);
 				}
-				{ StageTimer t(e, MNC_STAGE_DP_STITCH); launch_dp_stitch(B, work, next, e->cur_max_read_len > 0 ? e->cur_max_read_len : 8192, 4096, st); }
+				{ StageTimer t(e, MNC_STAGE_DP_STITCH); launch_dp_stitch(B, work, next, (e->debug & 0x200000) ? 0 : e->cur_max_read_len > 0 ? e->cur_max_read_len : 8192, 4096, st); }
 			} else {
 				launch_dp_plan(B, work, max_work, (int)DP_STATE_SMALL, DP_P_SMALL, (int)DP_CIG_SMALL, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE, st);
 				if (int rcf = fork()) return rcf;
@@ -1044,7 +1047,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 				else align_round(B, e, e->side[0], e->side[1], st, e->side[2]);
 				if (int rcj = join()) return rcj;
 				align_rest(B, e, st);
-				launch_dp_stitch(B, work, next, e->cur_max_read_len > 0 ? e->cur_max_read_len : 8192, 4096, st);
+				launch_dp_stitch(B, work, next, (e->debug & 0x200000) ? 0 : e->cur_max_read_len > 0 ? e->cur_max_read_len : 8192, 4096, st);
 			}
 			launch_dp_round_end(B, st);
 			// Z-drop splits make new regions for the next round (rare); one small read-back per round

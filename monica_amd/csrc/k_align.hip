@@ -920,7 +920,8 @@ __device__ __forceinline__ void append_op(uint32_t *c, int &n, uint32_t word)
 	else c[n++] = word;
 }
 
-__global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work_list, int32_t *next_list, int seq_q_max, int seq_t_max)
+__global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work_list, int32_t *next_list, int seq_q_max, int seq_t_max,
+                                                    int size_class, int q_fit, int t_fit)
 {
 	// LDS (dynamic: the sequences are sized for the batch's longest read, so that many regions share a CU):
 	// [joined CIGAR | score events | query codes | target codes]
@@ -935,6 +936,10 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 		mnc_reg_t r = B.regs[rslot];
 		RegDP d = B.regdp[rslot];
 		if (d.state != 1) continue;
+		if (size_class != 0) {                                   // a batch with long reads: two launches, by the LDS a region needs
+			const bool fits = d.qe0 - d.qs0 <= q_fit && d.re0 - d.rs0 <= t_fit;
+			if (fits != (size_class == 1)) continue;
+		}
 		const uint32_t rd = (uint32_t)d.read;
 		const int64_t a_off = B.an_off[rd];
 		const int qlen = (int)(B.offsets[rd + 1] - B.offsets[rd]);
@@ -1421,13 +1426,26 @@ void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max,
 void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_list, int max_read_len, int n_wg, hipStream_t st)
 {
 	// query codes of a whole read; a region's target span is longer by its deletions: a quarter more
-	int q_max = (max_read_len + 63) / 64 * 64, t_max = (max_read_len + max_read_len / 4 + 127) / 64 * 64;
-	if (q_max > 16384) q_max = 16384;
-	if (t_max > 20480) t_max = 20480;
-	if (q_max < 256) q_max = 256;
-	if (t_max < 320) t_max = 320;
-	const size_t lds = (size_t)ST_CIG_MAX * 4 + ST_EV_MAX + q_max + t_max;
-	hipLaunchKernelGGL(mnc_dp_stitch, dim3(n_wg), dim3(64), lds, st, B, work_list, next_list, q_max, t_max);
+	auto dims = [](int len, int &q_max, int &t_max) {
+		q_max = (len + 63) / 64 * 64, t_max = (len + len / 4 + 127) / 64 * 64;
+		if (q_max > 16384) q_max = 16384;
+		if (t_max > 20480) t_max = 20480;
+		if (q_max < 256) q_max = 256;
+		if (t_max < 320) t_max = 320;
+	};
+	auto launch = [&](int q_max, int t_max, int size_class, int q_fit, int t_fit, int wgs) {
+		const size_t lds = (size_t)ST_CIG_MAX * 4 + ST_EV_MAX + q_max + t_max;
+		hipLaunchKernelGGL(mnc_dp_stitch, dim3(wgs), dim3(64), lds, st, B, work_list, next_list, q_max, t_max, size_class, q_fit, t_fit);
+	};
+	int q_max, t_max;
+	dims(max_read_len, q_max, t_max);
+	constexpr int ST_SMALL = 6144;                   // up to here one launch: nine regions per CU (17.6 .. 20 KB of LDS each)
+	if (q_max <= ST_SMALL) { launch(q_max, t_max, 0, 0, 0, n_wg); return; }
+	// long reads in the batch: the regions that fit the small layout keep its occupancy, the rest get the LDS they need
+	int q_s, t_s;
+	dims(ST_SMALL, q_s, t_s);
+	launch(q_s, t_s, 1, q_s, t_s, n_wg);
+	launch(q_max, t_max, 2, q_s, t_s, n_wg / 4);
 }
 
 } // namespace mnc
