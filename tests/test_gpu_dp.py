@@ -196,3 +196,20 @@ def test_every_kernel_family_can_be_taken_out(capi, oracle, world, route):
         _compare_dp(capi, oracle, world, b, o, min_mapq=0)
     finally:
         eng.set_debug(0)
+
+
+def test_reads_with_many_errors_use_every_workspace_class(capi, oracle, world):
+    """16 % errors: seeds are sparse, so gaps between them are long, the banded kernels' proofs fail more often and
+    read flanks without seeds become extensions of thousands of bases -- calls for the literal kernel's large
+    workspace class and for what the banded kernels hand back to it.  (At 16 % the first form of the stage took 2 s
+    per 30 000 reads on eight large slots; tools/err_profile.py.)  Also: the stitch kernel reading bases in place."""
+    b, o, _ = synth.reads(world["seqs"], 500, 6000, seed=778, sub=700, ins=450, dele=450)
+    _compare_dp(capi, oracle, world, b, o, min_mapq=0)
+    c = world["eng"].counters()
+    assert c["dp_literal_big"] > 0 and c["dp_long_gaps"] > 0 and c["dp_long_extensions"] > 0 and c["dp_fill_tier3"] > 0
+    eng = world["eng"]
+    try:
+        eng.set_debug(0x200000)
+        _compare_dp(capi, oracle, world, b[: o[120]], o[:121], min_mapq=0)
+    finally:
+        eng.set_debug(0)
