@@ -8,7 +8,8 @@ module instead of the reference one.  What changes is underneath: `index.map(rea
 
 Deviations, all deliberate:
 * hits follow the chain-level contract (DESIGN.md section 1): no base-level DP, NM := blen - mlen;
-* index files are this library's own format under the reference's `indexN.mmi` names;
+* index files under the reference's `indexN.mmi` names are this library's own format unless
+  `mappy_compat.INDEX_FILE_FORMAT = "mmi"`; `index_loader` reads both, and minimap2's own files;
 * `n_threads=None` means 4 worker threads, not one per core: a thread only feeds the GPU.
 """
 import itertools
