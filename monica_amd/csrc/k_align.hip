@@ -1096,7 +1096,21 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 			const int ql = qe1 - qs1, tl = re1 - rs1;
 			const bool in_lds = ql <= seq_q_max && tl <= seq_t_max;
 			if (in_lds) {
-				for (int i = lane; i < ql; i += 64) s_q[i] = (uint8_t)qcode(read, qlen, rev, qs1 + i);
+				if (!B.ambig[rd]) {
+					// a read of A C G T only: its bases from the sketch stage's 2-bit words, 16 per lane and load
+					const int64_t g_lo = B.offsets[rd] + (rev ? qlen - qe1 : qs1), g_hi = g_lo + ql;
+					for (int64_t wd = (g_lo >> 4) + lane; wd <= (g_hi - 1) >> 4; wd += 64) {
+						const uint32_t v = B.packed[wd];
+#pragma unroll
+						for (int b16 = 0; b16 < 16; ++b16) {
+							const int64_t g = wd * 16 + b16;
+							const int c = (int)(v >> (30 - 2 * b16) & 3u);
+							const int i = rev ? (int)(g_hi - 1 - g) : (int)(g - g_lo);
+							if (g >= g_lo && g < g_hi) s_q[i] = (uint8_t)(rev ? 3 - c : c);
+						}
+					}
+				} else
+					for (int i = lane; i < ql; i += 64) s_q[i] = (uint8_t)qcode(read, qlen, rev, qs1 + i);
 				// eight target bases per word
 				const int64_t o0 = coff + rs1, w0 = o0 >> 3, w1 = (o0 + tl + 7) >> 3;
 				for (int64_t wd = w0 + lane; wd < w1; wd += 64) {
@@ -1112,6 +1126,11 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 			auto Q = [&](int i) -> int { return in_lds ? (int)s_q[i] : qcode(read, qlen, rev, qs1 + i); };
 			auto Tg = [&](int i) -> int { return in_lds ? (int)s_t[i] : tcode(B, coff, rs1 + i); };
+			// four bytes from byte offset `at` of an LDS array (4-aligned base; reads up to three bytes past the last one asked for)
+			auto lds4 = [&](const uint8_t *base, int at) -> uint32_t {
+				const uint32_t *w = reinterpret_cast<const uint32_t*>(base) + (at >> 2);
+				return __builtin_amdgcn_alignbyte(w[1], w[0], (uint32_t)at & 3u);
+			};
 			int qshift = 0, tshift = 0;
 			// ---- mm_fix_cigar.  Its common work -- sliding every indel between two M runs to the left
 			// as far as the bases repeat -- is independent per indel as long as no slide eats a whole
@@ -1284,39 +1303,105 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 				lane_form = dpp_max_all(longest) <= 384;
 			}
 			if (lane_form) {
-				const int per = (n_c + 63) / 64;
-				const int k_lo = lane * per < n_c ? lane * per : n_c, k_hi = k_lo + per < n_c ? k_lo + per : n_c;
-				int dq = 0, dt = 0;
-				for (int k = k_lo; k < k_hi; ++k) {
-					const uint32_t wd = C[k], op = wd & 0xf;
-					const int len = (int)(wd >> 4);
-					if (op != 2) dq += len;
-					if (op != 1) dt += len;
+				// shares of equal length in bases, cut at operation boundaries: lane l starts at the first operation whose
+				// bases begin at or after l * per_u (found by the lane that owns the operation, 64 operations at a time)
+				int T = 0;
+				for (int k = lane; k < n_c; k += 64) T += (int)(C[k] >> 4);
+				T = __builtin_amdgcn_readlane(dpp_incl_add(T), 63);
+				const int per_u = T / 64 + 1;
+				int32_t *s_b = reinterpret_cast<int32_t*>(s_d);                     // [64][3]: first operation, query and target offset there
+				s_b[lane * 3] = n_c, s_b[lane * 3 + 1] = 0, s_b[lane * 3 + 2] = 0;
+				c_order();
+				{
+					int cP = 0, cQ = qshift, cT = tshift, prev_last = -1;           // prev_last: where the operation before this chunk began
+					for (int k0 = 0; k0 < n_c; k0 += 64) {
+						const int k = k0 + lane;
+						const uint32_t wd = k < n_c ? C[k] : 0, op = wd & 0xf;
+						const int len = (int)(wd >> 4);
+						const int dq = k < n_c && op != 2 ? len : 0, dt = k < n_c && op != 1 ? len : 0;
+						const int il = dpp_incl_add(len), iq = dpp_incl_add(dq), it = dpp_incl_add(dt);
+						const int Pk = cP + il - len, Pq = cQ + iq - dq, Pt = cT + it - dt;
+						int before = __shfl_up(Pk, 1);
+						if (lane == 0) before = prev_last;
+						if (k < n_c) {
+							// the lanes l with before < l * per_u <= Pk start here
+							const int l_lo = before < 0 ? 0 : before / per_u + 1, l_hi = Pk / per_u;
+							for (int l = l_lo; l <= l_hi && l < 64; ++l) s_b[l * 3] = k, s_b[l * 3 + 1] = Pq, s_b[l * 3 + 2] = Pt;
+						}
+						prev_last = __builtin_amdgcn_readlane(Pk, 63);
+						cP += __builtin_amdgcn_readlane(il, 63), cQ += __builtin_amdgcn_readlane(iq, 63), cT += __builtin_amdgcn_readlane(it, 63);
+					}
 				}
-				int qo = qshift + dpp_incl_add(dq) - dq, to = tshift + dpp_incl_add(dt) - dt;
+				c_order();
+				int k = s_b[lane * 3], qo = s_b[lane * 3 + 1], to = s_b[lane * 3 + 2];
+				const int k_end = lane < 63 ? s_b[lane * 3 + 3] : n_c;
+				const bool mine = k < k_end;
+				// one base per lane and turn, whatever operation it belongs to: the lanes do not wait for each other's runs
 				int A = 0, Bv = SC_NONE, MA = SC_NONE, MB = SC_NONE, my_blen = 0, my_mlen = 0;
-				for (int k = k_lo; k < k_hi; ++k) {
-					const uint32_t wd = C[k], op = wd & 0xf;
-					const int len = (int)(wd >> 4);
-					my_blen += len;
-					if (op == 0) {
-						my_mlen += len;
-						for (int i = 0; i < len; ++i) {
-							const int cq = Q(qo + i), ct = Tg(to + i);
+				int len = 0, pos = 0;
+				uint32_t op = 0;
+				bool done = !mine;
+				// `C` is a generic pointer (LDS or the pool): a flat load per turn costs more than the turn.  The next word
+				// comes early and, when the CIGAR is in LDS, as an LDS read.
+				auto cword = [&](int kk) -> uint32_t { return kk >= k_end ? 0u : c_lds ? s_c[kk] : C[kk]; };
+				uint32_t nxt = cword(k);
+				for (;;) {
+					if (!done && pos == len) {
+						if (k >= k_end) done = true;
+						else {
+							const uint32_t wd = nxt;
+							nxt = cword(++k);
+							op = wd & 0xf, len = (int)(wd >> 4), pos = 0;
+							my_blen += len;
+							if (op == 0) my_mlen += len;
+							else {
+								const int dlt = -(B.gap_q + B.gap_e * len);
+								A += dlt, Bv = Bv + dlt > 0 ? Bv + dlt : 0;
+								MA = MA > A ? MA : A, MB = MB > Bv ? MB : Bv;
+							}
+						}
+					}
+					if (!__any(!done)) break;
+					if (in_lds) {
+						// up to four bases per lane and turn, from two aligned LDS words each: the turn's time is the LDS round
+						// trip, not the arithmetic
+						if (!done && pos < len) {
+							const int n = len - pos < 4 ? len - pos : 4;
+							pos += n;
+							if (op == 0) {
+								const uint32_t q4 = lds4(s_q, qo), t4 = lds4(s_t, to);
+								const uint32_t x4 = q4 ^ t4, a4 = (q4 | t4) & 0x0c0c0c0cu;
+#pragma unroll
+								for (int b4 = 0; b4 < 4; ++b4) {
+									if (b4 < n) {
+										const bool amb = (a4 >> (8 * b4) & 0xffu) != 0, dif = (x4 >> (8 * b4) & 0xffu) != 0;
+										const int dlt = amb ? -B.sc_ambi : dif ? -B.sc_b : B.sc_a;
+										c_amb += amb ? 1 : 0, c_diff += !amb && dif ? 1 : 0;
+										A += dlt, Bv = Bv + dlt > 0 ? Bv + dlt : 0;
+										MA = MA > A ? MA : A, MB = MB > Bv ? MB : Bv;
+									}
+								}
+								qo += n, to += n;
+							} else {
+								const uint32_t v4 = op == 1 ? lds4(s_q, qo) : lds4(s_t, to);
+								const uint32_t m4 = v4 & 0x0c0c0c0cu & (n == 4 ? 0xffffffffu : (1u << (8 * n)) - 1u);
+								if (m4) c_gamb += ((m4 & 0xffu) != 0) + ((m4 >> 8 & 0xffu) != 0) + ((m4 >> 16 & 0xffu) != 0) + ((m4 >> 24) != 0);
+								if (op == 1) qo += n; else to += n;
+							}
+						}
+					} else if (!done && pos < len) {
+						++pos;
+						if (op == 0) {
+							const int cq = Q(qo), ct = Tg(to);
 							int dlt;
 							if (ct > 3 || cq > 3) ++c_amb, dlt = -B.sc_ambi;
 							else if (ct != cq) ++c_diff, dlt = -B.sc_b;
 							else dlt = B.sc_a;
 							A += dlt, Bv = Bv + dlt > 0 ? Bv + dlt : 0;
 							MA = MA > A ? MA : A, MB = MB > Bv ? MB : Bv;
-						}
-						qo += len, to += len;
-					} else {
-						for (int i = 0; i < len; ++i) c_gamb += (op == 1 ? Q(qo + i) : Tg(to + i)) > 3;
-						const int dlt = -(B.gap_q + B.gap_e * len);
-						A += dlt, Bv = Bv + dlt > 0 ? Bv + dlt : 0;
-						MA = MA > A ? MA : A, MB = MB > Bv ? MB : Bv;
-						if (op == 1) qo += len; else to += len;
+							++qo, ++to;
+						} else if (op == 1) c_gamb += Q(qo) > 3, ++qo;
+						else c_gamb += Tg(to) > 3, ++to;
 					}
 				}
 				// the score every lane starts from: the lanes before it, composed, applied to 0
@@ -1325,7 +1410,7 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 				const int x_out = fa > fb ? fa : fb;                                 // max(0 + fa, fb)
 				int x_in = __shfl_up(x_out, 1);
 				if (lane == 0) x_in = 0;
-				const int top = k_lo < k_hi ? (x_in + MA > MB ? x_in + MA : MB) : 0;
+				const int top = mine ? (x_in + MA > MB ? x_in + MA : MB) : 0;
 				s_max = dpp_max_all(top > 0 ? top : 0);
 				blen = __builtin_amdgcn_readlane(dpp_incl_add(my_blen), 63), mlen = __builtin_amdgcn_readlane(dpp_incl_add(my_mlen), 63);
 			}
@@ -1434,7 +1519,7 @@ void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_li
 		if (t_max < 320) t_max = 320;
 	};
 	auto launch = [&](int q_max, int t_max, int size_class, int q_fit, int t_fit, int wgs) {
-		const size_t lds = (size_t)ST_CIG_MAX * 4 + ST_EV_MAX + q_max + t_max;
+		const size_t lds = (size_t)ST_CIG_MAX * 4 + ST_EV_MAX + q_max + t_max + 16;   // + 16: the stitch reads whole words
 		hipLaunchKernelGGL(mnc_dp_stitch, dim3(wgs), dim3(64), lds, st, B, work_list, next_list, q_max, t_max, size_class, q_fit, t_fit);
 	};
 	int q_max, t_max;
