@@ -121,6 +121,9 @@ struct RegDP {
 	int32_t n_cigar;          // region CIGAR (after the clean-up)
 	int32_t state;            // 0 unused, 1 planned this round, 2 done
 	int64_t cig_off;          // in the region pool
+	// what the stitch kernel would otherwise reach through three more dependent loads (written by mnc_dp_plan)
+	int32_t rid, rev, qlen, pad_;
+	int64_t coff, read_off;   // first base of the contig in seq4; of the read in the batch
 };
 
 struct RegX { uint64_t x0, y0, x1, y1; };   // first / last anchor of a region

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 	if (r.cnt == 0) { d.state = 2; B.regdp[rslot] = d; return; }
 	const int k2 = KMER >> 1;
 	const int rid = (int32_t)(a[r.as].x << 1 >> 33), rev = (int32_t)(a[r.as].x >> 63);
+	d.rid = rid, d.rev = rev, d.qlen = qlen, d.pad_ = 0, d.coff = B.seq_off[rid], d.read_off = B.offsets[rd];
 	const int ref_len = (int)(B.seq_off[rid + 1] - B.seq_off[rid]);
 	const int bw = (int)(B.bw * 1.5 + 1.);
 	int as1 = r.as, cnt1 = r.cnt;
@@ -912,6 +913,7 @@ __device__ __forceinline__ void dpp_scan_maps(int &a, int &b)
 // region pool.  One wave per region; lane 0 does the sequential bookkeeping, all lanes the walks.
 constexpr int ST_CIG_MAX = 1024;                            // CIGAR words in LDS
 constexpr int ST_EV_MAX = 2048;                             // score events (one byte each) buffered for one scan
+constexpr unsigned long long ST_POOL_CHUNK = 4096;           // words of the region CIGAR pool a wave reserves at a time
 constexpr int ST_EV_LIM = 127;                              // a gap that costs more is applied directly
 
 __device__ __forceinline__ void append_op(uint32_t *c, int &n, uint32_t word)
@@ -931,6 +933,8 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 	uint8_t *s_q = st_smem + ST_CIG_MAX * 4 + ST_EV_MAX, *s_t = s_q + seq_q_max;
 	const int lane = threadIdx.x;
 	const unsigned long long n_work = B.dp_ctr[9];
+	const bool chunked = n_work >= 4ull * gridDim.x;
+	unsigned long long pool_off = 0, pool_left = 0;
 	for (unsigned long long wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
 		const int64_t rslot = work_list[wi];
 		mnc_reg_t r = B.regs[rslot];
@@ -942,11 +946,11 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 		}
 		const uint32_t rd = (uint32_t)d.read;
 		const int64_t a_off = B.an_off[rd];
-		const int qlen = (int)(B.offsets[rd + 1] - B.offsets[rd]);
-		const uint8_t *read = B.bases + B.offsets[rd];
+		const int qlen = d.qlen;
+		const uint8_t *read = B.bases + d.read_off;
 		const Anchor *a = B.ca + a_off;
-		const int rid = (int32_t)(a[r.as].x << 1 >> 33), rev = (int32_t)(a[r.as].x >> 63);
-		const int64_t coff = B.seq_off[rid];
+		const int rev = d.rev;
+		const int64_t coff = d.coff;
 		const Seg *sg = B.segs + d.first_seg;
 		// ---- which segments are joined: all of them, or up to the first gap filling that Z-dropped; how many
 		// CIGAR words that is at most.  One segment per lane, 64 at a time.
@@ -964,9 +968,21 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 			if (k >= stop) nc = 0;
 			total += __builtin_amdgcn_readlane(dpp_incl_add(nc), 63);
 		}
+		// room in the region pool: a large batch takes it 4096 words at a time per wave (one counter for 100 000 regions
+		// is a queue of atomics, each a round trip the region waits for)
 		unsigned long long off = 0;
-		if (lane == 0 && total > 0) off = atomicAdd(&B.dp_ctr[2], (unsigned long long)total);
-		off = (unsigned long long)__shfl((long long)off, 0);
+		if (total > 0 && (unsigned long long)total <= pool_left) off = pool_off, pool_off += total, pool_left -= total;
+		else if (total > 0) {
+			const unsigned long long want = chunked && total < ST_POOL_CHUNK ? ST_POOL_CHUNK : (unsigned long long)total;
+			if (lane == 0) off = atomicAdd(&B.dp_ctr[2], want);
+			off = (unsigned long long)__shfl((long long)off, 0);
+			if ((long long)(off + want) > B.cig_reg_cap) {
+				if (lane == 0) atomicMax(&B.dp_ctr[4], 3ULL);
+				total = 0;
+				continue;
+			}
+			pool_off = off + total, pool_left = want - total;
+		}
 		if ((long long)(off + total) > B.cig_reg_cap) {
 			if (lane == 0) atomicMax(&B.dp_ctr[4], 3ULL);
 			total = 0;
@@ -980,6 +996,8 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 		// every value below is the same in all lanes; only the copies are shared out
 		const bool c_lds = total <= ST_CIG_MAX;
 		auto c_order = [&]() { if (c_lds) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); asm volatile("" ::: "memory"); } else mem_order(); };
+		// reads of the joined CIGAR in the passes below: `C` is a generic pointer (flat loads); in LDS, say so
+		auto CR = [&](int kk) -> uint32_t { return c_lds ? s_c[kk] : C[kk]; };
 		if (total > 0) flags |= REG_HAS_DP;
 		{
 			// the join: a segment whose first operation equals the last one before it adds its length there
@@ -1098,7 +1116,7 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 			if (in_lds) {
 				if (!B.ambig[rd]) {
 					// a read of A C G T only: its bases from the sketch stage's 2-bit words, 16 per lane and load
-					const int64_t g_lo = B.offsets[rd] + (rev ? qlen - qe1 : qs1), g_hi = g_lo + ql;
+					const int64_t g_lo = d.read_off + (rev ? qlen - qe1 : qs1), g_hi = g_lo + ql;
 					for (int64_t wd = (g_lo >> 4) + lane; wd <= (g_hi - 1) >> 4; wd += 64) {
 						const uint32_t v = B.packed[wd];
 #pragma unroll
@@ -1142,7 +1160,7 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 				int carry_q = 0, carry_t = 0;
 				for (int k0 = 0; k0 < n_c; k0 += 64) {
 					const int k = k0 + lane;
-					const uint32_t wd = k < n_c ? C[k] : 0;
+					const uint32_t wd = k < n_c ? CR(k) : 0;
 					const uint32_t op = wd & 0xf;
 					const int len = (int)(wd >> 4);
 					const int dq = k < n_c && op != 2 ? len : 0, dt = k < n_c && op != 1 ? len : 0;
@@ -1153,7 +1171,7 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 					if (k < n_c) {
 						if (len == 0) odd = true;
 						if (op != 0) {
-							const uint32_t nx = k + 1 < n_c ? C[k + 1] : 0u, pv = k > 0 ? C[k - 1] : 1u;
+							const uint32_t nx = k + 1 < n_c ? CR(k + 1) : 0u, pv = k > 0 ? CR(k - 1) : 1u;
 							if (k + 1 < n_c && (nx & 0xf) != 0) odd = true;          // I next to D
 							if (k > 0 && k < n_c - 1 && (pv & 0xf) == 0 && (nx & 0xf) == 0) {
 								const int prev_len = (int)(pv >> 4);
@@ -1299,14 +1317,14 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 			bool lane_form = n_c >= 128;
 			if (lane_form) {
 				int longest = 0;
-				for (int k = lane; k < n_c; k += 64) { const int len = (int)(C[k] >> 4); longest = longest > len ? longest : len; }
+				for (int k = lane; k < n_c; k += 64) { const int len = (int)(CR(k) >> 4); longest = longest > len ? longest : len; }
 				lane_form = dpp_max_all(longest) <= 384;
 			}
 			if (lane_form) {
 				// shares of equal length in bases, cut at operation boundaries: lane l starts at the first operation whose
 				// bases begin at or after l * per_u (found by the lane that owns the operation, 64 operations at a time)
 				int T = 0;
-				for (int k = lane; k < n_c; k += 64) T += (int)(C[k] >> 4);
+				for (int k = lane; k < n_c; k += 64) T += (int)(CR(k) >> 4);
 				T = __builtin_amdgcn_readlane(dpp_incl_add(T), 63);
 				const int per_u = T / 64 + 1;
 				int32_t *s_b = reinterpret_cast<int32_t*>(s_d);                     // [64][3]: first operation, query and target offset there
@@ -1316,7 +1334,7 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 					int cP = 0, cQ = qshift, cT = tshift, prev_last = -1;           // prev_last: where the operation before this chunk began
 					for (int k0 = 0; k0 < n_c; k0 += 64) {
 						const int k = k0 + lane;
-						const uint32_t wd = k < n_c ? C[k] : 0, op = wd & 0xf;
+						const uint32_t wd = k < n_c ? CR(k) : 0, op = wd & 0xf;
 						const int len = (int)(wd >> 4);
 						const int dq = k < n_c && op != 2 ? len : 0, dt = k < n_c && op != 1 ? len : 0;
 						const int il = dpp_incl_add(len), iq = dpp_incl_add(dq), it = dpp_incl_add(dt);
@@ -1363,29 +1381,34 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 					}
 					if (!__any(!done)) break;
 					if (in_lds) {
-						// up to four bases per lane and turn, from two aligned LDS words each: the turn's time is the LDS round
+						// up to eight bases per lane and turn, from three aligned LDS words each: the turn's time is the LDS round
 						// trip, not the arithmetic
 						if (!done && pos < len) {
-							const int n = len - pos < 4 ? len - pos : 4;
+							const int n = len - pos < 8 ? len - pos : 8;
 							pos += n;
 							if (op == 0) {
-								const uint32_t q4 = lds4(s_q, qo), t4 = lds4(s_t, to);
-								const uint32_t x4 = q4 ^ t4, a4 = (q4 | t4) & 0x0c0c0c0cu;
+								const uint32_t q4[2] = { lds4(s_q, qo), lds4(s_q, qo + 4) }, t4[2] = { lds4(s_t, to), lds4(s_t, to + 4) };
 #pragma unroll
-								for (int b4 = 0; b4 < 4; ++b4) {
-									if (b4 < n) {
-										const bool amb = (a4 >> (8 * b4) & 0xffu) != 0, dif = (x4 >> (8 * b4) & 0xffu) != 0;
-										const int dlt = amb ? -B.sc_ambi : dif ? -B.sc_b : B.sc_a;
-										c_amb += amb ? 1 : 0, c_diff += !amb && dif ? 1 : 0;
-										A += dlt, Bv = Bv + dlt > 0 ? Bv + dlt : 0;
-										MA = MA > A ? MA : A, MB = MB > Bv ? MB : Bv;
+								for (int h = 0; h < 2; ++h) {
+									const uint32_t x4 = q4[h] ^ t4[h], a4 = (q4[h] | t4[h]) & 0x0c0c0c0cu;
+#pragma unroll
+									for (int b4 = 0; b4 < 4; ++b4) {
+										if (h * 4 + b4 < n) {
+											const bool amb = (a4 >> (8 * b4) & 0xffu) != 0, dif = (x4 >> (8 * b4) & 0xffu) != 0;
+											const int dlt = amb ? -B.sc_ambi : dif ? -B.sc_b : B.sc_a;
+											c_amb += amb ? 1 : 0, c_diff += !amb && dif ? 1 : 0;
+											A += dlt, Bv = Bv + dlt > 0 ? Bv + dlt : 0;
+											MA = MA > A ? MA : A, MB = MB > Bv ? MB : Bv;
+										}
 									}
 								}
 								qo += n, to += n;
 							} else {
-								const uint32_t v4 = op == 1 ? lds4(s_q, qo) : lds4(s_t, to);
-								const uint32_t m4 = v4 & 0x0c0c0c0cu & (n == 4 ? 0xffffffffu : (1u << (8 * n)) - 1u);
-								if (m4) c_gamb += ((m4 & 0xffu) != 0) + ((m4 >> 8 & 0xffu) != 0) + ((m4 >> 16 & 0xffu) != 0) + ((m4 >> 24) != 0);
+								const uint8_t *src = op == 1 ? s_q : s_t;
+								const int at = op == 1 ? qo : to;
+								const uint64_t v8 = (uint64_t)lds4(src, at + 4) << 32 | lds4(src, at);
+								const uint64_t m8 = v8 & 0x0c0c0c0c0c0c0c0cULL & (n == 8 ? ~0ULL : (1ULL << (8 * n)) - 1ULL);
+								if (m8) for (int b8 = 0; b8 < 8; ++b8) c_gamb += (m8 >> (8 * b8) & 0xffu) != 0;
 								if (op == 1) qo += n; else to += n;
 							}
 						}
@@ -1418,7 +1441,7 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 			// operation's events (an M run: one per base; a gap: one) and counts
 			for (int k0 = 0; k0 < n_c && !lane_form; k0 += 64) {
 				const int k = k0 + lane, k1 = k0 + 64 < n_c ? k0 + 64 : n_c;
-				const uint32_t wd = k < n_c ? C[k] : 0;
+				const uint32_t wd = k < n_c ? CR(k) : 0;
 				const uint32_t op = wd & 0xf;
 				const int len = (int)(wd >> 4);
 				const int cost = B.gap_q + B.gap_e * len;
@@ -1519,7 +1542,7 @@ void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_li
 		if (t_max < 320) t_max = 320;
 	};
 	auto launch = [&](int q_max, int t_max, int size_class, int q_fit, int t_fit, int wgs) {
-		const size_t lds = (size_t)ST_CIG_MAX * 4 + ST_EV_MAX + q_max + t_max + 16;   // + 16: the stitch reads whole words
+		const size_t lds = (size_t)ST_CIG_MAX * 4 + ST_EV_MAX + q_max + t_max + 16;   // + 16: the stitch reads whole words, up to eleven bytes past a region's last base
 		hipLaunchKernelGGL(mnc_dp_stitch, dim3(wgs), dim3(64), lds, st, B, work_list, next_list, q_max, t_max, size_class, q_fit, t_fit);
 	};
 	int q_max, t_max;
