@@ -90,12 +90,24 @@ __device__ __forceinline__ int seed_gap(const Anchor *a, int i)
 	return ((int32_t)a[i].y - (int32_t)a[i - 1].y) - ((int32_t)a[i].x - (int32_t)a[i - 1].x);
 }
 
+// (four anchors per turn, loaded before any is used: one lane walks a region's anchors alone, and a turn's time is its
+// loads' round trip)
 __device__ int collect_long_gaps(const Anchor *a, int cnt1, int min_gap, int32_t *K)
 {
 	int n = 0;
-	for (int i = 1; i < cnt1; ++i) {
-		const int gap = seed_gap(a, i);
-		if (gap < -min_gap || gap > min_gap) K[n++] = i;
+	int32_t px = (int32_t)a[0].x, py = (int32_t)a[0].y;
+	for (int i = 1; i < cnt1; i += 4) {
+		int32_t x[4], y[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) { const int ii = i + u < cnt1 ? i + u : cnt1 - 1; x[u] = (int32_t)a[ii].x, y[u] = (int32_t)a[ii].y; }
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			if (i + u < cnt1) {
+				const int gap = (y[u] - py) - (x[u] - px);
+				if (gap < -min_gap || gap > min_gap) K[n++] = i + u;
+				px = x[u], py = y[u];
+			}
+		}
 	}
 	return n <= 1 ? 0 : n;
 }
@@ -272,10 +284,18 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 	int n_fill = 0;
 	{
 		int prs = rs, pqs = qs;
-		for (int i = 1; i < cnt1; ++i) {
-			if ((b[i].y & (SEED_IGNORE | SEED_TANDEM)) && i != cnt1 - 1) continue;
-			const int cre = (int32_t)b[i].x - k2, cqe = (int32_t)b[i].y - k2;
-			if (i == cnt1 - 1 || (b[i].y & SEED_LONG_JOIN) || (cqe - pqs >= B.min_ksw_len && cre - prs >= B.min_ksw_len)) ++n_fill, prs = cre, pqs = cqe;
+		for (int i0 = 1; i0 < cnt1; i0 += 4) {
+			uint64_t bx[4], by[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { const int ii = i0 + u < cnt1 ? i0 + u : cnt1 - 1; bx[u] = b[ii].x, by[u] = b[ii].y; }
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const int i = i0 + u;
+				if (i >= cnt1) break;
+				if ((by[u] & (SEED_IGNORE | SEED_TANDEM)) && i != cnt1 - 1) continue;
+				const int cre = (int32_t)bx[u] - k2, cqe = (int32_t)by[u] - k2;
+				if (i == cnt1 - 1 || (by[u] & SEED_LONG_JOIN) || (cqe - pqs >= B.min_ksw_len && cre - prs >= B.min_ksw_len)) ++n_fill, prs = cre, pqs = cqe;
+			}
 		}
 	}
 	// the last gap filling ends at the last seed: the right extension starts from (re, qe) above
@@ -395,16 +415,23 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 				emit(g);
 			}
 			int prs = rs, pqs = qs;
-			for (int i = 1; i < cnt1; ++i) {
-				if ((b[i].y & (SEED_IGNORE | SEED_TANDEM)) && i != cnt1 - 1) continue;
-				const int cre = (int32_t)b[i].x - k2, cqe = (int32_t)b[i].y - k2;
-				if (i == cnt1 - 1 || (b[i].y & SEED_LONG_JOIN) || (cqe - pqs >= B.min_ksw_len && cre - prs >= B.min_ksw_len)) {
-					Seg g;
-					g.kind = 1, g.ts = prs, g.tlen = cre - prs, g.qs = pqs, g.qlen = cqe - pqs;
-					g.w = (b[i].y & SEED_LONG_JOIN) ? (cqe - pqs > cre - prs ? cqe - pqs : cre - prs) : bw;
-					g.zdrop = B.zdrop, g.flag = EZ_APPROX_MAX, g.ai = i;
-					emit(g);
-					prs = cre, pqs = cqe;
+			for (int i0 = 1; i0 < cnt1; i0 += 4) {
+				uint64_t bx[4], by[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) { const int ii = i0 + u < cnt1 ? i0 + u : cnt1 - 1; bx[u] = b[ii].x, by[u] = b[ii].y; }
+				for (int u = 0; u < 4 && i0 + u < cnt1; ++u) {
+					const int i = i0 + u;
+					const uint64_t vx = u == 0 ? bx[0] : u == 1 ? bx[1] : u == 2 ? bx[2] : bx[3], vy = u == 0 ? by[0] : u == 1 ? by[1] : u == 2 ? by[2] : by[3];
+					if ((vy & (SEED_IGNORE | SEED_TANDEM)) && i != cnt1 - 1) continue;
+					const int cre = (int32_t)vx - k2, cqe = (int32_t)vy - k2;
+					if (i == cnt1 - 1 || (vy & SEED_LONG_JOIN) || (cqe - pqs >= B.min_ksw_len && cre - prs >= B.min_ksw_len)) {
+						Seg g;
+						g.kind = 1, g.ts = prs, g.tlen = cre - prs, g.qs = pqs, g.qlen = cqe - pqs;
+						g.w = (vy & SEED_LONG_JOIN) ? (cqe - pqs > cre - prs ? cqe - pqs : cre - prs) : bw;
+						g.zdrop = B.zdrop, g.flag = EZ_APPROX_MAX, g.ai = i;
+						emit(g);
+						prs = cre, pqs = cqe;
+					}
 				}
 			}
 			if (right) {
