@@ -757,7 +757,9 @@ static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream
 	launch_dp_fill(B, 128, B.fill_list3, 22, 23, B.fill_fb, 12, B.fill_fb, 12, e->ws->fill_p.as<uint8_t>(), e->ws->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
 	if (s2 == s0) launch_dp_lfill(B, B.lfill_list, 31, 61, B.fill_fb, 12, e->ws->lfill_p.as<uint8_t>(), DP_WG_LFILL, s0);   // one kernel at a time (profiling)
 	mark(MNC_STAGE_DP_FILL_T3, 1), mark(MNC_STAGE_DP_EXT, 0);
-	for (int i = 0; i < 8; ++i)
+	// the classes with the longest queries first: few calls, each long -- at the end of the stream they would be a tail
+	// of a few busy waves; the short ones (most of the calls) drain evenly
+	for (int i = 7; i >= 0; --i)
 		launch_dp_extp(B, 32 << (i >> 1), i & 1, B.extp_list + (int64_t)i * B.seg_cap, 32 + i, 40 + i, e->ws->extp_p.as<uint8_t>(), e->ws->extp_cig.as<uint32_t>(), DP_WG_EXT, s1);
 	launch_dp_ext(B, 32, B.ext_list1, 16, 18, B.fill_fb, 12, e->ws->ext_p.as<uint8_t>(), DP_WG_EXT, s1);
 	launch_dp_ext(B, 64, B.ext_list2, 17, 19, B.fill_fb, 12, e->ws->ext_p.as<uint8_t>(), DP_WG_EXT, s1);
