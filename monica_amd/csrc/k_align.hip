@@ -1410,34 +1410,32 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 					if (in_lds) {
 						// up to eight bases per lane and turn, from three aligned LDS words each: the turn's time is the LDS round
 						// trip, not the arithmetic
+						// one body for every operation, without branches: a gap's bases only count ambiguous codes (its score
+						// event was applied when it was fetched), and a base beyond the operation's end is an event of 0 -- which
+						// leaves the map as it is once a real event has been applied (Bv >= 0 from then on), and the first base
+						// of a turn is always real
 						if (!done && pos < len) {
 							const int n = len - pos < 8 ? len - pos : 8;
 							pos += n;
-							if (op == 0) {
-								const uint32_t q4[2] = { lds4(s_q, qo), lds4(s_q, qo + 4) }, t4[2] = { lds4(s_t, to), lds4(s_t, to + 4) };
+							const uint32_t q4[2] = { lds4(s_q, qo), lds4(s_q, qo + 4) }, t4[2] = { lds4(s_t, to), lds4(s_t, to + 4) };
+							const bool is_m = op == 0;
+							const int sc_match = is_m ? B.sc_a : 0, sc_mis = is_m ? -B.sc_b : 0, sc_amb = is_m ? -B.sc_ambi : 0;
 #pragma unroll
-								for (int h = 0; h < 2; ++h) {
-									const uint32_t x4 = q4[h] ^ t4[h], a4 = (q4[h] | t4[h]) & 0x0c0c0c0cu;
+							for (int h = 0; h < 2; ++h) {
+								// an M run compares the two; an insertion looks at the query's codes only, a deletion at the target's
+								const uint32_t qv = op == 2 ? 0u : q4[h], tv = op == 1 ? 0u : t4[h];
+								const uint32_t x4 = qv ^ tv, a4 = (qv | tv) & 0x0c0c0c0cu;
 #pragma unroll
-									for (int b4 = 0; b4 < 4; ++b4) {
-										if (h * 4 + b4 < n) {
-											const bool amb = (a4 >> (8 * b4) & 0xffu) != 0, dif = (x4 >> (8 * b4) & 0xffu) != 0;
-											const int dlt = amb ? -B.sc_ambi : dif ? -B.sc_b : B.sc_a;
-											c_amb += amb ? 1 : 0, c_diff += !amb && dif ? 1 : 0;
-											A += dlt, Bv = Bv + dlt > 0 ? Bv + dlt : 0;
-											MA = MA > A ? MA : A, MB = MB > Bv ? MB : Bv;
-										}
-									}
+								for (int b4 = 0; b4 < 4; ++b4) {
+									const bool valid = h * 4 + b4 < n;
+									const bool amb = valid && (a4 >> (8 * b4) & 0xffu) != 0, dif = valid && (x4 >> (8 * b4) & 0xffu) != 0;
+									const int dlt = !valid ? 0 : amb ? sc_amb : dif ? sc_mis : sc_match;
+									c_amb += is_m && amb ? 1 : 0, c_diff += is_m && !amb && dif ? 1 : 0, c_gamb += !is_m && amb ? 1 : 0;
+									A += dlt, Bv = Bv + dlt > 0 ? Bv + dlt : 0;
+									MA = MA > A ? MA : A, MB = MB > Bv ? MB : Bv;
 								}
-								qo += n, to += n;
-							} else {
-								const uint8_t *src = op == 1 ? s_q : s_t;
-								const int at = op == 1 ? qo : to;
-								const uint64_t v8 = (uint64_t)lds4(src, at + 4) << 32 | lds4(src, at);
-								const uint64_t m8 = v8 & 0x0c0c0c0c0c0c0c0cULL & (n == 8 ? ~0ULL : (1ULL << (8 * n)) - 1ULL);
-								if (m8) for (int b8 = 0; b8 < 8; ++b8) c_gamb += (m8 >> (8 * b8) & 0xffu) != 0;
-								if (op == 1) qo += n; else to += n;
 							}
+							qo += op == 2 ? 0 : n, to += op == 1 ? 0 : n;
 						}
 					} else if (!done && pos < len) {
 						++pos;
