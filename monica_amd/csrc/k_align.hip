@@ -1140,6 +1140,7 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 			// ---- sequences of [qs1, qe1) x [rs1, re1) into LDS (or read in place when too long)
 			const int ql = qe1 - qs1, tl = re1 - rs1;
 			const bool in_lds = ql <= seq_q_max && tl <= seq_t_max;
+			bool acgt_only = false;                                   // no ambiguous base in the region's read or target words
 			if (in_lds) {
 				if (!B.ambig[rd]) {
 					// a read of A C G T only: its bases from the sketch stage's 2-bit words, 16 per lane and load
@@ -1158,14 +1159,17 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 					for (int i = lane; i < ql; i += 64) s_q[i] = (uint8_t)qcode(read, qlen, rev, qs1 + i);
 				// eight target bases per word
 				const int64_t o0 = coff + rs1, w0 = o0 >> 3, w1 = (o0 + tl + 7) >> 3;
+				uint32_t t_amb = 0;
 				for (int64_t wd = w0 + lane; wd < w1; wd += 64) {
 					const uint32_t v = B.seq4[wd];
+					t_amb |= v & 0xccccccccu;                            // a code above 3 somewhere in these eight bases (or next to the region)
 #pragma unroll
 					for (int b8 = 0; b8 < 8; ++b8) {
 						const int64_t idx = wd * 8 + b8 - o0;
 						if (idx >= 0 && idx < tl) s_t[idx] = (uint8_t)(v >> (b8 * 4) & 15u);
 					}
 				}
+				acgt_only = !B.ambig[rd] && !__any(t_amb != 0);
 			}
 			c_order();
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1403,6 +1407,10 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 								const int dlt = -(B.gap_q + B.gap_e * len);
 								A += dlt, Bv = Bv + dlt > 0 ? Bv + dlt : 0;
 								MA = MA > A ? MA : A, MB = MB > Bv ? MB : Bv;
+								if (acgt_only) {                                   // nothing to count in its bases: no turn for them
+									if (op == 1) qo += len; else to += len;
+									pos = len;
+								}
 							}
 						}
 					}
