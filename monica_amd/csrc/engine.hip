@@ -46,6 +46,7 @@ void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work,
                     long long big_state, long long big_p, long long big_cig, long long huge_state, long long huge_p, long long huge_cig, hipStream_t st);
 size_t dp_align_ws_bytes(long long state_max, long long p_max, long long cig_max);
 int dp_align_prepare(int lds_bytes);
+int dp_stitch_prepare();
 void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max, long long p_max, long long cig_max,
                      int lds_state, int lds_p, int lds_cig, int big_pass, hipStream_t st);
 void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_list, int max_read_len, int n_wg, hipStream_t st);
@@ -629,6 +630,7 @@ extern "C" int mnc_engine_create(mnc_index *idx, int device, mnc_engine **out)
 	if (!rc) rc = e->cls_count.ensure((MAX_CHAIN_CLASSES + 1) * 4 + 64);
 	if (!rc) rc = chain_tail_prepare(chain_tail_lds_bytes(CHAIN_CLASSES.nm[CHAIN_CLASSES.n - 1]));
 	if (!rc) rc = expand_sort_prepare(CHAIN_CLASSES.nm[CHAIN_CLASSES.n - 1]);
+	if (!rc) rc = dp_stitch_prepare();
 	if (!rc) {
 		he = hipMemcpy(e->gap_lut.p, gap.data(), GAP_LUT * 4, hipMemcpyHostToDevice);
 		if (he == hipSuccess) he = hipMemcpy(e->logf_lut.p, lg.data(), (size_t)e->logf_n * 4, hipMemcpyHostToDevice);

@@ -940,6 +940,7 @@ __device__ __forceinline__ void dpp_scan_maps(int &a, int &b)
 // region pool.  One wave per region; lane 0 does the sequential bookkeeping, all lanes the walks.
 constexpr int ST_CIG_MAX = 1024;                            // CIGAR words in LDS
 constexpr int ST_EV_MAX = 2048;                             // score events (one byte each) buffered for one scan
+constexpr int ST_EV_LONG = 8192, ST_LONG_Q = 61440;         // ... and in the launch for the regions of long reads; its longest query in LDS
 constexpr unsigned long long ST_POOL_CHUNK = 4096;           // words of the region CIGAR pool a wave reserves at a time
 constexpr int ST_EV_LIM = 127;                              // a gap that costs more is applied directly
 
@@ -950,14 +951,14 @@ __device__ __forceinline__ void append_op(uint32_t *c, int &n, uint32_t word)
 }
 
 __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work_list, int32_t *next_list, int seq_q_max, int seq_t_max,
-                                                    int size_class, int q_fit, int t_fit)
+                                                    int size_class, int q_fit, int t_fit, int ev_max)
 {
 	// LDS (dynamic: the sequences are sized for the batch's longest read, so that many regions share a CU):
 	// [joined CIGAR | score events | query codes | target codes]
 	extern __shared__ __align__(16) uint8_t st_smem[];
 	uint32_t *s_c = reinterpret_cast<uint32_t*>(st_smem);
 	int8_t *s_d = reinterpret_cast<int8_t*>(st_smem + ST_CIG_MAX * 4);
-	uint8_t *s_q = st_smem + ST_CIG_MAX * 4 + ST_EV_MAX, *s_t = s_q + seq_q_max;
+	uint8_t *s_q = st_smem + ST_CIG_MAX * 4 + ev_max, *s_t = s_q + seq_q_max;      // ev_max: a multiple of 16
 	const int lane = threadIdx.x;
 	const unsigned long long n_work = B.dp_ctr[9];
 	const bool chunked = n_work >= 4ull * gridDim.x;
@@ -1211,14 +1212,14 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 								if (sl == prev_len) odd = true;
 							}
 						}
-						if (k < ST_EV_MAX && sl <= ST_EV_LIM) s_d[k] = (int8_t)sl; else if (sl) odd = true;
+						if (k < ev_max && sl <= ST_EV_LIM) s_d[k] = (int8_t)sl; else if (sl) odd = true;
 					}
 				}
 				rare = __any(odd) != 0;
 				c_order();
 				if (!rare) {
 					for (int k = lane; k < n_c; k += 64) {
-						const int sl = k < ST_EV_MAX ? (int)s_d[k] : 0;
+						const int sl = k < ev_max ? (int)s_d[k] : 0;
 						if (sl > 0) { atomicSub(&C[k - 1], (uint32_t)sl << 4); atomicAdd(&C[k + 1], (uint32_t)sl << 4); }
 					}
 				}
@@ -1309,8 +1310,8 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 				const int len = (int)(C[k] >> 4);
 				if (op == 0) {
 					for (int pos = 0; pos < len;) {
-						if (ev == ST_EV_MAX) flush();
-						const int take = len - pos < ST_EV_MAX - ev ? len - pos : ST_EV_MAX - ev;
+						if (ev == ev_max) flush();
+						const int take = len - pos < ev_max - ev ? len - pos : ev_max - ev;
 						for (int i = lane; i < take; i += 64) {
 							const int cq = Q(qoff + pos + i), ct = Tg(toff + pos + i);
 							int dlt;
@@ -1326,7 +1327,7 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 				} else {
 					for (int i = lane; i < len; i += 64) c_gamb += (op == 1 ? Q(qoff + i) : Tg(toff + i)) > 3;
 					blen += len;
-					if (ev == ST_EV_MAX) flush();
+					if (ev == ev_max) flush();
 					const int cost = B.gap_q + B.gap_e * len;
 					if (cost > ST_EV_LIM) {                               // does not fit an event: applied directly
 						flush();
@@ -1482,8 +1483,8 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 				const int iq = dpp_incl_add(dq), it = dpp_incl_add(dt), ie = dpp_incl_add(dev);
 				const int tot_ev = __builtin_amdgcn_readlane(ie, 63);
 				const int big = dpp_max_all(k < n_c ? (op == 0 ? len : cost > ST_EV_LIM ? 1 << 20 : 0) : 0);
-				if (big > 256 || tot_ev > ST_EV_MAX) { seq_ops(k0, k1); continue; }
-				if (ev + tot_ev > ST_EV_MAX) flush();
+				if (big > 256 || tot_ev > ev_max) { seq_ops(k0, k1); continue; }
+				if (ev + tot_ev > ev_max) flush();
 				if (k < n_c) {
 					const int qo = qoff + iq - dq, to = toff + it - dt, eo = ev + ie - dev;
 					if (op == 0) {
@@ -1567,26 +1568,34 @@ void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max,
 void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_list, int max_read_len, int n_wg, hipStream_t st)
 {
 	// query codes of a whole read; a region's target span is longer by its deletions: a quarter more
-	auto dims = [](int len, int &q_max, int &t_max) {
-		q_max = (len + 63) / 64 * 64, t_max = (len + len / 4 + 127) / 64 * 64;
-		if (q_max > 16384) q_max = 16384;
-		if (t_max > 20480) t_max = 20480;
+	auto dims = [](int len, int q_cap, int &q_max, int &t_max) {
+		q_max = (len + 63) / 64 * 64;
+		if (q_max > q_cap) q_max = q_cap;
 		if (q_max < 256) q_max = 256;
-		if (t_max < 320) t_max = 320;
+		t_max = (q_max + q_max / 4 + 127) / 64 * 64;
 	};
-	auto launch = [&](int q_max, int t_max, int size_class, int q_fit, int t_fit, int wgs) {
-		const size_t lds = (size_t)ST_CIG_MAX * 4 + ST_EV_MAX + q_max + t_max + 16;   // + 16: the stitch reads whole words, up to eleven bytes past a region's last base
-		hipLaunchKernelGGL(mnc_dp_stitch, dim3(wgs), dim3(64), lds, st, B, work_list, next_list, q_max, t_max, size_class, q_fit, t_fit);
+	auto launch = [&](int q_max, int t_max, int size_class, int q_fit, int t_fit, int ev_max, int wgs) {
+		const size_t lds = (size_t)ST_CIG_MAX * 4 + ev_max + q_max + t_max + 16;   // + 16: the stitch reads whole words, up to eleven bytes past a region's last base
+		hipLaunchKernelGGL(mnc_dp_stitch, dim3(wgs), dim3(64), lds, st, B, work_list, next_list, q_max, t_max, size_class, q_fit, t_fit, ev_max);
 	};
-	int q_max, t_max;
-	dims(max_read_len, q_max, t_max);
 	constexpr int ST_SMALL = 6144;                   // up to here one launch: nine regions per CU (17.6 .. 20 KB of LDS each)
-	if (q_max <= ST_SMALL) { launch(q_max, t_max, 0, 0, 0, n_wg); return; }
-	// long reads in the batch: the regions that fit the small layout keep its occupancy, the rest get the LDS they need
+	int q_max, t_max;
+	dims(max_read_len, ST_LONG_Q, q_max, t_max);
+	if (q_max <= ST_SMALL) { launch(q_max, t_max, 0, 0, 0, ST_EV_MAX, n_wg); return; }
+	// long reads in the batch: the regions that fit the small layout keep its occupancy; the rest get the LDS they need (up to
+	// 60 k query bases: one region per CU then; beyond that the bases are read in place) and room for one slide per CIGAR
+	// operation of mm_fix_cigar's parallel form (a 60 kb read with 10 % errors has ~8 000 of them)
 	int q_s, t_s;
-	dims(ST_SMALL, q_s, t_s);
-	launch(q_s, t_s, 1, q_s, t_s, n_wg);
-	launch(q_max, t_max, 2, q_s, t_s, n_wg / 4);
+	dims(ST_SMALL, ST_SMALL, q_s, t_s);
+	launch(q_s, t_s, 1, q_s, t_s, ST_EV_MAX, n_wg);
+	launch(q_max, t_max, 2, q_s, t_s, ST_EV_LONG, n_wg / 4);
+}
+int dp_stitch_prepare()
+{
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_stitch), hipFuncAttributeMaxDynamicSharedMemorySize,
+	                                   ST_CIG_MAX * 4 + ST_EV_LONG + ST_LONG_Q + (ST_LONG_Q + ST_LONG_Q / 4 + 127) / 64 * 64 + 16);
+	if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return MNC_ERR_HIP; }
+	return MNC_OK;
 }
 
 } // namespace mnc
