@@ -40,6 +40,8 @@ void launch_regions(const Batch &B, void *regx, uint64_t *k64a, uint64_t *k64b, 
 void launch_regions_post(const Batch &B, mnc_reg_t *work, void *regx, uint64_t *k64a, int32_t *tmp, mnc_hit_t *gated, hipStream_t st);
 // base-level alignment stage (k_align.hip)
 void launch_dp_gather(const Batch &B, hipStream_t st);
+int dp_gather_long_prepare(int lds_anchors);
+void launch_dp_gather_long(const Batch &B, const uint32_t *lists, const ClassSpans &spans, int lds_anchors, hipStream_t st);
 void launch_dp_round(const Batch &B, int first, hipStream_t st);
 void launch_dp_round_end(const Batch &B, hipStream_t st);
 void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work, int state_max, long long p_max, int cig_max,
@@ -631,6 +633,7 @@ extern "C" int mnc_engine_create(mnc_index *idx, int device, mnc_engine **out)
 	if (!rc) rc = chain_tail_prepare(chain_tail_lds_bytes(CHAIN_CLASSES.nm[CHAIN_CLASSES.n - 1]));
 	if (!rc) rc = expand_sort_prepare(CHAIN_CLASSES.nm[CHAIN_CLASSES.n - 1]);
 	if (!rc) rc = dp_stitch_prepare();
+	if (!rc) rc = dp_gather_long_prepare(CHAIN_CLASSES.nm[CHAIN_CLASSES.n - 1]);
 	if (!rc) {
 		he = hipMemcpy(e->gap_lut.p, gap.data(), GAP_LUT * 4, hipMemcpyHostToDevice);
 		if (he == hipSuccess) he = hipMemcpy(e->logf_lut.p, lg.data(), (size_t)e->logf_n * 4, hipMemcpyHostToDevice);
@@ -1023,7 +1026,17 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 		B.next_list = lists[0];                          // the regions kernel files every kept region here
 		HIP_TRY(hipMemsetAsync(e->dp_ctr.p, 0, 64 * 8, st));
 		{ StageTimer t(e, MNC_STAGE_REGIONS);   launch_regions(B, e->regx.p, e->k64a.as<uint64_t>(), e->k64b.as<uint64_t>(), e->gated.as<mnc_hit_t>(), st); }
-		{ StageTimer t(e, MNC_STAGE_DP_PLAN);   launch_dp_gather(B, st); }
+		{
+			StageTimer t(e, MNC_STAGE_DP_PLAN);
+			launch_dp_gather(B, st);
+			// reads of the size classes above 1024 anchors (and beyond the classes): a wave each
+			int c0 = 0;
+			while (c0 < CHAIN_CLASSES.n && CHAIN_CLASSES.nm[c0] <= 1024) ++c0;
+			ClassSpans sp;
+			sp.n = CHAIN_CLASSES.n + 1 - c0, sp.stride = (uint32_t)n_reads, sp.start[0] = 0;
+			for (int c = c0; c <= CHAIN_CLASSES.n; ++c) sp.start[c - c0 + 1] = sp.start[c - c0] + cls_count[c];
+			launch_dp_gather_long(B, e->cls_list.as<uint32_t>() + (size_t)c0 * n_reads, sp, CHAIN_CLASSES.nm[CHAIN_CLASSES.n - 1], st);
+		}
 		unsigned max_work = (unsigned)ns;
 		for (int round = 0;; ++round) {
 			const int32_t *work = lists[round & 1];

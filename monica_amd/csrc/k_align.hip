@@ -59,12 +59,15 @@ __device__ __forceinline__ int tcode(const Batch &B, int64_t contig_off, int pos
 }
 
 // ================================================================ gather: chained anchors, squeezed
+constexpr int GATHER_LONG = 1024;       // reads with more anchors: mnc_dp_gather_long
+
 __global__ __launch_bounds__(64) void mnc_dp_gather(Batch B)
 {
 	const uint32_t rd = blockIdx.x * blockDim.x + threadIdx.x;
 	if (rd >= B.n_reads) return;
 	const int n = B.n_chain[rd];
 	if (n <= 0) return;
+	if (B.an_off[rd + 1] - B.an_off[rd] > GATHER_LONG) return;
 	const int64_t a_off = B.an_off[rd], slot = a_off / 3;
 	const ChainRec *ch = B.chains_tmp + slot;
 	const Anchor *a = B.a + a_off;
@@ -84,24 +87,77 @@ __global__ __launch_bounds__(64) void mnc_dp_gather(Batch B)
 	}
 }
 
+// The same for a long read (a 60 kb read has ~4 700 chained anchors: one lane following p[] through HBM is 4 ms of
+// round trips): one wave per read, p[] in LDS, lane 0 walks a chain there and leaves the indices, all lanes copy.
+// `lists` / `spans`: the reads of the chain stage's size classes above GATHER_LONG anchors (and of the class beyond
+// the largest, whose p[] does not fit LDS: those walk in HBM as before).
+__global__ __launch_bounds__(64) void mnc_dp_gather_long(Batch B, const uint32_t *lists, ClassSpans spans, int lds_anchors)
+{
+	extern __shared__ int32_t gl_smem[];
+	if (blockIdx.x >= spans.start[spans.n]) return;
+	int cls = 0;
+	while (blockIdx.x >= spans.start[cls + 1]) ++cls;
+	const uint32_t rd = lists[(size_t)cls * spans.stride + (blockIdx.x - spans.start[cls])];
+	const int lane = threadIdx.x;
+	const int n = B.n_chain[rd];
+	if (n <= 0) return;
+	const int64_t a_off = B.an_off[rd], slot = a_off / 3;
+	const int n_an = (int)(B.an_off[rd + 1] - a_off);
+	if (n_an <= GATHER_LONG) return;                         // mnc_dp_gather took it
+	const ChainRec *ch = B.chains_tmp + slot;
+	const Anchor *a = B.a + a_off;
+	const int32_t *p = B.p + a_off;
+	Anchor *ca = B.ca + a_off;
+	const bool in_lds = n_an <= lds_anchors;
+	int32_t *s_p = gl_smem, *s_j = gl_smem + lds_anchors;
+	if (in_lds) for (int i = lane; i < n_an; i += 64) s_p[i] = p[i];
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	for (int c = 0; c < n; ++c) {
+		const int d = B.chain_dst[slot + c];
+		if (d < 0) continue;
+		const int dst = d & ((1 << 30) - 1), cnt = ch[c].cnt;
+		if (in_lds) {
+			if (lane == 0) {
+				int j = ch[c].as;
+				for (int k = cnt - 1; k >= 0; --k) s_j[k] = j, j = s_p[j];
+			}
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+			for (int k = lane; k < cnt; k += 64) {
+				Anchor x = a[s_j[k]];
+				if (k == 0 && (d >> 30 & 1)) x.y |= SEED_LONG_JOIN;
+				ca[dst + k] = x;
+			}
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		} else if (lane == 0) {
+			int j = ch[c].as;
+			for (int k = cnt - 1; k >= 0; --k) {
+				Anchor x = a[j];
+				if (k == 0 && (d >> 30 & 1)) x.y |= SEED_LONG_JOIN;
+				ca[dst + k] = x;
+				j = p[j];
+			}
+		}
+	}
+}
+
 // ================================================================ plan: one region (mm_align1 up to the kernel calls)
 __device__ __forceinline__ int seed_gap(const Anchor *a, int i)
 {
 	return ((int32_t)a[i].y - (int32_t)a[i - 1].y) - ((int32_t)a[i].x - (int32_t)a[i - 1].x);
 }
 
-// (four anchors per turn, loaded before any is used: one lane walks a region's anchors alone, and a turn's time is its
+// (eight anchors per turn, loaded before any is used: one lane walks a region's anchors alone, and a turn's time is its
 // loads' round trip)
 __device__ int collect_long_gaps(const Anchor *a, int cnt1, int min_gap, int32_t *K)
 {
 	int n = 0;
 	int32_t px = (int32_t)a[0].x, py = (int32_t)a[0].y;
-	for (int i = 1; i < cnt1; i += 4) {
-		int32_t x[4], y[4];
+	for (int i = 1; i < cnt1; i += 8) {
+		int32_t x[8], y[8];
 #pragma unroll
-		for (int u = 0; u < 4; ++u) { const int ii = i + u < cnt1 ? i + u : cnt1 - 1; x[u] = (int32_t)a[ii].x, y[u] = (int32_t)a[ii].y; }
+		for (int u = 0; u < 8; ++u) { const int ii = i + u < cnt1 ? i + u : cnt1 - 1; x[u] = (int32_t)a[ii].x, y[u] = (int32_t)a[ii].y; }
 #pragma unroll
-		for (int u = 0; u < 4; ++u) {
+		for (int u = 0; u < 8; ++u) {
 			if (i + u < cnt1) {
 				const int gap = (y[u] - py) - (x[u] - px);
 				if (gap < -min_gap || gap > min_gap) K[n++] = i + u;
@@ -284,12 +340,12 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 	int n_fill = 0;
 	{
 		int prs = rs, pqs = qs;
-		for (int i0 = 1; i0 < cnt1; i0 += 4) {
-			uint64_t bx[4], by[4];
+		for (int i0 = 1; i0 < cnt1; i0 += 8) {
+			uint64_t bx[8], by[8];
 #pragma unroll
-			for (int u = 0; u < 4; ++u) { const int ii = i0 + u < cnt1 ? i0 + u : cnt1 - 1; bx[u] = b[ii].x, by[u] = b[ii].y; }
+			for (int u = 0; u < 8; ++u) { const int ii = i0 + u < cnt1 ? i0 + u : cnt1 - 1; bx[u] = b[ii].x, by[u] = b[ii].y; }
 #pragma unroll
-			for (int u = 0; u < 4; ++u) {
+			for (int u = 0; u < 8; ++u) {
 				const int i = i0 + u;
 				if (i >= cnt1) break;
 				if ((by[u] & (SEED_IGNORE | SEED_TANDEM)) && i != cnt1 - 1) continue;
@@ -310,6 +366,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 			d.n_seg = 0, d.has_left = d.has_right = 0;
 		} else {
 			Seg *sg = B.segs + s0;
+			const bool k_ok = n_seg <= r.cnt;                        // the region's scratch: one int per anchor
 			int n_tier[20] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 			unsigned long long work[4] = { 0, 0, 0, 0 };             // anti-diagonals given to the banded tiers; steps x cells of the packed extensions
 			auto emit = [&](Seg g) {
@@ -405,6 +462,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 					if (all_lds) g.big = 8, ++n_tier[4];
 					else g.big = 20, ++n_tier[16];
 				}
+				if (k_ok) K[sg - (B.segs + s0)] = g.big;                // for the lists below (the scratch ints are free again)
 				*sg++ = g;
 			};
 			if (left) {
@@ -415,13 +473,15 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 				emit(g);
 			}
 			int prs = rs, pqs = qs;
-			for (int i0 = 1; i0 < cnt1; i0 += 4) {
-				uint64_t bx[4], by[4];
+			for (int i0 = 1; i0 < cnt1; i0 += 8) {
+				uint64_t bx[8], by[8];
 #pragma unroll
-				for (int u = 0; u < 4; ++u) { const int ii = i0 + u < cnt1 ? i0 + u : cnt1 - 1; bx[u] = b[ii].x, by[u] = b[ii].y; }
-				for (int u = 0; u < 4 && i0 + u < cnt1; ++u) {
+				for (int u = 0; u < 8; ++u) { const int ii = i0 + u < cnt1 ? i0 + u : cnt1 - 1; bx[u] = b[ii].x, by[u] = b[ii].y; }
+				for (int u = 0; u < 8 && i0 + u < cnt1; ++u) {
 					const int i = i0 + u;
-					const uint64_t vx = u == 0 ? bx[0] : u == 1 ? bx[1] : u == 2 ? bx[2] : bx[3], vy = u == 0 ? by[0] : u == 1 ? by[1] : u == 2 ? by[2] : by[3];
+					uint64_t vx = bx[0], vy = by[0];
+#pragma unroll
+					for (int w8 = 1; w8 < 8; ++w8) if (u == w8) vx = bx[w8], vy = by[w8];
 					if ((vy & (SEED_IGNORE | SEED_TANDEM)) && i != cnt1 - 1) continue;
 					const int cre = (int32_t)vx - k2, cqe = (int32_t)vy - k2;
 					if (i == cnt1 - 1 || (vy & SEED_LONG_JOIN) || (cqe - pqs >= B.min_ksw_len && cre - prs >= B.min_ksw_len)) {
@@ -450,7 +510,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 				             : tier == 0 ? B.fill_list1 : tier == 1 ? B.fill_list2 : tier == 2 ? B.ext_list1 : tier == 3 ? B.ext_list2 : tier == 4 ? B.gen_list
 				             : tier == 5 ? B.fill_list3 : tier == 6 ? B.ext_list3 : B.ext_list4;
 				for (int k = 0; k < n_seg; ++k)
-					if (B.segs[s0 + k].big == 4 + tier) lst[fi++] = (int32_t)(s0 + k);
+					if ((k_ok ? K[k] : B.segs[s0 + k].big) == 4 + tier) lst[fi++] = (int32_t)(s0 + k);
 			}
 		}
 	}
@@ -1543,6 +1603,17 @@ __global__ void mnc_dp_round_end(Batch B)
 void launch_dp_gather(const Batch &B, hipStream_t st)
 {
 	if (B.n_reads) hipLaunchKernelGGL(mnc_dp_gather, dim3((B.n_reads + 63) / 64), dim3(64), 0, st, B);
+}
+int dp_gather_long_prepare(int lds_anchors)
+{
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_gather_long), hipFuncAttributeMaxDynamicSharedMemorySize, lds_anchors * 8);
+	if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return MNC_ERR_HIP; }
+	return MNC_OK;
+}
+void launch_dp_gather_long(const Batch &B, const uint32_t *lists, const ClassSpans &spans, int lds_anchors, hipStream_t st)
+{
+	const uint32_t count = spans.start[spans.n];
+	if (count) hipLaunchKernelGGL(mnc_dp_gather_long, dim3(count), dim3(64), (size_t)lds_anchors * 8, st, B, lists, spans, lds_anchors);
 }
 void launch_dp_round(const Batch &B, int first, hipStream_t st) { hipLaunchKernelGGL(mnc_dp_round, dim3(1), dim3(1), 0, st, B, first); }
 void launch_dp_round_end(const Batch &B, hipStream_t st) { hipLaunchKernelGGL(mnc_dp_round_end, dim3(1), dim3(1), 0, st, B); }
