@@ -304,22 +304,23 @@ __global__ __launch_bounds__(64) void mnc_dp_fill(Batch B, const int32_t *list, 
 			}
 			fill_order();
 		}
-		// ---- mm_test_zdrop: a walk over the CIGAR (stored last operation first).  The drop it looks for
-		// is at most the sum of all the negative steps of the walk -- b per mismatch, q + e len per gap --
-		// and the number of mismatches follows from the score: S = a (M columns - mm) - b mm - (two-piece
-		// gap costs).  Below the threshold the answer is 0 without touching the sequences (an ambiguous
-		// base scores -1 and loosens the count: (a + 1) x <= a M - S - G2 for x columns that do not match).
+		// ---- mm_test_zdrop: a walk over the CIGAR (stored last operation first).  The drop it looks for, over any
+		// stretch of the walk, is (gap costs q + e len) - a (M columns) of the stretch + what its columns that do not
+		// match cost against matches (a + b per mismatch, a + 1 per ambiguous base).  The first part is at most the
+		// largest sum over contiguous operations of (gap: + q + e len, M run: - a len) -- one pass, no sequences --
+		// and the second at most its total over the whole walk, which follows from the score:
+		// a (M columns) - S - (two-piece gap costs).  Below the threshold the answer is 0 without touching the bases.
 		bool walk = leader && ok && !to_next && !to_fb;
 		if (walk) {
-			int mcols = 0, g1 = 0, g2 = 0;
+			int mcols = 0, g2 = 0, kd = 0, kbest = 0;
 			for (int k = 0; k < n_c; ++k) {
 				const uint32_t op = s_cg[sg][k] & 0xf;
 				const int len = (int)(s_cg[sg][k] >> 4);
-				if (op == 0) mcols += len;
-				else g1 += q + e * len, g2 += fill_gap(len, q, e, q2, e2);
+				if (op == 0) mcols += len, kd = kd - a * len > 0 ? kd - a * len : 0;
+				else g2 += fill_gap(len, q, e, q2, e2), kd += q + e * len, kbest = kbest > kd ? kbest : kd;
 			}
-			const int lost = a * mcols - S - g2;                   // >= (a + 1) per column that does not match
-			const int neg = (-bmis) * (lost / (a + 1)) + g1;
+			const int lost = a * mcols - S - g2;                   // what the columns that do not match cost against matches
+			const int neg = kbest + lost;
 			if (neg <= (B.zdrop_inv < B.zdrop ? B.zdrop_inv : B.zdrop)) walk = false;
 		}
 		if (walk) {
@@ -640,7 +641,7 @@ __global__ __launch_bounds__(64) void mnc_dp_fillp(Batch B, const int32_t *list,
 		int n_c = 0;
 		{
 			const uint8_t *pu = p_wave + (size_t)(lane / SEGS) * FILLP_PASS_BYTES + (lane % SEGS) * LANES * 32;
-			int bi = n - 1, bj = m - 1, state = 0, cid = -1, mcols = 0, g1 = 0, g2 = 0;
+			int bi = n - 1, bj = m - 1, state = 0, cid = -1, mcols = 0, g2 = 0, kd = 0, kbest = 0;   // kd / kbest: see mnc_dp_fill's mm_test_zdrop
 			uint32_t cur = 0;
 			bool walking = state_w == 1;
 			while (walking && bi >= 0 && bj >= 0) {
@@ -666,7 +667,8 @@ __global__ __launch_bounds__(64) void mnc_dp_fillp(Batch B, const int32_t *list,
 					if (cur != 0) {
 						if (n_c >= FILL_CIG_MAX - 4) { state_w = 3; walking = false; break; }   // more operations than the scratch holds
 						const int len = (int)(cur >> 4);
-						if ((cur & 0xf) == 0) mcols += len; else g1 += q + e * len, g2 += fill_gap(len, q, e, q2, e2);
+						if ((cur & 0xf) == 0) mcols += len, kd = kd - a * len > 0 ? kd - a * len : 0;
+						else g2 += fill_gap(len, q, e, q2, e2), kd += q + e * len, kbest = kbest > kd ? kbest : kd;
 						cg[n_c++] = cur;
 					}
 					cur = 1u << 4 | op;
@@ -675,17 +677,18 @@ __global__ __launch_bounds__(64) void mnc_dp_fillp(Batch B, const int32_t *list,
 			if (walking) {
 				auto push = [&](uint32_t w) {
 					const int len = (int)(w >> 4);
-					if ((w & 0xf) == 0) mcols += len; else g1 += q + e * len, g2 += fill_gap(len, q, e, q2, e2);
+					if ((w & 0xf) == 0) mcols += len, kd = kd - a * len > 0 ? kd - a * len : 0;
+					else g2 += fill_gap(len, q, e, q2, e2), kd += q + e * len, kbest = kbest > kd ? kbest : kd;
 					cg[n_c++] = w;
 				};
 				if (bi >= 0) { if (cur != 0 && (cur & 0xf) == 2) cur += (uint32_t)(bi + 1) << 4; else { if (cur != 0) push(cur); cur = (uint32_t)(bi + 1) << 4 | 2; } }
 				if (bj >= 0) { if (cur != 0 && (cur & 0xf) == 1) cur += (uint32_t)(bj + 1) << 4; else { if (cur != 0) push(cur); cur = (uint32_t)(bj + 1) << 4 | 1; } }
 				if (cur != 0) push(cur);
-				// mm_test_zdrop: the drop it looks for is at most the sum of the negative steps of the walk -- b per
-				// mismatch, q + e len per gap -- and the number of mismatches follows from the score:
-				// S = a (M columns - mm) - b mm - (two-piece gap costs).  Above the threshold: the literal kernel's
+				// mm_test_zdrop: the drop it looks for is at most (largest sum over contiguous operations of gap costs
+				// less a per M column) + (what all columns that do not match cost against matches, from the score); see
+				// mnc_dp_fill.  Above the threshold: the walk over the bases below
 				const int lost = a * mcols - S - g2;
-				const int neg = (-bmis) * (lost / (a - bmis)) + g1;
+				const int neg = kbest + lost;
 				if (neg > thr) state_w = 4;
 			}
 		}
