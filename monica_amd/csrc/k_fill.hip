@@ -642,7 +642,7 @@ __global__ __launch_bounds__(64) void mnc_dp_fillp(Batch B, const int32_t *list,
 		{
 			const uint8_t *pu = p_wave + (size_t)(lane / SEGS) * FILLP_PASS_BYTES + (lane % SEGS) * LANES * 32;
 			int bi = n - 1, bj = m - 1, state = 0, cid = -1, mcols = 0, g2 = 0, kd = 0, kbest = 0;   // kd / kbest: see mnc_dp_fill's mm_test_zdrop
-			uint32_t cur = 0;
+			uint32_t cur = 0, hm32 = 0;
 			bool walking = state_w == 1;
 			while (walking && bi >= 0 && bj >= 0) {
 				const int r = bi + bj, idx = bi - ((r + kmin + 1) >> 1);
@@ -653,6 +653,36 @@ __global__ __launch_bounds__(64) void mnc_dp_fillp(Batch B, const int32_t *list,
 					const uint4 v0 = src[0], v1 = src[1];
 					*reinterpret_cast<uint4*>(&s_chunk[lane][0]) = v0, *reinterpret_cast<uint4*>(&s_chunk[lane][16]) = v1;
 					cid = c;
+					// which of the chunk's 32 cells were won by the diagonal (tag 15: bit 3), as four 8-bit masks -- byte
+					// (row parity * 2 + cell) holds a bit per pair of rows: a run of matches is read off with one count
+					const uint32_t w8[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
+					hm32 = 0;
+#pragma unroll
+					for (int k = 0; k < 8; ++k) hm32 |= (w8[k] >> 3 & 0x01010101u) << k;
+				}
+				if (state == 0) {
+					// on the diagonal: the steps back along it stay in this lane's column, two rows apart -- all those the
+					// chunk still holds with the diagonal as their winner go in one turn (a 15-base match run: two turns)
+					const int rho = r & 15, bp = rho >> 1;
+					const uint32_t m8 = hm32 >> (8 * ((rho & 1) * 2 + (idx & 1))) & 0xffu;
+					const uint32_t zeros = ~m8 & ((2u << bp) - 1u);
+					int run = zeros ? bp - (31 - __clz((int)zeros)) : bp + 1;
+					const int lim = (bi < bj ? bi : bj) + 1;
+					run = run < lim ? run : lim;
+					if (run > 0) {
+						if (cur != 0 && (cur & 0xf) == 0) cur += (uint32_t)run << 4;
+						else {
+							if (cur != 0) {
+								if (n_c >= FILL_CIG_MAX - 4) { state_w = 3; walking = false; break; }
+								const int len = (int)(cur >> 4);
+								g2 += fill_gap(len, q, e, q2, e2), kd += q + e * len, kbest = kbest > kd ? kbest : kd;   // a gap: `cur` was not an M run
+								cg[n_c++] = cur;
+							}
+							cur = (uint32_t)run << 4;
+						}
+						bi -= run, bj -= run;
+						continue;
+					}
 				}
 				const uint32_t raw = s_chunk[lane][(r & 15) * 2 + (idx & 1)];
 				// bits 0-3: the winner's tag (H 15, E 7, F 3, E2 1, F2 0); bits 4-7: which gap states were opened here (fillp_opened)
