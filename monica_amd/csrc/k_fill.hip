@@ -497,7 +497,7 @@ template <int LANES>
 __global__ __launch_bounds__(64) void mnc_dp_fillp(Batch B, const int32_t *list, int ctr_n, int ctr_q, int32_t *next_list, int ctr_next,
                                                    int32_t *fb_list, int ctr_fb, uint8_t *p_all, uint32_t *cig_all)
 {
-	constexpr int SEGS = 64 / LANES, W = 2 * LANES, PAD = 2 * W, SEQ = FILL_MAX_LEN + 1 + 4 * W, NSEG = FILLP_G * SEGS;
+	constexpr int SEGS = 64 / LANES, W = 2 * LANES, PAD = 2 * W, SEQ = FILL_MAX_LEN + 1 + 4 * W;
 	__shared__ uint8_t s_t[SEGS][SEQ], s_q[SEGS][SEQ];        // bases at [PAD + i]; what lies around them feeds cells outside the matrix only
 	__shared__ __align__(16) uint8_t s_chunk[64][32];         // the walk: the 32 direction bytes a lane is reading from
 	__shared__ int32_t s_n[64], s_m[64], s_kmin[64], s_S[64], s_si[64], s_state[64];   // per segment of the group; state 0 none, 1 walk, 2 next tier, 3 literal kernel
@@ -1153,7 +1153,7 @@ __device__ __forceinline__ int pk_half(uint32_t v, int h) { return (int)(int16_t
 template <int LANES, int CPL, int RGT>
 __global__ __launch_bounds__(64) void mnc_dp_extp(Batch B, const int32_t *list, int ctr_n, int ctr_q, uint8_t *p_all, uint32_t *cig_all)
 {
-	constexpr int SEGS = 64 / LANES, WC = 2 * CPL * LANES, PAD = WC + 2, SEQ = PAD + EXTP_ROWS + 48, NSEG = EXTP_G * SEGS;
+	constexpr int SEGS = 64 / LANES, WC = 2 * CPL * LANES, PAD = WC + 2, SEQ = PAD + EXTP_ROWS + 48;
 	constexpr bool LIVE = SEGS > 1;
 	constexpr size_t PASS_BYTES = (size_t)FILLP_BLOCKS * 64 * 32 * CPL;
 	typedef ExtpTag<RGT> TG;
