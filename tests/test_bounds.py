@@ -113,3 +113,87 @@ def test_score_maps_compose_to_the_sequential_scan():
                 top = max(top, x_in + MA, MB)
             x_in = max(x_in + A, Bv)
         assert x_in == s and top == best
+
+
+# ---------------------------------------------------------------- the band proof of the gap-filling kernels
+def fill_band(n, m, cells):
+    d = n - m
+    b = (2 * cells - 2 - abs(d)) // 2
+    kmin = min(d, 0) - b
+    if kmin & 1:
+        kmin -= 1
+    return b, kmin, kmin + 2 * cells - 1
+
+
+def band_bound(n, m, kmin, kmax):
+    """csrc/k_fill.hip: dp_band_bound -- the best score of any global path that leaves the band of offsets kmin..kmax."""
+    d, U = n - m, -(1 << 28)
+    D0, I0 = kmax + 1, kmax + 1 - d
+    if n - D0 >= 0 and m - I0 >= 0:
+        U = max(U, A_ * (n - D0) - gap2(D0) - gap2(I0))
+    I0 = 1 - kmin
+    D0 = I0 + d
+    if m - I0 >= 0 and n - D0 >= 0:
+        U = max(U, A_ * (m - I0) - gap2(I0) - gap2(D0))
+    return U
+
+
+def global_score(t, q, lo=None, hi=None):
+    """Two-piece affine global alignment score (ksw2's recurrence without its band), optionally with the cells whose
+    offset i - j lies outside [lo, hi] forbidden."""
+    NEG = -(1 << 28)
+    n, m = len(t), len(q)
+    inside = (lambda i, j: True) if lo is None else (lambda i, j: lo <= i - j <= hi)
+    H = np.full((n + 1, m + 1), NEG, dtype=np.int64)
+    E1, E2, F1, F2 = H.copy(), H.copy(), H.copy(), H.copy()
+    H[0, 0] = 0
+    for i in range(n + 1):
+        for j in range(m + 1):
+            if i == 0 and j == 0:
+                continue
+            if i and j and not inside(i - 1, j - 1):
+                continue
+            if i == 0:
+                H[i, j] = -gap2(j)
+                continue
+            if j == 0:
+                H[i, j] = -gap2(i)
+                continue
+            E1[i, j] = max(E1[i - 1, j], H[i - 1, j] - Q_) - E_
+            E2[i, j] = max(E2[i - 1, j], H[i - 1, j] - Q2_) - E2_
+            F1[i, j] = max(F1[i, j - 1], H[i, j - 1] - Q_) - E_
+            F2[i, j] = max(F2[i, j - 1], H[i, j - 1] - Q2_) - E2_
+            H[i, j] = max(H[i - 1, j - 1] + (A_ if t[i - 1] == q[j - 1] else -B_), E1[i, j], E2[i, j], F1[i, j], F2[i, j])
+    return int(H[n, m])
+
+
+def test_a_banded_score_above_the_bound_is_the_full_matrix_score():
+    rng = np.random.default_rng(99)
+    proved = refused = 0
+    for _ in range(250):
+        n = int(rng.integers(12, 70))
+        t = rng.integers(0, 4, n)
+        q = list(t)
+        for _ in range(int(rng.integers(0, 8))):                        # a few substitutions and indels, sometimes a long one
+            k = int(rng.integers(0, len(q) + 1))
+            what = rng.random()
+            if what < 0.4 and k < len(q):
+                q[k] = int(rng.integers(0, 4))
+            elif what < 0.7:
+                q[k:k] = list(rng.integers(0, 4, int(rng.integers(1, 12 if rng.random() < 0.2 else 3))))
+            else:
+                del q[k:k + int(rng.integers(1, 12 if rng.random() < 0.2 else 3))]
+        m = len(q)
+        if m < 4:
+            continue
+        for cells in (4, 8, 16):
+            b, kmin, kmax = fill_band(n, m, cells)
+            if b < 1:
+                continue
+            S_band, U = global_score(t, q, kmin, kmax), band_bound(n, m, kmin, kmax)
+            if S_band > U:
+                assert S_band == global_score(t, q), (n, m, cells)
+                proved += 1
+            else:
+                refused += 1
+    assert proved > 100 and refused > 30
