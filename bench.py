@@ -238,6 +238,10 @@ def main():
                        "bound_note": "int16 pair arithmetic on the vector ALU: the roof is the VALU issue rate (6.144e11 wave64 "
                                      "instructions/s, measured: profiles/r02_valu_issue_rates.json), not HBM (the kernel writes 1 byte per cell: "
                                      f"{cells / t_s / 1e9:.0f} GB/s) and not MFMA",
+                       # the same launch against the HBM roof, for comparison with the contract's "hbm" bound: algorithmic
+                       # bytes = one direction byte written per band cell
+                       "as_hbm": {"bound": "hbm", "achieved": round(cells / t_s / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                  "frac": round(cells / t_s / 1e9 / 8000.0, 4), "traffic": fill_traffic},
                        "kernels_one_at_a_time_ms": {k: round(v, 4) for k, v in dp_kernel_ms.items()}}
 
     # ---------------------------------------------------------------- roofline of the probe kernel
