@@ -455,6 +455,7 @@ static int load_mmi(FILE *f, const char *path, int64_t file_size, mnc_index **ou
 		std::vector<std::pair<uint64_t, uint64_t>> pairs;
 		std::vector<uint64_t> p, kv;
 		const int64_t rest_min = (total + 7) / 8 * 4;
+		if (file_size > rest_min) pairs.reserve((size_t)((file_size - rest_min) / 8));      // every occurrence takes at least 8 bytes of the file
 		for (uint64_t bi = 0; bi < (1ull << h.b) && !rc; ++bi) {
 			int32_t n;
 			uint32_t size;
