@@ -192,7 +192,9 @@ int mnc_engine_set_debug(mnc_engine *eng, int mode);      /* test switches, a bi
                                                              timers), bits 8-15 a tuning value for the tier choice,
                                                              0x20000 / 0x40000 / 0x80000 / 0x100000 without the packed
                                                              extension / packed gap-filling / long-gap / long-extension
-                                                             kernels (their calls go to the next kernel in line) */
+                                                             kernels (their calls go to the next kernel in line),
+                                                             0x200000 the stitch kernel reads bases in place (its form
+                                                             for regions beyond its LDS) */
 /* accumulated since the last reset: ms[MNC_N_STAGES], launches[MNC_N_STAGES] */
 int mnc_engine_get_timings(mnc_engine *eng, double *ms, int64_t *launches, int reset);
 const char *mnc_stage_name(int stage);
