@@ -50,15 +50,22 @@ def parse():
     ap.add_argument("--contract", choices=["dp", "chain"], default="dp",
                     help="dp (default): minimap2's base-level alignment of every region, as mappy runs it for monica "
                          "(mapq / NM / mlen from the CIGAR); chain: stop after chaining (the kernels north_star lists)")
-    ap.add_argument("--mode", choices=["batch", "stream", "shard", "files"], default="batch",
+    ap.add_argument("--mode", choices=["batch", "stream", "shard", "files", "config3"], default="batch",
                     help="batch: the headline metric; stream: BASELINE config 5 (400 reads/s arrival, 1-s "
                          "micro-batches); shard: config 4 (index parts spread over the ranks, every part sees "
                          "all reads, summaries all-gathered and merged); files: the Python aligner API end to "
-                         "end on FASTQ files (parse, H2D, kernels, D2H, routed FASTQ output)")
+                         "end on FASTQ files (parse, H2D, kernels, D2H, routed FASTQ output); config3: the whole 10 M-read "
+                         "job of BASELINE config 3 (--total-reads, default 10 M there) split over the ranks, each rank's "
+                         "share generated in its HBM by ordinal and classified in blocks of --reads, ONE count all-reduce "
+                         "at the end of the job")
+    ap.add_argument("--block", type=int, default=100_000, help="reads per classify call in --mode shard")
     ap.add_argument("--parts", type=int, default=8, help="index parts in --mode shard")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                                                       "the N > 1 path on a box with fewer GPUs than ranks)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--collective", choices=["torch", "capi"], default="torch",
+                    help="who issues the count all-reduce: torch.distributed (default) or the library's own entry points "
+                         "(mnc_comm_* / mnc_allreduce_counts on an RCCL communicator made through the C-ABI, on the engine's stream)")
     ap.add_argument("--stream-seconds", type=int, default=1800)
     ap.add_argument("--stream-rate", type=int, default=400)
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "probe_traffic.json"),
@@ -101,6 +108,8 @@ def main():
     names, seqs = synth.genome_set(args.genomes, min_len=args.min_len, max_len=args.max_len)
     if args.mode == "shard":
         return shard_mode(args, names, seqs, rank, local_rank, world, dev)
+    if args.mode == "config3":
+        return config3_mode(args, names, seqs, rank, local_rank, world, dev)
     if args.mode == "files":
         return files_mode(args, names, seqs, local_rank)
     index = _capi.Index.from_seqs(names, seqs)
@@ -118,6 +127,18 @@ def main():
     if args.mode == "stream":
         return stream_mode(args, engine, index, seqs, synth)
 
+    comm = None
+    if args.collective == "capi":
+        # the communicator through the C-ABI alone: rank 0 makes the id, the other ranks get its 128 bytes
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(_capi.Comm.unique_id()), dtype=torch.uint8).clone()
+        if world > 1:
+            uid = uid.to(dev)
+            dist.broadcast(uid, 0)
+            uid = uid.cpu()
+        comm = _capi.Comm(uid.numpy().tobytes(), world, rank)
+
     d_bases = torch.from_numpy(bases).to(dev)
     d_off = torch.from_numpy(offsets).to(dev)
     d_assign = torch.empty(args.reads, dtype=torch.int32, device=dev)
@@ -133,8 +154,10 @@ def main():
         engine.classify_device(d_bases.data_ptr(), d_off.data_ptr(), args.reads, total_bases, args.read_len,
                                args.min_mapq, d_assign.data_ptr(), d_best.data_ptr(), d_nhits.data_ptr(),
                                d_counts.data_ptr())
+        if comm is not None:                   # on the engine's stream, behind the batch's last kernel
+            comm.allreduce_counts(d_counts.data_ptr(), n_genomes * 3, engine.stream)
         engine.sync()
-        if world > 1:
+        if world > 1 and comm is None:
             dist.all_reduce(d_counts)          # RCCL over xGMI: n_genomes*3 int64
 
     for _ in range(args.warmup):
@@ -379,6 +402,7 @@ def main():
                                f"mid_occ {info.mid_occ})",
                    "reads_per_gpu_per_step": args.reads, "read_len": args.read_len, "genomes": args.genomes,
                    "contract": "base-level alignment of every region (mappy's MM_F_CIGAR)" if args.contract == "dp" else "chain level",
+                   "collective": "mnc_allreduce_counts (C-ABI, RCCL communicator from mnc_comm_init_rank)" if comm is not None else "torch.distributed all_reduce (RCCL)",
                    "parallelism": f"read-sharded x{world}, index replicated, RCCL all-reduce of "
                                   f"{n_genomes * 3} int64 counts per step"},
         "roofline": roofline_dp if roofline_dp else roofline,
@@ -464,13 +488,20 @@ def shard_mode(args, names, seqs, rank, local_rank, world, dev):
     t_setup = time.time() - t0
     result = {}
 
+    # a classify call takes at most --block reads (its per-base scratch is ~40 B per base and every part has an
+    # engine of its own); the reads stay resident, a block is a slice of them
+    L = args.read_len
+    blocks = [(b0, min(n, b0 + args.block)) for b0 in range(0, n, args.block)]
+    d_off_blk = torch.arange(args.block + 1, dtype=torch.int64, device=dev) * L
+
     def step():
         local = []
         for lo, idx, eng in parts:
             torch.cuda.current_stream().synchronize()
-            eng.classify_device(d_bases.data_ptr(), d_off.data_ptr(), n, total_bases, args.read_len, args.min_mapq,
-                                d_assign.data_ptr(), d_best.data_ptr(), d_nhits.data_ptr(), 0)
-            eng.sync()
+            for b0, b1 in blocks:
+                eng.classify_device(d_bases.data_ptr() + b0 * L, d_off_blk.data_ptr(), b1 - b0, (b1 - b0) * L, L, args.min_mapq,
+                                    d_assign.data_ptr() + b0 * 4, d_best.data_ptr() + b0 * 16, d_nhits.data_ptr() + b0 * 4, 0)
+                eng.sync()
             local.append(mdist.shard_summary(d_assign, d_best, d_nhits, rid_offset=lo))
         stacked = torch.stack(local)                                  # [local parts, n, 5]
         if world > 1:
@@ -512,6 +543,91 @@ def shard_mode(args, names, seqs, rank, local_rank, world, dev):
             "mapped_reads": int((assign >= 0).sum()), "ambiguous_reads": int((assign == -2).sum()),
             "assigned_to_source_genome": round(float((assign[ok] == truth[ok]).mean()), 4),
             "setup_s": round(t_setup, 1)}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def config3_mode(args, names, seqs, rank, local_rank, world, dev):
+    """BASELINE config 3 as one job: --total-reads reads (10 M) vs the 20-genome index, the read ordinals split over
+    the ranks in contiguous shares (dist.shard_bounds), every share generated in its rank's HBM (50 GB at one GPU)
+    and resident when the clock starts, classified in blocks of --reads with on-device count accumulation, ONE
+    RCCL all-reduce of the count table at the end of the job (north_star; aligner.py:286-298 is the analogue).
+    A step = the whole job."""
+    import torch
+    import torch.distributed as dist
+    from monica_amd import _capi, synth
+    from monica_amd import dist as mdist
+
+    t0 = time.time()
+    total = args.total_reads if args.total_reads != 800_000 else 10_000_000
+    lo, hi = mdist.shard_bounds(total, rank, max(world, 1))
+    n, L, blk = hi - lo, args.read_len, args.reads
+    index = _capi.Index.from_seqs(names, seqs)
+    info = index.info()
+    engine = _capi.Engine(index, local_rank)
+    engine.set_contract(_capi.CONTRACT_DP if args.contract == "dp" else _capi.CONTRACT_CHAIN)
+    gen = synth.DeviceReads(seqs, dev)
+    d_bases = torch.empty(n * L, dtype=torch.uint8, device=dev)
+    d_truth = torch.empty(n, dtype=torch.int32, device=dev)
+    for b0 in range(0, n, 1_000_000):
+        b1 = min(n, b0 + 1_000_000)
+        gen.make(d_bases[b0 * L:], d_truth[b0:], b1 - b0, L, seed=synth.SEED_READS + 3, first=lo + b0)
+    torch.cuda.synchronize()
+    d_off = torch.arange(blk + 1, dtype=torch.int64, device=dev) * L
+    d_assign = torch.empty(n, dtype=torch.int32, device=dev)
+    d_best = torch.zeros(n * 4, dtype=torch.int32, device=dev)
+    n_genomes = info.n_genomes
+    d_counts = torch.zeros(n_genomes * 3, dtype=torch.int64, device=dev)
+    t_setup = time.time() - t0
+
+    def step():
+        d_counts.zero_()
+        torch.cuda.current_stream().synchronize()
+        for b0 in range(0, n, blk):
+            m = min(blk, n - b0)
+            engine.classify_device(d_bases.data_ptr() + b0 * L, d_off.data_ptr(), m, m * L, L, args.min_mapq,
+                                   d_assign.data_ptr() + b0 * 4, d_best.data_ptr() + b0 * 16, 0, d_counts.data_ptr())
+        engine.sync()
+        if world > 1:
+            dist.all_reduce(d_counts)                          # the job's one collective
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t1
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    assign, truth = d_assign.cpu().numpy(), d_truth.cpu().numpy()
+    counts = d_counts.cpu().numpy().reshape(-1, 3)
+    mapped = assign >= 0
+    local = torch.tensor([int(mapped.sum()), int((assign[mapped] == truth[mapped]).sum()), int((assign[truth < 0] != -1).sum())],
+                         dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(local)
+    if rank == 0:
+        mp, ok, bad = (int(x) for x in local.cpu())
+        print(json.dumps({
+            "metric": "reads/sec classified, 10 M-read job (BASELINE config 3)", "value": round(total * args.steps / elapsed, 1),
+            "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u32/u64 integer; int16 pairs in the alignment kernels", "data": "synthetic",
+            "config": {"workload": f"{total} synthetic {L} nt reads in all ({n} on rank 0, blocks of {blk}) vs {args.genomes}-genome "
+                                   f"minimizer index ({info.total_len} bp)", "contract": args.contract,
+                       "parallelism": f"read-sharded x{world}, index replicated, one RCCL all-reduce of {n_genomes * 3} int64 counts per job"},
+            "mapped_reads": mp, "counts_checksum": int(counts[:, 0].sum()), "counts_equal_mapped_reads": bool(int(counts[:, 0].sum()) == mp),
+            "assigned_to_source_genome": round(ok / max(mp, 1), 5), "random_reads_mapped": bad, "setup_s": round(t_setup, 1)}))
     if world > 1:
         dist.destroy_process_group()
 

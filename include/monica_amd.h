@@ -76,6 +76,10 @@ const char *mnc_last_error(void);          /* thread-local detail of the last fa
 /* ---------------------------------------------------------------- device */
 int mnc_device_count(int *n);              /* counts devices without initialising them */
 int mnc_device_name(int device, char *buf, size_t cap);
+/* free / total HBM of a device: what the host side sizes its cache of resident index parts against
+ * (the reference holds one part at a time, aligner.py:91-103; this library keeps parts resident
+ * between the passes of monica's loop as long as they fit) */
+int mnc_device_mem_info(int device, int64_t *free_bytes, int64_t *total_bytes);
 
 /* ---------------------------------------------------------------- index: build / load
  * mnc_index_build      <- mappy.Aligner(fn_idx_in=fasta(.gz), preset='map-ont', best_n=15,
@@ -120,6 +124,7 @@ int  mnc_engine_create(mnc_index *idx, int device, mnc_engine **out);
 int  mnc_engine_set_contract(mnc_engine *eng, int contract);
 void mnc_engine_destroy(mnc_engine *eng);
 void *mnc_engine_stream(mnc_engine *eng);                              /* hipStream_t */
+int  mnc_engine_device_bytes(mnc_engine *eng, int64_t *bytes);         /* HBM held by the engine's own batch buffers */
 
 /* ---------------------------------------------------------------- classify
  * mnc_classify_batch   <- the per-read loop body aligner.py:212-233 for one index part:
@@ -324,6 +329,15 @@ int mnc_synth_reads(int n_genomes, const char *const *genomes, const int64_t *le
                     uint64_t seed, int64_t first, int n_reads, int read_len,
                     int sub_e4, int ins_e4, int del_e4, int random_frac_e4,
                     char *out_bases, int32_t *out_truth);
+
+/* the same reads made on the device (one wave per read), byte for byte: d_genomes = the contigs
+ * concatenated (ASCII), d_g_off[n_genomes + 1] their starts; all pointers are device pointers, the
+ * launch is asynchronous on `stream` (a hipStream_t, NULL = the default stream).  BASELINE config 3's
+ * 10 M reads are 50 GB: they are generated where they are classified. */
+int mnc_synth_reads_device(int n_genomes, const uint8_t *d_genomes, const int64_t *d_g_off,
+                           uint64_t seed, int64_t first, int n_reads, int read_len,
+                           int sub_e4, int ins_e4, int del_e4, int random_frac_e4,
+                           uint8_t *d_out_bases, int32_t *d_out_truth, void *stream);
 
 const char *mnc_version(void);
 

@@ -38,11 +38,11 @@ CONTRACT_DP, CONTRACT_CHAIN = 0, 1
 
 # every symbol include/monica_amd.h declares (checked by tests/test_capi.py)
 EXPORTS = [
-    "mnc_strerror", "mnc_last_error", "mnc_device_count", "mnc_device_name",
+    "mnc_strerror", "mnc_last_error", "mnc_device_count", "mnc_device_name", "mnc_device_mem_info",
     "mnc_index_build", "mnc_index_build_mem", "mnc_index_save", "mnc_index_save_mmi", "mnc_index_load", "mnc_index_free",
     "mnc_index_info", "mnc_index_contig_name", "mnc_index_contig_len", "mnc_index_contig_genome",
     "mnc_index_genome_name", "mnc_index_genome_len", "mnc_index_dump", "mnc_index_set_mid_occ",
-    "mnc_engine_create", "mnc_engine_destroy", "mnc_engine_stream",
+    "mnc_engine_create", "mnc_engine_destroy", "mnc_engine_stream", "mnc_engine_device_bytes",
     "mnc_classify_batch", "mnc_classify_device", "mnc_engine_sync", "mnc_engine_fetch_hits",
     "mnc_counts", "mnc_best_hit",
     "mnc_engine_set_profiling", "mnc_engine_set_debug", "mnc_engine_set_contract", "mnc_index_set_host_tables", "mnc_engine_dump_tables",
@@ -52,7 +52,7 @@ EXPORTS = [
     "mnc_fastq_quals", "mnc_fastq_title", "mnc_fastq_route",
     "mnc_hitmap_create", "mnc_hitmap_load", "mnc_hitmap_save", "mnc_hitmap_free", "mnc_hitmap_size",
     "mnc_hitmap_update", "mnc_hitmap_n_names", "mnc_hitmap_name", "mnc_host_alloc", "mnc_host_free",
-    "mnc_synth_genome", "mnc_synth_diverge", "mnc_synth_reads", "mnc_version",
+    "mnc_synth_genome", "mnc_synth_diverge", "mnc_synth_reads", "mnc_synth_reads_device", "mnc_version",
 ]
 
 
@@ -101,6 +101,7 @@ def lib():
     sig("mnc_version", cp, [])
     sig("mnc_device_count", i32, [C.POINTER(i32)])
     sig("mnc_device_name", i32, [i32, cp, C.c_size_t])
+    sig("mnc_device_mem_info", i32, [i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)])
     sig("mnc_index_build", i32, [cp, cp, i32, i32, pp])
     sig("mnc_index_build_mem", i32, [i32, C.POINTER(cp), C.POINTER(cp), C.POINTER(i64), i32, i32, pp])
     sig("mnc_index_save", i32, [vp, cp])
@@ -118,6 +119,7 @@ def lib():
     sig("mnc_engine_create", i32, [vp, i32, pp])
     sig("mnc_engine_destroy", None, [vp])
     sig("mnc_engine_stream", vp, [vp])
+    sig("mnc_engine_device_bytes", i32, [vp, C.POINTER(C.c_int64)])
     sig("mnc_classify_batch", i32, [vp, vp, vp, u32, i32, vp, vp, vp])
     sig("mnc_classify_device", i32, [vp, vp, vp, u32, i64, i32, i32, vp, vp, vp, vp])
     sig("mnc_engine_sync", i32, [vp])
@@ -143,6 +145,7 @@ def lib():
     sig("mnc_synth_diverge", i32, [vp, i64, u64, i32, vp])
     sig("mnc_synth_reads", i32, [i32, C.POINTER(vp), C.POINTER(i64), u64, i64, i32, i32,
                                  i32, i32, i32, i32, vp, vp])
+    sig("mnc_synth_reads_device", i32, [i32, vp, vp, u64, i64, i32, i32, i32, i32, i32, i32, vp, vp, vp])
     sig("mnc_fastq_open", i32, [cp, pp])
     sig("mnc_fastq_close", None, [vp])
     sig("mnc_fastq_next", i32, [vp, u32, u64, C.POINTER(u32)])
@@ -226,6 +229,13 @@ def device_count():
     n = C.c_int(0)
     check(lib().mnc_device_count(C.byref(n)))
     return n.value
+
+
+def device_mem_info(device=0):
+    """(free, total) HBM bytes of a device."""
+    f, t = C.c_int64(0), C.c_int64(0)
+    check(lib().mnc_device_mem_info(device, C.byref(f), C.byref(t)))
+    return f.value, t.value
 
 
 # ---------------------------------------------------------------------------------- index
@@ -332,6 +342,12 @@ class Engine:
     @property
     def stream(self):
         return lib().mnc_engine_stream(self._h)
+
+    def device_bytes(self):
+        """HBM held by this engine's own batch buffers."""
+        n = C.c_int64(0)
+        check(lib().mnc_engine_device_bytes(self._h, C.byref(n)))
+        return n.value
 
     def classify(self, bases, offsets, min_mapq=60):
         """Host buffers in, host arrays out: (assign, best, nhits)."""

@@ -176,7 +176,13 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
         if not reader.next(BATCH_READS, BATCH_BASES):
             return None
         t1 = time.perf_counter()
-        assign, best, nhits = engine.classify_ptr(reader.bases_ptr, reader.offsets_ptr, reader.n, mapping_quality)
+        try:
+            assign, best, nhits = engine.classify_ptr(reader.bases_ptr, reader.offsets_ptr, reader.n, mapping_quality)
+        except _capi.MncError as err:                     # HBM exhausted beside the cached parts: free what is idle, once
+            if err.code != _capi.ERR_NOMEM:
+                raise
+            mappy.release_idle(index.index)
+            assign, best, nhits = engine.classify_ptr(reader.bases_ptr, reader.offsets_ptr, reader.n, mapping_quality)
         t2 = time.perf_counter()
         state = sample_hits.update(reader, index.index, assign, best, nhits)
         clock["parse"] += t1 - t0

@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 #include <cstring>
 #include <mutex>
+#include <string>
 
 #include "common.h"
 
@@ -30,6 +31,7 @@ struct Rccl {
 	int (*AllGather)(const void*, void*, size_t, int, void*, void*) = nullptr;
 	const char *(*GetErrorString)(int) = nullptr;
 	bool ok = false;
+	std::string why;                                       // what dlopen / dlsym said when it failed
 };
 
 Rccl &rccl()
@@ -40,8 +42,12 @@ Rccl &rccl()
 		for (const char *name : { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so" }) {
 			r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
 			if (r.lib) break;
+			const char *err = dlerror();                       // read once, here: a second call returns NULL
+			if (!r.why.empty()) r.why += "; ";
+			r.why += err ? err : name;
 		}
 		if (!r.lib) return;
+		r.why.clear();
 		r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
 		r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
 		r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
@@ -49,6 +55,7 @@ Rccl &rccl()
 		r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
 		r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
 		r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.AllGather;
+		if (!r.ok) r.why = "a symbol of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce / ncclAllGather is missing";
 	});
 	return r;
 }
@@ -56,7 +63,7 @@ Rccl &rccl()
 int need_rccl()
 {
 	if (rccl().ok) return MNC_OK;
-	mnc::set_error("librccl.so cannot be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+	mnc::set_error("librccl.so cannot be used: %s", rccl().why.c_str());
 	return MNC_ERR_NODEVICE;
 }
 

@@ -49,6 +49,7 @@ void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work,
 size_t dp_align_ws_bytes(long long state_max, long long p_max, long long cig_max);
 int dp_align_prepare(int lds_bytes);
 int dp_stitch_prepare();
+size_t dp_stitch_pool_slack(int n_wg);
 void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max, long long p_max, long long cig_max,
                      int lds_state, int lds_p, int lds_cig, int big_pass, hipStream_t st);
 void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_list, int max_read_len, int n_wg, hipStream_t st);
@@ -65,7 +66,7 @@ void launch_dp_extp(const Batch &B, int cells, int rgt, const int32_t *list, int
 void launch_dp_fill(const Batch &B, int lanes, const int32_t *list, int ctr_n, int ctr_q, int32_t *next_list, int ctr_next,
                     int32_t *fb_list, int ctr_fb, uint8_t *p_all, uint32_t *cig_all, int n_wg, hipStream_t st);
 void launch_dp_ext(const Batch &B, int lanes, const int32_t *list, int ctr_n, int ctr_q, int32_t *fb_list, int ctr_fb, uint8_t *p_all, int n_wg, hipStream_t st);
-constexpr int DP_WG_FILL = 256 * 16, DP_WG_EXT = 256 * 8;
+constexpr int DP_WG_FILL = 256 * 16, DP_WG_EXT = 256 * 8, DP_WG_STITCH = 4096;
 // workspace classes of the alignment kernel: a normal slot per workgroup, a few large ones
 constexpr int DP_LDS_BYTES = 16 * 1024;
 constexpr int DP_LDS0_STATE = 4 * 1024, DP_LDS0_P = 10 * 1024, DP_LDS0_CIG = 256;   // pass 0: 15 KB per workgroup
@@ -547,6 +548,17 @@ extern "C" int mnc_device_count(int *n)
 	return MNC_OK;
 }
 
+extern "C" int mnc_device_mem_info(int device, int64_t *free_bytes, int64_t *total_bytes)
+{
+	if (int rc = check_device(device)) return rc;
+	HIP_TRY(hipSetDevice(device));
+	size_t f = 0, t = 0;
+	HIP_TRY(hipMemGetInfo(&f, &t));
+	if (free_bytes) *free_bytes = (int64_t)f;
+	if (total_bytes) *total_bytes = (int64_t)t;
+	return MNC_OK;
+}
+
 extern "C" int mnc_device_name(int device, char *buf, size_t cap)
 {
 	if (!buf || cap == 0) return MNC_ERR_ARG;
@@ -558,18 +570,24 @@ extern "C" int mnc_device_name(int device, char *buf, size_t cap)
 	return MNC_OK;
 }
 
-extern "C" void mnc_engine_destroy(mnc_engine *e)
+// every device buffer an engine owns (release, accounting)
+template <class F> static void engine_bufs(mnc_engine *e, F f)
 {
-	if (!e) return;
-	(void)hipSetDevice(e->device);
-	if (e->stream) (void)hipStreamSynchronize(e->stream);
 	Buf *all[] = { &e->gap_lut, &e->logf_lut, &e->logf_a_lut, &e->ca, &e->ca_cnt, &e->chain_dst, &e->regdp, &e->segs, &e->cig_seg, &e->cig_reg, &e->dp_ctr,
 	               &e->work_a, &e->work_b, &e->big_list, &e->huge_list, &e->reg_cnt, &e->regs2, &e->fill1, &e->fill2, &e->fill3, &e->fill_fb, &e->extp, &e->mid_list, &e->lfill, &e->lext, &e->bigfb, &e->ext1, &e->ext2, &e->ext3, &e->ext4, &e->gen_list, &e->in_bases, &e->in_offsets, &e->out_assign, &e->out_best, &e->out_nhits,
 	               &e->packed, &e->mz, &e->hits, &e->hist_tm, &e->q_off, &e->qrec, &e->bhits, &e->bhit_cnt, &e->ambig, &e->mz_cnt, &e->hit_cnt, &e->rep_len, &e->an_cnt, &e->an_off,
 	               &e->n_chain, &e->n_reg, &e->best_mlen, &e->hist_sums, &e->hist_offs, &e->scan_sums, &e->hit_off, &e->a, &e->f, &e->p, &e->v, &e->t, &e->u,
 	               &e->chains_tmp, &e->regs, &e->regx, &e->k64a, &e->k64b, &e->tmp_i32, &e->gated,
 	               &e->hits_csr, &e->stats, &e->cls_count, &e->cls_list };
-	for (Buf *b : all) b->release();
+	for (Buf *b : all) f(b);
+}
+
+extern "C" void mnc_engine_destroy(mnc_engine *e)
+{
+	if (!e) return;
+	(void)hipSetDevice(e->device);
+	if (e->stream) (void)hipStreamSynchronize(e->stream);
+	engine_bufs(e, [](Buf *b) { b->release(); });
 	if (e->ws) { (void)shared_ws(e->device, -1); e->ws = nullptr; }
 	for (int s = 0; s < MNC_N_STAGES; ++s) for (int k = 0; k < 2; ++k) if (e->ev[s][k]) (void)hipEventDestroy(e->ev[s][k]);
 	for (int k = 0; k < mnc_engine::N_SIDE; ++k) {
@@ -592,7 +610,7 @@ extern "C" int mnc_engine_create(mnc_index *idx, int device, mnc_engine **out)
 	e->idx = idx, e->device = device;
 	e->ws = shared_ws(device, +1);
 	int rc = index_upload(idx, device, &e->didx);
-	if (rc) { delete e; return rc; }
+	if (rc) { mnc_engine_destroy(e); return rc; }      // gives the workspace reference back, too
 	hipError_t he = hipSetDevice(device);
 	if (he == hipSuccess) {
 		// the batch's own stream carries the latency-bound kernels (a few long calls on single waves) beside the
@@ -643,6 +661,16 @@ extern "C" int mnc_engine_create(mnc_index *idx, int device, mnc_engine **out)
 	}
 	if (rc) { mnc_engine_destroy(e); return rc; }
 	*out = e;
+	return MNC_OK;
+}
+
+// HBM held by this engine's own buffers (the per-device alignment scratch it shares is not counted)
+extern "C" int mnc_engine_device_bytes(mnc_engine *e, int64_t *bytes)
+{
+	if (!e || !bytes) return MNC_ERR_ARG;
+	size_t n = 0;
+	engine_bufs(e, [&](Buf *b) { n += b->cap; });
+	*bytes = (int64_t)n;
 	return MNC_OK;
 }
 
@@ -790,11 +818,11 @@ static void align_rest(const Batch &B, mnc_engine *e, hipStream_t st)
 // ---------------------------------------------------------------- one batch, device-resident
 static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d_offsets,
                          uint32_t n_reads, int64_t total_bases, int min_mapq,
-                         int32_t *d_assign, mnc_hit_t *d_best, int32_t *d_nhits, int64_t *d_counts, bool *overflowed)
+                         int32_t *d_assign, mnc_hit_t *d_best, int32_t *d_nhits, int64_t *d_counts, int *overflowed)
 {
 	hipStream_t st = e->stream;
 	const mnc_index *idx = e->idx;
-	*overflowed = false;
+	*overflowed = 0;                                  // 1: query records, 2: segments / CIGAR pools of the alignment stage
 	const size_t nr = (size_t)n_reads, nb = (size_t)total_bases;
 	const size_t n_tiles = (nr + PT_READS - 1) / PT_READS, n_super = (n_tiles + PS_TILES - 1) / PS_TILES;
 	// query records: a (w,k)-minimizer sketch keeps ~2/(w+1) of the k-mers; room for a third
@@ -905,7 +933,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	}
 	if (overflow || total_q > (int64_t)q_cap) {
 		e->q_cap_override = (size_t)total_q + (size_t)total_q / 8 + 4096;
-		*overflowed = true;
+		*overflowed = 1;
 		return MNC_OK;
 	}
 	if (total_anchors < 0 || total_anchors >= (1LL << 31) * 16) { set_error("anchor count %lld out of range", (long long)total_anchors); return MNC_ERR_UNSUPPORTED; }
@@ -1008,7 +1036,10 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 		// the device's alignment scratch is this engine's from here to the end of the stage
 		std::unique_lock<std::mutex> ws_hold(e->ws->mu);
 		ENS2(ca, na * sizeof(Anchor)); ENS2(ca_cnt, (nr + 1) * 4); ENS2(chain_dst, ns * 4); ENS2(regdp, ns * sizeof(RegDP));
-		ENS2(segs, seg_cap * sizeof(Seg)); ENS2(cig_seg, cig_cap * 4); ENS2(cig_reg, cig_cap * 4);
+		// the stitch kernel's waves reserve the region pool a chunk at a time (k_align.hip): what its two launches
+		// can leave unused is room on top of the CIGARs' own
+		const size_t cig_reg_cap = cig_cap + dp_stitch_pool_slack(DP_WG_STITCH);
+		ENS2(segs, seg_cap * sizeof(Seg)); ENS2(cig_seg, cig_cap * 4); ENS2(cig_reg, cig_reg_cap * 4);
 		ENS2(work_a, ns * 4); ENS2(work_b, ns * 4); ENS2(big_list, seg_cap * 4); ENS2(reg_cnt, (nr + 1) * 4); ENS2(regs2, ns * sizeof(mnc_reg_t));
 		const size_t ws_small = dp_align_ws_bytes(DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL), ws_big = dp_align_ws_bytes(DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG), ws_huge = dp_align_ws_bytes(DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE);
 		ENSW(dp_ws, ws_small * DP_WG_SMALL * 2); ENSW(dp_ws_big, ws_big * DP_WG_BIG); ENSW(dp_ws_huge, ws_huge * DP_WG_HUGE); ENS2(huge_list, seg_cap * 4); ENSW(dp_ws_mid, ws_small * DP_WG_MID); ENS2(mid_list, seg_cap * 4); ENS2(lfill, seg_cap * 4); ENSW(lfill_p, dp_lfill_p_slot() * DP_WG_LFILL); ENS2(lext, seg_cap * 4); ENS2(bigfb, seg_cap * 4); ENSW(lext_p, dp_lext_p_slot() * DP_WG_LEXT);
@@ -1017,7 +1048,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 		if (rc2) return rc2;
 		B.ca = e->ca.as<Anchor>(), B.ca_cnt = e->ca_cnt.as<int32_t>(), B.chain_dst = e->chain_dst.as<int32_t>(), B.regdp = e->regdp.as<RegDP>();
 		B.segs = e->segs.as<Seg>(), B.seg_cap = (int64_t)seg_cap, B.cig_seg = e->cig_seg.as<uint32_t>(), B.cig_reg = e->cig_reg.as<uint32_t>();
-		B.cig_seg_cap = B.cig_reg_cap = (int64_t)cig_cap, B.dp_ctr = e->dp_ctr.as<unsigned long long>();
+		B.cig_seg_cap = (int64_t)cig_cap, B.cig_reg_cap = (int64_t)cig_reg_cap, B.dp_ctr = e->dp_ctr.as<unsigned long long>();
 		B.big_list = e->big_list.as<int32_t>(), B.huge_list = e->huge_list.as<int32_t>(), B.reg_cnt = e->reg_cnt.as<int32_t>();
 		B.fill_list1 = e->fill1.as<int32_t>(), B.fill_list2 = e->fill2.as<int32_t>(), B.fill_list3 = e->fill3.as<int32_t>(), B.fill_fb = e->fill_fb.as<int32_t>();
 		B.ext_list1 = e->ext1.as<int32_t>(), B.ext_list2 = e->ext2.as<int32_t>(), B.ext_list3 = e->ext3.as<int32_t>(), B.ext_list4 = e->ext4.as<int32_t>(), B.gen_list = e->gen_list.as<int32_t>(), B.extp_list = e->extp.as<int32_t>(), B.mid_list = e->mid_list.as<int32_t>(), B.lfill_list = e->lfill.as<int32_t>(), B.lext_list = e->lext.as<int32_t>(), B.bigfb_list = e->bigfb.as<int32_t>();
@@ -1056,7 +1087,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 					StageTimer t(e, MNC_STAGE_DP_ALIGN);
 					align_rest(B, e, st);
 				}
-				{ StageTimer t(e, MNC_STAGE_DP_STITCH); launch_dp_stitch(B, work, next, (e->debug & 0x200000) ? 0 : e->cur_max_read_len > 0 ? e->cur_max_read_len : 8192, 4096, st); }
+				{ StageTimer t(e, MNC_STAGE_DP_STITCH); launch_dp_stitch(B, work, next, (e->debug & 0x200000) ? 0 : e->cur_max_read_len > 0 ? e->cur_max_read_len : 8192, DP_WG_STITCH, st); }
 			} else {
 				launch_dp_plan(B, work, max_work, (int)DP_STATE_SMALL, DP_P_SMALL, (int)DP_CIG_SMALL, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE, st);
 				if (int rcf = fork()) return rcf;
@@ -1064,7 +1095,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 				else align_round(B, e, e->side[0], e->side[1], st, e->side[2]);
 				if (int rcj = join()) return rcj;
 				align_rest(B, e, st);
-				launch_dp_stitch(B, work, next, (e->debug & 0x200000) ? 0 : e->cur_max_read_len > 0 ? e->cur_max_read_len : 8192, 4096, st);
+				launch_dp_stitch(B, work, next, (e->debug & 0x200000) ? 0 : e->cur_max_read_len > 0 ? e->cur_max_read_len : 8192, DP_WG_STITCH, st);
 			}
 			launch_dp_round_end(B, st);
 			// Z-drop splits make new regions for the next round (rare); one small read-back per round
@@ -1073,9 +1104,11 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 			HIP_TRY(hipStreamSynchronize(st));
 			if (ctr[4] != 0) {
 				if (ctr[4] >= 9) { set_error("a gap between two seeds is too large for the alignment workspace"); return MNC_ERR_UNSUPPORTED; }
+				// segments: the worst case; CIGAR words: four times the room, at most one word per base of every
+				// region's query and target span (regions of a read may overlap: bounded by the retry count instead)
 				e->seg_cap_override = na + 2 * ns + 1024;
 				e->cig_cap_override = cig_cap * 4;
-				*overflowed = true;
+				*overflowed = 2;
 				return MNC_OK;
 			}
 			if (ctr[5] == 0) break;
@@ -1108,12 +1141,18 @@ extern "C" int mnc_classify_device(mnc_engine *e, const uint8_t *d_bases, const 
 		e->have_batch = true, e->last_total_anchors = 0;
 		return MNC_OK;
 	}
-	bool overflowed = false;
+	int overflowed = 0, q_redone = 0, dp_redone = 0;
 	e->cur_max_read_len = max_read_len;
-	int rc = classify_once(e, d_bases, d_offsets, n_reads, total_bases, min_mapq, d_assign, d_best, d_nhits, d_counts, &overflowed);
-	if (!rc && overflowed)                          // denser sketch than budgeted: redo with exact room
+	int rc = MNC_OK;
+	// A batch that outgrows a budget is redone with more room: the query records once (the second try has exact
+	// room), the alignment stage's pools four times as large per try (4^6 times the first budget is beyond any CIGAR
+	// the batch's bases can make) -- and either may happen in the same batch.
+	for (;;) {
 		rc = classify_once(e, d_bases, d_offsets, n_reads, total_bases, min_mapq, d_assign, d_best, d_nhits, d_counts, &overflowed);
-	if (!rc && overflowed) { set_error("query record budget exceeded twice"); rc = MNC_ERR_NOMEM; }
+		if (rc || !overflowed) break;
+		if (overflowed == 1 && ++q_redone > 1) { set_error("query record budget exceeded twice"); rc = MNC_ERR_NOMEM; break; }
+		if (overflowed == 2 && ++dp_redone > 6) { set_error("segment / CIGAR pools of the alignment stage exceeded after %d enlargements", dp_redone - 1); rc = MNC_ERR_NOMEM; break; }
+	}
 	return rc;
 }
 

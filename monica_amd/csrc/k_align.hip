@@ -1661,6 +1661,9 @@ void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_li
 	launch(q_s, t_s, 1, q_s, t_s, ST_EV_MAX, n_wg);
 	launch(q_max, t_max, 2, q_s, t_s, ST_EV_LONG, n_wg / 4);
 }
+// what the waves of one round's launches (n_wg, and n_wg / 4 more for the regions of long reads) can hold back of the
+// region pool: the chunk each reserved last
+size_t dp_stitch_pool_slack(int n_wg) { return (size_t)(n_wg + n_wg / 4) * ST_POOL_CHUNK; }
 int dp_stitch_prepare()
 {
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_stitch), hipFuncAttributeMaxDynamicSharedMemorySize,

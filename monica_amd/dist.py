@@ -72,7 +72,7 @@ class PipeGroup:
         return [torch.from_numpy(a) for a in self.conns[0].recv()]
 
     def all_reduce_sum(self, t):
-        total = sum(self.all_gather(t))
+        total = sum(p.cpu() for p in self.all_gather(t))          # `t` may live on a GPU; the received parts do not
         t.copy_(total.to(t.device))
         return t
 

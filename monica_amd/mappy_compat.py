@@ -27,29 +27,93 @@ from . import _capi
 _INDEX_CACHE = {}
 _INDEX_CACHE_LOCK = threading.Lock()
 _INDEX_CACHE_MAX = 4
+# ... and by bytes: the reference holds ONE part at a time (aligner.py:91-103 rebinds `index` per part); a
+# database of many parts kept resident would exhaust host memory or HBM.  Host side: the file sizes of the
+# cached parts against a share of physical memory; device side: what the parts' tables and the idle engines'
+# batch buffers hold against a share of the device's HBM (the alignment scratch is one per device and is not
+# counted).  The most recently used part always stays.
+_HOST_SHARE, _DEVICE_SHARE = 0.5, 0.6
+_CACHE_BYTES = {}                    # key -> file size (the in-memory form of a part is about its file)
 # idle engines (stream + HBM workspace) per cached index, keyed by id(index).  Kept outside the
 # Index object: an Engine refers to its Index, so a pool stored on the Index would be a
 # reference cycle and an evicted index would hold its HBM until the cyclic collector ran.
 _ENGINE_POOLS = {}
+_POOL_MAX_PER_INDEX = 8
 
 
 def reserve_index_cache(n_parts):
     """Make room for every part of a multi-part database (monica loops over all parts on every
-    pass, aligner.py:91-103: a cache smaller than the loop would miss on every load)."""
+    pass, aligner.py:91-103: a cache smaller than the loop would miss on every load).  The byte
+    bounds still hold: parts that do not fit together are loaded again, as the reference does."""
     global _INDEX_CACHE_MAX
     with _INDEX_CACHE_LOCK:
         _INDEX_CACHE_MAX = max(_INDEX_CACHE_MAX, int(n_parts))
 
 
-def _evict_locked():
+def _host_budget():
+    try:
+        return int(os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") * _HOST_SHARE)
+    except (ValueError, OSError):
+        return 1 << 62
+
+
+def _device_budget(device):
+    try:
+        return int(_capi.device_mem_info(device)[1] * _DEVICE_SHARE)
+    except _capi.MncError:
+        return 1 << 62                                         # no device: nothing is resident either
+
+
+def _device_bytes_locked():
+    n = 0
+    for index in _INDEX_CACHE.values():
+        n += index.info().device_bytes
+        for eng in _ENGINE_POOLS.get(id(index), []):
+            n += eng.device_bytes()
+    return n
+
+
+def _drop_locked(key):
+    old = _INDEX_CACHE.pop(key)
+    _CACHE_BYTES.pop(key, None)
+    for eng in _ENGINE_POOLS.pop(id(old), []):
+        eng.close()                                            # idle by construction: free its HBM now
+    # the Index frees its host and device tables when the last Aligner using it lets go
+
+
+def _evict_locked(device=None):
+    """Least recently used parts go until the count and both byte budgets hold (the newest stays)."""
     while len(_INDEX_CACHE) > _INDEX_CACHE_MAX:
-        old = _INDEX_CACHE.pop(next(iter(_INDEX_CACHE)))
-        for eng in _ENGINE_POOLS.pop(id(old), []):
-            eng.close()                                        # idle by construction: free its HBM now
-        # the Index frees its device tables when the last Aligner using it lets go
+        _drop_locked(next(iter(_INDEX_CACHE)))
+    host = _host_budget()
+    while len(_INDEX_CACHE) > 1 and sum(_CACHE_BYTES.values()) > host:
+        _drop_locked(next(iter(_INDEX_CACHE)))
+    if device is not None and len(_INDEX_CACHE) > 1:
+        dev = _device_budget(device)
+        while len(_INDEX_CACHE) > 1 and _device_bytes_locked() > dev:
+            # first the idle engines of the parts that are not the newest (their batch buffers are the
+            # larger share), then the parts themselves
+            oldest = next(iter(_INDEX_CACHE))
+            pool = _ENGINE_POOLS.get(id(_INDEX_CACHE[oldest]), [])
+            if pool:
+                while pool:
+                    pool.pop().close()
+            else:
+                _drop_locked(oldest)
 
 
-def _load_index_cached(path):
+def release_idle(keep_index=None):
+    """Free what the cache holds beyond `keep_index`: every idle engine and every other part.
+    Called when an allocation fails (MNC_ERR_NOMEM) before the one retry."""
+    with _INDEX_CACHE_LOCK:
+        for key in [k for k, v in _INDEX_CACHE.items() if v is not keep_index]:
+            _drop_locked(key)
+        for pool in _ENGINE_POOLS.values():
+            while pool:
+                pool.pop().close()
+
+
+def _load_index_cached(path, device=None):
     st = os.stat(path)
     key = (os.path.realpath(path), st.st_mtime_ns, st.st_size)
     with _INDEX_CACHE_LOCK:
@@ -57,10 +121,17 @@ def _load_index_cached(path):
         if hit is not None:
             _INDEX_CACHE[key] = _INDEX_CACHE.pop(key)          # most recently used last
             return hit
-    index = _capi.Index.load(path)
+    try:
+        index = _capi.Index.load(path)
+    except _capi.MncError as e:
+        if e.code != _capi.ERR_NOMEM:
+            raise
+        release_idle()
+        index = _capi.Index.load(path)
     with _INDEX_CACHE_LOCK:
         _INDEX_CACHE[key] = index
-        _evict_locked()
+        _CACHE_BYTES[key] = st.st_size
+        _evict_locked(device)
     return index
 
 
@@ -134,7 +205,7 @@ class Aligner:
             elif fn_idx_in is None:
                 raise ValueError("fn_idx_in or seq is required")
             elif self._is_index_file(fn_idx_in):
-                self._index = _load_index_cached(fn_idx_in)
+                self._index = _load_index_cached(fn_idx_in, self._device)
             elif INDEX_FILE_FORMAT == "mmi" and fn_idx_out:
                 self._index = _capi.Index.build(fn_idx_in, None, kk, ww)
                 self._index.save(fn_idx_out, mmi=True)
@@ -186,8 +257,17 @@ class Aligner:
             pool = _engine_pool(self._index)
             with _INDEX_CACHE_LOCK:
                 e = pool.pop() if pool else None
-            if e is None or e.device != self._device:
-                e = _capi.Engine(self._index, self._device)
+            if e is not None and e.device != self._device:
+                e.close()
+                e = None
+            if e is None:
+                try:
+                    e = _capi.Engine(self._index, self._device)
+                except _capi.MncError as err:                  # HBM exhausted: free what is idle, once
+                    if err.code != _capi.ERR_NOMEM:
+                        raise
+                    release_idle(self._index)
+                    e = _capi.Engine(self._index, self._device)
             self._tls.engine = e
             with _INDEX_CACHE_LOCK:
                 self._borrowed.append(e)
@@ -198,12 +278,14 @@ class Aligner:
             if self._index is not None and self._borrowed:
                 pool = _engine_pool(self._index)
                 with _INDEX_CACHE_LOCK:
-                    keep = self._borrowed[:max(0, 8 - len(pool))] if pool is not None else []
+                    keep = self._borrowed[:max(0, _POOL_MAX_PER_INDEX - len(pool))] if pool is not None else []
                     if pool is not None:
                         pool.extend(keep)
                     rest, self._borrowed = self._borrowed[len(keep):], []
                 for eng in rest:                               # not pooled: release the HBM now
                     eng.close()
+                with _INDEX_CACHE_LOCK:                        # the returned engines count against the device budget
+                    _evict_locked(self._device)
         except Exception:
             pass
 
@@ -213,7 +295,13 @@ class Aligner:
         hits[hit_offsets[r]:hit_offsets[r+1]] are the (rid, mapq, nm, mlen) of the hits of read r
         that pass `is_primary and mapq >= min_mapq`."""
         eng = self.engine()
-        assign, best, nhits = eng.classify(bases, offsets, min_mapq)
+        try:
+            assign, best, nhits = eng.classify(bases, offsets, min_mapq)
+        except _capi.MncError as err:                          # the batch's buffers did not fit beside the cache
+            if err.code != _capi.ERR_NOMEM:
+                raise
+            release_idle(self._index)
+            assign, best, nhits = eng.classify(bases, offsets, min_mapq)
         hit_off, hits = eng.fetch_hits()
         return assign, best, nhits, hit_off, hits
 

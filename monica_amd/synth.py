@@ -82,6 +82,31 @@ def reads(genomes, n_reads, read_len=5000, seed=SEED_READS, first=0, sub=400, in
     return out, offsets, truth
 
 
+class DeviceReads:
+    """The same reads made in HBM (`mnc_synth_reads_device`, one wave per read; byte for byte the
+    host generator's).  Holds the genomes on the device; `make` fills caller-owned torch tensors."""
+
+    def __init__(self, genomes, device):
+        import torch
+        self.n = len(genomes)
+        lens = np.array([len(g) for g in genomes], dtype=np.int64)
+        off = np.zeros(self.n + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        cat = torch.empty(int(off[-1]), dtype=torch.uint8, device=device)
+        for i, g in enumerate(genomes):
+            cat[off[i]:off[i + 1]] = torch.from_numpy(np.ascontiguousarray(g, dtype=np.uint8)).to(device)
+        self.genomes, self.offsets, self.device = cat, torch.from_numpy(off).to(device), device
+
+    def make(self, out_bases, out_truth, n_reads, read_len=5000, seed=SEED_READS, first=0, sub=400, ins=300,
+             dele=300, random_frac=200, stream=0):
+        """out_bases: uint8[>= n_reads * read_len], out_truth: int32[>= n_reads] (or None), both on the
+        device.  Asynchronous on `stream` (a raw hipStream_t; 0 = the default stream)."""
+        assert out_bases.numel() >= n_reads * read_len and (out_truth is None or out_truth.numel() >= n_reads)
+        _capi.check(_capi.lib().mnc_synth_reads_device(
+            self.n, self.genomes.data_ptr(), self.offsets.data_ptr(), seed, first, n_reads, read_len, sub, ins, dele,
+            random_frac, out_bases.data_ptr(), out_truth.data_ptr() if out_truth is not None else None, stream or None))
+
+
 def write_fasta(path, names, seqs, width=80, gz=None):
     """Write contigs as (optionally gzipped) FASTA."""
     import gzip

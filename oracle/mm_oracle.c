@@ -210,6 +210,36 @@ static inline uint64_t tslot(uint64_t h, uint64_t tmask)
 	return (h * 0x9E3779B97F4A7C15ULL >> 20) & tmask;
 }
 
+/* The (hash, y) pairs are distinct, so their total order has one sorted form whatever the
+ * method: slices sorted with qsort side by side, then merged pairwise (the oracle's index build
+ * is test set-up time: 50 M pairs per 280 Mbp part of BASELINE config 4). */
+static void sort128(orc128_t *a, int64_t n)
+{
+	int T = omp_get_max_threads(), t, width;
+	int64_t bound[65];
+	orc128_t *tmp, *src, *dst;
+	if (T > 64) T = 64;
+	while (T & (T - 1)) T &= T - 1;                        /* a power of two */
+	if (n < 1000000 || T < 2) { qsort(a, (size_t)n, sizeof(orc128_t), cmp128); return; }
+	for (t = 0; t <= T; ++t) bound[t] = n * t / T;
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+	for (t = 0; t < T; ++t) qsort(a + bound[t], (size_t)(bound[t + 1] - bound[t]), sizeof(orc128_t), cmp128);
+	tmp = (orc128_t*)malloc((size_t)n * sizeof(orc128_t));
+	src = a, dst = tmp;
+	for (width = 1; width < T; width *= 2) {
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+		for (t = 0; t < T; t += 2 * width) {
+			int64_t i = bound[t], ie = bound[t + width], j = ie, je = bound[t + 2 * width], o = bound[t];
+			while (i < ie && j < je) dst[o++] = cmp128(&src[j], &src[i]) < 0 ? src[j++] : src[i++];
+			while (i < ie) dst[o++] = src[i++];
+			while (j < je) dst[o++] = src[j++];
+		}
+		{ orc128_t *x = src; src = dst; dst = x; }
+	}
+	if (src != a) memcpy(a, src, (size_t)n * sizeof(orc128_t));
+	free(tmp);
+}
+
 /* all minimizers of all contigs -> (hash, y) pairs -> groups.  The position list of one
  * hash is sorted by y ascending, as A.3 says ("positions sorted ascending"). */
 static orc_index *index_from_pairs(orc_index *mi, vec128 *v)
@@ -217,7 +247,9 @@ static orc_index *index_from_pairs(orc_index *mi, vec128 *v)
 	int64_t i, j, nk = 0, off;
 	uint64_t tsize = 16;
 	for (i = 0; i < v->n; ++i) v->a[i].x >>= 8;         /* key = hash only (span dropped) */
-	qsort(v->a, (size_t)v->n, sizeof(orc128_t), cmp128);
+	double t0 = omp_get_wtime();
+	sort128(v->a, v->n);
+	if (getenv("ORC_TIMING")) fprintf(stderr, "[oracle] sort %.2f s\n", omp_get_wtime() - t0);
 	for (i = 0; i < v->n; ++i) if (i == 0 || v->a[i].x != v->a[i-1].x) ++nk;
 	mi->n_occ = v->n, mi->n_keys = nk;
 	while (tsize < (uint64_t)nk * 2) tsize <<= 1;
@@ -238,6 +270,7 @@ static orc_index *index_from_pairs(orc_index *mi, vec128 *v)
 		off = j;
 	}
 	if (v->n >= (1LL << 32)) { fprintf(stderr, "[oracle] index too large for 32-bit offsets\n"); abort(); }
+	if (getenv("ORC_TIMING")) fprintf(stderr, "[oracle] sort + table %.2f s\n", omp_get_wtime() - t0);
 	return mi;
 }
 
@@ -252,14 +285,30 @@ orc_index *orc_index_build_mem(int n_seq, const char *const *names, const char *
 	mi->name = (char**)calloc((size_t)(n_seq ? n_seq : 1), sizeof(char*));
 	mi->len = (int*)calloc((size_t)(n_seq ? n_seq : 1), sizeof(int));
 	mi->seq = (uint8_t**)calloc((size_t)(n_seq ? n_seq : 1), sizeof(uint8_t*));
-	for (i = 0; i < n_seq; ++i) {
-		int j;
-		mi->name[i] = strdup(names[i]);
-		mi->len[i] = lens[i];
-		mi->seq[i] = (uint8_t*)malloc((size_t)(lens[i] ? lens[i] : 1));
-		for (j = 0; j < lens[i]; ++j) mi->seq[i][j] = orc_nt4((unsigned char)seqs[i][j]);
-		sketch_core(seqs[i], lens[i], w, k, (uint32_t)i, &v);
+	{
+		/* contigs side by side, their minimizers joined in contig order (the order does not matter to
+		 * the sort below; it keeps the build the same whatever the number of threads) */
+		vec128 *per = (vec128*)calloc((size_t)(n_seq ? n_seq : 1), sizeof(vec128));
+		int64_t total = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+		for (i = 0; i < n_seq; ++i) {
+			int j;
+			mi->name[i] = strdup(names[i]);
+			mi->len[i] = lens[i];
+			mi->seq[i] = (uint8_t*)malloc((size_t)(lens[i] ? lens[i] : 1));
+			for (j = 0; j < lens[i]; ++j) mi->seq[i][j] = orc_nt4((unsigned char)seqs[i][j]);
+			sketch_core(seqs[i], lens[i], w, k, (uint32_t)i, &per[i]);
+		}
+		for (i = 0; i < n_seq; ++i) total += per[i].n;
+		v.a = (orc128_t*)malloc((size_t)(total ? total : 1) * sizeof(orc128_t)), v.m = total;
+		for (i = 0; i < n_seq; ++i) {
+			if (per[i].n) memcpy(v.a + v.n, per[i].a, (size_t)per[i].n * sizeof(orc128_t));
+			v.n += per[i].n;
+			free(per[i].a);
+		}
+		free(per);
 	}
+	if (getenv("ORC_TIMING")) fprintf(stderr, "[oracle] sketch done\n");
 	index_from_pairs(mi, &v);
 	free(v.a);
 	return mi;

@@ -213,3 +213,33 @@ def test_reads_with_many_errors_use_every_workspace_class(capi, oracle, world):
         _compare_dp(capi, oracle, world, b[: o[120]], o[:121], min_mapq=0)
     finally:
         eng.set_debug(0)
+
+
+def test_a_batch_of_many_short_regions_fits_the_cigar_pools(capi, oracle, world):
+    """20 000 reads of 600 bases: more than 16 384 regions, so the stitch kernel's waves reserve the region CIGAR pool
+    a chunk at a time (4 096 workgroups x 4 096 words) although the batch's bases would budget far less -- the pool
+    is sized with that slack, and an alignment-stage overflow is redone with more room until it fits instead of
+    failing after one retry.  Decisions, gated hits and a sample of CIGARs equal the oracle."""
+    seqs = world["seqs"]
+    n = 20_000
+    bases, offsets, truth = synth.reads(seqs, n, 600, seed=4242)
+    eng, oidx = world["eng"], world["oidx"]
+    eng.set_contract(capi.CONTRACT_DP)
+    oidx.opt.cigar = 1
+    assign, best, nhits = eng.classify(bases, offsets, 60)
+    reg_off = eng.dump(capi.DUMP_REG_OFFSETS, np.int64)
+    assert reg_off[-1] >= 16_384
+    regs = eng.dump(capi.DUMP_REGS, capi.REG_DTYPE)
+    cigs = eng.cigars()
+    oassign, obest, onh, _ = oidx.classify(bases, offsets, 60, n_threads=8)
+    assert np.array_equal(assign, oassign) and np.array_equal(nhits, onh)
+    for name in capi.HIT_DTYPE.names:
+        assert np.array_equal(best[name], obest[name]), name
+    raw = bases.tobytes()
+    for r in range(0, n, 97):
+        oregs, ocigs = oidx.map_cigar(raw[offsets[r]:offsets[r + 1]])
+        assert cigs[reg_off[r]:reg_off[r + 1]] == ocigs, f"read {r}: CIGAR"
+        for name in capi.REG_DTYPE.names:
+            assert np.array_equal(regs[reg_off[r]:reg_off[r + 1]][name], oregs[name]), f"read {r}: {name}"
+    mapped = assign >= 0
+    assert mapped.sum() > 0.9 * n and (assign[mapped] == truth[mapped]).mean() > 0.99
