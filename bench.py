@@ -477,7 +477,11 @@ def shard_mode(args, names, seqs, rank, local_rank, world, dev):
     for p in mine:
         lo, hi = bounds[p]
         idx = _capi.Index.from_seqs(names[lo:hi], seqs[lo:hi])
-        parts.append((lo, idx, _capi.Engine(idx, local_rank)))
+        parts.append((lo, idx))
+    # ONE engine per rank (stream + batch buffers), rebound to the part at hand -- `index = index_loader(part)` in the
+    # reference's loop (aligner.py:91-103); every part of the rank is resident in HBM after its first use
+    eng = _capi.Engine(parts[0][1], local_rank)
+    eng.set_contract(_capi.CONTRACT_DP if args.contract == "dp" else _capi.CONTRACT_CHAIN)
     bases, offsets, truth = synth.reads(seqs, args.reads, args.read_len, seed=synth.SEED_READS + 4)
     n = args.reads
     d_bases, d_off = torch.from_numpy(bases).to(dev), torch.from_numpy(offsets).to(dev)
@@ -496,8 +500,9 @@ def shard_mode(args, names, seqs, rank, local_rank, world, dev):
 
     def step():
         local = []
-        for lo, idx, eng in parts:
+        for lo, idx in parts:
             torch.cuda.current_stream().synchronize()
+            eng.set_index(idx)
             for b0, b1 in blocks:
                 eng.classify_device(d_bases.data_ptr() + b0 * L, d_off_blk.data_ptr(), b1 - b0, (b1 - b0) * L, L, args.min_mapq,
                                     d_assign.data_ptr() + b0 * 4, d_best.data_ptr() + b0 * 16, d_nhits.data_ptr() + b0 * 4, 0)

@@ -123,6 +123,9 @@ int  mnc_engine_create(mnc_index *idx, int device, mnc_engine **out);
 #define MNC_CONTRACT_CHAIN 1
 int  mnc_engine_set_contract(mnc_engine *eng, int contract);
 void mnc_engine_destroy(mnc_engine *eng);
+/* another index part behind the same engine: `index = index_loader(part)` in the reference's loop over the
+ * parts of a database (aligner.py:91-103).  Same k / w / match score as the index the engine was made for. */
+int  mnc_engine_set_index(mnc_engine *eng, mnc_index *idx);
 void *mnc_engine_stream(mnc_engine *eng);                              /* hipStream_t */
 int  mnc_engine_device_bytes(mnc_engine *eng, int64_t *bytes);         /* HBM held by the engine's own batch buffers */
 

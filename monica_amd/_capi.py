@@ -42,7 +42,7 @@ EXPORTS = [
     "mnc_index_build", "mnc_index_build_mem", "mnc_index_save", "mnc_index_save_mmi", "mnc_index_load", "mnc_index_free",
     "mnc_index_info", "mnc_index_contig_name", "mnc_index_contig_len", "mnc_index_contig_genome",
     "mnc_index_genome_name", "mnc_index_genome_len", "mnc_index_dump", "mnc_index_set_mid_occ",
-    "mnc_engine_create", "mnc_engine_destroy", "mnc_engine_stream", "mnc_engine_device_bytes",
+    "mnc_engine_create", "mnc_engine_destroy", "mnc_engine_stream", "mnc_engine_device_bytes", "mnc_engine_set_index",
     "mnc_classify_batch", "mnc_classify_device", "mnc_engine_sync", "mnc_engine_fetch_hits",
     "mnc_counts", "mnc_best_hit",
     "mnc_engine_set_profiling", "mnc_engine_set_debug", "mnc_engine_set_contract", "mnc_index_set_host_tables", "mnc_engine_dump_tables",
@@ -119,6 +119,7 @@ def lib():
     sig("mnc_engine_create", i32, [vp, i32, pp])
     sig("mnc_engine_destroy", None, [vp])
     sig("mnc_engine_stream", vp, [vp])
+    sig("mnc_engine_set_index", i32, [vp, vp])
     sig("mnc_engine_device_bytes", i32, [vp, C.POINTER(C.c_int64)])
     sig("mnc_classify_batch", i32, [vp, vp, vp, u32, i32, vp, vp, vp])
     sig("mnc_classify_device", i32, [vp, vp, vp, u32, i64, i32, i32, vp, vp, vp, vp])
@@ -342,6 +343,11 @@ class Engine:
     @property
     def stream(self):
         return lib().mnc_engine_stream(self._h)
+
+    def set_index(self, index):
+        """Another index part behind the same stream and batch buffers (aligner.py:91-103 rebinds `index`)."""
+        check(lib().mnc_engine_set_index(self._h, index._h))
+        self.index = index
 
     def device_bytes(self):
         """HBM held by this engine's own batch buffers."""

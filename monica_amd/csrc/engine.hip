@@ -674,6 +674,27 @@ extern "C" int mnc_engine_device_bytes(mnc_engine *e, int64_t *bytes)
 	return MNC_OK;
 }
 
+// Another index part behind the same engine (stream, batch buffers): the reference's loop over the parts of a
+// database rebinds `index` and keeps its thread (aligner.py:91-103).  The part is made resident if it is not yet;
+// the tables an engine holds of its own (gap costs by k, logf(dp_max / a)) must fit the new part.
+extern "C" int mnc_engine_set_index(mnc_engine *e, mnc_index *idx)
+{
+	if (!e || !idx) return MNC_ERR_ARG;
+	if (idx == e->idx) return MNC_OK;
+	if (idx->k != e->idx->k || idx->w != e->idx->w || idx->par.a != e->idx->par.a) {
+		set_error("the engine was made for k = %d, w = %d, a = %d; the index has k = %d, w = %d, a = %d", e->idx->k, e->idx->w, e->idx->par.a, idx->k, idx->w, idx->par.a);
+		return MNC_ERR_UNSUPPORTED;
+	}
+	if (idx->par.bw >= GAP_LUT) { set_error("bw too large for the gap look-up"); return MNC_ERR_UNSUPPORTED; }
+	HIP_TRY(hipSetDevice(e->device));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	DeviceIndex *d = nullptr;
+	if (int rc = index_upload(idx, e->device, &d)) return rc;
+	e->idx = idx, e->didx = d;
+	e->have_batch = false;
+	return MNC_OK;
+}
+
 extern "C" void *mnc_engine_stream(mnc_engine *e) { return e ? (void*)e->stream : nullptr; }
 
 extern "C" int mnc_index_set_host_tables(mnc_index *idx, int on)

@@ -34,11 +34,12 @@ _INDEX_CACHE_MAX = 4
 # counted).  The most recently used part always stays.
 _HOST_SHARE, _DEVICE_SHARE = 0.5, 0.6
 _CACHE_BYTES = {}                    # key -> file size (the in-memory form of a part is about its file)
-# idle engines (stream + HBM workspace) per cached index, keyed by id(index).  Kept outside the
-# Index object: an Engine refers to its Index, so a pool stored on the Index would be a
-# reference cycle and an evicted index would hold its HBM until the cyclic collector ran.
+# idle engines (stream + per-batch HBM buffers), per DEVICE: an engine is not tied to an index part -- it is
+# rebound to the part at hand (`mnc_engine_set_index`), as the reference's threads keep running while `index` is
+# rebound in the loop over the parts (aligner.py:91-103).  So a database of many parts needs as many engines as
+# monica has threads, not threads x parts.  (Kept outside the Index objects: an Engine refers to its Index.)
 _ENGINE_POOLS = {}
-_POOL_MAX_PER_INDEX = 8
+_POOL_MAX_PER_DEVICE = 8
 
 
 def reserve_index_cache(n_parts):
@@ -64,20 +65,18 @@ def _device_budget(device):
         return 1 << 62                                         # no device: nothing is resident either
 
 
-def _device_bytes_locked():
-    n = 0
-    for index in _INDEX_CACHE.values():
-        n += index.info().device_bytes
-        for eng in _ENGINE_POOLS.get(id(index), []):
-            n += eng.device_bytes()
-    return n
+def _device_bytes_locked(device):
+    n = sum(index.info().device_bytes for index in _INDEX_CACHE.values())
+    return n + sum(eng.device_bytes() for eng in _ENGINE_POOLS.get(device, []))
 
 
 def _drop_locked(key):
     old = _INDEX_CACHE.pop(key)
     _CACHE_BYTES.pop(key, None)
-    for eng in _ENGINE_POOLS.pop(id(old), []):
-        eng.close()                                            # idle by construction: free its HBM now
+    for pool in _ENGINE_POOLS.values():                        # idle engines still bound to the part would keep it alive
+        for eng in [e for e in pool if e.index is old]:
+            pool.remove(eng)
+            eng.close()
     # the Index frees its host and device tables when the last Aligner using it lets go
 
 
@@ -88,18 +87,13 @@ def _evict_locked(device=None):
     host = _host_budget()
     while len(_INDEX_CACHE) > 1 and sum(_CACHE_BYTES.values()) > host:
         _drop_locked(next(iter(_INDEX_CACHE)))
-    if device is not None and len(_INDEX_CACHE) > 1:
+    if device is not None:
         dev = _device_budget(device)
-        while len(_INDEX_CACHE) > 1 and _device_bytes_locked() > dev:
-            # first the idle engines of the parts that are not the newest (their batch buffers are the
-            # larger share), then the parts themselves
-            oldest = next(iter(_INDEX_CACHE))
-            pool = _ENGINE_POOLS.get(id(_INDEX_CACHE[oldest]), [])
-            if pool:
-                while pool:
-                    pool.pop().close()
-            else:
-                _drop_locked(oldest)
+        while len(_INDEX_CACHE) > 1 and _device_bytes_locked(device) > dev:
+            _drop_locked(next(iter(_INDEX_CACHE)))
+        pool = _ENGINE_POOLS.get(device, [])
+        while pool and _device_bytes_locked(device) > dev:      # one part alone and still over: the idle engines go
+            pool.pop().close()
 
 
 def release_idle(keep_index=None):
@@ -135,12 +129,8 @@ def _load_index_cached(path, device=None):
     return index
 
 
-def _engine_pool(index):
-    """Pool of idle engines of a CACHED index (None for an index the cache does not hold)."""
-    with _INDEX_CACHE_LOCK:
-        if not any(v is index for v in _INDEX_CACHE.values()):
-            return None
-        return _ENGINE_POOLS.setdefault(id(index), [])
+def _is_cached(index):
+    return any(v is index for v in _INDEX_CACHE.values())
 
 
 def default_device():
@@ -248,18 +238,20 @@ class Aligner:
         return list(self._index.contig_names)
 
     def engine(self):
-        """One engine (HIP stream + HBM workspace) per calling thread: the reference shares one
-        index between the threads of its pool (aligner.py:89-103).  Engines outlive this object:
-        they go back to a pool kept with the (cached) index, so the next pass of monica's loop
-        does not allocate its workspace again."""
+        """One engine (HIP stream + HBM batch buffers) per calling thread: the reference shares one
+        index between the threads of its pool (aligner.py:89-103).  Engines outlive this object and
+        are not tied to an index part: an idle engine of the device is rebound to this part."""
         e = getattr(self._tls, "engine", None)
         if e is None:
-            pool = _engine_pool(self._index)
             with _INDEX_CACHE_LOCK:
+                pool = _ENGINE_POOLS.setdefault(self._device, [])
                 e = pool.pop() if pool else None
-            if e is not None and e.device != self._device:
-                e.close()
-                e = None
+            if e is not None:
+                try:
+                    e.set_index(self._index)
+                except _capi.MncError:                         # made for another k / w: not reusable here
+                    e.close()
+                    e = None
             if e is None:
                 try:
                     e = _capi.Engine(self._index, self._device)
@@ -276,12 +268,13 @@ class Aligner:
     def __del__(self):
         try:
             if self._index is not None and self._borrowed:
-                pool = _engine_pool(self._index)
                 with _INDEX_CACHE_LOCK:
-                    keep = self._borrowed[:max(0, _POOL_MAX_PER_INDEX - len(pool))] if pool is not None else []
-                    if pool is not None:
-                        pool.extend(keep)
-                    rest, self._borrowed = self._borrowed[len(keep):], []
+                    pool = _ENGINE_POOLS.setdefault(self._device, [])
+                    # only engines of a cached part go back: one bound to an uncached index would keep that index alive
+                    room = max(0, _POOL_MAX_PER_DEVICE - len(pool)) if _is_cached(self._index) else 0
+                    keep, rest = self._borrowed[:room], self._borrowed[room:]
+                    pool.extend(keep)
+                    self._borrowed = []
                 for eng in rest:                               # not pooled: release the HBM now
                     eng.close()
                 with _INDEX_CACHE_LOCK:                        # the returned engines count against the device budget

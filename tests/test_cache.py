@@ -56,8 +56,17 @@ def test_release_idle_drops_everything_but_the_part_in_use(tmp_path, capi, monke
         def close(self):
             FakeEngine.closed += 1
 
-    mc._ENGINE_POOLS[id(loaded[0])] = [FakeEngine(), FakeEngine()]
-    mc._ENGINE_POOLS[id(loaded[2])] = [FakeEngine()]
+    def fake(index):
+        e = FakeEngine()
+        e.index = index
+        return e
+
+    # dropping a part closes the idle engines still bound to it (they would keep it alive), not the others
+    mc._ENGINE_POOLS[0] = [fake(loaded[0]), fake(loaded[2]), fake(loaded[0])]
+    with mc._INDEX_CACHE_LOCK:
+        mc._drop_locked(next(iter(mc._INDEX_CACHE)))
+    assert FakeEngine.closed == 2 and [e.index for e in mc._ENGINE_POOLS[0]] == [loaded[2]]
+    mc._ENGINE_POOLS[0].append(fake(loaded[1]))
     mc.release_idle(keep_index=loaded[2])
     assert list(mc._INDEX_CACHE.values()) == [loaded[2]]
-    assert FakeEngine.closed == 3 and all(len(p) == 0 for p in mc._ENGINE_POOLS.values())
+    assert FakeEngine.closed == 4 and all(len(p) == 0 for p in mc._ENGINE_POOLS.values())

@@ -131,13 +131,16 @@ def test_config4_500_genomes_in_eight_parts(capi, oracle):
     bases, offsets, truth = synth.reads(seqs, n_truth, 5000, seed=synth.SEED_READS + 4)
     ob_, oo_ = bases[:offsets[n_oracle]], offsets[:n_oracle + 1]
     summaries, lists = [], [[] for _ in range(n_oracle)]
+    eng = None
     for lo, hi in bounds:
         pn, ps = names[lo:hi], seqs[lo:hi]
         idx = capi.Index.from_seqs(pn, ps)
-        eng = capi.Engine(idx, 0)
+        if eng is None:
+            eng = capi.Engine(idx, 0)
+        else:
+            eng.set_index(idx)                                    # `index = index_loader(part)`: the same engine, the next part
         assign, best, nhits = eng.classify(bases, offsets, 60)
         summaries.append(mdist.shard_summary(assign, best, nhits, rid_offset=lo))
-        eng.close()
         oidx = oracle.Index.from_seqs(pn, [s.tobytes() for s in ps])
         assert idx.mid_occ == oidx.mid_occ
         oa, ob, onh, flat = oidx.classify(ob_, oo_, 60, n_threads=N_THREADS)
@@ -150,6 +153,7 @@ def test_config4_500_genomes_in_eight_parts(capi, oracle):
                 lists[r].append((int(h["rid"]) + lo, int(h["nm"]), int(h["mlen"])))
             k += onh[r]
         del idx, oidx
+    eng.close()
     got, nm, ml, tot = mdist.merge_summaries(torch.stack(summaries))
     got, tot = got.numpy(), tot.numpy()
     # ---- the reference's multi-part loop on the oracle's hit lists (aligner.py:219-233)
