@@ -192,7 +192,9 @@ int mnc_best_hit(const mnc_hit_t *hits, int n, int *best_index /* -1 = ambiguous
 #define MNC_STAGE_DP_FILL_T2  17  /*   the banded gap-filling kernel's 32- / 64- / 128-cell launches     */
 #define MNC_STAGE_DP_FILL_T3  18
 #define MNC_STAGE_DP_EXT      19  /*   all the extension kernels                                         */
-#define MNC_N_STAGES          20
+#define MNC_STAGE_DP_FILL_TM  20  /*   the 42-cell launch of the banded kernel (between T1 and T2)       */
+#define MNC_STAGE_DP_LFILL    21  /*   gaps of 512 .. 2047 bases on the int32 banded kernel              */
+#define MNC_N_STAGES          22
 int mnc_engine_set_profiling(mnc_engine *eng, int on);    /* HIP events around every stage */
 int mnc_engine_set_debug(mnc_engine *eng, int mode);      /* test switches, a bit mask: 2 stress build of the
                                                              chaining ring, 4 displacement bytes read from HBM,

@@ -28,10 +28,10 @@ REG_DTYPE = np.dtype([("id", "<i4"), ("parent", "<i4"), ("rid", "<i4"), ("rev", 
 MZ_DTYPE = np.dtype([("hash", "<u4"), ("pos_strand", "<u4")])
 ANCHOR_DTYPE = np.dtype([("x", "<u8"), ("y", "<u8")])
 
-N_STAGES = 20
+N_STAGES = 22
 (STAGE_PACK, STAGE_SKETCH, STAGE_PARTITION, STAGE_PROBE, STAGE_COLLECT, STAGE_SORT, STAGE_SORT2, STAGE_CHAIN,
  STAGE_BACKTRACK, STAGE_REGIONS, STAGE_GATHER, STAGE_DP_PLAN, STAGE_DP_ALIGN, STAGE_DP_STITCH,
- STAGE_DP_POST, STAGE_DP_FILL, STAGE_DP_FILL_T1, STAGE_DP_FILL_T2, STAGE_DP_FILL_T3, STAGE_DP_EXT) = range(N_STAGES)
+ STAGE_DP_POST, STAGE_DP_FILL, STAGE_DP_FILL_T1, STAGE_DP_FILL_T2, STAGE_DP_FILL_T3, STAGE_DP_EXT, STAGE_DP_FILL_TM, STAGE_DP_LFILL) = range(N_STAGES)
 (DUMP_MINIMIZERS, DUMP_MZ_OFFSETS, DUMP_ANCHORS, DUMP_AN_OFFSETS, DUMP_CHAIN_F, DUMP_CHAIN_P,
  DUMP_CHAIN_V, DUMP_REGS, DUMP_REG_OFFSETS, DUMP_REP_LEN, DUMP_CIGARS) = range(1, 12)
 CONTRACT_DP, CONTRACT_CHAIN = 0, 1
@@ -445,7 +445,8 @@ class Engine:
         keys = ["minimizers", "probe_hits", "anchors", "chains", "regions", "gated_hits", "ambiguous_reads", "_",
                 "dp_segments", "dp_fill_tier1", "dp_fill_tier2", "dp_fill_handed_back",
                 "dp_fill_steps_t1", "dp_fill_steps_t2", "dp_fill_steps_t3", "dp_ext_cell_steps",
-                "dp_literal_big", "dp_literal_mid", "dp_long_gaps", "dp_literal_big_handed_back", "dp_long_extensions", "dp_fill_tier3"]
+                "dp_literal_big", "dp_literal_mid", "dp_long_gaps", "dp_literal_big_handed_back", "dp_long_extensions", "dp_fill_tier3",
+                "dp_fill_tier_mid", "dp_fill_steps_tm"]
         return dict(zip(keys, (int(x) for x in c)))
 
     def dump(self, what, dtype):

@@ -92,6 +92,7 @@ constexpr int EZ_RIGHT = 0x02, EZ_APPROX_MAX = 0x08, EZ_EXTZ_ONLY = 0x40, EZ_REV
 constexpr int SEG_NEEDS_BIG_WS = 0x10000;                 // Seg.flag, ours: the literal kernel needs its large workspace for this call
 constexpr int DP_NEG_INF = -0x40000000;
 constexpr int FILL_MAX_LEN = 511;     // longest target / query of a gap filling the banded kernel (k_fill.hip) takes
+constexpr int FILL_MID_CELLS = 42;    // the band between the 32- and the 64-cell tier: 21 lanes a segment, three segments a wave
 
 // one call of the two-piece affine kernel (ksw_extd2): left extension, a gap between two seeds,
 // right extension
@@ -197,8 +198,9 @@ struct Batch {
 	int64_t *stats;               // device counters (see mnc_engine_get_counters)
 	// ---- base-level alignment stage (contract MNC_CONTRACT_DP)
 	int contract;
-	int debug_route;              // test switch: 1 no packed extension kernel, 2 no packed gap-filling kernel, 4 no long tiers
-	int fill_pred;                // a gap filling tries the 32-lane tier when its bound is below fill_pred / 25 per base
+	int debug_route;              // test switch: 1 no packed extension kernel, 2 no packed gap-filling kernel, 4 no long tiers, 16 no 42-cell tier
+	int fill_pred;                // a gap filling tries the 32-cell tier when its bound is below fill_pred / 25 per base
+	int fill_pred_mid;            // ... and the 42-cell tier likewise
 	const uint32_t *seq4;         // contig bases, 4 bits each
 	const int64_t *seq_off;       // [n_contigs + 1]
 	int sc_a, sc_b, gap_q, gap_e, gap_q2, gap_e2, sc_ambi, zdrop, zdrop_inv, end_bonus, min_dp_max, min_ksw_len;
@@ -219,6 +221,7 @@ struct Batch {
 	int32_t *big_list;            // segment indices for the large-workspace launch
 	int32_t *fill_list1, *fill_list2, *fill_fb;   // banded gap-filling kernel: 32-lane tier, 64-lane tier, handed back
 	int32_t *fill_list3;                          // ... and the 128-cell tier
+	int32_t *fill_list_mid;                       // ... and the 42-cell tier between the first two: length dp_ctr[30], queue [54], anti-diagonals [52]
 	int32_t *ext_list1, *ext_list2;               // extension kernel: 32 / 64 lanes per segment
 	int32_t *ext_list3, *ext_list4;               // ... 128 / 256 cells (two / four per lane)
 	int32_t *gen_list;                            // the literal kernel's first pass

@@ -461,7 +461,7 @@ struct mnc_engine {
 	int contract = MNC_CONTRACT_DP;
 	Buf ca, ca_cnt, chain_dst, regdp, segs, cig_seg, cig_reg, dp_ctr, work_a, work_b, big_list, huge_list, reg_cnt, regs2;
 	SharedWs *ws = nullptr;                  // the device's alignment scratch (held during the alignment stage only)
-	Buf fill1, fill2, fill3, fill_fb, extp, mid_list, lfill, lext, bigfb, ext1, ext2, ext3, ext4, gen_list;
+	Buf fill1, fill2, fill3, fill_mid, fill_fb, extp, mid_list, lfill, lext, bigfb, ext1, ext2, ext3, ext4, gen_list;
 	size_t seg_cap_override = 0, cig_cap_override = 0;
 	int cur_max_read_len = 0;                // of the batch being classified (sizes the stitch kernel's LDS)
 	int debug = 0;                           // bit mask (tests): 2 stress build of the chaining ring, 4 displacement bytes read from HBM, 0x10000 alignment kernels one at a time (with stage timers), 0x200000 the stitch kernel reads bases in place (its form for regions beyond its LDS)
@@ -479,11 +479,11 @@ struct mnc_engine {
 };
 
 static const char *STAGE_NAME[MNC_N_STAGES] = { "pack", "sketch", "partition", "probe", "collect", "offsets", "sort", "chain", "backtrack", "regions", "gather",
-                                                "dp_plan", "dp_align", "dp_stitch", "dp_post", "dp_fill", "dp_fill_t1", "dp_fill_t2", "dp_fill_t3", "dp_ext" };
+                                                "dp_plan", "dp_align", "dp_stitch", "dp_post", "dp_fill", "dp_fill_t1", "dp_fill_t2", "dp_fill_t3", "dp_ext", "dp_fill_tm", "dp_lfill" };
 static const char *STAGE_KERNEL[MNC_N_STAGES] = {
 	"mnc_pack_bases", "mnc_sketch_minimizers", "mnc_partition_queries", "mnc_probe_buckets", "mnc_collect_hits",
 	"mnc_bin_reads", "mnc_expand_sort", "mnc_chain_dp_ring", "mnc_chain_tail", "mnc_regions_decide", "mnc_gather_hits",
-	"mnc_dp_plan", "mnc_dp_align", "mnc_dp_stitch", "mnc_regions_post", "mnc_dp_fillp", "mnc_dp_fillp<16>", "mnc_dp_fillp<32>", "mnc_dp_fillp<64>", "mnc_dp_extp" };
+	"mnc_dp_plan", "mnc_dp_align", "mnc_dp_stitch", "mnc_regions_post", "mnc_dp_fillp", "mnc_dp_fillp<16>", "mnc_dp_fillp<32>", "mnc_dp_fillp<64>", "mnc_dp_extp", "mnc_dp_fillp<21>", "mnc_dp_fill<64, 4, 2047, 1024>" };
 
 extern "C" const char *mnc_stage_name(int s) { return s >= 0 && s < MNC_N_STAGES ? STAGE_NAME[s] : nullptr; }
 extern "C" const char *mnc_stage_kernel(int s) { return s >= 0 && s < MNC_N_STAGES ? STAGE_KERNEL[s] : nullptr; }
@@ -574,7 +574,7 @@ extern "C" int mnc_device_name(int device, char *buf, size_t cap)
 template <class F> static void engine_bufs(mnc_engine *e, F f)
 {
 	Buf *all[] = { &e->gap_lut, &e->logf_lut, &e->logf_a_lut, &e->ca, &e->ca_cnt, &e->chain_dst, &e->regdp, &e->segs, &e->cig_seg, &e->cig_reg, &e->dp_ctr,
-	               &e->work_a, &e->work_b, &e->big_list, &e->huge_list, &e->reg_cnt, &e->regs2, &e->fill1, &e->fill2, &e->fill3, &e->fill_fb, &e->extp, &e->mid_list, &e->lfill, &e->lext, &e->bigfb, &e->ext1, &e->ext2, &e->ext3, &e->ext4, &e->gen_list, &e->in_bases, &e->in_offsets, &e->out_assign, &e->out_best, &e->out_nhits,
+	               &e->work_a, &e->work_b, &e->big_list, &e->huge_list, &e->reg_cnt, &e->regs2, &e->fill1, &e->fill2, &e->fill3, &e->fill_mid, &e->fill_fb, &e->extp, &e->mid_list, &e->lfill, &e->lext, &e->bigfb, &e->ext1, &e->ext2, &e->ext3, &e->ext4, &e->gen_list, &e->in_bases, &e->in_offsets, &e->out_assign, &e->out_best, &e->out_nhits,
 	               &e->packed, &e->mz, &e->hits, &e->hist_tm, &e->q_off, &e->qrec, &e->bhits, &e->bhit_cnt, &e->ambig, &e->mz_cnt, &e->hit_cnt, &e->rep_len, &e->an_cnt, &e->an_off,
 	               &e->n_chain, &e->n_reg, &e->best_mlen, &e->hist_sums, &e->hist_offs, &e->scan_sums, &e->hit_off, &e->a, &e->f, &e->p, &e->v, &e->t, &e->u,
 	               &e->chains_tmp, &e->regs, &e->regx, &e->k64a, &e->k64b, &e->tmp_i32, &e->gated,
@@ -804,13 +804,16 @@ static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream
 	// before the persistent workgroups of the gap-filling tiers take the wave slots
 	if (s2 != s0) launch_dp_lfill(B, B.lfill_list, 31, 61, B.fill_fb, 12, e->ws->lfill_p.as<uint8_t>(), DP_WG_LFILL, s2);
 	mark(MNC_STAGE_DP_FILL_T1, 0);
-	launch_dp_fill(B, 32, B.fill_list1, 10, 13, B.fill_list2, 11, B.fill_fb, 12, e->ws->fill_p.as<uint8_t>(), e->ws->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
-	mark(MNC_STAGE_DP_FILL_T1, 1), mark(MNC_STAGE_DP_FILL_T2, 0);
+	launch_dp_fill(B, 32, B.fill_list1, 10, 13, B.fill_list_mid, 30, B.fill_fb, 12, e->ws->fill_p.as<uint8_t>(), e->ws->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
+	mark(MNC_STAGE_DP_FILL_T1, 1), mark(MNC_STAGE_DP_FILL_TM, 0);
+	launch_dp_fill(B, FILL_MID_CELLS, B.fill_list_mid, 30, 54, B.fill_list2, 11, B.fill_fb, 12, e->ws->fill_p.as<uint8_t>(), e->ws->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
+	mark(MNC_STAGE_DP_FILL_TM, 1), mark(MNC_STAGE_DP_FILL_T2, 0);
 	launch_dp_fill(B, 64, B.fill_list2, 11, 14, B.fill_list3, 22, B.fill_fb, 12, e->ws->fill_p.as<uint8_t>(), e->ws->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
 	mark(MNC_STAGE_DP_FILL_T2, 1), mark(MNC_STAGE_DP_FILL_T3, 0);
 	launch_dp_fill(B, 128, B.fill_list3, 22, 23, B.fill_fb, 12, B.fill_fb, 12, e->ws->fill_p.as<uint8_t>(), e->ws->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
+	mark(MNC_STAGE_DP_FILL_T3, 1), mark(MNC_STAGE_DP_LFILL, 0);
 	if (s2 == s0) launch_dp_lfill(B, B.lfill_list, 31, 61, B.fill_fb, 12, e->ws->lfill_p.as<uint8_t>(), DP_WG_LFILL, s0);   // one kernel at a time (profiling)
-	mark(MNC_STAGE_DP_FILL_T3, 1), mark(MNC_STAGE_DP_EXT, 0);
+	mark(MNC_STAGE_DP_LFILL, 1), mark(MNC_STAGE_DP_EXT, 0);
 	// the classes with the longest queries first: few calls, each long -- at the end of the stream they would be a tail
 	// of a few busy waves; the short ones (most of the calls) drain evenly
 	for (int i = 7; i >= 0; --i)
@@ -901,8 +904,12 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	B.max_join_short = P.max_join_short, B.min_join_flank_sc = P.min_join_flank_sc, B.mask_level = P.mask_level;
 	B.pri_ratio = P.pri_ratio, B.min_join_flank_ratio = P.min_join_flank_ratio;
 	B.gap_lut = e->gap_lut.as<int32_t>(), B.logf_lut = e->logf_lut.as<float>(), B.logf_a_lut = e->logf_a_lut.as<float>(), B.logf_n = e->logf_n;
-	B.debug_route = e->debug >> 17 & 15;
-	B.fill_pred = (e->debug >> 8 & 0xff) ? (e->debug >> 8 & 0xff) : 34;     // tuning knob: debug bits 8-15
+	B.debug_route = (e->debug >> 17 & 15) | ((e->debug >> 22 & 1) << 4);
+	// tuning knobs: debug bits 8-15 and 24-30.  Trying a tier pays when the chance that its band can be proven outweighs
+	// the cost of running the next tier after it as well: 32 cells (1 unit) before 42 (4/3): above three in four;
+	// 42 before 64 (2 units): above two in three -- a read with 10 % errors scores 1.36 +- 0.13 per base
+	B.fill_pred = (e->debug >> 8 & 0xff) ? (e->debug >> 8 & 0xff) : 32;
+	B.fill_pred_mid = (e->debug >> 24 & 0x7f) ? (e->debug >> 24 & 0x7f) : 33;
 	B.contract = e->contract, B.seq4 = e->didx->seq4, B.seq_off = e->didx->seq_off;
 	B.sc_a = P.a, B.sc_b = P.b, B.gap_q = P.q, B.gap_e = P.e, B.gap_q2 = P.q2, B.gap_e2 = P.e2, B.sc_ambi = P.sc_ambi;
 	B.zdrop = P.zdrop, B.zdrop_inv = P.zdrop_inv, B.end_bonus = P.end_bonus, B.min_dp_max = P.min_dp_max, B.min_ksw_len = P.min_ksw_len;
@@ -1064,14 +1071,14 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 		ENS2(work_a, ns * 4); ENS2(work_b, ns * 4); ENS2(big_list, seg_cap * 4); ENS2(reg_cnt, (nr + 1) * 4); ENS2(regs2, ns * sizeof(mnc_reg_t));
 		const size_t ws_small = dp_align_ws_bytes(DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL), ws_big = dp_align_ws_bytes(DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG), ws_huge = dp_align_ws_bytes(DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE);
 		ENSW(dp_ws, ws_small * DP_WG_SMALL * 2); ENSW(dp_ws_big, ws_big * DP_WG_BIG); ENSW(dp_ws_huge, ws_huge * DP_WG_HUGE); ENS2(huge_list, seg_cap * 4); ENSW(dp_ws_mid, ws_small * DP_WG_MID); ENS2(mid_list, seg_cap * 4); ENS2(lfill, seg_cap * 4); ENSW(lfill_p, dp_lfill_p_slot() * DP_WG_LFILL); ENS2(lext, seg_cap * 4); ENS2(bigfb, seg_cap * 4); ENSW(lext_p, dp_lext_p_slot() * DP_WG_LEXT);
-		ENS2(fill1, seg_cap * 4); ENS2(fill2, seg_cap * 4); ENS2(fill3, seg_cap * 4); ENS2(fill_fb, seg_cap * 4); ENSW(fill_p, dp_fillp_slot() * DP_WG_FILL); ENSW(fill_cig, dp_fillp_cig_slot() * DP_WG_FILL); ENS2(extp, seg_cap * 4 * 8); ENSW(extp_p, dp_extp_slot() * DP_WG_EXT); ENSW(extp_cig, dp_extp_cig_slot() * DP_WG_EXT); ENS2(ext1, seg_cap * 4); ENS2(ext2, seg_cap * 4); ENS2(ext3, seg_cap * 4); ENS2(ext4, seg_cap * 4); ENS2(gen_list, seg_cap * 4); ENSW(ext_p, dp_fill_p_slot() * DP_WG_EXT);
+		ENS2(fill1, seg_cap * 4); ENS2(fill2, seg_cap * 4); ENS2(fill3, seg_cap * 4); ENS2(fill_mid, seg_cap * 4); ENS2(fill_fb, seg_cap * 4); ENSW(fill_p, dp_fillp_slot() * DP_WG_FILL); ENSW(fill_cig, dp_fillp_cig_slot() * DP_WG_FILL); ENS2(extp, seg_cap * 4 * 8); ENSW(extp_p, dp_extp_slot() * DP_WG_EXT); ENSW(extp_cig, dp_extp_cig_slot() * DP_WG_EXT); ENS2(ext1, seg_cap * 4); ENS2(ext2, seg_cap * 4); ENS2(ext3, seg_cap * 4); ENS2(ext4, seg_cap * 4); ENS2(gen_list, seg_cap * 4); ENSW(ext_p, dp_fill_p_slot() * DP_WG_EXT);
 #undef ENS2
 		if (rc2) return rc2;
 		B.ca = e->ca.as<Anchor>(), B.ca_cnt = e->ca_cnt.as<int32_t>(), B.chain_dst = e->chain_dst.as<int32_t>(), B.regdp = e->regdp.as<RegDP>();
 		B.segs = e->segs.as<Seg>(), B.seg_cap = (int64_t)seg_cap, B.cig_seg = e->cig_seg.as<uint32_t>(), B.cig_reg = e->cig_reg.as<uint32_t>();
 		B.cig_seg_cap = (int64_t)cig_cap, B.cig_reg_cap = (int64_t)cig_reg_cap, B.dp_ctr = e->dp_ctr.as<unsigned long long>();
 		B.big_list = e->big_list.as<int32_t>(), B.huge_list = e->huge_list.as<int32_t>(), B.reg_cnt = e->reg_cnt.as<int32_t>();
-		B.fill_list1 = e->fill1.as<int32_t>(), B.fill_list2 = e->fill2.as<int32_t>(), B.fill_list3 = e->fill3.as<int32_t>(), B.fill_fb = e->fill_fb.as<int32_t>();
+		B.fill_list1 = e->fill1.as<int32_t>(), B.fill_list2 = e->fill2.as<int32_t>(), B.fill_list3 = e->fill3.as<int32_t>(), B.fill_list_mid = e->fill_mid.as<int32_t>(), B.fill_fb = e->fill_fb.as<int32_t>();
 		B.ext_list1 = e->ext1.as<int32_t>(), B.ext_list2 = e->ext2.as<int32_t>(), B.ext_list3 = e->ext3.as<int32_t>(), B.ext_list4 = e->ext4.as<int32_t>(), B.gen_list = e->gen_list.as<int32_t>(), B.extp_list = e->extp.as<int32_t>(), B.mid_list = e->mid_list.as<int32_t>(), B.lfill_list = e->lfill.as<int32_t>(), B.lext_list = e->lext.as<int32_t>(), B.bigfb_list = e->bigfb.as<int32_t>();
 		B.lds0_state = DP_LDS0_STATE, B.lds0_p = DP_LDS0_P, B.lds0_cig = DP_LDS0_CIG;
 		int32_t *lists[2] = { e->work_a.as<int32_t>(), e->work_b.as<int32_t>() };
@@ -1275,6 +1282,7 @@ extern "C" int mnc_engine_get_counters(mnc_engine *e, int64_t *c, int n)
 		c[8] = (int64_t)d[0], c[9] = (int64_t)d[10], c[10] = (int64_t)d[11], c[11] = (int64_t)d[12];
 		if (n >= 16) c[12] = (int64_t)d[48], c[13] = (int64_t)d[49], c[14] = (int64_t)d[50], c[15] = (int64_t)d[51];
 		if (n >= 24) c[16] = (int64_t)d[6], c[17] = (int64_t)d[28], c[18] = (int64_t)d[31], c[19] = (int64_t)d[56], c[20] = (int64_t)d[62], c[21] = (int64_t)d[22];
+		if (n >= 24) c[22] = (int64_t)d[30], c[23] = (int64_t)d[52];       // the 42-cell tier: segments, anti-diagonals
 
 
 	}

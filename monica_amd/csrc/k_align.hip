@@ -368,7 +368,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 			Seg *sg = B.segs + s0;
 			const bool k_ok = n_seg <= r.cnt;                        // the region's scratch: one int per anchor
 			int n_tier[20] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-			unsigned long long work[4] = { 0, 0, 0, 0 };             // anti-diagonals given to the banded tiers; steps x cells of the packed extensions
+			unsigned long long work[5] = { 0, 0, 0, 0, 0 };          // anti-diagonals given to the banded tiers (32 / 64 / 128 cells; [4]: 42 cells); [3]: steps x cells of the packed extensions
 			auto emit = [&](Seg g) {
 				g.read = (int32_t)rd, g.reg = (int32_t)rslot, g.rid = rid, g.rev = rev;
 				g.n_cigar = 0, g.zdropped = 0, g.zdrop_code = 0, g.max = 0, g.max_t = g.max_q = -1, g.score = DP_NEG_INF, g.reach_end = 0, g.mqe_t = -1, g.cig_off = 0;
@@ -417,12 +417,18 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 					const int ad = g.tlen > g.qlen ? g.tlen - g.qlen : g.qlen - g.tlen;
 					// the 32-lane tier only when its proof has a chance: the bound a band of that width leaves
 					// against what a read with ~10 % errors scores (~1.28 per base)
-					int tier = (62 - ad) / 2 >= 12 ? 1 : (126 - ad) / 2 >= 8 ? 2 : 6;
+					int tier = (62 - ad) / 2 >= 12 ? 1 : (2 * FILL_MID_CELLS - 2 - ad) / 2 >= 12 ? 18 : (126 - ad) / 2 >= 8 ? 2 : 6;
 					if (tier == 1) {
 						const int bb = (62 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
 						const int g1 = B.gap_q + B.gap_e * (bb + 1), g2 = B.gap_q2 + B.gap_e2 * (bb + 1);
 						const int U = B.sc_a * (mn - bb - 1) - 2 * (g1 < g2 ? g1 : g2);
-						if (U * 25 > mn * B.fill_pred) tier = 2;          // trying costs one unit, failing two more: worth it below even odds
+						if (U * 25 > mn * B.fill_pred) tier = 18;         // trying costs one unit, failing more than that again: worth it below even odds
+					}
+					if (tier == 18) {                                     // the 42-cell tier (three segments a wave: 4/3 units) against the 64-cell one (2 units)
+						const int bb = (2 * FILL_MID_CELLS - 2 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
+						const int g1 = B.gap_q + B.gap_e * (bb + 1), g2 = B.gap_q2 + B.gap_e2 * (bb + 1);
+						const int U = B.sc_a * (mn - bb - 1) - 2 * (g1 < g2 ? g1 : g2);
+						if ((B.debug_route & 16) || bb < 8 || U * 25 > mn * B.fill_pred_mid) tier = 2;
 					}
 					if (tier == 2) {                                      // and the 64-lane tier likewise, against the literal kernel
 						const int bb = (126 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 						if (bb < 8 || U * 25 > mn * 32) tier = 0;
 					}
 					if (tier) g.big = 3 + tier, ++n_tier[tier - 1];          // not for the literal kernel's first pass
-					if (tier) work[tier == 1 ? 0 : tier == 2 ? 1 : 2] += (unsigned long long)(g.tlen + g.qlen - 1);
+					if (tier) work[tier == 1 ? 0 : tier == 2 ? 1 : tier == 18 ? 4 : 2] += (unsigned long long)(g.tlen + g.qlen - 1);
 				} else if (!(B.debug_route & 1) && g.big == 0 && g.kind != 1 && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= g.w && g.qlen <= g.w &&
 				           g.tlen + g.qlen - 1 <= 2 * FILL_MAX_LEN && g.qlen <= 256) {
 					// an extension whose matrix the band never clips, one cell per query base: the packed
@@ -500,13 +506,13 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 				g.zdrop = B.zdrop, g.flag = EZ_EXTZ_ONLY, g.ai = cnt1 - 1;
 				emit(g);
 			}
-			for (int k = 0; k < 4; ++k) if (work[k]) atomicAdd(&B.dp_ctr[48 + k], work[k]);
+			for (int k = 0; k < 5; ++k) if (work[k]) atomicAdd(&B.dp_ctr[48 + k], work[k]);
 			// the banded kernel's lists: one reservation per region and tier
 			for (int tier = 0; tier < 20; ++tier) {
 				if (n_tier[tier] == 0) continue;
 				const int ci = tier == 19 ? 62 : tier >= 17 ? 13 + tier : tier == 16 ? 28 : tier >= 8 ? 24 + tier : tier < 2 ? 10 + tier : tier < 4 ? 14 + tier : tier == 4 ? 20 : tier == 5 ? 22 : 18 + tier;   // 6 -> 24, 7 -> 25; 8.. -> 32..
 				unsigned long long fi = atomicAdd(&B.dp_ctr[ci], (unsigned long long)n_tier[tier]);
-				int32_t *lst = tier == 19 ? B.lext_list : tier == 18 ? B.lfill_list : tier == 16 ? B.mid_list : tier >= 8 ? B.extp_list + (int64_t)(tier - 8) * B.seg_cap
+				int32_t *lst = tier == 19 ? B.lext_list : tier == 18 ? B.lfill_list : tier == 17 ? B.fill_list_mid : tier == 16 ? B.mid_list : tier >= 8 ? B.extp_list + (int64_t)(tier - 8) * B.seg_cap
 				             : tier == 0 ? B.fill_list1 : tier == 1 ? B.fill_list2 : tier == 2 ? B.ext_list1 : tier == 3 ? B.ext_list2 : tier == 4 ? B.gen_list
 				             : tier == 5 ? B.fill_list3 : tier == 6 ? B.ext_list3 : B.ext_list4;
 				for (int k = 0; k < n_seg; ++k)
@@ -1590,6 +1596,7 @@ __global__ void mnc_dp_round(Batch B, int first)
 	B.dp_ctr[6] = 0, B.dp_ctr[7] = 0;
 	for (int k = 10; k < 48; ++k) B.dp_ctr[k] = 0;
 	B.dp_ctr[56] = B.dp_ctr[57] = B.dp_ctr[58] = B.dp_ctr[59] = B.dp_ctr[60] = B.dp_ctr[61] = B.dp_ctr[62] = B.dp_ctr[63] = 0;
+	B.dp_ctr[54] = 0;                     // queue of the 42-cell tier (its list length is [30], its anti-diagonals [52])
 	if (first) for (int k = 48; k < 64; ++k) B.dp_ctr[k] = 0;   // banded kernel: list lengths 10 / 11 / 12 (tier 1, tier 2, handed back), queues 13 / 14 / 15;
 	                                                 // extension kernel: lists 16 / 17, queues 18 / 19; literal kernel's first pass: list 20, queue 21; banded kernel, 128 cells: list 22, queue 23; extension kernel, 128 / 256 cells: lists 24 / 25, queues 26 / 27
 }

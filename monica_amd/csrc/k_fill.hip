@@ -422,7 +422,7 @@ __host__ __device__ __forceinline__ bool fillp_bias(int cells, int a, int bmis_a
 	return hi + bias < 2040 && lo + bias > -2040;
 }
 
-template <int LANES, int ODD, bool EDGE>
+template <int LANES, int ODD, bool EDGE, bool CAPTURE = true>
 __device__ __forceinline__ void fillp_step(const PkConst &K, const int r, const int L, const int rows_m1, const uint8_t *st, const uint8_t *sq,
                                            const int q, const int e, const int q2, const int e2,
                                            int &t_lo, int &tn, int &jn, uint32_t &T2, uint32_t &Q2, uint32_t &Hs,
@@ -430,20 +430,21 @@ __device__ __forceinline__ void fillp_step(const PkConst &K, const int r, const 
                                            uint32_t &nb1, uint32_t &nb2, uint32_t &acc)
 {
 	constexpr int SHR = LANES == 16 ? 0x111 : 0x138, SHL = LANES == 16 ? 0x101 : 0x130;   // row_shr:1 / wave_shr:1
+	constexpr bool SEG_EDGES = LANES != 16 && LANES != 64;      // segments inside the reach of a wave shift: their edge lanes get the neighbouring segment's
 	uint32_t vE, vE2, vF, vF2;
 	// nb1 / nb2 receive the neighbouring lane's register; the lane at the band's edge has no source and
 	// keeps what they held: PK_NEG, from before the loop
 	if (!ODD) {
 		nb1 = (uint32_t)__builtin_amdgcn_update_dpp((int)nb1, (int)E, SHR, 0xf, 0xf, false);
 		nb2 = (uint32_t)__builtin_amdgcn_update_dpp((int)nb2, (int)E2, SHR, 0xf, 0xf, false);
-		if (LANES == 32 && L == 0) nb1 = nb2 = PK_NEG;               // lane 32 got the other segment's
+		if (SEG_EDGES && L == 0) nb1 = nb2 = PK_NEG;                 // it got the other segment's
 		vE = __builtin_amdgcn_alignbit(E, nb1, 16), vE2 = __builtin_amdgcn_alignbit(E2, nb2, 16);
 		vF = F, vF2 = F2;
 		Q2 = __builtin_amdgcn_perm(Q2, (uint32_t)sq[jn], 0x05040100u), ++jn;   // (old low half -> high, the new base -> low)
 	} else {
 		nb1 = (uint32_t)__builtin_amdgcn_update_dpp((int)nb1, (int)F, SHL, 0xf, 0xf, false);
 		nb2 = (uint32_t)__builtin_amdgcn_update_dpp((int)nb2, (int)F2, SHL, 0xf, 0xf, false);
-		if (LANES == 32 && L == LANES - 1) nb1 = nb2 = PK_NEG;
+		if (SEG_EDGES && L == LANES - 1) nb1 = nb2 = PK_NEG;
 		vF = __builtin_amdgcn_alignbit(nb1, F, 16), vF2 = __builtin_amdgcn_alignbit(nb2, F2, 16);
 		vE = E, vE2 = E2;
 		T2 = __builtin_amdgcn_perm((uint32_t)st[tn], T2, 0x05040302u), ++tn;   // (old high half -> low, the new base -> high)
@@ -478,7 +479,7 @@ __device__ __forceinline__ void fillp_step(const PkConst &K, const int r, const 
 	const uint32_t d = pk_bfi(0x000f000fu, z, (mE ^ mF ^ mE2 ^ mF2) << 4);
 	// two steps' direction bytes per register: (even step: cells 2 L, 2 L + 1; odd step: likewise)
 	acc = ODD ? __builtin_amdgcn_perm(d, acc, 0x06040100u) : __builtin_amdgcn_perm(d, d, 0x0c0c0200u);
-	Sc = r == rows_m1 ? zt : Sc;
+	if (CAPTURE) Sc = r == rows_m1 ? zt : Sc;                  // the corner's score: only the blocks that hold a segment's last step look for it
 	Hs = zt;
 }
 
@@ -488,22 +489,30 @@ __device__ __forceinline__ void fillp_step(const PkConst &K, const int r, const 
 // ONE walk phase in which every lane backtracks a segment of its own: a walk is a few dozen
 // instructions per CIGAR column whatever the number of active lanes, and with 4 of 64 it used to cost
 // as much issue time as the fill itself.
-constexpr int FILLP_G = 16;
+// LANES need not divide 64: with 21 lanes a segment (a band of 42 cells) a wave holds three, lane 63 idles.
+constexpr int FILLP_G = 16, FILLP_G_MAX = 21;
+template <int LANES> struct FillpShape {
+	static constexpr int SEGS = 64 / LANES;
+	static constexpr int G = SEGS == 3 ? 21 : FILLP_G;                    // passes per group: 3 x 21 = 63 walks in one walk phase
+};
 constexpr int FILLP_BLOCKS = (2 * FILL_MAX_LEN + 15) / 16 + 1;           // 16-step blocks of direction bytes per pass
 constexpr size_t FILLP_PASS_BYTES = (size_t)FILLP_BLOCKS * 64 * 32;
-constexpr size_t FILLP_SLOT = FILLP_G * FILLP_PASS_BYTES;
+constexpr size_t FILLP_SLOT = FILLP_G_MAX * FILLP_PASS_BYTES;
 
 template <int LANES>
 __global__ __launch_bounds__(64) void mnc_dp_fillp(Batch B, const int32_t *list, int ctr_n, int ctr_q, int32_t *next_list, int ctr_next,
                                                    int32_t *fb_list, int ctr_fb, uint8_t *p_all, uint32_t *cig_all)
 {
-	constexpr int SEGS = 64 / LANES, W = 2 * LANES, PAD = 2 * W, SEQ = FILL_MAX_LEN + 1 + 4 * W;
+	constexpr int SEGS = FillpShape<LANES>::SEGS, G_MAX = FillpShape<LANES>::G, W = 2 * LANES, PAD = 2 * W, SEQ = FILL_MAX_LEN + 1 + 4 * W;
+	static_assert(SEGS * G_MAX <= 64, "one walk per lane");
 	__shared__ uint8_t s_t[SEGS][SEQ], s_q[SEGS][SEQ];        // bases at [PAD + i]; what lies around them feeds cells outside the matrix only
 	__shared__ __align__(16) uint8_t s_chunk[64][32];         // the walk: the 32 direction bytes a lane is reading from
 	__shared__ int32_t s_n[64], s_m[64], s_kmin[64], s_S[64], s_si[64], s_state[64];   // per segment of the group; state 0 none, 1 walk, 2 next tier, 3 literal kernel
 	__shared__ int32_t s_item[64];                             // the group's segments, shortest first
-	const int lane = threadIdx.x, sg = lane / LANES, L = lane % LANES, lead = sg * LANES;
-	const bool leader = L == 0;
+	const int lane = threadIdx.x;
+	const bool live = lane < SEGS * LANES;                     // lanes beyond the last whole segment compute along on segment 0's bases, unseen
+	const int sg = live ? lane / LANES : 0, L = live ? lane % LANES : 0, lead = sg * LANES;
+	const bool leader = live && L == 0;
 	const int a = B.sc_a, bmis = -B.sc_b, q = B.gap_q, e = B.gap_e, q2 = B.gap_q2, e2 = B.gap_e2;
 	PkConst K;
 	K.kmatch = pk_rep((a - bmis) << 4), K.kmis = pk_rep(bmis << 4), K.q8 = pk_rep(q << 4), K.q28 = pk_rep(q2 << 4), K.e8 = pk_rep(e << 4), K.e28 = pk_rep(e2 << 4);
@@ -515,7 +524,7 @@ __global__ __launch_bounds__(64) void mnc_dp_fillp(Batch B, const int32_t *list,
 	const int thr = B.zdrop_inv < B.zdrop ? B.zdrop_inv : B.zdrop;
 	// few segments (a micro-batch): fewer forward passes per group, so that every workgroup has some
 	int g_eff = (int)((n_items + (unsigned long long)gridDim.x * SEGS - 1) / ((unsigned long long)gridDim.x * SEGS));
-	g_eff = g_eff < 1 ? 1 : g_eff > FILLP_G ? FILLP_G : g_eff;
+	g_eff = g_eff < 1 ? 1 : g_eff > G_MAX ? G_MAX : g_eff;
 	for (;;) {
 		unsigned long long q0 = 0;
 		if (lane == 0) q0 = atomicAdd(&B.dp_ctr[ctr_q], (unsigned long long)(g_eff * SEGS));
@@ -542,7 +551,7 @@ __global__ __launch_bounds__(64) void mnc_dp_fillp(Batch B, const int32_t *list,
 		// ================================================ forward passes
 		for (int u = 0; u < g_eff; ++u) {
 			if (q0 + (unsigned long long)u * SEGS >= n_items) break;
-			const long long si = s_item[u * SEGS + sg];
+			const long long si = live ? s_item[u * SEGS + sg] : -1;
 			const bool has = si >= 0;
 			struct { int32_t tlen, qlen, ts, qs, read, rid, rev; } g = { 0, 0, 0, 0, 0, 0, 0 };
 			if (has) {
@@ -573,18 +582,31 @@ __global__ __launch_bounds__(64) void mnc_dp_fillp(Batch B, const int32_t *list,
 					s_q[sg][PAD + i] = (uint8_t)((g.rev ? 3 - c : c) & 3);
 				}
 			}
-			const bool seg_amb = (__ballot(ambiguous) & segmask) != 0;
+			const bool seg_amb = (__ballot(ambiguous && live) & segmask) != 0;
 			const bool to_fb = ok && seg_amb;                       // the literal kernel scores an ambiguous base
 			ok = ok && !seg_amb;
 			fill_order();
 			const int rows = ok ? n + m - 1 : 0;
 			int max_rows = (rows + 15) & ~15, edge_rows = ok ? ((-kmin > kmax ? -kmin : kmax) + 2 + 15) & ~15 : 0;
+			{
+				// the pass runs as long as its longest segment: the maximum over the segments' first lanes
+				int mr = 0, er = 0;
 #pragma unroll
-			for (int sft = LANES; sft < 64; sft <<= 1) {
-				const int o = __shfl_xor(max_rows, sft), oe = __shfl_xor(edge_rows, sft);
-				max_rows = max_rows > o ? max_rows : o, edge_rows = edge_rows > oe ? edge_rows : oe;
+				for (int s2 = 0; s2 < SEGS; ++s2) {
+					const int o = __builtin_amdgcn_readlane(max_rows, s2 * LANES), oe = __builtin_amdgcn_readlane(edge_rows, s2 * LANES);
+					mr = mr > o ? mr : o, er = er > oe ? er : oe;
+				}
+				max_rows = mr, edge_rows = er;
 			}
-			max_rows = __builtin_amdgcn_readfirstlane(max_rows), edge_rows = __builtin_amdgcn_readfirstlane(edge_rows);
+			// the first 16-step block that holds the last step of one of the pass's segments (they are sorted by length:
+			// the few blocks from there on compare every step with the segment's last)
+			int cap_from = ok ? (rows - 1) & ~15 : INT32_MAX;
+			{
+				int cf = INT32_MAX;
+#pragma unroll
+				for (int s2 = 0; s2 < SEGS; ++s2) { const int o = __builtin_amdgcn_readlane(cap_from, s2 * LANES); cf = cf < o ? cf : o; }
+				cap_from = cf < max_rows ? cf : max_rows;
+			}
 			if (edge_rows > max_rows) edge_rows = max_rows;
 			const int kmin_run = ok ? kmin : -2 * W;                // a segment that sits out: indices inside the arrays all the same
 			// one anti-diagonal per step; cells 2 L, 2 L + 1 of the band hold t = t0 + 2 L (+ 1)
@@ -604,6 +626,15 @@ __global__ __launch_bounds__(64) void mnc_dp_fillp(Batch B, const int32_t *list,
 				for (int k = 0; k < 8; ++k) {
 					fillp_step<LANES, 0, true>(K, r + 2 * k, L, rows_m1, st, sq, q, e, q2, e2, t_lo, tn, jn, T2, Q2, He, E, E2, F, F2, Sc, nbe1, nbe2, acc[k]);
 					fillp_step<LANES, 1, true>(K, r + 2 * k + 1, L, rows_m1, st, sq, q, e, q2, e2, t_lo, tn, jn, T2, Q2, Ho, E, E2, F, F2, Sc, nbf1, nbf2, acc[k]);
+				}
+				pblk[0] = make_uint4(acc[0], acc[1], acc[2], acc[3]), pblk[1] = make_uint4(acc[4], acc[5], acc[6], acc[7]);
+			}
+			for (; r < cap_from; r += 16, pblk += 2048 / 16) {
+				uint32_t acc[8];
+#pragma unroll
+				for (int k = 0; k < 8; ++k) {
+					fillp_step<LANES, 0, false, false>(K, r + 2 * k, L, rows_m1, st, sq, q, e, q2, e2, t_lo, tn, jn, T2, Q2, He, E, E2, F, F2, Sc, nbe1, nbe2, acc[k]);
+					fillp_step<LANES, 1, false, false>(K, r + 2 * k + 1, L, rows_m1, st, sq, q, e, q2, e2, t_lo, tn, jn, T2, Q2, Ho, E, E2, F, F2, Sc, nbf1, nbf2, acc[k]);
 				}
 				pblk[0] = make_uint4(acc[0], acc[1], acc[2], acc[3]), pblk[1] = make_uint4(acc[4], acc[5], acc[6], acc[7]);
 			}
@@ -1458,6 +1489,7 @@ void launch_dp_fill(const Batch &B, int lanes, const int32_t *list, int ctr_n, i
 {
 	// `lanes` = cells of the band
 	if (lanes == 32) hipLaunchKernelGGL((mnc_dp_fillp<16>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all, cig_all);
+	else if (lanes == FILL_MID_CELLS) hipLaunchKernelGGL((mnc_dp_fillp<FILL_MID_CELLS / 2>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all, cig_all);
 	else if (lanes == 64) hipLaunchKernelGGL((mnc_dp_fillp<32>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all, cig_all);
 	else hipLaunchKernelGGL((mnc_dp_fillp<64>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all, cig_all);
 }
