@@ -118,9 +118,12 @@ def main():
                                         first=first_read)
     engine = _capi.Engine(index, local_rank)
     engine.set_contract(_capi.CONTRACT_DP if args.contract == "dp" else _capi.CONTRACT_CHAIN)
-    if os.environ.get("MNC_FILL_PRED") or os.environ.get("MNC_DP_SERIAL") or os.environ.get("MNC_DEBUG_BITS"):
-        engine.set_debug(int(os.environ.get("MNC_FILL_PRED", "0")) << 8 | (0x10000 if os.environ.get("MNC_DP_SERIAL") else 0) |
-                         int(os.environ.get("MNC_DEBUG_BITS", "0"), 0))
+    # tuning / profiling switches (mnc_engine_set_debug): MNC_FILL_PRED, MNC_FILL_PRED_MID = the planner's thresholds for the
+    # 32- and the 42-cell tier; MNC_DP_SERIAL = the alignment kernels one at a time; MNC_DEBUG_BITS = anything else
+    env_debug = (int(os.environ.get("MNC_FILL_PRED", "0")) << 8 | int(os.environ.get("MNC_FILL_PRED_MID", "0")) << 24 |
+                 int(os.environ.get("MNC_DEBUG_BITS", "0"), 0))
+    if env_debug or os.environ.get("MNC_DP_SERIAL"):
+        engine.set_debug(env_debug | (0x10000 if os.environ.get("MNC_DP_SERIAL") else 0))
     n_genomes = info.n_genomes
     t_setup = time.time() - t0
 
@@ -210,7 +213,7 @@ def main():
     # each launch, on the stream it runs on -- the dominant kernel's own duration for `roofline`
     dp_kernel_ms = None
     if args.contract == "dp" and world == 1:
-        base_debug = int(os.environ.get("MNC_FILL_PRED", "0")) << 8
+        base_debug = env_debug
         engine.set_debug(base_debug | 0x10000)
         engine.set_profiling(True)
         engine.timings(reset=True)
@@ -220,7 +223,7 @@ def main():
         tk = engine.timings()
         engine.set_profiling(False)
         engine.set_debug(base_debug | (0x10000 if os.environ.get("MNC_DP_SERIAL") else 0))
-        dp_kernel_ms = {k: tk[k][0] / max(tk[k][1], 1) for k in ("dp_fill_t1", "dp_fill_t2", "dp_fill_t3", "dp_ext", "dp_stitch") if k in tk}
+        dp_kernel_ms = {k: tk[k][0] / max(tk[k][1], 1) for k in ("dp_fill_t1", "dp_fill_tm", "dp_fill_t2", "dp_fill_t3", "dp_lfill", "dp_ext", "dp_stitch") if k in tk}
 
     if rank != 0:
         if world > 1:
@@ -238,7 +241,8 @@ def main():
     # roof is that many cell updates/s.  Algorithmic work per launch = the anti-diagonals of the gap
     # fillings given to this tier (counter dp_fill_steps_t1) x 32 cells.
     VALU_PEAK = 256 * 4 * 2.4e9 / 4
-    FILLP_INSTR_PER_STEP = 597 / 16                      # vector instructions of the unrolled 16-step block (llvm-objdump)
+    FILLP_INSTR_PER_STEP = 568 / 16                      # vector instructions of the unrolled 16-step block of the main loop (ISA listing)
+    VALU_PEAK_GUIDE = 256 * 4 * 2.4e9 / 2                # the guide's nominal 2-cycle wave64 issue (MI355X_MICROARCH.md), for comparison
     roofline_dp = None
     if dp_kernel_ms and dp_kernel_ms.get("dp_fill_t1", 0) > 0 and counters.get("dp_fill_steps_t1", 0) > 0:
         cells = counters["dp_fill_steps_t1"] * 32
@@ -255,7 +259,12 @@ def main():
         except Exception:
             pass
         roofline_dp = {"bound": "valu", "kernel": "mnc_dp_fillp<16>", "achieved": round(ach, 2), "peak": round(peak, 1),
-                       "unit": "Gcell/s", "frac": round(ach / peak, 4), "traffic": fill_traffic,
+                       "unit": "Gcell/s", "frac": round(ach / peak, 4),
+                       # the same launch against the guide's nominal issue rate (one wave64 instruction per 2 cycles and SIMD):
+                       # the packed-16-bit / perm / DPP instructions this kernel is made of issue at half that (measured)
+                       "frac_guide_nominal": round(ach / (VALU_PEAK_GUIDE / instr_per_cell / 1e9), 4),
+                       "peak_guide_nominal": round(VALU_PEAK_GUIDE / instr_per_cell / 1e9, 1),
+                       "traffic": fill_traffic,
                        "algorithmic_cells_per_launch": int(cells), "avg_launch_ms": round(dp_kernel_ms["dp_fill_t1"], 4),
                        "vector_instructions_per_cell": round(instr_per_cell, 4),
                        "bound_note": "int16 pair arithmetic on the vector ALU: the roof is the VALU issue rate (6.144e11 wave64 "

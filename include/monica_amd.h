@@ -239,6 +239,10 @@ int mnc_engine_dump_tables(mnc_engine *eng, void *dst, int64_t cap_bytes, int64_
 #define MNC_DUMP_REP_LEN    10 /* int32 per read                                                */
 #define MNC_DUMP_CIGARS     11 /* uint32 len<<4|op (0 M, 1 I, 2 D) of the dumped regions, back to back
                                   (regs[i].n_cigar words each); MNC_CONTRACT_DP only              */
+#define MNC_DUMP_SEGS       12 /* the alignment stage's kernel calls (one per ksw_extd2 call of mm_align1): 24 int32
+                                  {read, region slot, kind 0 left ext / 1 gap / 2 right ext, rid, rev, ts, tlen,
+                                  qs, qlen, w, zdrop, flag, seed, kernel class, n_cigar, zdropped, zdrop_code,
+                                  max, max_t, max_q, score, reach_end, mqe_t, pad} + int64 CIGAR offset; tools only */
 typedef struct {
 	int32_t id, parent, rid, rev, rs, re, qs, qe, score, score0, cnt, as, mlen, blen,
 	        subsc, n_sub, mapq;

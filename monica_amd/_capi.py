@@ -33,7 +33,10 @@ N_STAGES = 22
  STAGE_BACKTRACK, STAGE_REGIONS, STAGE_GATHER, STAGE_DP_PLAN, STAGE_DP_ALIGN, STAGE_DP_STITCH,
  STAGE_DP_POST, STAGE_DP_FILL, STAGE_DP_FILL_T1, STAGE_DP_FILL_T2, STAGE_DP_FILL_T3, STAGE_DP_EXT, STAGE_DP_FILL_TM, STAGE_DP_LFILL) = range(N_STAGES)
 (DUMP_MINIMIZERS, DUMP_MZ_OFFSETS, DUMP_ANCHORS, DUMP_AN_OFFSETS, DUMP_CHAIN_F, DUMP_CHAIN_P,
- DUMP_CHAIN_V, DUMP_REGS, DUMP_REG_OFFSETS, DUMP_REP_LEN, DUMP_CIGARS) = range(1, 12)
+ DUMP_CHAIN_V, DUMP_REGS, DUMP_REG_OFFSETS, DUMP_REP_LEN, DUMP_CIGARS, DUMP_SEGS) = range(1, 13)
+SEG_DTYPE = np.dtype([(k, np.int32) for k in ("read", "reg", "kind", "rid", "rev", "ts", "tlen", "qs", "qlen", "w", "zdrop", "flag",
+                                              "ai", "big", "n_cigar", "zdropped", "zdrop_code", "max", "max_t", "max_q", "score",
+                                              "reach_end", "mqe_t", "pad")] + [("cig_off", np.int64)])
 CONTRACT_DP, CONTRACT_CHAIN = 0, 1
 
 # every symbol include/monica_amd.h declares (checked by tests/test_capi.py)

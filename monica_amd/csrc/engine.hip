@@ -1383,6 +1383,16 @@ extern "C" int mnc_engine_dump(mnc_engine *e, int what, void *dst, int64_t cap_b
 		if (!out.empty()) memcpy(dst, out.data(), out.size() * 4);
 		return MNC_OK;
 	}
+	case MNC_DUMP_SEGS: {
+		// the kernel calls of the alignment stage (every round's), as the plan kernel filed them and the kernels answered
+		if (B.contract != MNC_CONTRACT_DP || !e->dp_ctr.p) { set_error("segments exist under MNC_CONTRACT_DP only"); return MNC_ERR_ARG; }
+		unsigned long long n_seg = 0;
+		HIP_TRY(hipMemcpy(&n_seg, e->dp_ctr.p, 8, hipMemcpyDeviceToHost));
+		*n_bytes = (int64_t)(n_seg * sizeof(Seg));
+		if (!dst || cap_bytes < *n_bytes) return MNC_ERR_RANGE;
+		if (n_seg) HIP_TRY(hipMemcpy(dst, B.segs, (size_t)*n_bytes, hipMemcpyDeviceToHost));
+		return MNC_OK;
+	}
 	case MNC_DUMP_REP_LEN:
 		*n_bytes = (int64_t)nr * 4;
 		if (!dst || cap_bytes < *n_bytes) return MNC_ERR_RANGE;
