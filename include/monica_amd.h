@@ -267,6 +267,10 @@ void mnc_fastq_close(mnc_fastq *fq);
 /* parse the next batch: stops after max_reads records or once max_bases bases are held.
  * *n_reads = 0 at the end of the file. */
 int mnc_fastq_next(mnc_fastq *fq, uint32_t max_reads, uint64_t max_bases, uint32_t *n_reads);
+/* the current batch as a handle of its own (the reader goes on with fresh arrays): for a host loop that parses
+ * batch k + 1 while batch k is classified and batch k - 1 is written out.  Accessors, mnc_fastq_route and
+ * mnc_hitmap_update take it like the reader; mnc_fastq_close frees it. */
+int mnc_fastq_detach_batch(mnc_fastq *fq, mnc_fastq **out);
 const uint8_t *mnc_fastq_bases(const mnc_fastq *fq);     /* concatenated sequences (page-locked when a GPU is present) */
 const int64_t *mnc_fastq_offsets(const mnc_fastq *fq);   /* n_reads + 1, starts at 0 */
 const uint8_t *mnc_fastq_quals(const mnc_fastq *fq);     /* quality characters, same offsets */

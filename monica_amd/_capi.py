@@ -51,7 +51,7 @@ EXPORTS = [
     "mnc_engine_set_profiling", "mnc_engine_set_debug", "mnc_engine_set_contract", "mnc_index_set_host_tables", "mnc_engine_dump_tables",
     "mnc_comm_unique_id", "mnc_comm_init_rank", "mnc_comm_destroy", "mnc_allreduce_counts", "mnc_allgather_summaries", "mnc_engine_get_timings", "mnc_stage_name", "mnc_stage_kernel",
     "mnc_engine_get_counters", "mnc_engine_dump",
-    "mnc_fastq_open", "mnc_fastq_close", "mnc_fastq_next", "mnc_fastq_bases", "mnc_fastq_offsets",
+    "mnc_fastq_open", "mnc_fastq_close", "mnc_fastq_next", "mnc_fastq_detach_batch", "mnc_fastq_bases", "mnc_fastq_offsets",
     "mnc_fastq_quals", "mnc_fastq_title", "mnc_fastq_route",
     "mnc_hitmap_create", "mnc_hitmap_load", "mnc_hitmap_save", "mnc_hitmap_free", "mnc_hitmap_size",
     "mnc_hitmap_update", "mnc_hitmap_n_names", "mnc_hitmap_name", "mnc_host_alloc", "mnc_host_free",
@@ -152,6 +152,7 @@ def lib():
     sig("mnc_synth_reads_device", i32, [i32, vp, vp, u64, i64, i32, i32, i32, i32, i32, i32, vp, vp, vp])
     sig("mnc_fastq_open", i32, [cp, pp])
     sig("mnc_fastq_close", None, [vp])
+    sig("mnc_fastq_detach_batch", i32, [vp, pp])
     sig("mnc_fastq_next", i32, [vp, u32, u64, C.POINTER(u32)])
     sig("mnc_fastq_bases", vp, [vp])
     sig("mnc_fastq_offsets", vp, [vp])
@@ -492,11 +493,23 @@ class FastqReader:
     """Batches of a FASTQ file as flat arrays held by the library (``mnc_fastq``).  A malformed
     file raises ValueError with Biopython's message, as SeqIO.parse would."""
 
-    def __init__(self, path):
+    def __init__(self, path, _handle=None, _n=0):
+        if _handle is not None:                     # a detached batch (see detach)
+            self._h, self.n = _handle, _n
+            return
         h = C.c_void_p()
         check(lib().mnc_fastq_open(_b(path), C.byref(h)))
         self._h = h
         self.n = 0
+
+    def detach(self):
+        """The current batch as an object of its own; this reader goes on with the next batch in fresh
+        arrays.  The detached batch has the reader's accessors, `route`, and is what HitMap.update takes."""
+        h = C.c_void_p()
+        check(lib().mnc_fastq_detach_batch(self._h, C.byref(h)))
+        out = FastqReader(None, _handle=h, _n=self.n)
+        self.n = 0
+        return out
 
     def next(self, max_reads=100_000, max_bases=1 << 29):
         n = C.c_uint32(0)

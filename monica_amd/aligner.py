@@ -7,7 +7,6 @@ module instead of the reference one.  What changes is underneath: `index.map(rea
 (`mappy_compat.Aligner.map_batch`), and Biopython record objects become flat arrays.
 
 Deviations, all deliberate:
-* hits follow the chain-level contract (DESIGN.md section 1): no base-level DP, NM := blen - mlen;
 * index files under the reference's `indexN.mmi` names are this library's own format unless
   `mappy_compat.INDEX_FILE_FORMAT = "mmi"`; `index_loader` reads both, and minimap2's own files;
 * `n_threads=None` means 4 worker threads, not one per core: a thread only feeds the GPU.
@@ -15,6 +14,8 @@ Deviations, all deliberate:
 import itertools
 import os
 import pickle
+import queue
+import threading
 import time
 from collections import Counter
 from multiprocessing.dummy import Pool as ThreadPool
@@ -54,8 +55,8 @@ HITS_FILES_FOLDER = "hits"
 FOCUS_FILES_FOLDER = "focus"
 
 DEFAULT_THREADS = 4
-BATCH_READS = 100_000            # reads / bases per C-ABI call
-BATCH_BASES = 1 << 29
+BATCH_READS = 25_000             # reads / bases per C-ABI call: a sample file is worked through in batches of this size,
+BATCH_BASES = 1 << 27             # three at a time (one being parsed, one on the GPU, one being written out)
 TIMINGS = {}                      # per sample name: seconds spent per phase of aligner() (diagnostics)
 
 
@@ -171,29 +172,72 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
     clock["engine"] += t_engine
     clock["open"] += t_open
 
-    def classify_next():
-        t0 = time.perf_counter()
-        if not reader.next(BATCH_READS, BATCH_BASES):
-            return None
+    # Three batches are in flight: while the GPU classifies batch k, a helper thread parses batch k + 1 out of the file
+    # (mnc_fastq_next on all host threads) and another appends batch k - 1 to the routing folders (mnc_fastq_route,
+    # parallel pwrite).  The C-ABI calls release the GIL; every stage handles the batches in file order, so the
+    # carried hits, the appended files and the counts are what the one-batch-at-a-time loop gives.
+    parsed = queue.Queue(maxsize=2)                   # (batch | None | exception)
+    to_route = queue.Queue(maxsize=2)
+    stop = threading.Event()
+
+    def put(q, item):
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def parse_stage():
+        try:
+            while not stop.is_set():
+                t0 = time.perf_counter()
+                if not reader.next(BATCH_READS, BATCH_BASES):
+                    break
+                batch = reader.detach()
+                clock["parse"] += time.perf_counter() - t0
+                if not put(parsed, batch):
+                    batch.close()
+                    return
+            put(parsed, None)
+        except BaseException as e:                    # a malformed file: raised where the reference would raise
+            put(parsed, e)
+
+    def classify_batch(batch):
         t1 = time.perf_counter()
         try:
-            assign, best, nhits = engine.classify_ptr(reader.bases_ptr, reader.offsets_ptr, reader.n, mapping_quality)
+            assign, best, nhits = engine.classify_ptr(batch.bases_ptr, batch.offsets_ptr, batch.n, mapping_quality)
         except _capi.MncError as err:                     # HBM exhausted beside the cached parts: free what is idle, once
             if err.code != _capi.ERR_NOMEM:
                 raise
             mappy.release_idle(index.index)
-            assign, best, nhits = engine.classify_ptr(reader.bases_ptr, reader.offsets_ptr, reader.n, mapping_quality)
+            assign, best, nhits = engine.classify_ptr(batch.bases_ptr, batch.offsets_ptr, batch.n, mapping_quality)
         t2 = time.perf_counter()
-        state = sample_hits.update(reader, index.index, assign, best, nhits)
-        clock["parse"] += t1 - t0
+        state = sample_hits.update(batch, index.index, assign, best, nhits)
         clock["classify"] += t2 - t1
         clock["carry"] += time.perf_counter() - t2
         return state
 
+    def batches():
+        """Parsed batches in file order; re-raises what the parser raised."""
+        while True:
+            item = parsed.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+
+    parser = threading.Thread(target=parse_stage, name="mnc-parse", daemon=True)
+    parser.start()
+    router = None
+    route_error = []
     try:
         if not last_index:
-            while classify_next() is not None:
-                pass
+            for batch in batches():
+                classify_batch(batch)
+                batch.close()
             sample_hits.save(carried_file)
             return None
 
@@ -202,49 +246,66 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
         for path in paths:                                # the reference opens them all in 'a' mode
             if path:
                 open(path, "ab").close()
-        totals = np.zeros(0, dtype=np.int64)              # per contig name: counted amount, first read ordinal
-        first = np.zeros(0, dtype=np.int64)
+        acc = {"totals": np.zeros(0, dtype=np.int64),      # per contig name: counted amount, first read ordinal
+               "first": np.zeros(0, dtype=np.int64), "seen": 0}
         decoded = []                                      # per contig name: (tax_unit, accession, in focus)
-        seen_reads = 0
-        while True:
-            state = classify_next()
-            if state is None:
+
+        def route_stage():
+            try:
+                while True:
+                    item = to_route.get()
+                    if item is None:
+                        return
+                    batch, state, names_now = item
+                    try:
+                        if not route_error:
+                            _route_and_count(batch, state, names_now, decoded, acc, mode, overnight, focus_species, paths, clock)
+                    finally:
+                        batch.close()
+            except BaseException as e:
+                route_error.append(e)
+                stop.set()
+                while True:                               # let the producer finish: drain what it still hands over
+                    try:
+                        item = to_route.get(timeout=0.2)
+                    except queue.Empty:
+                        if not parser.is_alive():
+                            return
+                        continue
+                    if item is None:
+                        return
+                    item[0].close()
+
+        router = threading.Thread(target=route_stage, name="mnc-route", daemon=True)
+        router.start()
+        for batch in batches():
+            if route_error:
+                batch.close()
                 break
-            hits, mlen, name, tied = state[:, 0], state[:, 2], state[:, 3], state[:, 4]
-            mapped = (hits > 0) & (tied == 0)             # one hit, or best_hit found a unique minimum
-            names = sample_hits.names()
-            for ctg in names[len(decoded):]:
-                decoded.append(None if ":" not in ctg else _decode(ctg, overnight, focus_species))
-            used = np.unique(name[mapped])
-            for u in used:
-                if decoded[u] is None:
-                    raise IndexError("list index out of range")      # best[0].split(sep=':')[1]
-            if len(totals) < len(names):
-                totals = np.concatenate([totals, np.zeros(len(names) - len(totals), dtype=np.int64)])
-                first = np.concatenate([first, np.full(len(names) - len(first), -1, dtype=np.int64)])
-            dest = np.where(hits == 0, _capi.TO_UNMAPPED, np.where(mapped, _capi.TO_MAPPED, _capi.TO_AMBIGUOUS)).astype(np.uint8)
-            if focus_species and len(used):
-                in_focus = np.array([bool(d and d[2]) for d in decoded], dtype=bool)
-                dest[mapped & in_focus[np.where(mapped, name, 0)]] |= _capi.TO_FOCUS
-            t0 = time.perf_counter()
-            reader.route(dest, np.where(mapped, name, -1), [d[0] if d else "" for d in decoded], paths)
-            clock["route"] += time.perf_counter() - t0
-            if mode == "basic":
-                amount = np.ones(reader.n, dtype=np.int64)
-            elif mode == "query_length":
-                amount = np.diff(reader.offsets())
-            elif mode == "matching":
-                amount = mlen.astype(np.int64)
-            else:
-                amount = None
-            if amount is not None and len(used):
-                np.add.at(totals, name[mapped], amount[mapped])
-                ordinal = seen_reads + np.flatnonzero(mapped)
-                for u in used:
-                    if first[u] < 0:
-                        first[u] = ordinal[np.argmax(name[mapped] == u)]
-            seen_reads += reader.n
+            state = classify_batch(batch)
+            names_now = sample_hits.names()               # grows with the batches: the router sees this batch's view
+            if not put(to_route, (batch, state, names_now)):
+                batch.close()
+                break
+        to_route.put(None)
+        router.join()
+        router = None
+        if route_error:
+            raise route_error[0]
+        totals, first = acc["totals"], acc["first"]
     finally:
+        stop.set()
+        if router is not None:
+            to_route.put(None)
+            router.join()
+        while parser.is_alive():                          # unblock a parser waiting on a full queue
+            try:
+                item = parsed.get(timeout=0.05)
+                if item is not None and not isinstance(item, BaseException):
+                    item.close()
+            except queue.Empty:
+                pass
+        parser.join()
         t0 = time.perf_counter()
         reader.close()
         clock["close"] += time.perf_counter() - t0
@@ -256,9 +317,71 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
         os.remove(carried_file)
     print(f"{sample} done")
     t0 = time.perf_counter()
-    os.remove(sample)
+    _remove_consumed(sample)
     clock["remove"] += time.perf_counter() - t0
     return sample_alignment, sample_name
+
+
+def _remove_consumed(sample):
+    """`os.remove(sample)` of the reference (aligner.py:278).  Giving a gigabyte of page cache back takes ~0.1 s, as
+    long as classifying the reads in it: the file leaves the folder at once under a name monica's scan for `*fastq`
+    files does not match (one rename) and is unlinked by a thread of its own (not a daemon: it finishes before the
+    interpreter exits)."""
+    gone = os.path.join(os.path.dirname(sample), f".{os.path.basename(sample)}.{time.time_ns():x}.consumed")
+    try:
+        os.rename(sample, gone)
+    except OSError:
+        os.remove(sample)
+        return
+    threading.Thread(target=_unlink_quietly, args=(gone,), name="mnc-unlink").start()
+
+
+def _unlink_quietly(path):
+    try:
+        os.remove(path)
+    except OSError:
+        pass
+
+
+def _route_and_count(batch, state, names, decoded, acc, mode, overnight, focus_species, paths, clock):
+    """One classified batch on the last index part: its records to the routing folders (aligner.py:232-243, 265)
+    and its share of the counts (aligner.py:247-263)."""
+    hits, mlen, name, tied = state[:, 0], state[:, 2], state[:, 3], state[:, 4]
+    mapped = (hits > 0) & (tied == 0)             # one hit, or best_hit found a unique minimum
+    for ctg in names[len(decoded):]:
+        decoded.append(None if ":" not in ctg else _decode(ctg, overnight, focus_species))
+    used = np.unique(name[mapped])
+    for u in used:
+        if decoded[u] is None:
+            raise IndexError("list index out of range")      # best[0].split(sep=':')[1]
+    if len(acc["totals"]) < len(names):
+        acc["totals"] = np.concatenate([acc["totals"], np.zeros(len(names) - len(acc["totals"]), dtype=np.int64)])
+        acc["first"] = np.concatenate([acc["first"], np.full(len(names) - len(acc["first"]), -1, dtype=np.int64)])
+    totals, first = acc["totals"], acc["first"]
+    dest = np.where(hits == 0, _capi.TO_UNMAPPED, np.where(mapped, _capi.TO_MAPPED, _capi.TO_AMBIGUOUS)).astype(np.uint8)
+    if focus_species and len(used):
+        in_focus = np.array([bool(d and d[2]) for d in decoded], dtype=bool)
+        dest[mapped & in_focus[np.where(mapped, name, 0)]] |= _capi.TO_FOCUS
+    t0 = time.perf_counter()
+    batch.route(dest, np.where(mapped, name, -1), [d[0] if d else "" for d in decoded], paths)
+    clock["route"] += time.perf_counter() - t0
+    t0 = time.perf_counter()
+    if mode == "basic":
+        amount = np.ones(batch.n, dtype=np.int64)
+    elif mode == "query_length":
+        amount = np.diff(batch.offsets())
+    elif mode == "matching":
+        amount = mlen.astype(np.int64)
+    else:
+        amount = None
+    if amount is not None and len(used):
+        np.add.at(totals, name[mapped], amount[mapped])
+        ordinal = acc["seen"] + np.flatnonzero(mapped)
+        for u in used:
+            if first[u] < 0:
+                first[u] = ordinal[np.argmax(name[mapped] == u)]
+    acc["seen"] += batch.n
+    clock["count"] += time.perf_counter() - t0
 
 
 def _decode(ctg, overnight, focus_species):

@@ -909,7 +909,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	// the cost of running the next tier after it as well: 32 cells (1 unit) before 42 (4/3): above three in four;
 	// 42 before 64 (2 units): above two in three -- a read with 10 % errors scores 1.36 +- 0.13 per base
 	B.fill_pred = (e->debug >> 8 & 0xff) ? (e->debug >> 8 & 0xff) : 32;
-	B.fill_pred_mid = (e->debug >> 24 & 0x7f) ? (e->debug >> 24 & 0x7f) : 33;
+	B.fill_pred_mid = (e->debug >> 24 & 0x7f) ? (e->debug >> 24 & 0x7f) : 34;   // (tools/sweep_pred.sh: flat around 32 / 34)
 	B.contract = e->contract, B.seq4 = e->didx->seq4, B.seq_off = e->didx->seq_off;
 	B.sc_a = P.a, B.sc_b = P.b, B.gap_q = P.q, B.gap_e = P.e, B.gap_q2 = P.q2, B.gap_e2 = P.e2, B.sc_ambi = P.sc_ambi;
 	B.zdrop = P.zdrop, B.zdrop_inv = P.zdrop_inv, B.end_bonus = P.end_bonus, B.min_dp_max = P.min_dp_max, B.min_ksw_len = P.min_ksw_len;

@@ -269,6 +269,29 @@ extern "C" void mnc_fastq_close(mnc_fastq *fq)
 	delete fq;
 }
 
+// The current batch leaves the reader: a second handle (no file behind it) takes the batch's arrays, the
+// reader starts its next batch in fresh ones.  A host loop can then parse batch k + 1 while batch k is being
+// classified and batch k - 1 written to the routing folders; every accessor, mnc_fastq_route and
+// mnc_hitmap_update work on the detached handle as on the reader; mnc_fastq_close frees it.
+extern "C" int mnc_fastq_detach_batch(mnc_fastq *fq, mnc_fastq **out)
+{
+	if (!fq || !out) return MNC_ERR_ARG;
+	mnc_fastq *b = new (std::nothrow) mnc_fastq();
+	if (!b) return MNC_ERR_NOMEM;
+	b->in.fd = -1;
+	b->done = true;
+	b->bases.pinned = true;
+	b->n = fq->n;
+	std::swap(b->bases, fq->bases), std::swap(b->quals, fq->quals);
+	b->offsets.swap(fq->offsets), b->titles.swap(fq->titles), b->title_off.swap(fq->title_off);
+	b->id_len.swap(fq->id_len), b->id_off.swap(fq->id_off);
+	fq->bases.pinned = true;
+	fq->n = 0;
+	fq->offsets.assign(1, 0), fq->title_off.assign(1, 0);
+	*out = b;
+	return MNC_OK;
+}
+
 // ---------------------------------------------------------------- the four-line fast path
 // A batch of records that each take exactly four lines (title, sequence, '+' line, qualities -- what
 // every basecaller writes) is found and copied by all host threads at once: line ends by slices of
