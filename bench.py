@@ -354,6 +354,7 @@ def main():
     # host-buffer entry point -- H2D of the bases, all kernels, D2H of the decisions
     end_to_end = None
     if world == 1:
+        import threading
         hb = _capi.pinned_array(bases)
         engine.classify(hb, offsets, args.min_mapq)
         te = time.perf_counter()
@@ -364,9 +365,32 @@ def main():
         end_to_end = {"value": round(args.reads * n_e2e / de, 1), "unit": "reads/s", "ms_per_batch": round(de / n_e2e * 1e3, 3),
                       "what": "mnc_classify_batch on page-locked host buffers: H2D of 5 000 ASCII bytes per read, kernels, D2H",
                       "equal_to_resident": bool(np.array_equal(e_assign, assign))}
+        # ... with the next batch's copy started before this batch's call (mnc_engine_prefetch: a copy stream and a spare
+        # device buffer inside the ONE engine), as the aligner's loop does with the batch its parser thread has ready
+        hb2 = _capi.pinned_array(bases)
+        bufs = [hb, hb2]
+        engine.classify(bufs[0], offsets, args.min_mapq)
+        n_pf = 6
+
+        def announce(buf):                          # the spare device buffer is free once the running call has taken its own
+            while not engine.prefetch_ptr(buf.ctypes.data, offsets.ctypes.data, args.reads):
+                time.sleep(0.0005)
+
+        announce(bufs[0])
+        te = time.perf_counter()
+        for k in range(n_pf):
+            t = threading.Thread(target=announce, args=(bufs[(k + 1) & 1],)) if k + 1 < n_pf else None
+            if t:
+                t.start()
+            p_assign, _, _ = engine.classify_ptr(bufs[k & 1].ctypes.data, offsets.ctypes.data, args.reads, args.min_mapq)
+            if t:
+                t.join()
+        dp_ = time.perf_counter() - te
+        end_to_end["prefetch"] = {"value": round(args.reads * n_pf / dp_, 1), "unit": "reads/s", "ms_per_batch": round(dp_ / n_pf * 1e3, 3),
+                                  "equal_to_resident": bool(np.array_equal(p_assign, assign)),
+                                  "what": "one engine; the next batch's H2D copy runs behind this batch's kernels (mnc_engine_prefetch)"}
         # ... and as monica's thread pool drives it (aligner.py:65-111: one sample per thread): two engines of the same
         # device on two host threads, one's copies behind the other's kernels
-        import threading
         engine_b = _capi.Engine(index, local_rank)
         engine_b.set_contract(_capi.CONTRACT_DP if args.contract == "dp" else _capi.CONTRACT_CHAIN)
         hb_b = _capi.pinned_array(bases)

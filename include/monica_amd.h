@@ -146,6 +146,16 @@ int mnc_classify_batch(mnc_engine *eng, const uint8_t *bases, const int64_t *off
                        uint32_t n_reads, int min_mapq,
                        int32_t *out_assign, mnc_hit_t *out_best, int32_t *out_nhits);
 
+/* The next batch's bases on their way while this one is classified: starts the host-to-device copy of (bases,
+ * offsets) into a spare device buffer on a stream of its own and returns.  The mnc_classify_batch call that
+ * follows with the SAME pointers and n_reads skips its copy.  The reference has no counterpart -- its loop
+ * hands mappy one read at a time (aligner.py:191-193, 212-215); here a batch crosses PCIe (5 kB of ASCII per
+ * read), which would otherwise sit in front of every batch's kernels.  The caller leaves the host arrays as they
+ * are until that call (page-locked arrays, e.g. mnc_fastq's, make the copy asynchronous).  *started = 0 when a
+ * prefetched batch is still waiting for its call (one spare buffer): nothing was done.  Thread-safe against the
+ * engine's classifying thread. */
+int mnc_engine_prefetch(mnc_engine *eng, const uint8_t *bases, const int64_t *offsets, uint32_t n_reads, int *started);
+
 /* Same, all buffers device-resident (HBM), asynchronous on the engine's stream.
  * total_bases = offsets[n_reads].  d_counts (may be NULL) is an int64[n_genomes*3] table
  * that the call ADDS to: {reads, read bases, mlen} per genome, i.e. the three counting

@@ -46,7 +46,7 @@ EXPORTS = [
     "mnc_index_info", "mnc_index_contig_name", "mnc_index_contig_len", "mnc_index_contig_genome",
     "mnc_index_genome_name", "mnc_index_genome_len", "mnc_index_dump", "mnc_index_set_mid_occ",
     "mnc_engine_create", "mnc_engine_destroy", "mnc_engine_stream", "mnc_engine_device_bytes", "mnc_engine_set_index",
-    "mnc_classify_batch", "mnc_classify_device", "mnc_engine_sync", "mnc_engine_fetch_hits",
+    "mnc_classify_batch", "mnc_engine_prefetch", "mnc_classify_device", "mnc_engine_sync", "mnc_engine_fetch_hits",
     "mnc_counts", "mnc_best_hit",
     "mnc_engine_set_profiling", "mnc_engine_set_debug", "mnc_engine_set_contract", "mnc_index_set_host_tables", "mnc_engine_dump_tables",
     "mnc_comm_unique_id", "mnc_comm_init_rank", "mnc_comm_destroy", "mnc_allreduce_counts", "mnc_allgather_summaries", "mnc_engine_get_timings", "mnc_stage_name", "mnc_stage_kernel",
@@ -122,6 +122,7 @@ def lib():
     sig("mnc_engine_create", i32, [vp, i32, pp])
     sig("mnc_engine_destroy", None, [vp])
     sig("mnc_engine_stream", vp, [vp])
+    sig("mnc_engine_prefetch", i32, [vp, vp, vp, u32, C.POINTER(C.c_int)])
     sig("mnc_engine_set_index", i32, [vp, vp])
     sig("mnc_engine_device_bytes", i32, [vp, C.POINTER(C.c_int64)])
     sig("mnc_classify_batch", i32, [vp, vp, vp, u32, i32, vp, vp, vp])
@@ -371,6 +372,13 @@ class Engine:
                                        assign.ctypes.data, best.ctypes.data, nhits.ctypes.data))
         self.n_reads = n
         return assign, best, nhits
+
+    def prefetch_ptr(self, bases_ptr, offsets_ptr, n):
+        """Start the H2D copy of the NEXT batch (same pointers as its classify_ptr call will pass) behind the kernels
+        of the one being classified.  False: a prefetched batch is still waiting for its call; nothing was done."""
+        started = C.c_int(0)
+        check(lib().mnc_engine_prefetch(self._h, bases_ptr, offsets_ptr, n, C.byref(started)))
+        return bool(started.value)
 
     def classify_ptr(self, bases_ptr, offsets_ptr, n, min_mapq=60):
         """As classify(), on caller-owned host buffers given by address (e.g. a FastqReader batch)."""

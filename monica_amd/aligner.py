@@ -173,9 +173,10 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
     clock["open"] += t_open
 
     # Three batches are in flight: while the GPU classifies batch k, a helper thread parses batch k + 1 out of the file
-    # (mnc_fastq_next on all host threads) and another appends batch k - 1 to the routing folders (mnc_fastq_route,
-    # parallel pwrite).  The C-ABI calls release the GIL; every stage handles the batches in file order, so the
-    # carried hits, the appended files and the counts are what the one-batch-at-a-time loop gives.
+    # (mnc_fastq_next on all host threads) and starts its copy to the device, and another merges batch k - 1 into the
+    # carried hits and appends it to the routing folders (mnc_hitmap_update; mnc_fastq_route, parallel pwrite).  The
+    # C-ABI calls release the GIL; every stage handles the batches in file order, so the carried hits, the appended
+    # files and the counts are what the one-batch-at-a-time loop gives.
     parsed = queue.Queue(maxsize=2)                   # (batch | None | exception)
     to_route = queue.Queue(maxsize=2)
     stop = threading.Event()
@@ -197,6 +198,10 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
                     break
                 batch = reader.detach()
                 clock["parse"] += time.perf_counter() - t0
+                # the batch's bases cross PCIe behind the kernels of the batch before it (one spare buffer on the
+                # device: it is free again as soon as the batch announced last has started)
+                while not stop.is_set() and batch.n and not engine.prefetch_ptr(batch.bases_ptr, batch.offsets_ptr, batch.n):
+                    time.sleep(0.0005)
                 if not put(parsed, batch):
                     batch.close()
                     return
@@ -207,17 +212,14 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
     def classify_batch(batch):
         t1 = time.perf_counter()
         try:
-            assign, best, nhits = engine.classify_ptr(batch.bases_ptr, batch.offsets_ptr, batch.n, mapping_quality)
+            out = engine.classify_ptr(batch.bases_ptr, batch.offsets_ptr, batch.n, mapping_quality)
         except _capi.MncError as err:                     # HBM exhausted beside the cached parts: free what is idle, once
             if err.code != _capi.ERR_NOMEM:
                 raise
             mappy.release_idle(index.index)
-            assign, best, nhits = engine.classify_ptr(batch.bases_ptr, batch.offsets_ptr, batch.n, mapping_quality)
-        t2 = time.perf_counter()
-        state = sample_hits.update(batch, index.index, assign, best, nhits)
-        clock["classify"] += t2 - t1
-        clock["carry"] += time.perf_counter() - t2
-        return state
+            out = engine.classify_ptr(batch.bases_ptr, batch.offsets_ptr, batch.n, mapping_quality)
+        clock["classify"] += time.perf_counter() - t1
+        return out
 
     def batches():
         """Parsed batches in file order; re-raises what the parser raised."""
@@ -229,75 +231,68 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
                 raise item
             yield item
 
-    parser = threading.Thread(target=parse_stage, name="mnc-parse", daemon=True)
-    parser.start()
-    router = None
-    route_error = []
-    try:
-        if not last_index:
-            for batch in batches():
-                classify_batch(batch)
-                batch.close()
-            sample_hits.save(carried_file)
-            return None
-
+    paths = None
+    acc = {"totals": np.zeros(0, dtype=np.int64),          # per contig name: counted amount, first read ordinal
+           "first": np.zeros(0, dtype=np.int64), "seen": 0}
+    decoded = []                                          # per contig name: (tax_unit, accession, in focus)
+    if last_index:
         paths = [os.path.join(unmapped_folder, sample), os.path.join(ambiguous_folder, sample),
                  os.path.join(mapped_folder, sample), os.path.join(focus_folder, sample) if focus_species else None]
         for path in paths:                                # the reference opens them all in 'a' mode
             if path:
                 open(path, "ab").close()
-        acc = {"totals": np.zeros(0, dtype=np.int64),      # per contig name: counted amount, first read ordinal
-               "first": np.zeros(0, dtype=np.int64), "seen": 0}
-        decoded = []                                      # per contig name: (tax_unit, accession, in focus)
 
-        def route_stage():
-            try:
-                while True:
-                    item = to_route.get()
-                    if item is None:
-                        return
-                    batch, state, names_now = item
-                    try:
-                        if not route_error:
-                            _route_and_count(batch, state, names_now, decoded, acc, mode, overnight, focus_species, paths, clock)
-                    finally:
-                        batch.close()
-            except BaseException as e:
-                route_error.append(e)
-                stop.set()
-                while True:                               # let the producer finish: drain what it still hands over
-                    try:
-                        item = to_route.get(timeout=0.2)
-                    except queue.Empty:
-                        if not parser.is_alive():
-                            return
-                        continue
-                    if item is None:
-                        return
-                    item[0].close()
+    post_error = []
 
-        router = threading.Thread(target=route_stage, name="mnc-route", daemon=True)
-        router.start()
+    def post_stage():
+        """What follows a batch's classification, in file order: the hits carried between index parts
+        (`sample_hits`, aligner.py:196-203, 218-223) and, on the last part, routing and counting."""
+        try:
+            while True:
+                item = to_route.get()
+                if item is None:
+                    return
+                batch, (assign, best, nhits) = item
+                try:
+                    if not post_error:
+                        t2 = time.perf_counter()
+                        state = sample_hits.update(batch, index.index, assign, best, nhits)
+                        clock["carry"] += time.perf_counter() - t2
+                        if last_index:
+                            _route_and_count(batch, state, sample_hits.names(), decoded, acc, mode, overnight, focus_species, paths, clock)
+                finally:
+                    batch.close()
+        except BaseException as e:
+            post_error.append(e)
+            stop.set()
+            while True:                                   # let the producers finish: take what they still hand over
+                try:
+                    item = to_route.get(timeout=0.2)
+                except queue.Empty:
+                    if not parser.is_alive():
+                        return
+                    continue
+                if item is None:
+                    return
+                item[0].close()
+
+    parser = threading.Thread(target=parse_stage, name="mnc-parse", daemon=True)
+    poster = threading.Thread(target=post_stage, name="mnc-post", daemon=True)
+    parser.start()
+    poster.start()
+    try:
         for batch in batches():
-            if route_error:
+            if post_error:
                 batch.close()
                 break
-            state = classify_batch(batch)
-            names_now = sample_hits.names()               # grows with the batches: the router sees this batch's view
-            if not put(to_route, (batch, state, names_now)):
+            out = classify_batch(batch)
+            if not put(to_route, (batch, out)):
                 batch.close()
                 break
-        to_route.put(None)
-        router.join()
-        router = None
-        if route_error:
-            raise route_error[0]
-        totals, first = acc["totals"], acc["first"]
     finally:
+        to_route.put(None)
+        poster.join()
         stop.set()
-        if router is not None:
-            to_route.put(None)
-            router.join()
         while parser.is_alive():                          # unblock a parser waiting on a full queue
             try:
                 item = parsed.get(timeout=0.05)
@@ -309,6 +304,12 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
         t0 = time.perf_counter()
         reader.close()
         clock["close"] += time.perf_counter() - t0
+    if post_error:
+        raise post_error[0]
+    if not last_index:
+        sample_hits.save(carried_file)
+        return None
+    totals, first = acc["totals"], acc["first"]
     sample_alignment = dict()
     for u in sorted(np.flatnonzero(first >= 0), key=lambda u: first[u]):
         tax_unit, accession, _ = decoded[u]

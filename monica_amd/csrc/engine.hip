@@ -447,6 +447,16 @@ struct mnc_engine {
 	int logf_n = 0;
 	// inputs / outputs for the host-buffer entry point
 	Buf in_bases, in_offsets, out_assign, out_best, out_nhits;
+	// the next batch's bases on their way to the device while this one is classified (mnc_engine_prefetch)
+	Buf pf_bases_buf, pf_offsets_buf;
+	hipStream_t copy_stream = nullptr;
+	hipEvent_t ev_prefetch = nullptr;
+	std::mutex pf_mu;
+	bool pf_valid = false;
+	const uint8_t *pf_bases = nullptr;
+	const int64_t *pf_offsets = nullptr;
+	uint32_t pf_n = 0;
+	int64_t pf_total = 0;
 	// per base slot
 	Buf packed, mz, hits, hist_tm, q_off, qrec, bhits, bhit_cnt;
 	size_t q_cap_override = 0;              // grown after an overflowing batch
@@ -574,7 +584,7 @@ extern "C" int mnc_device_name(int device, char *buf, size_t cap)
 template <class F> static void engine_bufs(mnc_engine *e, F f)
 {
 	Buf *all[] = { &e->gap_lut, &e->logf_lut, &e->logf_a_lut, &e->ca, &e->ca_cnt, &e->chain_dst, &e->regdp, &e->segs, &e->cig_seg, &e->cig_reg, &e->dp_ctr,
-	               &e->work_a, &e->work_b, &e->big_list, &e->huge_list, &e->reg_cnt, &e->regs2, &e->fill1, &e->fill2, &e->fill3, &e->fill_mid, &e->fill_fb, &e->extp, &e->mid_list, &e->lfill, &e->lext, &e->bigfb, &e->ext1, &e->ext2, &e->ext3, &e->ext4, &e->gen_list, &e->in_bases, &e->in_offsets, &e->out_assign, &e->out_best, &e->out_nhits,
+	               &e->work_a, &e->work_b, &e->big_list, &e->huge_list, &e->reg_cnt, &e->regs2, &e->fill1, &e->fill2, &e->fill3, &e->fill_mid, &e->fill_fb, &e->extp, &e->mid_list, &e->lfill, &e->lext, &e->bigfb, &e->ext1, &e->ext2, &e->ext3, &e->ext4, &e->gen_list, &e->in_bases, &e->in_offsets, &e->pf_bases_buf, &e->pf_offsets_buf, &e->out_assign, &e->out_best, &e->out_nhits,
 	               &e->packed, &e->mz, &e->hits, &e->hist_tm, &e->q_off, &e->qrec, &e->bhits, &e->bhit_cnt, &e->ambig, &e->mz_cnt, &e->hit_cnt, &e->rep_len, &e->an_cnt, &e->an_off,
 	               &e->n_chain, &e->n_reg, &e->best_mlen, &e->hist_sums, &e->hist_offs, &e->scan_sums, &e->hit_off, &e->a, &e->f, &e->p, &e->v, &e->t, &e->u,
 	               &e->chains_tmp, &e->regs, &e->regx, &e->k64a, &e->k64b, &e->tmp_i32, &e->gated,
@@ -587,6 +597,7 @@ extern "C" void mnc_engine_destroy(mnc_engine *e)
 	if (!e) return;
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
+	if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
 	engine_bufs(e, [](Buf *b) { b->release(); });
 	if (e->ws) { (void)shared_ws(e->device, -1); e->ws = nullptr; }
 	for (int s = 0; s < MNC_N_STAGES; ++s) for (int k = 0; k < 2; ++k) if (e->ev[s][k]) (void)hipEventDestroy(e->ev[s][k]);
@@ -595,6 +606,8 @@ extern "C" void mnc_engine_destroy(mnc_engine *e)
 		if (e->ev_join[k]) (void)hipEventDestroy(e->ev_join[k]);
 	}
 	if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+	if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
+	if (e->ev_prefetch) (void)hipEventDestroy(e->ev_prefetch);
 	if (e->stream) (void)hipStreamDestroy(e->stream);
 	delete e;
 }
@@ -624,6 +637,8 @@ extern "C" int mnc_engine_create(mnc_index *idx, int device, mnc_engine **out)
 		if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming);
 	}
 	if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+	if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking);
+	if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_prefetch, hipEventDisableTiming);
 	if (he != hipSuccess) { set_error("stream creation failed: %s", hipGetErrorString(he)); mnc_engine_destroy(e); return MNC_ERR_HIP; }
 	for (int s = 0; s < MNC_N_STAGES; ++s) for (int k = 0; k < 2; ++k) (void)hipEventCreate(&e->ev[s][k]);
 	// gap cost: (int)(dd * .01 * avg_span) + (ilog2(dd) >> 1), evaluated in double exactly as
@@ -1184,6 +1199,35 @@ extern "C" int mnc_classify_device(mnc_engine *e, const uint8_t *d_bases, const 
 	return rc;
 }
 
+// ---------------------------------------------------------------- the next batch's bases, ahead of its call
+// Starts the copy of a batch's bases and offsets to a spare device buffer on a stream of its own and returns; the
+// mnc_classify_batch call that follows with the SAME pointers and read count finds them there and skips its copy --
+// so one batch's transfer runs behind the previous batch's kernels.  The caller leaves the host arrays alone in
+// between (page-locked ones, e.g. a FASTQ reader's, make the copy asynchronous).  *started = 0: a prefetched batch
+// is still waiting for its call (one spare buffer); nothing was done, the batch will be copied by its own call.
+// May be called from another host thread than the one classifying.
+extern "C" int mnc_engine_prefetch(mnc_engine *e, const uint8_t *bases, const int64_t *offsets, uint32_t n_reads, int *started)
+{
+	if (!e || !offsets || !started) return MNC_ERR_ARG;
+	*started = 0;
+	const int64_t total = offsets[n_reads] - offsets[0];
+	if (offsets[0] != 0 || total < 0 || (total > 0 && !bases)) { set_error("offsets must start at 0 and be non-decreasing"); return MNC_ERR_ARG; }
+	std::lock_guard<std::mutex> lk(e->pf_mu);
+	if (e->pf_valid) return MNC_OK;
+	HIP_TRY(hipSetDevice(e->device));
+	// the spare buffers may still be the source of the running batch's kernels only after a swap -- and a swap
+	// happens when a prefetched batch is taken, which clears pf_valid: they are free here
+	int rc = e->pf_bases_buf.ensure((size_t)total + 32);
+	if (!rc) rc = e->pf_offsets_buf.ensure(((size_t)n_reads + 1) * 8);
+	if (rc) return rc;
+	if (total > 0) HIP_TRY(hipMemcpyAsync(e->pf_bases_buf.p, bases, (size_t)total, hipMemcpyHostToDevice, e->copy_stream));
+	HIP_TRY(hipMemcpyAsync(e->pf_offsets_buf.p, offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, e->copy_stream));
+	HIP_TRY(hipEventRecord(e->ev_prefetch, e->copy_stream));
+	e->pf_valid = true, e->pf_bases = bases, e->pf_offsets = offsets, e->pf_n = n_reads, e->pf_total = total;
+	*started = 1;
+	return MNC_OK;
+}
+
 // ---------------------------------------------------------------- one batch, host buffers
 extern "C" int mnc_classify_batch(mnc_engine *e, const uint8_t *bases, const int64_t *offsets, uint32_t n_reads,
                                   int min_mapq, int32_t *out_assign, mnc_hit_t *out_best, int32_t *out_nhits)
@@ -1200,15 +1244,31 @@ extern "C" int mnc_classify_batch(mnc_engine *e, const uint8_t *bases, const int
 	}
 	HIP_TRY(hipSetDevice(e->device));
 	const size_t nr = n_reads;
-	int rc = e->in_bases.ensure((size_t)total + 32);
-	if (!rc) rc = e->in_offsets.ensure((nr + 1) * 8);
-	if (!rc) rc = e->out_assign.ensure((nr + 1) * 4);
+	int rc = e->out_assign.ensure((nr + 1) * 4);
 	if (!rc) rc = e->out_best.ensure((nr + 1) * sizeof(mnc_hit_t));
 	if (!rc) rc = e->out_nhits.ensure((nr + 1) * 4);
 	if (rc) return rc;
 	hipStream_t st = e->stream;
-	if (total > 0) HIP_TRY(hipMemcpyAsync(e->in_bases.p, bases, (size_t)total, hipMemcpyHostToDevice, st));
-	HIP_TRY(hipMemcpyAsync(e->in_offsets.p, offsets, (nr + 1) * 8, hipMemcpyHostToDevice, st));
+	bool prefetched = false;
+	{
+		std::lock_guard<std::mutex> lk(e->pf_mu);
+		if (e->pf_valid) {
+			if (e->pf_bases == bases && e->pf_offsets == offsets && e->pf_n == n_reads && e->pf_total == total) {
+				// this batch is on the device already (or on its way): its buffers become the input, the old input the spare
+				std::swap(e->in_bases, e->pf_bases_buf), std::swap(e->in_offsets, e->pf_offsets_buf);
+				HIP_TRY(hipStreamWaitEvent(st, e->ev_prefetch, 0));
+				prefetched = true;
+			} else HIP_TRY(hipStreamSynchronize(e->copy_stream));      // another batch was announced: let its copy finish, then forget it
+			e->pf_valid = false;
+		}
+	}
+	if (!prefetched) {
+		rc = e->in_bases.ensure((size_t)total + 32);
+		if (!rc) rc = e->in_offsets.ensure((nr + 1) * 8);
+		if (rc) return rc;
+		if (total > 0) HIP_TRY(hipMemcpyAsync(e->in_bases.p, bases, (size_t)total, hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemcpyAsync(e->in_offsets.p, offsets, (nr + 1) * 8, hipMemcpyHostToDevice, st));
+	}
 	rc = mnc_classify_device(e, e->in_bases.as<uint8_t>(), e->in_offsets.as<int64_t>(), n_reads, total, max_len, min_mapq,
 	                         e->out_assign.as<int32_t>(), e->out_best.as<mnc_hit_t>(), e->out_nhits.as<int32_t>(), nullptr);
 	if (rc) return rc;

@@ -243,3 +243,44 @@ def test_golden_fixture_on_the_hip_path(capi):
     for k in g["regs"].dtype.names:
         assert np.array_equal(regs[k], g["regs"][k]), k
     eng.close()
+
+
+def test_prefetched_batches_equal_plain_calls(capi):
+    """mnc_engine_prefetch: the next batch's bases copied behind the running batch's kernels.  Whatever the order of
+    announcements -- the batch that is classified next, another one, none, an announcement refused because one is
+    pending -- the results are those of plain mnc_classify_batch calls."""
+    import threading
+    names, seqs = synth.genome_set(4, min_len=150_000, max_len=250_000)
+    idx = capi.Index.from_seqs(names, seqs)
+    eng = capi.Engine(idx, 0)
+    batches = []
+    for k, (n, L) in enumerate(((3000, 2000), (500, 5000), (2500, 1500), (1, 3000))):
+        b, o, _ = synth.reads(seqs, n, L, seed=900 + k)
+        batches.append((capi.pinned_array(b), np.ascontiguousarray(o)))
+    plain = [eng.classify(b, o, 60) for b, o in batches]
+
+    def same(got, want):
+        return all(np.array_equal(g, w) for g, w in zip(got[:1] + got[2:], want[:1] + want[2:])) and \
+            all(np.array_equal(got[1][k], want[1][k]) for k in capi.HIT_DTYPE.names)
+
+    # announced, then classified: in a row, and with the announcement of the next one while a call runs
+    assert eng.prefetch_ptr(batches[0][0].ctypes.data, batches[0][1].ctypes.data, len(batches[0][1]) - 1)
+    assert not eng.prefetch_ptr(batches[1][0].ctypes.data, batches[1][1].ctypes.data, len(batches[1][1]) - 1)   # one spare buffer
+    for k, (b, o) in enumerate(batches):
+        nxt = batches[k + 1] if k + 1 < len(batches) else None
+        done = []
+
+        def announce():
+            while nxt is not None and not eng.prefetch_ptr(nxt[0].ctypes.data, nxt[1].ctypes.data, len(nxt[1]) - 1):
+                pass
+            done.append(1)
+        t = threading.Thread(target=announce)
+        t.start()
+        got = eng.classify_ptr(b.ctypes.data, o.ctypes.data, len(o) - 1, 60)
+        t.join()
+        assert same(got, plain[k]), f"batch {k}"
+    # an announced batch that is NOT the next one classified: dropped, the call copies its own
+    assert eng.prefetch_ptr(batches[2][0].ctypes.data, batches[2][1].ctypes.data, len(batches[2][1]) - 1)
+    assert same(eng.classify_ptr(batches[1][0].ctypes.data, batches[1][1].ctypes.data, len(batches[1][1]) - 1, 60), plain[1])
+    assert same(eng.classify(batches[2][0], batches[2][1], 60), plain[2])
+    eng.close()
