@@ -55,8 +55,10 @@ HITS_FILES_FOLDER = "hits"
 FOCUS_FILES_FOLDER = "focus"
 
 DEFAULT_THREADS = 4
-BATCH_READS = 25_000             # reads / bases per C-ABI call: a sample file is worked through in batches of this size,
-BATCH_BASES = 1 << 27             # three at a time (one being parsed, one on the GPU, one being written out)
+# reads / bases per C-ABI call: a sample file is worked through in batches of this size, three at a time (one being
+# parsed, one on the GPU, one being written out)
+BATCH_READS = int(os.environ.get("MONICA_AMD_BATCH_READS", "25000"))
+BATCH_BASES = 1 << 27
 TIMINGS = {}                      # per sample name: seconds spent per phase of aligner() (diagnostics)
 
 

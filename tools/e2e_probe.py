@@ -1,0 +1,61 @@
+"""Where the PCIe-inclusive call spends its time beyond the resident one (python tools/e2e_probe.py)."""
+import sys, time
+import numpy as np
+sys.path.insert(0, ".")
+import torch
+from monica_amd import _capi, synth
+
+n = 100_000
+names, seqs = synth.genome_set(20)
+idx = _capi.Index.from_seqs(names, seqs)
+eng = _capi.Engine(idx, 0)
+bases, offsets, _ = synth.reads(seqs, n, 5000, seed=synth.SEED_READS + 2)
+hb, hb2 = _capi.pinned_array(bases), _capi.pinned_array(bases)
+dev = torch.device("cuda:0")
+d_b, d_o = torch.from_numpy(bases).to(dev), torch.from_numpy(offsets).to(dev)
+d_a = torch.empty(n, dtype=torch.int32, device=dev)
+d_best = torch.zeros(n * 4, dtype=torch.int32, device=dev)
+d_nh = torch.zeros(n, dtype=torch.int32, device=dev)
+
+
+def t(f, k=4):
+    f()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        f()
+    return (time.perf_counter() - t0) / k * 1e3
+
+
+def resident():
+    eng.classify_device(d_b.data_ptr(), d_o.data_ptr(), n, int(offsets[-1]), 5000, 60, d_a.data_ptr(), d_best.data_ptr(), d_nh.data_ptr(), 0)
+    eng.sync()
+
+
+def plain():
+    eng.classify_ptr(hb.ctypes.data, offsets.ctypes.data, n, 60)
+
+
+def copy_only():
+    assert eng.prefetch_ptr(hb.ctypes.data, offsets.ctypes.data, n)
+    t0 = time.perf_counter()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng.classify_ptr(hb2.ctypes.data, offsets.ctypes.data, n, 60)     # drops the announcement
+    return dt
+
+
+def prefetched_done():
+    assert eng.prefetch_ptr(hb.ctypes.data, offsets.ctypes.data, n)
+    time.sleep(0.03)                                                   # the copy has finished
+    t0 = time.perf_counter()
+    eng.classify_ptr(hb.ctypes.data, offsets.ctypes.data, n, 60)
+    return time.perf_counter() - t0
+
+
+print("resident ms", round(t(resident), 2))
+print("plain host-buffer call ms", round(t(plain), 2))
+print("H2D of the bases alone ms (device sync)", [round(copy_only() * 1e3, 2) for _ in range(3)])
+print("call on a batch whose copy has finished ms", [round(prefetched_done() * 1e3, 2) for _ in range(3)])
+t0 = time.perf_counter()
+a = np.empty(n, dtype=np.int32); b = np.zeros(n, dtype=_capi.HIT_DTYPE); c = np.zeros(n, dtype=np.int32)
+print("output arrays ms", round((time.perf_counter() - t0) * 1e3, 3))
