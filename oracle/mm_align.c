@@ -18,10 +18,10 @@
  * monica reads hit.mapq, hit.NM (= blen - mlen + n_ambi) and hit.mlen from the result
  * (aligner.py:194-195, 216-217) and counts mlen in 'matching' mode (aligner.py:259-263).
  *
- * Not restated: the inversion alignment between the two halves of a region split by an
- * inversion-like Z-drop (mm_align1_inv).  Such a hit carries MAPQ 0 by construction and can
- * never pass monica's fixed gate of 60; the inversion TEST itself (which lowers the Z-drop
- * threshold of the second pass and of the next region's left extension) is restated.
+ * The inversion alignment between the two halves of a region split by an inversion-like Z-drop
+ * (mm_align1_inv) is restated too (align1_inv below): its hit has MAPQ 0 and cannot pass monica's
+ * gate of 60 itself, but it takes part in the second hierarchy pass (it may become a secondary of
+ * another primary and raise that one's dp_max2 / n_sub).
  *
  * PARITY UNPINNED (mm_oracle.h): none of this could be run against the real library here.
  */
@@ -544,6 +544,65 @@ static void align1(const orc_opt_t *opt, const orc_index *mi, int qlen, uint8_t 
 	free(tseq);
 }
 
+/* ------------------------------------------------------------------ the inversion between two halves */
+
+/* mm_align1_inv: r1 / r2 are the two halves of a region split by a Z-drop whose inversion test was
+ * positive (r2 carries split_inv), both aligned.  The stretch between them -- query [r1.qe, r2.qs) on the
+ * halves' strand, target [r1.re, r2.rs) -- is aligned on the OTHER strand of the query: a striped
+ * Smith-Waterman on the reversed sequences (ksw_ll_i16) finds where the best local alignment starts,
+ * an extension from there (ksw_extd2, band (int)(bw * 1.5), end bonus -1, Z-drop `zdrop`) gives the
+ * alignment.  qcat = the read's two strands back to back (forward, then reverse complement), as
+ * mm_align_skeleton lays them out: with the start found in the profile's padding (orc_ksw_ll_i16) the
+ * query offset is negative and the reference reads up to seven bases in front of the stretch -- inside
+ * this array, except at its very beginning, where the restatement gives up (the reference reads
+ * foreign memory there). */
+static int align1_inv(const orc_opt_t *opt, const orc_index *mi, int qlen, const uint8_t *qcat, const orc_reg_t *r1, const orc_reg_t *r2,
+                      orc_reg_t *r_inv, cig_t *cig, orc_extz_t *ez)
+{
+	int tl, ql, score, q_off, t_off, ret = 0;
+	int64_t q_base;
+	uint8_t *tseq, *trev, *qrev;
+	int8_t mat[25];
+	memset(r_inv, 0, sizeof(*r_inv));
+	if (!(r1->flags & ORC_REG_SPLIT_L) || !(r2->flags & ORC_REG_SPLIT_R)) return 0;
+	if (r1->id != r1->parent && r1->parent != ORC_PARENT_TMP_PRI) return 0;
+	if (r2->id != r2->parent && r2->parent != ORC_PARENT_TMP_PRI) return 0;
+	if (r1->rid != r2->rid || r1->rev != r2->rev) return 0;
+	ql = r1->rev ? r1->qs - r2->qe : r2->qs - r1->qe;
+	tl = r2->rs - r1->re;
+	if (ql < opt->min_chain_score || ql > opt->max_gap) return 0;
+	if (tl < opt->min_chain_score || tl > opt->max_gap) return 0;
+	orc_gen_simple_mat(5, mat, (int8_t)opt->a, (int8_t)opt->b, (int8_t)opt->sc_ambi);
+	tseq = (uint8_t*)malloc((size_t)tl * 2 + (size_t)ql);
+	trev = tseq + tl, qrev = trev + tl;
+	orc_index_getseq(mi, (uint32_t)r1->rid, (uint32_t)r1->re, (uint32_t)r2->rs, tseq);
+	q_base = r1->rev ? (int64_t)r2->qe : (int64_t)qlen + (qlen - r2->qs);     /* the other strand's copy of the stretch */
+	{
+		int i;
+		for (i = 0; i < ql; ++i) qrev[i] = qcat[q_base + ql - 1 - i];
+		for (i = 0; i < tl; ++i) trev[i] = tseq[tl - 1 - i];
+	}
+	score = orc_ksw_ll_i16(ql, qrev, tl, trev, 5, mat, opt->q, opt->e, &q_off, &t_off);
+	if (score < opt->min_dp_max) goto end_inv;
+	q_off = ql - (q_off + 1), t_off = tl - (t_off + 1);
+	if (q_base + q_off < 0) goto end_inv;                      /* in front of the read's first base: see above */
+	align_pair(opt, ql - q_off, qcat + q_base + q_off, tl - t_off, tseq + t_off, mat, (int)(opt->bw * 1.5), -1, opt->zdrop, ORC_EZ_EXTZ_ONLY, ez);
+	if (ez->n_cigar == 0) goto end_inv;
+	append_cigar(cig, ez->n_cigar, ez->cigar);
+	r_inv->flags = ORC_REG_HAS_DP | ORC_REG_INV;
+	r_inv->dp_score = (int32_t)ez->max;
+	r_inv->id = -1, r_inv->parent = ORC_PARENT_UNSET;
+	r_inv->rev = !r1->rev, r_inv->rid = r1->rid;
+	if (r_inv->rev == 0) r_inv->qs = r2->qe + q_off, r_inv->qe = r_inv->qs + ez->max_q + 1;
+	else r_inv->qe = r2->qs - q_off, r_inv->qs = r_inv->qe - (ez->max_q + 1);
+	r_inv->rs = r1->re + t_off, r_inv->re = r_inv->rs + ez->max_t + 1;
+	update_extra(r_inv, cig, qcat + q_base + q_off, tseq + t_off, mat, (int8_t)opt->q, (int8_t)opt->e);
+	ret = 1;
+end_inv:
+	free(tseq);
+	return ret;
+}
+
 /* ------------------------------------------------------------------ all regions of a read */
 
 static int cmp_sort_key(const void *pa, const void *pb)
@@ -590,7 +649,24 @@ orc_reg_t *orc_align_regs(const orc_index *mi, const orc_opt_t *opt, int qlen, c
 			memset(&cigs[i + 1], 0, sizeof(cig_t));
 			++n_regs;
 		}
-		/* mm_align1_inv (the inversion between regs[i-1] and regs[i]) is not restated: see the header */
+		if (i > 0 && (regs[i].flags & ORC_REG_SPLIT_INV)) {     /* the inversion between regs[i-1] and regs[i] */
+			orc_reg_t r_inv;
+			cig_t c_inv = { 0, 0, 0 };
+			if (align1_inv(opt, mi, qlen, qseq0[0], &regs[i - 1], &regs[i], &r_inv, &c_inv, &ez)) {
+				if (n_regs == m_regs) {
+					m_regs = m_regs ? m_regs << 1 : 4;
+					regs = (orc_reg_t*)realloc(regs, (size_t)m_regs * sizeof(orc_reg_t));
+					cigs = (cig_t*)realloc(cigs, (size_t)m_regs * sizeof(cig_t));
+				}
+				if (i + 1 != n_regs) {
+					memmove(&regs[i + 2], &regs[i + 1], sizeof(orc_reg_t) * (size_t)(n_regs - i - 1));
+					memmove(&cigs[i + 2], &cigs[i + 1], sizeof(cig_t) * (size_t)(n_regs - i - 1));
+				}
+				regs[i + 1] = r_inv, cigs[i + 1] = c_inv;
+				++n_regs;
+				++i;                                            /* not aligned again */
+			} else free(c_inv.c);
+		}
 	}
 	free(qseq0[0]);
 	free(ez.cigar);
@@ -612,7 +688,7 @@ orc_reg_t *orc_align_regs(const orc_index *mi, const orc_opt_t *opt, int qlen, c
 		t = (orc_reg_t*)malloc((size_t)(n_regs ? n_regs : 1) * sizeof(orc_reg_t));
 		tc = (cig_t*)malloc((size_t)(n_regs ? n_regs : 1) * sizeof(cig_t));
 		for (i = 0; i < n_regs; ++i) {
-			if (regs[i].cnt > 0) {
+			if ((regs[i].flags & ORC_REG_INV) || regs[i].cnt > 0) {
 				int score = (regs[i].flags & ORC_REG_HAS_DP) ? regs[i].dp_max : regs[i].score;
 				aux[n_aux].x = (uint64_t)(uint32_t)score << 32 | regs[i].hash;
 				aux[n_aux++].y = (uint64_t)i;

@@ -431,3 +431,123 @@ int orc_local_score(int qlen, const uint8_t *query, int tlen, const uint8_t *tar
 	free(H), free(E);
 	return best > 32767 ? 32767 : best;
 }
+
+
+/* ksw_ll_i16 LITERALLY (ksw2_ll_sse.c, the int16 form of Farrar's striped Smith-Waterman that
+ * minimap2 calls from mm_align1_inv and mm_test_zdrop): eight lanes of int16, the query striped over
+ * slen = ceil(qlen / 8) vectors (position k sits in vector k % slen, lane k / slen; positions beyond
+ * the query score 0), E kept per position, F carried along a column and corrected by the "lazy F"
+ * loop, unsigned saturating subtractions as the floor at zero.  What mm_align1_inv consumes beyond the
+ * score are the END coordinates, whose tie rules come from this layout: *te is the LAST column whose
+ * maximum equals the best score (`imax >= gmax`), *qe the position of that column with the largest
+ * index in the striped memory order (the loop over Hmax keeps the last match) -- which may be a
+ * padding position >= qlen when the best alignment ends on the query's last base and its score is
+ * carried diagonally into the padding (then the caller's offsets fall outside the sequences; the
+ * restatement of mm_align1_inv gives up there).  Sequences are codes 0 .. m-1. */
+static inline int16_t ll_adds(int16_t a, int16_t b) { int v = (int)a + b; return (int16_t)(v > 32767 ? 32767 : v < -32768 ? -32768 : v); }
+static inline int16_t ll_subu(int16_t a, int16_t b) { unsigned x = (uint16_t)a, y = (uint16_t)b; return (int16_t)(uint16_t)(x > y ? x - y : 0); }
+static inline int16_t ll_max(int16_t a, int16_t b) { return a > b ? a : b; }
+
+int orc_ksw_ll_i16(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat,
+                   int gapo, int gape, int *qe, int *te)
+{
+	const int p = 8, slen = (qlen + p - 1) / p, qlen8 = slen * p;
+	int16_t *qp, *H0, *H1, *E, *Hmax, *t;
+	int a, i, gmax = 0;
+	const int16_t gapoe = (int16_t)(gapo + gape), ge = (int16_t)gape;
+	*qe = *te = -1;
+	if (qlen <= 0) return 0;
+	qp = (int16_t*)malloc((size_t)m * qlen8 * 2);
+	H0 = (int16_t*)calloc((size_t)qlen8, 2), H1 = (int16_t*)calloc((size_t)qlen8, 2);
+	E = (int16_t*)calloc((size_t)qlen8, 2), Hmax = (int16_t*)calloc((size_t)qlen8, 2);
+	for (a = 0, t = qp; a < m; ++a) {                          /* the query profile, striped */
+		int k;
+		const int8_t *ma = mat + a * m;
+		for (i = 0; i < slen; ++i)
+			for (k = i; k < qlen8; k += slen) *t++ = (int16_t)(k >= qlen ? 0 : ma[query[k]]);
+	}
+	for (i = 0; i < tlen; ++i) {
+		int j, k, l, imax;
+		int16_t h[8], f[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, mx[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, *tmp;
+		const int16_t *S = qp + (size_t)target[i] * qlen8;
+		for (l = 0; l < 8; ++l) h[l] = l ? H0[(slen - 1) * 8 + l - 1] : 0;      /* the last vector, shifted by one lane */
+		for (j = 0; j < slen; ++j) {
+			for (l = 0; l < 8; ++l) {
+				int16_t v = ll_adds(h[l], S[j * 8 + l]), e = E[j * 8 + l], hu;
+				v = ll_max(v, e), v = ll_max(v, f[l]);
+				mx[l] = ll_max(mx[l], v);
+				H1[j * 8 + l] = v;
+				hu = ll_subu(v, gapoe);
+				e = ll_subu(e, ge), e = ll_max(e, hu);
+				E[j * 8 + l] = e;
+				f[l] = ll_subu(f[l], ge), f[l] = ll_max(f[l], hu);
+				h[l] = H0[j * 8 + l];
+			}
+		}
+		for (k = 0; k < 8; ++k) {                              /* lazy F */
+			int16_t g[8];
+			for (l = 0; l < 8; ++l) g[l] = l ? f[l - 1] : 0;
+			memcpy(f, g, sizeof(f));
+			for (j = 0; j < slen; ++j) {
+				int any = 0;
+				for (l = 0; l < 8; ++l) {
+					int16_t hh = ll_max(H1[j * 8 + l], f[l]);
+					H1[j * 8 + l] = hh;
+					hh = ll_subu(hh, gapoe);
+					f[l] = ll_subu(f[l], ge);
+					if (f[l] > hh) any = 1;
+				}
+				if (!any) goto end_loop;
+			}
+		}
+end_loop:
+		for (l = 0, imax = 0; l < 8; ++l) imax = imax > mx[l] ? imax : mx[l];
+		if (imax >= gmax) {
+			gmax = imax, *te = i;
+			memcpy(Hmax, H1, (size_t)qlen8 * 2);
+		}
+		tmp = H1, H1 = H0, H0 = tmp;
+	}
+	for (i = 0; i < qlen8; ++i)
+		if ((int)(uint16_t)Hmax[i] == gmax) *qe = i / 8 + i % 8 * slen;
+	free(qp), free(H0), free(H1), free(E), free(Hmax);
+	return gmax;
+}
+
+/* The same three numbers from the plain recurrence (a second formulation, for the tests and for what the
+ * GPU computes): Smith-Waterman with one affine gap cost over the query PADDED to a multiple of eight
+ * positions that score 0, the best score, the last target position whose column holds it, and in that
+ * column the position k with the largest (k % slen, k / slen). */
+int orc_local_end(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int q, int e, int *qe, int *te)
+{
+	const int slen = (qlen + 7) / 8, L = slen * 8;
+	int32_t *H = (int32_t*)calloc((size_t)L + 1, 4), *E = (int32_t*)calloc((size_t)L + 1, 4), *col = (int32_t*)calloc((size_t)L + 1, 4);
+	int i, j, best = 0;
+	*qe = *te = -1;
+	if (qlen <= 0) { free(H), free(E), free(col); return 0; }
+	for (i = 0; i < tlen; ++i) {
+		int32_t f = 0, diag = 0, cmax = 0;
+		for (j = 0; j < L; ++j) {
+			int32_t h = diag + (j < qlen ? mat[target[i] * 5 + query[j]] : 0), t;
+			diag = H[j + 1];
+			h = h > E[j + 1] ? h : E[j + 1];
+			h = h > f ? h : f;
+			h = h > 0 ? h : 0;
+			H[j + 1] = h;
+			cmax = cmax > h ? cmax : h;
+			t = h - (q + e);
+			t = t > 0 ? t : 0;
+			E[j + 1] = E[j + 1] - e > t ? E[j + 1] - e : t;
+			f = f - e > t ? f - e : t;
+		}
+		if (cmax >= best) {
+			int bk = -1;
+			best = cmax, *te = i;
+			for (j = 0; j < L; ++j)
+				if (H[j + 1] == best && (bk < 0 || j % slen > bk % slen || (j % slen == bk % slen && j / slen > bk / slen))) bk = j;
+			*qe = bk;
+		}
+	}
+	free(H), free(E), free(col);
+	return best;
+}

@@ -795,7 +795,7 @@ void orc_select_sub(float pri_ratio, int min_diff, int best_n, int *n_, orc_reg_
 		int i, k, n = *n_, n_2nd = 0;
 		for (i = k = 0; i < n; ++i) {
 			int p = r[i].parent;
-			if (p == i) {
+			if (p == i || (r[i].flags & ORC_REG_INV)) {         /* primary or inversion */
 				r[k++] = r[i];
 			} else if ((r[i].score >= r[p].score * pri_ratio || r[i].score + min_diff >= r[p].score) && n_2nd < best_n) {
 				if (!(r[i].qs == r[p].qs && r[i].qe == r[p].qe && r[i].rid == r[p].rid && r[i].rs == r[p].rs && r[i].re == r[p].re))
@@ -831,7 +831,7 @@ void orc_filter_regs(const orc_opt_t *opt, int qlen, int *n_regs, orc_reg_t *reg
 	for (i = k = 0; i < *n_regs; ++i) {
 		const orc_reg_t *r = &regs[i];
 		int flt = 0;
-		if (r->cnt < opt->min_cnt) flt = 1;
+		if (!(r->flags & ORC_REG_INV) && r->cnt < opt->min_cnt) flt = 1;
 		if (r->flags & ORC_REG_HAS_DP) {                    /* only with a base-level alignment */
 			if (r->mlen < opt->min_chain_score) flt = 1;
 			else if (r->dp_max < opt->min_dp_max) flt = 1;
@@ -909,7 +909,9 @@ static void set_mapq(int n_regs, orc_reg_t *regs, int min_chain_sc, int match_sc
 	uniq_ratio = (float)sum_sc / (sum_sc + rep_len);
 	for (i = 0; i < n_regs; ++i) {
 		orc_reg_t *r = &regs[i];
-		if (r->parent == r->id) {
+		if (r->flags & ORC_REG_INV) {
+			r->mapq = 0;
+		} else if (r->parent == r->id) {
 			const int has_dp = r->flags & ORC_REG_HAS_DP;
 			int mapq, subsc;
 			float pen_s1 = (r->score > 100 ? 1.0f : 0.01f * r->score) * uniq_ratio;

@@ -57,6 +57,7 @@ typedef struct {
 #define ORC_REG_SPLIT_L    2   /* mm_reg1_t::split & 1                         */
 #define ORC_REG_SPLIT_R    4   /* mm_reg1_t::split & 2                         */
 #define ORC_REG_SPLIT_INV  8   /* mm_reg1_t::split_inv                         */
+#define ORC_REG_INV        16  /* mm_reg1_t::inv: the alignment of an inversion between the halves of a split region */
 
 typedef struct orc_index orc_index;
 
@@ -154,6 +155,11 @@ void orc_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targ
 void orc_dp_clean(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat,
                   int q, int e, int q2, int e2, int zdrop, int end_bonus, int flag, orc_extz_t *ez);
 int orc_local_score(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int q, int e);
+/* ksw_ll_i16 literally (striped int16 Smith-Waterman: score, end of the query, end of the target with its tie
+ * rules) and the same from the plain recurrence; see mm_ksw.c */
+int orc_ksw_ll_i16(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat,
+                   int gapo, int gape, int *qe, int *te);
+int orc_local_end(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int q, int e, int *qe, int *te);
 
 /* base-level alignment of all regions of one read (mm_align_skeleton + the second hierarchy
  * pass of align_regs); regs is realloc'd when a Z-drop splits a region.  a[] are the chained

@@ -59,3 +59,44 @@ print("call on a batch whose copy has finished ms", [round(prefetched_done() * 1
 t0 = time.perf_counter()
 a = np.empty(n, dtype=np.int32); b = np.zeros(n, dtype=_capi.HIT_DTYPE); c = np.zeros(n, dtype=np.int32)
 print("output arrays ms", round((time.perf_counter() - t0) * 1e3, 3))
+
+# ---- does a host-to-device copy on another stream overlap the batch's kernels at all?
+import threading
+pin = torch.empty(len(bases), dtype=torch.uint8).pin_memory()
+pin.numpy()[:] = bases
+dst = torch.empty(len(bases), dtype=torch.uint8, device=dev)
+side = torch.cuda.Stream()
+
+
+def copy_torch():
+    with torch.cuda.stream(side):
+        dst.copy_(pin, non_blocking=True)
+
+
+torch.cuda.synchronize()
+t0 = time.perf_counter(); copy_torch(); side.synchronize(); print("torch pinned H2D alone ms", round((time.perf_counter() - t0) * 1e3, 2))
+for trial in range(3):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    th = threading.Thread(target=lambda: (time.sleep(0.005), copy_torch(), side.synchronize()))
+    th.start()
+    resident()
+    t1 = time.perf_counter()
+    th.join()
+    t2 = time.perf_counter()
+    print("resident batch with a torch H2D copy started 5 ms into it: batch done after ms", round((t1 - t0) * 1e3, 2), "copy thread done after ms", round((t2 - t0) * 1e3, 2))
+# ... and the engine's own prefetch while a resident batch runs
+for trial in range(3):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    box = []
+    th = threading.Thread(target=lambda: (time.sleep(0.005), box.append(time.perf_counter()), eng.prefetch_ptr(hb.ctypes.data, offsets.ctypes.data, n), box.append(time.perf_counter())))
+    th.start()
+    resident()
+    t1 = time.perf_counter()
+    th.join()
+    tcall = time.perf_counter()
+    eng.classify_ptr(hb.ctypes.data, offsets.ctypes.data, n, 60)
+    t2 = time.perf_counter()
+    print("resident batch with mnc_engine_prefetch 5 ms into it: batch ms", round((t1 - t0) * 1e3, 2), "prefetch call took ms", round((box[1] - box[0]) * 1e3, 2),
+          "the prefetched batch's own call ms", round((t2 - tcall) * 1e3, 2))
