@@ -58,7 +58,7 @@ DEFAULT_THREADS = 4
 # reads / bases per C-ABI call: a sample file is worked through in batches of this size, three at a time (one being
 # parsed, one on the GPU, one being written out)
 BATCH_READS = int(os.environ.get("MONICA_AMD_BATCH_READS", "25000"))
-BATCH_BASES = 1 << 27
+BATCH_BASES = min(1 << 27, BATCH_READS * 6000)
 TIMINGS = {}                      # per sample name: seconds spent per phase of aligner() (diagnostics)
 
 
@@ -174,11 +174,11 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
     clock["engine"] += t_engine
     clock["open"] += t_open
 
-    # Three batches are in flight: while the GPU classifies batch k, a helper thread parses batch k + 1 out of the file
-    # (mnc_fastq_next on all host threads) and starts its copy to the device, and another merges batch k - 1 into the
-    # carried hits and appends it to the routing folders (mnc_hitmap_update; mnc_fastq_route, parallel pwrite).  The
-    # C-ABI calls release the GIL; every stage handles the batches in file order, so the carried hits, the appended
-    # files and the counts are what the one-batch-at-a-time loop gives.
+    # Four batches are in flight: while the GPU classifies batch k, a helper thread parses batch k + 1 out of the file
+    # (mnc_fastq_next on all host threads) and starts its copy to the device, a second one merges batch k - 1 into the
+    # carried hits (mnc_hitmap_update) and a third appends batch k - 2 to the routing folders (mnc_fastq_route, parallel
+    # writes).  The C-ABI calls release the GIL; every stage handles the batches in file order, so the carried hits, the
+    # appended files and the counts are what the one-batch-at-a-time loop gives.
     parsed = queue.Queue(maxsize=2)                   # (batch | None | exception)
     to_route = queue.Queue(maxsize=2)
     stop = threading.Event()
@@ -245,43 +245,69 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
                 open(path, "ab").close()
 
     post_error = []
+    to_write = queue.Queue(maxsize=2)
 
-    def post_stage():
-        """What follows a batch's classification, in file order: the hits carried between index parts
-        (`sample_hits`, aligner.py:196-203, 218-223) and, on the last part, routing and counting."""
+    def drain(q, upstream):
+        """After an error: take what the stage before still hands over, so that nobody blocks on a full queue."""
+        while True:
+            try:
+                item = q.get(timeout=0.2)
+            except queue.Empty:
+                if not upstream.is_alive():
+                    return
+                continue
+            if item is None:
+                return
+            item[0].close()
+
+    def carry_stage():
+        """The hits carried between index parts (`sample_hits`, aligner.py:196-203, 218-223), in file order."""
         try:
             while True:
                 item = to_route.get()
                 if item is None:
-                    return
+                    break
                 batch, (assign, best, nhits) = item
+                if post_error:
+                    batch.close()
+                    continue
+                t2 = time.perf_counter()
+                state = sample_hits.update(batch, index.index, assign, best, nhits)
+                clock["carry"] += time.perf_counter() - t2
+                if not last_index:
+                    batch.close()
+                elif not put(to_write, (batch, state, sample_hits.names())):
+                    batch.close()
+            to_write.put(None)
+        except BaseException as e:
+            post_error.append(e)
+            stop.set()
+            to_write.put(None)
+            drain(to_route, parser)
+
+    def write_stage():
+        """On the last part: routing and counting (aligner.py:232-265), in file order."""
+        try:
+            while True:
+                item = to_write.get()
+                if item is None:
+                    return
+                batch, state, names_now = item
                 try:
                     if not post_error:
-                        t2 = time.perf_counter()
-                        state = sample_hits.update(batch, index.index, assign, best, nhits)
-                        clock["carry"] += time.perf_counter() - t2
-                        if last_index:
-                            _route_and_count(batch, state, sample_hits.names(), decoded, acc, mode, overnight, focus_species, paths, clock)
+                        _route_and_count(batch, state, names_now, decoded, acc, mode, overnight, focus_species, paths, clock)
                 finally:
                     batch.close()
         except BaseException as e:
             post_error.append(e)
             stop.set()
-            while True:                                   # let the producers finish: take what they still hand over
-                try:
-                    item = to_route.get(timeout=0.2)
-                except queue.Empty:
-                    if not parser.is_alive():
-                        return
-                    continue
-                if item is None:
-                    return
-                item[0].close()
+            drain(to_write, carrier)
 
     parser = threading.Thread(target=parse_stage, name="mnc-parse", daemon=True)
-    poster = threading.Thread(target=post_stage, name="mnc-post", daemon=True)
-    parser.start()
-    poster.start()
+    carrier = threading.Thread(target=carry_stage, name="mnc-carry", daemon=True)
+    writer = threading.Thread(target=write_stage, name="mnc-route", daemon=True)
+    for th in (parser, carrier, writer):
+        th.start()
     try:
         for batch in batches():
             if post_error:
@@ -293,7 +319,8 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
                 break
     finally:
         to_route.put(None)
-        poster.join()
+        carrier.join()
+        writer.join()
         stop.set()
         while parser.is_alive():                          # unblock a parser waiting on a full queue
             try:

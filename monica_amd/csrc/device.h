@@ -87,7 +87,7 @@ struct ChainRec {
 
 // ---------------------------------------------------------------- base-level alignment stage
 constexpr uint64_t SEED_LONG_JOIN = 1ULL << 40, SEED_IGNORE = 1ULL << 41, SEED_TANDEM = 1ULL << 42;
-constexpr int REG_HAS_DP = 1, REG_SPLIT_L = 2, REG_SPLIT_R = 4, REG_SPLIT_INV = 8;
+constexpr int REG_HAS_DP = 1, REG_SPLIT_L = 2, REG_SPLIT_R = 4, REG_SPLIT_INV = 8, REG_INV = 16;   // REG_INV: mm_reg1_t::inv (mm_align1_inv's region)
 constexpr int EZ_RIGHT = 0x02, EZ_APPROX_MAX = 0x08, EZ_EXTZ_ONLY = 0x40, EZ_REV_CIGAR = 0x80;
 constexpr int SEG_NEEDS_BIG_WS = 0x10000;                 // Seg.flag, ours: the literal kernel needs its large workspace for this call
 constexpr int DP_NEG_INF = -0x40000000;
@@ -123,8 +123,11 @@ struct RegDP {
 	int32_t state;            // 0 unused, 1 planned this round, 2 done
 	int64_t cig_off;          // in the region pool
 	// what the stitch kernel would otherwise reach through three more dependent loads (written by mnc_dp_plan)
-	int32_t rid, rev, qlen, pad_;
+	int32_t rid, rev, qlen;
+	int32_t head;             // the tail of a Z-drop split: region slot of its head + 1 (0: none) -- mm_align1_inv's r1
 	int64_t coff, read_off;   // first base of the contig in seq4; of the read in the batch
+	int32_t inv_after;        // an inversion region was inserted behind this one: it, not this region, precedes the tail
+	int32_t pad_;
 };
 
 struct RegX { uint64_t x0, y0, x1, y1; };   // first / last anchor of a region
@@ -234,6 +237,7 @@ struct Batch {
 	int32_t *extp_list;                           // packed extension kernel: 8 lists (32 / 64 / 128 / 256 query bases x right, left), `seg_cap` apart;
 	                                              // lengths dp_ctr[32 + i], queues dp_ctr[40 + i]
 	int32_t *reg_cnt;             // per read: regions in the skeleton's array (kept + split tails)
+	int slot_pad;                 // region slots per read beyond anchors / 3 (split tails, inversion regions): see reg_slot()
 };
 
 // size classes of the row chaining kernel (anchors per LDS tile)
@@ -256,5 +260,11 @@ __device__ __forceinline__ uint32_t hash30(uint32_t key)
 }
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// First region slot of a read (regs, regdp, regx, ... are indexed by it; chains_tmp / chain_dst keep anchors / 3).
+// A chain needs three anchors, so a read's chains fit anchors / 3 slots -- but a Z-drop split peels a head of as little
+// as one anchor off a region, and an inversion region has no anchors at all: every read gets slot_pad more, and a read
+// that needs even more fails the batch with dp_ctr[4] = 5 (redone with a larger pad).
+__device__ __forceinline__ int64_t reg_slot(const Batch &B, uint32_t rd) { return B.an_off[rd] / 3 + (int64_t)rd * B.slot_pad; }
 
 } // namespace mnc

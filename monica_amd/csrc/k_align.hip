@@ -185,14 +185,22 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 	const int n_a = B.ca_cnt[rd];
 	int32_t *K = B.t + a_off + r.as;                       // scratch: one int per anchor of the region
 	d.n_seg = 0, d.first_seg = 0, d.has_left = d.has_right = 0;
-	if (r.cnt == 0) { d.state = 2; B.regdp[rslot] = d; return; }
+	// an inversion region (mnc_dp_inv): no seeds -- one extension from the start the local alignment found, on the strand
+	// and with the window that kernel left in the region's record
+	const bool inv = (r.flags & REG_INV) != 0;
+	if (r.cnt == 0 && !inv) { d.state = 2; B.regdp[rslot] = d; return; }
 	const int k2 = KMER >> 1;
-	const int rid = (int32_t)(a[r.as].x << 1 >> 33), rev = (int32_t)(a[r.as].x >> 63);
+	const int rid = inv ? d.rid : (int32_t)(a[r.as].x << 1 >> 33), rev = inv ? d.rev : (int32_t)(a[r.as].x >> 63);
 	d.rid = rid, d.rev = rev, d.qlen = qlen, d.pad_ = 0, d.coff = B.seq_off[rid], d.read_off = B.offsets[rd];
 	const int ref_len = (int)(B.seq_off[rid + 1] - B.seq_off[rid]);
-	const int bw = (int)(B.bw * 1.5 + 1.);
+	const int bw = inv ? (int)(B.bw * 1.5) : (int)(B.bw * 1.5 + 1.);   // mm_align1_inv passes (int)(bw * 1.5), mm_align1 one more
 	int as1 = r.as, cnt1 = r.cnt;
-
+	int rs = 0, qs = 0, re = 0, qe = 0, rs0 = 0, qs0 = 0, re0 = 0, qe0 = 0;
+	Anchor *b = a;
+	if (inv) {
+		rs = re = d.rs, qs = qe = d.qs, rs0 = rs, qs0 = qs, re0 = d.re0, qe0 = d.qe0;
+		as1 = 0, cnt1 = 0;
+	} else {
 	// ---- mm_fix_bad_ends
 	if (r.cnt >= 3) {
 		const int min_match = B.min_sc * 2;
@@ -221,7 +229,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 			if (l >= B.bw << 1 || (m >= min_match && m >= B.bw) || m >= r.mlen >> 1) break;
 		}
 	}
-	Anchor *b = a + as1;
+	b = a + as1;
 	// ---- mm_filter_bad_seeds(as1, cnt1, a, 10, 40, max_gap >> 1, 10)
 	{
 		const int n = collect_long_gaps(b, cnt1, 10, K);
@@ -280,10 +288,10 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 		}
 	}
 	// ---- DP window
-	int rs = (int32_t)b[0].x - k2, qs = (int32_t)b[0].y - k2;
-	int re = (int32_t)b[cnt1 - 1].x - k2, qe = (int32_t)b[cnt1 - 1].y - k2;
-	int rs0 = (int32_t)a[r.as].x + 1 - (int32_t)(a[r.as].y >> 32 & 0xff);
-	int qs0 = (int32_t)a[r.as].y + 1 - (int32_t)(a[r.as].y >> 32 & 0xff);
+	rs = (int32_t)b[0].x - k2, qs = (int32_t)b[0].y - k2;
+	re = (int32_t)b[cnt1 - 1].x - k2, qe = (int32_t)b[cnt1 - 1].y - k2;
+	rs0 = (int32_t)a[r.as].x + 1 - (int32_t)(a[r.as].y >> 32 & 0xff);
+	qs0 = (int32_t)a[r.as].y + 1 - (int32_t)(a[r.as].y >> 32 & 0xff);
 	if (rs0 < 0) rs0 = 0;
 	int rs1 = 0, qs1 = 0, l;
 	for (int i = r.as - 1, c = 0; i >= 0 && a[i].x >> 32 == a[r.as].x >> 32; --i) {
@@ -309,7 +317,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 		rs0 = rs0 < rs1 ? rs0 : rs1;
 		rs0 = rs0 < rs ? rs0 : rs;
 	} else rs0 = rs, qs0 = qs;
-	int re0 = (int32_t)a[r.as + r.cnt - 1].x + 1, qe0 = (int32_t)a[r.as + r.cnt - 1].y + 1;
+	re0 = (int32_t)a[r.as + r.cnt - 1].x + 1, qe0 = (int32_t)a[r.as + r.cnt - 1].y + 1;
 	int re1 = ref_len, qe1 = qlen;
 	for (int i = r.as + r.cnt, c = 0; i < n_a && a[i].x >> 32 == a[r.as].x >> 32; ++i) {
 		const int x = (int32_t)a[i].x + 1 - (int32_t)(a[i].y >> 32 & 0xff);
@@ -332,11 +340,12 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 		re1 = re1 < re + l ? re1 : re + l;
 		re0 = re0 > re1 ? re0 : re1;
 	} else re0 = re, qe0 = qe;
+	}   // !inv
 	d.as1 = as1, d.cnt1 = cnt1, d.rs = rs, d.qs = qs, d.re = re, d.qe = qe;
 	d.rs0 = rs0, d.qs0 = qs0, d.re0 = re0, d.qe0 = qe0;
 
 	// ---- segments: count, allocate, fill
-	const bool left = qs > 0 && rs > 0;
+	const bool left = !inv && qs > 0 && rs > 0;
 	int n_fill = 0;
 	{
 		int prs = rs, pqs = qs;
@@ -1189,13 +1198,17 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 			flags |= REG_SPLIT_L;
 			if (lane == 0) {
 				const int idx = atomicAdd(&B.reg_cnt[rd], 1);
-				const int64_t nslot = B.an_off[rd] / 3 + idx;
-				RegDP d2;
-				memset(&d2, 0, sizeof(d2));
-				d2.read = (int32_t)rd, d2.order = d.order + 1, d2.state = 1;
-				B.regs[nslot] = r2, B.regdp[nslot] = d2;
-				const unsigned long long ni = atomicAdd(&B.dp_ctr[5], 1ULL);
-				next_list[ni] = (int32_t)nslot;
+				const int64_t nslot = reg_slot(B, rd) + idx;
+				if (nslot >= reg_slot(B, rd + 1)) atomicMax(&B.dp_ctr[4], 5ULL);       // out of region slots: the batch is redone with more per read
+				else {
+					RegDP d2;
+					memset(&d2, 0, sizeof(d2));
+					// skeleton order: the tail right behind its head; the odd number between them is the inversion region's
+					d2.read = (int32_t)rd, d2.order = d.order + 2, d2.state = 1, d2.head = (int32_t)rslot + 1;
+					B.regs[nslot] = r2, B.regdp[nslot] = d2;
+					const unsigned long long ni = atomicAdd(&B.dp_ctr[5], 1ULL);
+					next_list[ni] = (int32_t)nslot;
+				}
 			}
 		}
 		r.rs = rs1, r.re = re1;
@@ -1585,6 +1598,130 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 	}
 }
 
+// ================================================================ the inversion between two halves (mm_align1_inv)
+// A region split by a Z-drop whose inversion test was positive leaves a tail with REG_SPLIT_INV.  Once head and tail are
+// both aligned, the stretch between them -- query [r1.qe, r2.qs) on the halves' strand, target [r1.re, r2.rs) -- is
+// aligned on the OTHER strand of the read: minimap2 runs ksw_ll_i16 (striped int16 Smith-Waterman, one affine gap cost)
+// on the two sequences reversed, takes the END it reports as the start of the alignment, and extends from there with
+// ksw_extd2.  This kernel does the first half and leaves a region of its own (REG_INV, no seeds) whose one extension the
+// next round's plan / alignment / stitch kernels run like any other.
+//
+// The local alignment, one wave per candidate: column by column over the (reversed) target, 64 query positions per step;
+// the vertical gap state F[j] = max_{k<j} (H[k] - q - e (j - k)) is a prefix maximum of h[k] + e k over the column (opening
+// a gap from a cell that was itself reached through a gap is never better than extending that gap), the horizontal one E
+// is kept per position.  What minimap2 consumes are the score and the end coordinates with the tie rules of the striped
+// layout (oracle/mm_ksw.c: orc_ksw_ll_i16 / orc_local_end): the query padded to a multiple of eight positions that score 0;
+// te = the LAST column whose maximum equals the best score, qe = that column's position j with the largest
+// (j % slen, j / slen), slen = padded length / 8.
+constexpr int INV_NEG = -(1 << 29);
+
+__global__ __launch_bounds__(64) void mnc_dp_inv(Batch B, const int32_t *work_list, int32_t *next_list, int32_t *ws_all, int ws_half)
+{
+	const int lane = threadIdx.x;
+	const unsigned long long n_work = B.dp_ctr[9];
+	int32_t *Hc = ws_all + (size_t)blockIdx.x * 2 * ws_half, *Ec = Hc + ws_half;
+	for (unsigned long long wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+		const int64_t tslot = work_list[wi];
+		const mnc_reg_t r2 = B.regs[tslot];
+		const RegDP d2 = B.regdp[tslot];
+		if (!(r2.flags & REG_SPLIT_INV) || d2.state != 2 || d2.head <= 0) continue;
+		const int64_t hslot = d2.head - 1;
+		const mnc_reg_t r1 = B.regs[hslot];
+		if (B.regdp[hslot].inv_after) continue;                 // what precedes the tail in the skeleton's array is that inversion, not the head
+		if (!(r1.flags & REG_SPLIT_L) || !(r2.flags & REG_SPLIT_R)) continue;
+		if (r1.id != r1.parent && r1.parent != -2) continue;    // primaries only (-2: a tail of one)
+		if (r2.id != r2.parent && r2.parent != -2) continue;
+		if (r1.rid != r2.rid || r1.rev != r2.rev) continue;
+		const int ql = r1.rev ? r1.qs - r2.qe : r2.qs - r1.qe, tl = r2.rs - r1.re;
+		if (ql < B.min_sc || ql > B.max_gap || tl < B.min_sc || tl > B.max_gap) continue;
+		const uint32_t rd = (uint32_t)d2.read;
+		const int qlen = (int)(B.offsets[rd + 1] - B.offsets[rd]);
+		const uint8_t *read = B.bases + B.offsets[rd];
+		const int s = r1.rev ? 0 : 1;                           // the other strand
+		const int base = r1.rev ? r2.qe : qlen - r2.qs;         // the stretch's first base on it
+		const int64_t coff = B.seq_off[r1.rid];
+		const int L = (ql + 7) / 8 * 8, slen = L / 8;
+		if (L + 1 > ws_half) { if (lane == 0) atomicMax(&B.dp_ctr[4], 9ULL); continue; }   // cannot happen: ql <= max_gap sizes the scratch
+		const int q = B.gap_q, e = B.gap_e, a = B.sc_a, bmis = -B.sc_b, scN = -B.sc_ambi;
+		for (int j = lane; j <= L; j += 64) Hc[j] = 0, Ec[j] = 0;
+		mem_order();
+		int best = 0, te = -1, qe = -1;
+		for (int i = 0; i < tl; ++i) {
+			const int tb = tcode(B, coff, r1.re + tl - 1 - i);  // the target, reversed
+			int carry = INV_NEG, prev_last_old = 0, cmax = 0;
+			for (int j0 = 0; j0 < L; j0 += 64) {
+				const int j = j0 + lane;
+				const bool in = j < L;
+				const int old = in ? Hc[j] : 0;                  // H of the previous column
+				int diag = __shfl_up(old, 1);
+				if (lane == 0) diag = prev_last_old;
+				prev_last_old = __shfl(old, 63);
+				int sc = 0;
+				if (j < ql) {
+					const int qb = qcode(read, qlen, s, base + ql - 1 - j);   // the query, reversed
+					sc = (tb > 3 || qb > 3) ? scN : tb == qb ? a : bmis;
+				}
+				int h = diag + sc;
+				const int ein = in ? Ec[j] : 0;
+				h = h > ein ? h : ein;
+				h = h > 0 ? h : 0;
+				// F: exclusive prefix maximum of h[k] + e k over the column
+				int v = in ? h + e * j : INV_NEG, incl = v;
+#pragma unroll
+				for (int sft = 1; sft < 64; sft <<= 1) { const int o = __shfl_up(incl, sft); if (lane >= sft) incl = incl > o ? incl : o; }
+				int excl = __shfl_up(incl, 1);
+				if (lane == 0) excl = INV_NEG;
+				excl = excl > carry ? excl : carry;
+				const int last = __shfl(incl, 63);
+				carry = carry > last ? carry : last;
+				const int f = excl - q - e * j;
+				h = h > f ? h : f;
+				if (in) {
+					int en = ein - e, t2 = h - q - e;
+					en = en > t2 ? en : t2;
+					Hc[j] = h, Ec[j] = en > 0 ? en : 0;
+					cmax = cmax > h ? cmax : h;
+				}
+			}
+#pragma unroll
+			for (int sft = 32; sft > 0; sft >>= 1) { const int o = __shfl_xor(cmax, sft); cmax = cmax > o ? cmax : o; }
+			mem_order();
+			if (cmax >= best) {                                 // `imax >= gmax`: the last column with the best score
+				best = cmax, te = i;
+				int key = -1;
+				for (int j = lane; j < L; j += 64)
+					if (Hc[j] == best) { const int k = (j % slen) * 8 + j / slen; key = key > k ? key : k; }
+#pragma unroll
+				for (int sft = 32; sft > 0; sft >>= 1) { const int o = __shfl_xor(key, sft); key = key > o ? key : o; }
+				qe = key < 0 ? -1 : (key >> 3) + (key & 7) * slen;
+			}
+		}
+		if (best < B.min_dp_max || qe < 0) continue;
+		const int q_off = ql - (qe + 1), t_off = tl - (te + 1);
+		if (base + q_off < 0) continue;                         // in front of the read's first base (never: a tail holds three seeds)
+		if (lane == 0) {
+			const int idx = atomicAdd(&B.reg_cnt[rd], 1);
+			const int64_t nslot = reg_slot(B, rd) + idx;
+			if (nslot >= reg_slot(B, rd + 1)) atomicMax(&B.dp_ctr[4], 5ULL);
+			else {
+				mnc_reg_t ri;
+				memset(&ri, 0, sizeof(ri));
+				ri.id = -1, ri.parent = -1, ri.rid = r1.rid, ri.rev = s, ri.flags = REG_INV;
+				RegDP di;
+				memset(&di, 0, sizeof(di));
+				di.read = (int32_t)rd, di.order = d2.order + 1, di.state = 1;
+				di.rid = r1.rid, di.rev = s, di.qlen = qlen;
+				di.rs = di.re = di.rs0 = r1.re + t_off, di.qs = di.qe = di.qs0 = base + q_off;
+				di.re0 = r1.re + tl, di.qe0 = base + ql;
+				B.regs[nslot] = ri, B.regdp[nslot] = di;
+				B.regdp[tslot].inv_after = 1;
+				const unsigned long long ni = atomicAdd(&B.dp_ctr[5], 1ULL);
+				next_list[ni] = (int32_t)nslot;
+			}
+		}
+	}
+}
+
 // ================================================================ round bookkeeping (one thread)
 __global__ void mnc_dp_round(Batch B, int first)
 {
@@ -1671,6 +1808,11 @@ void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_li
 // what the waves of one round's launches (n_wg, and n_wg / 4 more for the regions of long reads) can hold back of the
 // region pool: the chunk each reserved last
 size_t dp_stitch_pool_slack(int n_wg) { return (size_t)(n_wg + n_wg / 4) * ST_POOL_CHUNK; }
+size_t dp_inv_ws_words(int max_gap) { return (size_t)(max_gap + 8 + 64) * 2; }   // H and E of one column, per workgroup
+void launch_dp_inv(const Batch &B, const int32_t *work_list, int32_t *next_list, int32_t *ws, int n_wg, hipStream_t st)
+{
+	hipLaunchKernelGGL(mnc_dp_inv, dim3(n_wg), dim3(64), 0, st, B, work_list, next_list, ws, B.max_gap + 8 + 64);
+}
 int dp_stitch_prepare()
 {
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_stitch), hipFuncAttributeMaxDynamicSharedMemorySize,

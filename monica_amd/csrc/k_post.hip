@@ -191,7 +191,7 @@ __device__ __forceinline__ int select_sub(const Batch &B, int n_regs, RegP r, Ex
 	int k = 0, n_2nd = 0;
 	for (int i = 0; i < n_regs; ++i) {
 		const int p = r[i].parent;
-		if (p == i) {
+		if (p == i || (r[i].flags & REG_INV)) {                // a primary, or an inversion
 			r[k] = r[i], ex[k] = ex[i], ++k;
 		} else if (((float)r[i].score >= __fmul_rn((float)r[p].score, B.pri_ratio) || r[i].score + min_diff >= r[p].score) && n_2nd < B.best_n) {
 			if (!(r[i].qs == r[p].qs && r[i].qe == r[p].qe && r[i].rid == r[p].rid && r[i].rs == r[p].rs && r[i].re == r[p].re)) {
@@ -213,7 +213,7 @@ __device__ __forceinline__ void set_mapq(const Batch &B, uint32_t rd, int n_regs
 	for (int i = 0; i < n_regs; ++i) {
 		const mnc_reg_t x = r[i];
 		int mapq = 0;
-		if (x.parent == x.id) {
+		if (!(x.flags & REG_INV) && x.parent == x.id) {        // an inversion: 0
 			const bool has_dp = (x.flags & REG_HAS_DP) != 0;
 			const float pen_s1 = __fmul_rn(x.score > 100 ? 1.0f : __fmul_rn(0.01f, (float)x.score), uniq_ratio);
 			float pen_cm = x.cnt > 10 ? 1.0f : __fmul_rn(0.1f, (float)x.cnt);
@@ -440,10 +440,10 @@ __global__ __launch_bounds__(64) void mnc_regions_decide(Batch B, RegX *regx_all
 	const int n = B.n_chain[rd];
 	int n_regs = 0;
 	if (n > 0) {
-		const int64_t slot = B.an_off[rd] / 3;
-		const ChainRec *ch = B.chains_tmp + slot;               // backtrack order (pad = rank)
+		const int64_t cslot = B.an_off[rd] / 3, slot = reg_slot(B, rd);      // chain slots, region slots
+		const ChainRec *ch = B.chains_tmp + cslot;              // backtrack order (pad = rank)
 		mnc_hit_t *gated = gated_all + slot;
-		int32_t *chain_dst = dp ? B.chain_dst + slot : nullptr;
+		int32_t *chain_dst = dp ? B.chain_dst + cslot : nullptr;
 		if (n <= RG_LDS_CHAINS) {
 			const int t = threadIdx.x;
 			n_regs = regions_of_read(B, rd, qlen, n, ch, Strided<mnc_reg_t>{&s_r[0][t]}, Strided<RegX>{&s_ex[0][t]},
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(64) void mnc_regions_post(Batch B, mnc_reg_t *work_
 	const int n0 = B.reg_cnt[rd];
 	int n_regs = 0;
 	if (n0 > 0) {
-		const int64_t slot = B.an_off[rd] / 3;
+		const int64_t slot = reg_slot(B, rd);
 		mnc_reg_t *src = B.regs + slot, *r = work_all + slot;
 		RegX *ex = regx_all + slot;                          // x0: CIGAR offset, x1: n_cigar -- travels with the region
 		uint64_t *ka = k64a_all + slot;
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(64) void mnc_regions_post(Batch B, mnc_reg_t *work_
 		int k = 0;
 		for (int i = 0; i < n0; ++i) {
 			const mnc_reg_t x = src[w[i]];
-			bool flt = x.cnt < B.min_cnt;
+			bool flt = !(x.flags & REG_INV) && x.cnt < B.min_cnt;
 			if (x.flags & REG_HAS_DP) {
 				if (x.mlen < B.min_sc) flt = true;
 				else if (x.dp_max < B.min_dp_max) flt = true;
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256) void mnc_gather_hits(Batch B, const mnc_hit_t 
 	if (rd >= B.n_reads) return;
 	const int n = B.nhits[rd];
 	if (n == 0) return;
-	const mnc_hit_t *src = gated_all + B.an_off[rd] / 3;
+	const mnc_hit_t *src = gated_all + reg_slot(B, rd);
 	mnc_hit_t *dst = out + hit_off[rd];
 	for (int i = 0; i < n; ++i) dst[i] = src[i];
 }

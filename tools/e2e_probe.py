@@ -100,3 +100,27 @@ for trial in range(3):
     t2 = time.perf_counter()
     print("resident batch with mnc_engine_prefetch 5 ms into it: batch ms", round((t1 - t0) * 1e3, 2), "prefetch call took ms", round((box[1] - box[0]) * 1e3, 2),
           "the prefetched batch's own call ms", round((t2 - tcall) * 1e3, 2))
+
+# ---- the bench's loop, with per-iteration detail
+bufs = [hb, hb2]
+eng.classify(bufs[0], offsets, 60)
+log = []
+
+
+def announce(buf, t_ref):
+    tries = 0
+    while not eng.prefetch_ptr(buf.ctypes.data, offsets.ctypes.data, n):
+        tries += 1
+        time.sleep(0.0005)
+    log.append(("copy issued after ms", round((time.perf_counter() - t_ref) * 1e3, 2), "tries", tries))
+
+
+announce(bufs[0], time.perf_counter())
+for k in range(6):
+    t0 = time.perf_counter()
+    th = threading.Thread(target=announce, args=(bufs[(k + 1) & 1], t0))
+    th.start()
+    eng.classify_ptr(bufs[k & 1].ctypes.data, offsets.ctypes.data, n, 60)
+    t1 = time.perf_counter()
+    th.join()
+    print("iteration", k, "call ms", round((t1 - t0) * 1e3, 2), log[-1])
