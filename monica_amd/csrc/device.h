@@ -126,7 +126,7 @@ struct RegDP {
 	int32_t rid, rev, qlen;
 	int32_t head;             // the tail of a Z-drop split: region slot of its head + 1 (0: none) -- mm_align1_inv's r1
 	int64_t coff, read_off;   // first base of the contig in seq4; of the read in the batch
-	int32_t inv_after;        // an inversion region was inserted behind this one: it, not this region, precedes the tail
+	int32_t inv_after;        // slot + 1 of the inversion region inserted behind this one: it, not this region, precedes the next tail
 	int32_t pad_;
 };
 

@@ -49,6 +49,8 @@ void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work,
 size_t dp_align_ws_bytes(long long state_max, long long p_max, long long cig_max);
 int dp_align_prepare(int lds_bytes);
 int dp_stitch_prepare();
+size_t dp_inv_ws_words(int max_gap);
+void launch_dp_inv(const Batch &B, const int32_t *work_list, int32_t *next_list, int32_t *ws, int n_wg, hipStream_t st);
 size_t dp_stitch_pool_slack(int n_wg);
 void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max, long long p_max, long long cig_max,
                      int lds_state, int lds_p, int lds_cig, int big_pass, hipStream_t st);
@@ -66,7 +68,7 @@ void launch_dp_extp(const Batch &B, int cells, int rgt, const int32_t *list, int
 void launch_dp_fill(const Batch &B, int lanes, const int32_t *list, int ctr_n, int ctr_q, int32_t *next_list, int ctr_next,
                     int32_t *fb_list, int ctr_fb, uint8_t *p_all, uint32_t *cig_all, int n_wg, hipStream_t st);
 void launch_dp_ext(const Batch &B, int lanes, const int32_t *list, int ctr_n, int ctr_q, int32_t *fb_list, int ctr_fb, uint8_t *p_all, int n_wg, hipStream_t st);
-constexpr int DP_WG_FILL = 256 * 16, DP_WG_EXT = 256 * 8, DP_WG_STITCH = 4096;
+constexpr int DP_WG_FILL = 256 * 16, DP_WG_EXT = 256 * 8, DP_WG_STITCH = 4096, DP_WG_INV = 256;
 // workspace classes of the alignment kernel: a normal slot per workgroup, a few large ones
 constexpr int DP_LDS_BYTES = 16 * 1024;
 constexpr int DP_LDS0_STATE = 4 * 1024, DP_LDS0_P = 10 * 1024, DP_LDS0_CIG = 256;   // pass 0: 15 KB per workgroup
@@ -473,6 +475,8 @@ struct mnc_engine {
 	SharedWs *ws = nullptr;                  // the device's alignment scratch (held during the alignment stage only)
 	Buf fill1, fill2, fill3, fill_mid, fill_fb, extp, mid_list, lfill, lext, bigfb, ext1, ext2, ext3, ext4, gen_list;
 	size_t seg_cap_override = 0, cig_cap_override = 0;
+	int slot_pad = 2;                        // region slots per read beyond anchors / 3 (device.h: reg_slot); grown when a batch runs out
+	Buf inv_ws;                              // mnc_dp_inv: two columns per workgroup
 	int cur_max_read_len = 0;                // of the batch being classified (sizes the stitch kernel's LDS)
 	int debug = 0;                           // bit mask (tests): 2 stress build of the chaining ring, 4 displacement bytes read from HBM, 0x10000 alignment kernels one at a time (with stage timers), 0x200000 the stitch kernel reads bases in place (its form for regions beyond its LDS)
 	// last batch
@@ -584,7 +588,7 @@ extern "C" int mnc_device_name(int device, char *buf, size_t cap)
 template <class F> static void engine_bufs(mnc_engine *e, F f)
 {
 	Buf *all[] = { &e->gap_lut, &e->logf_lut, &e->logf_a_lut, &e->ca, &e->ca_cnt, &e->chain_dst, &e->regdp, &e->segs, &e->cig_seg, &e->cig_reg, &e->dp_ctr,
-	               &e->work_a, &e->work_b, &e->big_list, &e->huge_list, &e->reg_cnt, &e->regs2, &e->fill1, &e->fill2, &e->fill3, &e->fill_mid, &e->fill_fb, &e->extp, &e->mid_list, &e->lfill, &e->lext, &e->bigfb, &e->ext1, &e->ext2, &e->ext3, &e->ext4, &e->gen_list, &e->in_bases, &e->in_offsets, &e->pf_bases_buf, &e->pf_offsets_buf, &e->out_assign, &e->out_best, &e->out_nhits,
+	               &e->work_a, &e->work_b, &e->big_list, &e->huge_list, &e->reg_cnt, &e->regs2, &e->inv_ws, &e->fill1, &e->fill2, &e->fill3, &e->fill_mid, &e->fill_fb, &e->extp, &e->mid_list, &e->lfill, &e->lext, &e->bigfb, &e->ext1, &e->ext2, &e->ext3, &e->ext4, &e->gen_list, &e->in_bases, &e->in_offsets, &e->pf_bases_buf, &e->pf_offsets_buf, &e->out_assign, &e->out_best, &e->out_nhits,
 	               &e->packed, &e->mz, &e->hits, &e->hist_tm, &e->q_off, &e->qrec, &e->bhits, &e->bhit_cnt, &e->ambig, &e->mz_cnt, &e->hit_cnt, &e->rep_len, &e->an_cnt, &e->an_off,
 	               &e->n_chain, &e->n_reg, &e->best_mlen, &e->hist_sums, &e->hist_offs, &e->scan_sums, &e->hit_off, &e->a, &e->f, &e->p, &e->v, &e->t, &e->u,
 	               &e->chains_tmp, &e->regs, &e->regx, &e->k64a, &e->k64b, &e->tmp_i32, &e->gated,
@@ -981,16 +985,18 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	}
 	if (total_anchors < 0 || total_anchors >= (1LL << 31) * 16) { set_error("anchor count %lld out of range", (long long)total_anchors); return MNC_ERR_UNSUPPORTED; }
 	e->last_total_anchors = total_anchors;
-	const size_t na = (size_t)total_anchors + 4, ns = (size_t)total_anchors / 3 + 4;
+	// ns chain slots (a chain has three anchors or more); nsr region slots: slot_pad more per read (device.h: reg_slot)
+	const size_t na = (size_t)total_anchors + 4, ns = (size_t)total_anchors / 3 + 4, nsr = ns + nr * (size_t)e->slot_pad;
 	ENS(a, na * sizeof(Anchor));
 	ENS(f, na * 4); ENS(p, na * 4); ENS(v, na * 4); ENS(t, na * 4);
 	ENS(u, na * 8);
 	ENS(chains_tmp, ns * sizeof(ChainRec));
-	ENS(regs, ns * sizeof(mnc_reg_t)); ENS(regx, ns * 32);
-	ENS(k64a, ns * 8); ENS(k64b, ns * 8); ENS(tmp_i32, ns * 16); ENS(gated, ns * sizeof(mnc_hit_t));
+	ENS(regs, nsr * sizeof(mnc_reg_t)); ENS(regx, nsr * 32);
+	ENS(k64a, nsr * 8); ENS(k64b, nsr * 8); ENS(tmp_i32, nsr * 16); ENS(gated, nsr * sizeof(mnc_hit_t));
 	if (rc) return rc;
 #undef ENS
 	B.an_cap = (int64_t)na;
+	B.slot_pad = e->slot_pad;
 	B.a = e->a.as<Anchor>(), B.chains_tmp = e->chains_tmp.as<ChainRec>();
 	B.f = e->f.as<int32_t>(), B.p = e->p.as<int32_t>(), B.v = e->v.as<int32_t>(), B.t = e->t.as<int32_t>(), B.u = e->u.as<uint64_t>();
 	B.regs = e->regs.as<mnc_reg_t>(), B.tmp_i32 = e->tmp_i32.as<int32_t>();
@@ -1078,12 +1084,13 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 #define ENSW(buf, bytes) do { if (!rc2) rc2 = e->ws->buf.ensure(bytes); } while (0)
 		// the device's alignment scratch is this engine's from here to the end of the stage
 		std::unique_lock<std::mutex> ws_hold(e->ws->mu);
-		ENS2(ca, na * sizeof(Anchor)); ENS2(ca_cnt, (nr + 1) * 4); ENS2(chain_dst, ns * 4); ENS2(regdp, ns * sizeof(RegDP));
+		ENS2(ca, na * sizeof(Anchor)); ENS2(ca_cnt, (nr + 1) * 4); ENS2(chain_dst, ns * 4); ENS2(regdp, nsr * sizeof(RegDP));
+		ENS2(inv_ws, dp_inv_ws_words(B.max_gap) * 4 * DP_WG_INV);
 		// the stitch kernel's waves reserve the region pool a chunk at a time (k_align.hip): what its two launches
 		// can leave unused is room on top of the CIGARs' own
 		const size_t cig_reg_cap = cig_cap + dp_stitch_pool_slack(DP_WG_STITCH);
 		ENS2(segs, seg_cap * sizeof(Seg)); ENS2(cig_seg, cig_cap * 4); ENS2(cig_reg, cig_reg_cap * 4);
-		ENS2(work_a, ns * 4); ENS2(work_b, ns * 4); ENS2(big_list, seg_cap * 4); ENS2(reg_cnt, (nr + 1) * 4); ENS2(regs2, ns * sizeof(mnc_reg_t));
+		ENS2(work_a, nsr * 4); ENS2(work_b, nsr * 4); ENS2(big_list, seg_cap * 4); ENS2(reg_cnt, (nr + 1) * 4); ENS2(regs2, nsr * sizeof(mnc_reg_t));
 		const size_t ws_small = dp_align_ws_bytes(DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL), ws_big = dp_align_ws_bytes(DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG), ws_huge = dp_align_ws_bytes(DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE);
 		ENSW(dp_ws, ws_small * DP_WG_SMALL * 2); ENSW(dp_ws_big, ws_big * DP_WG_BIG); ENSW(dp_ws_huge, ws_huge * DP_WG_HUGE); ENS2(huge_list, seg_cap * 4); ENSW(dp_ws_mid, ws_small * DP_WG_MID); ENS2(mid_list, seg_cap * 4); ENS2(lfill, seg_cap * 4); ENSW(lfill_p, dp_lfill_p_slot() * DP_WG_LFILL); ENS2(lext, seg_cap * 4); ENS2(bigfb, seg_cap * 4); ENSW(lext_p, dp_lext_p_slot() * DP_WG_LEXT);
 		ENS2(fill1, seg_cap * 4); ENS2(fill2, seg_cap * 4); ENS2(fill3, seg_cap * 4); ENS2(fill_mid, seg_cap * 4); ENS2(fill_fb, seg_cap * 4); ENSW(fill_p, dp_fillp_slot() * DP_WG_FILL); ENSW(fill_cig, dp_fillp_cig_slot() * DP_WG_FILL); ENS2(extp, seg_cap * 4 * 8); ENSW(extp_p, dp_extp_slot() * DP_WG_EXT); ENSW(extp_cig, dp_extp_cig_slot() * DP_WG_EXT); ENS2(ext1, seg_cap * 4); ENS2(ext2, seg_cap * 4); ENS2(ext3, seg_cap * 4); ENS2(ext4, seg_cap * 4); ENS2(gen_list, seg_cap * 4); ENSW(ext_p, dp_fill_p_slot() * DP_WG_EXT);
@@ -1111,7 +1118,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 			for (int c = c0; c <= CHAIN_CLASSES.n; ++c) sp.start[c - c0 + 1] = sp.start[c - c0] + cls_count[c];
 			launch_dp_gather_long(B, e->cls_list.as<uint32_t>() + (size_t)c0 * n_reads, sp, CHAIN_CLASSES.nm[CHAIN_CLASSES.n - 1], st);
 		}
-		unsigned max_work = (unsigned)ns;
+		unsigned max_work = (unsigned)nsr;
 		for (int round = 0;; ++round) {
 			const int32_t *work = lists[round & 1];
 			int32_t *next = lists[(round + 1) & 1];
@@ -1139,6 +1146,9 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 				if (int rcj = join()) return rcj;
 				align_rest(B, e, st);
 				launch_dp_stitch(B, work, next, (e->debug & 0x200000) ? 0 : e->cur_max_read_len > 0 ? e->cur_max_read_len : 8192, DP_WG_STITCH, st);
+				// the tails of Z-drop splits are aligned now: the inversion between a head and its tail (mm_align1_inv), whose
+				// region -- one extension -- is aligned in the next round
+				launch_dp_inv(B, work, next, e->inv_ws.as<int32_t>(), (int)std::min<unsigned>(DP_WG_INV, max_work), st);
 			}
 			launch_dp_round_end(B, st);
 			// Z-drop splits make new regions for the next round (rare); one small read-back per round
@@ -1147,6 +1157,11 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 			HIP_TRY(hipStreamSynchronize(st));
 			if (ctr[4] != 0) {
 				if (ctr[4] >= 9) { set_error("a gap between two seeds is too large for the alignment workspace"); return MNC_ERR_UNSUPPORTED; }
+				if (ctr[4] == 5) {                            // a read ran out of region slots (split tails, inversion regions)
+					e->slot_pad = e->slot_pad * 4;
+					*overflowed = 2;
+					return MNC_OK;
+				}
 				// segments: the worst case; CIGAR words: four times the room, at most one word per base of every
 				// region's query and target span (regions of a read may overlap: bounded by the retry count instead)
 				e->seg_cap_override = na + 2 * ns + 1024;
@@ -1420,7 +1435,7 @@ extern "C" int mnc_engine_dump(mnc_engine *e, int what, void *dst, int64_t cap_b
 	case MNC_DUMP_REG_OFFSETS: {
 		if (nr) HIP_TRY(hipMemcpy(c32.data(), B.n_reg, nr * 4, hipMemcpyDeviceToHost));
 		if (what == MNC_DUMP_REG_OFFSETS) return dump_offsets(c32, dst, cap_bytes, n_bytes);
-		for (size_t r = 0; r < nr; ++r) base[r] = an_off[r] / 3, cnt[r] = c32[r];
+		for (size_t r = 0; r < nr; ++r) base[r] = an_off[r] / 3 + (int64_t)r * B.slot_pad, cnt[r] = c32[r];
 		return dump_segments(B.regs, base, cnt, dst, cap_bytes, n_bytes);
 	}
 	case MNC_DUMP_CIGARS: {
@@ -1431,7 +1446,7 @@ extern "C" int mnc_engine_dump(mnc_engine *e, int what, void *dst, int64_t cap_b
 		for (size_t r = 0; r < nr; ++r) {
 			if (c32[r] <= 0) continue;
 			rd.resize((size_t)c32[r]);
-			HIP_TRY(hipMemcpy(rd.data(), B.regdp + an_off[r] / 3, (size_t)c32[r] * sizeof(RegDP), hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(rd.data(), B.regdp + an_off[r] / 3 + (int64_t)r * B.slot_pad, (size_t)c32[r] * sizeof(RegDP), hipMemcpyDeviceToHost));
 			for (int i = 0; i < c32[r]; ++i) {
 				const size_t o = out.size();
 				out.resize(o + (size_t)rd[i].n_cigar);

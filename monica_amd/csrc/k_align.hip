@@ -1627,7 +1627,12 @@ __global__ __launch_bounds__(64) void mnc_dp_inv(Batch B, const int32_t *work_li
 		if (!(r2.flags & REG_SPLIT_INV) || d2.state != 2 || d2.head <= 0) continue;
 		const int64_t hslot = d2.head - 1;
 		const mnc_reg_t r1 = B.regs[hslot];
-		if (B.regdp[hslot].inv_after) continue;                 // what precedes the tail in the skeleton's array is that inversion, not the head
+		{
+			// what precedes the tail in the skeleton's array is the inversion region behind the head, if it has one (aligned by
+			// now: this kernel follows the round's stitch), and not the head
+			const int ia = B.regdp[hslot].inv_after;
+			if (ia > 0 && (B.regs[ia - 1].flags & REG_HAS_DP)) continue;
+		}
 		if (!(r1.flags & REG_SPLIT_L) || !(r2.flags & REG_SPLIT_R)) continue;
 		if (r1.id != r1.parent && r1.parent != -2) continue;    // primaries only (-2: a tail of one)
 		if (r2.id != r2.parent && r2.parent != -2) continue;
@@ -1714,7 +1719,7 @@ __global__ __launch_bounds__(64) void mnc_dp_inv(Batch B, const int32_t *work_li
 				di.rs = di.re = di.rs0 = r1.re + t_off, di.qs = di.qe = di.qs0 = base + q_off;
 				di.re0 = r1.re + tl, di.qe0 = base + ql;
 				B.regs[nslot] = ri, B.regdp[nslot] = di;
-				B.regdp[tslot].inv_after = 1;
+				B.regdp[tslot].inv_after = (int32_t)nslot + 1;
 				const unsigned long long ni = atomicAdd(&B.dp_ctr[5], 1ULL);
 				next_list[ni] = (int32_t)nslot;
 			}

@@ -517,6 +517,7 @@ __global__ __launch_bounds__(64) void mnc_regions_post(Batch B, mnc_reg_t *work_
 		for (int i = 0; i < n0; ++i) {
 			const mnc_reg_t x = src[w[i]];
 			bool flt = !(x.flags & REG_INV) && x.cnt < B.min_cnt;
+			if ((x.flags & REG_INV) && !(x.flags & REG_HAS_DP)) flt = true;   // its extension found nothing: mm_align1_inv returns no region then
 			if (x.flags & REG_HAS_DP) {
 				if (x.mlen < B.min_sc) flt = true;
 				else if (x.dp_max < B.min_dp_max) flt = true;

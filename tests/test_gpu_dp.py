@@ -83,6 +83,48 @@ def test_zdrop_split_inversion_and_long_extensions(capi, oracle, world):
     _compare_dp(capi, oracle, world, bases, offsets, min_mapq=60)
 
 
+def test_inversion_regions(capi, oracle, world):
+    """mm_align1_inv on the GPU: reads with an inverted block (300 .. 1 500 bases, either strand, with errors, two
+    inversions in one read, an inversion next to junk): the stretch between the two halves of the split region is aligned
+    on the other strand -- a region of its own (flag 16, MAPQ 0, no seeds), every field and its CIGAR equal to the
+    oracle's.  With a diverged copy of the contig the second mapping has its own inversion region, a secondary of the
+    first's."""
+    g0, g1 = world["seqs"][0], world["seqs"][1]
+    rng = np.random.default_rng(5)
+
+    def noisy(x, rate):
+        x = x.copy()
+        k = rng.random(len(x)) < rate
+        x[k] = util.ACGT[rng.integers(0, 4, int(k.sum()))]
+        return x
+    reads = []
+    for inv_len in (300, 500, 700, 1000, 1500):
+        reads.append(np.concatenate([g0[40000:42000], util.revcomp(g0[42000:42000 + inv_len]), g0[42000 + inv_len:44000 + inv_len]]))
+    reads.append(util.revcomp(reads[2]))                                                  # the whole read on the other strand
+    reads.append(noisy(reads[2], 0.05))
+    reads.append(noisy(reads[4], 0.08))
+    reads.append(np.concatenate([g1[10000:12000], util.revcomp(g1[12000:12600]), g1[12600:14600], util.revcomp(g1[14600:15400]), g1[15400:17400]]))
+    reads.append(np.concatenate([g1[30000:32000], util.revcomp(g1[32000:32700]), util.ACGT[rng.integers(0, 4, 300)], g1[33000:35000]]))
+    bases, offsets = util.pack_reads(reads)
+    for mq in (0, 60):
+        _compare_dp(capi, oracle, world, bases, offsets, min_mapq=mq)
+    regs = world["eng"].dump(capi.DUMP_REGS, capi.REG_DTYPE)
+    reg_off = world["eng"].dump(capi.DUMP_REG_OFFSETS, np.int64)
+    n_inv = [int(((regs["flags"][reg_off[r]:reg_off[r + 1]] & 16) != 0).sum()) for r in range(len(reads))]
+    assert n_inv[:6] == [1] * 6 and n_inv[8] == 2, n_inv
+    inv = regs[(regs["flags"] & 16) != 0]
+    assert (inv["mapq"] == 0).all() and (inv["cnt"] == 0).all() and (inv["flags"] & 1).all() and (inv["dp_max"] > 400).all()
+    # a diverged copy of the contig: both mappings split, both get an inversion region
+    base = synth.genome(0x51, 150_000)
+    seqs = [base, synth.diverge(base, 0x52, 20_000)]
+    w = _world_from(capi, oracle, [synth.contig_name(i) for i in range(2)], seqs)
+    rd = np.concatenate([base[60000:62000], util.revcomp(base[62000:62800]), base[62800:64800]])
+    b, o = util.pack_reads([rd, noisy(rd, 0.04)])
+    _compare_dp(capi, oracle, w, b, o, min_mapq=0)
+    regs = w["eng"].dump(capi.DUMP_REGS, capi.REG_DTYPE)
+    assert ((regs["flags"] & 16) != 0).sum() >= 2
+
+
 def test_repetitive_index_with_secondaries(capi, oracle):
     """Diverged copies: every read has secondaries whose DP scores set dp_max2 / n_sub of the
     primary (the DP branch of the MAPQ formula), and some reads change hands after alignment."""

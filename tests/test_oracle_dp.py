@@ -187,3 +187,72 @@ def test_chain_level_contract_is_still_available(oracle, world):
     assert (dp[0] == ch[0]).mean() > 0.9
     m = (dp[0] >= 0) & (ch[0] >= 0)
     assert (dp[1]["mlen"][m] > ch[1]["mlen"][m]).all()                      # exact matches vs. seed matches
+
+
+def test_striped_local_alignment_equals_the_plain_recurrence(oracle):
+    """ksw_ll_i16 literally (eight int16 lanes, striped query, lazy F, unsigned saturation as the floor) against plain
+    Smith-Waterman on the padded query with the striped layout's tie rules restated: score, end of the query, end of
+    the target -- the three numbers mm_align1_inv takes from it.  Random, related and low-complexity pairs."""
+    import ctypes as C
+    L = oracle.lib()
+    mat = np.zeros(25, dtype=np.int8)
+    L.orc_gen_simple_mat(5, mat.ctypes.data_as(C.c_void_p), C.c_int8(2), C.c_int8(4), C.c_int8(1))
+    rng = np.random.default_rng(11)
+
+    def both(q, t):
+        out = []
+        for f, extra in ((L.orc_ksw_ll_i16, (5,)), (L.orc_local_end, ())):
+            qe, te = C.c_int(), C.c_int()
+            args = [len(q), q.ctypes.data_as(C.c_void_p), len(t), t.ctypes.data_as(C.c_void_p)] + list(extra) + \
+                   [mat.ctypes.data_as(C.c_void_p), 4, 2, C.byref(qe), C.byref(te)]
+            out.append((f(*args), qe.value, te.value))
+        return out
+
+    in_padding = 0
+    for it in range(6000):
+        ql, tl = int(rng.integers(1, 150)), int(rng.integers(1, 150))
+        base = rng.integers(0, 4, max(ql, tl) + 40).astype(np.uint8)
+        if it % 4 == 0:
+            q, t = rng.integers(0, 4, ql).astype(np.uint8), rng.integers(0, 4, tl).astype(np.uint8)
+        else:
+            o1, o2 = int(rng.integers(0, 20)), int(rng.integers(0, 20))
+            q, t = base[o1:o1 + ql].copy(), base[o2:o2 + tl].copy()
+            for arr in (q, t):
+                k = rng.random(len(arr)) < 0.05 * (it % 4)
+                arr[k] = rng.integers(0, 5, int(k.sum()))
+            if it % 8 == 3:
+                q, t = q % 2, t % 2                                  # two letters: ties everywhere
+        a, b = both(np.ascontiguousarray(q), np.ascontiguousarray(t))
+        assert a == b, (ql, tl, a, b)
+        assert a[0] == L.orc_local_score(len(q), q.ctypes.data_as(C.c_void_p), len(t), t.ctypes.data_as(C.c_void_p),
+                                         mat.ctypes.data_as(C.c_void_p), 4, 2)
+        in_padding += a[1] >= ql
+    assert in_padding > 100                                       # the quirk of the layout is exercised: an end among the padding positions
+
+
+def test_inversion_between_the_halves_of_a_split_region(oracle):
+    """mm_align1_inv: a read whose middle block is inverted.  The chain runs over the block, the gap filling there
+    Z-drops with a positive inversion test, the region splits -- and the stretch between the halves is aligned on the
+    other strand: a third region, flagged, with MAPQ 0, covering the block on query and target."""
+    import util
+    names, seqs = util.small_genomes()
+    idx = oracle.Index.from_seqs(names, [s.tobytes() for s in seqs])
+    idx.opt.cigar = 1
+    g0 = seqs[0]
+    for inv_len in (300, 700, 1500):
+        read = np.concatenate([g0[40000:42000], util.revcomp(g0[42000:42000 + inv_len]), g0[42000 + inv_len:44000 + inv_len]])
+        regs, cigs = idx.map_cigar(read.tobytes())
+        inv = [i for i in range(len(regs)) if regs["flags"][i] & 16]
+        assert len(regs) == 3 and len(inv) == 1
+        i = inv[0]
+        assert regs["rev"][i] == 1 and regs["mapq"][i] == 0 and regs["cnt"][i] == 0 and regs["score"][i] == 0
+        assert abs(int(regs["qs"][i]) - 2000) <= 15 and abs(int(regs["qe"][i]) - (2000 + inv_len)) <= 15
+        assert abs(int(regs["rs"][i]) - 42000) <= 15 and abs(int(regs["re"][i]) - (42000 + inv_len)) <= 15
+        assert regs["dp_max"][i] >= 2 * inv_len - 40 and regs["mlen"][i] >= inv_len - 20
+        assert sum(l for l, op in cigs[i] if op in "MI") == regs["qe"][i] - regs["qs"][i]
+        others = [k for k in range(3) if k != i]
+        assert all(regs["mapq"][k] == 60 and regs["flags"][k] & 6 for k in others)      # the two halves, split
+    # the same block on the forward strand: no split, no inversion region
+    read = np.concatenate([g0[40000:42000], g0[42000:42700], g0[42700:44700]])
+    regs, _ = idx.map_cigar(read.tobytes())
+    assert len(regs) == 1 and regs["flags"][0] == 1
