@@ -354,6 +354,20 @@ static void filter_bad_seeds_alt(int as1, int cnt1, orc128_t *a, int min_gap, in
 	free(K);
 }
 
+/* test hook: what mm_align1 does to a region's seeds before any base is aligned -- trims the chain's ends
+ * (mm_fix_bad_ends) and flags seeds around long indels (mm_filter_bad_seeds, mm_filter_bad_seeds_alt), with the
+ * constants mm_align1 passes.  a[0 .. n) are the seeds of ONE region (x = reference end position, y = span << 32 |
+ * query end position); the flags come back in a[].y (bit 40 LONG_JOIN, bit 41 IGNORE), the kept range in as1 / cnt1. */
+void orc_test_seed_filters(const orc_opt_t *opt, int n, orc128_t *a, int mlen, int32_t *as1, int32_t *cnt1)
+{
+	orc_reg_t r;
+	memset(&r, 0, sizeof(r));
+	r.as = 0, r.cnt = n, r.mlen = mlen;
+	fix_bad_ends(&r, a, opt->bw, opt->min_chain_score * 2, as1, cnt1);
+	filter_bad_seeds(*as1, *cnt1, a, 10, 40, opt->max_gap >> 1, 10);
+	filter_bad_seeds_alt(*as1, *cnt1, a, 30, opt->max_gap >> 1);
+}
+
 /* ------------------------------------------------------------------ one region */
 
 static void split_reg(orc_reg_t *r, orc_reg_t *r2, int n, int qlen, const orc128_t *a)
@@ -712,9 +726,9 @@ orc_reg_t *orc_align_regs(const orc_index *mi, const orc_opt_t *opt, int qlen, c
 		for (i = 0; i < n0; ++i) regs[i].n_cigar = cigs[i].n;
 		{
 			/* replicate select_sub's keep / drop decisions on a copy to learn the mapping */
-			orc_reg_t *cp = (orc_reg_t*)malloc((size_t)(n0 ? n0 : 1) * sizeof(orc_reg_t));
+			orc_reg_t *cp = (orc_reg_t*)malloc((size_t)(n0 > 0 ? n0 : 1) * sizeof(orc_reg_t));
 			int n1 = n0;
-			memcpy(cp, regs, sizeof(orc_reg_t) * (size_t)n0);
+			if (n0 > 0) memcpy(cp, regs, sizeof(orc_reg_t) * (size_t)n0);
 			for (i = 0; i < n0; ++i) cp[i].dp_score = i;           /* carry the slot through the compaction */
 			orc_select_sub(opt->pri_ratio, orc_index_k(mi) * 2, opt->best_n, &n1, cp);
 			for (i = 0; i < n1; ++i) old_of[i] = cp[i].dp_score;

@@ -161,6 +161,9 @@ int orc_ksw_ll_i16(int qlen, const uint8_t *query, int tlen, const uint8_t *targ
                    int gapo, int gape, int *qe, int *te);
 int orc_local_end(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int q, int e, int *qe, int *te);
 
+/* test hook for the seed filters of mm_align1 (mm_align.c) */
+void orc_test_seed_filters(const orc_opt_t *opt, int n, orc128_t *a, int mlen, int32_t *as1, int32_t *cnt1);
+
 /* base-level alignment of all regions of one read (mm_align_skeleton + the second hierarchy
  * pass of align_regs); regs is realloc'd when a Z-drop splits a region.  a[] are the chained
  * anchors; seq the read (ASCII). */

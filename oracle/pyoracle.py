@@ -56,7 +56,7 @@ A128_DTYPE = np.dtype([("x", "<u8"), ("y", "<u8")])
 
 def build(force=False):
     so = os.path.join(_HERE, "liborc.so")
-    src = [os.path.join(_HERE, f) for f in ("mm_oracle.c", "mm_oracle.h", "Makefile")]
+    src = [os.path.join(_HERE, f) for f in ("mm_oracle.c", "mm_ksw.c", "mm_align.c", "mm_oracle.h", "mm_internal.h", "Makefile")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
