@@ -42,7 +42,7 @@ CONTRACT_DP, CONTRACT_CHAIN = 0, 1
 # every symbol include/monica_amd.h declares (checked by tests/test_capi.py)
 EXPORTS = [
     "mnc_strerror", "mnc_last_error", "mnc_device_count", "mnc_device_name", "mnc_device_mem_info",
-    "mnc_index_build", "mnc_index_build_mem", "mnc_index_save", "mnc_index_save_mmi", "mnc_index_load", "mnc_index_free",
+    "mnc_index_build", "mnc_index_build_mem", "mnc_index_build_device", "mnc_index_build_mem_device", "mnc_index_save", "mnc_index_save_mmi", "mnc_index_load", "mnc_index_free",
     "mnc_index_info", "mnc_index_contig_name", "mnc_index_contig_len", "mnc_index_contig_genome",
     "mnc_index_genome_name", "mnc_index_genome_len", "mnc_index_dump", "mnc_index_set_mid_occ",
     "mnc_engine_create", "mnc_engine_destroy", "mnc_engine_stream", "mnc_engine_device_bytes", "mnc_engine_set_index",
@@ -107,6 +107,8 @@ def lib():
     sig("mnc_device_mem_info", i32, [i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)])
     sig("mnc_index_build", i32, [cp, cp, i32, i32, pp])
     sig("mnc_index_build_mem", i32, [i32, C.POINTER(cp), C.POINTER(cp), C.POINTER(i64), i32, i32, pp])
+    sig("mnc_index_build_device", i32, [cp, cp, i32, i32, i32, pp])
+    sig("mnc_index_build_mem_device", i32, [i32, C.POINTER(cp), C.POINTER(cp), C.POINTER(i64), i32, i32, i32, pp])
     sig("mnc_index_save", i32, [vp, cp])
     sig("mnc_index_save_mmi", i32, [vp, cp])
     sig("mnc_index_load", i32, [cp, pp])
@@ -261,13 +263,16 @@ class Index:
         self.genome_lens = [int(L.mnc_index_genome_len(handle, g)) for g in range(info.n_genomes)]
 
     @classmethod
-    def build(cls, fasta_path, out_path=None, k=15, w=10):
+    def build(cls, fasta_path, out_path=None, k=15, w=10, device=None):
         h = C.c_void_p()
-        check(lib().mnc_index_build(_b(fasta_path), _b(out_path) if out_path else None, k, w, C.byref(h)))
+        if device is None:
+            check(lib().mnc_index_build(_b(fasta_path), _b(out_path) if out_path else None, k, w, C.byref(h)))
+        else:                                       # sketch + sort on that device: the same index
+            check(lib().mnc_index_build_device(_b(fasta_path), _b(out_path) if out_path else None, k, w, int(device), C.byref(h)))
         return cls(h)
 
     @classmethod
-    def from_seqs(cls, names, seqs, k=15, w=10):
+    def from_seqs(cls, names, seqs, k=15, w=10, device=None):
         n = len(names)
         bn = [_b(x) for x in names]
         bs = [x if isinstance(x, (bytes, bytearray)) else (x.tobytes() if isinstance(x, np.ndarray) else _b(x))
@@ -276,7 +281,10 @@ class Index:
         as_ = (C.c_char_p * n)(*bs)
         al = (C.c_int64 * n)(*[len(x) for x in bs])
         h = C.c_void_p()
-        check(lib().mnc_index_build_mem(n, an, as_, al, k, w, C.byref(h)))
+        if device is None:
+            check(lib().mnc_index_build_mem(n, an, as_, al, k, w, C.byref(h)))
+        else:                                       # sketch + sort on that device: the same index
+            check(lib().mnc_index_build_mem_device(n, an, as_, al, k, w, int(device), C.byref(h)))
         return cls(h)
 
     @classmethod

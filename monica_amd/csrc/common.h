@@ -107,6 +107,8 @@ struct mnc_index {
 namespace mnc {
 // index.cpp
 int index_finalize(mnc_index *idx, std::vector<std::pair<uint64_t, uint64_t>> &pairs);
+void index_genome_table(mnc_index *idx);
+void pack_contigs(mnc_index *idx, const char *const *seqs, const int64_t *lens, int n_seq);
 int cal_mid_occ(const mnc_index *idx, float f);
 // engine side
 int index_upload(mnc_index *idx, int device, DeviceIndex **out);

@@ -1235,7 +1235,14 @@ extern "C" int mnc_engine_prefetch(mnc_engine *e, const uint8_t *bases, const in
 	int rc = e->pf_bases_buf.ensure((size_t)total + 32);
 	if (!rc) rc = e->pf_offsets_buf.ensure(((size_t)n_reads + 1) * 8);
 	if (rc) return rc;
-	if (total > 0) HIP_TRY(hipMemcpyAsync(e->pf_bases_buf.p, bases, (size_t)total, hipMemcpyHostToDevice, e->copy_stream));
+	// In pieces: the copy engines take their requests in turn, and the running batch's small read-backs (anchor totals,
+	// round counters: a few bytes each, the host waits for them) would otherwise queue behind half a gigabyte --
+	// measured: a batch that starts together with a 500 MB copy takes 48.4 ms instead of 41.0 (profiles/r03i_e2e_probe.txt)
+	constexpr size_t PF_PIECE = 4u << 20;
+	for (size_t o = 0; o < (size_t)total; o += PF_PIECE) {
+		const size_t len = std::min(PF_PIECE, (size_t)total - o);
+		HIP_TRY(hipMemcpyAsync((uint8_t*)e->pf_bases_buf.p + o, bases + o, len, hipMemcpyHostToDevice, e->copy_stream));
+	}
 	HIP_TRY(hipMemcpyAsync(e->pf_offsets_buf.p, offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, e->copy_stream));
 	HIP_TRY(hipEventRecord(e->ev_prefetch, e->copy_stream));
 	e->pf_valid = true, e->pf_bases = bases, e->pf_offsets = offsets, e->pf_n = n_reads, e->pf_total = total;

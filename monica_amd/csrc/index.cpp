@@ -135,7 +135,7 @@ static void contig_minimizers(const char *s, int64_t len, int64_t lo, int64_t hi
 
 // contig bases -> 4-bit codes.  Words shared by two contigs are written by one thread only:
 // a contig's leading and trailing partial words are merged serially afterwards.
-static void pack_contigs(mnc_index *idx, const char *const *seqs, const int64_t *lens, int n_seq)
+void pack_contigs(mnc_index *idx, const char *const *seqs, const int64_t *lens, int n_seq)
 {
 	uint32_t *S = idx->seq4.data();
 #pragma omp parallel for schedule(dynamic, 1)
@@ -184,8 +184,15 @@ int index_finalize(mnc_index *idx, std::vector<std::pair<uint64_t, uint64_t>> &p
 		idx->pos[i] = pairs[i].second;
 	}
 	idx->key_off.push_back(pairs.size());
-	// genomes = distinct contig names in order of first appearance (database.py:59-64 gives
-	// every record of one genome the same "tax_unit:accession" id)
+	index_genome_table(idx);
+	idx->mid_occ = cal_mid_occ(idx, idx->par.mid_occ_frac);
+	return MNC_OK;
+}
+
+// genomes = distinct contig names in order of first appearance (database.py:59-64 gives
+// every record of one genome the same "tax_unit:accession" id)
+void index_genome_table(mnc_index *idx)
+{
 	std::map<std::string, int> seen;
 	idx->contig_genome.assign(idx->contig_name.size(), 0);
 	idx->genome_name.clear(), idx->genome_len.clear();
@@ -203,8 +210,6 @@ int index_finalize(mnc_index *idx, std::vector<std::pair<uint64_t, uint64_t>> &p
 		idx->genome_len[g] += idx->contig_len[i];
 		idx->total_len += idx->contig_len[i];
 	}
-	idx->mid_occ = cal_mid_occ(idx, idx->par.mid_occ_frac);
-	return MNC_OK;
 }
 
 static int check_kw(int k, int w)
@@ -289,7 +294,7 @@ extern "C" int mnc_index_build_mem(int n_seq, const char *const *names, const ch
 	return MNC_OK;
 }
 
-extern "C" int mnc_index_build(const char *fasta_path, const char *out_path, int k, int w, mnc_index **out)
+static int index_build_from_fasta(const char *fasta_path, const char *out_path, int k, int w, int device, mnc_index **out)
 {
 	if (!fasta_path || !out) return MNC_ERR_ARG;
 	*out = nullptr;
@@ -325,7 +330,8 @@ extern "C" int mnc_index_build(const char *fasta_path, const char *out_path, int
 	std::vector<int64_t> lp(names.size());
 	for (size_t i = 0; i < names.size(); ++i) np[i] = names[i].c_str(), sp[i] = seqs[i].data(), lp[i] = (int64_t)seqs[i].size();
 	mnc_index *idx = nullptr;
-	int e = mnc_index_build_mem((int)names.size(), np.data(), sp.data(), lp.data(), k, w, &idx);
+	int e = device < 0 ? mnc_index_build_mem((int)names.size(), np.data(), sp.data(), lp.data(), k, w, &idx)
+	                   : mnc_index_build_mem_device((int)names.size(), np.data(), sp.data(), lp.data(), k, w, device, &idx);
 	if (e) return e;
 	if (idx->keys.empty()) { delete idx; set_error("no minimizer in %s", fasta_path); return MNC_ERR_FORMAT; }
 	if (out_path) {
@@ -334,6 +340,17 @@ extern "C" int mnc_index_build(const char *fasta_path, const char *out_path, int
 	}
 	*out = idx;
 	return MNC_OK;
+}
+
+extern "C" int mnc_index_build(const char *fasta_path, const char *out_path, int k, int w, mnc_index **out)
+{
+	return index_build_from_fasta(fasta_path, out_path, k, w, -1, out);
+}
+
+extern "C" int mnc_index_build_device(const char *fasta_path, const char *out_path, int k, int w, int device, mnc_index **out)
+{
+	if (device < 0) return MNC_ERR_ARG;
+	return index_build_from_fasta(fasta_path, out_path, k, w, device, out);
 }
 
 namespace {

@@ -141,6 +141,15 @@ def default_device():
     return 0
 
 
+def _build_device(device):
+    """The device that sketches and sorts an index being built (csrc/k_idxbuild.hip), or None for the host builder
+    when no device is visible (building an index is not part of the classified path; both give the same index)."""
+    try:
+        return device if 0 <= device < _capi.device_count() else None
+    except _capi.MncError:
+        return None
+
+
 class Hit:
     """The attributes of a mappy alignment."""
     __slots__ = ("ctg", "ctg_len", "r_st", "r_en", "q_st", "q_en", "strand", "mapq", "mlen", "blen", "NM",
@@ -197,10 +206,10 @@ class Aligner:
             elif self._is_index_file(fn_idx_in):
                 self._index = _load_index_cached(fn_idx_in, self._device)
             elif INDEX_FILE_FORMAT == "mmi" and fn_idx_out:
-                self._index = _capi.Index.build(fn_idx_in, None, kk, ww)
+                self._index = _capi.Index.build(fn_idx_in, None, kk, ww, device=_build_device(self._device))
                 self._index.save(fn_idx_out, mmi=True)
             else:
-                self._index = _capi.Index.build(fn_idx_in, fn_idx_out, kk, ww)
+                self._index = _capi.Index.build(fn_idx_in, fn_idx_out, kk, ww, device=_build_device(self._device))
         except (_capi.MncError, OSError, ValueError) as e:      # mappy: a falsy Aligner, no exception
             self.error = e
             self._index = None

@@ -363,3 +363,76 @@ def test_device_built_tables_equal_the_host_form(capi):
         capi.check(capi.lib().mnc_index_set_host_tables(b._h, 1))
         ta, tb = capi.Engine(a, 0).dump_tables(), capi.Engine(b, 0).dump_tables()
         assert len(ta) == len(tb) and np.array_equal(ta, tb)
+
+
+def test_index_built_on_the_device_equals_the_host_builder(capi, oracle, tmp_path):
+    """mnc_index_build_mem_device / mnc_index_build_device (csrc/k_idxbuild.hip: contig pieces through the batch sketch
+    kernel, radix sort, run lengths) against the host builder and the oracle's index: every (hash, occurrence) pair in
+    order, mid_occ, the totals -- contigs whose lengths sit on the 256 kb piece boundaries, contigs shorter than a
+    k-mer / than a window, ambiguous bases (runs of N across a piece boundary, periodic n), lower case, a
+    low-complexity stretch, many contigs of one genome."""
+    rng = np.random.default_rng(17)
+    P = 1 << 18
+    seqs = [synth.genome(900 + i, L) for i, L in enumerate((P - 1, P, P + 1, 2 * P + 17, 3 * P - 5, 700_001, 9, 14, 15, 24, 25, 40, 100, 5000))]
+    n_run = seqs[3].copy()
+    n_run[P - 30:P + 45] = ord("N")                                   # a run of N across a piece boundary
+    n_run[2 * P - 3:2 * P + 2] = ord("n")
+    n_run[1000::7919] = ord("N")
+    seqs.append(n_run)
+    lower = np.frombuffer(seqs[5].tobytes().lower(), dtype=np.uint8).copy()
+    seqs.append(lower[:300_000])
+    lowc = seqs[5][:400_000].copy()
+    lowc[100_000:100_600] = np.tile(np.frombuffer(b"ACACACGT", dtype=np.uint8), 75)
+    lowc[P - 200:P + 200] = ord("A")                                  # a homopolymer across the boundary
+    seqs.append(lowc)
+    names = [synth.contig_name(i // 3) for i in range(len(seqs))]     # several contigs per genome
+    host = capi.Index.from_seqs(names, seqs)
+    dev = capi.Index.from_seqs(names, seqs, device=0)
+    hh, hy = host.dump()
+    dh, dy = dev.dump()
+    assert np.array_equal(hh, dh) and np.array_equal(hy, dy)
+    hi, di = host.info(), dev.info()
+    for f in ("k", "w", "n_contigs", "n_genomes", "mid_occ", "n_keys", "n_occ", "total_len"):
+        assert getattr(hi, f) == getattr(di, f), f
+    assert host.genome_names == dev.genome_names and host.genome_lens == dev.genome_lens
+    oidx = oracle.Index.from_seqs(names, [s.tobytes() for s in seqs])
+    assert dev.mid_occ == oidx.mid_occ
+    oh, oy = oidx.dump()
+    assert np.array_equal(dh, oh) and np.array_equal(dy, oy)
+    # the two indexes classify alike (the contig bases of the alignment stage included)
+    good = [s for s in seqs if len(s) > 100_000]
+    b, o, _ = synth.reads(good, 300, 3000, seed=5)
+    e1, e2 = capi.Engine(host, 0), capi.Engine(dev, 0)
+    r1, r2 = e1.classify(b, o, 0), e2.classify(b, o, 0)
+    assert np.array_equal(r1[0], r2[0]) and np.array_equal(r1[2], r2[2])
+    for k in capi.HIT_DTYPE.names:
+        assert np.array_equal(r1[1][k], r2[1][k]), k
+    e1.close(), e2.close()
+    # from a FASTA file, written to an index file: the file loads to the same index
+    fa = str(tmp_path / "db.fna.gz")
+    synth.write_fasta(fa, names[:6], seqs[:6])
+    out = str(tmp_path / "index1.mmi")
+    built = capi.Index.build(fa, out, device=0)
+    again = capi.Index.load(out)
+    ref = capi.Index.from_seqs(names[:6], seqs[:6])
+    for x in (built, again):
+        a1, a2 = x.dump()
+        b1, b2 = ref.dump()
+        assert np.array_equal(a1, b1) and np.array_equal(a2, b2) and x.mid_occ == ref.mid_occ
+
+
+def test_the_20_genome_index_is_built_on_the_device_in_a_fraction_of_a_second(capi):
+    import time
+    names, seqs = synth.genome_set(20)
+    bs = [s.tobytes() for s in seqs]
+    capi.Index.from_seqs(names[:1], bs[:1], device=0)             # the first call pays for module load and allocator warm-up
+    t0 = time.perf_counter()
+    dev = capi.Index.from_seqs(names, bs, device=0)
+    t_dev = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    host = capi.Index.from_seqs(names, bs)
+    t_host = time.perf_counter() - t0
+    a, b = dev.dump(), host.dump()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and dev.mid_occ == host.mid_occ
+    print(f"index of 94 Mbp: device {t_dev:.3f} s, host {t_host:.3f} s")
+    assert t_dev < 0.6 and t_dev < t_host
