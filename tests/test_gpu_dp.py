@@ -111,7 +111,9 @@ def test_inversion_regions(capi, oracle, world):
     regs = world["eng"].dump(capi.DUMP_REGS, capi.REG_DTYPE)
     reg_off = world["eng"].dump(capi.DUMP_REG_OFFSETS, np.int64)
     n_inv = [int(((regs["flags"][reg_off[r]:reg_off[r + 1]] & 16) != 0).sum()) for r in range(len(reads))]
-    assert n_inv[:6] == [1] * 6 and n_inv[8] == 2, n_inv
+    # (the read with two inverted blocks gets ONE inversion region: when the second tail is reached, what precedes it in
+    # the skeleton's array is the first inversion's region, not a split head, and mm_align1_inv declines)
+    assert n_inv[:6] == [1] * 6 and n_inv[8] == 1, str(n_inv)
     inv = regs[(regs["flags"] & 16) != 0]
     assert (inv["mapq"] == 0).all() and (inv["cnt"] == 0).all() and (inv["flags"] & 1).all() and (inv["dp_max"] > 400).all()
     # a diverged copy of the contig: both mappings split, both get an inversion region
