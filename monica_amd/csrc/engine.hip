@@ -187,6 +187,23 @@ __global__ __launch_bounds__(PB_N) void mnc_hist_offsets(const uint32_t *hist_tm
 	if (c == 0 && b == 0) q_off[(size_t)n_tiles * PB_N] = chunk_off_bm[(size_t)PB_N * n_chunks];   // the total
 }
 
+// ================================================================ small read-backs
+// The few numbers the host needs in the middle of a batch (anchor total, size-class counts, round counters) are written
+// by a one-wave kernel straight into page-locked host memory instead of being fetched with hipMemcpyAsync: a copy
+// request queues behind every copy submitted before it on the same engine, and with the next batch's bases on their
+// way (mnc_engine_prefetch: half a gigabyte) a four-byte read-back waited 7 ms for them -- measured, profiles/r03*.
+struct MailItem { const void *src; uint32_t dst_word, n_words; };
+constexpr int MAIL_MAX = 8;
+struct MailList { MailItem it[MAIL_MAX]; int n; };
+__global__ __launch_bounds__(64) void mnc_mail(MailList L, uint32_t *host_box)
+{
+	for (int k = 0; k < L.n; ++k) {
+		const uint32_t *s = static_cast<const uint32_t*>(L.it[k].src);
+		for (uint32_t i = threadIdx.x; i < L.it[k].n_words; i += 64) host_box[L.it[k].dst_word + i] = s[i];
+	}
+	__threadfence_system();
+}
+
 // ================================================================ device buffer
 struct Buf {
 	void *p = nullptr;
@@ -475,6 +492,7 @@ struct mnc_engine {
 	SharedWs *ws = nullptr;                  // the device's alignment scratch (held during the alignment stage only)
 	Buf fill1, fill2, fill3, fill_mid, fill_fb, extp, mid_list, lfill, lext, bigfb, ext1, ext2, ext3, ext4, gen_list;
 	size_t seg_cap_override = 0, cig_cap_override = 0;
+	uint32_t *mailbox = nullptr;             // 1 KiB of page-locked host memory the device writes its small read-backs to (mnc_mail)
 	int slot_pad = 2;                        // region slots per read beyond anchors / 3 (device.h: reg_slot); grown when a batch runs out
 	Buf inv_ws;                              // mnc_dp_inv: two columns per workgroup
 	int cur_max_read_len = 0;                // of the batch being classified (sizes the stitch kernel's LDS)
@@ -612,6 +630,7 @@ extern "C" void mnc_engine_destroy(mnc_engine *e)
 	if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
 	if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
 	if (e->ev_prefetch) (void)hipEventDestroy(e->ev_prefetch);
+	if (e->mailbox) (void)hipHostFree(e->mailbox);
 	if (e->stream) (void)hipStreamDestroy(e->stream);
 	delete e;
 }
@@ -643,6 +662,7 @@ extern "C" int mnc_engine_create(mnc_index *idx, int device, mnc_engine **out)
 	if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
 	if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking);
 	if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_prefetch, hipEventDisableTiming);
+	if (he == hipSuccess) he = hipHostMalloc((void**)&e->mailbox, 1024, hipHostMallocDefault);
 	if (he != hipSuccess) { set_error("stream creation failed: %s", hipGetErrorString(he)); mnc_engine_destroy(e); return MNC_ERR_HIP; }
 	for (int s = 0; s < MNC_N_STAGES; ++s) for (int k = 0; k < 2; ++k) (void)hipEventCreate(&e->ev[s][k]);
 	// gap cost: (int)(dd * .01 * avg_span) + (ilog2(dd) >> 1), evaluated in double exactly as
@@ -972,11 +992,15 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 		HIP_TRY(hipMemsetAsync(e->cls_count.p, 0, (MAX_CHAIN_CLASSES + 1) * 4, st));
 		launch_bin_reads(B, CHAIN_CLASSES, e->cls_count.as<uint32_t>(), e->cls_list.as<uint32_t>(), st);
 		// the anchor total sizes every later buffer: one small read-back per batch
-		HIP_TRY(hipMemcpyAsync(&total_anchors, B.an_off + n_reads, 8, hipMemcpyDeviceToHost, st));
-		HIP_TRY(hipMemcpyAsync(&total_q, B.q_off + n_tiles * PB_N, 8, hipMemcpyDeviceToHost, st));
-		HIP_TRY(hipMemcpyAsync(cls_count, e->cls_count.p, (MAX_CHAIN_CLASSES + 1) * 4, hipMemcpyDeviceToHost, st));
-		HIP_TRY(hipMemcpyAsync(&overflow, B.overflow, 4, hipMemcpyDeviceToHost, st));
+		MailList ml;
+		ml.n = 4;
+		ml.it[0] = { B.an_off + n_reads, 0, 2 }, ml.it[1] = { B.q_off + n_tiles * PB_N, 2, 2 };
+		ml.it[2] = { e->cls_count.p, 4, (uint32_t)(MAX_CHAIN_CLASSES + 1) }, ml.it[3] = { B.overflow, 4 + MAX_CHAIN_CLASSES + 1, 1 };
+		hipLaunchKernelGGL(mnc_mail, dim3(1), dim3(64), 0, st, ml, e->mailbox);
 		HIP_TRY(hipStreamSynchronize(st));
+		memcpy(&total_anchors, e->mailbox, 8), memcpy(&total_q, e->mailbox + 2, 8);
+		memcpy(cls_count, e->mailbox + 4, (MAX_CHAIN_CLASSES + 1) * 4);
+		overflow = e->mailbox[4 + MAX_CHAIN_CLASSES + 1];
 	}
 	if (overflow || total_q > (int64_t)q_cap) {
 		e->q_cap_override = (size_t)total_q + (size_t)total_q / 8 + 4096;
@@ -1153,8 +1177,14 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 			launch_dp_round_end(B, st);
 			// Z-drop splits make new regions for the next round (rare); one small read-back per round
 			unsigned long long ctr[6] = {0};
-			HIP_TRY(hipMemcpyAsync(ctr, e->dp_ctr.p, sizeof(ctr), hipMemcpyDeviceToHost, st));
-			HIP_TRY(hipStreamSynchronize(st));
+			{
+				MailList ml;
+				ml.n = 1;
+				ml.it[0] = { e->dp_ctr.p, 0, 12 };
+				hipLaunchKernelGGL(mnc_mail, dim3(1), dim3(64), 0, st, ml, e->mailbox);
+				HIP_TRY(hipStreamSynchronize(st));
+				memcpy(ctr, e->mailbox, sizeof(ctr));
+			}
 			if (ctr[4] != 0) {
 				if (ctr[4] >= 9) { set_error("a gap between two seeds is too large for the alignment workspace"); return MNC_ERR_UNSUPPORTED; }
 				if (ctr[4] == 5) {                            // a read ran out of region slots (split tails, inversion regions)

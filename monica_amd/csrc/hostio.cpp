@@ -19,7 +19,6 @@
 #include <cstring>
 #include <fcntl.h>
 #include <sys/stat.h>
-#include <sys/uio.h>
 #include <algorithm>
 #include <unistd.h>
 #include <omp.h>
@@ -613,41 +612,26 @@ extern "C" int mnc_fastq_route(const mnc_fastq *fq, const uint8_t *dest, const i
 		for (int t = 0; t < T; ++t) {
 			const uint32_t r0 = (uint32_t)((uint64_t)fq->n * (uint64_t)t / (uint64_t)T), r1 = (uint32_t)((uint64_t)fq->n * (uint64_t)(t + 1) / (uint64_t)T);
 			off_t pos[4];
-			// a record goes out as the pieces it consists of (title, bases, qualities: where the batch holds them), a few
-			// hundred records per pwritev call: no copy into a buffer of its own in between
-			std::vector<struct iovec> iov[4];
-			size_t iov_bytes[4] = { 0, 0, 0, 0 };
-			static const char AT[] = "@", NL[] = "\n", PLUS[] = "\n+\n", SP[] = " ";
+			std::string buf[4];
 			for (int k = 0; k < 4; ++k) {
 				pos[k] = start[k];
 				for (int u = 0; u < t; ++u) pos[k] += (off_t)slice_bytes[(size_t)u * 4 + k];
-				iov[k].reserve(1024);
 			}
 			auto flush = [&](int k) {
-				std::vector<struct iovec> &v = iov[k];
-				size_t first = 0;
-				while (first < v.size()) {
-					const int cnt = (int)std::min<size_t>(v.size() - first, 1024);
-					const ssize_t w = pwritev(fds[k], v.data() + first, cnt, pos[k]);
+				std::string &b = buf[k];
+				size_t done = 0;
+				while (done < b.size()) {
+					const ssize_t w = pwrite(fds[k], b.data() + done, b.size() - done, pos[k] + (off_t)done);
 					if (w < 0 && errno == EINTR) continue;
 					if (w <= 0) {
 #pragma omp atomic write
 						fail[k] = errno ? errno : EIO;
 						break;
 					}
-					pos[k] += (off_t)w;
-					size_t left = (size_t)w;                                // pieces written in full, then the partial one
-					while (first < v.size() && left >= v[first].iov_len) left -= v[first].iov_len, ++first;
-					if (left > 0) v[first].iov_base = (char*)v[first].iov_base + left, v[first].iov_len -= left;
+					done += (size_t)w;
 				}
-				if (fail[k]) for (size_t i = first; i < v.size(); ++i) pos[k] += (off_t)v[i].iov_len;   // keep the later slices' offsets
-				v.clear(), iov_bytes[k] = 0;
-			};
-			auto piece = [&](int k, const void *p_, size_t len) {
-				if (len == 0) return;
-				struct iovec e;
-				e.iov_base = const_cast<void*>(p_), e.iov_len = len;
-				iov[k].push_back(e), iov_bytes[k] += len;
+				pos[k] += (off_t)b.size();
+				b.clear();
 			};
 			for (uint32_t r = r0; r < r1; ++r) {
 				const uint8_t d = dest[r];
@@ -657,23 +641,24 @@ extern "C" int mnc_fastq_route(const mnc_fastq *fq, const uint8_t *dest, const i
 				const int64_t o = fq->offsets[r], l = fq->offsets[r + 1] - o;
 				for (int k = 0; k < 4; ++k) {
 					if (!(d >> k & 1)) continue;
-					piece(k, AT, 1);
+					std::string &b = buf[k];
+					b.push_back('@');
 					if (k == 2 && label && label[r] >= 0) {           // seq_record.id = tax_unit
 						const char *id = labels[label[r]];
 						const size_t idl = strlen(id);
-						if (t_len == 0) piece(k, id, idl);
-						else if (fq->id_len[r] == idl && memcmp(tt + fq->id_off[r], id, idl) == 0) piece(k, tt, t_len);
-						else { piece(k, id, idl); piece(k, SP, 1); piece(k, tt, t_len); }
-					} else piece(k, tt, t_len);
-					piece(k, NL, 1);
-					piece(k, fq->bases.p + o, (size_t)l);
-					piece(k, PLUS, 3);
-					piece(k, fq->quals.p + o, (size_t)l);
-					piece(k, NL, 1);
-					if (iov[k].size() > 1024 - 16 || iov_bytes[k] > (8u << 20)) flush(k);
+						if (t_len == 0) b.append(id, idl);
+						else if (fq->id_len[r] == idl && memcmp(tt + fq->id_off[r], id, idl) == 0) b.append(tt, t_len);
+						else { b.append(id, idl); b.push_back(' '); b.append(tt, t_len); }
+					} else b.append(tt, t_len);
+					b.push_back('\n');
+					b.append((const char*)fq->bases.p + o, (size_t)l);
+					b.append("\n+\n", 3);
+					b.append((const char*)fq->quals.p + o, (size_t)l);
+					b.push_back('\n');
+					if (b.size() > (2u << 20)) flush(k);
 				}
 			}
-			for (int k = 0; k < 4; ++k) if (!iov[k].empty()) flush(k);
+			for (int k = 0; k < 4; ++k) if (!buf[k].empty()) flush(k);
 		}
 	}
 	for (int k = 0; k < 4; ++k) {
