@@ -240,6 +240,9 @@ int mnc_engine_get_counters(mnc_engine *eng, int64_t *c, int n);
  * mnc_engine_dump_tables copies what the engine's device holds ([region_bits, disp_bits] int32, salts, displacement
  * bytes, presence filter, table slots) so that the two can be compared. */
 int mnc_index_set_host_tables(mnc_index *idx, int on);
+/* the device tables are cut into 2^bits regions (8 .. 10; 0 = chosen from the number of keys so that a region stays at
+ * 2 MiB): a speed matter only -- every value gives the same results (tests force the larger ones on small indexes) */
+int mnc_index_set_region_bits(mnc_index *idx, int bits);
 int mnc_engine_dump_tables(mnc_engine *eng, void *dst, int64_t cap_bytes, int64_t *n_bytes);
 
 /* stage dumps of the last batch, for kernel-level parity tests */

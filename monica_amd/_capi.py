@@ -48,7 +48,7 @@ EXPORTS = [
     "mnc_engine_create", "mnc_engine_destroy", "mnc_engine_stream", "mnc_engine_device_bytes", "mnc_engine_set_index",
     "mnc_classify_batch", "mnc_engine_prefetch", "mnc_classify_device", "mnc_engine_sync", "mnc_engine_fetch_hits",
     "mnc_counts", "mnc_best_hit",
-    "mnc_engine_set_profiling", "mnc_engine_set_debug", "mnc_engine_set_contract", "mnc_index_set_host_tables", "mnc_engine_dump_tables",
+    "mnc_engine_set_profiling", "mnc_engine_set_debug", "mnc_engine_set_contract", "mnc_index_set_host_tables", "mnc_index_set_region_bits", "mnc_engine_dump_tables",
     "mnc_comm_unique_id", "mnc_comm_init_rank", "mnc_comm_destroy", "mnc_allreduce_counts", "mnc_allgather_summaries", "mnc_engine_get_timings", "mnc_stage_name", "mnc_stage_kernel",
     "mnc_engine_get_counters", "mnc_engine_dump",
     "mnc_fastq_open", "mnc_fastq_close", "mnc_fastq_next", "mnc_fastq_detach_batch", "mnc_fastq_bases", "mnc_fastq_offsets",
@@ -136,6 +136,7 @@ def lib():
     sig("mnc_engine_set_profiling", i32, [vp, i32])
     sig("mnc_engine_set_debug", i32, [vp, i32])
     sig("mnc_index_set_host_tables", i32, [vp, i32])
+    sig("mnc_index_set_region_bits", i32, [vp, i32])
     sig("mnc_engine_dump_tables", i32, [vp, vp, C.c_int64, vp])
     sig("mnc_engine_set_contract", i32, [vp, i32])
     sig("mnc_comm_unique_id", i32, [vp])

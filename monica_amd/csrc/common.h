@@ -63,7 +63,8 @@ struct alignas(16) TableSlot {
 
 struct DeviceIndex {          // one per (index, device)
 	int device = -1;
-	TableSlot *table = nullptr;    // PB_N regions x region_slots
+	int pb_bits = 8;               // log2(regions): 8 .. 10, from the number of keys (index_upload)
+	TableSlot *table = nullptr;    // regions x region_slots
 	int region_bits = 0;           // log2(slots per region)
 	int disp_bits = 0;             // log2(displacement buckets per region)
 	uint8_t *disp = nullptr;       // [PB_N][1 << disp_bits]
@@ -102,6 +103,7 @@ struct mnc_index {
 	std::mutex dev_mutex;
 	std::deque<mnc::DeviceIndex> dev;   // a deque: engines keep pointers to its elements
 	bool host_tables = false;           // test switch: build the device tables with the host form (mnc_index_set_host_tables)
+	int force_pb_bits = 0;              // test switch: this many region bits whatever the size (mnc_index_set_region_bits); 0 = by size
 };
 
 namespace mnc {

@@ -18,10 +18,15 @@ struct Anchor { uint64_t x, y; };    // x = strand<<63 | rid<<32 | rpos ; y = sp
 // The hash table is cut into 2^PB_BITS contiguous regions ("buckets") by the top bits of the
 // hash.  Query minimizers are partitioned by bucket so that the probe of one bucket
 // touches one region (2 MiB for the 20-genome index: L2-resident) instead of random HBM lines.
-constexpr int PB_BITS = 8;
-constexpr int PB_N = 1 << PB_BITS;
+// How many regions follows the index (index_upload): 256 for up to ~15 M keys, 512 / 1 024 beyond, so that a region's
+// slots stay at 2 MiB -- the hot set of the XCD that walks it (a 62-genome part, 35 M keys, in 256 regions of 8 MiB ran
+// the probe at 0.32 of the roofline; profiles/README.md).
+constexpr int PB_BITS_MIN = 8, PB_BITS_MAX = 10;
+constexpr int PB_N_MAX = 1 << PB_BITS_MAX;
 constexpr int PT_READS = 4;                 // reads per partition tile (= one sketch workgroup)
-constexpr int PS_TILES = 64;                // tiles per super-tile (probe / collect granularity: 256 reads)
+constexpr int PS_TILES_MIN = 64;            // tiles per super-tile (probe / collect granularity) with 256 regions: 256 reads; it grows
+                                            // with the region count, so that a run (region, super-tile) keeps its ~900 queries
+constexpr int SUPER_READS_MAX = PS_TILES_MIN * PT_READS << (PB_BITS_MAX - PB_BITS_MIN);   // 1 024 (a hit record has 11 bits for the read)
 constexpr int PF_BITS = 18;                 // presence filter: 2^18 bits = 32 KiB per table region (fits LDS)
 constexpr int PF_WORDS = (1 << PF_BITS) / 32;
 // one-word Bloom filter: a key sets two bits of the word its rest selects; a query whose two bits
@@ -36,13 +41,12 @@ constexpr uint32_t HIT_HIGH = 0x7fffffffu;  // cnt marker: occurrences >= mid_oc
 
 // 64-bit query record: [21:0] rest of the hash, [22] strand, [23] tandem,
 // [43:24] query position (last base of the k-mer), [63:44] read ordinal in the batch
-constexpr int PB_REST_BITS = 2 * KMER - PB_BITS;            // 22
 constexpr int PD_MAX_BITS = 14;                             // at most 16384 displacement buckets (16 KiB of LDS)
 // The region comes from the LOW hash bits: minimizers are window minima, so their hash values
 // crowd towards zero and the high bits are far from uniform (region 0 would hold 5x its share).
-__host__ __device__ __forceinline__ uint32_t pb_bucket(uint32_t hash) { return hash & (uint32_t)(PB_N - 1); }
-__host__ __device__ __forceinline__ uint32_t pb_rest(uint32_t hash) { return hash >> PB_BITS; }
-__host__ __device__ __forceinline__ uint32_t pb_hash(uint32_t rest, uint32_t bucket) { return rest << PB_BITS | bucket; }
+__host__ __device__ __forceinline__ uint32_t pb_bucket(uint32_t hash, int pb_bits) { return hash & ((1u << pb_bits) - 1u); }
+__host__ __device__ __forceinline__ uint32_t pb_rest(uint32_t hash, int pb_bits) { return hash >> pb_bits; }
+__host__ __device__ __forceinline__ uint32_t pb_hash(uint32_t rest, uint32_t bucket, int pb_bits) { return rest << pb_bits | bucket; }
 // base slot of a rest inside its region (independent of the low bits that pick the displacement bucket)
 __host__ __device__ __forceinline__ uint32_t pd_base(uint32_t rest, int region_bits)
 {
@@ -62,11 +66,11 @@ __host__ __device__ __forceinline__ uint32_t pd_slot(uint32_t rest, uint32_t dis
 // start of run (bucket, tile) in the bucket-major record array.  The offsets are stored
 // tile-major ([tile][bucket], so a tile's 256 starts are one contiguous 2 KiB row); the end of
 // a run is the start of the next one in bucket-major order.
-__device__ __forceinline__ int64_t q_start(const int64_t *q_off, uint32_t n_tiles, uint32_t bucket, uint32_t tile)
+__device__ __forceinline__ int64_t q_start(const int64_t *q_off, uint32_t n_tiles, uint32_t bucket, uint32_t tile, uint32_t pb_n)
 {
 	if (tile >= n_tiles) { tile = 0; ++bucket; }
-	if (bucket >= (uint32_t)PB_N) return q_off[(size_t)n_tiles * PB_N];
-	return q_off[(size_t)tile * PB_N + bucket];
+	if (bucket >= pb_n) return q_off[(size_t)n_tiles * pb_n];
+	return q_off[(size_t)tile * pb_n + bucket];
 }
 
 // one probe hit = one query minimizer with 0 < cnt < mid_occ
@@ -141,10 +145,12 @@ struct Batch {
 	int64_t total_bases;
 	int min_mapq;
 	// ---- index
-	const TableSlot *table;       // [PB_N][1 << region_bits]
-	const uint8_t *disp;          // [PB_N][1 << disp_bits] hash-and-displace displacements
-	const uint32_t *salt;         // [PB_N] per-region salt of the slot function
-	const uint32_t *filter;       // [PB_N][PF_WORDS] presence bits of (region, low PF_BITS of the rest)
+	const TableSlot *table;       // [pb_n][1 << region_bits]
+	const uint8_t *disp;          // [pb_n][1 << disp_bits] hash-and-displace displacements
+	const uint32_t *salt;         // [pb_n] per-region salt of the slot function
+	const uint32_t *filter;       // [pb_n][PF_WORDS] presence bits of (region, low PF_BITS of the rest)
+	int pb_bits;                  // log2 of the number of table regions (8 .. 10), from the index
+	uint32_t pb_n, ps_tiles;      // 1 << pb_bits; tiles per super-tile = PS_TILES_MIN << (pb_bits - 8)
 	int region_bits, disp_bits;
 	int disp_in_lds;              // the displacement table of a region fits the probe kernel's LDS copy
 	const uint64_t *positions;

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64) void mnc_scan_sums(int64_t *sums, int64_t n_blo
 }
 
 template <class In>
-__global__ __launch_bounds__(SC_THREADS) void mnc_scan_apply(In in, int64_t n, const int64_t *sums, int64_t *out, int64_t out_tiles)
+__global__ __launch_bounds__(SC_THREADS) void mnc_scan_apply(In in, int64_t n, const int64_t *sums, int64_t *out, int64_t out_tiles, int64_t out_stride)
 {
 	__shared__ long long s[SC_THREADS / 64];
 	const int64_t base = (int64_t)blockIdx.x * SC_TILE + (int64_t)threadIdx.x * SC_ITEMS;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(SC_THREADS) void mnc_scan_apply(In in, int64_t n, c
 	for (int k = 0; k < SC_ITEMS; ++k) {
 		if (base + k < n) {
 			const int64_t i = base + k;
-			out[out_tiles ? (i % out_tiles) * PB_N + i / out_tiles : i] = pre;
+			out[out_tiles ? (i % out_tiles) * out_stride + i / out_tiles : i] = pre;
 		}
 		pre += v[k];
 		if (base + k == n - 1) out[n] = pre;
@@ -148,13 +148,13 @@ __global__ __launch_bounds__(SC_THREADS) void mnc_scan_apply(In in, int64_t n, c
 }
 
 template <class In>
-static void exclusive_scan(In in, int64_t n, int64_t *out, int64_t *sums, hipStream_t st, int64_t out_tiles = 0)
+static void exclusive_scan(In in, int64_t n, int64_t *out, int64_t *sums, hipStream_t st, int64_t out_tiles = 0, int64_t out_stride = 0)
 {
 	if (n <= 0) { (void)hipMemsetAsync(out, 0, 8, st); return; }
 	const int64_t nb = (n + SC_TILE - 1) / SC_TILE;
 	hipLaunchKernelGGL(mnc_scan_reduce<In>, dim3((unsigned)nb), dim3(SC_THREADS), 0, st, in, n, sums);
 	hipLaunchKernelGGL(mnc_scan_sums, dim3(1), dim3(64), 0, st, sums, nb);
-	hipLaunchKernelGGL(mnc_scan_apply<In>, dim3((unsigned)nb), dim3(SC_THREADS), 0, st, in, n, sums, out, out_tiles);
+	hipLaunchKernelGGL(mnc_scan_apply<In>, dim3((unsigned)nb), dim3(SC_THREADS), 0, st, in, n, sums, out, out_tiles, out_stride);
 }
 
 // ---------------------------------------------------------------- run offsets of the partition
@@ -165,19 +165,19 @@ static void exclusive_scan(In in, int64_t n, int64_t *out, int64_t *sums, hipStr
 // each chunk then walks its rows again with the running offsets.
 constexpr int HC_TILES = 64;
 
-__global__ __launch_bounds__(PB_N) void mnc_hist_chunk_sums(const uint32_t *hist_tm, uint32_t n_tiles, uint32_t n_chunks, uint32_t *sums_bm)
+__global__ __launch_bounds__(PB_N_MAX) void mnc_hist_chunk_sums(const uint32_t *hist_tm, uint32_t n_tiles, uint32_t n_chunks, uint32_t *sums_bm)
 {
-	const uint32_t c = blockIdx.x, b = threadIdx.x;
+	const uint32_t c = blockIdx.x, b = threadIdx.x, PB_N = blockDim.x;        // one thread per table region
 	const uint32_t t0 = c * HC_TILES, t1 = min(n_tiles, t0 + HC_TILES);
 	uint32_t s = 0;
 	for (uint32_t t = t0; t < t1; ++t) s += hist_tm[(size_t)t * PB_N + b];
 	sums_bm[(size_t)b * n_chunks + c] = s;
 }
 
-__global__ __launch_bounds__(PB_N) void mnc_hist_offsets(const uint32_t *hist_tm, uint32_t n_tiles, uint32_t n_chunks,
-                                                         const int64_t *chunk_off_bm, int64_t *q_off)
+__global__ __launch_bounds__(PB_N_MAX) void mnc_hist_offsets(const uint32_t *hist_tm, uint32_t n_tiles, uint32_t n_chunks,
+                                                             const int64_t *chunk_off_bm, int64_t *q_off)
 {
-	const uint32_t c = blockIdx.x, b = threadIdx.x;
+	const uint32_t c = blockIdx.x, b = threadIdx.x, PB_N = blockDim.x;
 	const uint32_t t0 = c * HC_TILES, t1 = min(n_tiles, t0 + HC_TILES);
 	int64_t run = chunk_off_bm[(size_t)b * n_chunks + c];
 	for (uint32_t t = t0; t < t1; ++t) {
@@ -264,7 +264,7 @@ static int check_device(int device)
 }
 
 int index_tables_on_device(const std::vector<uint32_t> &keys, const std::vector<uint64_t> &key_off, const std::vector<uint32_t> &reg_count,
-                           int region_bits, int disp_bits, TableSlot *d_table, uint8_t *d_disp, uint32_t *d_salt, uint32_t *d_filter,
+                           int pb_bits, int region_bits, int disp_bits, TableSlot *d_table, uint8_t *d_disp, uint32_t *d_salt, uint32_t *d_filter,
                            const uint64_t *d_positions);
 
 // the rest of the index (occurrence words, genome of a contig, contig bases) next to tables that are on the device already
@@ -289,24 +289,32 @@ int index_upload(mnc_index *idx, int device, DeviceIndex **out)
 	for (auto &d : idx->dev) if (d.device == device) { *out = &d; return MNC_OK; }
 	if (idx->keys.empty()) { set_error("empty index"); return MNC_ERR_FORMAT; }
 	HIP_TRY(hipSetDevice(device));
-	// ---- regions: PB_N blocks of R slots (load <= 0.5), perfectly hashed by hash-and-displace
-	std::vector<uint32_t> reg_count(PB_N, 0);
-	for (size_t i = 0; i < idx->keys.size(); ++i) ++reg_count[pb_bucket(idx->keys[i])];
-	size_t biggest = 0;
-	for (uint32_t c : reg_count) biggest = std::max(biggest, (size_t)c);
-	int region_bits = 6;
-	while ((1ULL << region_bits) < biggest * 2) ++region_bits;
+	// ---- regions: 2^pb_bits blocks of R slots (load <= 0.5), perfectly hashed by hash-and-displace.  As few regions
+	// as keep a region at 2^17 slots (2 MiB: what an XCD's L2 holds of the two or three regions its probe workgroups
+	// walk at a time), at most 2^PB_BITS_MAX
+	int pb_bits = idx->force_pb_bits ? idx->force_pb_bits : PB_BITS_MIN, region_bits = 6;
+	std::vector<uint32_t> reg_count;
+	for (;; ++pb_bits) {
+		reg_count.assign((size_t)1 << pb_bits, 0);
+		for (size_t i = 0; i < idx->keys.size(); ++i) ++reg_count[pb_bucket(idx->keys[i], pb_bits)];
+		size_t biggest = 0;
+		for (uint32_t c : reg_count) biggest = std::max(biggest, (size_t)c);
+		region_bits = 6;
+		while ((1ULL << region_bits) < biggest * 2) ++region_bits;
+		if (region_bits <= 17 || pb_bits == PB_BITS_MAX || idx->force_pb_bits) break;
+	}
+	const int PB_N = 1 << pb_bits;
 	// ---- the construction on the device (k_index.hip): the same tables in a few milliseconds; the host form below
 	// takes over when a region does not fit that kernel (or needs larger regions)
 	if (!idx->host_tables && region_bits <= 28) {
 		DeviceIndex d;
-		d.device = device, d.region_bits = region_bits, d.disp_bits = std::max(0, region_bits - 3);
+		d.device = device, d.pb_bits = pb_bits, d.region_bits = region_bits, d.disp_bits = std::max(0, region_bits - 3);
 		const size_t Rd = (size_t)1 << d.region_bits, NBd = (size_t)1 << d.disp_bits;
 		bool ok = hipMalloc((void**)&d.filter, (size_t)PB_N * PF_WORDS * 4) == hipSuccess && hipMalloc((void**)&d.disp, (size_t)PB_N * NBd) == hipSuccess &&
 		          hipMalloc((void**)&d.salt, PB_N * 4) == hipSuccess && hipMalloc((void**)&d.table, (size_t)PB_N * Rd * sizeof(TableSlot)) == hipSuccess &&
 		          hipMalloc((void**)&d.positions, idx->pos.size() * 8 + 8) == hipSuccess &&
 		          hipMemcpy(d.positions, idx->pos.data(), idx->pos.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
-		int trc = ok ? index_tables_on_device(idx->keys, idx->key_off, reg_count, d.region_bits, d.disp_bits, d.table, d.disp, d.salt, d.filter, d.positions) : 1;
+		int trc = ok ? index_tables_on_device(idx->keys, idx->key_off, reg_count, pb_bits, d.region_bits, d.disp_bits, d.table, d.disp, d.salt, d.filter, d.positions) : 1;
 		if (trc == 0) trc = index_upload_rest(idx, d) == MNC_OK ? 0 : -1;
 		if (trc == 0) {
 			d.bytes = (int64_t)((size_t)PB_N * Rd * sizeof(TableSlot) + (size_t)PB_N * PF_WORDS * 4 + (size_t)PB_N * NBd + (idx->pos.size() + 1) * 8 +
@@ -321,7 +329,7 @@ int index_upload(mnc_index *idx, int device, DeviceIndex **out)
 		if (trc < 0) { set_error("index upload failed"); return MNC_ERR_NOMEM; }
 	}
 	std::vector<std::vector<uint32_t>> reg(PB_N);       // key indices per region
-	for (size_t i = 0; i < idx->keys.size(); ++i) reg[pb_bucket(idx->keys[i])].push_back((uint32_t)i);
+	for (size_t i = 0; i < idx->keys.size(); ++i) reg[pb_bucket(idx->keys[i], pb_bits)].push_back((uint32_t)i);
 	int disp_bits = 0;
 	size_t R = 0, NB = 0;
 	std::vector<TableSlot> tab;
@@ -346,7 +354,7 @@ int index_upload(mnc_index *idx, int device, DeviceIndex **out)
 				TableSlot *T = tab.data() + (size_t)b * R;
 				for (auto &v : bk) v.clear();
 				for (uint32_t ki : reg[b]) {
-					const uint32_t rest = pb_rest(idx->keys[ki]);
+					const uint32_t rest = pb_rest(idx->keys[ki], pb_bits);
 					bk[rest & (NB - 1)].push_back(ki);
 					filt[(size_t)b * PF_WORDS + pf_word(rest)] |= pf_mask(rest);
 				}
@@ -369,10 +377,10 @@ int index_upload(mnc_index *idx, int device, DeviceIndex **out)
 						for (; d < 256; ++d) {
 							bool ok = true;
 							for (size_t a = 0; a < keys.size() && ok; ++a) {
-								const uint32_t sa = pd_slot(pb_rest(idx->keys[keys[a]]), (uint32_t)d, region_bits, sv);
+								const uint32_t sa = pd_slot(pb_rest(idx->keys[keys[a]], pb_bits), (uint32_t)d, region_bits, sv);
 								if (T[sa].key) ok = false;
 								for (size_t c = 0; c < a && ok; ++c)
-									if (sa == pd_slot(pb_rest(idx->keys[keys[c]]), (uint32_t)d, region_bits, sv)) ok = false;
+									if (sa == pd_slot(pb_rest(idx->keys[keys[c]], pb_bits), (uint32_t)d, region_bits, sv)) ok = false;
 							}
 							if (ok) break;
 						}
@@ -381,7 +389,7 @@ int index_upload(mnc_index *idx, int device, DeviceIndex **out)
 						for (uint32_t ki : keys) {
 							const uint32_t h = idx->keys[ki];
 							const uint64_t off = idx->key_off[ki], c = idx->key_off[ki + 1] - off;
-							TableSlot &sl = T[pd_slot(pb_rest(h), (uint32_t)d, region_bits, sv)];
+							TableSlot &sl = T[pd_slot(pb_rest(h, pb_bits), (uint32_t)d, region_bits, sv)];
 							sl.key = h + 1, sl.cnt = (uint32_t)c, sl.val = c == 1 ? idx->pos[off] : off;
 						}
 					}
@@ -404,7 +412,7 @@ int index_upload(mnc_index *idx, int device, DeviceIndex **out)
 		}
 	}
 	DeviceIndex d;
-	d.device = device, d.region_bits = region_bits, d.disp_bits = disp_bits;
+	d.device = device, d.pb_bits = pb_bits, d.region_bits = region_bits, d.disp_bits = disp_bits;
 	auto upload = [&](void **dst, const void *src, size_t bytes, size_t spare = 0) -> int {
 		HIP_TRY(hipMalloc(dst, bytes + spare ? bytes + spare : 8));
 		if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
@@ -736,6 +744,15 @@ extern "C" int mnc_engine_set_index(mnc_engine *e, mnc_index *idx)
 
 extern "C" void *mnc_engine_stream(mnc_engine *e) { return e ? (void*)e->stream : nullptr; }
 
+// test / tuning switch: this many region bits (8 .. 10) for the device tables made from now on; 0 = by the index's size
+extern "C" int mnc_index_set_region_bits(mnc_index *idx, int bits)
+{
+	if (!idx || (bits != 0 && (bits < PB_BITS_MIN || bits > PB_BITS_MAX))) return MNC_ERR_ARG;
+	std::lock_guard<std::mutex> lk(idx->dev_mutex);
+	idx->force_pb_bits = bits;
+	return MNC_OK;
+}
+
 extern "C" int mnc_index_set_host_tables(mnc_index *idx, int on)
 {
 	if (!idx) return MNC_ERR_ARG;
@@ -751,12 +768,12 @@ extern "C" int mnc_engine_dump_tables(mnc_engine *e, void *dst, int64_t cap_byte
 	if (!e || !n_bytes || !e->didx) return MNC_ERR_ARG;
 	HIP_TRY(hipSetDevice(e->device));
 	const DeviceIndex &d = *e->didx;
-	const size_t R = (size_t)1 << d.region_bits, NB = (size_t)1 << d.disp_bits;
+	const size_t R = (size_t)1 << d.region_bits, NB = (size_t)1 << d.disp_bits, PB_N = (size_t)1 << d.pb_bits;
 	const size_t sz[] = { 8, PB_N * 4, (size_t)PB_N * NB, (size_t)PB_N * PF_WORDS * 4, (size_t)PB_N * R * sizeof(TableSlot) };
 	*n_bytes = (int64_t)(sz[0] + sz[1] + sz[2] + sz[3] + sz[4]);
 	if (!dst || cap_bytes < *n_bytes) return MNC_ERR_RANGE;
 	uint8_t *o = (uint8_t*)dst;
-	const int32_t hdr[2] = { d.region_bits, d.disp_bits };
+	const int32_t hdr[2] = { d.region_bits | d.pb_bits << 16, d.disp_bits };
 	memcpy(o, hdr, 8), o += 8;
 	HIP_TRY(hipMemcpy(o, d.salt, sz[1], hipMemcpyDeviceToHost));
 	o += sz[1];
@@ -887,6 +904,8 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	const mnc_index *idx = e->idx;
 	*overflowed = 0;                                  // 1: query records, 2: segments / CIGAR pools of the alignment stage
 	const size_t nr = (size_t)n_reads, nb = (size_t)total_bases;
+	const int pb_bits = e->didx->pb_bits;
+	const size_t PB_N = (size_t)1 << pb_bits, PS_TILES = (size_t)PS_TILES_MIN << (pb_bits - PB_BITS_MIN);
 	const size_t n_tiles = (nr + PT_READS - 1) / PT_READS, n_super = (n_tiles + PS_TILES - 1) / PS_TILES;
 	// query records: a (w,k)-minimizer sketch keeps ~2/(w+1) of the k-mers; room for a third
 	// of the bases, and the whole batch is redone with room for all of them if that overflows
@@ -925,6 +944,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	B.bases = d_bases, B.offsets = d_offsets, B.n_reads = n_reads, B.total_bases = total_bases, B.min_mapq = min_mapq;
 	B.table = e->didx->table, B.filter = e->didx->filter, B.disp = e->didx->disp, B.salt = e->didx->salt, B.disp_in_lds = (e->didx->disp_bits <= PD_MAX_BITS && !(e->debug & 4)) ? 1 : 0, B.positions = e->didx->positions;
 	B.region_bits = e->didx->region_bits, B.disp_bits = e->didx->disp_bits;
+	B.pb_bits = pb_bits, B.pb_n = (uint32_t)PB_N, B.ps_tiles = (uint32_t)PS_TILES;
 	B.contig_genome = e->didx->contig_genome, B.mid_occ = idx->mid_occ, B.n_genomes = (int)idx->genome_name.size();
 	{
 		// an anchor is (strand, contig, position, tandem flag, query position < 2^20): when that
@@ -975,9 +995,9 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 			const uint32_t n_chunks = (uint32_t)((n_tiles + HC_TILES - 1) / HC_TILES);
 			uint32_t *sums_bm = e->hist_sums.as<uint32_t>();
 			int64_t *off_bm = e->hist_offs.as<int64_t>();
-			hipLaunchKernelGGL(mnc_hist_chunk_sums, dim3(n_chunks), dim3(PB_N), 0, st, B.hist_tm, (uint32_t)n_tiles, n_chunks, sums_bm);
+			hipLaunchKernelGGL(mnc_hist_chunk_sums, dim3(n_chunks), dim3((unsigned)PB_N), 0, st, B.hist_tm, (uint32_t)n_tiles, n_chunks, sums_bm);
 			exclusive_scan(ScanInPlain<uint32_t>{sums_bm}, (int64_t)n_chunks * PB_N, off_bm, e->scan_sums.as<int64_t>(), st);
-			hipLaunchKernelGGL(mnc_hist_offsets, dim3(n_chunks), dim3(PB_N), 0, st, B.hist_tm, (uint32_t)n_tiles, n_chunks, off_bm, B.q_off);
+			hipLaunchKernelGGL(mnc_hist_offsets, dim3(n_chunks), dim3((unsigned)PB_N), 0, st, B.hist_tm, (uint32_t)n_tiles, n_chunks, off_bm, B.q_off);
 		}
 		launch_partition(B, st);
 	}

@@ -120,7 +120,7 @@ int index_build_on_device(mnc_index *idx, int n_seq, const char *const *seqs, co
 	IB_TRY(d_mz.get(((size_t)total + 1) * sizeof(uint2)));
 	IB_TRY(d_cnt.get((np + 1) * 4));
 	const size_t n_tiles = (np + PT_READS - 1) / PT_READS;
-	IB_TRY(d_hist.get((n_tiles + 1) * PB_N * 4));
+	IB_TRY(d_hist.get((n_tiles + 1) * ((size_t)1 << PB_BITS_MIN) * 4));
 	IB_TRY(d_kept.get((np + 1) * 8));
 	IB_TRY(d_kept_off.get((np + 1) * 8));
 	hipStream_t st = nullptr;                                 // the default stream: everything here is one sequence
@@ -141,6 +141,7 @@ int index_build_on_device(mnc_index *idx, int n_seq, const char *const *seqs, co
 	B.bases = d_bases.as<uint8_t>(), B.offsets = d_off.as<int64_t>(), B.n_reads = (uint32_t)np, B.total_bases = total;
 	B.packed = d_packed.as<uint32_t>(), B.ambig = d_ambig.as<uint32_t>(), B.mz = d_mz.as<uint2>(), B.mz_cnt = d_cnt.as<int32_t>();
 	B.hist_tm = d_hist.as<uint32_t>(), B.n_tiles = (uint32_t)n_tiles;
+	B.pb_bits = PB_BITS_MIN, B.pb_n = 1u << PB_BITS_MIN, B.ps_tiles = PS_TILES_MIN;   // (the sketch kernel fills a histogram row per tile: unused here)
 	launch_pack(B, st);
 	launch_sketch(B, st);
 	// ---- what every piece keeps

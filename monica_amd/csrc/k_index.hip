@@ -16,11 +16,11 @@ namespace mnc {
 constexpr int IDX_MAX_BUCKET = 32;          // keys of one displacement bucket handled here (more: host form)
 constexpr int IDX_MAX_SALTS = 32;
 
-__global__ __launch_bounds__(256) void mnc_idx_scatter(const uint32_t *keys, int64_t n_keys, const uint32_t *reg_off, uint32_t *cursor, uint32_t *reg_list)
+__global__ __launch_bounds__(256) void mnc_idx_scatter(const uint32_t *keys, int64_t n_keys, const uint32_t *reg_off, uint32_t *cursor, uint32_t *reg_list, int pb_bits)
 {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n_keys) return;
-	const uint32_t b = pb_bucket(keys[i]);
+	const uint32_t b = pb_bucket(keys[i], pb_bits);
 	reg_list[reg_off[b] + atomicAdd(&cursor[b], 1u)] = (uint32_t)i;
 }
 
@@ -34,7 +34,7 @@ __device__ __forceinline__ void idx_order()
 __global__ __launch_bounds__(64) void mnc_idx_build(const uint32_t *keys, const uint64_t *key_off, const uint64_t *positions,
                                                     const uint32_t *reg_off, const uint32_t *reg_list, TableSlot *table, uint8_t *disp,
                                                     uint32_t *salt, uint32_t *filter, uint32_t *cnt_all, uint32_t *start_all, uint32_t *fill_all,
-                                                    uint32_t *rk_all, int32_t *fail, int region_bits, int disp_bits)
+                                                    uint32_t *rk_all, int32_t *fail, int pb_bits, int region_bits, int disp_bits)
 {
 	extern __shared__ uint32_t s_mem[];
 	const int lane = threadIdx.x, b = blockIdx.x;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64) void mnc_idx_build(const uint32_t *keys, const 
 	TableSlot *T = table + (size_t)b * R;
 	uint8_t *D = disp + (size_t)b * NB;
 	for (uint32_t i = lane; i < nk; i += 64) {
-		const uint32_t rest = pb_rest(keys[list[i]]);
+		const uint32_t rest = pb_rest(keys[list[i]], pb_bits);
 		atomicOr(&filter[(size_t)b * PF_WORDS + pf_word(rest)], pf_mask(rest));
 		atomicAdd(&cnt[rest & (NB - 1)], 1u);
 	}
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64) void mnc_idx_build(const uint32_t *keys, const 
 	}
 	idx_order();
 	for (uint32_t i = lane; i < nk; i += 64) {
-		const uint32_t ki = list[i], bkt = pb_rest(keys[ki]) & (NB - 1);
+		const uint32_t ki = list[i], bkt = pb_rest(keys[ki], pb_bits) & (NB - 1);
 		rk[start[bkt] + atomicAdd(&fillc[bkt], 1u)] = ki;
 	}
 	idx_order();
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64) void mnc_idx_build(const uint32_t *keys, const 
 					m &= m - 1;
 					const uint32_t st = start[bkt];
 					const uint32_t my_ki = (uint32_t)lane < s ? rk[st + lane] : 0u;
-					const uint32_t my_rest = (uint32_t)lane < s ? pb_rest(keys[my_ki]) : 0u;
+					const uint32_t my_rest = (uint32_t)lane < s ? pb_rest(keys[my_ki], pb_bits) : 0u;
 					int found = -1;
 					for (uint32_t d0 = 0; d0 < 256 && found < 0; d0 += 64) {
 						const uint32_t dd = d0 + lane;
@@ -129,10 +129,11 @@ __global__ __launch_bounds__(64) void mnc_idx_build(const uint32_t *keys, const 
 
 // 0 = built; 1 = not applicable here (the host form takes over); < 0 = error
 int index_tables_on_device(const std::vector<uint32_t> &keys, const std::vector<uint64_t> &key_off, const std::vector<uint32_t> &reg_count,
-                           int region_bits, int disp_bits, TableSlot *d_table, uint8_t *d_disp, uint32_t *d_salt, uint32_t *d_filter,
+                           int pb_bits, int region_bits, int disp_bits, TableSlot *d_table, uint8_t *d_disp, uint32_t *d_salt, uint32_t *d_filter,
                            const uint64_t *d_positions)
 {
 	const size_t R = (size_t)1 << region_bits, NB = (size_t)1 << disp_bits;
+	const int PB_N = 1 << pb_bits;
 	const size_t lds = R / 8 + (size_t)64 * IDX_MAX_BUCKET * 4;
 	if (lds > 150 * 1024 || keys.empty() || NB < 64) return 1;   // (a tiny index: fewer displacement buckets than lanes -- the host form)
 	if (hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_idx_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return 1; }
@@ -162,9 +163,9 @@ int index_tables_on_device(const std::vector<uint32_t> &keys, const std::vector<
 	IDX_TRY(hipMemset(d_disp, 0, (size_t)PB_N * NB));
 	IDX_TRY(hipMemset(d_salt, 0, PB_N * 4));
 	IDX_TRY(hipMemset(d_filter, 0, (size_t)PB_N * PF_WORDS * 4));
-	hipLaunchKernelGGL(mnc_idx_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_keys, (int64_t)n, d_reg_off, d_cursor, d_list);
+	hipLaunchKernelGGL(mnc_idx_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_keys, (int64_t)n, d_reg_off, d_cursor, d_list, pb_bits);
 	hipLaunchKernelGGL(mnc_idx_build, dim3(PB_N), dim3(64), lds, 0, d_keys, d_koff, d_positions, d_reg_off, d_list, d_table, d_disp, d_salt, d_filter,
-	                   d_cnt, d_cnt + (size_t)PB_N * NB, d_cnt + (size_t)PB_N * NB * 2, d_rk, d_fail, region_bits, disp_bits);
+	                   d_cnt, d_cnt + (size_t)PB_N * NB, d_cnt + (size_t)PB_N * NB * 2, d_rk, d_fail, pb_bits, region_bits, disp_bits);
 	std::vector<int32_t> fail(PB_N);
 	IDX_TRY(hipMemcpy(fail.data(), d_fail, PB_N * 4, hipMemcpyDeviceToHost));
 	IDX_TRY(hipGetLastError());

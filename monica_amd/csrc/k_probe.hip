@@ -6,7 +6,7 @@
 //
 // A random 16-byte gather into a 0.5 GB table costs a whole 64-byte HBM request (measured:
 // 6.8 GB fetched for 2.6 GB of algorithmic traffic, profiles/r01b).  So the batch's query
-// minimizers are first partitioned by table region (PB_N = 256 regions of contiguous slots,
+// minimizers are first partitioned by table region (256 .. 1 024 regions of contiguous slots,
 // 2 MiB each for the 20-genome index); the probe of one region then runs out of one XCD's
 // L2, and HBM only sees the streams: query records in, the table once, hit records out.
 //
@@ -28,13 +28,17 @@ constexpr int PA_THREADS = 64 * PT_READS;
 constexpr int PA_STAGE = 4096;                      // records staged per tile
 constexpr int PA_PRE = 16;                          // minimizers a lane fetches ahead (1024 per wave)
 
+// BK: the type that holds a region number in the stage (a byte with 256 regions: the kernel's LDS sets its occupancy)
+template <class BK>
 __global__ __launch_bounds__(PA_THREADS) void mnc_partition_queries(Batch B)
 {
-	__shared__ uint32_t s_cur[PB_N];
-	__shared__ uint32_t s_loc[PB_N + 1];            // local exclusive offsets of the buckets
-	__shared__ int64_t s_off[PB_N];
-	__shared__ uint64_t s_rec[PA_STAGE];
-	__shared__ uint8_t s_bkt[PA_STAGE];
+	extern __shared__ __align__(16) uint8_t pa_smem[];
+	const int pb_n = (int)B.pb_n, pb_bits = B.pb_bits;
+	uint64_t *s_rec = reinterpret_cast<uint64_t*>(pa_smem);                   // [PA_STAGE]
+	int64_t *s_off = reinterpret_cast<int64_t*>(s_rec + PA_STAGE);            // [pb_n]
+	uint32_t *s_cur = reinterpret_cast<uint32_t*>(s_off + pb_n);              // [pb_n]
+	uint32_t *s_loc = s_cur + pb_n;                                           // [pb_n + 1] local exclusive offsets of the buckets
+	BK *s_bkt = reinterpret_cast<BK*>(s_loc + pb_n + 4);                      // [PA_STAGE]
 	// Workgroups are dealt round-robin over the 8 XCDs: give each XCD a contiguous range of
 	// tiles, so that the short runs of neighbouring tiles (adjacent in a bucket's query array)
 	// are merged into full lines by one L2 instead of being written piecemeal by eight
@@ -52,26 +56,25 @@ __global__ __launch_bounds__(PA_THREADS) void mnc_partition_queries(Batch B)
 #pragma unroll
 	for (int k = 0; k < PA_PRE; ++k) pre[k] = k * 64 + lane < n ? mz[k * 64 + lane] : make_uint2(0xffffffffu, 0);
 
-	for (int k = tid; k < PB_N; k += PA_THREADS) {
+	for (int k = tid; k < pb_n; k += PA_THREADS) {
 		s_cur[k] = 0;
-		s_off[k] = B.q_off[(size_t)tile * PB_N + k];
-		s_loc[k + 1] = B.hist_tm[(size_t)tile * PB_N + k];
+		s_off[k] = B.q_off[(size_t)tile * pb_n + k];
+		s_loc[k + 1] = B.hist_tm[(size_t)tile * pb_n + k];
 	}
 	if (tid == 0) s_loc[0] = 0;
 	__syncthreads();
-	if (tid < 64) {                                  // inclusive scan of 256 counts by one wave
-		uint32_t v[4], sum = 0;
-#pragma unroll
-		for (int k = 0; k < 4; ++k) { v[k] = s_loc[1 + tid * 4 + k]; sum += v[k]; }
+	if (tid < 64) {                                  // inclusive scan of the region counts by one wave: pb_n / 64 per lane
+		const int per = pb_n >> 6;                      // 4, 8 or 16
+		uint32_t sum = 0;
+		for (int k = 0; k < per; ++k) sum += s_loc[1 + tid * per + k];
 		uint32_t inc = sum;
 #pragma unroll
 		for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (tid >= d) inc += o; }
 		uint32_t run = inc - sum;
-#pragma unroll
-		for (int k = 0; k < 4; ++k) { run += v[k]; s_loc[1 + tid * 4 + k] = run; }
+		for (int k = 0; k < per; ++k) { run += s_loc[1 + tid * per + k]; s_loc[1 + tid * per + k] = run; }
 	}
 	__syncthreads();
-	const uint32_t total = s_loc[PB_N];
+	const uint32_t total = s_loc[pb_n];
 	const bool staged = total <= (uint32_t)PA_STAGE;
 	uint32_t prev_hash = 0xffffffffu;               // hash of minimizer i0 - 1
 	for (int i0 = 0; i0 < n; i0 += 64) {
@@ -89,13 +92,13 @@ __global__ __launch_bounds__(PA_THREADS) void mnc_partition_queries(Batch B)
 		const bool tandem = valid && (q.x == left || q.x == right);
 		prev_hash = __shfl(q.x, 63);
 		if (valid) {
-			const uint32_t b = pb_bucket(q.x);
+			const uint32_t b = pb_bucket(q.x, pb_bits);
 			const uint32_t rank = atomicAdd(&s_cur[b], 1u);
 			const int64_t dst = s_off[b] + rank;
-			const uint64_t rec = (uint64_t)pb_rest(q.x) | (uint64_t)(q.y & 1u) << 22 | (uint64_t)(tandem ? 1u : 0u) << 23 |
+			const uint64_t rec = (uint64_t)pb_rest(q.x, pb_bits) | (uint64_t)(q.y & 1u) << 22 | (uint64_t)(tandem ? 1u : 0u) << 23 |
 			                     (uint64_t)(q.y >> 1) << 24 | (uint64_t)r << 44;
 			if (dst >= B.q_cap) *B.overflow = 1u;
-			else if (staged) { const uint32_t at = s_loc[b] + rank; s_rec[at] = rec; s_bkt[at] = (uint8_t)b; }
+			else if (staged) { const uint32_t at = s_loc[b] + rank; s_rec[at] = rec; s_bkt[at] = (BK)b; }
 			else B.qrec[dst] = rec;
 		}
 	}
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(PR_THREADS) void mnc_probe_buckets(Batch B, uint32_
 	__shared__ __align__(16) uint32_t s_filter[PF_WORDS];
 	__shared__ __align__(16) uint8_t s_disp[1 << PD_MAX_BITS];
 	const int nb = 1 << B.disp_bits;
-	if (bucket < (uint32_t)PB_N) {
+	if (bucket < B.pb_n) {
 		const uint4 *src = reinterpret_cast<const uint4*>(B.filter + (size_t)bucket * PF_WORDS);
 		uint4 *dst = reinterpret_cast<uint4*>(s_filter);
 #pragma unroll
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(PR_THREADS) void mnc_probe_buckets(Batch B, uint32_
 		} else for (int k = threadIdx.x; k < nb; k += PR_THREADS) s_disp[k] = ds[k];
 	}
 	__syncthreads();
-	if (bucket >= (uint32_t)PB_N || T >= B.n_super) return;
+	if (bucket >= B.pb_n || T >= B.n_super) return;
 	const int lane = lane_id();
 	const unsigned long long lt = (1ULL << lane) - 1ULL;
 	const uint32_t mid_occ = (uint32_t)B.mid_occ;
@@ -153,9 +156,9 @@ __global__ __launch_bounds__(PR_THREADS) void mnc_probe_buckets(Batch B, uint32_
 	const uint8_t *disp_hbm = B.disp + (size_t)bucket * nb;
 	const TableSlot *table = B.table + ((size_t)bucket << rbits);
 	{
-		const uint32_t t0 = T * PS_TILES, t1 = min(t0 + PS_TILES, B.n_tiles);
-		const int64_t q0 = q_start(B.q_off, B.n_tiles, bucket, t0), q1 = q_start(B.q_off, B.n_tiles, bucket, t1);
-		const uint32_t read0 = T * (PS_TILES * PT_READS);
+		const uint32_t t0 = T * B.ps_tiles, t1 = min(t0 + B.ps_tiles, B.n_tiles);
+		const int64_t q0 = q_start(B.q_off, B.n_tiles, bucket, t0, B.pb_n), q1 = q_start(B.q_off, B.n_tiles, bucket, t1, B.pb_n);
+		const uint32_t read0 = T * (B.ps_tiles * PT_READS);
 		int n_out = 0;
 		if (q1 <= B.q_cap) {
 			// PR_U queries per lane in flight: their probe chains overlap; the records of the
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(PR_THREADS) void mnc_probe_buckets(Batch B, uint32_
 					const uint32_t rest = (uint32_t)rec[u] & 0x3fffffu;
 					const uint32_t fm = pf_mask(rest);
 					pend[u] = pend[u] && (s_filter[pf_word(rest)] & fm) == fm;
-					want[u] = pb_hash(rest, bucket) + 1;
+					want[u] = pb_hash(rest, bucket, B.pb_bits) + 1;
 					const uint32_t db = rest & (uint32_t)(nb - 1);
 					slot[u] = pd_slot(rest, disp_in_lds ? s_disp[db] : (pend[u] ? disp_hbm[db] : 0), rbits, salt);
 				}
@@ -214,17 +217,17 @@ __global__ __launch_bounds__(PR_THREADS) void mnc_probe_buckets(Batch B, uint32_
 // (hits from the bottom of the read's slot range, too-frequent minimizers from the top), then
 // one wave per read finishes hit_cnt / an_cnt / rep_len.
 constexpr int CO_THREADS = 1024;
-constexpr int SUPER_READS = PS_TILES * PT_READS;
 
 __global__ __launch_bounds__(CO_THREADS) void mnc_collect_hits(Batch B)
 {
-	__shared__ int64_t s_start[PB_N];
-	__shared__ uint32_t s_pre[PB_N + 1];
-	__shared__ uint32_t s_cur[SUPER_READS], s_hi[SUPER_READS];
-	__shared__ unsigned long long s_an[SUPER_READS];
+	__shared__ int64_t s_start[PB_N_MAX];
+	__shared__ uint32_t s_pre[PB_N_MAX + 1];
+	__shared__ uint32_t s_cur[SUPER_READS_MAX], s_hi[SUPER_READS_MAX];
+	__shared__ unsigned long long s_an[SUPER_READS_MAX];
 	const uint32_t T = blockIdx.x;
-	const uint32_t t0 = T * PS_TILES;
+	const uint32_t t0 = T * B.ps_tiles;
 	const int tid = threadIdx.x;
+	const int PB_N = (int)B.pb_n, SUPER_READS = (int)(B.ps_tiles * PT_READS);
 	for (int b = tid; b < PB_N; b += CO_THREADS) {
 		s_start[b] = B.q_off[(size_t)t0 * PB_N + b];
 		s_pre[b + 1] = B.bhit_cnt[(size_t)b * B.n_super + T];
@@ -290,14 +293,16 @@ __global__ __launch_bounds__(CO_THREADS) void mnc_collect_hits(Batch B)
 void launch_partition(const Batch &B, hipStream_t st)
 {
 	if (B.n_tiles == 0) return;
-	hipLaunchKernelGGL(mnc_partition_queries, dim3((B.n_tiles + 7) / 8 * 8), dim3(PA_THREADS), 0, st, B);
+	const size_t fixed = (size_t)PA_STAGE * 8 + (size_t)B.pb_n * 16 + 16;
+	if (B.pb_n <= 256) hipLaunchKernelGGL(mnc_partition_queries<uint8_t>, dim3((B.n_tiles + 7) / 8 * 8), dim3(PA_THREADS), fixed + PA_STAGE, st, B);
+	else hipLaunchKernelGGL(mnc_partition_queries<uint16_t>, dim3((B.n_tiles + 7) / 8 * 8), dim3(PA_THREADS), fixed + 2 * PA_STAGE, st, B);
 }
 
 void launch_probe(const Batch &B, hipStream_t st)
 {
 	if (B.n_super == 0) return;
 	const uint32_t W = (B.n_super + PR_THREADS / 64 - 1) / (PR_THREADS / 64);
-	hipLaunchKernelGGL(mnc_probe_buckets, dim3(PB_N * W), dim3(PR_THREADS), 0, st, B, W);
+	hipLaunchKernelGGL(mnc_probe_buckets, dim3(B.pb_n * W), dim3(PR_THREADS), 0, st, B, W);
 }
 
 void launch_collect(const Batch &B, hipStream_t st)

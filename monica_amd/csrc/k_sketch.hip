@@ -174,15 +174,15 @@ __global__ __launch_bounds__(SK_THREADS) void mnc_sketch_minimizers(Batch B)
 	__shared__ __align__(16) int32_t s_hash_all[SK_THREADS / 64][SK_SLOTS];
 	__shared__ uint32_t s_words_all[SK_THREADS / 64][SK_WORDS];
 	__shared__ uint32_t s_strand_all[SK_THREADS / 64][64 + SK_EXTRA];   // per hashing lane: strand bits of its 17 positions
-	__shared__ uint32_t s_hist[PB_N];             // minimizers of this tile per table bucket
+	__shared__ uint32_t s_hist[PB_N_MAX];         // minimizers of this tile per table bucket
 
 	const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const uint32_t r = blockIdx.x * (SK_THREADS / 64) + wv;
-	for (int k = threadIdx.x; k < PB_N; k += SK_THREADS) s_hist[k] = 0;
+	for (int k = threadIdx.x; k < (int)B.pb_n; k += SK_THREADS) s_hist[k] = 0;
 	__syncthreads();
 	sketch_one_read(B, r, wv, lane, s_hash_all[wv], s_words_all[wv], s_strand_all[wv], s_hist);
 	__syncthreads();
-	for (int k = threadIdx.x; k < PB_N; k += SK_THREADS) B.hist_tm[(size_t)blockIdx.x * PB_N + k] = s_hist[k];
+	for (int k = threadIdx.x; k < (int)B.pb_n; k += SK_THREADS) B.hist_tm[(size_t)blockIdx.x * B.pb_n + k] = s_hist[k];
 }
 
 __device__ void sketch_one_read(const Batch &B, uint32_t r, int wv, int lane, int32_t *s_hash, uint32_t *s_words,
@@ -315,7 +315,7 @@ __device__ void sketch_one_read(const Batch &B, uint32_t r, int wv, int lane, in
 			const int32_t h = s_hash[q];
 			const int hl = t < SK_PER - SK_PAD ? lane : lane + 1, hb = t < SK_PER - SK_PAD ? t + SK_PAD : t + SK_PAD - SK_PER;
 			const uint32_t strand = q < SK_CHUNK ? (s_strand[hl] >> hb) & 1u : s_strand[64 + q - SK_CHUNK];
-			atomicAdd(&s_hist[pb_bucket((uint32_t)h)], 1u);
+			atomicAdd(&s_hist[pb_bucket((uint32_t)h, B.pb_bits)], 1u);
 			out[k_out++] = make_uint2((uint32_t)h, (uint32_t)(first_p + t + KMER - 1) << 1 | strand);
 		}
 	}
@@ -334,8 +334,8 @@ __global__ __launch_bounds__(64) void mnc_sketch_ambiguous(Batch B)
 	uint2 *out = B.mz + off;
 	const int n = sketch_serial(B.bases + off, len, out);
 	B.mz_cnt[r] = n;
-	uint32_t *row = B.hist_tm + (size_t)(r / PT_READS) * PB_N;
-	for (int i = 0; i < n; ++i) atomicAdd(&row[pb_bucket(out[i].x)], 1u);
+	uint32_t *row = B.hist_tm + (size_t)(r / PT_READS) * B.pb_n;
+	for (int i = 0; i < n; ++i) atomicAdd(&row[pb_bucket(out[i].x, B.pb_bits)], 1u);
 }
 
 void launch_pack(const Batch &B, hipStream_t st)

@@ -436,3 +436,35 @@ def test_the_20_genome_index_is_built_on_the_device_in_a_fraction_of_a_second(ca
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and dev.mid_occ == host.mid_occ
     print(f"index of 94 Mbp: device {t_dev:.3f} s, host {t_host:.3f} s")
     assert t_dev < 0.6 and t_dev < t_host
+
+
+@pytest.mark.parametrize("bits", [9, 10])
+def test_more_table_regions_change_nothing(capi, oracle, bits):
+    """The device tables are cut into 256, 512 or 1 024 regions by the index's size (a region stays at 2 MiB, the hot set of
+    an XCD's L2); the query partition, the probe and the collect kernels follow (region-major runs, super-tiles of 256 /
+    512 / 1 024 reads).  Forced onto a small index: every stage against the oracle as with 256 regions, the device-built
+    tables equal to the host form, batches around the super-tile boundaries."""
+    names, seqs = util.small_genomes()
+    idx = capi.Index.from_seqs(names, seqs)
+    capi.check(capi.lib().mnc_index_set_region_bits(idx._h, bits))
+    oidx = oracle.Index.from_seqs(names, [s.tobytes() for s in seqs])
+    w = dict(names=names, seqs=seqs, idx=idx, oidx=oidx, eng=capi.Engine(idx, 0))
+    rng = np.random.default_rng(bits)
+    bases, offsets = util.pack_reads(util.edge_reads(seqs, rng))
+    _compare_batch(capi, oracle, w, bases, offsets, min_mapq=0)
+    full, offs, _ = synth.reads(seqs, 2600, 1200, seed=400 + bits)
+    for n in (1, 255, 256, 257, 1023, 1025, 2600):
+        _compare_chain(capi, oracle, w, full[:offs[n]], offs[:n + 1])
+    b, o, truth = synth.reads(seqs, 500, 5000, seed=7)
+    assign, best, nhits = _compare_batch(capi, oracle, w, b, o)
+    assert (assign >= 0).sum() > 450
+    # the same index with 256 regions: equal decisions; host-form tables equal the device-built ones at this region count
+    ref = capi.Engine(capi.Index.from_seqs(names, seqs), 0)
+    r = ref.classify(b, o, 60)
+    assert np.array_equal(r[0], assign) and np.array_equal(r[2], nhits)
+    host_form = capi.Index.from_seqs(names, seqs)
+    capi.check(capi.lib().mnc_index_set_region_bits(host_form._h, bits))
+    capi.check(capi.lib().mnc_index_set_host_tables(host_form._h, 1))
+    ta, tb = w["eng"].dump_tables(), capi.Engine(host_form, 0).dump_tables()
+    assert len(ta) == len(tb) and np.array_equal(ta, tb)
+    assert int(ta[:4].view(np.int32)[0]) >> 16 == bits
