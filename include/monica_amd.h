@@ -290,6 +290,9 @@ int mnc_fastq_next(mnc_fastq *fq, uint32_t max_reads, uint64_t max_bases, uint32
  * batch k + 1 while batch k is classified and batch k - 1 is written out.  Accessors, mnc_fastq_route and
  * mnc_hitmap_update take it like the reader; mnc_fastq_close frees it. */
 int mnc_fastq_detach_batch(mnc_fastq *fq, mnc_fastq **out);
+/* bytes of the file no batch has taken yet (-1 for a pipe): a host loop that overlaps parsing, classification and
+ * output makes its first and last batches small, so that the pipeline fills and drains quickly */
+int mnc_fastq_remaining(const mnc_fastq *fq, int64_t *bytes);
 const uint8_t *mnc_fastq_bases(const mnc_fastq *fq);     /* concatenated sequences (page-locked when a GPU is present) */
 const int64_t *mnc_fastq_offsets(const mnc_fastq *fq);   /* n_reads + 1, starts at 0 */
 const uint8_t *mnc_fastq_quals(const mnc_fastq *fq);     /* quality characters, same offsets */

@@ -51,7 +51,7 @@ EXPORTS = [
     "mnc_engine_set_profiling", "mnc_engine_set_debug", "mnc_engine_set_contract", "mnc_index_set_host_tables", "mnc_index_set_region_bits", "mnc_engine_dump_tables",
     "mnc_comm_unique_id", "mnc_comm_init_rank", "mnc_comm_destroy", "mnc_allreduce_counts", "mnc_allgather_summaries", "mnc_engine_get_timings", "mnc_stage_name", "mnc_stage_kernel",
     "mnc_engine_get_counters", "mnc_engine_dump",
-    "mnc_fastq_open", "mnc_fastq_close", "mnc_fastq_next", "mnc_fastq_detach_batch", "mnc_fastq_bases", "mnc_fastq_offsets",
+    "mnc_fastq_open", "mnc_fastq_close", "mnc_fastq_next", "mnc_fastq_detach_batch", "mnc_fastq_remaining", "mnc_fastq_bases", "mnc_fastq_offsets",
     "mnc_fastq_quals", "mnc_fastq_title", "mnc_fastq_route",
     "mnc_hitmap_create", "mnc_hitmap_load", "mnc_hitmap_save", "mnc_hitmap_free", "mnc_hitmap_size",
     "mnc_hitmap_update", "mnc_hitmap_n_names", "mnc_hitmap_name", "mnc_host_alloc", "mnc_host_free",
@@ -157,6 +157,7 @@ def lib():
     sig("mnc_fastq_open", i32, [cp, pp])
     sig("mnc_fastq_close", None, [vp])
     sig("mnc_fastq_detach_batch", i32, [vp, pp])
+    sig("mnc_fastq_remaining", i32, [vp, C.POINTER(i64)])
     sig("mnc_fastq_next", i32, [vp, u32, u64, C.POINTER(u32)])
     sig("mnc_fastq_bases", vp, [vp])
     sig("mnc_fastq_offsets", vp, [vp])
@@ -518,6 +519,12 @@ class FastqReader:
         check(lib().mnc_fastq_open(_b(path), C.byref(h)))
         self._h = h
         self.n = 0
+
+    def remaining(self):
+        """Bytes of the file that no batch has taken yet (-1 when unknown)."""
+        n = C.c_int64(-1)
+        check(lib().mnc_fastq_remaining(self._h, C.byref(n)))
+        return n.value
 
     def detach(self):
         """The current batch as an object of its own; this reader goes on with the next batch in fresh

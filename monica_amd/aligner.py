@@ -193,11 +193,25 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
         return False
 
     def parse_stage():
+        # The first and the last batches are small: the other stages wait for the first one, and the last one's
+        # classification, carry and output follow when nothing else is left to overlap them with.
+        taken_reads, taken_bytes, total_bytes = 0, 0, reader.remaining()
         try:
             while not stop.is_set():
                 t0 = time.perf_counter()
-                if not reader.next(BATCH_READS, BATCH_BASES):
+                want = BATCH_READS
+                if taken_reads == 0:
+                    want = max(BATCH_READS // 4, 1)
+                elif total_bytes > 0:
+                    left = reader.remaining()
+                    per_read = max(taken_bytes / taken_reads, 1.0)
+                    reads_left = left / per_read
+                    if reads_left < 1.75 * BATCH_READS:              # the tail: halves, down to an eighth of a batch
+                        want = int(reads_left) + 64 if reads_left < BATCH_READS / 8 else max(int(reads_left / 2), BATCH_READS // 8)
+                if not reader.next(max(want, 1), BATCH_BASES):
                     break
+                taken_reads += reader.n
+                taken_bytes = total_bytes - reader.remaining() if total_bytes > 0 else 0
                 batch = reader.detach()
                 clock["parse"] += time.perf_counter() - t0
                 # the batch's bases cross PCIe behind the kernels of the batch before it (one spare buffer on the

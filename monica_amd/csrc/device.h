@@ -24,9 +24,7 @@ struct Anchor { uint64_t x, y; };    // x = strand<<63 | rid<<32 | rpos ; y = sp
 constexpr int PB_BITS_MIN = 8, PB_BITS_MAX = 10;
 constexpr int PB_N_MAX = 1 << PB_BITS_MAX;
 constexpr int PT_READS = 4;                 // reads per partition tile (= one sketch workgroup)
-constexpr int PS_TILES_MIN = 64;            // tiles per super-tile (probe / collect granularity) with 256 regions: 256 reads; it grows
-                                            // with the region count, so that a run (region, super-tile) keeps its ~900 queries
-constexpr int SUPER_READS_MAX = PS_TILES_MIN * PT_READS << (PB_BITS_MAX - PB_BITS_MIN);   // 1 024 (a hit record has 11 bits for the read)
+constexpr int PS_TILES_MIN = 64;            // tiles per super-tile (probe / collect granularity): 256 reads
 constexpr int PF_BITS = 18;                 // presence filter: 2^18 bits = 32 KiB per table region (fits LDS)
 constexpr int PF_WORDS = (1 << PF_BITS) / 32;
 // one-word Bloom filter: a key sets two bits of the word its rest selects; a query whose two bits
@@ -150,7 +148,7 @@ struct Batch {
 	const uint32_t *salt;         // [pb_n] per-region salt of the slot function
 	const uint32_t *filter;       // [pb_n][PF_WORDS] presence bits of (region, low PF_BITS of the rest)
 	int pb_bits;                  // log2 of the number of table regions (8 .. 10), from the index
-	uint32_t pb_n, ps_tiles;      // 1 << pb_bits; tiles per super-tile = PS_TILES_MIN << (pb_bits - 8)
+	uint32_t pb_n, ps_tiles;      // 1 << pb_bits; tiles per super-tile (PS_TILES_MIN)
 	int region_bits, disp_bits;
 	int disp_in_lds;              // the displacement table of a region fits the probe kernel's LDS copy
 	const uint64_t *positions;

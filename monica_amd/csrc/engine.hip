@@ -905,7 +905,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	*overflowed = 0;                                  // 1: query records, 2: segments / CIGAR pools of the alignment stage
 	const size_t nr = (size_t)n_reads, nb = (size_t)total_bases;
 	const int pb_bits = e->didx->pb_bits;
-	const size_t PB_N = (size_t)1 << pb_bits, PS_TILES = (size_t)PS_TILES_MIN << (pb_bits - PB_BITS_MIN);
+	const size_t PB_N = (size_t)1 << pb_bits, PS_TILES = (size_t)PS_TILES_MIN;
 	const size_t n_tiles = (nr + PT_READS - 1) / PT_READS, n_super = (n_tiles + PS_TILES - 1) / PS_TILES;
 	// query records: a (w,k)-minimizer sketch keeps ~2/(w+1) of the k-mers; room for a third
 	// of the bases, and the whole batch is redone with room for all of them if that overflows

@@ -269,6 +269,19 @@ extern "C" void mnc_fastq_close(mnc_fastq *fq)
 	delete fq;
 }
 
+// bytes of the file that no batch has taken yet (-1: not a regular file): a host loop sizes its last batches by it
+extern "C" int mnc_fastq_remaining(const mnc_fastq *fq, int64_t *bytes)
+{
+	if (!fq || !bytes) return MNC_ERR_ARG;
+	*bytes = -1;
+	if (fq->in.fd < 0 || !fq->in.seekable) return MNC_OK;
+	const off_t pos = lseek(fq->in.fd, 0, SEEK_CUR);
+	if (pos < 0) return MNC_OK;
+	const int64_t buffered = (int64_t)(fq->in.hi - fq->in.lo) + (fq->have_pending ? (int64_t)fq->pending.size() + 1 : 0);
+	*bytes = fq->done ? 0 : std::max<int64_t>(0, fq->file_size - (int64_t)pos) + buffered;
+	return MNC_OK;
+}
+
 // The current batch leaves the reader: a second handle (no file behind it) takes the batch's arrays, the
 // reader starts its next batch in fresh ones.  A host loop can then parse batch k + 1 while batch k is being
 // classified and batch k - 1 written to the routing folders; every accessor, mnc_fastq_route and

@@ -28,14 +28,16 @@ constexpr int PA_THREADS = 64 * PT_READS;
 constexpr int PA_STAGE = 4096;                      // records staged per tile
 constexpr int PA_PRE = 16;                          // minimizers a lane fetches ahead (1024 per wave)
 
-// BK: the type that holds a region number in the stage (a byte with 256 regions: the kernel's LDS sets its occupancy)
-template <class BK>
+// BK: the type that holds a region number in the stage (a byte with 256 regions), OFF: a run's start in the record array
+// (32 bits whenever the batch's records fit) -- the kernel's LDS sets its occupancy: 39 KB (four workgroups a CU) with
+// 256 regions, 52 KB (three) with 1 024
+template <class BK, class OFF>
 __global__ __launch_bounds__(PA_THREADS) void mnc_partition_queries(Batch B)
 {
 	extern __shared__ __align__(16) uint8_t pa_smem[];
 	const int pb_n = (int)B.pb_n, pb_bits = B.pb_bits;
 	uint64_t *s_rec = reinterpret_cast<uint64_t*>(pa_smem);                   // [PA_STAGE]
-	int64_t *s_off = reinterpret_cast<int64_t*>(s_rec + PA_STAGE);            // [pb_n]
+	OFF *s_off = reinterpret_cast<OFF*>(s_rec + PA_STAGE);                    // [pb_n]
 	uint32_t *s_cur = reinterpret_cast<uint32_t*>(s_off + pb_n);              // [pb_n]
 	uint32_t *s_loc = s_cur + pb_n;                                           // [pb_n + 1] local exclusive offsets of the buckets
 	BK *s_bkt = reinterpret_cast<BK*>(s_loc + pb_n + 4);                      // [PA_STAGE]
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(PA_THREADS) void mnc_partition_queries(Batch B)
 
 	for (int k = tid; k < pb_n; k += PA_THREADS) {
 		s_cur[k] = 0;
-		s_off[k] = B.q_off[(size_t)tile * pb_n + k];
+		s_off[k] = (OFF)B.q_off[(size_t)tile * pb_n + k];
 		s_loc[k + 1] = B.hist_tm[(size_t)tile * pb_n + k];
 	}
 	if (tid == 0) s_loc[0] = 0;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(PA_THREADS) void mnc_partition_queries(Batch B)
 		if (valid) {
 			const uint32_t b = pb_bucket(q.x, pb_bits);
 			const uint32_t rank = atomicAdd(&s_cur[b], 1u);
-			const int64_t dst = s_off[b] + rank;
+			const int64_t dst = (int64_t)s_off[b] + rank;
 			const uint64_t rec = (uint64_t)pb_rest(q.x, pb_bits) | (uint64_t)(q.y & 1u) << 22 | (uint64_t)(tandem ? 1u : 0u) << 23 |
 			                     (uint64_t)(q.y >> 1) << 24 | (uint64_t)r << 44;
 			if (dst >= B.q_cap) *B.overflow = 1u;
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(PA_THREADS) void mnc_partition_queries(Batch B)
 	if (staged) {
 		for (uint32_t i = tid; i < total; i += PA_THREADS) {
 			const uint32_t b = s_bkt[i];
-			const int64_t dst = s_off[b] + (int64_t)(i - s_loc[b]);
+			const int64_t dst = (int64_t)s_off[b] + (int64_t)(i - s_loc[b]);
 			if (dst < B.q_cap) B.qrec[dst] = s_rec[i];
 		}
 	}
@@ -119,13 +121,16 @@ __global__ __launch_bounds__(PA_THREADS) void mnc_partition_queries(Batch B)
 // or three buckets, whose 2 MiB table regions stay hot in its 4 MiB L2 (speed only, never
 // correctness).
 constexpr int PR_THREADS = 512;
-constexpr int PR_U = 8;                             // queries per lane in flight
 
+// PR_U: queries per lane in flight; RUNS: consecutive runs (super-tiles) of the region a wave takes.  With more table
+// regions a run holds fewer queries (930 with 256 regions, 230 with 1 024): the wave then takes four of them, 256
+// queries at a time, so that the work per wave -- and per copy of the region's filter into LDS -- stays what it was.
+template <int PR_U, int RUNS>
 __global__ __launch_bounds__(PR_THREADS) void mnc_probe_buckets(Batch B, uint32_t wgs_per_bucket)
 {
 	const uint32_t g = blockIdx.x, x = g & 7u, seq = g >> 3;
 	const uint32_t bucket = (seq / wgs_per_bucket) * 8u + x;
-	const uint32_t T = (seq % wgs_per_bucket) * (PR_THREADS / 64) + (threadIdx.x >> 6);
+	const uint32_t T0 = ((seq % wgs_per_bucket) * (PR_THREADS / 64) + (threadIdx.x >> 6)) * RUNS;
 	// the region's presence filter and displacement table into LDS: 3 of 4 queries are absent
 	// from the table and most of them stop at the filter, at LDS speed; a survivor costs one
 	// 8-bit LDS read and exactly one 16-byte gather
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(PR_THREADS) void mnc_probe_buckets(Batch B, uint32_
 		} else for (int k = threadIdx.x; k < nb; k += PR_THREADS) s_disp[k] = ds[k];
 	}
 	__syncthreads();
-	if (bucket >= B.pb_n || T >= B.n_super) return;
+	if (bucket >= B.pb_n || T0 >= B.n_super) return;
 	const int lane = lane_id();
 	const unsigned long long lt = (1ULL << lane) - 1ULL;
 	const uint32_t mid_occ = (uint32_t)B.mid_occ;
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(PR_THREADS) void mnc_probe_buckets(Batch B, uint32_
 	const bool disp_in_lds = B.disp_in_lds != 0;
 	const uint8_t *disp_hbm = B.disp + (size_t)bucket * nb;
 	const TableSlot *table = B.table + ((size_t)bucket << rbits);
-	{
+	for (uint32_t T = T0; T < T0 + RUNS && T < B.n_super; ++T) {
 		const uint32_t t0 = T * B.ps_tiles, t1 = min(t0 + B.ps_tiles, B.n_tiles);
 		const int64_t q0 = q_start(B.q_off, B.n_tiles, bucket, t0, B.pb_n), q1 = q_start(B.q_off, B.n_tiles, bucket, t1, B.pb_n);
 		const uint32_t read0 = T * (B.ps_tiles * PT_READS);
@@ -222,8 +227,8 @@ __global__ __launch_bounds__(CO_THREADS) void mnc_collect_hits(Batch B)
 {
 	__shared__ int64_t s_start[PB_N_MAX];
 	__shared__ uint32_t s_pre[PB_N_MAX + 1];
-	__shared__ uint32_t s_cur[SUPER_READS_MAX], s_hi[SUPER_READS_MAX];
-	__shared__ unsigned long long s_an[SUPER_READS_MAX];
+	__shared__ uint32_t s_cur[PS_TILES_MIN * PT_READS], s_hi[PS_TILES_MIN * PT_READS];
+	__shared__ unsigned long long s_an[PS_TILES_MIN * PT_READS];
 	const uint32_t T = blockIdx.x;
 	const uint32_t t0 = T * B.ps_tiles;
 	const int tid = threadIdx.x;
@@ -293,16 +298,23 @@ __global__ __launch_bounds__(CO_THREADS) void mnc_collect_hits(Batch B)
 void launch_partition(const Batch &B, hipStream_t st)
 {
 	if (B.n_tiles == 0) return;
-	const size_t fixed = (size_t)PA_STAGE * 8 + (size_t)B.pb_n * 16 + 16;
-	if (B.pb_n <= 256) hipLaunchKernelGGL(mnc_partition_queries<uint8_t>, dim3((B.n_tiles + 7) / 8 * 8), dim3(PA_THREADS), fixed + PA_STAGE, st, B);
-	else hipLaunchKernelGGL(mnc_partition_queries<uint16_t>, dim3((B.n_tiles + 7) / 8 * 8), dim3(PA_THREADS), fixed + 2 * PA_STAGE, st, B);
+	const bool small = B.q_cap < (1LL << 32);
+	const size_t fixed = (size_t)PA_STAGE * 8 + (size_t)B.pb_n * (small ? 12 : 16) + 16, bk = (size_t)PA_STAGE * (B.pb_n <= 256 ? 1 : 2);
+	const dim3 grid((B.n_tiles + 7) / 8 * 8);
+	if (B.pb_n <= 256 && small) hipLaunchKernelGGL((mnc_partition_queries<uint8_t, uint32_t>), grid, dim3(PA_THREADS), fixed + bk, st, B);
+	else if (B.pb_n <= 256) hipLaunchKernelGGL((mnc_partition_queries<uint8_t, int64_t>), grid, dim3(PA_THREADS), fixed + bk, st, B);
+	else if (small) hipLaunchKernelGGL((mnc_partition_queries<uint16_t, uint32_t>), grid, dim3(PA_THREADS), fixed + bk, st, B);
+	else hipLaunchKernelGGL((mnc_partition_queries<uint16_t, int64_t>), grid, dim3(PA_THREADS), fixed + bk, st, B);
 }
 
 void launch_probe(const Batch &B, hipStream_t st)
 {
 	if (B.n_super == 0) return;
-	const uint32_t W = (B.n_super + PR_THREADS / 64 - 1) / (PR_THREADS / 64);
-	hipLaunchKernelGGL(mnc_probe_buckets, dim3(B.pb_n * W), dim3(PR_THREADS), 0, st, B, W);
+	const uint32_t runs = B.pb_n / 256, per_wg = (PR_THREADS / 64) * runs;      // super-tiles a workgroup takes
+	const uint32_t W = (B.n_super + per_wg - 1) / per_wg;
+	if (runs == 1) hipLaunchKernelGGL((mnc_probe_buckets<8, 1>), dim3(B.pb_n * W), dim3(PR_THREADS), 0, st, B, W);
+	else if (runs == 2) hipLaunchKernelGGL((mnc_probe_buckets<8, 2>), dim3(B.pb_n * W), dim3(PR_THREADS), 0, st, B, W);
+	else hipLaunchKernelGGL((mnc_probe_buckets<4, 4>), dim3(B.pb_n * W), dim3(PR_THREADS), 0, st, B, W);
 }
 
 void launch_collect(const Batch &B, hipStream_t st)

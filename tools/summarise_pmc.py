@@ -22,7 +22,7 @@ json.dump(out, open(os.path.join(root, "profiles", f"{tag}_pmc_hbm_counters.json
 
 
 def hbm(kernel):          # FETCH_SIZE / WRITE_SIZE are in KiB; FETCH doubled (gfx950 correction for coalesced streams)
-    k = [x for x in out if x.endswith(kernel)]
+    k = [x for x in out if x.endswith(kernel) or kernel + "<" in x]
     if not k:
         return None
     c = out[k[0]]
@@ -31,6 +31,9 @@ def hbm(kernel):          # FETCH_SIZE / WRITE_SIZE are in KiB; FETCH doubled (g
 
 probe = hbm("mnc_probe_buckets")
 stage = [hbm(k) for k in ("mnc_partition_queries", "mnc_probe_buckets", "mnc_collect_hits")]
+if probe and ("g62" in tag or "g120" in tag):
+    print(tag, "probe HBM bytes/launch", int(probe), "stage", int(sum(x for x in stage if x)))
+    probe = None
 if probe:
     pk = [x for x in out if x.endswith("mnc_probe_buckets")][0]
     json.dump({"kernel": "mnc_probe_buckets", "reads": 100000, "read_len": 5000, "hbm_bytes_per_launch": int(probe),
