@@ -113,6 +113,8 @@ def main():
     if args.mode == "files":
         return files_mode(args, names, seqs, local_rank)
     index = _capi.Index.from_seqs(names, seqs)
+    if os.environ.get("MNC_REGION_BITS"):            # sweep only: table regions = 1 << bits (8..10) instead of the builder's choice
+        _capi.check(_capi.lib().mnc_index_set_region_bits(index._h, int(os.environ["MNC_REGION_BITS"])))
     info = index.info()
     bases, offsets, truth = synth.reads(seqs, args.reads, args.read_len, seed=synth.SEED_READS + 2,
                                         first=first_read)

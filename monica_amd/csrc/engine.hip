@@ -656,10 +656,10 @@ extern "C" int mnc_engine_create(mnc_index *idx, int device, mnc_engine **out)
 	int rc = index_upload(idx, device, &e->didx);
 	if (rc) { mnc_engine_destroy(e); return rc; }      // gives the workspace reference back, too
 	hipError_t he = hipSetDevice(device);
+	int least = 0, greatest = 0;
 	if (he == hipSuccess) {
 		// the batch's own stream carries the latency-bound kernels (a few long calls on single waves) beside the
 		// chip-filling ones of the side streams: its workgroups go first when wave slots come free
-		int least = 0, greatest = 0;
 		if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
 		he = hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, greatest);
 	}
@@ -668,7 +668,13 @@ extern "C" int mnc_engine_create(mnc_index *idx, int device, mnc_engine **out)
 		if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming);
 	}
 	if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
-	if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking);
+	// The copy stream gets the LOWEST priority -- not for the priority: the runtime keeps one set of hardware queues per
+	// priority class and deals a class's streams round-robin over its queues, so a fifth stream of the side streams' class
+	// shares a queue with one of them, and the barrier packet behind a half-gigabyte copy (the event record of
+	// mnc_engine_prefetch) then holds back that side stream's kernels until the copy is over: the sort launches of a
+	// batch took 7.9 ms instead of 0.8 whenever the next batch's copy had been issued before them
+	// (profiles/r03k_e2e_delay.txt).  Only copies and markers ever go to this stream.
+	if (he == hipSuccess) he = hipStreamCreateWithPriority(&e->copy_stream, hipStreamNonBlocking, least);
 	if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_prefetch, hipEventDisableTiming);
 	if (he == hipSuccess) he = hipHostMalloc((void**)&e->mailbox, 1024, hipHostMallocDefault);
 	if (he != hipSuccess) { set_error("stream creation failed: %s", hipGetErrorString(he)); mnc_engine_destroy(e); return MNC_ERR_HIP; }
