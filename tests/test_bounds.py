@@ -197,3 +197,87 @@ def test_a_banded_score_above_the_bound_is_the_full_matrix_score():
             else:
                 refused += 1
     assert proved > 100 and refused > 30
+
+
+# ---------------------------------------------------------------- a sequence-aware bound (examined in round 3, not used)
+def banded_matrix(t, q, lo, hi):
+    """H of the banded two-piece affine DP, cells with offset i - j outside [lo, hi] forbidden (NEG)."""
+    NEG = -(1 << 28)
+    n, m = len(t), len(q)
+    H = np.full((n + 1, m + 1), NEG, dtype=np.int64)
+    E1, E2, F1, F2 = H.copy(), H.copy(), H.copy(), H.copy()
+    H[0, 0] = 0
+    for i in range(n + 1):
+        for j in range(max(0, i - hi - 1), min(m, i - lo + 1) + 1):
+            if i == 0 and j == 0:
+                continue
+            if i and j and not lo <= (i - 1) - (j - 1) <= hi:
+                continue
+            if i == 0:
+                H[i, j] = -gap2(j)
+                continue
+            if j == 0:
+                H[i, j] = -gap2(i)
+                continue
+            E1[i, j] = max(E1[i - 1, j], H[i - 1, j] - Q_) - E_
+            E2[i, j] = max(E2[i - 1, j], H[i - 1, j] - Q2_) - E2_
+            F1[i, j] = max(F1[i, j - 1], H[i, j - 1] - Q_) - E_
+            F2[i, j] = max(F2[i, j - 1], H[i, j - 1] - Q2_) - E2_
+            H[i, j] = max(H[i - 1, j - 1] + (A_ if t[i - 1] == q[j - 1] else -B_), E1[i, j], E2[i, j], F1[i, j], F2[i, j])
+    return H
+
+
+def edge_bound(H, n, m, lo, hi):
+    """A path that leaves the band leaves it for the first time from a cell on one of its two edges; up to there it is a
+    path inside the band, so it has scored at most the banded H of that cell (whatever gap state it is in: H is the
+    largest).  Beyond: at least one more gap base to be outside (continuing a gap costs min(e, e2) = 1), a fresh gap of
+    the other kind to come back to the final offset n - m, and at most a per base for what is left of the shorter
+    sequence.  """
+    NEG = -(1 << 28)
+    d, best = n - m, NEG
+    for i in range(n + 1):
+        for j, out_i, out_j in ((i - hi, i + 1, i - hi), (i - lo, i, i - lo + 1)):      # upper edge leaves down, lower edge right
+            if not 0 <= j <= m or H[i, j] <= NEG // 2 or out_i > n or out_j > m:
+                continue
+            back = abs((out_i - out_j) - d)                     # gap bases of the other kind needed to end on the corner
+            rest = min(n - out_i - (back if out_i - out_j < d else 0), m - out_j - (back if out_i - out_j > d else 0))
+            if rest < 0:
+                continue
+            best = max(best, int(H[i, j]) - min(E_, E2_) - gap2(back) + A_ * rest)
+    return best
+
+
+def test_a_bound_from_the_band_edge_cells_is_valid_and_hardly_tighter():
+    rng = np.random.default_rng(7)
+    by_u = by_edge = cases = 0
+    for _ in range(70):
+        n = int(rng.integers(30, 120))
+        t = rng.integers(0, 4, n)
+        q = []
+        for x in t:                                             # ~10 % errors, as the benchmark's reads
+            r = rng.random()
+            if r < 0.04:
+                q.append(int(rng.integers(0, 4)))
+            elif r < 0.07:
+                q.extend([int(x), int(rng.integers(0, 4))])
+            elif r < 0.10:
+                continue
+            else:
+                q.append(int(x))
+        m = len(q)
+        for cells in (4, 6, 8):
+            b, kmin, kmax = fill_band(n, m, cells)
+            if b < 1 or m < 8:
+                continue
+            H = banded_matrix(t, q, kmin, kmax)
+            S_band, U, Ue = int(H[n, m]), band_bound(n, m, kmin, kmax), edge_bound(H, n, m, kmin, kmax)
+            cases += 1
+            if S_band > U:
+                by_u += 1
+            if S_band > Ue:                                     # the claim: then no path outside the band does as well
+                assert S_band == global_score(t, q), (n, m, cells)
+                by_edge += 1
+    # valid -- and no lever: the largest edge-cell bound sits at the first anti-diagonals, where nothing has been
+    # scored yet and all that follows is priced as perfect matches
+    assert cases > 150 and by_edge <= by_u + cases // 10
+    print(f"band proofs out of {cases}: {by_u} by the length bound, {by_edge} by the edge-cell bound")
