@@ -292,6 +292,7 @@ def main():
         try:
             with open(args.traffic_json) as f:
                 tj = json.load(f)
+            tj = tj.get("by_genomes", {}).get(str(args.genomes), tj if args.genomes == tj.get("genomes", 20) else {})
             if tj.get("reads") == args.reads and tj.get("read_len") == args.read_len:
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
@@ -313,6 +314,7 @@ def main():
             try:
                 with open(args.traffic_json) as f:
                     tj = json.load(f)
+                tj = tj.get("by_genomes", {}).get(str(args.genomes), tj if args.genomes == tj.get("genomes", 20) else {})
                 if tj.get("reads") == args.reads and tj.get("read_len") == args.read_len:
                     st_traffic = tj.get("stage_hbm_bytes_per_launch")
             except Exception:

@@ -163,10 +163,13 @@ struct LineReader {
 		}
 		return true;
 	}
+	// Host threads of one parse or routing pass (MNC_IO_THREADS caps it: the aligner's pipeline runs a parse and a
+	// routing pass side by side with the thread that launches kernels).
 	static int io_threads()
 	{
+		static const int cap = [] { const char *e = getenv("MNC_IO_THREADS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 16; }();
 		int t = omp_get_max_threads();
-		return t < 1 ? 1 : t > 16 ? 16 : t;
+		return t < 1 ? 1 : t > cap ? cap : t;
 	}
 };
 

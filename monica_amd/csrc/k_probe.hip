@@ -120,14 +120,17 @@ __global__ __launch_bounds__(PA_THREADS) void mnc_partition_queries(Batch B)
 // walks its own buckets in order, and the ~256 workgroups resident on it at any time span two
 // or three buckets, whose 2 MiB table regions stay hot in its 4 MiB L2 (speed only, never
 // correctness).
-constexpr int PR_THREADS = 512;
-
-// PR_U: queries per lane in flight; RUNS: consecutive runs (super-tiles) of the region a wave takes.  With more table
-// regions a run holds fewer queries (930 with 256 regions, 230 with 1 024): the wave then takes four of them, 256
-// queries at a time, so that the work per wave -- and per copy of the region's filter into LDS -- stays what it was.
-template <int PR_U, int RUNS>
-__global__ __launch_bounds__(PR_THREADS) void mnc_probe_buckets(Batch B, uint32_t wgs_per_bucket)
+// THREADS: the workgroup; PR_U: queries per lane in flight; RUNS: consecutive runs (super-tiles) of the region a wave takes.
+// What decides the kernel's speed at a large index is how many regions an XCD has open at once: its resident workgroups
+// (LDS: two or three a CU) times the queries of a workgroup, over the queries of a region.  With 256 regions a region
+// has 363 k queries and a workgroup of 8 waves x 930 takes 7.4 k: two regions open, 2 x 2 MiB of table in the 4 MiB L2.
+// With 1 024 regions a region has 91 k and a run 232: workgroups that kept their 7.4 k queries (four runs a wave) had
+// EIGHT regions open per XCD -- 16 MiB -- and 64 % of the table reads missed the L2 (profiles/r03l_pmc, 62 genomes).
+// So a workgroup takes fewer queries, not more: one run a wave, 16 waves per copy of the region's filter into LDS.
+template <int THREADS, int PR_U, int RUNS>
+__global__ __launch_bounds__(THREADS) void mnc_probe_buckets(Batch B, uint32_t wgs_per_bucket)
 {
+	constexpr int PR_THREADS = THREADS;
 	const uint32_t g = blockIdx.x, x = g & 7u, seq = g >> 3;
 	const uint32_t bucket = (seq / wgs_per_bucket) * 8u + x;
 	const uint32_t T0 = ((seq % wgs_per_bucket) * (PR_THREADS / 64) + (threadIdx.x >> 6)) * RUNS;
@@ -307,14 +310,19 @@ void launch_partition(const Batch &B, hipStream_t st)
 	else hipLaunchKernelGGL((mnc_partition_queries<uint16_t, int64_t>), grid, dim3(PA_THREADS), fixed + bk, st, B);
 }
 
+template <int THREADS, int PR_U, int RUNS>
+static void launch_probe_as(const Batch &B, hipStream_t st)
+{
+	const uint32_t per_wg = (THREADS / 64) * RUNS;                              // super-tiles a workgroup takes
+	const uint32_t W = (B.n_super + per_wg - 1) / per_wg;
+	hipLaunchKernelGGL((mnc_probe_buckets<THREADS, PR_U, RUNS>), dim3(B.pb_n * W), dim3(THREADS), 0, st, B, W);
+}
+
 void launch_probe(const Batch &B, hipStream_t st)
 {
 	if (B.n_super == 0) return;
-	const uint32_t runs = B.pb_n / 256, per_wg = (PR_THREADS / 64) * runs;      // super-tiles a workgroup takes
-	const uint32_t W = (B.n_super + per_wg - 1) / per_wg;
-	if (runs == 1) hipLaunchKernelGGL((mnc_probe_buckets<8, 1>), dim3(B.pb_n * W), dim3(PR_THREADS), 0, st, B, W);
-	else if (runs == 2) hipLaunchKernelGGL((mnc_probe_buckets<8, 2>), dim3(B.pb_n * W), dim3(PR_THREADS), 0, st, B, W);
-	else hipLaunchKernelGGL((mnc_probe_buckets<4, 4>), dim3(B.pb_n * W), dim3(PR_THREADS), 0, st, B, W);
+	if (B.pb_n <= 512) launch_probe_as<512, 8, 1>(B, st);
+	else launch_probe_as<1024, 4, 1>(B, st);
 }
 
 void launch_collect(const Batch &B, hipStream_t st)

@@ -31,20 +31,30 @@ def hbm(kernel):          # FETCH_SIZE / WRITE_SIZE are in KiB; FETCH doubled (g
 
 probe = hbm("mnc_probe_buckets")
 stage = [hbm(k) for k in ("mnc_partition_queries", "mnc_probe_buckets", "mnc_collect_hits")]
-if probe and ("g62" in tag or "g120" in tag):
-    print(tag, "probe HBM bytes/launch", int(probe), "stage", int(sum(x for x in stage if x)))
-    probe = None
 if probe:
-    pk = [x for x in out if x.endswith("mnc_probe_buckets")][0]
-    json.dump({"kernel": "mnc_probe_buckets", "reads": 100000, "read_len": 5000, "hbm_bytes_per_launch": int(probe),
-               "stage_hbm_bytes_per_launch": int(sum(x for x in stage if x)),
-               "fetch_size_kib": out[pk]["FETCH_SIZE"]["avg_per_launch"], "write_size_kib": out[pk]["WRITE_SIZE"]["avg_per_launch"],
-               "tcc_hit": out[pk].get("TCC_HIT_sum", {}).get("avg_per_launch"), "tcc_miss": out[pk].get("TCC_MISS_sum", {}).get("avg_per_launch"),
-               "note": f"{tag}: separate rocprofv3 --pmc passes of bench.py --steps 2 --warmup 1 --contract chain (tools/prof_r02.sh); "
-                       "FETCH_SIZE/WRITE_SIZE in KiB; FETCH doubled per the guide's gfx950 correction for coalesced streams; "
-                       "stage = partition + probe + collect"},
-              open(os.path.join(root, "profiles", "probe_traffic.json"), "w"), indent=1)
-    print("probe HBM bytes/launch", int(probe), "stage", int(sum(x for x in stage if x)))
+    import re
+    m = re.search(r"g(\d+)$", tag)
+    genomes = int(m.group(1)) if m else 20
+    pk = [x for x in out if x.endswith("mnc_probe_buckets") or "mnc_probe_buckets<" in x][0]
+    entry = {"kernel": pk, "genomes": genomes, "reads": 100000, "read_len": 5000, "hbm_bytes_per_launch": int(probe),
+             "stage_hbm_bytes_per_launch": int(sum(x for x in stage if x)),
+             "fetch_size_kib": out[pk]["FETCH_SIZE"]["avg_per_launch"], "write_size_kib": out[pk]["WRITE_SIZE"]["avg_per_launch"],
+             "tcc_hit": out[pk].get("TCC_HIT_sum", {}).get("avg_per_launch"), "tcc_miss": out[pk].get("TCC_MISS_sum", {}).get("avg_per_launch"),
+             "note": f"{tag}: separate rocprofv3 --pmc passes of bench.py --genomes {genomes} --steps 2 --warmup 1 --contract chain "
+                     "(tools/prof_r03.sh); FETCH_SIZE/WRITE_SIZE in KiB; FETCH doubled per the guide's gfx950 correction for "
+                     "coalesced streams; stage = partition + probe + collect"}
+    path = os.path.join(root, "profiles", "probe_traffic.json")
+    try:
+        cur = json.load(open(path))
+    except Exception:
+        cur = {}
+    by = cur.get("by_genomes", {})
+    by[str(genomes)] = entry
+    if genomes == 20:                                     # the default workload's figures stay at the top level
+        cur = dict(entry)
+    cur["by_genomes"] = by
+    json.dump(cur, open(path, "w"), indent=1)
+    print(tag, "probe HBM bytes/launch", int(probe), "stage", int(sum(x for x in stage if x)))
 # the dominant kernel with base-level alignment: the 32-cell tier of the banded gap-filling kernel
 fk = [x for x in out if "mnc_dp_fillp<16>" in x]
 if fk and "FETCH_SIZE" in out[fk[0]] and "WRITE_SIZE" in out[fk[0]]:
