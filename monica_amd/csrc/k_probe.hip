@@ -16,6 +16,7 @@
 //   K2b          one wave per (bucket, super-tile of 256 reads) run: probe, compact hits
 //   K2c          one workgroup per super-tile: gather its 256 runs, split hits per read
 #include "device.h"
+#include <cstdlib>
 
 namespace mnc {
 
@@ -321,7 +322,10 @@ static void launch_probe_as(const Batch &B, hipStream_t st)
 void launch_probe(const Batch &B, hipStream_t st)
 {
 	if (B.n_super == 0) return;
+	static const int shape = [] { const char *e = getenv("MNC_PROBE_SHAPE"); return e ? atoi(e) : 0; }();   // sweep only
 	if (B.pb_n <= 512) launch_probe_as<512, 8, 1>(B, st);
+	else if (shape == 1) launch_probe_as<512, 4, 1>(B, st);
+	else if (shape == 2) launch_probe_as<256, 4, 1>(B, st);
 	else launch_probe_as<1024, 4, 1>(B, st);
 }
 
