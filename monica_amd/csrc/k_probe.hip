@@ -16,7 +16,6 @@
 //   K2b          one wave per (bucket, super-tile of 256 reads) run: probe, compact hits
 //   K2c          one workgroup per super-tile: gather its 256 runs, split hits per read
 #include "device.h"
-#include <cstdlib>
 
 namespace mnc {
 
@@ -322,10 +321,9 @@ static void launch_probe_as(const Batch &B, hipStream_t st)
 void launch_probe(const Batch &B, hipStream_t st)
 {
 	if (B.n_super == 0) return;
-	static const int shape = [] { const char *e = getenv("MNC_PROBE_SHAPE"); return e ? atoi(e) : 0; }();   // sweep only
+	// (1 024 regions: 16 waves x one run measured against 8 x 1 and 4 x 1 -- 0.73 / 0.79 / 1.02 ms at 62 genomes: fewer
+	// queries per copy of the filter cost more than the locality gives, profiles/r03n_probe_shapes.txt)
 	if (B.pb_n <= 512) launch_probe_as<512, 8, 1>(B, st);
-	else if (shape == 1) launch_probe_as<512, 4, 1>(B, st);
-	else if (shape == 2) launch_probe_as<256, 4, 1>(B, st);
 	else launch_probe_as<1024, 4, 1>(B, st);
 }
 
