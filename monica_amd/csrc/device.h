@@ -177,7 +177,7 @@ struct Batch {
 	uint64_t *qrec;               // query records in bucket-major order
 	int64_t q_cap;                // capacity of qrec / bhits in records
 	HitRec *bhits;                // probe hits, compacted at the start of each (bucket, super-tile) run
-	uint32_t *bhit_cnt;           // [bucket][super-tile] number of hits in the run
+	uint32_t *bhit_cnt;           // [super-tile][bucket] number of hits in the run (the collect workgroup of a super-tile reads a row)
 	uint32_t *overflow;           // set when the batch needs more than q_cap records
 	// ---- per read
 	int32_t *mz_cnt;

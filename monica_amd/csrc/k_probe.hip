@@ -216,7 +216,7 @@ __global__ __launch_bounds__(THREADS) void mnc_probe_buckets(Batch B, uint32_t w
 				}
 			}
 		}
-		if (lane == 0) B.bhit_cnt[(size_t)bucket * B.n_super + T] = (uint32_t)n_out;
+		if (lane == 0) B.bhit_cnt[(size_t)T * B.pb_n + bucket] = (uint32_t)n_out;
 	}
 }
 
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(CO_THREADS) void mnc_collect_hits(Batch B)
 	const int PB_N = (int)B.pb_n, SUPER_READS = (int)(B.ps_tiles * PT_READS);
 	for (int b = tid; b < PB_N; b += CO_THREADS) {
 		s_start[b] = B.q_off[(size_t)t0 * PB_N + b];
-		s_pre[b + 1] = B.bhit_cnt[(size_t)b * B.n_super + T];
+		s_pre[b + 1] = B.bhit_cnt[(size_t)T * PB_N + b];
 	}
 	if (tid < SUPER_READS) s_cur[tid] = 0, s_hi[tid] = 0, s_an[tid] = 0;
 	if (tid == 0) s_pre[0] = 0;
