@@ -1129,12 +1129,24 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 				const int cnt = nk - mk;
 				const int incl = dpp_incl_add(cnt);
 				const int dst = n_c + incl - cnt;
-				for (int j = 0; j < 64 && k0 + j < stop; ++j) {
-					const int nj = __shfl(nk, j);
-					if (nj == 0) continue;
-					const int mj = __shfl(mk, j), dj = __shfl(dst, j);
-					const int64_t oj = (int64_t)__shfl((long long)ok, j);
-					for (int c = mj + lane; c < nj; c += 64) C[dj + c - mj] = B.cig_seg[oj + c];
+				// four segments' words are fetched before any of them is stored: a store through `C` (LDS or the pool) orders
+				// the loads behind it, and one segment at a time the copies were 23 memory round trips in a row per region
+				for (int j = 0; j < 64 && k0 + j < stop; j += 4) {
+					int nj[4], mj[4], dj[4];
+					int64_t oj[4];
+					uint32_t w[4];
+#pragma unroll
+					for (int u = 0; u < 4; ++u) {
+						const int ju = j + u < 64 ? j + u : 63;
+						nj[u] = j + u < 64 ? __shfl(nk, ju) : 0, mj[u] = __shfl(mk, ju), dj[u] = __shfl(dst, ju);
+						oj[u] = (int64_t)__shfl((long long)ok, ju);
+						w[u] = mj[u] + lane < nj[u] ? B.cig_seg[oj[u] + mj[u] + lane] : 0u;
+					}
+#pragma unroll
+					for (int u = 0; u < 4; ++u) {
+						if (mj[u] + lane < nj[u]) C[dj[u] + lane] = w[u];
+						for (int c = mj[u] + lane + 64; c < nj[u]; c += 64) C[dj[u] + c - mj[u]] = B.cig_seg[oj[u] + c];
+					}
 				}
 				c_order();
 				if (mk) atomicAdd(&C[dst - 1], first >> 4 << 4);
