@@ -4,7 +4,7 @@
 // (monica/genomes/aligner.py:193, 215: mappy always sets MM_F_CIGAR), whose
 // results monica reads as hit.mapq / hit.NM / hit.mlen (aligner.py:194-195, 216-217).
 //
-//   mnc_dp_gather   thread / read: the anchors of the kept chains, squeezed together in `as` order
+//   mnc_dp_gather   wave / read: the anchors of the kept chains, squeezed together in `as` order
 //                   (mm_squeeze_a), LONG_JOIN flag on the first anchor of a fused chain
 //   mnc_dp_plan     thread / region: trim bad chain ends, flag seeds around long indels, DP window
 //                   from neighbouring seeds, the list of kernel calls ("segments": left extension,
@@ -61,29 +61,46 @@ __device__ __forceinline__ int tcode(const Batch &B, int64_t contig_off, int pos
 // ================================================================ gather: chained anchors, squeezed
 constexpr int GATHER_LONG = 1024;       // reads with more anchors: mnc_dp_gather_long
 
+// One wave per read: p[] of the read in LDS; lane c walks chain c there (its anchors' indices go to the chain's place in
+// the squeezed order), then all lanes copy the anchors, coalesced.  (One LANE per read walking p[] through memory --
+// the first form -- was 0.7 ms of dependent round trips per batch.)
 __global__ __launch_bounds__(64) void mnc_dp_gather(Batch B)
 {
-	const uint32_t rd = blockIdx.x * blockDim.x + threadIdx.x;
-	if (rd >= B.n_reads) return;
+	__shared__ int32_t s_p[GATHER_LONG], s_j[GATHER_LONG];
+	const uint32_t rd = blockIdx.x;
+	const int lane = threadIdx.x;
 	const int n = B.n_chain[rd];
 	if (n <= 0) return;
-	if (B.an_off[rd + 1] - B.an_off[rd] > GATHER_LONG) return;
 	const int64_t a_off = B.an_off[rd], slot = a_off / 3;
+	const int n_an = (int)(B.an_off[rd + 1] - a_off);
+	if (n_an > GATHER_LONG) return;                          // mnc_dp_gather_long takes it
 	const ChainRec *ch = B.chains_tmp + slot;
 	const Anchor *a = B.a + a_off;
 	const int32_t *p = B.p + a_off;
 	Anchor *ca = B.ca + a_off;
-	for (int c = 0; c < n; ++c) {
+	for (int i = lane; i < n_an; i += 64) s_p[i] = p[i], s_j[i] = INT32_MAX;
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	int total = 0;
+	for (int c = lane; c < n; c += 64) {
 		const int d = B.chain_dst[slot + c];
 		if (d < 0) continue;
 		const int dst = d & ((1 << 30) - 1), cnt = ch[c].cnt;
 		int j = ch[c].as;                                   // the chain's last anchor; p[] leads back
 		for (int k = cnt - 1; k >= 0; --k) {
-			Anchor x = a[j];
-			if (k == 0 && (d >> 30 & 1)) x.y |= SEED_LONG_JOIN;
-			ca[dst + k] = x;
-			j = p[j];
+			s_j[dst + k] = k == 0 && (d >> 30 & 1) ? j | INT32_MIN : j;      // the sign: first anchor of a long-joined chain
+			j = s_p[j];
 		}
+		total = total > dst + cnt ? total : dst + cnt;
+	}
+#pragma unroll
+	for (int sft = 32; sft > 0; sft >>= 1) { const int o = __shfl_xor(total, sft); total = total > o ? total : o; }
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	for (int i = lane; i < total; i += 64) {
+		const int jj = s_j[i];
+		if (jj == INT32_MAX) continue;                       // (no chain put an anchor here)
+		Anchor x = a[jj & INT32_MAX];
+		if (jj < 0) x.y |= SEED_LONG_JOIN;
+		ca[i] = x;
 	}
 }
 
@@ -168,22 +185,35 @@ __device__ int collect_long_gaps(const Anchor *a, int cnt1, int min_gap, int32_t
 	return n <= 1 ? 0 : n;
 }
 
+// One wave per region (a persistent grid over the work list): the read's squeezed anchors are copied into LDS by all
+// lanes, lane 0 runs mm_align1's sequential logic on them there, the lanes write the seed flags back.  (The first form, one
+// LANE per region with the anchors in memory, read 64 different lines per load instruction: 0.9 ms per batch.)
+constexpr int PLAN_LDS_ANCHORS = 768;         // reads with more chained anchors are planned from memory
+constexpr unsigned DP_WG_PLAN = 256 * 8;      // 176 registers a lane: two waves a SIMD (LDS, 15 KB a wave, would allow ten a CU)
+
 __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_list, int slot_state_max, long long slot_p_max, int slot_cig_max,
                                                   long long big_state_max, long long big_p_max, long long big_cig_max,
                                                   long long huge_state_max, long long huge_p_max, long long huge_cig_max)
 {
+	__shared__ Anchor s_a[PLAN_LDS_ANCHORS];
+	__shared__ int32_t s_K[PLAN_LDS_ANCHORS];
 	const unsigned long long n_work = B.dp_ctr[9];
-	const unsigned long long wi = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-	if (wi >= n_work) return;
+	const int lane = threadIdx.x;
+	for (unsigned long long wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
 	const int64_t rslot = work_list[wi];
 	mnc_reg_t r = B.regs[rslot];
 	RegDP d = B.regdp[rslot];
 	const uint32_t rd = (uint32_t)d.read;
 	const int64_t a_off = B.an_off[rd];
 	const int qlen = (int)(B.offsets[rd + 1] - B.offsets[rd]);
-	Anchor *a = B.ca + a_off;
 	const int n_a = B.ca_cnt[rd];
-	int32_t *K = B.t + a_off + r.as;                       // scratch: one int per anchor of the region
+	const bool staged = r.cnt > 0 && n_a <= PLAN_LDS_ANCHORS;
+	if (staged) for (int i = lane; i < n_a; i += 64) s_a[i] = B.ca[a_off + i];
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	Anchor *a = staged ? s_a : B.ca + a_off;
+	int32_t *K = staged ? s_K : B.t + a_off + r.as;        // scratch: one int per anchor of the region
+	auto plan_region = [&]() {
 	d.n_seg = 0, d.first_seg = 0, d.has_left = d.has_right = 0;
 	// an inversion region (mnc_dp_inv): no seeds -- one extension from the start the local alignment found, on the strand
 	// and with the window that kernel left in the region's record
@@ -530,6 +560,15 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 		}
 	}
 	B.regdp[rslot] = d;
+	};   // plan_region
+	if (lane == 0) plan_region();
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	// the seed filters' flags (SEED_IGNORE, SEED_LONG_JOIN) live in the anchors' y words: the stitch kernel reads them
+	if (staged && !(r.flags & REG_INV)) for (int i = lane; i < r.cnt; i += 64) B.ca[a_off + r.as + i].y = s_a[r.as + i].y;
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	}
 }
 
 // ================================================================ align: ksw_extd2 on one wave
@@ -1763,7 +1802,7 @@ __global__ void mnc_dp_round_end(Batch B)
 // ================================================================ launches
 void launch_dp_gather(const Batch &B, hipStream_t st)
 {
-	if (B.n_reads) hipLaunchKernelGGL(mnc_dp_gather, dim3((B.n_reads + 63) / 64), dim3(64), 0, st, B);
+	if (B.n_reads) hipLaunchKernelGGL(mnc_dp_gather, dim3(B.n_reads), dim3(64), 0, st, B);
 }
 int dp_gather_long_prepare(int lds_anchors)
 {
@@ -1781,7 +1820,8 @@ void launch_dp_round_end(const Batch &B, hipStream_t st) { hipLaunchKernelGGL(mn
 void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work, int state_max, long long p_max, int cig_max,
                     long long big_state, long long big_p, long long big_cig, long long huge_state, long long huge_p, long long huge_cig, hipStream_t st)
 {
-	if (max_work) hipLaunchKernelGGL(mnc_dp_plan, dim3((max_work + 63) / 64), dim3(64), 0, st, B, work_list, state_max, p_max, cig_max, big_state, big_p, big_cig,
+	const unsigned grid = max_work < DP_WG_PLAN ? max_work : DP_WG_PLAN;
+	if (max_work) hipLaunchKernelGGL(mnc_dp_plan, dim3(grid), dim3(64), 0, st, B, work_list, state_max, p_max, cig_max, big_state, big_p, big_cig,
 	                                 huge_state, huge_p, huge_cig);
 }
 size_t dp_align_ws_bytes(long long state_max, long long p_max, long long cig_max) { return align_ws(state_max, p_max, cig_max).total; }
