@@ -185,35 +185,22 @@ __device__ int collect_long_gaps(const Anchor *a, int cnt1, int min_gap, int32_t
 	return n <= 1 ? 0 : n;
 }
 
-// One wave per region (a persistent grid over the work list): the read's squeezed anchors are copied into LDS by all
-// lanes, lane 0 runs mm_align1's sequential logic on them there, the lanes write the seed flags back.  (The first form, one
-// LANE per region with the anchors in memory, read 64 different lines per load instruction: 0.9 ms per batch.)
-constexpr int PLAN_LDS_ANCHORS = 768;         // reads with more chained anchors are planned from memory
-constexpr unsigned DP_WG_PLAN = 256 * 8;      // 176 registers a lane: two waves a SIMD (LDS, 15 KB a wave, would allow ten a CU)
-
 __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_list, int slot_state_max, long long slot_p_max, int slot_cig_max,
                                                   long long big_state_max, long long big_p_max, long long big_cig_max,
                                                   long long huge_state_max, long long huge_p_max, long long huge_cig_max)
 {
-	__shared__ Anchor s_a[PLAN_LDS_ANCHORS];
-	__shared__ int32_t s_K[PLAN_LDS_ANCHORS];
 	const unsigned long long n_work = B.dp_ctr[9];
-	const int lane = threadIdx.x;
-	for (unsigned long long wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+	const unsigned long long wi = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (wi >= n_work) return;
 	const int64_t rslot = work_list[wi];
 	mnc_reg_t r = B.regs[rslot];
 	RegDP d = B.regdp[rslot];
 	const uint32_t rd = (uint32_t)d.read;
 	const int64_t a_off = B.an_off[rd];
 	const int qlen = (int)(B.offsets[rd + 1] - B.offsets[rd]);
+	Anchor *a = B.ca + a_off;
 	const int n_a = B.ca_cnt[rd];
-	const bool staged = r.cnt > 0 && n_a <= PLAN_LDS_ANCHORS;
-	if (staged) for (int i = lane; i < n_a; i += 64) s_a[i] = B.ca[a_off + i];
-	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-	__builtin_amdgcn_wave_barrier();
-	Anchor *a = staged ? s_a : B.ca + a_off;
-	int32_t *K = staged ? s_K : B.t + a_off + r.as;        // scratch: one int per anchor of the region
-	auto plan_region = [&]() {
+	int32_t *K = B.t + a_off + r.as;                       // scratch: one int per anchor of the region
 	d.n_seg = 0, d.first_seg = 0, d.has_left = d.has_right = 0;
 	// an inversion region (mnc_dp_inv): no seeds -- one extension from the start the local alignment found, on the strand
 	// and with the window that kernel left in the region's record
@@ -560,15 +547,6 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 		}
 	}
 	B.regdp[rslot] = d;
-	};   // plan_region
-	if (lane == 0) plan_region();
-	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-	__builtin_amdgcn_wave_barrier();
-	// the seed filters' flags (SEED_IGNORE, SEED_LONG_JOIN) live in the anchors' y words: the stitch kernel reads them
-	if (staged && !(r.flags & REG_INV)) for (int i = lane; i < r.cnt; i += 64) B.ca[a_off + r.as + i].y = s_a[r.as + i].y;
-	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-	__builtin_amdgcn_wave_barrier();
-	}
 }
 
 // ================================================================ align: ksw_extd2 on one wave
@@ -1820,8 +1798,7 @@ void launch_dp_round_end(const Batch &B, hipStream_t st) { hipLaunchKernelGGL(mn
 void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work, int state_max, long long p_max, int cig_max,
                     long long big_state, long long big_p, long long big_cig, long long huge_state, long long huge_p, long long huge_cig, hipStream_t st)
 {
-	const unsigned grid = max_work < DP_WG_PLAN ? max_work : DP_WG_PLAN;
-	if (max_work) hipLaunchKernelGGL(mnc_dp_plan, dim3(grid), dim3(64), 0, st, B, work_list, state_max, p_max, cig_max, big_state, big_p, big_cig,
+	if (max_work) hipLaunchKernelGGL(mnc_dp_plan, dim3((max_work + 63) / 64), dim3(64), 0, st, B, work_list, state_max, p_max, cig_max, big_state, big_p, big_cig,
 	                                 huge_state, huge_p, huge_cig);
 }
 size_t dp_align_ws_bytes(long long state_max, long long p_max, long long cig_max) { return align_ws(state_max, p_max, cig_max).total; }
