@@ -44,8 +44,7 @@ int dp_gather_long_prepare(int lds_anchors);
 void launch_dp_gather_long(const Batch &B, const uint32_t *lists, const ClassSpans &spans, int lds_anchors, hipStream_t st);
 void launch_dp_round(const Batch &B, int first, hipStream_t st);
 void launch_dp_round_end(const Batch &B, hipStream_t st);
-int dp_plan_prepare();
-void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work, bool long_reads, int state_max, long long p_max, int cig_max,
+void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work, int state_max, long long p_max, int cig_max,
                     long long big_state, long long big_p, long long big_cig, long long huge_state, long long huge_p, long long huge_cig, hipStream_t st);
 size_t dp_align_ws_bytes(long long state_max, long long p_max, long long cig_max);
 int dp_align_prepare(int lds_bytes);
@@ -706,7 +705,6 @@ extern "C" int mnc_engine_create(mnc_index *idx, int device, mnc_engine **out)
 	if (!rc) rc = expand_sort_prepare(CHAIN_CLASSES.nm[CHAIN_CLASSES.n - 1]);
 	if (!rc) rc = dp_stitch_prepare();
 	if (!rc) rc = dp_gather_long_prepare(CHAIN_CLASSES.nm[CHAIN_CLASSES.n - 1]);
-	if (!rc) rc = dp_plan_prepare();
 	if (!rc) {
 		he = hipMemcpy(e->gap_lut.p, gap.data(), GAP_LUT * 4, hipMemcpyHostToDevice);
 		if (he == hipSuccess) he = hipMemcpy(e->logf_lut.p, lg.data(), (size_t)e->logf_n * 4, hipMemcpyHostToDevice);
@@ -1171,15 +1169,13 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 			launch_dp_gather_long(B, e->cls_list.as<uint32_t>() + (size_t)c0 * n_reads, sp, CHAIN_CLASSES.nm[CHAIN_CLASSES.n - 1], st);
 		}
 		unsigned max_work = (unsigned)nsr;
-		// reads long enough for more than 1 024 chained anchors (a 5 kb read has ~200): their regions are planned a wave each
-		const bool long_reads = e->cur_max_read_len <= 0 || e->cur_max_read_len > 8192;
 		for (int round = 0;; ++round) {
 			const int32_t *work = lists[round & 1];
 			int32_t *next = lists[(round + 1) & 1];
 			B.next_list = next;
 			launch_dp_round(B, round == 0, st);
 			if (round == 0) {
-				{ StageTimer t(e, MNC_STAGE_DP_PLAN);   launch_dp_plan(B, work, max_work, long_reads, (int)DP_STATE_SMALL, DP_P_SMALL, (int)DP_CIG_SMALL, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE, st); }
+				{ StageTimer t(e, MNC_STAGE_DP_PLAN);   launch_dp_plan(B, work, max_work, (int)DP_STATE_SMALL, DP_P_SMALL, (int)DP_CIG_SMALL, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE, st); }
 				{
 					StageTimer t(e, MNC_STAGE_DP_FILL);               // the four streams, fork to join
 					if (int rcf = fork()) return rcf;
@@ -1193,7 +1189,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 				}
 				{ StageTimer t(e, MNC_STAGE_DP_STITCH); launch_dp_stitch(B, work, next, (e->debug & 0x200000) ? 0 : e->cur_max_read_len > 0 ? e->cur_max_read_len : 8192, DP_WG_STITCH, st); }
 			} else {
-				launch_dp_plan(B, work, max_work, long_reads, (int)DP_STATE_SMALL, DP_P_SMALL, (int)DP_CIG_SMALL, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE, st);
+				launch_dp_plan(B, work, max_work, (int)DP_STATE_SMALL, DP_P_SMALL, (int)DP_CIG_SMALL, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE, st);
 				if (int rcf = fork()) return rcf;
 				if (e->debug & 0x10000) align_round(B, e, e->side[0], e->side[0], e->side[0], e->side[0]);
 				else align_round(B, e, e->side[0], e->side[1], st, e->side[2]);

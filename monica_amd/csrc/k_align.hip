@@ -185,65 +185,22 @@ __device__ int collect_long_gaps(const Anchor *a, int cnt1, int min_gap, int32_t
 	return n <= 1 ? 0 : n;
 }
 
-// WAVE = false: one lane per region (a region's plan is some twenty thousand instructions of sequential logic: 64 regions
-// share a wave's issue slots).  That lane reads its anchors from memory eight at a time, and a 60 kb read's region has
-// 4 700 of them, four passes: 2 400 round trips, 4.6 ms that the whole batch waits for.  So with long reads in the batch
-// (`long_from` > 0) the regions of reads with that many chained anchors are left to a second launch, WAVE = true: one wave
-// per such region, the read's squeezed anchors copied into LDS by all lanes, lane 0 running the same logic on them there,
-// the lanes writing the seed flags back.
-template <bool WAVE>
-__global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_list, int long_from, int lds_anchors,
-                                                  int slot_state_max, long long slot_p_max, int slot_cig_max,
+__global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_list, int slot_state_max, long long slot_p_max, int slot_cig_max,
                                                   long long big_state_max, long long big_p_max, long long big_cig_max,
                                                   long long huge_state_max, long long huge_p_max, long long huge_cig_max)
 {
-	extern __shared__ __align__(16) uint8_t pl_smem[];       // WAVE: [anchors | one int per anchor]
 	const unsigned long long n_work = B.dp_ctr[9];
-	const int lane = threadIdx.x;
-	// WAVE: the wave looks at 64 regions at a time and takes those of long reads one after the other
-	const unsigned long long step = WAVE ? (unsigned long long)gridDim.x * 64 : n_work;
-	for (unsigned long long base = (unsigned long long)blockIdx.x * 64; base < n_work; base += step) {
-	unsigned long long todo = 1;
-	int64_t my_slot = 0;
-	if (WAVE) {
-		bool lng = false;
-		if (base + lane < n_work) {
-			my_slot = work_list[base + lane];
-			lng = B.ca_cnt[B.regdp[my_slot].read] >= long_from;
-		}
-		todo = __ballot(lng);
-	} else if (base + lane >= n_work) todo = 0;
-	while (todo) {
-	int64_t rslot;
-	if (WAVE) {
-		const int l = __ffsll((long long)todo) - 1;
-		todo &= todo - 1;
-		rslot = (int64_t)__shfl((long long)my_slot, l);
-	} else {
-		todo = 0;
-		rslot = work_list[base + lane];
-	}
+	const unsigned long long wi = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (wi >= n_work) return;
+	const int64_t rslot = work_list[wi];
 	mnc_reg_t r = B.regs[rslot];
 	RegDP d = B.regdp[rslot];
 	const uint32_t rd = (uint32_t)d.read;
 	const int64_t a_off = B.an_off[rd];
 	const int qlen = (int)(B.offsets[rd + 1] - B.offsets[rd]);
-	const int n_a = B.ca_cnt[rd];
-	if (!WAVE && long_from > 0 && n_a >= long_from) continue;       // the other launch plans it
 	Anchor *a = B.ca + a_off;
+	const int n_a = B.ca_cnt[rd];
 	int32_t *K = B.t + a_off + r.as;                       // scratch: one int per anchor of the region
-	bool staged = false;
-	if (WAVE) {
-		staged = r.cnt > 0 && n_a <= lds_anchors;
-		Anchor *s_a = reinterpret_cast<Anchor*>(pl_smem);
-		if (staged) {
-			for (int i = lane; i < n_a; i += 64) s_a[i] = B.ca[a_off + i];
-			a = s_a, K = reinterpret_cast<int32_t*>(s_a + lds_anchors);
-		}
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-		__builtin_amdgcn_wave_barrier();
-	}
-	auto plan_region = [&]() {
 	d.n_seg = 0, d.first_seg = 0, d.has_left = d.has_right = 0;
 	// an inversion region (mnc_dp_inv): no seeds -- one extension from the start the local alignment found, on the strand
 	// and with the window that kernel left in the region's record
@@ -590,18 +547,6 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 		}
 	}
 	B.regdp[rslot] = d;
-	};   // plan_region
-	if (!WAVE || lane == 0) plan_region();
-	if (WAVE) {
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-		__builtin_amdgcn_wave_barrier();
-		// the seed filters' flags (SEED_IGNORE, SEED_LONG_JOIN) live in the anchors' y words: the stitch kernel reads them
-		if (staged) for (int i = lane; i < r.cnt; i += 64) B.ca[a_off + r.as + i].y = a[r.as + i].y;
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-		__builtin_amdgcn_wave_barrier();
-	}
-	}   // todo
-	}   // base
 }
 
 // ================================================================ align: ksw_extd2 on one wave
@@ -1098,7 +1043,7 @@ __device__ __forceinline__ void append_op(uint32_t *c, int &n, uint32_t word)
 }
 
 __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work_list, int32_t *next_list, int seq_q_max, int seq_t_max,
-                                                    int size_class, int q_fit, int t_fit, int ev_max)
+                                                    int q_lo, int t_lo, int q_hi, int t_hi, int ev_max)
 {
 	// LDS (dynamic: the sequences are sized for the batch's longest read, so that many regions share a CU):
 	// [joined CIGAR | score events | query codes | target codes]
@@ -1115,9 +1060,11 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 		mnc_reg_t r = B.regs[rslot];
 		RegDP d = B.regdp[rslot];
 		if (d.state != 1) continue;
-		if (size_class != 0) {                                   // a batch with long reads: two launches, by the LDS a region needs
-			const bool fits = d.qe0 - d.qs0 <= q_fit && d.re0 - d.rs0 <= t_fit;
-			if (fits != (size_class == 1)) continue;
+		{
+			// a batch with long reads: several launches, by the LDS a region needs -- this one takes the regions that fit
+			// (q_hi, t_hi) and did not fit the launch before it (q_lo, t_lo; -1: there was none)
+			const int wq = d.qe0 - d.qs0, wt = d.re0 - d.rs0;
+			if ((wq <= q_lo && wt <= t_lo) || wq > q_hi || wt > t_hi) continue;
 		}
 		const uint32_t rd = (uint32_t)d.read;
 		const int64_t a_off = B.an_off[rd];
@@ -1850,24 +1797,11 @@ void launch_dp_gather_long(const Batch &B, const uint32_t *lists, const ClassSpa
 }
 void launch_dp_round(const Batch &B, int first, hipStream_t st) { hipLaunchKernelGGL(mnc_dp_round, dim3(1), dim3(1), 0, st, B, first); }
 void launch_dp_round_end(const Batch &B, hipStream_t st) { hipLaunchKernelGGL(mnc_dp_round_end, dim3(1), dim3(1), 0, st, B); }
-constexpr int PLAN_LONG = 1024;               // chained anchors of a read from which the wave form plans its regions
-constexpr int PLAN_LDS_ANCHORS = 6144;        // ... out of LDS up to this many (20 bytes each: 120 KB), from memory beyond
-int dp_plan_prepare()
-{
-	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_plan<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PLAN_LDS_ANCHORS * 20);
-	if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return MNC_ERR_HIP; }
-	return MNC_OK;
-}
-// `long_reads`: the batch holds reads long enough for more than PLAN_LONG chained anchors (the caller knows its longest read)
-void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work, bool long_reads, int state_max, long long p_max, int cig_max,
+void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work, int state_max, long long p_max, int cig_max,
                     long long big_state, long long big_p, long long big_cig, long long huge_state, long long huge_p, long long huge_cig, hipStream_t st)
 {
-	if (!max_work) return;
-	hipLaunchKernelGGL(mnc_dp_plan<false>, dim3((max_work + 63) / 64), dim3(64), 0, st, B, work_list, long_reads ? PLAN_LONG : 0, 0,
-	                   state_max, p_max, cig_max, big_state, big_p, big_cig, huge_state, huge_p, huge_cig);
-	if (long_reads)
-		hipLaunchKernelGGL(mnc_dp_plan<true>, dim3(256), dim3(64), (size_t)PLAN_LDS_ANCHORS * 20, st, B, work_list, PLAN_LONG, PLAN_LDS_ANCHORS,
-		                   state_max, p_max, cig_max, big_state, big_p, big_cig, huge_state, huge_p, huge_cig);
+	if (max_work) hipLaunchKernelGGL(mnc_dp_plan, dim3((max_work + 63) / 64), dim3(64), 0, st, B, work_list, state_max, p_max, cig_max, big_state, big_p, big_cig,
+	                                 huge_state, huge_p, huge_cig);
 }
 size_t dp_align_ws_bytes(long long state_max, long long p_max, long long cig_max) { return align_ws(state_max, p_max, cig_max).total; }
 int dp_align_prepare(int lds_bytes)
@@ -1891,25 +1825,31 @@ void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_li
 		if (q_max < 256) q_max = 256;
 		t_max = (q_max + q_max / 4 + 127) / 64 * 64;
 	};
-	auto launch = [&](int q_max, int t_max, int size_class, int q_fit, int t_fit, int ev_max, int wgs) {
+	auto launch = [&](int q_max, int t_max, int q_lo, int t_lo, int q_hi, int t_hi, int ev_max, int wgs) {
 		const size_t lds = (size_t)ST_CIG_MAX * 4 + ev_max + q_max + t_max + 16;   // + 16: the stitch reads whole words, up to eleven bytes past a region's last base
-		hipLaunchKernelGGL(mnc_dp_stitch, dim3(wgs), dim3(64), lds, st, B, work_list, next_list, q_max, t_max, size_class, q_fit, t_fit, ev_max);
+		hipLaunchKernelGGL(mnc_dp_stitch, dim3(wgs), dim3(64), lds, st, B, work_list, next_list, q_max, t_max, q_lo, t_lo, q_hi, t_hi, ev_max);
 	};
 	constexpr int ST_SMALL = 6144;                   // up to here one launch: nine regions per CU (17.6 .. 20 KB of LDS each)
 	int q_max, t_max;
 	dims(max_read_len, ST_LONG_Q, q_max, t_max);
-	if (q_max <= ST_SMALL) { launch(q_max, t_max, 0, 0, 0, ST_EV_MAX, n_wg); return; }
-	// long reads in the batch: the regions that fit the small layout keep its occupancy; the rest get the LDS they need (up to
-	// 60 k query bases: one region per CU then; beyond that the bases are read in place) and room for one slide per CIGAR
-	// operation of mm_fix_cigar's parallel form (a 60 kb read with 10 % errors has ~8 000 of them)
-	int q_s, t_s;
-	dims(ST_SMALL, ST_SMALL, q_s, t_s);
-	launch(q_s, t_s, 1, q_s, t_s, ST_EV_MAX, n_wg);
-	launch(q_max, t_max, 2, q_s, t_s, ST_EV_LONG, n_wg / 4);
+	if (q_max <= ST_SMALL) { launch(q_max, t_max, -1, -1, INT32_MAX, INT32_MAX, ST_EV_MAX, n_wg); return; }
+	// long reads in the batch: a launch per LDS class, each region in the smallest that holds it -- 6 k query bases (nine
+	// regions per CU), 12 k (four), 24 k (two), then whatever the batch's longest read needs (up to 60 k query bases: one
+	// region per CU; beyond that the bases are read in place).  The long classes also have room for one slide per CIGAR
+	// operation of mm_fix_cigar's parallel form (a 60 kb read with 10 % errors has ~8 000 of them).  With two classes only,
+	// half the regions of a nanopore-like length mix (median 6 kb) ran one per CU: 5.4 ms of a 34 ms batch.
+	int q_lo = -1, t_lo = -1, share = 1;
+	for (int cls = ST_SMALL; cls < q_max; cls *= 2, share *= 2) {
+		int q_c, t_c;
+		dims(cls, cls, q_c, t_c);
+		launch(q_c, t_c, q_lo, t_lo, q_c, t_c, cls / 6 < ST_EV_MAX ? ST_EV_MAX : (cls / 6 + 15) / 16 * 16, n_wg / share);
+		q_lo = q_c, t_lo = t_c;
+	}
+	launch(q_max, t_max, q_lo, t_lo, INT32_MAX, INT32_MAX, ST_EV_LONG, n_wg / 4);
 }
-// what the waves of one round's launches (n_wg, and n_wg / 4 more for the regions of long reads) can hold back of the
+// what the waves of one round's launches (one per LDS class) can hold back of the
 // region pool: the chunk each reserved last
-size_t dp_stitch_pool_slack(int n_wg) { return (size_t)(n_wg + n_wg / 4) * ST_POOL_CHUNK; }
+size_t dp_stitch_pool_slack(int n_wg) { return (size_t)(2 * n_wg + n_wg / 4) * ST_POOL_CHUNK; }   // (n_wg + n_wg / 2 + n_wg / 4 + ... for the classes, n_wg / 4 for the last)
 size_t dp_inv_ws_words(int max_gap) { return (size_t)(max_gap + 8 + 64) * 2; }   // H and E of one column, per workgroup
 void launch_dp_inv(const Batch &B, const int32_t *work_list, int32_t *next_list, int32_t *ws, int n_wg, hipStream_t st)
 {
