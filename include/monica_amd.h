@@ -220,7 +220,10 @@ int mnc_engine_set_debug(mnc_engine *eng, int mode);      /* test switches, a bi
                                                              extension / packed gap-filling / long-gap / long-extension
                                                              kernels (their calls go to the next kernel in line),
                                                              0x200000 the stitch kernel reads bases in place (its form
-                                                             for regions beyond its LDS) */
+                                                             for regions beyond its LDS), 0x400000 without the 42-cell
+                                                             tier, bits 24-30 that tier's tuning value, 0x800000 the
+                                                             regions of long reads planned one lane each as all others
+                                                             (not by mnc_dp_plan_long) */
 /* accumulated since the last reset: ms[MNC_N_STAGES], launches[MNC_N_STAGES] */
 int mnc_engine_get_timings(mnc_engine *eng, double *ms, int64_t *launches, int reset);
 const char *mnc_stage_name(int stage);

@@ -228,6 +228,8 @@ struct Batch {
 	int32_t *big_list;            // segment indices for the large-workspace launch
 	int32_t *fill_list1, *fill_list2, *fill_fb;   // banded gap-filling kernel: 32-lane tier, 64-lane tier, handed back
 	int32_t *fill_list3;                          // ... and the 128-cell tier
+	int32_t *plan_long_list;                      // region slots mnc_dp_plan leaves to mnc_dp_plan_long (reads with many chained anchors): length dp_ctr[53]
+	long long plan_long_cap;
 	int32_t *fill_list_mid;                       // ... and the 42-cell tier between the first two: length dp_ctr[30], queue [54], anti-diagonals [52]
 	int32_t *ext_list1, *ext_list2;               // extension kernel: 32 / 64 lanes per segment
 	int32_t *ext_list3, *ext_list4;               // ... 128 / 256 cells (two / four per lane)

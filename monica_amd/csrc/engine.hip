@@ -44,7 +44,8 @@ int dp_gather_long_prepare(int lds_anchors);
 void launch_dp_gather_long(const Batch &B, const uint32_t *lists, const ClassSpans &spans, int lds_anchors, hipStream_t st);
 void launch_dp_round(const Batch &B, int first, hipStream_t st);
 void launch_dp_round_end(const Batch &B, hipStream_t st);
-void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work, int state_max, long long p_max, int cig_max,
+int dp_plan_prepare();
+void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work, bool long_reads, int state_max, long long p_max, int cig_max,
                     long long big_state, long long big_p, long long big_cig, long long huge_state, long long huge_p, long long huge_cig, hipStream_t st);
 size_t dp_align_ws_bytes(long long state_max, long long p_max, long long cig_max);
 int dp_align_prepare(int lds_bytes);
@@ -498,7 +499,7 @@ struct mnc_engine {
 	int contract = MNC_CONTRACT_DP;
 	Buf ca, ca_cnt, chain_dst, regdp, segs, cig_seg, cig_reg, dp_ctr, work_a, work_b, big_list, huge_list, reg_cnt, regs2;
 	SharedWs *ws = nullptr;                  // the device's alignment scratch (held during the alignment stage only)
-	Buf fill1, fill2, fill3, fill_mid, fill_fb, extp, mid_list, lfill, lext, bigfb, ext1, ext2, ext3, ext4, gen_list;
+	Buf fill1, fill2, fill3, fill_mid, fill_fb, plan_long, extp, mid_list, lfill, lext, bigfb, ext1, ext2, ext3, ext4, gen_list;
 	size_t seg_cap_override = 0, cig_cap_override = 0;
 	uint32_t *mailbox = nullptr;             // 1 KiB of page-locked host memory the device writes its small read-backs to (mnc_mail)
 	int slot_pad = 2;                        // region slots per read beyond anchors / 3 (device.h: reg_slot); grown when a batch runs out
@@ -614,7 +615,7 @@ extern "C" int mnc_device_name(int device, char *buf, size_t cap)
 template <class F> static void engine_bufs(mnc_engine *e, F f)
 {
 	Buf *all[] = { &e->gap_lut, &e->logf_lut, &e->logf_a_lut, &e->ca, &e->ca_cnt, &e->chain_dst, &e->regdp, &e->segs, &e->cig_seg, &e->cig_reg, &e->dp_ctr,
-	               &e->work_a, &e->work_b, &e->big_list, &e->huge_list, &e->reg_cnt, &e->regs2, &e->inv_ws, &e->fill1, &e->fill2, &e->fill3, &e->fill_mid, &e->fill_fb, &e->extp, &e->mid_list, &e->lfill, &e->lext, &e->bigfb, &e->ext1, &e->ext2, &e->ext3, &e->ext4, &e->gen_list, &e->in_bases, &e->in_offsets, &e->pf_bases_buf, &e->pf_offsets_buf, &e->out_assign, &e->out_best, &e->out_nhits,
+	               &e->work_a, &e->work_b, &e->big_list, &e->huge_list, &e->reg_cnt, &e->regs2, &e->inv_ws, &e->fill1, &e->fill2, &e->fill3, &e->fill_mid, &e->fill_fb, &e->plan_long, &e->extp, &e->mid_list, &e->lfill, &e->lext, &e->bigfb, &e->ext1, &e->ext2, &e->ext3, &e->ext4, &e->gen_list, &e->in_bases, &e->in_offsets, &e->pf_bases_buf, &e->pf_offsets_buf, &e->out_assign, &e->out_best, &e->out_nhits,
 	               &e->packed, &e->mz, &e->hits, &e->hist_tm, &e->q_off, &e->qrec, &e->bhits, &e->bhit_cnt, &e->ambig, &e->mz_cnt, &e->hit_cnt, &e->rep_len, &e->an_cnt, &e->an_off,
 	               &e->n_chain, &e->n_reg, &e->best_mlen, &e->hist_sums, &e->hist_offs, &e->scan_sums, &e->hit_off, &e->a, &e->f, &e->p, &e->v, &e->t, &e->u,
 	               &e->chains_tmp, &e->regs, &e->regx, &e->k64a, &e->k64b, &e->tmp_i32, &e->gated,
@@ -705,6 +706,7 @@ extern "C" int mnc_engine_create(mnc_index *idx, int device, mnc_engine **out)
 	if (!rc) rc = expand_sort_prepare(CHAIN_CLASSES.nm[CHAIN_CLASSES.n - 1]);
 	if (!rc) rc = dp_stitch_prepare();
 	if (!rc) rc = dp_gather_long_prepare(CHAIN_CLASSES.nm[CHAIN_CLASSES.n - 1]);
+	if (!rc) rc = dp_plan_prepare();
 	if (!rc) {
 		he = hipMemcpy(e->gap_lut.p, gap.data(), GAP_LUT * 4, hipMemcpyHostToDevice);
 		if (he == hipSuccess) he = hipMemcpy(e->logf_lut.p, lg.data(), (size_t)e->logf_n * 4, hipMemcpyHostToDevice);
@@ -1143,6 +1145,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 		ENS2(work_a, nsr * 4); ENS2(work_b, nsr * 4); ENS2(big_list, seg_cap * 4); ENS2(reg_cnt, (nr + 1) * 4); ENS2(regs2, nsr * sizeof(mnc_reg_t));
 		const size_t ws_small = dp_align_ws_bytes(DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL), ws_big = dp_align_ws_bytes(DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG), ws_huge = dp_align_ws_bytes(DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE);
 		ENSW(dp_ws, ws_small * DP_WG_SMALL * 2); ENSW(dp_ws_big, ws_big * DP_WG_BIG); ENSW(dp_ws_huge, ws_huge * DP_WG_HUGE); ENS2(huge_list, seg_cap * 4); ENSW(dp_ws_mid, ws_small * DP_WG_MID); ENS2(mid_list, seg_cap * 4); ENS2(lfill, seg_cap * 4); ENSW(lfill_p, dp_lfill_p_slot() * DP_WG_LFILL); ENS2(lext, seg_cap * 4); ENS2(bigfb, seg_cap * 4); ENSW(lext_p, dp_lext_p_slot() * DP_WG_LEXT);
+		ENS2(plan_long, (nr * 4 + 1024) * 4);
 		ENS2(fill1, seg_cap * 4); ENS2(fill2, seg_cap * 4); ENS2(fill3, seg_cap * 4); ENS2(fill_mid, seg_cap * 4); ENS2(fill_fb, seg_cap * 4); ENSW(fill_p, dp_fillp_slot() * DP_WG_FILL); ENSW(fill_cig, dp_fillp_cig_slot() * DP_WG_FILL); ENS2(extp, seg_cap * 4 * 8); ENSW(extp_p, dp_extp_slot() * DP_WG_EXT); ENSW(extp_cig, dp_extp_cig_slot() * DP_WG_EXT); ENS2(ext1, seg_cap * 4); ENS2(ext2, seg_cap * 4); ENS2(ext3, seg_cap * 4); ENS2(ext4, seg_cap * 4); ENS2(gen_list, seg_cap * 4); ENSW(ext_p, dp_fill_p_slot() * DP_WG_EXT);
 #undef ENS2
 		if (rc2) return rc2;
@@ -1150,6 +1153,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 		B.segs = e->segs.as<Seg>(), B.seg_cap = (int64_t)seg_cap, B.cig_seg = e->cig_seg.as<uint32_t>(), B.cig_reg = e->cig_reg.as<uint32_t>();
 		B.cig_seg_cap = (int64_t)cig_cap, B.cig_reg_cap = (int64_t)cig_reg_cap, B.dp_ctr = e->dp_ctr.as<unsigned long long>();
 		B.big_list = e->big_list.as<int32_t>(), B.huge_list = e->huge_list.as<int32_t>(), B.reg_cnt = e->reg_cnt.as<int32_t>();
+		B.plan_long_list = e->plan_long.as<int32_t>(), B.plan_long_cap = (long long)(nr * 4 + 1024);
 		B.fill_list1 = e->fill1.as<int32_t>(), B.fill_list2 = e->fill2.as<int32_t>(), B.fill_list3 = e->fill3.as<int32_t>(), B.fill_list_mid = e->fill_mid.as<int32_t>(), B.fill_fb = e->fill_fb.as<int32_t>();
 		B.ext_list1 = e->ext1.as<int32_t>(), B.ext_list2 = e->ext2.as<int32_t>(), B.ext_list3 = e->ext3.as<int32_t>(), B.ext_list4 = e->ext4.as<int32_t>(), B.gen_list = e->gen_list.as<int32_t>(), B.extp_list = e->extp.as<int32_t>(), B.mid_list = e->mid_list.as<int32_t>(), B.lfill_list = e->lfill.as<int32_t>(), B.lext_list = e->lext.as<int32_t>(), B.bigfb_list = e->bigfb.as<int32_t>();
 		B.lds0_state = DP_LDS0_STATE, B.lds0_p = DP_LDS0_P, B.lds0_cig = DP_LDS0_CIG;
@@ -1169,13 +1173,16 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 			launch_dp_gather_long(B, e->cls_list.as<uint32_t>() + (size_t)c0 * n_reads, sp, CHAIN_CLASSES.nm[CHAIN_CLASSES.n - 1], st);
 		}
 		unsigned max_work = (unsigned)nsr;
+		// reads long enough for 512 chained anchors (a 5 kb read has ~200 a chain): their regions are planned a wave each;
+		// debug bit 0x800000: everything on the lane form (tests)
+		const bool long_reads = !(e->debug & 0x800000) && (e->cur_max_read_len <= 0 || e->cur_max_read_len > 6144);
 		for (int round = 0;; ++round) {
 			const int32_t *work = lists[round & 1];
 			int32_t *next = lists[(round + 1) & 1];
 			B.next_list = next;
 			launch_dp_round(B, round == 0, st);
 			if (round == 0) {
-				{ StageTimer t(e, MNC_STAGE_DP_PLAN);   launch_dp_plan(B, work, max_work, (int)DP_STATE_SMALL, DP_P_SMALL, (int)DP_CIG_SMALL, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE, st); }
+				{ StageTimer t(e, MNC_STAGE_DP_PLAN);   launch_dp_plan(B, work, max_work, long_reads, (int)DP_STATE_SMALL, DP_P_SMALL, (int)DP_CIG_SMALL, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE, st); }
 				{
 					StageTimer t(e, MNC_STAGE_DP_FILL);               // the four streams, fork to join
 					if (int rcf = fork()) return rcf;
@@ -1189,7 +1196,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 				}
 				{ StageTimer t(e, MNC_STAGE_DP_STITCH); launch_dp_stitch(B, work, next, (e->debug & 0x200000) ? 0 : e->cur_max_read_len > 0 ? e->cur_max_read_len : 8192, DP_WG_STITCH, st); }
 			} else {
-				launch_dp_plan(B, work, max_work, (int)DP_STATE_SMALL, DP_P_SMALL, (int)DP_CIG_SMALL, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE, st);
+				launch_dp_plan(B, work, max_work, long_reads, (int)DP_STATE_SMALL, DP_P_SMALL, (int)DP_CIG_SMALL, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE, st);
 				if (int rcf = fork()) return rcf;
 				if (e->debug & 0x10000) align_round(B, e, e->side[0], e->side[0], e->side[0], e->side[0]);
 				else align_round(B, e, e->side[0], e->side[1], st, e->side[2]);

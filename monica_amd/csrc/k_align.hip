@@ -185,7 +185,126 @@ __device__ int collect_long_gaps(const Anchor *a, int cnt1, int min_gap, int32_t
 	return n <= 1 ? 0 : n;
 }
 
-__global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_list, int slot_state_max, long long slot_p_max, int slot_cig_max,
+// The kernel a segment goes to (Seg.big: 0..3 the literal kernel's workspace classes, 4 + t the work list t of a banded /
+// extension kernel) and its bookkeeping fields; `widx` / `wamt`: what it adds to the work counters dp_ctr[48 + widx].
+struct PlanLimits { int slot_state_max; long long slot_p_max; int slot_cig_max; long long big_state_max, big_p_max, big_cig_max, huge_state_max, huge_p_max, huge_cig_max; };
+__device__ void plan_seg_class(const Batch &B, const PlanLimits &lim, int bw, uint32_t rd, int64_t rslot, int rid, int rev, int32_t seg_index,
+                               Seg &g, int &widx, unsigned long long &wamt)
+{
+	widx = -1, wamt = 0;
+	g.read = (int32_t)rd, g.reg = (int32_t)rslot, g.rid = rid, g.rev = rev;
+	g.n_cigar = 0, g.zdropped = 0, g.zdrop_code = 0, g.max = 0, g.max_t = g.max_q = -1, g.score = DP_NEG_INF, g.reach_end = 0, g.mqe_t = -1, g.cig_off = 0;
+	// workspace class
+	const long long T = (g.tlen + 15) / 16 * 16, Q = (g.qlen + 15) / 16 * 16 + 32;
+	long long nc = g.qlen < g.tlen ? g.qlen : g.tlen;
+	const int wb = g.w < 0 ? (g.tlen > g.qlen ? g.tlen : g.qlen) : g.w;
+	nc = ((nc < wb + 1 ? nc : wb + 1) + 15) / 16 + 1;
+	const long long p_bytes = ((long long)(g.qlen + g.tlen - 1) * nc + 1) * 16;
+	g.big = (12 * T + Q > lim.slot_state_max || p_bytes > lim.slot_p_max || g.qlen + g.tlen + 8 > lim.slot_cig_max) ? 1 : 0;
+	if ((long long)g.tlen * g.qlen > B.max_sw_mat) g.big = 0;      // not aligned at all (ksw_reset_extz + zdropped)
+	else if (12 * T + Q > lim.big_state_max || p_bytes > lim.big_p_max || g.qlen + g.tlen + 8 > lim.big_cig_max) {
+		g.big = 3;                                              // the few largest: a class of their own, a handful of very large slots
+		if (12 * T + Q > lim.huge_state_max || p_bytes > lim.huge_p_max || g.qlen + g.tlen + 8 > lim.huge_cig_max) {
+			g.big = 2;                                          // beyond even those: the batch fails
+			atomicMax(&B.dp_ctr[4], 9ULL);
+		}
+	}
+	bool lfill = false;
+	if (!(B.debug_route & 4) && g.big <= 1 && g.kind == 1 && g.w == bw && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= 2047 && g.qlen <= 2047 &&
+	    (g.tlen > FILL_MAX_LEN || g.qlen > FILL_MAX_LEN) && (long long)g.tlen * g.qlen <= B.max_sw_mat) {
+		// a longer gap between two seeds (512 .. 2047 bases): the banded kernel's int32 form, a band of 256
+		// cells (one launch, early, beside the packed tiers: a narrower first try would put its failures
+		// behind them)
+		const int ad = g.tlen > g.qlen ? g.tlen - g.qlen : g.qlen - g.tlen;
+		const int tier = (510 - ad) / 2 >= 8 ? 18 : 0;
+		if (tier) {
+			if (g.big == 1) g.flag |= SEG_NEEDS_BIG_WS;           // should the banded kernel hand it back
+			g.big = 4 + tier, lfill = true;
+		}
+	}
+	if (lfill) {
+	} else if (!(B.debug_route & 8) && g.big == 1 && g.kind != 1 && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= g.w && g.qlen <= g.w &&
+	           g.tlen + g.qlen - 1 <= 2 * 1535 && (g.tlen < g.qlen ? g.tlen : g.qlen) <= 512) {
+		g.flag |= SEG_NEEDS_BIG_WS;                             // a longer extension (below) that would need the large workspace
+		g.big = 4 + 19;
+	} else if (g.big == 1) {
+		const unsigned long long bi = atomicAdd(&B.dp_ctr[6], 1ULL);
+		B.big_list[bi] = seg_index;
+	} else if (g.big == 3) {
+		const unsigned long long bi = atomicAdd(&B.dp_ctr[58], 1ULL);
+		B.huge_list[bi] = seg_index;
+	} else if (!(B.debug_route & 2) && g.big == 0 && g.kind == 1 && g.w == bw && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= FILL_MAX_LEN && g.qlen <= FILL_MAX_LEN) {
+		// a gap between two seeds whose matrix the band never clips: the banded kernel of
+		// k_fill.hip, 32 lanes per segment when |tlen - qlen| leaves a band worth trying, else 64
+		const int ad = g.tlen > g.qlen ? g.tlen - g.qlen : g.qlen - g.tlen;
+		// the 32-lane tier only when its proof has a chance: the bound a band of that width leaves
+		// against what a read with ~10 % errors scores (~1.28 per base)
+		int tier = (62 - ad) / 2 >= 12 ? 1 : (2 * FILL_MID_CELLS - 2 - ad) / 2 >= 12 ? 18 : (126 - ad) / 2 >= 8 ? 2 : 6;
+		if (tier == 1) {
+			const int bb = (62 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
+			const int g1 = B.gap_q + B.gap_e * (bb + 1), g2 = B.gap_q2 + B.gap_e2 * (bb + 1);
+			const int U = B.sc_a * (mn - bb - 1) - 2 * (g1 < g2 ? g1 : g2);
+			if (U * 25 > mn * B.fill_pred) tier = 18;         // trying costs one unit, failing more than that again: worth it below even odds
+		}
+		if (tier == 18) {                                     // the 42-cell tier (three segments a wave: 4/3 units) against the 64-cell one (2 units)
+			const int bb = (2 * FILL_MID_CELLS - 2 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
+			const int g1 = B.gap_q + B.gap_e * (bb + 1), g2 = B.gap_q2 + B.gap_e2 * (bb + 1);
+			const int U = B.sc_a * (mn - bb - 1) - 2 * (g1 < g2 ? g1 : g2);
+			if ((B.debug_route & 16) || bb < 8 || U * 25 > mn * B.fill_pred_mid) tier = 2;
+		}
+		if (tier == 2) {                                      // and the 64-lane tier likewise, against the literal kernel
+			const int bb = (126 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
+			const int g1 = B.gap_q + B.gap_e * (bb + 1), g2 = B.gap_q2 + B.gap_e2 * (bb + 1);
+			const int U = B.sc_a * (mn - bb - 1) - 2 * (g1 < g2 ? g1 : g2);
+			if (U * 25 > mn * 32) tier = 6;                   // two cells per lane: a band of 128
+		}
+		if (tier == 6) {
+			const int bb = (254 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
+			const int g1 = B.gap_q + B.gap_e * (bb + 1), g2 = B.gap_q2 + B.gap_e2 * (bb + 1);
+			const int U = B.sc_a * (mn - bb - 1) - 2 * (g1 < g2 ? g1 : g2);
+			if (bb < 8 || U * 25 > mn * 32) tier = 0;
+		}
+		if (tier) g.big = 3 + tier;          // not for the literal kernel's first pass
+		if (tier) widx = tier == 1 ? 0 : tier == 2 ? 1 : tier == 18 ? 4 : 2, wamt = (unsigned long long)(g.tlen + g.qlen - 1);
+	} else if (!(B.debug_route & 1) && g.big == 0 && g.kind != 1 && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= g.w && g.qlen <= g.w &&
+	           g.tlen + g.qlen - 1 <= 2 * FILL_MAX_LEN && g.qlen <= 256) {
+		// an extension whose matrix the band never clips, one cell per query base: the packed
+		// extension kernel of k_fill.hip (tiers 8..15: by query length, right / left)
+		const int tier = 8 + 2 * (g.qlen <= 32 ? 0 : g.qlen <= 64 ? 1 : g.qlen <= 128 ? 2 : 3) + ((g.flag & EZ_RIGHT) ? 1 : 0);
+		g.big = 4 + tier;
+		widx = 3, wamt = (unsigned long long)(g.tlen + g.qlen - 1) * g.qlen;
+	} else if (g.big == 0 && g.kind != 1 && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= g.w && g.qlen <= g.w &&
+	           g.tlen + g.qlen - 1 <= 2 * FILL_MAX_LEN && (g.tlen < g.qlen ? g.tlen : g.qlen) <= 256) {
+		// ... or with anti-diagonals that fit a wave (up to four cells per lane): the step-by-step one
+		const int mn = g.tlen < g.qlen ? g.tlen : g.qlen;
+		const int tier = mn <= 32 ? 3 : mn <= 64 ? 4 : mn <= 128 ? 7 : 8;
+		g.big = 3 + tier;
+	}
+	if (!(B.debug_route & 8) && g.big == 0 && g.kind != 1 && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= g.w && g.qlen <= g.w &&
+	    g.tlen + g.qlen - 1 <= 2 * 1535 && (g.tlen < g.qlen ? g.tlen : g.qlen) <= 512) {
+		g.big = 4 + 19;                           // a longer extension: the step-by-step kernel, eight cells per lane
+	}
+	if (g.big == 0) {
+		// the literal kernel: its first pass with everything in LDS, or from the start on its own list
+		const bool all_lds = 12 * T + Q <= B.lds0_state && p_bytes <= B.lds0_p && g.qlen + g.tlen + 2 <= B.lds0_cig;
+		if (all_lds) g.big = 8;
+		else g.big = 20;
+	}
+}
+
+// work list `tier` (Seg.big - 4) of the alignment kernels: its counter in dp_ctr, its array
+__device__ __forceinline__ int plan_list_ctr(int tier)
+{
+	return tier == 19 ? 62 : tier >= 17 ? 13 + tier : tier == 16 ? 28 : tier >= 8 ? 24 + tier : tier < 2 ? 10 + tier : tier < 4 ? 14 + tier : tier == 4 ? 20 : tier == 5 ? 22 : 18 + tier;   // 6 -> 24, 7 -> 25; 8.. -> 32..
+}
+__device__ __forceinline__ int32_t *plan_list(const Batch &B, int tier)
+{
+	return tier == 19 ? B.lext_list : tier == 18 ? B.lfill_list : tier == 17 ? B.fill_list_mid : tier == 16 ? B.mid_list : tier >= 8 ? B.extp_list + (int64_t)(tier - 8) * B.seg_cap
+	     : tier == 0 ? B.fill_list1 : tier == 1 ? B.fill_list2 : tier == 2 ? B.ext_list1 : tier == 3 ? B.ext_list2 : tier == 4 ? B.gen_list
+	     : tier == 5 ? B.fill_list3 : tier == 6 ? B.ext_list3 : B.ext_list4;
+}
+
+__global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_list, int long_from, int slot_state_max, long long slot_p_max, int slot_cig_max,
                                                   long long big_state_max, long long big_p_max, long long big_cig_max,
                                                   long long huge_state_max, long long huge_p_max, long long huge_cig_max)
 {
@@ -200,6 +319,10 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 	const int qlen = (int)(B.offsets[rd + 1] - B.offsets[rd]);
 	Anchor *a = B.ca + a_off;
 	const int n_a = B.ca_cnt[rd];
+	if (long_from > 0 && n_a >= long_from) {                // a long read's region: mnc_dp_plan_long, unless its list is full
+		const unsigned long long li = atomicAdd(&B.dp_ctr[53], 1ULL);
+		if (li < (unsigned long long)B.plan_long_cap) { B.plan_long_list[li] = (int32_t)rslot; return; }
+	}
 	int32_t *K = B.t + a_off + r.as;                       // scratch: one int per anchor of the region
 	d.n_seg = 0, d.first_seg = 0, d.has_left = d.has_right = 0;
 	// an inversion region (mnc_dp_inv): no seeds -- one extension from the start the local alignment found, on the strand
@@ -395,105 +518,13 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 			const bool k_ok = n_seg <= r.cnt;                        // the region's scratch: one int per anchor
 			int n_tier[20] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 			unsigned long long work[5] = { 0, 0, 0, 0, 0 };          // anti-diagonals given to the banded tiers (32 / 64 / 128 cells; [4]: 42 cells); [3]: steps x cells of the packed extensions
+			const PlanLimits lim = { slot_state_max, slot_p_max, slot_cig_max, big_state_max, big_p_max, big_cig_max, huge_state_max, huge_p_max, huge_cig_max };
 			auto emit = [&](Seg g) {
-				g.read = (int32_t)rd, g.reg = (int32_t)rslot, g.rid = rid, g.rev = rev;
-				g.n_cigar = 0, g.zdropped = 0, g.zdrop_code = 0, g.max = 0, g.max_t = g.max_q = -1, g.score = DP_NEG_INF, g.reach_end = 0, g.mqe_t = -1, g.cig_off = 0;
-				// workspace class
-				const long long T = (g.tlen + 15) / 16 * 16, Q = (g.qlen + 15) / 16 * 16 + 32;
-				long long nc = g.qlen < g.tlen ? g.qlen : g.tlen;
-				const int wb = g.w < 0 ? (g.tlen > g.qlen ? g.tlen : g.qlen) : g.w;
-				nc = ((nc < wb + 1 ? nc : wb + 1) + 15) / 16 + 1;
-				const long long p_bytes = ((long long)(g.qlen + g.tlen - 1) * nc + 1) * 16;
-				g.big = (12 * T + Q > slot_state_max || p_bytes > slot_p_max || g.qlen + g.tlen + 8 > slot_cig_max) ? 1 : 0;
-				if ((long long)g.tlen * g.qlen > B.max_sw_mat) g.big = 0;      // not aligned at all (ksw_reset_extz + zdropped)
-				else if (12 * T + Q > big_state_max || p_bytes > big_p_max || g.qlen + g.tlen + 8 > big_cig_max) {
-					g.big = 3;                                              // the few largest: a class of their own, a handful of very large slots
-					if (12 * T + Q > huge_state_max || p_bytes > huge_p_max || g.qlen + g.tlen + 8 > huge_cig_max) {
-						g.big = 2;                                          // beyond even those: the batch fails
-						atomicMax(&B.dp_ctr[4], 9ULL);
-					}
-				}
-				bool lfill = false;
-				if (!(B.debug_route & 4) && g.big <= 1 && g.kind == 1 && g.w == bw && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= 2047 && g.qlen <= 2047 &&
-				    (g.tlen > FILL_MAX_LEN || g.qlen > FILL_MAX_LEN) && (long long)g.tlen * g.qlen <= B.max_sw_mat) {
-					// a longer gap between two seeds (512 .. 2047 bases): the banded kernel's int32 form, a band of 256
-					// cells (one launch, early, beside the packed tiers: a narrower first try would put its failures
-					// behind them)
-					const int ad = g.tlen > g.qlen ? g.tlen - g.qlen : g.qlen - g.tlen;
-					const int tier = (510 - ad) / 2 >= 8 ? 18 : 0;
-					if (tier) {
-						if (g.big == 1) g.flag |= SEG_NEEDS_BIG_WS;           // should the banded kernel hand it back
-						g.big = 4 + tier, ++n_tier[tier], lfill = true;
-					}
-				}
-				if (lfill) {
-				} else if (!(B.debug_route & 8) && g.big == 1 && g.kind != 1 && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= g.w && g.qlen <= g.w &&
-				           g.tlen + g.qlen - 1 <= 2 * 1535 && (g.tlen < g.qlen ? g.tlen : g.qlen) <= 512) {
-					g.flag |= SEG_NEEDS_BIG_WS;                             // a longer extension (below) that would need the large workspace
-					g.big = 4 + 19, ++n_tier[19];
-				} else if (g.big == 1) {
-					const unsigned long long bi = atomicAdd(&B.dp_ctr[6], 1ULL);
-					B.big_list[bi] = (int32_t)(sg - B.segs);
-				} else if (g.big == 3) {
-					const unsigned long long bi = atomicAdd(&B.dp_ctr[58], 1ULL);
-					B.huge_list[bi] = (int32_t)(sg - B.segs);
-				} else if (!(B.debug_route & 2) && g.big == 0 && g.kind == 1 && g.w == bw && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= FILL_MAX_LEN && g.qlen <= FILL_MAX_LEN) {
-					// a gap between two seeds whose matrix the band never clips: the banded kernel of
-					// k_fill.hip, 32 lanes per segment when |tlen - qlen| leaves a band worth trying, else 64
-					const int ad = g.tlen > g.qlen ? g.tlen - g.qlen : g.qlen - g.tlen;
-					// the 32-lane tier only when its proof has a chance: the bound a band of that width leaves
-					// against what a read with ~10 % errors scores (~1.28 per base)
-					int tier = (62 - ad) / 2 >= 12 ? 1 : (2 * FILL_MID_CELLS - 2 - ad) / 2 >= 12 ? 18 : (126 - ad) / 2 >= 8 ? 2 : 6;
-					if (tier == 1) {
-						const int bb = (62 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
-						const int g1 = B.gap_q + B.gap_e * (bb + 1), g2 = B.gap_q2 + B.gap_e2 * (bb + 1);
-						const int U = B.sc_a * (mn - bb - 1) - 2 * (g1 < g2 ? g1 : g2);
-						if (U * 25 > mn * B.fill_pred) tier = 18;         // trying costs one unit, failing more than that again: worth it below even odds
-					}
-					if (tier == 18) {                                     // the 42-cell tier (three segments a wave: 4/3 units) against the 64-cell one (2 units)
-						const int bb = (2 * FILL_MID_CELLS - 2 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
-						const int g1 = B.gap_q + B.gap_e * (bb + 1), g2 = B.gap_q2 + B.gap_e2 * (bb + 1);
-						const int U = B.sc_a * (mn - bb - 1) - 2 * (g1 < g2 ? g1 : g2);
-						if ((B.debug_route & 16) || bb < 8 || U * 25 > mn * B.fill_pred_mid) tier = 2;
-					}
-					if (tier == 2) {                                      // and the 64-lane tier likewise, against the literal kernel
-						const int bb = (126 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
-						const int g1 = B.gap_q + B.gap_e * (bb + 1), g2 = B.gap_q2 + B.gap_e2 * (bb + 1);
-						const int U = B.sc_a * (mn - bb - 1) - 2 * (g1 < g2 ? g1 : g2);
-						if (U * 25 > mn * 32) tier = 6;                   // two cells per lane: a band of 128
-					}
-					if (tier == 6) {
-						const int bb = (254 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
-						const int g1 = B.gap_q + B.gap_e * (bb + 1), g2 = B.gap_q2 + B.gap_e2 * (bb + 1);
-						const int U = B.sc_a * (mn - bb - 1) - 2 * (g1 < g2 ? g1 : g2);
-						if (bb < 8 || U * 25 > mn * 32) tier = 0;
-					}
-					if (tier) g.big = 3 + tier, ++n_tier[tier - 1];          // not for the literal kernel's first pass
-					if (tier) work[tier == 1 ? 0 : tier == 2 ? 1 : tier == 18 ? 4 : 2] += (unsigned long long)(g.tlen + g.qlen - 1);
-				} else if (!(B.debug_route & 1) && g.big == 0 && g.kind != 1 && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= g.w && g.qlen <= g.w &&
-				           g.tlen + g.qlen - 1 <= 2 * FILL_MAX_LEN && g.qlen <= 256) {
-					// an extension whose matrix the band never clips, one cell per query base: the packed
-					// extension kernel of k_fill.hip (tiers 8..15: by query length, right / left)
-					const int tier = 8 + 2 * (g.qlen <= 32 ? 0 : g.qlen <= 64 ? 1 : g.qlen <= 128 ? 2 : 3) + ((g.flag & EZ_RIGHT) ? 1 : 0);
-					g.big = 4 + tier, ++n_tier[tier];
-					work[3] += (unsigned long long)(g.tlen + g.qlen - 1) * g.qlen;
-				} else if (g.big == 0 && g.kind != 1 && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= g.w && g.qlen <= g.w &&
-				           g.tlen + g.qlen - 1 <= 2 * FILL_MAX_LEN && (g.tlen < g.qlen ? g.tlen : g.qlen) <= 256) {
-					// ... or with anti-diagonals that fit a wave (up to four cells per lane): the step-by-step one
-					const int mn = g.tlen < g.qlen ? g.tlen : g.qlen;
-					const int tier = mn <= 32 ? 3 : mn <= 64 ? 4 : mn <= 128 ? 7 : 8;
-					g.big = 3 + tier, ++n_tier[tier - 1];
-				}
-				if (!(B.debug_route & 8) && g.big == 0 && g.kind != 1 && g.tlen >= 1 && g.qlen >= 1 && g.tlen <= g.w && g.qlen <= g.w &&
-				    g.tlen + g.qlen - 1 <= 2 * 1535 && (g.tlen < g.qlen ? g.tlen : g.qlen) <= 512) {
-					g.big = 4 + 19, ++n_tier[19];                           // a longer extension: the step-by-step kernel, eight cells per lane
-				}
-				if (g.big == 0) {
-					// the literal kernel: its first pass with everything in LDS, or from the start on its own list
-					const bool all_lds = 12 * T + Q <= B.lds0_state && p_bytes <= B.lds0_p && g.qlen + g.tlen + 2 <= B.lds0_cig;
-					if (all_lds) g.big = 8, ++n_tier[4];
-					else g.big = 20, ++n_tier[16];
-				}
+				int widx;
+				unsigned long long wamt;
+				plan_seg_class(B, lim, bw, rd, rslot, rid, rev, (int32_t)(sg - B.segs), g, widx, wamt);
+				if (g.big >= 4) ++n_tier[g.big - 4];
+				if (widx >= 0) work[widx] += wamt;
 				if (k_ok) K[sg - (B.segs + s0)] = g.big;                // for the lists below (the scratch ints are free again)
 				*sg++ = g;
 			};
@@ -536,17 +567,329 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 			// the banded kernel's lists: one reservation per region and tier
 			for (int tier = 0; tier < 20; ++tier) {
 				if (n_tier[tier] == 0) continue;
-				const int ci = tier == 19 ? 62 : tier >= 17 ? 13 + tier : tier == 16 ? 28 : tier >= 8 ? 24 + tier : tier < 2 ? 10 + tier : tier < 4 ? 14 + tier : tier == 4 ? 20 : tier == 5 ? 22 : 18 + tier;   // 6 -> 24, 7 -> 25; 8.. -> 32..
-				unsigned long long fi = atomicAdd(&B.dp_ctr[ci], (unsigned long long)n_tier[tier]);
-				int32_t *lst = tier == 19 ? B.lext_list : tier == 18 ? B.lfill_list : tier == 17 ? B.fill_list_mid : tier == 16 ? B.mid_list : tier >= 8 ? B.extp_list + (int64_t)(tier - 8) * B.seg_cap
-				             : tier == 0 ? B.fill_list1 : tier == 1 ? B.fill_list2 : tier == 2 ? B.ext_list1 : tier == 3 ? B.ext_list2 : tier == 4 ? B.gen_list
-				             : tier == 5 ? B.fill_list3 : tier == 6 ? B.ext_list3 : B.ext_list4;
+				unsigned long long fi = atomicAdd(&B.dp_ctr[plan_list_ctr(tier)], (unsigned long long)n_tier[tier]);
+				int32_t *lst = plan_list(B, tier);
 				for (int k = 0; k < n_seg; ++k)
 					if ((k_ok ? K[k] : B.segs[s0 + k].big) == 4 + tier) lst[fi++] = (int32_t)(s0 + k);
 			}
 		}
 	}
 	B.regdp[rslot] = d;
+}
+
+// ================================================================ plan, regions of long reads
+// The lane that plans a region reads its anchors eight at a time from memory, four passes: a 60 kb read's region has
+// 4 700 anchors -- 2 400 round trips, 4 ms that a batch with such a read waits for.  Regions of reads with `long_from`
+// chained anchors or more are therefore planned by a WAVE each: the read's squeezed anchors in LDS; the passes over all
+// anchors as wave-wide steps (the two collections of long gaps as ballot compactions; the choice of the gap fillings'
+// end seeds 64 candidates at a time; the segments' records one per lane); the short sequential pieces -- mm_fix_bad_ends,
+// the walks over the collected long gaps, the DP window -- on lane 0, out of LDS.  Same results as mnc_dp_plan, which
+// tests/test_gpu_dp.py::test_long_reads_and_mixed_lengths and debug bit 0x800000 (everything on the lane form) hold it to.
+__device__ int plan_long_gaps_wave(const Anchor *b, int cnt1, int min_gap, int32_t *K, int lane)
+{
+	int n = 0;
+	for (int i0 = 1; i0 < cnt1; i0 += 64) {
+		const int i = i0 + lane;
+		bool hit = false;
+		if (i < cnt1) { const int gap = seed_gap(b, i); hit = gap < -min_gap || gap > min_gap; }
+		const unsigned long long m = __ballot(hit);
+		if (hit) K[n + __popcll(m & ((1ULL << lane) - 1ULL))] = i;
+		n += __popcll(m);
+	}
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	return n <= 1 ? 0 : n;
+}
+
+__global__ __launch_bounds__(64) void mnc_dp_plan_long(Batch B, int lds_anchors, int n_a_from, int n_a_below, PlanLimits lim)
+{
+	extern __shared__ __align__(16) uint8_t pl_smem[];       // [anchors | one int per anchor]
+	const int lane = threadIdx.x;
+	const unsigned long long lt = (1ULL << lane) - 1ULL;
+	auto sync = [&]() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); };
+	auto bc = [&](int v) { return __builtin_amdgcn_readfirstlane(v); };
+	// the regions mnc_dp_plan left in the list (it ran before this kernel on the same stream), dealt out one at a time:
+	// neighbours in the list are regions of neighbouring reads, about as long as each other
+	{
+		const unsigned long long listed = B.dp_ctr[53];
+		const unsigned long long n_long = listed < (unsigned long long)B.plan_long_cap ? listed : (unsigned long long)B.plan_long_cap;
+		for (unsigned long long wi = blockIdx.x; wi < n_long; wi += gridDim.x) {
+			const int64_t rslot = B.plan_long_list[wi];
+			mnc_reg_t r = B.regs[rslot];
+			RegDP d = B.regdp[rslot];
+			const uint32_t rd = (uint32_t)d.read;
+			const int64_t a_off = B.an_off[rd];
+			const int qlen = (int)(B.offsets[rd + 1] - B.offsets[rd]);
+			const int n_a = B.ca_cnt[rd];
+			if (n_a < n_a_from || n_a >= n_a_below) continue;      // the launch with the other LDS size takes it
+			d.n_seg = 0, d.first_seg = 0, d.has_left = d.has_right = 0;
+			const bool inv = (r.flags & REG_INV) != 0;
+			if (r.cnt == 0 && !inv) { d.state = 2; if (lane == 0) B.regdp[rslot] = d; continue; }
+			const bool staged = r.cnt > 0 && n_a <= lds_anchors;
+			Anchor *a = B.ca + a_off;
+			int32_t *K = B.t + a_off + r.as;                   // scratch: one int per anchor of the region
+			if (staged) {
+				Anchor *s_a = reinterpret_cast<Anchor*>(pl_smem);
+				for (int i = lane; i < n_a; i += 64) s_a[i] = a[i];
+				a = s_a, K = reinterpret_cast<int32_t*>(s_a + lds_anchors);
+			}
+			sync();
+			const int k2 = KMER >> 1;
+			const int rid = inv ? d.rid : (int32_t)(a[r.as].x << 1 >> 33), rev = inv ? d.rev : (int32_t)(a[r.as].x >> 63);
+			d.rid = rid, d.rev = rev, d.qlen = qlen, d.pad_ = 0, d.coff = B.seq_off[rid], d.read_off = B.offsets[rd];
+			const int ref_len = (int)(B.seq_off[rid + 1] - B.seq_off[rid]);
+			const int bw = inv ? (int)(B.bw * 1.5) : (int)(B.bw * 1.5 + 1.);
+			int as1 = r.as, cnt1 = r.cnt;
+			int rs = 0, qs = 0, re = 0, qe = 0, rs0 = 0, qs0 = 0, re0 = 0, qe0 = 0;
+			Anchor *b = a;
+			if (inv) {
+				rs = re = d.rs, qs = qe = d.qs, rs0 = rs, qs0 = qs, re0 = d.re0, qe0 = d.qe0;
+				as1 = 0, cnt1 = 0;
+			} else {
+				// ---- mm_fix_bad_ends (lane 0: it stops after 2 bw bases from either end)
+				if (lane == 0 && r.cnt >= 3) {
+					const int min_match = B.min_sc * 2;
+					int m, l;
+					m = l = (int)(a[r.as].y >> 32 & 0xff);
+					for (int i = r.as + 1; i < r.as + r.cnt - 1; ++i) {
+						const int q_span = (int)(a[i].y >> 32 & 0xff);
+						if (a[i].y & SEED_LONG_JOIN) break;
+						const int lr = (int32_t)a[i].x - (int32_t)a[i - 1].x, lq = (int32_t)a[i].y - (int32_t)a[i - 1].y;
+						const int mn = lr < lq ? lr : lq, mx = lr > lq ? lr : lq;
+						if (mx - mn > l >> 1) as1 = i;
+						l += mn;
+						m += mn < q_span ? mn : q_span;
+						if (l >= B.bw << 1 || (m >= min_match && m >= B.bw) || m >= r.mlen >> 1) break;
+					}
+					cnt1 = r.as + r.cnt - as1;
+					m = l = (int)(a[r.as + r.cnt - 1].y >> 32 & 0xff);
+					for (int i = r.as + r.cnt - 2; i > as1; --i) {
+						const int q_span = (int)(a[i + 1].y >> 32 & 0xff);
+						if (a[i + 1].y & SEED_LONG_JOIN) break;
+						const int lr = (int32_t)a[i + 1].x - (int32_t)a[i].x, lq = (int32_t)a[i + 1].y - (int32_t)a[i].y;
+						const int mn = lr < lq ? lr : lq, mx = lr > lq ? lr : lq;
+						if (mx - mn > l >> 1) cnt1 = i + 1 - as1;
+						l += mn;
+						m += mn < q_span ? mn : q_span;
+						if (l >= B.bw << 1 || (m >= min_match && m >= B.bw) || m >= r.mlen >> 1) break;
+					}
+				}
+				as1 = bc(as1), cnt1 = bc(cnt1);
+				b = a + as1;
+				// ---- mm_filter_bad_seeds(as1, cnt1, a, 10, 40, max_gap >> 1, 10): the long gaps by all lanes, the walk over them on lane 0
+				{
+					const int n = plan_long_gaps_wave(b, cnt1, 10, K, lane);
+					if (lane == 0 && n > 0) {
+						const int diff_thres = 40, max_ext_len = B.max_gap >> 1, max_ext_cnt = 10;
+						int mx = 0, max_st = -1, max_en = -1;
+						for (int k = 0;; ++k) {
+							int gap, l, n_ins = 0, n_del = 0, max_diff = 0, max_diff_l = -1;
+							if (k == n || k >= max_en) {
+								if (max_en > 0)
+									for (int i = K[max_st]; i < K[max_en]; ++i) b[i].y |= SEED_IGNORE;
+								mx = 0, max_st = max_en = -1;
+								if (k == n) break;
+							}
+							const int i = K[k];
+							gap = seed_gap(b, i);
+							if (gap > 0) n_ins += gap; else n_del += -gap;
+							const int qs_ = (int32_t)b[i - 1].y, rs_ = (int32_t)b[i - 1].x;
+							for (l = k + 1; l < n && l <= k + max_ext_cnt; ++l) {
+								const int j = K[l];
+								if ((int32_t)b[j].y - qs_ > max_ext_len || (int32_t)b[j].x - rs_ > max_ext_len) break;
+								gap = seed_gap(b, j);
+								if (gap > 0) n_ins += gap; else n_del += -gap;
+								const int diff = n_ins + n_del - abs(n_ins - n_del);
+								if (max_diff < diff) max_diff = diff, max_diff_l = l;
+							}
+							if (max_diff > diff_thres && max_diff > mx) mx = max_diff, max_st = k, max_en = max_diff_l;
+						}
+					}
+					sync();
+				}
+				// ---- mm_filter_bad_seeds_alt(as1, cnt1, a, 30, max_gap >> 1)
+				{
+					const int n = plan_long_gaps_wave(b, cnt1, 30, K, lane);
+					if (lane == 0) {
+						const int max_ext = B.max_gap >> 1;
+						for (int k = 0; k < n;) {
+							const int i = K[k];
+							int l, gap1 = seed_gap(b, i), re1 = (int32_t)b[i].x, qe1 = (int32_t)b[i].y;
+							gap1 = gap1 > 0 ? gap1 : -gap1;
+							for (l = k + 1; l < n; ++l) {
+								const int j = K[l];
+								if ((int32_t)b[j].y - qe1 > max_ext || (int32_t)b[j].x - re1 > max_ext) break;
+								int gap2 = seed_gap(b, j);
+								const int q_span_pre = (int)(b[j - 1].y >> 32 & 0xff);
+								const int rs2 = (int32_t)b[j - 1].x + q_span_pre, qs2 = (int32_t)b[j - 1].y + q_span_pre;
+								const int m = rs2 - re1 < qs2 - qe1 ? rs2 - re1 : qs2 - qe1;
+								gap2 = gap2 > 0 ? gap2 : -gap2;
+								if (m > gap1 + gap2) break;
+								re1 = (int32_t)b[j].x, qe1 = (int32_t)b[j].y, gap1 = gap2;
+							}
+							if (l > k + 1) {
+								const int end = K[l - 1];
+								for (int j = K[k]; j < end; ++j) b[j].y |= SEED_IGNORE;
+								b[end].y |= SEED_LONG_JOIN;
+							}
+							k = l;
+						}
+					}
+					sync();
+				}
+				// ---- DP window (lane 0: it looks at a few neighbours of the region)
+				if (lane == 0) {
+					rs = (int32_t)b[0].x - k2, qs = (int32_t)b[0].y - k2;
+					re = (int32_t)b[cnt1 - 1].x - k2, qe = (int32_t)b[cnt1 - 1].y - k2;
+					rs0 = (int32_t)a[r.as].x + 1 - (int32_t)(a[r.as].y >> 32 & 0xff);
+					qs0 = (int32_t)a[r.as].y + 1 - (int32_t)(a[r.as].y >> 32 & 0xff);
+					if (rs0 < 0) rs0 = 0;
+					int rs1 = 0, qs1 = 0, l;
+					for (int i = r.as - 1, c = 0; i >= 0 && a[i].x >> 32 == a[r.as].x >> 32; --i) {
+						const int x = (int32_t)a[i].x + 1 - (int32_t)(a[i].y >> 32 & 0xff);
+						const int y = (int32_t)a[i].y + 1 - (int32_t)(a[i].y >> 32 & 0xff);
+						if (x < rs0 && y < qs0) {
+							if (++c > B.min_cnt) {
+								l = rs0 - x > qs0 - y ? rs0 - x : qs0 - y;
+								rs1 = rs0 - l, qs1 = qs0 - l;
+								if (rs1 < 0) rs1 = 0;
+								break;
+							}
+						}
+					}
+					if (qs > 0 && rs > 0) {
+						l = qs < B.max_gap ? qs : B.max_gap;
+						qs1 = qs1 > qs - l ? qs1 : qs - l;
+						qs0 = qs0 < qs1 ? qs0 : qs1;
+						l += l * B.sc_a > B.gap_q ? (l * B.sc_a - B.gap_q) / B.gap_e : 0;
+						l = l < B.max_gap ? l : B.max_gap;
+						l = l < rs ? l : rs;
+						rs1 = rs1 > rs - l ? rs1 : rs - l;
+						rs0 = rs0 < rs1 ? rs0 : rs1;
+						rs0 = rs0 < rs ? rs0 : rs;
+					} else rs0 = rs, qs0 = qs;
+					re0 = (int32_t)a[r.as + r.cnt - 1].x + 1, qe0 = (int32_t)a[r.as + r.cnt - 1].y + 1;
+					int re1 = ref_len, qe1 = qlen;
+					for (int i = r.as + r.cnt, c = 0; i < n_a && a[i].x >> 32 == a[r.as].x >> 32; ++i) {
+						const int x = (int32_t)a[i].x + 1 - (int32_t)(a[i].y >> 32 & 0xff);
+						const int y = (int32_t)a[i].y + 1 - (int32_t)(a[i].y >> 32 & 0xff);
+						if (x > re0 && y > qe0) {
+							if (++c > B.min_cnt) {
+								l = x - re0 > y - qe0 ? x - re0 : y - qe0;
+								re1 = re0 + l, qe1 = qe0 + l;
+								break;
+							}
+						}
+					}
+					if (qe < qlen && re < ref_len) {
+						l = qlen - qe < B.max_gap ? qlen - qe : B.max_gap;
+						qe1 = qe1 < qe + l ? qe1 : qe + l;
+						qe0 = qe0 > qe1 ? qe0 : qe1;
+						l += l * B.sc_a > B.gap_q ? (l * B.sc_a - B.gap_q) / B.gap_e : 0;
+						l = l < B.max_gap ? l : B.max_gap;
+						l = l < ref_len - re ? l : ref_len - re;
+						re1 = re1 < re + l ? re1 : re + l;
+						re0 = re0 > re1 ? re0 : re1;
+					} else re0 = re, qe0 = qe;
+				}
+				rs = bc(rs), qs = bc(qs), re = bc(re), qe = bc(qe), rs0 = bc(rs0), qs0 = bc(qs0), re0 = bc(re0), qe0 = bc(qe0);
+			}   // !inv
+			d.as1 = as1, d.cnt1 = cnt1, d.rs = rs, d.qs = qs, d.re = re, d.qe = qe;
+			d.rs0 = rs0, d.qs0 = qs0, d.re0 = re0, d.qe0 = qe0;
+
+			// ---- the seeds the gap fillings end at: the next seed (not ignored, not tandem) at least min_ksw_len past the
+			// last one on both sequences, or a long-join seed, or the last seed -- 64 candidates at a time
+			const bool left = !inv && qs > 0 && rs > 0;
+			int n_fill = 0;
+			{
+				int pos = 0, prs = rs, pqs = qs;
+				while (pos < cnt1 - 1) {
+					const int i = pos + 1 + lane;
+					bool elig = false;
+					int cre = 0, cqe = 0;
+					if (i < cnt1) {
+						const uint64_t vx = b[i].x, vy = b[i].y;
+						cre = (int32_t)vx - k2, cqe = (int32_t)vy - k2;
+						const bool skip = (vy & (SEED_IGNORE | SEED_TANDEM)) && i != cnt1 - 1;
+						elig = !skip && (i == cnt1 - 1 || (vy & SEED_LONG_JOIN) || (cqe - pqs >= B.min_ksw_len && cre - prs >= B.min_ksw_len));
+					}
+					const unsigned long long m = __ballot(elig);
+					if (!m) { pos += 64; continue; }
+					const int l = __ffsll((long long)m) - 1;
+					pos += 1 + l, prs = __shfl(cre, l), pqs = __shfl(cqe, l);
+					if (lane == 0) K[n_fill] = pos;                    // (the long gaps' list is done with)
+					++n_fill;
+				}
+				sync();
+			}
+			const bool right = qe < qe0 && re < re0;
+			const int n_seg = (left ? 1 : 0) + n_fill + (right ? 1 : 0);
+			d.n_seg = n_seg, d.has_left = left, d.has_right = right, d.state = 1;
+			if (n_seg > 0) {
+				unsigned long long s0 = 0;
+				if (lane == 0) s0 = atomicAdd(&B.dp_ctr[0], (unsigned long long)n_seg);
+				s0 = (unsigned long long)__shfl((long long)s0, 0);
+				d.first_seg = (int32_t)s0;
+				if ((long long)(s0 + n_seg) > B.seg_cap) {
+					if (lane == 0) atomicMax(&B.dp_ctr[4], 1ULL);       // overflow: the batch is redone with more room
+					d.n_seg = 0, d.has_left = d.has_right = 0;
+				} else {
+					// one segment per lane, 64 at a time
+					for (int k0 = 0; k0 < n_seg; k0 += 64) {
+						const int k = k0 + lane;
+						const bool in = k < n_seg;
+						Seg g;
+						int widx = -1;
+						unsigned long long wamt = 0;
+						if (in) {
+							if (left && k == 0) {
+								g.kind = 0, g.ts = rs0, g.tlen = rs - rs0, g.qs = qs0, g.qlen = qs - qs0, g.w = bw;
+								g.zdrop = (r.flags & REG_SPLIT_INV) ? B.zdrop_inv : B.zdrop;
+								g.flag = EZ_EXTZ_ONLY | EZ_RIGHT | EZ_REV_CIGAR, g.ai = 0;
+							} else if (right && k == n_seg - 1) {
+								g.kind = 2, g.ts = re, g.tlen = re0 - re, g.qs = qe, g.qlen = qe0 - qe, g.w = bw;
+								g.zdrop = B.zdrop, g.flag = EZ_EXTZ_ONLY, g.ai = cnt1 - 1;
+							} else {
+								const int f = k - (left ? 1 : 0), i = K[f];
+								const uint64_t vx = b[i].x, vy = b[i].y;
+								int prs = rs, pqs = qs;
+								if (f > 0) { const int ip = K[f - 1]; prs = (int32_t)b[ip].x - k2, pqs = (int32_t)b[ip].y - k2; }
+								const int cre = (int32_t)vx - k2, cqe = (int32_t)vy - k2;
+								g.kind = 1, g.ts = prs, g.tlen = cre - prs, g.qs = pqs, g.qlen = cqe - pqs;
+								g.w = (vy & SEED_LONG_JOIN) ? (cqe - pqs > cre - prs ? cqe - pqs : cre - prs) : bw;
+								g.zdrop = B.zdrop, g.flag = EZ_APPROX_MAX, g.ai = i;
+							}
+							plan_seg_class(B, lim, bw, rd, rslot, rid, rev, (int32_t)(s0 + k), g, widx, wamt);
+							B.segs[s0 + k] = g;
+						}
+						// the work counters and the kernels' lists: one reservation per tier and 64 segments
+						for (int w5 = 0; w5 < 5; ++w5) {
+							unsigned long long v = in && widx == w5 ? wamt : 0ULL;
+#pragma unroll
+							for (int sft = 32; sft > 0; sft >>= 1) v += (unsigned long long)__shfl_xor((long long)v, sft);
+							if (lane == 0 && v) atomicAdd(&B.dp_ctr[48 + w5], v);
+						}
+						const int tier = in && g.big >= 4 ? g.big - 4 : -1;
+						unsigned long long left_t = __ballot(tier >= 0);
+						while (left_t) {
+							const int t = __shfl(tier, __ffsll((long long)left_t) - 1);
+							const unsigned long long mt = __ballot(tier == t);
+							left_t &= ~mt;
+							unsigned long long fi = 0;
+							if (lane == 0) fi = atomicAdd(&B.dp_ctr[plan_list_ctr(t)], (unsigned long long)__popcll(mt));
+							fi = (unsigned long long)__shfl((long long)fi, 0);
+							if (tier == t) plan_list(B, t)[fi + __popcll(mt & lt)] = (int32_t)(s0 + k);
+						}
+					}
+				}
+			}
+			if (lane == 0) B.regdp[rslot] = d;
+			sync();
+			// the seed filters' flags (SEED_IGNORE, SEED_LONG_JOIN) live in the anchors' y words: the stitch kernel reads them
+			if (staged) for (int i = lane; i < r.cnt; i += 64) B.ca[a_off + r.as + i].y = a[r.as + i].y;
+			sync();
+		}
+	}
 }
 
 // ================================================================ align: ksw_extd2 on one wave
@@ -1770,6 +2113,7 @@ __global__ void mnc_dp_round(Batch B, int first)
 	for (int k = 10; k < 48; ++k) B.dp_ctr[k] = 0;
 	B.dp_ctr[56] = B.dp_ctr[57] = B.dp_ctr[58] = B.dp_ctr[59] = B.dp_ctr[60] = B.dp_ctr[61] = B.dp_ctr[62] = B.dp_ctr[63] = 0;
 	B.dp_ctr[54] = 0;                     // queue of the 42-cell tier (its list length is [30], its anti-diagonals [52])
+	B.dp_ctr[53] = 0;                     // regions left to mnc_dp_plan_long this round
 	if (first) for (int k = 48; k < 64; ++k) B.dp_ctr[k] = 0;   // banded kernel: list lengths 10 / 11 / 12 (tier 1, tier 2, handed back), queues 13 / 14 / 15;
 	                                                 // extension kernel: lists 16 / 17, queues 18 / 19; literal kernel's first pass: list 20, queue 21; banded kernel, 128 cells: list 22, queue 23; extension kernel, 128 / 256 cells: lists 24 / 25, queues 26 / 27
 }
@@ -1797,11 +2141,27 @@ void launch_dp_gather_long(const Batch &B, const uint32_t *lists, const ClassSpa
 }
 void launch_dp_round(const Batch &B, int first, hipStream_t st) { hipLaunchKernelGGL(mnc_dp_round, dim3(1), dim3(1), 0, st, B, first); }
 void launch_dp_round_end(const Batch &B, hipStream_t st) { hipLaunchKernelGGL(mnc_dp_round_end, dim3(1), dim3(1), 0, st, B); }
-void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work, int state_max, long long p_max, int cig_max,
+constexpr int PLAN_LONG = 512;                // chained anchors of a read from which its regions are planned a wave each (a 5 kb read has ~200 per chain)
+constexpr int PLAN_LDS_ANCHORS = 6144;        // ... out of LDS up to this many (20 bytes each: 120 KB, one wave a CU), from memory beyond
+constexpr int PLAN_LDS_MID = 2560;            // most of them (reads up to ~30 kb) in a launch of their own with 50 KB a wave: three a CU
+int dp_plan_prepare()
+{
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_plan_long), hipFuncAttributeMaxDynamicSharedMemorySize, PLAN_LDS_ANCHORS * 20);
+	if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return MNC_ERR_HIP; }
+	return MNC_OK;
+}
+// `long_reads`: the batch holds reads long enough for PLAN_LONG chained anchors (the caller knows its longest read)
+void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work, bool long_reads, int state_max, long long p_max, int cig_max,
                     long long big_state, long long big_p, long long big_cig, long long huge_state, long long huge_p, long long huge_cig, hipStream_t st)
 {
-	if (max_work) hipLaunchKernelGGL(mnc_dp_plan, dim3((max_work + 63) / 64), dim3(64), 0, st, B, work_list, state_max, p_max, cig_max, big_state, big_p, big_cig,
-	                                 huge_state, huge_p, huge_cig);
+	if (!max_work) return;
+	hipLaunchKernelGGL(mnc_dp_plan, dim3((max_work + 63) / 64), dim3(64), 0, st, B, work_list, long_reads ? PLAN_LONG : 0,
+	                   state_max, p_max, cig_max, big_state, big_p, big_cig, huge_state, huge_p, huge_cig);
+	if (long_reads) {
+		const PlanLimits lim = { state_max, p_max, cig_max, big_state, big_p, big_cig, huge_state, huge_p, huge_cig };
+		hipLaunchKernelGGL(mnc_dp_plan_long, dim3(256 * 3), dim3(64), (size_t)PLAN_LDS_MID * 20, st, B, PLAN_LDS_MID, 0, PLAN_LDS_MID + 1, lim);
+		hipLaunchKernelGGL(mnc_dp_plan_long, dim3(256), dim3(64), (size_t)PLAN_LDS_ANCHORS * 20, st, B, PLAN_LDS_ANCHORS, PLAN_LDS_MID + 1, INT32_MAX, lim);
+	}
 }
 size_t dp_align_ws_bytes(long long state_max, long long p_max, long long cig_max) { return align_ws(state_max, p_max, cig_max).total; }
 int dp_align_prepare(int lds_bytes)

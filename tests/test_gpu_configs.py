@@ -86,7 +86,9 @@ def test_config2_100k_reads_vs_20_genomes(capi, oracle):
     assert sum(len(s) for s in seqs) == 94_031_982
     n = 100_000
     bases, offsets, truth = synth.reads(seqs, n, 5000, seed=synth.SEED_READS + 2)
-    assign, best, nhits = _check_whole_batch(capi, oracle, names, seqs, bases, offsets, truth, 0.999, dp_sample=6000)
+    # every one of the 100 000 reads against the oracle under both contracts (its scalar ksw2 simulation does ~1 900 reads/s
+    # on the box's 16 cores: about a minute)
+    assign, best, nhits = _check_whole_batch(capi, oracle, names, seqs, bases, offsets, truth, 0.999)
     # the device-resident entry point with on-device taxon counts (what bench.py times)
     idx = capi.Index.from_seqs(names, seqs)
     eng = capi.Engine(idx, 0)

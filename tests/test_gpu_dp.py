@@ -170,6 +170,51 @@ def test_long_reads_and_mixed_lengths(capi, oracle, world):
     assert regs["n_cigar"].max() > 1024 and (regs["qe"] - regs["qs"]).max() > 40_000
 
 
+def test_long_reads_regions_planned_by_a_wave(capi, oracle, world):
+    """Regions of reads with 512 chained anchors or more are planned by mnc_dp_plan_long (a wave per region: the passes
+    over all anchors as wave-wide steps) instead of mnc_dp_plan (a lane per region).  Long reads with long insertions,
+    deletions that cancel them, junk in the middle and noisy stretches -- what the seed filters and the long-join seeds
+    exist for -- must come out the same from both forms (debug bit 0x800000: the lane form for everything) and equal the
+    oracle."""
+    seqs = world["seqs"]
+    rng = np.random.default_rng(4242)
+    junk = lambda n: util.ACGT[rng.integers(0, 4, n)]
+    g = seqs[0]
+    reads = []
+    for L, (sub, ins, dele) in ((40_000, (400, 300, 300)), (36_000, (150, 100, 100)), (50_000, (550, 400, 400))):
+        b, o, _ = synth.reads(seqs, 1, L, seed=int(rng.integers(1, 1 << 30)), sub=sub, ins=ins, dele=dele)
+        reads.append(b[o[0]:o[1]])
+    # an insertion cancelled by a deletion 1.5 kb on; two long gaps close together; junk flanks; a 600-base deletion
+    reads.append(np.concatenate([g[10_000:25_000], junk(60), g[25_000:26_500], g[26_560:45_000]]))
+    reads.append(np.concatenate([g[50_000:70_000], junk(45), g[70_000:70_400], junk(50), g[70_400:90_000]]))
+    reads.append(np.concatenate([junk(1500), g[100_000:118_000], g[118_600:140_000], junk(900)]))
+    reads.append(util.revcomp(np.concatenate([g[5_000:30_000], junk(800), g[30_800:52_000]])))
+    bases, offsets = util.pack_reads(reads)
+    eng = world["eng"]
+    assign, best, nhits = _compare_dp(capi, oracle, world, bases, offsets, min_mapq=0)
+    regs = eng.dump(capi.DUMP_REGS, capi.REG_DTYPE).copy()
+    cigs = eng.dump(capi.DUMP_CIGARS, np.uint32).copy()
+    segs = eng.dump(capi.DUMP_SEGS, capi.SEG_DTYPE).copy()
+    assert len(regs) >= len(reads) and (regs["cnt"] >= 1024).any()
+    try:
+        eng.set_debug(0x800000)
+        a2, b2, n2 = eng.classify(bases, offsets, 0)
+        regs2 = eng.dump(capi.DUMP_REGS, capi.REG_DTYPE)
+        cigs2 = eng.dump(capi.DUMP_CIGARS, np.uint32)
+        segs2 = eng.dump(capi.DUMP_SEGS, capi.SEG_DTYPE)
+    finally:
+        eng.set_debug(0)
+    assert np.array_equal(assign, a2) and np.array_equal(nhits, n2)
+    for k in capi.REG_DTYPE.names:
+        assert np.array_equal(regs[k], regs2[k]), k
+    assert np.array_equal(cigs, cigs2)
+    # the kernel calls themselves: the same set (their order in the pool depends on which wave came first)
+    def planned(t):
+        cols = np.stack([t[k] for k in ("read", "kind", "rid", "rev", "ts", "tlen", "qs", "qlen", "w", "zdrop", "flag", "ai", "big")], axis=1)
+        return cols[np.lexsort(cols.T[::-1])]
+    assert np.array_equal(planned(segs), planned(segs2))
+
+
 def test_engines_on_threads_share_the_device_workspace(capi, oracle, world):
     """monica's thread pool: one engine per thread on the same index; the alignment scratch of the device
     is lent to one engine at a time.  Every thread must get what a single engine gets."""
