@@ -45,7 +45,7 @@ void launch_dp_gather_long(const Batch &B, const uint32_t *lists, const ClassSpa
 void launch_dp_round(const Batch &B, int first, hipStream_t st);
 void launch_dp_round_end(const Batch &B, hipStream_t st);
 int dp_plan_prepare();
-void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work, bool long_reads, int state_max, long long p_max, int cig_max,
+void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work, int wave_form, int state_max, long long p_max, int cig_max,
                     long long big_state, long long big_p, long long big_cig, long long huge_state, long long huge_p, long long huge_cig, hipStream_t st);
 size_t dp_align_ws_bytes(long long state_max, long long p_max, long long cig_max);
 int dp_align_prepare(int lds_bytes);
@@ -1175,7 +1175,8 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 		unsigned max_work = (unsigned)nsr;
 		// reads long enough for 512 chained anchors (a 5 kb read has ~200 a chain): their regions are planned a wave each;
 		// debug bit 0x800000: everything on the lane form (tests)
-		const bool long_reads = !(e->debug & 0x800000) && (e->cur_max_read_len <= 0 || e->cur_max_read_len > 6144);
+		// 0x10: every region on the wave form (tests)
+		const int long_reads = (e->debug & 0x10) ? 2 : !(e->debug & 0x800000) && (e->cur_max_read_len <= 0 || e->cur_max_read_len > 6144) ? 1 : 0;
 		for (int round = 0;; ++round) {
 			const int32_t *work = lists[round & 1];
 			int32_t *next = lists[(round + 1) & 1];

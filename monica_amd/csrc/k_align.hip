@@ -2150,12 +2150,14 @@ int dp_plan_prepare()
 	if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return MNC_ERR_HIP; }
 	return MNC_OK;
 }
-// `long_reads`: the batch holds reads long enough for PLAN_LONG chained anchors (the caller knows its longest read)
-void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work, bool long_reads, int state_max, long long p_max, int cig_max,
+// `wave_form`: 1 the batch holds reads long enough for PLAN_LONG chained anchors (the caller knows its longest read): their
+// regions go to mnc_dp_plan_long; 2 every region does (a test switch: the wave form on ordinary reads); 0 none
+void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work, int wave_form, int state_max, long long p_max, int cig_max,
                     long long big_state, long long big_p, long long big_cig, long long huge_state, long long huge_p, long long huge_cig, hipStream_t st)
 {
 	if (!max_work) return;
-	hipLaunchKernelGGL(mnc_dp_plan, dim3((max_work + 63) / 64), dim3(64), 0, st, B, work_list, long_reads ? PLAN_LONG : 0,
+	const bool long_reads = wave_form != 0;
+	hipLaunchKernelGGL(mnc_dp_plan, dim3((max_work + 63) / 64), dim3(64), 0, st, B, work_list, wave_form == 2 ? 1 : wave_form == 1 ? PLAN_LONG : 0,
 	                   state_max, p_max, cig_max, big_state, big_p, big_cig, huge_state, huge_p, huge_cig);
 	if (long_reads) {
 		const PlanLimits lim = { state_max, p_max, cig_max, big_state, big_p, big_cig, huge_state, huge_p, huge_cig };

@@ -84,3 +84,7 @@ def test_random_world(capi, oracle, k):
         w["eng"].set_debug(2)                                      # every look-back through HBM
         _compare_batch(capi, oracle, w, bases, offsets, min_mapq=60)
         w["eng"].set_debug(0)
+    # every region planned by the wave form of the plan kernel (mnc_dp_plan_long: on its own only long reads' regions)
+    w["eng"].set_debug(0x10)
+    _compare_batch(capi, oracle, w, bases, offsets, min_mapq=0)
+    w["eng"].set_debug(0)
