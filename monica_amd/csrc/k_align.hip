@@ -9,6 +9,10 @@
 //   mnc_dp_plan     thread / region: trim bad chain ends, flag seeds around long indels, DP window
 //                   from neighbouring seeds, the list of kernel calls ("segments": left extension,
 //                   one gap filling per >= min_ksw_len of seeds, right extension)
+//   mnc_dp_plan_long  wave / region, for the regions of long reads: the same, the passes over all
+//                   anchors as wave-wide steps on a copy of the anchors in LDS
+//   mnc_dp_inv      wave / region tail after an inversion-like Z-drop: mm_align1_inv (local alignment
+//                   of the reverse-complemented query stretch, extension back from its end)
 //   mnc_dp_align    wave / segment from a work queue: ksw2's two-piece affine kernel in its
 //                   anti-diagonal difference form (u, v, x, y, x2, y2 as int8 in LDS, 64 cells per
 //                   step), the exact / approximate maximum, Z-drop, direction bytes to HBM, the
