@@ -58,7 +58,10 @@ def parse():
                          "job of BASELINE config 3 (--total-reads, default 10 M there) split over the ranks, each rank's "
                          "share generated in its HBM by ordinal and classified in blocks of --reads, ONE count all-reduce "
                          "at the end of the job")
-    ap.add_argument("--block", type=int, default=100_000, help="reads per classify call in --mode shard")
+    ap.add_argument("--block", type=int, default=500_000,
+                    help="reads per classify call in --mode shard (a part leaves most reads unmapped and aligns the rest -- many of "
+                         "them against a diverged copy of their genome, with long extensions on single waves: the larger the call, "
+                         "the more work runs beside those; ~200 KB of HBM per read)")
     ap.add_argument("--parts", type=int, default=8, help="index parts in --mode shard")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                                                       "the N > 1 path on a box with fewer GPUs than ranks)")
