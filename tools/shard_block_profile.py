@@ -1,8 +1,8 @@
 """Stage times of ONE block of BASELINE config 4 (python tools/shard_block_profile.py): 100 000 reads drawn from all 500
 genomes classified against one index part of 62 genomes -- three quarters of the reads have no genome in the part."""
-import sys, time
+import os, sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from monica_amd import _capi, synth, dist as mdist
 
 names, seqs = synth.genome_set(500)
