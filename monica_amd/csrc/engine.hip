@@ -1176,7 +1176,10 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 		// reads long enough for 512 chained anchors (a 5 kb read has ~200 a chain): their regions are planned a wave each;
 		// debug bit 0x800000: everything on the lane form (tests)
 		// 0x10: every region on the wave form (tests)
-		const int long_reads = (e->debug & 0x10) ? 2 : !(e->debug & 0x800000) && (e->cur_max_read_len <= 0 || e->cur_max_read_len > 6144) ? 1 : 0;
+		// A micro-batch: every region on the wave form -- a lane's plan is 0.5 ms of dependent loads however few regions there
+		// are, a wave's 45 us, and a few hundred regions are one round of waves (p50 of a 400-read batch 3.9 -> 3.5 ms)
+		const int long_reads = (e->debug & 0x10) ? 2 : (e->debug & 0x800000) ? 0 : n_reads <= 4096 ? 2
+		                     : (e->cur_max_read_len <= 0 || e->cur_max_read_len > 6144) ? 1 : 0;
 		for (int round = 0;; ++round) {
 			const int32_t *work = lists[round & 1];
 			int32_t *next = lists[(round + 1) & 1];

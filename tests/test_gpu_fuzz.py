@@ -84,7 +84,8 @@ def test_random_world(capi, oracle, k):
         w["eng"].set_debug(2)                                      # every look-back through HBM
         _compare_batch(capi, oracle, w, bases, offsets, min_mapq=60)
         w["eng"].set_debug(0)
-    # every region planned by the wave form of the plan kernel (mnc_dp_plan_long: on its own only long reads' regions)
-    w["eng"].set_debug(0x10)
+    # every region planned by the LANE form of the plan kernel (a batch this small takes the wave form, mnc_dp_plan_long,
+    # by itself; large batches use the lane form for all but long reads' regions)
+    w["eng"].set_debug(0x800000)
     _compare_batch(capi, oracle, w, bases, offsets, min_mapq=0)
     w["eng"].set_debug(0)
