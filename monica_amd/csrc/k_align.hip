@@ -955,6 +955,7 @@ __device__ void ksw_wave(int qlen, int tlen, S8 mem, S32 H, PP p, CP cig,
 {
 	constexpr bool LDS = PtrTraits<S8>::lds;
 	typedef typename PtrTraits<S8>::u8 SU8;
+	constexpr int KW = PtrTraits<S8>::lds ? 2 : 4;            // chunks of 64 cells in flight per turn of the per-step loops (state in LDS / in the workspace)
 	const int lane = threadIdx.x;
 	const bool approx_max = (flag & EZ_APPROX_MAX) != 0, right = (flag & EZ_RIGHT) != 0;
 	ez.max = 0, ez.zdropped = 0, ez.max_q = ez.max_t = ez.mqe_t = -1, ez.mqe = ez.score = DP_NEG_INF, ez.reach_end = 0, ez.n_cigar = 0;
@@ -1007,62 +1008,82 @@ __device__ void ksw_wave(int qlen, int tlen, S8 mem, S32 H, PP p, CP cig,
 		{
 			SU8 qrr = qr + (qlen - 1 - r);
 			const int n16 = (en0 - st0) / 16 + 1;
-			for (int c0 = 0; c0 < n16 * 16; c0 += 64) {
-				const int i = c0 + lane;
-				int sc = 0;
-				const bool act = i < n16 * 16;
-				if (act) {
-					const int sq = sf[st0 + i], sq2 = qrr[st0 + i];
-					sc = (sq == 4 || sq2 == 4) ? sc_N : sq == sq2 ? sc_mch : sc_mis;
+			// (KW chunks of 64 cells per turn: a long call is one wave's serial work, and a turn is a round trip to LDS)
+			for (int c0 = 0; c0 < n16 * 16; c0 += 64 * KW) {
+				int sc[KW];
+#pragma unroll
+				for (int k = 0; k < KW; ++k) {
+					const int i = c0 + 64 * k + lane;
+					sc[k] = 0;
+					if (i < n16 * 16) {
+						const int sq = sf[st0 + i], sq2 = qrr[st0 + i];
+						sc[k] = (sq == 4 || sq2 == 4) ? sc_N : sq == sq2 ? sc_mch : sc_mis;
+					}
 				}
 				st_order<LDS>();
-				if (act) s[st0 + i] = (int8_t)sc;
+#pragma unroll
+				for (int k = 0; k < KW; ++k) {
+					const int i = c0 + 64 * k + lane;
+					if (i < n16 * 16) s[st0 + i] = (int8_t)sc[k];
+				}
 			}
 		}
 		st_order<LDS>();
 		// core: chunks of 64 lanes from the top; a chunk reads [t-1] of the chunk below before that is updated
 		PP pr = p + (size_t)r * ncol;
-		for (int c0 = (en - st) / 64 * 64; c0 >= 0; c0 -= 64) {
-			const int t = st + c0 + lane;
-			const bool act = t <= en;
-			int z = 0, xt1 = 0, vt1 = 0, x2t1 = 0, ut = 0, yt = 0, y2t = 0;
-			if (act) {
-				z = s[t];
-				xt1 = t > st ? (int)x[t - 1] : x1;
-				vt1 = t > st ? (int)v[t - 1] : v1;
-				x2t1 = t > st ? (int)x2[t - 1] : x21;
-				ut = u[t], yt = y[t], y2t = y2[t];
+		// (every cell of the anti-diagonal reads old values only -- its own and [t-1] of the cell below -- so KW chunks may
+		// load before any of them stores: the same values as one chunk at a time from the top)
+		for (int c0 = (en - st) / 64 * 64; c0 >= 0; c0 -= 64 * KW) {
+			int z[KW], xt1[KW], vt1[KW], x2t1[KW], ut[KW], yt[KW], y2t[KW];
+#pragma unroll
+			for (int k = 0; k < KW; ++k) {
+				const int t = st + c0 - 64 * k + lane;
+				const bool act = c0 - 64 * k >= 0 && t <= en;
+				z[k] = xt1[k] = vt1[k] = x2t1[k] = ut[k] = yt[k] = y2t[k] = 0;
+				if (act) {
+					z[k] = s[t];
+					xt1[k] = t > st ? (int)x[t - 1] : x1;
+					vt1[k] = t > st ? (int)v[t - 1] : v1;
+					x2t1[k] = t > st ? (int)x2[t - 1] : x21;
+					ut[k] = u[t], yt[k] = y[t], y2t[k] = y2[t];
+				}
 			}
 			st_order<LDS>();
-			if (act) {
-				int a = I8(xt1 + vt1), b = I8(yt + ut), a2 = I8(x2t1 + vt1), b2 = I8(y2t + ut), d, tmp;
-				if (!right) {
-					d = a > z ? 1 : 0;  z = z > a ? z : a;
-					d = b > z ? 2 : d;  z = z > b ? z : b;
-					d = a2 > z ? 3 : d; z = z > a2 ? z : a2;
-					d = b2 > z ? 4 : d; z = z > b2 ? z : b2;
-				} else {
-					d = z > a ? 0 : 1;  z = z > a ? z : a;
-					d = z > b ? d : 2;  z = z > b ? z : b;
-					d = z > a2 ? d : 3; z = z > a2 ? z : a2;
-					d = z > b2 ? d : 4; z = z > b2 ? z : b2;
+#pragma unroll
+			for (int k = 0; k < KW; ++k) {
+				const int t = st + c0 - 64 * k + lane;
+				const bool act = c0 - 64 * k >= 0 && t <= en;
+				if (act) {
+					int zz = z[k];
+					int a = I8(xt1[k] + vt1[k]), b = I8(yt[k] + ut[k]), a2 = I8(x2t1[k] + vt1[k]), b2 = I8(y2t[k] + ut[k]), d, tmp;
+					if (!right) {
+						d = a > zz ? 1 : 0;  zz = zz > a ? zz : a;
+						d = b > zz ? 2 : d;  zz = zz > b ? zz : b;
+						d = a2 > zz ? 3 : d; zz = zz > a2 ? zz : a2;
+						d = b2 > zz ? 4 : d; zz = zz > b2 ? zz : b2;
+					} else {
+						d = zz > a ? 0 : 1;  zz = zz > a ? zz : a;
+						d = zz > b ? d : 2;  zz = zz > b ? zz : b;
+						d = zz > a2 ? d : 3; zz = zz > a2 ? zz : a2;
+						d = zz > b2 ? d : 4; zz = zz > b2 ? zz : b2;
+					}
+					zz = zz < sc_mch ? zz : sc_mch;
+					u[t] = (int8_t)(zz - vt1[k]), v[t] = (int8_t)(zz - ut[k]);
+					tmp = I8(zz - q), a = I8(a - tmp), b = I8(b - tmp);
+					tmp = I8(zz - q2), a2 = I8(a2 - tmp), b2 = I8(b2 - tmp);
+					if (!right) {
+						x[t] = (int8_t)((a > 0 ? a : 0) - qe);          d |= a > 0 ? 0x08 : 0;
+						y[t] = (int8_t)((b > 0 ? b : 0) - qe);          d |= b > 0 ? 0x10 : 0;
+						x2[t] = (int8_t)((a2 > 0 ? a2 : 0) - (q2 + e2)); d |= a2 > 0 ? 0x20 : 0;
+						y2[t] = (int8_t)((b2 > 0 ? b2 : 0) - (q2 + e2)); d |= b2 > 0 ? 0x40 : 0;
+					} else {
+						x[t] = (int8_t)((0 > a ? 0 : a) - qe);          d |= 0 > a ? 0 : 0x08;
+						y[t] = (int8_t)((0 > b ? 0 : b) - qe);          d |= 0 > b ? 0 : 0x10;
+						x2[t] = (int8_t)((0 > a2 ? 0 : a2) - (q2 + e2)); d |= 0 > a2 ? 0 : 0x20;
+						y2[t] = (int8_t)((0 > b2 ? 0 : b2) - (q2 + e2)); d |= 0 > b2 ? 0 : 0x40;
+					}
+					pr[t - st] = (uint8_t)d;
 				}
-				z = z < sc_mch ? z : sc_mch;
-				u[t] = (int8_t)(z - vt1), v[t] = (int8_t)(z - ut);
-				tmp = I8(z - q), a = I8(a - tmp), b = I8(b - tmp);
-				tmp = I8(z - q2), a2 = I8(a2 - tmp), b2 = I8(b2 - tmp);
-				if (!right) {
-					x[t] = (int8_t)((a > 0 ? a : 0) - qe);          d |= a > 0 ? 0x08 : 0;
-					y[t] = (int8_t)((b > 0 ? b : 0) - qe);          d |= b > 0 ? 0x10 : 0;
-					x2[t] = (int8_t)((a2 > 0 ? a2 : 0) - (q2 + e2)); d |= a2 > 0 ? 0x20 : 0;
-					y2[t] = (int8_t)((b2 > 0 ? b2 : 0) - (q2 + e2)); d |= b2 > 0 ? 0x40 : 0;
-				} else {
-					x[t] = (int8_t)((0 > a ? 0 : a) - qe);          d |= 0 > a ? 0 : 0x08;
-					y[t] = (int8_t)((0 > b ? 0 : b) - qe);          d |= 0 > b ? 0 : 0x10;
-					x2[t] = (int8_t)((0 > a2 ? 0 : a2) - (q2 + e2)); d |= 0 > a2 ? 0 : 0x20;
-					y2[t] = (int8_t)((0 > b2 ? 0 : b2) - (q2 + e2)); d |= 0 > b2 ? 0 : 0x40;
-				}
-				pr[t - st] = (uint8_t)d;
 			}
 			st_order<LDS>();
 		}
@@ -1076,14 +1097,23 @@ __device__ void ksw_wave(int qlen, int tlen, S8 mem, S32 H, PP p, CP cig,
 				st_order<LDS>();
 				int best_h = DP_NEG_INF - 1;
 				unsigned best_rank = 0xffffffffu;
-				for (int c0 = 0; c0 < en0 - st0; c0 += 64) {
-					const int t = st0 + c0 + lane;
-					if (t < en0) {
-						const int h = H[t] + (int)v[t];
-						H[t] = h;
-						const unsigned rank = t < en1 ? 1u + ((unsigned)(t - st0) & 3u) * 0x1000000u + ((unsigned)(t - st0) >> 2)
-						                              : 1u + 4u * 0x1000000u + (unsigned)(t - en1);
-						if (h > best_h || (h == best_h && rank < best_rank)) best_h = h, best_rank = rank;
+				for (int c0 = 0; c0 < en0 - st0; c0 += 64 * KW) {
+					int hh[KW];
+#pragma unroll
+					for (int k = 0; k < KW; ++k) {
+						const int t = st0 + c0 + 64 * k + lane;
+						hh[k] = t < en0 ? H[t] + (int)v[t] : 0;
+					}
+#pragma unroll
+					for (int k = 0; k < KW; ++k) {
+						const int t = st0 + c0 + 64 * k + lane;
+						if (t < en0) {
+							const int h = hh[k];
+							H[t] = h;
+							const unsigned rank = t < en1 ? 1u + ((unsigned)(t - st0) & 3u) * 0x1000000u + ((unsigned)(t - st0) >> 2)
+							                              : 1u + 4u * 0x1000000u + (unsigned)(t - en1);
+							if (h > best_h || (h == best_h && rank < best_rank)) best_h = h, best_rank = rank;
+						}
 					}
 				}
 				if (lane == 0) {
