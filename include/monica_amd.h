@@ -214,7 +214,8 @@ int mnc_best_hit(const mnc_hit_t *hits, int n, int *best_index /* -1 = ambiguous
 int mnc_engine_set_profiling(mnc_engine *eng, int on);    /* HIP events around every stage */
 int mnc_engine_set_debug(mnc_engine *eng, int mode);      /* test switches, a bit mask: 2 stress build of the
                                                              chaining ring, 4 displacement bytes read from HBM,
-                                                             0x10 every region planned by mnc_dp_plan_long,
+                                                             0x10 every region planned by mnc_dp_plan_long, 0x20 the
+                                                             literal kernel's long calls on one wave (not four),
                                                              0x10000 the alignment kernels one at a time (per-kernel
                                                              timers), bits 8-15 a tuning value for the tier choice,
                                                              0x20000 / 0x40000 / 0x80000 / 0x100000 without the packed

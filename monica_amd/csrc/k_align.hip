@@ -939,16 +939,65 @@ template <> struct PtrTraits<lds_i8p> { typedef lds_u8p u8; static constexpr boo
 // One call of the kernel on sequences already laid out in `mem` (sf = target codes, qr = the
 // query reversed), exactly as ksw_extd2_sse works on its buffer.  `cig` receives the CIGAR the
 // way ksw_backtrack pushes it (reversed unless EZ_REV_CIGAR asks for that order).
-template <bool LDS>
+template <bool LDS, int NW = 1>
 __device__ __forceinline__ void st_order()
 {
+	if (NW > 1) { __syncthreads(); return; }                  // several waves on one call: they meet (state in the workspace)
 	// state in LDS: its operations execute in issue order within the wave, only the compiler has to
 	// be pinned (the direction bytes stream to HBM without being waited for); state in HBM: wait
 	if (LDS) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); asm volatile("" ::: "memory"); }
 	else mem_order();
 }
 
-template <class S8, class S32, class PP, class CP>
+// reductions and a broadcast over the NW waves of a call (NW == 1: the wave's own)
+template <int NW> __device__ __forceinline__ int wg_max_i32(int v)
+{
+	v = wave_max_i32(v);
+	if (NW > 1) {
+		__shared__ int s_red[16];
+		__syncthreads();
+		if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+		__syncthreads();
+		v = s_red[0];
+#pragma unroll
+		for (int k = 1; k < NW; ++k) v = v > s_red[k] ? v : s_red[k];
+	}
+	return v;
+}
+template <int NW> __device__ __forceinline__ unsigned wg_min_u32(unsigned v)
+{
+	v = wave_min_u32(v);
+	if (NW > 1) {
+		__shared__ unsigned s_redu[16];
+		__syncthreads();
+		if ((threadIdx.x & 63) == 0) s_redu[threadIdx.x >> 6] = v;
+		__syncthreads();
+		v = s_redu[0];
+#pragma unroll
+		for (int k = 1; k < NW; ++k) v = v < s_redu[k] ? v : s_redu[k];
+	}
+	return v;
+}
+template <int NW> __device__ __forceinline__ unsigned long long wg_bcast0_u64(unsigned long long v)
+{
+	if (NW == 1) return (unsigned long long)__shfl((long long)v, 0);
+	__shared__ unsigned long long s_bc64;
+	__syncthreads();
+	if (threadIdx.x == 0) s_bc64 = v;
+	__syncthreads();
+	return s_bc64;
+}
+template <int NW> __device__ __forceinline__ int wg_bcast0(int v)
+{
+	if (NW == 1) return __shfl(v, 0);
+	__shared__ int s_bc;
+	__syncthreads();
+	if (threadIdx.x == 0) s_bc = v;
+	__syncthreads();
+	return s_bc;
+}
+
+template <int NW, class S8, class S32, class PP, class CP>
 __device__ void ksw_wave(int qlen, int tlen, S8 mem, S32 H, PP p, CP cig,
                          int q, int e, int q2, int e2, int sc_mch, int sc_mis, int sc_N,
                          int w, int zdrop, int end_bonus, int flag, Ez &ez)
@@ -956,7 +1005,10 @@ __device__ void ksw_wave(int qlen, int tlen, S8 mem, S32 H, PP p, CP cig,
 	constexpr bool LDS = PtrTraits<S8>::lds;
 	typedef typename PtrTraits<S8>::u8 SU8;
 	constexpr int KW = PtrTraits<S8>::lds ? 2 : 4;            // chunks of 64 cells in flight per turn of the per-step loops (state in LDS / in the workspace)
+	// NW waves share the call (NW > 1: state in the workspace only; `lane` is then the index in the workgroup, a "chunk" 64 NW cells)
+	constexpr int CH = 64 * NW;
 	const int lane = threadIdx.x;
+	static_assert(NW == 1 || !LDS, "several waves per call: the workspace layout only");
 	const bool approx_max = (flag & EZ_APPROX_MAX) != 0, right = (flag & EZ_RIGHT) != 0;
 	ez.max = 0, ez.zdropped = 0, ez.max_q = ez.max_t = ez.mqe_t = -1, ez.mqe = ez.score = DP_NEG_INF, ez.reach_end = 0, ez.n_cigar = 0;
 	const int qe = q + e;
@@ -974,11 +1026,11 @@ __device__ void ksw_wave(int qlen, int tlen, S8 mem, S32 H, PP p, CP cig,
 	SU8 sf = (SU8)(s + T), qr = sf + T;
 	(void)qlen_;
 	// u, v, x, y = -q - e ; x2, y2 = -q2 - e2 ; s = 0 ; H = -inf  (sf / qr were filled by the caller)
-	for (int i = lane; i < 4 * T; i += 64) u[i] = (int8_t)(-q - e);
-	for (int i = lane; i < 2 * T; i += 64) x2[i] = (int8_t)(-q2 - e2);
-	for (int i = lane; i < T; i += 64) s[i] = 0;
-	if (!approx_max) for (int i = lane; i < T; i += 64) H[i] = DP_NEG_INF;
-	st_order<LDS>();
+	for (int i = lane; i < 4 * T; i += CH) u[i] = (int8_t)(-q - e);
+	for (int i = lane; i < 2 * T; i += CH) x2[i] = (int8_t)(-q2 - e2);
+	for (int i = lane; i < T; i += CH) s[i] = 0;
+	if (!approx_max) for (int i = lane; i < T; i += CH) H[i] = DP_NEG_INF;
+	st_order<LDS, NW>();
 
 	int last_st = -1, last_en = -1, H0 = 0, last_H0_t = 0;
 	const int n_r = qlen + tlen - 1;
@@ -999,7 +1051,7 @@ __device__ void ksw_wave(int qlen, int tlen, S8 mem, S32 H, PP p, CP cig,
 			x1 = -q - e, x21 = -q2 - e2;
 			v1 = r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
 		}
-		st_order<LDS>();
+		st_order<LDS, NW>();
 		if (en >= r && lane == 0) {
 			y[r] = (int8_t)(-q - e), y2[r] = (int8_t)(-q2 - e2);
 			u[r] = (int8_t)(r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2);
@@ -1009,36 +1061,36 @@ __device__ void ksw_wave(int qlen, int tlen, S8 mem, S32 H, PP p, CP cig,
 			SU8 qrr = qr + (qlen - 1 - r);
 			const int n16 = (en0 - st0) / 16 + 1;
 			// (KW chunks of 64 cells per turn: a long call is one wave's serial work, and a turn is a round trip to LDS)
-			for (int c0 = 0; c0 < n16 * 16; c0 += 64 * KW) {
+			for (int c0 = 0; c0 < n16 * 16; c0 += CH * KW) {
 				int sc[KW];
 #pragma unroll
 				for (int k = 0; k < KW; ++k) {
-					const int i = c0 + 64 * k + lane;
+					const int i = c0 + CH * k + lane;
 					sc[k] = 0;
 					if (i < n16 * 16) {
 						const int sq = sf[st0 + i], sq2 = qrr[st0 + i];
 						sc[k] = (sq == 4 || sq2 == 4) ? sc_N : sq == sq2 ? sc_mch : sc_mis;
 					}
 				}
-				st_order<LDS>();
+				st_order<LDS, NW>();
 #pragma unroll
 				for (int k = 0; k < KW; ++k) {
-					const int i = c0 + 64 * k + lane;
+					const int i = c0 + CH * k + lane;
 					if (i < n16 * 16) s[st0 + i] = (int8_t)sc[k];
 				}
 			}
 		}
-		st_order<LDS>();
+		st_order<LDS, NW>();
 		// core: chunks of 64 lanes from the top; a chunk reads [t-1] of the chunk below before that is updated
 		PP pr = p + (size_t)r * ncol;
 		// (every cell of the anti-diagonal reads old values only -- its own and [t-1] of the cell below -- so KW chunks may
 		// load before any of them stores: the same values as one chunk at a time from the top)
-		for (int c0 = (en - st) / 64 * 64; c0 >= 0; c0 -= 64 * KW) {
+		for (int c0 = (en - st) / CH * CH; c0 >= 0; c0 -= CH * KW) {
 			int z[KW], xt1[KW], vt1[KW], x2t1[KW], ut[KW], yt[KW], y2t[KW];
 #pragma unroll
 			for (int k = 0; k < KW; ++k) {
-				const int t = st + c0 - 64 * k + lane;
-				const bool act = c0 - 64 * k >= 0 && t <= en;
+				const int t = st + c0 - CH * k + lane;
+				const bool act = c0 - CH * k >= 0 && t <= en;
 				z[k] = xt1[k] = vt1[k] = x2t1[k] = ut[k] = yt[k] = y2t[k] = 0;
 				if (act) {
 					z[k] = s[t];
@@ -1048,11 +1100,11 @@ __device__ void ksw_wave(int qlen, int tlen, S8 mem, S32 H, PP p, CP cig,
 					ut[k] = u[t], yt[k] = y[t], y2t[k] = y2[t];
 				}
 			}
-			st_order<LDS>();
+			st_order<LDS, NW>();
 #pragma unroll
 			for (int k = 0; k < KW; ++k) {
-				const int t = st + c0 - 64 * k + lane;
-				const bool act = c0 - 64 * k >= 0 && t <= en;
+				const int t = st + c0 - CH * k + lane;
+				const bool act = c0 - CH * k >= 0 && t <= en;
 				if (act) {
 					int zz = z[k];
 					int a = I8(xt1[k] + vt1[k]), b = I8(yt[k] + ut[k]), a2 = I8(x2t1[k] + vt1[k]), b2 = I8(y2t[k] + ut[k]), d, tmp;
@@ -1085,7 +1137,7 @@ __device__ void ksw_wave(int qlen, int tlen, S8 mem, S32 H, PP p, CP cig,
 					pr[t - st] = (uint8_t)d;
 				}
 			}
-			st_order<LDS>();
+			st_order<LDS, NW>();
 		}
 		if (!approx_max) {
 			int max_H, max_t;
@@ -1094,19 +1146,19 @@ __device__ void ksw_wave(int qlen, int tlen, S8 mem, S32 H, PP p, CP cig,
 				// the SSE scan's tie order: en0, four interleaved lanes over [st0, en1), the tail [en1, en0)
 				const int en1 = st0 + (en0 - st0) / 4 * 4;
 				const int h_en0 = en0 > 0 ? H[en0 - 1] + (int)u[en0] : H[en0] + (int)v[en0];
-				st_order<LDS>();
+				st_order<LDS, NW>();
 				int best_h = DP_NEG_INF - 1;
 				unsigned best_rank = 0xffffffffu;
-				for (int c0 = 0; c0 < en0 - st0; c0 += 64 * KW) {
+				for (int c0 = 0; c0 < en0 - st0; c0 += CH * KW) {
 					int hh[KW];
 #pragma unroll
 					for (int k = 0; k < KW; ++k) {
-						const int t = st0 + c0 + 64 * k + lane;
+						const int t = st0 + c0 + CH * k + lane;
 						hh[k] = t < en0 ? H[t] + (int)v[t] : 0;
 					}
 #pragma unroll
 					for (int k = 0; k < KW; ++k) {
-						const int t = st0 + c0 + 64 * k + lane;
+						const int t = st0 + c0 + CH * k + lane;
 						if (t < en0) {
 							const int h = hh[k];
 							H[t] = h;
@@ -1120,16 +1172,16 @@ __device__ void ksw_wave(int qlen, int tlen, S8 mem, S32 H, PP p, CP cig,
 					H[en0] = h_en0;
 					if (h_en0 > best_h || (h_en0 == best_h)) best_h = h_en0, best_rank = 0;   // en0 comes first in the scan
 				}
-				const int mh = wave_max_i32(best_h);
-				const unsigned mr = wave_min_u32(best_h == mh ? best_rank : 0xffffffffu);
+				const int mh = wg_max_i32<NW>(best_h);
+				const unsigned mr = wg_min_u32<NW>(best_h == mh ? best_rank : 0xffffffffu);
 				max_H = mh;
 				if (mr == 0) max_t = en0;
 				else if (mr < 1u + 4u * 0x1000000u) { const unsigned k = mr - 1u; max_t = st0 + (int)((k & 0xffffffu) * 4u + (k >> 24)); }
 				else max_t = en1 + (int)(mr - 1u - 4u * 0x1000000u);
-				st_order<LDS>();
+				st_order<LDS, NW>();
 			} else {
 				if (lane == 0) H[0] = (int)v[0] - qe;
-				st_order<LDS>();
+				st_order<LDS, NW>();
 				max_H = H[0], max_t = 0;
 			}
 			if (r - st0 == qlen - 1 && H[st0] > ez.mqe) ez.mqe = H[st0], ez.mqe_t = st0;
@@ -1151,7 +1203,7 @@ __device__ void ksw_wave(int qlen, int tlen, S8 mem, S32 H, PP p, CP cig,
 		}
 		last_st = st, last_en = en;
 	}
-	mem_order();                                            // the direction bytes have to be in memory before the walk reads them
+	st_order<false, NW>();                                  // the direction bytes have to be in memory before the walk reads them
 	// ---- backtrack (ksw_backtrack, rotated layout): one lane walks, all lanes prefetch nothing yet
 	int i0 = -1, j0 = -1;
 	if (!ez.zdropped && !(flag & EZ_EXTZ_ONLY)) i0 = tlen - 1, j0 = qlen - 1;
@@ -1191,8 +1243,8 @@ __device__ void ksw_wave(int qlen, int tlen, S8 mem, S32 H, PP p, CP cig,
 		if (!(flag & EZ_REV_CIGAR))
 			for (int k = 0; k < n_cigar >> 1; ++k) { const uint32_t t2 = cig[k]; cig[k] = cig[n_cigar - 1 - k], cig[n_cigar - 1 - k] = t2; }
 	}
-	ez.n_cigar = __shfl(n_cigar, 0);
-	mem_order();
+	ez.n_cigar = wg_bcast0<NW>(n_cigar);
+	st_order<false, NW>();
 }
 
 // mm_test_zdrop on a finished gap-filling CIGAR: 0 fine, 1 the score drops by more than zdrop, 2 and
@@ -1274,7 +1326,10 @@ __host__ __device__ __forceinline__ AlignWs align_ws(long long state_max, long l
 // LDS of a workgroup: [state: lds_bytes | direction bytes: lds_p | CIGAR: lds_cig words].  Pass 0 runs
 // with a small all-in-LDS layout (many workgroups per CU: the kernel is a chain of LDS round
 // trips, only other waves hide them) and hands what does not fit to pass 2's list.
-__global__ __launch_bounds__(64) void mnc_dp_align(Batch B, uint8_t *ws_all, long long state_max, long long p_max, long long cig_max,
+// NW: waves per call.  The launches for the long calls (the workspace layouts) put four waves on one: a call of 1 500 x
+// 3 000 bases is 4 500 anti-diagonals of up to 751 cells, 27 ms on a single wave that a batch of divergent reads waits for.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void mnc_dp_align(Batch B, uint8_t *ws_all, long long state_max, long long p_max, long long cig_max,
                                                    int lds_bytes, int lds_p, int lds_cig, int big_pass)
 {
 	extern __shared__ __align__(16) uint8_t smem[];
@@ -1291,7 +1346,7 @@ __global__ __launch_bounds__(64) void mnc_dp_align(Batch B, uint8_t *ws_all, lon
 	for (;;) {
 		unsigned long long qi = 0;
 		if (lane == 0) qi = atomicAdd(&B.dp_ctr[ctr_q], 1ULL);
-		qi = (unsigned long long)__shfl((long long)qi, 0);
+		qi = wg_bcast0_u64<NW>(qi);
 		if (qi >= n_items) break;                              // every wave reaches this: the queue is finite
 		const long long si = big_pass == 0 ? (long long)B.gen_list[qi] : big_pass == 1 ? (long long)B.big_list[qi] : big_pass == 3 ? (long long)B.mid_list[qi] : big_pass == 4 ? (long long)B.bigfb_list[qi] : big_pass == 5 ? (long long)B.huge_list[qi] : (long long)B.fill_fb[qi];
 		Seg g = B.segs[si];
@@ -1328,41 +1383,46 @@ __global__ __launch_bounds__(64) void mnc_dp_align(Batch B, uint8_t *ws_all, lon
 				typedef typename PtrTraits<decltype(mem)>::u8 SU8;
 				SU8 sf = (SU8)(mem + 7 * (size_t)T), qr = sf + T;
 				// target / reversed query; the left extension runs on both sequences reversed
-				for (int i = lane; i < T; i += 64) sf[i] = i < g.tlen ? (uint8_t)tcode(B, coff, g.kind == 0 ? g.ts + g.tlen - 1 - i : g.ts + i) : 0;
-				for (int i = lane; i < Q; i += 64)
+				for (int i = lane; i < T; i += 64 * NW) sf[i] = i < g.tlen ? (uint8_t)tcode(B, coff, g.kind == 0 ? g.ts + g.tlen - 1 - i : g.ts + i) : 0;
+				for (int i = lane; i < Q; i += 64 * NW)
 					qr[i] = i < g.qlen ? (uint8_t)qcode(read, rlen, g.rev, g.kind == 0 ? g.qs + i : g.qs + g.qlen - 1 - i) : 0;
-				mem_order();
-				ksw_wave(g.qlen, g.tlen, mem, H, pbuf, cg, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, sc_N,
+				st_order<false, NW>();
+				ksw_wave<NW>(g.qlen, g.tlen, mem, H, pbuf, cg, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, sc_N,
 				         g.w, g.zdrop, g.kind == 1 ? -1 : B.end_bonus, g.flag, ez);
 				if (g.kind == 1) {
 					// the kernel's last 16-lane score store may spill into the first 15 target bytes (as in the
 					// SSE buffer, where those are dead by then): restore them for the walk and the second pass
 					if (lane < 16) sf[lane] = lane < g.tlen ? (uint8_t)tcode(B, coff, g.ts + lane) : 0;
-					mem_order();
+					st_order<false, NW>();
 					if (lane == 0) zdrop_code = test_zdrop_lane0(B, g.qlen, g.tlen, sf, qr, ez.n_cigar, cg, sc_mch, sc_mis, sc_N,
 					                                              reinterpret_cast<int32_t*>(ws + W.sw), reinterpret_cast<int32_t*>(ws + W.sw) + cig_max);
-					zdrop_code = __shfl(zdrop_code, 0);
+					zdrop_code = wg_bcast0<NW>(zdrop_code);
 					if (zdrop_code != 0)                             // second pass: exact maximum, real Z-drop
-						ksw_wave(g.qlen, g.tlen, mem, H, pbuf, cg, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, sc_N,
+						ksw_wave<NW>(g.qlen, g.tlen, mem, H, pbuf, cg, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, sc_N,
 						         g.w, zdrop_code == 2 ? B.zdrop_inv : B.zdrop, -1, 0, ez);
 				}
 				// the CIGAR goes to the segment pool
 				if (lane == 0 && ez.n_cigar > 0) off = atomicAdd(&B.dp_ctr[1], (unsigned long long)ez.n_cigar);
-				off = (unsigned long long)__shfl((long long)off, 0);
+				off = wg_bcast0_u64<NW>(off);
 				if (ez.n_cigar > 0) {
 					if ((long long)(off + ez.n_cigar) > B.cig_seg_cap) {
 						if (lane == 0) atomicMax(&B.dp_ctr[4], 2ULL);
 						ez.n_cigar = 0;
-					} else for (int k = lane; k < ez.n_cigar; k += 64) B.cig_seg[off + k] = cg[k];
+					} else for (int k = lane; k < ez.n_cigar; k += 64 * NW) B.cig_seg[off + k] = cg[k];
 				}
 			};
 			const size_t h_off = (size_t)(8 * T + Q + 15) / 16 * 16;
-			if (all_lds)
-				run((lds_i8p)smem, (lds_i32p)(smem + h_off), (lds_u8p)(smem + lds_bytes), (lds_u32p)(smem + lds_bytes + lds_p));
-			else if (in_lds)
-				run((lds_i8p)smem, (lds_i32p)(smem + h_off), ws + W.p, reinterpret_cast<uint32_t*>(ws + W.cig));
-			else
+			if constexpr (NW == 1) {
+				if (all_lds)
+					run((lds_i8p)smem, (lds_i32p)(smem + h_off), (lds_u8p)(smem + lds_bytes), (lds_u32p)(smem + lds_bytes + lds_p));
+				else if (in_lds)
+					run((lds_i8p)smem, (lds_i32p)(smem + h_off), ws + W.p, reinterpret_cast<uint32_t*>(ws + W.cig));
+				else
+					run(reinterpret_cast<int8_t*>(ws + W.state), reinterpret_cast<int32_t*>(ws + W.h), ws + W.p, reinterpret_cast<uint32_t*>(ws + W.cig));
+			} else {
+				(void)h_off;
 				run(reinterpret_cast<int8_t*>(ws + W.state), reinterpret_cast<int32_t*>(ws + W.h), ws + W.p, reinterpret_cast<uint32_t*>(ws + W.cig));
+			}
 		}
 		if (lane == 0) {
 			Seg *o = B.segs + si;
@@ -1370,7 +1430,7 @@ __global__ __launch_bounds__(64) void mnc_dp_align(Batch B, uint8_t *ws_all, lon
 			o->max = ez.max, o->max_t = ez.max_t, o->max_q = ez.max_q, o->score = ez.score, o->reach_end = ez.reach_end, o->mqe_t = ez.mqe_t;
 			o->cig_off = (int64_t)off;
 		}
-		mem_order();
+		st_order<false, NW>();
 	}
 }
 
@@ -2202,15 +2262,19 @@ void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work,
 size_t dp_align_ws_bytes(long long state_max, long long p_max, long long cig_max) { return align_ws(state_max, p_max, cig_max).total; }
 int dp_align_prepare(int lds_bytes)
 {
-	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
 	if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return MNC_ERR_HIP; }
 	return MNC_OK;
 }
 void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max, long long p_max, long long cig_max,
                      int lds_state, int lds_p, int lds_cig, int big_pass, hipStream_t st)
 {
-	hipLaunchKernelGGL(mnc_dp_align, dim3(n_wg), dim3(64), (size_t)lds_state + lds_p + lds_cig * 4, st, B, ws, state_max, p_max, cig_max,
-	                   lds_state, lds_p, lds_cig, big_pass);
+	// the long calls (passes 1, 3, 4, 5: state in the workspace) on four waves each; debug_route bit 5: one wave, as the rest
+	if ((big_pass == 1 || big_pass >= 3) && !(B.debug_route & 32))
+		hipLaunchKernelGGL(mnc_dp_align<4>, dim3(n_wg), dim3(256), 0, st, B, ws, state_max, p_max, cig_max, 0, 0, 0, big_pass);
+	else
+		hipLaunchKernelGGL(mnc_dp_align<1>, dim3(n_wg), dim3(64), (size_t)lds_state + lds_p + lds_cig * 4, st, B, ws, state_max, p_max, cig_max,
+		                   lds_state, lds_p, lds_cig, big_pass);
 }
 void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_list, int max_read_len, int n_wg, hipStream_t st)
 {
