@@ -76,8 +76,54 @@ def parse():
     return ap.parse_args()
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` alone (no WORLD_SIZE in the environment): start the N ranks as a CHILD
+    `python -m torch.distributed.run` job, pass its output through and exit with its code.  This parent
+    never touches the GPU (no torch import, no HIP call) and never execs: the child processes own the devices."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                       # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    last_json = None
+    for line in proc.stdout:                         # rank 0 prints ONE JSON line; anything else goes to stderr untouched
+        if line.lstrip().startswith("{"):
+            last_json = line
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if last_json is not None:
+        sys.stdout.write(last_json)
+        sys.stdout.flush()
+    sys.exit(rc)
+
+
+def rank_report(world, backend, reads_done, dev):
+    """What the collective backend saw, for the JSON line: the size of the process group the count all-reduce ran on
+    (`rccl_ranks`: ranks of the RCCL communicator when the backend is nccl) and the reads every rank classified in
+    the timed region (gathered over that same group) -- "did RCCL see N ranks" is answerable from the record."""
+    import torch
+    import torch.distributed as dist
+    if world <= 1:
+        return {"backend": None, "group_ranks": 1, "rccl_ranks": None, "reads_per_rank": [int(reads_done)]}
+    mine = torch.tensor([int(reads_done)], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+    got = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    n = dist.get_world_size()
+    return {"backend": dist.get_backend(), "group_ranks": n, "rccl_ranks": n if dist.get_backend() == "nccl" else 0,
+            "reads_per_rank": [int(g.item()) for g in got]}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -230,6 +276,7 @@ def main():
         engine.set_debug(base_debug | (0x10000 if os.environ.get("MNC_DP_SERIAL") else 0))
         dp_kernel_ms = {k: tk[k][0] / max(tk[k][1], 1) for k in ("dp_fill_t1", "dp_fill_tm", "dp_fill_t2", "dp_fill_t3", "dp_lfill", "dp_ext", "dp_stitch") if k in tk}
 
+    ranks = rank_report(world, args.backend, args.reads * args.steps, dev)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -352,10 +399,18 @@ def main():
             if args.cpu_sample > 0 or dt >= 10.0 or reps >= 50:
                 break
         agree = bool(np.array_equal(oa, assign[:n_s]))
+        # SURVEY 8(d) also asks for the 1-core figure: the same oracle, one thread, a smaller slice of the same sample
+        n_1 = max(1, min(n_s, 500 if args.contract == "dp" else 20_000))
+        tc = time.perf_counter()
+        o1, _, _, _ = oidx.classify(bases[: n_1 * args.read_len], offsets[: n_1 + 1], args.min_mapq, n_threads=1)
+        dt1 = time.perf_counter() - tc
+        one_core = {"value": round(n_1 / dt1, 1), "unit": "reads/s", "cores": 1,
+                    "sample": f"first {n_1} reads of the same batch, one pass, one thread, {dt1:.1f} s",
+                    "agrees_with_gpu": bool(np.array_equal(o1, assign[:n_1]))}
         cpu = {"value": round(n_s * reps / dt, 1), "unit": "reads/s", "cores": cores, "kind": "port",
                "sample": f"first {n_s} reads of the same batch x {reps} passes, CPU oracle (minimap2-2.17 restatement "
                          f"{'with base-level alignment, scalar ksw2 simulation' if args.contract == 'dp' else 'at the chain level'}"
-                         f", OpenMP over reads), {dt:.1f} s", "agrees_with_gpu": agree}
+                         f", OpenMP over reads), {dt:.1f} s", "agrees_with_gpu": agree, "one_core": one_core}
 
     # the PCIe-inclusive rate (never `value`): fresh batches from page-locked host memory through the
     # host-buffer entry point -- H2D of the bases, all kernels, D2H of the decisions
@@ -432,6 +487,9 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "timed_region_s": round(elapsed, 4),
+        "rccl_ranks": ranks["rccl_ranks"] if comm is None else comm.count(),
+        "ranks": ranks,
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
@@ -574,12 +632,14 @@ def shard_mode(args, names, seqs, rank, local_rank, world, dev):
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     assign = result["assign"].cpu().numpy()
+    ranks = rank_report(world, args.backend, n * len(parts) * args.steps, dev)
     if rank == 0:
         ok = truth >= 0
         print(json.dumps({
             "metric": "reads/sec classified, index sharded (BASELINE config 4)", "value": round(n * args.steps / elapsed, 1),
             "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "timed_region_s": round(elapsed, 4),
+            "rccl_ranks": ranks["rccl_ranks"], "ranks": ranks, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32/u64 integer", "data": "synthetic",
             "config": {"workload": f"{n} synthetic {args.read_len} nt reads vs {G} genomes "
                                    f"({sum(len(s) for s in seqs)} bp) in {P} index parts, {P // world} per GPU; "
@@ -661,12 +721,14 @@ def config3_mode(args, names, seqs, rank, local_rank, world, dev):
                          dtype=torch.int64, device=dev)
     if world > 1:
         dist.all_reduce(local)
+    ranks = rank_report(world, args.backend, n * args.steps, dev)
     if rank == 0:
         mp, ok, bad = (int(x) for x in local.cpu())
         print(json.dumps({
             "metric": "reads/sec classified, 10 M-read job (BASELINE config 3)", "value": round(total * args.steps / elapsed, 1),
             "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "timed_region_s": round(elapsed, 4),
+            "rccl_ranks": ranks["rccl_ranks"], "ranks": ranks, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u32/u64 integer; int16 pairs in the alignment kernels", "data": "synthetic",
             "config": {"workload": f"{total} synthetic {L} nt reads in all ({n} on rank 0, blocks of {blk}) vs {args.genomes}-genome "
                                    f"minimizer index ({info.total_len} bp)", "contract": args.contract,

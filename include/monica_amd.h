@@ -352,6 +352,7 @@ const char *mnc_hitmap_name(const mnc_hitmap *hm, int id);
 int mnc_comm_unique_id(void *id128);
 int mnc_comm_init_rank(const void *id128, int n_ranks, int rank, void **comm);
 int mnc_comm_destroy(void *comm);
+int mnc_comm_count(void *comm, int *n_ranks);   /* ncclCommCount: the ranks the communicator really spans */
 int mnc_allreduce_counts(int64_t *d_counts, int n, void *comm, void *stream);
 int mnc_allgather_summaries(const void *d_send, void *d_recv, size_t bytes_per_rank, void *comm, void *stream);
 

@@ -53,7 +53,7 @@ EXPORTS = [
     "mnc_classify_batch", "mnc_engine_prefetch", "mnc_classify_device", "mnc_engine_sync", "mnc_engine_fetch_hits",
     "mnc_counts", "mnc_best_hit",
     "mnc_engine_set_profiling", "mnc_engine_set_debug", "mnc_engine_set_contract", "mnc_index_set_host_tables", "mnc_index_set_region_bits", "mnc_engine_dump_tables",
-    "mnc_comm_unique_id", "mnc_comm_init_rank", "mnc_comm_destroy", "mnc_allreduce_counts", "mnc_allgather_summaries", "mnc_engine_get_timings", "mnc_stage_name", "mnc_stage_kernel",
+    "mnc_comm_unique_id", "mnc_comm_init_rank", "mnc_comm_destroy", "mnc_comm_count", "mnc_allreduce_counts", "mnc_allgather_summaries", "mnc_engine_get_timings", "mnc_stage_name", "mnc_stage_kernel",
     "mnc_engine_get_counters", "mnc_engine_dump",
     "mnc_fastq_open", "mnc_fastq_close", "mnc_fastq_next", "mnc_fastq_detach_batch", "mnc_fastq_remaining", "mnc_fastq_bases", "mnc_fastq_offsets",
     "mnc_fastq_quals", "mnc_fastq_title", "mnc_fastq_route",
@@ -146,6 +146,7 @@ def lib():
     sig("mnc_comm_unique_id", i32, [vp])
     sig("mnc_comm_init_rank", i32, [vp, i32, i32, C.POINTER(vp)])
     sig("mnc_comm_destroy", i32, [vp])
+    sig("mnc_comm_count", i32, [vp, C.POINTER(i32)])
     sig("mnc_allreduce_counts", i32, [vp, i32, vp, vp])
     sig("mnc_allgather_summaries", i32, [vp, vp, C.c_size_t, vp, vp])
     sig("mnc_engine_get_timings", i32, [vp, vp, vp, i32])
@@ -207,6 +208,12 @@ class Comm:
         buf = (C.c_char * 128)()
         check(lib().mnc_comm_unique_id(buf))
         return bytes(buf)
+
+    def count(self):
+        """ncclCommCount: the number of ranks RCCL itself reports for this communicator."""
+        n = C.c_int32(0)
+        check(lib().mnc_comm_count(self._h, C.byref(n)))
+        return int(n.value)
 
     def allreduce_counts(self, d_counts_ptr, n, stream=None):
         check(lib().mnc_allreduce_counts(C.c_void_p(d_counts_ptr), int(n), self._h, C.c_void_p(stream or 0)))

@@ -27,6 +27,7 @@ struct Rccl {
 	int (*GetUniqueId)(UniqueId*) = nullptr;
 	int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
 	int (*CommDestroy)(void*) = nullptr;
+	int (*CommCount)(const void*, int*) = nullptr;
 	int (*AllReduce)(const void*, void*, size_t, int, int, void*, void*) = nullptr;
 	int (*AllGather)(const void*, void*, size_t, int, void*, void*) = nullptr;
 	const char *(*GetErrorString)(int) = nullptr;
@@ -51,6 +52,7 @@ Rccl &rccl()
 		r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
 		r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
 		r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+		r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.lib, "ncclCommCount"));
 		r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
 		r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
 		r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
@@ -103,6 +105,14 @@ extern "C" int mnc_comm_destroy(void *comm)
 	if (!comm) return MNC_OK;
 	if (int rc = need_rccl()) return rc;
 	return check(rccl().CommDestroy(comm), "ncclCommDestroy");
+}
+
+extern "C" int mnc_comm_count(void *comm, int *n_ranks)
+{
+	if (!comm || !n_ranks) return MNC_ERR_ARG;
+	if (int rc = need_rccl()) return rc;
+	if (!rccl().CommCount) { mnc::set_error("librccl.so has no ncclCommCount"); return MNC_ERR_UNSUPPORTED; }
+	return check(rccl().CommCount(comm, n_ranks), "ncclCommCount");
 }
 
 extern "C" int mnc_allreduce_counts(int64_t *d_counts, int n, void *comm, void *stream)
