@@ -133,6 +133,7 @@ void mnc_engine_destroy(mnc_engine *eng);
  * parts of a database (aligner.py:91-103).  Same k / w / match score as the index the engine was made for. */
 int  mnc_engine_set_index(mnc_engine *eng, mnc_index *idx);
 void *mnc_engine_stream(mnc_engine *eng);                              /* hipStream_t */
+int  mnc_index_device_bytes(const mnc_index *idx, int device, int64_t *bytes); /* HBM the index holds on that one device */
 int  mnc_engine_device_bytes(mnc_engine *eng, int64_t *bytes);         /* HBM held by the engine's own batch buffers */
 
 /* ---------------------------------------------------------------- classify
@@ -161,6 +162,10 @@ int mnc_classify_batch(mnc_engine *eng, const uint8_t *bases, const int64_t *off
  * prefetched batch is still waiting for its call (one spare buffer): nothing was done.  Thread-safe against the
  * engine's classifying thread. */
 int mnc_engine_prefetch(mnc_engine *eng, const uint8_t *bases, const int64_t *offsets, uint32_t n_reads, int *started);
+/* Forget the batch announced last, if any (waits for its copy; the host arrays are the caller's again).  For a caller
+ * that gives up on an announced batch -- an error in its loop (the reference's loop simply raises, aligner.py:212-215),
+ * an engine handed to another sample: the announcement is matched by host address, so it must not outlive its arrays. */
+int mnc_engine_prefetch_cancel(mnc_engine *eng);
 
 /* Same, all buffers device-resident (HBM), asynchronous on the engine's stream.
  * total_bases = offsets[n_reads].  d_counts (may be NULL) is an int64[n_genomes*3] table

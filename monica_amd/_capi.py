@@ -49,8 +49,8 @@ EXPORTS = [
     "mnc_index_build", "mnc_index_build_mem", "mnc_index_build_device", "mnc_index_build_mem_device", "mnc_index_save", "mnc_index_save_mmi", "mnc_index_load", "mnc_index_free",
     "mnc_index_info", "mnc_index_contig_name", "mnc_index_contig_len", "mnc_index_contig_genome",
     "mnc_index_genome_name", "mnc_index_genome_len", "mnc_index_dump", "mnc_index_set_mid_occ",
-    "mnc_engine_create", "mnc_engine_destroy", "mnc_engine_stream", "mnc_engine_device_bytes", "mnc_engine_set_index",
-    "mnc_classify_batch", "mnc_engine_prefetch", "mnc_classify_device", "mnc_engine_sync", "mnc_engine_fetch_hits",
+    "mnc_engine_create", "mnc_engine_destroy", "mnc_engine_stream", "mnc_engine_device_bytes", "mnc_index_device_bytes", "mnc_engine_set_index",
+    "mnc_classify_batch", "mnc_engine_prefetch", "mnc_engine_prefetch_cancel", "mnc_classify_device", "mnc_engine_sync", "mnc_engine_fetch_hits",
     "mnc_counts", "mnc_best_hit",
     "mnc_engine_set_profiling", "mnc_engine_set_debug", "mnc_engine_set_contract", "mnc_index_set_host_tables", "mnc_index_set_region_bits", "mnc_engine_dump_tables",
     "mnc_comm_unique_id", "mnc_comm_init_rank", "mnc_comm_destroy", "mnc_comm_count", "mnc_allreduce_counts", "mnc_allgather_summaries", "mnc_engine_get_timings", "mnc_stage_name", "mnc_stage_kernel",
@@ -129,8 +129,10 @@ def lib():
     sig("mnc_engine_destroy", None, [vp])
     sig("mnc_engine_stream", vp, [vp])
     sig("mnc_engine_prefetch", i32, [vp, vp, vp, u32, C.POINTER(C.c_int)])
+    sig("mnc_engine_prefetch_cancel", i32, [vp])
     sig("mnc_engine_set_index", i32, [vp, vp])
     sig("mnc_engine_device_bytes", i32, [vp, C.POINTER(C.c_int64)])
+    sig("mnc_index_device_bytes", i32, [vp, i32, C.POINTER(C.c_int64)])
     sig("mnc_classify_batch", i32, [vp, vp, vp, u32, i32, vp, vp, vp])
     sig("mnc_classify_device", i32, [vp, vp, vp, u32, i64, i32, i32, vp, vp, vp, vp])
     sig("mnc_engine_sync", i32, [vp])
@@ -316,6 +318,12 @@ class Index:
         check(lib().mnc_index_info(self._h, C.byref(info)))
         return info
 
+    def device_bytes(self, device):
+        """HBM this index holds on one device (info().device_bytes sums over all devices)."""
+        n = C.c_int64(0)
+        check(lib().mnc_index_device_bytes(self._h, int(device), C.byref(n)))
+        return int(n.value)
+
     @property
     def mid_occ(self):
         return self.info().mid_occ
@@ -400,6 +408,10 @@ class Engine:
         started = C.c_int(0)
         check(lib().mnc_engine_prefetch(self._h, bases_ptr, offsets_ptr, n, C.byref(started)))
         return bool(started.value)
+
+    def prefetch_cancel(self):
+        """Forget an announced batch that will not be classified (its host arrays may be reused afterwards)."""
+        check(lib().mnc_engine_prefetch_cancel(self._h))
 
     def classify_ptr(self, bases_ptr, offsets_ptr, n, min_mapq=60):
         """As classify(), on caller-owned host buffers given by address (e.g. a FastqReader batch)."""

@@ -214,16 +214,42 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
                 taken_bytes = total_bytes - reader.remaining() if total_bytes > 0 else 0
                 batch = reader.detach()
                 clock["parse"] += time.perf_counter() - t0
-                # the batch's bases cross PCIe behind the kernels of the batch before it (one spare buffer on the
-                # device: it is free again as soon as the batch announced last has started)
-                while not stop.is_set() and batch.n and not engine.prefetch_ptr(batch.bases_ptr, batch.offsets_ptr, batch.n):
-                    time.sleep(0.0005)
+                try:
+                    _announce(batch)
+                except BaseException:
+                    batch.close()
+                    raise
                 if not put(parsed, batch):
                     batch.close()
                     return
             put(parsed, None)
         except BaseException as e:                    # a malformed file: raised where the reference would raise
             put(parsed, e)
+
+    def _announce(batch):
+        """Best effort: the batch's bases cross PCIe behind the kernels of the batch before it.  There is one spare
+        buffer on the device, free again as soon as the batch announced last has STARTED its call -- so waiting makes
+        sense only while the classifying thread still has an earlier batch to take out of `parsed`; with the queue
+        empty the announced batch is running (the slot frees within a moment) or will never run, and the batch goes
+        to the queue unannounced (its own call copies it).  A refusal for lack of device memory means the same."""
+        if not batch.n:
+            return
+        idle_since = None
+        while not stop.is_set():
+            try:
+                if engine.prefetch_ptr(batch.bases_ptr, batch.offsets_ptr, batch.n):
+                    return
+            except _capi.MncError:
+                return
+            if parsed.empty():
+                now = time.perf_counter()
+                if idle_since is None:
+                    idle_since = now
+                elif now - idle_since > 0.02:
+                    return
+            else:
+                idle_since = None
+            time.sleep(0.0005)
 
     def classify_batch(batch):
         t1 = time.perf_counter()
@@ -317,6 +343,7 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
             stop.set()
             drain(to_write, carrier)
 
+    engine.prefetch_cancel()                           # an engine from the pool: nothing of an earlier run may be pending
     parser = threading.Thread(target=parse_stage, name="mnc-parse", daemon=True)
     carrier = threading.Thread(target=carry_stage, name="mnc-carry", daemon=True)
     writer = threading.Thread(target=write_stage, name="mnc-route", daemon=True)
@@ -336,14 +363,28 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
         carrier.join()
         writer.join()
         stop.set()
+        leftover = []
         while parser.is_alive():                          # unblock a parser waiting on a full queue
             try:
                 item = parsed.get(timeout=0.05)
                 if item is not None and not isinstance(item, BaseException):
-                    item.close()
+                    leftover.append(item)
             except queue.Empty:
                 pass
         parser.join()
+        while True:                                       # ... and what it had queued before it saw the stop
+            try:
+                item = parsed.get_nowait()
+            except queue.Empty:
+                break
+            if item is not None and not isinstance(item, BaseException):
+                leftover.append(item)
+        try:
+            engine.prefetch_cancel()                      # a batch announced and not classified (an error, a stop):
+        except _capi.MncError:                            # its copy is over before its page-locked arrays are given back
+            pass
+        for item in leftover:
+            item.close()
         t0 = time.perf_counter()
         reader.close()
         clock["close"] += time.perf_counter() - t0

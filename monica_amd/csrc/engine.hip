@@ -743,6 +743,7 @@ extern "C" int mnc_engine_set_index(mnc_engine *e, mnc_index *idx)
 	if (idx->par.bw >= GAP_LUT) { set_error("bw too large for the gap look-up"); return MNC_ERR_UNSUPPORTED; }
 	HIP_TRY(hipSetDevice(e->device));
 	HIP_TRY(hipStreamSynchronize(e->stream));
+	if (int rc = mnc_engine_prefetch_cancel(e)) return rc;       // a batch announced for the previous part's run is not this run's
 	DeviceIndex *d = nullptr;
 	if (int rc = index_upload(idx, e->device, &d)) return rc;
 	e->idx = idx, e->didx = d;
@@ -1317,6 +1318,21 @@ extern "C" int mnc_engine_prefetch(mnc_engine *e, const uint8_t *bases, const in
 	return MNC_OK;
 }
 
+// Forget the batch announced last, if any: waits for its copy (the host arrays are the caller's again afterwards)
+// and frees the spare buffer for the next announcement.  For a caller that gives up on a batch it has announced --
+// an error between announcement and call, an engine handed to another sample.  Matching is by the host pointers, so
+// an abandoned announcement whose page-locked arrays are recycled for another batch must be cancelled, not left.
+extern "C" int mnc_engine_prefetch_cancel(mnc_engine *e)
+{
+	if (!e) return MNC_ERR_ARG;
+	std::lock_guard<std::mutex> lk(e->pf_mu);
+	if (!e->pf_valid) return MNC_OK;
+	e->pf_valid = false, e->pf_bases = nullptr, e->pf_offsets = nullptr;
+	HIP_TRY(hipSetDevice(e->device));
+	HIP_TRY(hipStreamSynchronize(e->copy_stream));
+	return MNC_OK;
+}
+
 // ---------------------------------------------------------------- one batch, host buffers
 extern "C" int mnc_classify_batch(mnc_engine *e, const uint8_t *bases, const int64_t *offsets, uint32_t n_reads,
                                   int min_mapq, int32_t *out_assign, mnc_hit_t *out_best, int32_t *out_nhits)
@@ -1342,13 +1358,14 @@ extern "C" int mnc_classify_batch(mnc_engine *e, const uint8_t *bases, const int
 	{
 		std::lock_guard<std::mutex> lk(e->pf_mu);
 		if (e->pf_valid) {
-			if (e->pf_bases == bases && e->pf_offsets == offsets && e->pf_n == n_reads && e->pf_total == total) {
+			const bool mine = e->pf_bases == bases && e->pf_offsets == offsets && e->pf_n == n_reads && e->pf_total == total;
+			e->pf_valid = false, e->pf_bases = nullptr, e->pf_offsets = nullptr;     // whatever happens below, the announcement is spent
+			if (mine) {
 				// this batch is on the device already (or on its way): its buffers become the input, the old input the spare
-				std::swap(e->in_bases, e->pf_bases_buf), std::swap(e->in_offsets, e->pf_offsets_buf);
 				HIP_TRY(hipStreamWaitEvent(st, e->ev_prefetch, 0));
+				std::swap(e->in_bases, e->pf_bases_buf), std::swap(e->in_offsets, e->pf_offsets_buf);
 				prefetched = true;
 			} else HIP_TRY(hipStreamSynchronize(e->copy_stream));      // another batch was announced: let its copy finish, then forget it
-			e->pf_valid = false;
 		}
 	}
 	if (!prefetched) {

@@ -635,7 +635,17 @@ extern "C" int mnc_index_info(const mnc_index *idx, mnc_index_info_t *info)
 	info->n_keys = (int64_t)idx->keys.size();
 	info->n_occ = (int64_t)idx->pos.size();
 	info->total_len = idx->total_len;
-	for (auto &d : idx->dev) { info->device_bytes += d.bytes; info->table_slots = (int64_t)256 << d.region_bits; }
+	for (auto &d : idx->dev) { info->device_bytes += d.bytes; info->table_slots = ((int64_t)1 << d.pb_bits) << d.region_bits; }
+	return MNC_OK;
+}
+
+// HBM the index holds on ONE device (mnc_index_info sums over every device it is resident on)
+extern "C" int mnc_index_device_bytes(const mnc_index *idx, int device, int64_t *bytes)
+{
+	if (!idx || !bytes) return MNC_ERR_ARG;
+	*bytes = 0;
+	std::lock_guard<std::mutex> lk(const_cast<mnc_index*>(idx)->dev_mutex);
+	for (auto &d : idx->dev) if (d.device == device) *bytes += d.bytes;
 	return MNC_OK;
 }
 

@@ -66,7 +66,7 @@ def _device_budget(device):
 
 
 def _device_bytes_locked(device):
-    n = sum(index.info().device_bytes for index in _INDEX_CACHE.values())
+    n = sum(index.device_bytes(device) for index in _INDEX_CACHE.values())
     return n + sum(eng.device_bytes() for eng in _ENGINE_POOLS.get(device, []))
 
 

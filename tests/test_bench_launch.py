@@ -21,14 +21,16 @@ def run_bench(*argv, timeout=900):
 
 
 def test_gpus_2_starts_two_child_ranks_and_forwards_their_exit_code():
-    """No GPU here: every rank refuses with bench.py's own message.  Two refusals = two ranks were started; the
-    parent's exit code is the launcher's (non-zero), and nothing JSON-like reaches stdout."""
+    """No GPU here: a rank refuses with bench.py's own message (the launcher may end the other one before it gets
+    that far); its failure report names both ranks = two ranks were started; the parent's exit code is the
+    launcher's (non-zero), and nothing JSON-like reaches stdout."""
     import torch
     if torch.cuda.is_available():
         pytest.skip("a GPU is present: the -m gpu test below covers the real run")
     r = run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--reads", "100", timeout=300)
     assert r.returncode != 0
-    assert r.stderr.count("bench.py needs an MI355X") == 2, r.stderr[-2000:]
+    assert r.stderr.count("bench.py needs an MI355X") >= 1, r.stderr[-2000:]
+    assert "local_rank: 0" in r.stderr and "local_rank: 1" in r.stderr, r.stderr[-2000:]
     assert r.stdout.strip() == ""
 
 

@@ -189,3 +189,43 @@ def test_mappy_compat_map_yields_hits(oracle):
     assert len(hits) == 1 and hits[0].is_primary and hits[0].mapq == 60 and hits[0].ctg == "N/A"
     assert hits[0].r_st <= 1020 and hits[0].r_en >= 3980 and hits[0].strand == 1 and hits[0].NM == hits[0].blen - hits[0].mlen
     assert not mappy_compat.Aligner(fn_idx_in="/nonexistent/file.fa")
+
+
+@pytest.mark.timeout(300)
+def test_a_failed_sample_leaves_the_engine_usable(oracle, tmp_path, monkeypatch):
+    """A malformed record in the middle of a file raises where the reference's loop would (SeqIO.parse inside
+    aligner.py:212) -- after batches have been announced to the engine ahead of their call.  The engine goes back to
+    the pool; the next invocation (monica's loop calls again, aligner.py:65) must neither wait for the abandoned
+    announcement nor take it for one of its own batches."""
+    names, seqs = util.small_genomes(4, 150_000, 200_000)
+    dbs = tmp_path / "databases"
+    dbs.mkdir()
+    synth.write_fasta(str(dbs / "database0.fna.gz"), names, seqs)
+    paths = aligner.indexer(str(dbs), str(tmp_path / "indexes"))
+    query, out = tmp_path / "query", tmp_path / "output"
+    query.mkdir(), out.mkdir()
+    monkeypatch.setattr(aligner, "BATCH_READS", 64)            # many small batches: several are in flight when it breaks
+    bases, offsets, truth = synth.reads(seqs, 600, 2000, seed=79)
+    fq = query / "s.fastq"
+    synth.write_fastq(str(fq), bases, offsets, ids=[f"r{i}" for i in range(600)])
+    good = fq.read_bytes()
+    lines = good.split(b"\n")
+    lines[4 * 400 + 3] = lines[4 * 400 + 3][:-7]               # record 400: quality shorter than the sequence
+    fq.write_bytes(b"\n".join(lines))
+    cwd = os.getcwd()
+    try:
+        with pytest.raises(ValueError):
+            aligner.multi_threaded_aligner(str(query), paths, mode="basic", n_threads=1, output_folder=str(out))
+        # same engine (pooled per device), a different file of the same shape: same batch sizes, recycled page-locked arrays
+        for stale in ("mapped", "unmapped", "ambiguous"):
+            p = query / stale / "s.fastq"
+            if p.exists():
+                p.unlink()
+        b2, o2, _ = synth.reads(seqs, 600, 2000, seed=80)
+        synth.write_fastq(str(fq), b2, o2, ids=[f"q{i}" for i in range(600)])
+        got = aligner.multi_threaded_aligner(str(query), paths, mode="basic", n_threads=1, output_folder=str(out))
+    finally:
+        os.chdir(cwd)
+    want, route = expected_from_oracle(oracle, [(names, seqs, 0)], names, b2, o2, "basic")
+    assert got == {"s": want}
+    assert count_records(str(query / "mapped" / "s.fastq")) == sum(r.startswith("mapped") for r in route)
