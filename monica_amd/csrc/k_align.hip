@@ -1247,6 +1247,310 @@ __device__ void ksw_wave(int qlen, int tlen, S8 mem, S32 H, PP p, CP cig,
 	st_order<false, NW>();
 }
 
+// ================================================================ ksw_extd2 on a whole workgroup, state in registers
+// The same call as ksw_wave, for the long ones (an extension of 1 500 query bases is 4 500 anti-diagonals of up to 751 + 31
+// cells): NW waves, ONE cell per thread, one barrier per anti-diagonal.
+//
+// ksw2 keeps u v x y x2 y2 s (int8) and H (int32) in arrays indexed by the target position t and updates them in place;
+// an anti-diagonal touches t in [st, en] (both rounded to 16, which is why cells outside the band hold values that only
+// this layout defines) and reads x, v, x2 of t - 1.  Both ends only move up, and en - (st - 1) stays below the
+// workgroup's 64 NW threads: so the arrays live in REGISTERS, cell t in thread t mod 64 NW -- the window of cells the
+// workgroup holds is [st - 1, st - 2 + 64 NW]; a thread whose cell has dropped out below takes the next one above the
+// window, which no step has touched yet (the arrays' initial values: the window's top stays more than a rounding step above en).
+// What a step reads of OTHER cells -- x, v, x2 of the cell below, H of the cell below en0, and what the host-side
+// bookkeeping of ksw2 reads (the exact maximum's H[st0], H[tlen - 1]; the approximate maximum's u, v) -- goes through an
+// 8-byte record per thread in LDS {x, v, x2, u, H}, written before the step's barrier (two buffers in turn: one barrier a step).
+// The exact-maximum scan is a DPP reduction per wave and NW records in LDS; its result, the Z-drop test and `mqe` are
+// evaluated one step late, after the next step's barrier -- a step more is computed than ksw2 would (its direction bytes
+// are never read: the walk starts at or below the maximum's anti-diagonal).
+// The sequences lie in LDS, one byte per base; the walk afterwards reads the direction bytes through LDS tiles of
+// 128 anti-diagonals x 128 target positions that all threads load (a walk step is an LDS round trip instead of one to L2).
+#define MNC_DPPW(old, src, ctrl, rmask) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rmask), 0xf, false)
+typedef __attribute__((address_space(3))) unsigned long long *lds_u64p;
+constexpr int WG_SEQ_LDS = 40960;          // bytes of LDS for the target codes, and for the reversed query's
+constexpr int WG_TILE = 128;               // the walk's LDS tile: anti-diagonals x target positions
+template <int NW> constexpr int wg_lds_bytes() { return 2 * 64 * NW * 8 + 2 * NW * 8 + 64 + 2 * WG_SEQ_LDS; }
+
+__device__ __forceinline__ int wave_max_dpp(int v)           // the maximum over the wave, uniform
+{
+	const int lo = INT32_MIN;
+	int o;
+	o = MNC_DPPW(lo, v, 0x111, 0xf); v = v > o ? v : o;  o = MNC_DPPW(lo, v, 0x112, 0xf); v = v > o ? v : o;
+	o = MNC_DPPW(lo, v, 0x114, 0xf); v = v > o ? v : o;  o = MNC_DPPW(lo, v, 0x118, 0xf); v = v > o ? v : o;
+	o = MNC_DPPW(lo, v, 0x142, 0xa); v = v > o ? v : o;  o = MNC_DPPW(lo, v, 0x143, 0xc); v = v > o ? v : o;
+	return __builtin_amdgcn_readlane(v, 63);
+}
+
+// can this call run on ksw_wg<NW>?  (the widest anti-diagonal, its rounding, the cell below, one rounding step of head room)
+template <int NW> __device__ __forceinline__ bool wg_fits(int qlen, int tlen, int w)
+{
+	if (w < 0) w = tlen > qlen ? tlen : qlen;
+	int width = qlen < tlen ? qlen : tlen;
+	if (w + 1 < width) width = w + 1;
+	return width + 31 + 17 <= 64 * NW - 1 && (tlen + 15) / 16 * 16 <= WG_SEQ_LDS && (qlen + 15) / 16 * 16 + 32 <= WG_SEQ_LDS;
+}
+
+template <int NW, class PP, class CP>
+__device__ int walk_wg(int qlen, int tlen, int wl, int wr, int ncol, PP p, CP cig, int i0, int j0, int flag, lds_u8p tile, lds_i32p bc)
+{
+	constexpr int CW = 64 * NW, TR = WG_TILE;
+	const int lane = threadIdx.x;
+	int i = i0, j = j0, state = 0, n_cigar = 0;
+	uint32_t cur = 0;                                         // op being grown: len << 4 | op, 0 = none
+	auto push = [&](uint32_t op, int len) {
+		if (cur != 0 && (cur & 0xf) == op) cur += (uint32_t)len << 4;
+		else { if (cur != 0) cig[n_cigar++] = cur; cur = (uint32_t)len << 4 | op; }
+	};
+	auto row_range = [&](int r, int &st, int &en) {           // off[r], off_end[r]
+		st = 0, en = tlen - 1;
+		if (st < r - qlen + 1) st = r - qlen + 1;
+		if (en > r) en = r;
+		if (st < (r - wr + 1) >> 1) st = (r - wr + 1) >> 1;
+		if (en > (r + wl) >> 1) en = (r + wl) >> 1;
+		st = st / 16 * 16, en = (en + 16) / 16 * 16 - 1;
+	};
+	for (;;) {
+		if (lane == 0) bc[0] = i, bc[1] = j;
+		__syncthreads();
+		const int ti = bc[0], tj = bc[1];
+		if (ti < 0 || tj < 0) break;                          // uniform: the walk has left the matrix
+		const int r_top = ti + tj;
+		// the tile: anti-diagonals r_top - k, target positions ti - c (a walk step goes down one or two anti-diagonals
+		// and at most one target position)
+		for (int idx = lane; idx < TR * TR; idx += CW) {
+			const int k = idx / TR, c = idx % TR, rr = r_top - k, ii = ti - c;
+			if (rr >= 0 && ii >= 0) {
+				int st, en;
+				row_range(rr, st, en);
+				if (ii >= st && ii <= en) tile[idx] = p[(size_t)rr * ncol + (size_t)(ii - st)];
+			}
+		}
+		__syncthreads();
+		if (lane == 0) {
+			while (i >= 0 && j >= 0) {
+				const int r = i + j, k = r_top - r, c = ti - i;
+				if (k >= TR || c >= TR) break;                    // the next tile
+				int st, en;
+				row_range(r, st, en);
+				int force_state = -1;
+				if (i < st) force_state = 2;
+				if (i > en) force_state = 1;
+				const uint32_t tmp = force_state < 0 ? tile[k * TR + c] : 0;
+				if (state == 0) state = tmp & 7;
+				else if (!(tmp >> (state + 2) & 1)) state = 0;
+				if (state == 0) state = tmp & 7;
+				if (force_state >= 0) state = force_state;
+				if (state == 0) push(0, 1), --i, --j;
+				else if (state == 1 || state == 3) push(2, 1), --i;
+				else push(1, 1), --j;
+			}
+		}
+	}
+	if (lane == 0) {
+		if (i >= 0) push(2, i + 1);
+		if (j >= 0) push(1, j + 1);
+		if (cur != 0) cig[n_cigar++] = cur;
+		if (!(flag & EZ_REV_CIGAR))
+			for (int k = 0; k < n_cigar >> 1; ++k) { const uint32_t t2 = cig[k]; cig[k] = cig[n_cigar - 1 - k], cig[n_cigar - 1 - k] = t2; }
+	}
+	return n_cigar;                                           // thread 0's
+}
+
+template <int NW, class PP, class CP>
+__device__ void ksw_wg(int qlen, int tlen, const uint8_t *sf_g, const uint8_t *qr_g, lds_u8p lds, PP p, CP cig,
+                       int q, int e, int q2, int e2, int sc_mch, int sc_mis, int sc_N,
+                       int w, int zdrop, int end_bonus, int flag, Ez &ez)
+{
+	constexpr int CW = 64 * NW, M = CW - 1;
+	static_assert((NW & (NW - 1)) == 0 && NW <= 16, "a power of two, a row of 16 lanes at most");
+	const int lane = threadIdx.x, wv = lane >> 6;
+	lds_u64p ex = (lds_u64p)lds;                              // [2][CW] {x, v, x2, u | H}
+	lds_u64p sl = ex + 2 * CW;                                // [2][NW] the waves' (H, rank) of the exact-maximum scan
+	lds_i32p bc = (lds_i32p)(sl + 2 * NW);                    // 16 words for the walk
+	lds_u8p sq = (lds_u8p)(bc + 16);                          // the reversed query's codes
+	lds_u8p stg = sq + WG_SEQ_LDS;                            // the target's
+	const bool approx_max = (flag & EZ_APPROX_MAX) != 0, right = (flag & EZ_RIGHT) != 0;
+	ez.max = 0, ez.zdropped = 0, ez.max_q = ez.max_t = ez.mqe_t = -1, ez.mqe = ez.score = DP_NEG_INF, ez.reach_end = 0, ez.n_cigar = 0;
+	const int qe = q + e;
+	if (w < 0) w = tlen > qlen ? tlen : qlen;
+	const int wl = w, wr = w;
+	int n_col_ = qlen < tlen ? qlen : tlen;
+	n_col_ = ((n_col_ < w + 1 ? n_col_ : w + 1) + 15) / 16 + 1;
+	const int ncol = n_col_ * 16;
+	int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+	const int T = (tlen + 15) / 16 * 16, Q = (qlen + 15) / 16 * 16 + 32;
+	__syncthreads();                                          // (the LDS may still hold the previous call's walk)
+	for (int i = lane; i < T; i += CW) stg[i] = sf_g[i];
+	for (int i = lane; i < Q; i += CW) sq[i] = qr_g[i];
+	if (lane < 2 * NW) sl[lane] = 0;
+	__syncthreads();
+
+	// this thread's cell
+	int t_mine = -1 + ((lane + 1) & M);
+	int tb = t_mine >= 0 && t_mine < T ? (int)stg[t_mine] : 0;
+	int cu = -q - e, cv = -q - e, cx = -q - e, cy = -q - e, cx2 = -q2 - e2, cy2 = -q2 - e2, cs = 0, cH = DP_NEG_INF;
+	unsigned long long wkey = 0;                              // the wave's exact-maximum key of the step before (uniform)
+	int last_st = -1, last_en = -1, H0 = 0, last_H0_t = 0;
+	int p_st = 0, p_en = 0, p_st0 = 0, p_en0 = 0;
+	const int n_r = qlen + tlen - 1;
+	for (int r = 0;; ++r) {
+		// ---- the cells as step r - 1 left them, for whoever reads another thread's
+		lds_u64p exb = ex + (r & 1) * CW;
+		lds_u64p slb = sl + (r & 1) * NW;
+		exb[lane] = (unsigned long long)((unsigned)(cx & 0xff) | (unsigned)(cv & 0xff) << 8 | (unsigned)(cx2 & 0xff) << 16 | (unsigned)(cu & 0xff) << 24)
+		            | (unsigned long long)(unsigned)cH << 32;
+		if ((lane & 63) == 0) slb[wv] = wkey;
+		__syncthreads();
+		// ---- what ksw2 does after the cells of an anti-diagonal, for step r - 1
+		if (r > 0) {
+			const int rp = r - 1;
+			if (!approx_max) {
+				int max_H, max_t;
+				if (rp > 0) {
+					// the largest of the waves' keys: a row of 16 lanes reads them, a prefix maximum along the row
+					unsigned long long k = slb[lane & (NW - 1)];
+#define MNC_KEY_STEP(ctrl) { const unsigned lo = (unsigned)MNC_DPPW(0, (int)(unsigned)k, ctrl, 0xf), hi = (unsigned)MNC_DPPW(0, (int)(unsigned)(k >> 32), ctrl, 0xf); \
+	const unsigned long long o = (unsigned long long)hi << 32 | lo; k = o > k ? o : k; }
+					if constexpr (NW > 1) MNC_KEY_STEP(0x111)
+					if constexpr (NW > 2) MNC_KEY_STEP(0x112)
+					if constexpr (NW > 4) MNC_KEY_STEP(0x114)
+					if constexpr (NW > 8) MNC_KEY_STEP(0x118)
+#undef MNC_KEY_STEP
+					const unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, NW - 1), khi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), NW - 1);
+					max_H = (int)(khi ^ 0x80000000u);
+					const unsigned mr = ~klo;
+					const int en1 = p_st0 + (p_en0 - p_st0) / 4 * 4;
+					if (mr == 0) max_t = p_en0;
+					else if (mr < 1u + 4u * 0x1000000u) { const unsigned kk = mr - 1u; max_t = p_st0 + (int)((kk & 0xffffffu) * 4u + (kk >> 24)); }
+					else max_t = en1 + (int)(mr - 1u - 4u * 0x1000000u);
+				} else max_H = (int)(unsigned)(exb[0] >> 32), max_t = 0;
+				if (rp - p_st0 == qlen - 1) {
+					const int h = (int)(unsigned)(exb[p_st0 & M] >> 32);
+					if (h > ez.mqe) ez.mqe = h, ez.mqe_t = p_st0;
+				}
+				if (apply_zdrop(ez, max_H, rp, max_t, zdrop, e2)) break;
+				if (rp == qlen + tlen - 2 && p_en0 == tlen - 1) ez.score = (int)(unsigned)(exb[(tlen - 1) & M] >> 32);
+			} else {
+				if (rp > 0) {
+					if (last_H0_t >= p_st0 && last_H0_t <= p_en0 && last_H0_t + 1 >= p_st0 && last_H0_t + 1 <= p_en0) {
+						const int d0 = I8((unsigned)exb[last_H0_t & M] >> 8), d1 = I8((unsigned)exb[(last_H0_t + 1) & M] >> 24);
+						if (d0 > d1) H0 += d0;
+						else H0 += d1, ++last_H0_t;
+					} else if (last_H0_t >= p_st0 && last_H0_t <= p_en0) {
+						H0 += I8((unsigned)exb[last_H0_t & M] >> 8);
+					} else {
+						++last_H0_t, H0 += I8((unsigned)exb[last_H0_t & M] >> 24);
+					}
+				} else H0 = I8((unsigned)exb[0] >> 8) - qe, last_H0_t = 0;
+				if (rp == qlen + tlen - 2 && p_en0 == tlen - 1) ez.score = H0;
+			}
+			last_st = p_st, last_en = p_en;
+		}
+		if (r >= n_r) break;
+		int st = 0, en = tlen - 1;
+		if (st < r - qlen + 1) st = r - qlen + 1;
+		if (en > r) en = r;
+		if (st < (r - wr + 1) >> 1) st = (r - wr + 1) >> 1;
+		if (en > (r + wl) >> 1) en = (r + wl) >> 1;
+		if (st > en) { ez.zdropped = 1; break; }
+		const int st0 = st, en0 = en;
+		st = st / 16 * 16, en = (en + 16) / 16 * 16 - 1;
+		// ---- the cell below, as the last step left it (the thread of the cell at st: ksw2's x1, x21, v1)
+		const unsigned long long nb = exb[(lane - 1) & M];
+		// ---- the window moves up with st: a thread whose cell has left it takes a fresh one at the top
+		{
+			const int base = st - 1;
+			const int tn = base + ((lane - base) & M);
+			if (tn != t_mine) {
+				t_mine = tn;
+				cu = cv = cx = cy = -q - e, cx2 = cy2 = -q2 - e2, cs = 0, cH = DP_NEG_INF;
+				tb = tn < T ? (int)stg[tn] : 0;
+			}
+		}
+		const int t = t_mine;
+		int xt1 = I8((unsigned)nb), vt1 = I8((unsigned)nb >> 8), x2t1 = I8((unsigned)nb >> 16);
+		const int nbH = (int)(unsigned)(nb >> 32);
+		const int v_edge = r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
+		if (t == st) {
+			if (st > 0) {
+				if (!(st - 1 >= last_st && st - 1 <= last_en)) xt1 = -q - e, x2t1 = -q2 - e2, vt1 = -q - e;
+			} else xt1 = -q - e, x2t1 = -q2 - e2, vt1 = v_edge;
+		}
+		if (en >= r && t == r) cy = -q - e, cy2 = -q2 - e2, cu = v_edge;
+		// scores: 16-lane strides from st0
+		{
+			const int n16 = (en0 - st0) / 16 + 1;
+			if (t >= st0 && t < st0 + n16 * 16) {
+				const int qb = sq[qlen - 1 - r + t];
+				cs = (tb == 4 || qb == 4) ? sc_N : tb == qb ? sc_mch : sc_mis;
+			}
+		}
+		// the cell (every cell of the anti-diagonal reads old values only: no order among the threads)
+		if (t >= st && t <= en) {
+			int zz = cs;
+			int a = I8(xt1 + vt1), b = I8(cy + cu), a2 = I8(x2t1 + vt1), b2 = I8(cy2 + cu), d, tmp;
+			if (!right) {
+				d = a > zz ? 1 : 0;  zz = zz > a ? zz : a;
+				d = b > zz ? 2 : d;  zz = zz > b ? zz : b;
+				d = a2 > zz ? 3 : d; zz = zz > a2 ? zz : a2;
+				d = b2 > zz ? 4 : d; zz = zz > b2 ? zz : b2;
+			} else {
+				d = zz > a ? 0 : 1;  zz = zz > a ? zz : a;
+				d = zz > b ? d : 2;  zz = zz > b ? zz : b;
+				d = zz > a2 ? d : 3; zz = zz > a2 ? zz : a2;
+				d = zz > b2 ? d : 4; zz = zz > b2 ? zz : b2;
+			}
+			zz = zz < sc_mch ? zz : sc_mch;
+			const int ut = cu;
+			cu = I8(zz - vt1), cv = I8(zz - ut);
+			tmp = I8(zz - q), a = I8(a - tmp), b = I8(b - tmp);
+			tmp = I8(zz - q2), a2 = I8(a2 - tmp), b2 = I8(b2 - tmp);
+			if (!right) {
+				cx = I8((a > 0 ? a : 0) - qe);            d |= a > 0 ? 0x08 : 0;
+				cy = I8((b > 0 ? b : 0) - qe);            d |= b > 0 ? 0x10 : 0;
+				cx2 = I8((a2 > 0 ? a2 : 0) - (q2 + e2));  d |= a2 > 0 ? 0x20 : 0;
+				cy2 = I8((b2 > 0 ? b2 : 0) - (q2 + e2));  d |= b2 > 0 ? 0x40 : 0;
+			} else {
+				cx = I8((0 > a ? 0 : a) - qe);            d |= 0 > a ? 0 : 0x08;
+				cy = I8((0 > b ? 0 : b) - qe);            d |= 0 > b ? 0 : 0x10;
+				cx2 = I8((0 > a2 ? 0 : a2) - (q2 + e2));  d |= 0 > a2 ? 0 : 0x20;
+				cy2 = I8((0 > b2 ? 0 : b2) - (q2 + e2));  d |= 0 > b2 ? 0 : 0x40;
+			}
+			p[(size_t)r * ncol + (size_t)(t - st)] = (uint8_t)d;
+		}
+		if (!approx_max) {
+			// H[en0] from the OLD H[en0 - 1]; H[t] += v[t] for t in [st0, en0); the maximum in the SSE scan's tie order
+			int h = DP_NEG_INF - 1;
+			unsigned rank = 0xffffffffu;
+			if (r > 0) {
+				const int en1 = st0 + (en0 - st0) / 4 * 4;
+				if (t >= st0 && t < en0) {
+					cH += cv, h = cH;
+					rank = t < en1 ? 1u + ((unsigned)(t - st0) & 3u) * 0x1000000u + ((unsigned)(t - st0) >> 2)
+					               : 1u + 4u * 0x1000000u + (unsigned)(t - en1);
+				} else if (t == en0) {
+					cH = en0 > 0 ? nbH + cu : cH + cv, h = cH, rank = 0;       // en0 comes first in the scan
+				}
+			} else if (t == 0) cH = cv - qe, h = cH, rank = 0;
+			const int mh = wave_max_dpp(h);
+			const int mrk = wave_max_dpp((int)(h == mh ? ~rank : 0u) ^ INT32_MIN);     // the smallest rank among the wave's best
+			wkey = (unsigned long long)((unsigned)mh ^ 0x80000000u) << 32 | ((unsigned)mrk ^ 0x80000000u);
+		}
+		p_st = st, p_en = en, p_st0 = st0, p_en0 = en0;
+	}
+	__syncthreads();                                          // the direction bytes are written; the sequences' LDS is free
+	int i0 = -1, j0 = -1;
+	if (!ez.zdropped && !(flag & EZ_EXTZ_ONLY)) i0 = tlen - 1, j0 = qlen - 1;
+	else if (!ez.zdropped && (flag & EZ_EXTZ_ONLY) && ez.mqe + end_bonus > ez.max) ez.reach_end = 1, i0 = ez.mqe_t, j0 = qlen - 1;
+	else if (ez.max_t >= 0 && ez.max_q >= 0) i0 = ez.max_t, j0 = ez.max_q;
+	int n_cigar = 0;
+	if (i0 >= 0 && j0 >= 0) n_cigar = walk_wg<NW>(qlen, tlen, wl, wr, ncol, p, cig, i0, j0, flag, sq, bc);
+	ez.n_cigar = wg_bcast0<NW>(n_cigar);
+	st_order<false, NW>();
+}
+
 // mm_test_zdrop on a finished gap-filling CIGAR: 0 fine, 1 the score drops by more than zdrop, 2 and
 // the dropped stretch aligns to its own reverse complement.  One lane; sequences come from `mem`.
 template <class SU8, class CP>
@@ -1387,8 +1691,21 @@ __global__ __launch_bounds__(64 * NW) void mnc_dp_align(Batch B, uint8_t *ws_all
 				for (int i = lane; i < Q; i += 64 * NW)
 					qr[i] = i < g.qlen ? (uint8_t)qcode(read, rlen, g.rev, g.kind == 0 ? g.qs + i : g.qs + g.qlen - 1 - i) : 0;
 				st_order<false, NW>();
-				ksw_wave<NW>(g.qlen, g.tlen, mem, H, pbuf, cg, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, sc_N,
-				         g.w, g.zdrop, g.kind == 1 ? -1 : B.end_bonus, g.flag, ez);
+				// the widest workgroups hold the cells in registers (ksw_wg) unless the call's anti-diagonals or sequences outgrow that
+				// form; debug_route bit 6: never (the workspace form on this many waves, for the tests)
+				bool on_wg = false;
+				if constexpr (NW >= 8) on_wg = !(B.debug_route & 64) && wg_fits<NW>(g.qlen, g.tlen, g.w);
+				auto call = [&](int zdrop, int end_bonus, int flag) {
+					if constexpr (NW >= 8) {
+						if (on_wg) {
+							ksw_wg<NW>(g.qlen, g.tlen, (const uint8_t*)sf, (const uint8_t*)qr, (lds_u8p)smem, pbuf, cg, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2,
+							           sc_mch, sc_mis, sc_N, g.w, zdrop, end_bonus, flag, ez);
+							return;
+						}
+					}
+					ksw_wave<NW>(g.qlen, g.tlen, mem, H, pbuf, cg, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, sc_N, g.w, zdrop, end_bonus, flag, ez);
+				};
+				call(g.zdrop, g.kind == 1 ? -1 : B.end_bonus, g.flag);
 				if (g.kind == 1) {
 					// the kernel's last 16-lane score store may spill into the first 15 target bytes (as in the
 					// SSE buffer, where those are dead by then): restore them for the walk and the second pass
@@ -1398,8 +1715,7 @@ __global__ __launch_bounds__(64 * NW) void mnc_dp_align(Batch B, uint8_t *ws_all
 					                                              reinterpret_cast<int32_t*>(ws + W.sw), reinterpret_cast<int32_t*>(ws + W.sw) + cig_max);
 					zdrop_code = wg_bcast0<NW>(zdrop_code);
 					if (zdrop_code != 0)                             // second pass: exact maximum, real Z-drop
-						ksw_wave<NW>(g.qlen, g.tlen, mem, H, pbuf, cg, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, sc_N,
-						         g.w, zdrop_code == 2 ? B.zdrop_inv : B.zdrop, -1, 0, ez);
+						call(zdrop_code == 2 ? B.zdrop_inv : B.zdrop, -1, 0);
 				}
 				// the CIGAR goes to the segment pool
 				if (lane == 0 && ez.n_cigar > 0) off = atomicAdd(&B.dp_ctr[1], (unsigned long long)ez.n_cigar);
@@ -2260,17 +2576,23 @@ void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work,
 	}
 }
 size_t dp_align_ws_bytes(long long state_max, long long p_max, long long cig_max) { return align_ws(state_max, p_max, cig_max).total; }
+constexpr int ALIGN_WG_WAVES = 16;            // waves on one of the literal kernel's long calls (ksw_wg: one cell per thread, up to ~970 per anti-diagonal)
 int dp_align_prepare(int lds_bytes)
 {
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+	if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align<ALIGN_WG_WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, wg_lds_bytes<ALIGN_WG_WAVES>());
 	if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return MNC_ERR_HIP; }
 	return MNC_OK;
 }
 void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max, long long p_max, long long cig_max,
                      int lds_state, int lds_p, int lds_cig, int big_pass, hipStream_t st)
 {
-	// the long calls (passes 1, 3, 4, 5: state in the workspace) on four waves each; debug_route bit 5: one wave, as the rest
-	if ((big_pass == 1 || big_pass >= 3) && !(B.debug_route & 32))
+	// the long calls (passes 1, 3, 4, 5: state in the workspace) on several waves each: sixteen with the cells in registers
+	// (ksw_wg; the small-workspace class, pass 3, and debug_route bit 7: four waves on the workspace); debug_route bit 5:
+	// one wave, as the rest
+	if ((big_pass == 1 || big_pass >= 4) && !(B.debug_route & (32 | 128)))
+		hipLaunchKernelGGL(mnc_dp_align<ALIGN_WG_WAVES>, dim3(n_wg), dim3(64 * ALIGN_WG_WAVES), (size_t)wg_lds_bytes<ALIGN_WG_WAVES>(), st, B, ws, state_max, p_max, cig_max, 0, 0, 0, big_pass);
+	else if ((big_pass == 1 || big_pass >= 3) && !(B.debug_route & 32))
 		hipLaunchKernelGGL(mnc_dp_align<4>, dim3(n_wg), dim3(256), 0, st, B, ws, state_max, p_max, cig_max, 0, 0, 0, big_pass);
 	else
 		hipLaunchKernelGGL(mnc_dp_align<1>, dim3(n_wg), dim3(64), (size_t)lds_state + lds_p + lds_cig * 4, st, B, ws, state_max, p_max, cig_max,

@@ -59,7 +59,7 @@ def test_one_rank_line_carries_the_timed_region_and_both_cpu_baselines():
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["rccl_ranks"] is None and out["ranks"]["reads_per_rank"] == [8000]
-    assert abs(out["timed_region_s"] * 1e3 / 2 - out["ms_per_step"]) < 0.01
+    assert abs(out["timed_region_s"] * 1e3 / 2 - out["ms_per_step"]) < 0.06     # the region is rounded to 0.1 ms
     cpu = out["cpu_baseline"]
     assert cpu["agrees_with_gpu"] and cpu["one_core"]["cores"] == 1 and cpu["one_core"]["agrees_with_gpu"]
     assert out["roofline"]["frac"] > 0 and out["roofline"]["bound"] in ("valu", "hbm")

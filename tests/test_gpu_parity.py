@@ -421,6 +421,34 @@ def test_index_built_on_the_device_equals_the_host_builder(capi, oracle, tmp_pat
         assert np.array_equal(a1, b1) and np.array_equal(a2, b2) and x.mid_occ == ref.mid_occ
 
 
+def test_device_builder_on_degenerate_and_repetitive_inputs(capi):
+    """What the device builder's early exits and its mid_occ selection must still get right (mappy.Aligner on such a
+    FASTA gives an index object too, monica/genomes/aligner.py:45-48): contigs all shorter than a k-mer, all ambiguous,
+    one contig -- no minimizer at all, yet the contig / genome tables and mid_occ are the host builder's; and a satellite
+    whose k-mers occur tens of thousands of times (counts beyond the device histogram's bins: the host's selection)."""
+    def same(names, seqs):
+        host, dev = capi.Index.from_seqs(names, seqs), capi.Index.from_seqs(names, seqs, device=0)
+        (hh, hy), (dh, dy) = host.dump(), dev.dump()
+        assert np.array_equal(hh, dh) and np.array_equal(hy, dy)
+        hi, di = host.info(), dev.info()
+        for f in ("k", "w", "n_contigs", "n_genomes", "mid_occ", "n_keys", "n_occ", "total_len"):
+            assert getattr(hi, f) == getattr(di, f), f
+        assert host.genome_names == dev.genome_names and host.genome_lens == dev.genome_lens
+        assert np.array_equal(host.contig_genome, dev.contig_genome)
+        return dev
+    short = [synth.genome(7 + i, L) for i, L in enumerate((3, 9, 14, 1))]
+    d = same(["Ga_a:A.1", "Ga_a:A.1", "Gb_b:B.1", "Gc_c:C.1"], short)
+    assert d.info().n_keys == 0 and d.info().n_genomes == 3 and len(d.contig_genome) == 4
+    same(["Gn_n:N.1"], [np.full(5000, ord("N"), dtype=np.uint8)])
+    same(["Ge_e:E.1"], [np.zeros(0, dtype=np.uint8)])
+    # 5 000 copies of a 2 kb unit next to ordinary sequence: ~360 minimizers with 5 000 occurrences each, more than the
+    # 2e-4 of the distinct ones that lie above the mid_occ rank -- the count at that rank is beyond the histogram's bins
+    unit = synth.genome(99, 2000)
+    sat = np.concatenate([synth.genome(100, 50_000), np.tile(unit, 5_000), synth.genome(101, 50_000)])
+    d = same(["Gs_s:S.1", "Gt_t:T.1"], [sat, synth.genome(102, 300_000)])
+    assert d.mid_occ > 4096
+
+
 def test_the_20_genome_index_is_built_on_the_device_in_a_fraction_of_a_second(capi):
     import time
     names, seqs = synth.genome_set(20)
