@@ -6,10 +6,11 @@ module instead of the reference one.  What changes is underneath: `index.map(rea
 (aligner.py:193, 215) becomes one C-ABI call per micro-batch into the gfx950 kernels
 (`mappy_compat.Aligner.map_batch`), and Biopython record objects become flat arrays.
 
-Deviations, all deliberate:
-* index files under the reference's `indexN.mmi` names are this library's own format unless
-  `mappy_compat.INDEX_FILE_FORMAT = "mmi"`; `index_loader` reads both, and minimap2's own files;
-* `n_threads=None` means 4 worker threads, not one per core: a thread only feeds the GPU.
+One deliberate deviation: index files under the reference's `indexN.mmi` names are this library's
+own format unless `mappy_compat.INDEX_FILE_FORMAT = "mmi"`; `index_loader` reads both, and minimap2's
+own files.  (`n_threads=None` is `ThreadPool(None)`, one worker per core, as in the reference
+(aligner.py:89); a worker makes its engine -- a HIP stream and the batch buffers in HBM -- only when it
+is handed a sample file, so idle workers cost nothing on the device.)
 """
 import itertools
 import os
@@ -54,7 +55,6 @@ AMBIGUOUS_FILES_FOLDER = "ambiguous"
 HITS_FILES_FOLDER = "hits"
 FOCUS_FILES_FOLDER = "focus"
 
-DEFAULT_THREADS = 4
 # reads / bases per C-ABI call: a sample file is worked through in batches of this size, three at a time (one being
 # parsed, one on the GPU, one being written out)
 BATCH_READS = int(os.environ.get("MONICA_AMD_BATCH_READS", "25000"))
@@ -129,7 +129,7 @@ def multi_threaded_aligner(query_folder, indexes_paths, mode=None, mapping_quali
         if focus_species:
             os.mkdir(folders["focus"])
 
-    pool = ThreadPool(n_threads if n_threads else DEFAULT_THREADS)
+    pool = ThreadPool(n_threads)                  # None: one worker per core (aligner.py:89)
     rep = itertools.repeat
     mappy.reserve_index_cache(len(indexes_paths))
     try:

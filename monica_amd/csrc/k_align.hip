@@ -1249,27 +1249,33 @@ __device__ void ksw_wave(int qlen, int tlen, S8 mem, S32 H, PP p, CP cig,
 
 // ================================================================ ksw_extd2 on a whole workgroup, state in registers
 // The same call as ksw_wave, for the long ones (an extension of 1 500 query bases is 4 500 anti-diagonals of up to 751 + 31
-// cells): NW waves, ONE cell per thread, one barrier per anti-diagonal.
+// cells): NW waves, C consecutive cells per thread, one barrier per anti-diagonal.
 //
 // ksw2 keeps u v x y x2 y2 s (int8) and H (int32) in arrays indexed by the target position t and updates them in place;
 // an anti-diagonal touches t in [st, en] (both rounded to 16, which is why cells outside the band hold values that only
-// this layout defines) and reads x, v, x2 of t - 1.  Both ends only move up, and en - (st - 1) stays below the
-// workgroup's 64 NW threads: so the arrays live in REGISTERS, cell t in thread t mod 64 NW -- the window of cells the
-// workgroup holds is [st - 1, st - 2 + 64 NW]; a thread whose cell has dropped out below takes the next one above the
-// window, which no step has touched yet (the arrays' initial values: the window's top stays more than a rounding step above en).
-// What a step reads of OTHER cells -- x, v, x2 of the cell below, H of the cell below en0, and what the host-side
-// bookkeeping of ksw2 reads (the exact maximum's H[st0], H[tlen - 1]; the approximate maximum's u, v) -- goes through an
-// 8-byte record per thread in LDS {x, v, x2, u, H}, written before the step's barrier (two buffers in turn: one barrier a step).
-// The exact-maximum scan is a DPP reduction per wave and NW records in LDS; its result, the Z-drop test and `mqe` are
+// this layout defines) and reads x, v, x2 of t - 1.  Both ends only move up, and en - st stays below the workgroup's
+// CW = 64 NW C cells: so the arrays live in REGISTERS, cell t in thread (t mod CW) / C -- the window of cells the workgroup
+// holds is [st - 16, st - 16 + CW); a thread whose cells have dropped out below takes the next C above the window, which no
+// step has touched yet (the arrays' initial values: the window's top stays more than a rounding step above en).  st and
+// en + 1 are multiples of 16, so a thread's C cells (C divides 16) are inside the anti-diagonal together or not at all.
+// What a step reads of ANOTHER thread's cells -- x, v, x2 (and H, below en0) of the cell below a thread's first -- comes
+// from the neighbouring lane by a DPP shift, from the neighbouring wave through one LDS word per wave, written before
+// the step's barrier (two buffers in turn: one barrier a step).  What ksw2's bookkeeping reads of single cells (the
+// exact maximum's H[st0], H[tlen - 1]; the approximate maximum's u, v) their owners put into four LDS words likewise.
+// The exact-maximum scan is a DPP reduction per wave and NW words in LDS; its result, the Z-drop test and `mqe` are
 // evaluated one step late, after the next step's barrier -- a step more is computed than ksw2 would (its direction bytes
 // are never read: the walk starts at or below the maximum's anti-diagonal).
 // The sequences lie in LDS, one byte per base; the walk afterwards reads the direction bytes through LDS tiles of
 // 128 anti-diagonals x 128 target positions that all threads load (a walk step is an LDS round trip instead of one to L2).
+// <16, 1>: one call as fast as it goes (a micro-batch, a block with a handful of long calls waits for the longest);
+// <4, 4>: four times the calls side by side at ~1.5 times the time each (a batch of divergent reads has thousands).
 #define MNC_DPPW(old, src, ctrl, rmask) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rmask), 0xf, false)
 typedef __attribute__((address_space(3))) unsigned long long *lds_u64p;
-constexpr int WG_SEQ_LDS = 40960;          // bytes of LDS for the target codes, and for the reversed query's
 constexpr int WG_TILE = 128;               // the walk's LDS tile: anti-diagonals x target positions
-template <int NW> constexpr int wg_lds_bytes() { return 2 * 64 * NW * 8 + 2 * NW * 8 + 64 + 2 * WG_SEQ_LDS; }
+// LDS of a workgroup: [2][NW] boundary records | [2][NW] maximum keys | [2][4] single cells | 16 words of the walk | the
+// reversed query's codes | the target's (`seq` bytes each; at least the walk's tile together)
+template <int NW> constexpr int wg_lds_head() { return 2 * NW * 8 * 2 + 2 * 4 * 8 + 64; }
+template <int NW> constexpr int wg_lds_bytes(int seq) { return wg_lds_head<NW>() + 2 * seq; }
 
 __device__ __forceinline__ int wave_max_dpp(int v)           // the maximum over the wave, uniform
 {
@@ -1281,13 +1287,14 @@ __device__ __forceinline__ int wave_max_dpp(int v)           // the maximum over
 	return __builtin_amdgcn_readlane(v, 63);
 }
 
-// can this call run on ksw_wg<NW>?  (the widest anti-diagonal, its rounding, the cell below, one rounding step of head room)
-template <int NW> __device__ __forceinline__ bool wg_fits(int qlen, int tlen, int w)
+// can this call run on ksw_wg<NW, C>?  (the widest anti-diagonal, its rounding at both ends, the 16 cells below st, one
+// rounding step of head room; the sequences in `seq` bytes of LDS each)
+template <int NW, int C> __device__ __forceinline__ bool wg_fits(int qlen, int tlen, int w, int seq)
 {
 	if (w < 0) w = tlen > qlen ? tlen : qlen;
 	int width = qlen < tlen ? qlen : tlen;
 	if (w + 1 < width) width = w + 1;
-	return width + 31 + 17 <= 64 * NW - 1 && (tlen + 15) / 16 * 16 <= WG_SEQ_LDS && (qlen + 15) / 16 * 16 + 32 <= WG_SEQ_LDS;
+	return width + 30 + 16 + 17 <= 64 * NW * C && (tlen + 15) / 16 * 16 <= seq && (qlen + 15) / 16 * 16 + 32 <= seq;
 }
 
 template <int NW, class PP, class CP>
@@ -1356,21 +1363,37 @@ __device__ int walk_wg(int qlen, int tlen, int wl, int wr, int ncol, PP p, CP ci
 	return n_cigar;                                           // thread 0's
 }
 
-template <int NW, class PP, class CP>
-__device__ void ksw_wg(int qlen, int tlen, const uint8_t *sf_g, const uint8_t *qr_g, lds_u8p lds, PP p, CP cig,
+// an LDS word every lane reads from the same address: as scalars
+__device__ __forceinline__ int uni_hi(unsigned long long v) { return __builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)); }
+__device__ __forceinline__ unsigned uni_lo(unsigned long long v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v); }
+
+template <int NW, int C, class PP, class CP>
+__device__ __attribute__((noinline)) void ksw_wg(int qlen, int tlen, const uint8_t *sf_g, const uint8_t *qr_g, lds_u8p lds, int seq_lds, PP p, CP cig,
                        int q, int e, int q2, int e2, int sc_mch, int sc_mis, int sc_N,
-                       int w, int zdrop, int end_bonus, int flag, Ez &ez)
+                       int w, int zdrop, int end_bonus, int flag, Ez &ez_out)
 {
-	constexpr int CW = 64 * NW, M = CW - 1;
-	static_assert((NW & (NW - 1)) == 0 && NW <= 16, "a power of two, a row of 16 lanes at most");
+	constexpr int CW = 64 * NW * C, M = CW - 1;
+	static_assert((NW & (NW - 1)) == 0 && NW <= 16 && (C == 1 || C == 2 || C == 4), "waves: a power of two, a row of 16 lanes at most; cells per thread divide 16");
+	// a function of its own (not inlined into the kernel's other forms): its arguments arrive in vector registers, and
+	// every one of them is the same in all lanes -- back into scalars, or the bookkeeping of every step runs on the vector ALU
+	{
+		auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+		auto unip = [&](auto ptr) { const unsigned long long v = (unsigned long long)ptr; return (decltype(ptr))((unsigned long long)(unsigned)uni((int)(unsigned)v) | (unsigned long long)(unsigned)uni((int)(unsigned)(v >> 32)) << 32); };
+		qlen = uni(qlen), tlen = uni(tlen), seq_lds = uni(seq_lds), q = uni(q), e = uni(e), q2 = uni(q2), e2 = uni(e2), sc_mch = uni(sc_mch), sc_mis = uni(sc_mis), sc_N = uni(sc_N);
+		w = uni(w), zdrop = uni(zdrop), end_bonus = uni(end_bonus), flag = uni(flag);
+		sf_g = unip(sf_g), qr_g = unip(qr_g), p = unip(p), cig = unip(cig);
+		lds = (lds_u8p)(unsigned)uni((int)(unsigned)(unsigned long long)lds);
+	}
 	const int lane = threadIdx.x, wv = lane >> 6;
-	lds_u64p ex = (lds_u64p)lds;                              // [2][CW] {x, v, x2, u | H}
-	lds_u64p sl = ex + 2 * CW;                                // [2][NW] the waves' (H, rank) of the exact-maximum scan
-	lds_i32p bc = (lds_i32p)(sl + 2 * NW);                    // 16 words for the walk
+	lds_u64p bnd = (lds_u64p)lds;                             // [2][NW] {x, v, x2 | H} of the last cell of a wave's last lane
+	lds_u64p sl = bnd + 2 * NW;                               // [2][NW] the waves' (H, rank) of the exact-maximum scan
+	lds_u64p one = sl + 2 * NW;                               // [2][4] single cells: H[st0], H[tlen - 1], v[last_H0_t], u[last_H0_t + 1]
+	lds_i32p bc = (lds_i32p)(one + 2 * 4);                    // 16 words for the walk
 	lds_u8p sq = (lds_u8p)(bc + 16);                          // the reversed query's codes
-	lds_u8p stg = sq + WG_SEQ_LDS;                            // the target's
+	lds_u8p stg = sq + seq_lds;                               // the target's
 	const bool approx_max = (flag & EZ_APPROX_MAX) != 0, right = (flag & EZ_RIGHT) != 0;
-	ez.max = 0, ez.zdropped = 0, ez.max_q = ez.max_t = ez.mqe_t = -1, ez.mqe = ez.score = DP_NEG_INF, ez.reach_end = 0, ez.n_cigar = 0;
+	// ksw2's `ez`, field by field in scalars of this function (the caller's struct lives in memory; every field is wave-uniform)
+	int z_max = 0, z_zdropped = 0, z_max_q = -1, z_max_t = -1, z_mqe_t = -1, z_mqe = DP_NEG_INF, z_score = DP_NEG_INF, z_reach_end = 0;
 	const int qe = q + e;
 	if (w < 0) w = tlen > qlen ? tlen : qlen;
 	const int wl = w, wr = w;
@@ -1382,69 +1405,87 @@ __device__ void ksw_wg(int qlen, int tlen, const uint8_t *sf_g, const uint8_t *q
 	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
 	const int T = (tlen + 15) / 16 * 16, Q = (qlen + 15) / 16 * 16 + 32;
 	__syncthreads();                                          // (the LDS may still hold the previous call's walk)
-	for (int i = lane; i < T; i += CW) stg[i] = sf_g[i];
-	for (int i = lane; i < Q; i += CW) sq[i] = qr_g[i];
+	for (int i = lane; i < T; i += 64 * NW) stg[i] = sf_g[i];
+	for (int i = lane; i < Q; i += 64 * NW) sq[i] = qr_g[i];
 	if (lane < 2 * NW) sl[lane] = 0;
 	__syncthreads();
 
-	// this thread's cell
-	int t_mine = -1 + ((lane + 1) & M);
-	int tb = t_mine >= 0 && t_mine < T ? (int)stg[t_mine] : 0;
-	int cu = -q - e, cv = -q - e, cx = -q - e, cy = -q - e, cx2 = -q2 - e2, cy2 = -q2 - e2, cs = 0, cH = DP_NEG_INF;
+	// this thread's cells: t0 .. t0 + C - 1
+	int t0 = -16 + ((lane * C + 16) & M);
+	int tb[C], cu[C], cv[C], cx[C], cy[C], cx2[C], cy2[C], cs[C], cH[C];
+#pragma unroll
+	for (int c = 0; c < C; ++c) {
+		tb[c] = t0 + c >= 0 && t0 + c < T ? (int)stg[t0 + c] : 0;
+		cu[c] = cv[c] = cx[c] = cy[c] = -q - e, cx2[c] = cy2[c] = -q2 - e2, cs[c] = 0, cH[c] = DP_NEG_INF;
+	}
 	unsigned long long wkey = 0;                              // the wave's exact-maximum key of the step before (uniform)
 	int last_st = -1, last_en = -1, H0 = 0, last_H0_t = 0;
 	int p_st = 0, p_en = 0, p_st0 = 0, p_en0 = 0;
 	const int n_r = qlen + tlen - 1;
 	for (int r = 0;; ++r) {
 		// ---- the cells as step r - 1 left them, for whoever reads another thread's
-		lds_u64p exb = ex + (r & 1) * CW;
-		lds_u64p slb = sl + (r & 1) * NW;
-		exb[lane] = (unsigned long long)((unsigned)(cx & 0xff) | (unsigned)(cv & 0xff) << 8 | (unsigned)(cx2 & 0xff) << 16 | (unsigned)(cu & 0xff) << 24)
-		            | (unsigned long long)(unsigned)cH << 32;
+		lds_u64p bndb = bnd + (r & 1) * NW, slb = sl + (r & 1) * NW, oneb = one + (r & 1) * 4;
+		const unsigned top = (unsigned)(cx[C - 1] & 0xff) | (unsigned)(cv[C - 1] & 0xff) << 8 | (unsigned)(cx2[C - 1] & 0xff) << 16;
+		if ((lane & 63) == 63) bndb[wv] = (unsigned long long)top | (unsigned long long)(unsigned)cH[C - 1] << 32;
 		if ((lane & 63) == 0) slb[wv] = wkey;
+#pragma unroll
+		for (int c = 0; c < C; ++c) {
+			const int t = t0 + c;
+			if (!approx_max) {
+				if (t == p_st0) oneb[0] = (unsigned long long)(unsigned)cH[c] << 32;
+				if (t == tlen - 1) oneb[1] = (unsigned long long)(unsigned)cH[c] << 32;
+			} else {
+				if (t == last_H0_t) oneb[2] = (unsigned)(cv[c] & 0xff);
+				if (t == last_H0_t + 1) oneb[3] = (unsigned)(cu[c] & 0xff);
+			}
+		}
 		__syncthreads();
 		// ---- what ksw2 does after the cells of an anti-diagonal, for step r - 1
 		if (r > 0) {
 			const int rp = r - 1;
 			if (!approx_max) {
-				int max_H, max_t;
-				if (rp > 0) {
-					// the largest of the waves' keys: a row of 16 lanes reads them, a prefix maximum along the row
-					unsigned long long k = slb[lane & (NW - 1)];
+				// the largest of the waves' keys: a row of 16 lanes reads them, a prefix maximum along the row
+				unsigned long long k = slb[lane & (NW - 1)];
 #define MNC_KEY_STEP(ctrl) { const unsigned lo = (unsigned)MNC_DPPW(0, (int)(unsigned)k, ctrl, 0xf), hi = (unsigned)MNC_DPPW(0, (int)(unsigned)(k >> 32), ctrl, 0xf); \
 	const unsigned long long o = (unsigned long long)hi << 32 | lo; k = o > k ? o : k; }
-					if constexpr (NW > 1) MNC_KEY_STEP(0x111)
-					if constexpr (NW > 2) MNC_KEY_STEP(0x112)
-					if constexpr (NW > 4) MNC_KEY_STEP(0x114)
-					if constexpr (NW > 8) MNC_KEY_STEP(0x118)
+				if constexpr (NW > 1) MNC_KEY_STEP(0x111)
+				if constexpr (NW > 2) MNC_KEY_STEP(0x112)
+				if constexpr (NW > 4) MNC_KEY_STEP(0x114)
+				if constexpr (NW > 8) MNC_KEY_STEP(0x118)
 #undef MNC_KEY_STEP
-					const unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, NW - 1), khi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), NW - 1);
-					max_H = (int)(khi ^ 0x80000000u);
-					const unsigned mr = ~klo;
-					const int en1 = p_st0 + (p_en0 - p_st0) / 4 * 4;
-					if (mr == 0) max_t = p_en0;
-					else if (mr < 1u + 4u * 0x1000000u) { const unsigned kk = mr - 1u; max_t = p_st0 + (int)((kk & 0xffffffu) * 4u + (kk >> 24)); }
-					else max_t = en1 + (int)(mr - 1u - 4u * 0x1000000u);
-				} else max_H = (int)(unsigned)(exb[0] >> 32), max_t = 0;
+				const unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, NW - 1), khi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), NW - 1);
+				const int max_H = (int)(khi ^ 0x80000000u);
+				const unsigned mr = ~klo;
+				const int en1 = p_st0 + (p_en0 - p_st0) / 4 * 4;
+				int max_t;
+				if (mr == 0) max_t = p_en0;
+				else if (mr < 1u + 4u * 0x1000000u) { const unsigned kk = mr - 1u; max_t = p_st0 + (int)((kk & 0xffffffu) * 4u + (kk >> 24)); }
+				else max_t = en1 + (int)(mr - 1u - 4u * 0x1000000u);
 				if (rp - p_st0 == qlen - 1) {
-					const int h = (int)(unsigned)(exb[p_st0 & M] >> 32);
-					if (h > ez.mqe) ez.mqe = h, ez.mqe_t = p_st0;
+					const int h = uni_hi(oneb[0]);
+					if (h > z_mqe) z_mqe = h, z_mqe_t = p_st0;
 				}
-				if (apply_zdrop(ez, max_H, rp, max_t, zdrop, e2)) break;
-				if (rp == qlen + tlen - 2 && p_en0 == tlen - 1) ez.score = (int)(unsigned)(exb[(tlen - 1) & M] >> 32);
+				// ksw_apply_zdrop
+				if (max_H > z_max) z_max = max_H, z_max_t = max_t, z_max_q = rp - max_t;
+				else if (max_t >= z_max_t && rp - max_t >= z_max_q) {
+					const int tl = max_t - z_max_t, ql = (rp - max_t) - z_max_q;
+					const int l = tl > ql ? tl - ql : ql - tl;
+					if (zdrop >= 0 && z_max - max_H > zdrop + l * e2) { z_zdropped = 1; break; }
+				}
+				if (rp == qlen + tlen - 2 && p_en0 == tlen - 1) z_score = uni_hi(oneb[1]);
 			} else {
 				if (rp > 0) {
+					const int d0 = I8(uni_lo(oneb[2])), d1 = I8(uni_lo(oneb[3]));
 					if (last_H0_t >= p_st0 && last_H0_t <= p_en0 && last_H0_t + 1 >= p_st0 && last_H0_t + 1 <= p_en0) {
-						const int d0 = I8((unsigned)exb[last_H0_t & M] >> 8), d1 = I8((unsigned)exb[(last_H0_t + 1) & M] >> 24);
 						if (d0 > d1) H0 += d0;
 						else H0 += d1, ++last_H0_t;
 					} else if (last_H0_t >= p_st0 && last_H0_t <= p_en0) {
-						H0 += I8((unsigned)exb[last_H0_t & M] >> 8);
+						H0 += d0;
 					} else {
-						++last_H0_t, H0 += I8((unsigned)exb[last_H0_t & M] >> 24);
+						++last_H0_t, H0 += d1;
 					}
-				} else H0 = I8((unsigned)exb[0] >> 8) - qe, last_H0_t = 0;
-				if (rp == qlen + tlen - 2 && p_en0 == tlen - 1) ez.score = H0;
+				} else H0 = I8(uni_lo(oneb[2])) - qe, last_H0_t = 0;
+				if (rp == qlen + tlen - 2 && p_en0 == tlen - 1) z_score = H0;
 			}
 			last_st = p_st, last_en = p_en;
 		}
@@ -1454,100 +1495,122 @@ __device__ void ksw_wg(int qlen, int tlen, const uint8_t *sf_g, const uint8_t *q
 		if (en > r) en = r;
 		if (st < (r - wr + 1) >> 1) st = (r - wr + 1) >> 1;
 		if (en > (r + wl) >> 1) en = (r + wl) >> 1;
-		if (st > en) { ez.zdropped = 1; break; }
+		if (st > en) { z_zdropped = 1; break; }
 		const int st0 = st, en0 = en;
 		st = st / 16 * 16, en = (en + 16) / 16 * 16 - 1;
-		// ---- the cell below, as the last step left it (the thread of the cell at st: ksw2's x1, x21, v1)
-		const unsigned long long nb = exb[(lane - 1) & M];
-		// ---- the window moves up with st: a thread whose cell has left it takes a fresh one at the top
+		// ---- the cell below this thread's first, as the last step left it: the lane below, or the wave below through LDS
+		unsigned nb = (unsigned)MNC_DPPW(0, (int)top, 0x138, 0xf);          // wave_shr:1
+		int nbH = MNC_DPPW(0, cH[C - 1], 0x138, 0xf);
+		if ((lane & 63) == 0) { const unsigned long long b = bndb[(wv - 1) & (NW - 1)]; nb = (unsigned)b, nbH = (int)(unsigned)(b >> 32); }
+		// ---- the window moves up with st: a thread whose cells have left it takes fresh ones at the top
 		{
-			const int base = st - 1;
-			const int tn = base + ((lane - base) & M);
-			if (tn != t_mine) {
-				t_mine = tn;
-				cu = cv = cx = cy = -q - e, cx2 = cy2 = -q2 - e2, cs = 0, cH = DP_NEG_INF;
-				tb = tn < T ? (int)stg[tn] : 0;
+			const int base = st - 16;
+			const int tn = base + ((lane * C - base) & M);
+			if (tn != t0) {
+				t0 = tn;
+#pragma unroll
+				for (int c = 0; c < C; ++c) {
+					cu[c] = cv[c] = cx[c] = cy[c] = -q - e, cx2[c] = cy2[c] = -q2 - e2, cs[c] = 0, cH[c] = DP_NEG_INF;
+					tb[c] = tn + c < T ? (int)stg[tn + c] : 0;
+				}
 			}
 		}
-		const int t = t_mine;
-		int xt1 = I8((unsigned)nb), vt1 = I8((unsigned)nb >> 8), x2t1 = I8((unsigned)nb >> 16);
-		const int nbH = (int)(unsigned)(nb >> 32);
 		const int v_edge = r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
-		if (t == st) {
+		// x, v, x2 of the cell below cell c: the neighbour's for c = 0 (ksw2's x1, x21, v1 at st), else this thread's own, OLD
+		int xb = I8(nb), vb = I8(nb >> 8), x2b = I8(nb >> 16), Hb = nbH;
+		if (t0 == st) {
 			if (st > 0) {
-				if (!(st - 1 >= last_st && st - 1 <= last_en)) xt1 = -q - e, x2t1 = -q2 - e2, vt1 = -q - e;
-			} else xt1 = -q - e, x2t1 = -q2 - e2, vt1 = v_edge;
+				if (!(st - 1 >= last_st && st - 1 <= last_en)) xb = -q - e, x2b = -q2 - e2, vb = -q - e;
+			} else xb = -q - e, x2b = -q2 - e2, vb = v_edge;
 		}
-		if (en >= r && t == r) cy = -q - e, cy2 = -q2 - e2, cu = v_edge;
-		// scores: 16-lane strides from st0
-		{
-			const int n16 = (en0 - st0) / 16 + 1;
+		const bool in_row = t0 >= st && t0 <= en;             // all C cells, or none
+		const int n16 = (en0 - st0) / 16 + 1, en1 = st0 + (en0 - st0) / 4 * 4;
+		int h_best = DP_NEG_INF - 1;
+		unsigned rank_best = 0xffffffffu;
+		unsigned dpack = 0;
+#pragma unroll
+		for (int c = 0; c < C; ++c) {
+			const int t = t0 + c;
+			const int x_old = cx[c], v_old = cv[c], x2_old = cx2[c], H_old = cH[c];
+			if (en >= r && t == r) cy[c] = -q - e, cy2[c] = -q2 - e2, cu[c] = v_edge;
+			// scores: 16-lane strides from st0
 			if (t >= st0 && t < st0 + n16 * 16) {
 				const int qb = sq[qlen - 1 - r + t];
-				cs = (tb == 4 || qb == 4) ? sc_N : tb == qb ? sc_mch : sc_mis;
+				cs[c] = (tb[c] == 4 || qb == 4) ? sc_N : tb[c] == qb ? sc_mch : sc_mis;
 			}
+			// the cell (every cell of the anti-diagonal reads old values only)
+			if (in_row) {
+				int zz = cs[c];
+				int a = I8(xb + vb), b = I8(cy[c] + cu[c]), a2 = I8(x2b + vb), b2 = I8(cy2[c] + cu[c]), d, tmp;
+				if (!right) {
+					d = a > zz ? 1 : 0;  zz = zz > a ? zz : a;
+					d = b > zz ? 2 : d;  zz = zz > b ? zz : b;
+					d = a2 > zz ? 3 : d; zz = zz > a2 ? zz : a2;
+					d = b2 > zz ? 4 : d; zz = zz > b2 ? zz : b2;
+				} else {
+					d = zz > a ? 0 : 1;  zz = zz > a ? zz : a;
+					d = zz > b ? d : 2;  zz = zz > b ? zz : b;
+					d = zz > a2 ? d : 3; zz = zz > a2 ? zz : a2;
+					d = zz > b2 ? d : 4; zz = zz > b2 ? zz : b2;
+				}
+				zz = zz < sc_mch ? zz : sc_mch;
+				const int ut = cu[c];
+				cu[c] = I8(zz - vb), cv[c] = I8(zz - ut);
+				tmp = I8(zz - q), a = I8(a - tmp), b = I8(b - tmp);
+				tmp = I8(zz - q2), a2 = I8(a2 - tmp), b2 = I8(b2 - tmp);
+				if (!right) {
+					cx[c] = I8((a > 0 ? a : 0) - qe);            d |= a > 0 ? 0x08 : 0;
+					cy[c] = I8((b > 0 ? b : 0) - qe);            d |= b > 0 ? 0x10 : 0;
+					cx2[c] = I8((a2 > 0 ? a2 : 0) - (q2 + e2));  d |= a2 > 0 ? 0x20 : 0;
+					cy2[c] = I8((b2 > 0 ? b2 : 0) - (q2 + e2));  d |= b2 > 0 ? 0x40 : 0;
+				} else {
+					cx[c] = I8((0 > a ? 0 : a) - qe);            d |= 0 > a ? 0 : 0x08;
+					cy[c] = I8((0 > b ? 0 : b) - qe);            d |= 0 > b ? 0 : 0x10;
+					cx2[c] = I8((0 > a2 ? 0 : a2) - (q2 + e2));  d |= 0 > a2 ? 0 : 0x20;
+					cy2[c] = I8((0 > b2 ? 0 : b2) - (q2 + e2));  d |= 0 > b2 ? 0 : 0x40;
+				}
+				dpack |= (unsigned)d << (8 * c);
+			}
+			if (!approx_max) {
+				// H[en0] from the OLD H[en0 - 1]; H[t] += v[t] for t in [st0, en0); the maximum in the SSE scan's tie order
+				int h = DP_NEG_INF - 1;
+				unsigned rank = 0xffffffffu;
+				if (r > 0) {
+					if (t >= st0 && t < en0) {
+						cH[c] += cv[c], h = cH[c];
+						rank = t < en1 ? 1u + ((unsigned)(t - st0) & 3u) * 0x1000000u + ((unsigned)(t - st0) >> 2)
+						               : 1u + 4u * 0x1000000u + (unsigned)(t - en1);
+					} else if (t == en0) {
+						cH[c] = en0 > 0 ? Hb + cu[c] : cH[c] + cv[c], h = cH[c], rank = 0;   // en0 comes first in the scan
+					}
+				} else if (t == 0) cH[c] = cv[c] - qe, h = cH[c], rank = 0;
+				if (h > h_best || (h == h_best && rank < rank_best)) h_best = h, rank_best = rank;
+			}
+			xb = x_old, vb = v_old, x2b = x2_old, Hb = H_old;   // ... of the next cell up
 		}
-		// the cell (every cell of the anti-diagonal reads old values only: no order among the threads)
-		if (t >= st && t <= en) {
-			int zz = cs;
-			int a = I8(xt1 + vt1), b = I8(cy + cu), a2 = I8(x2t1 + vt1), b2 = I8(cy2 + cu), d, tmp;
-			if (!right) {
-				d = a > zz ? 1 : 0;  zz = zz > a ? zz : a;
-				d = b > zz ? 2 : d;  zz = zz > b ? zz : b;
-				d = a2 > zz ? 3 : d; zz = zz > a2 ? zz : a2;
-				d = b2 > zz ? 4 : d; zz = zz > b2 ? zz : b2;
-			} else {
-				d = zz > a ? 0 : 1;  zz = zz > a ? zz : a;
-				d = zz > b ? d : 2;  zz = zz > b ? zz : b;
-				d = zz > a2 ? d : 3; zz = zz > a2 ? zz : a2;
-				d = zz > b2 ? d : 4; zz = zz > b2 ? zz : b2;
-			}
-			zz = zz < sc_mch ? zz : sc_mch;
-			const int ut = cu;
-			cu = I8(zz - vt1), cv = I8(zz - ut);
-			tmp = I8(zz - q), a = I8(a - tmp), b = I8(b - tmp);
-			tmp = I8(zz - q2), a2 = I8(a2 - tmp), b2 = I8(b2 - tmp);
-			if (!right) {
-				cx = I8((a > 0 ? a : 0) - qe);            d |= a > 0 ? 0x08 : 0;
-				cy = I8((b > 0 ? b : 0) - qe);            d |= b > 0 ? 0x10 : 0;
-				cx2 = I8((a2 > 0 ? a2 : 0) - (q2 + e2));  d |= a2 > 0 ? 0x20 : 0;
-				cy2 = I8((b2 > 0 ? b2 : 0) - (q2 + e2));  d |= b2 > 0 ? 0x40 : 0;
-			} else {
-				cx = I8((0 > a ? 0 : a) - qe);            d |= 0 > a ? 0 : 0x08;
-				cy = I8((0 > b ? 0 : b) - qe);            d |= 0 > b ? 0 : 0x10;
-				cx2 = I8((0 > a2 ? 0 : a2) - (q2 + e2));  d |= 0 > a2 ? 0 : 0x20;
-				cy2 = I8((0 > b2 ? 0 : b2) - (q2 + e2));  d |= 0 > b2 ? 0 : 0x40;
-			}
-			p[(size_t)r * ncol + (size_t)(t - st)] = (uint8_t)d;
+		if (in_row) {
+			PP pr = p + (size_t)r * ncol + (size_t)(t0 - st);
+			if constexpr (C == 4) *reinterpret_cast<uint32_t*>(&pr[0]) = dpack;
+			else if constexpr (C == 2) *reinterpret_cast<uint16_t*>(&pr[0]) = (uint16_t)dpack;
+			else pr[0] = (uint8_t)dpack;
 		}
 		if (!approx_max) {
-			// H[en0] from the OLD H[en0 - 1]; H[t] += v[t] for t in [st0, en0); the maximum in the SSE scan's tie order
-			int h = DP_NEG_INF - 1;
-			unsigned rank = 0xffffffffu;
-			if (r > 0) {
-				const int en1 = st0 + (en0 - st0) / 4 * 4;
-				if (t >= st0 && t < en0) {
-					cH += cv, h = cH;
-					rank = t < en1 ? 1u + ((unsigned)(t - st0) & 3u) * 0x1000000u + ((unsigned)(t - st0) >> 2)
-					               : 1u + 4u * 0x1000000u + (unsigned)(t - en1);
-				} else if (t == en0) {
-					cH = en0 > 0 ? nbH + cu : cH + cv, h = cH, rank = 0;       // en0 comes first in the scan
-				}
-			} else if (t == 0) cH = cv - qe, h = cH, rank = 0;
-			const int mh = wave_max_dpp(h);
-			const int mrk = wave_max_dpp((int)(h == mh ? ~rank : 0u) ^ INT32_MIN);     // the smallest rank among the wave's best
+			const int mh = wave_max_dpp(h_best);
+			const int mrk = wave_max_dpp((int)(h_best == mh ? ~rank_best : 0u) ^ INT32_MIN);   // the smallest rank among the wave's best
 			wkey = (unsigned long long)((unsigned)mh ^ 0x80000000u) << 32 | ((unsigned)mrk ^ 0x80000000u);
 		}
 		p_st = st, p_en = en, p_st0 = st0, p_en0 = en0;
 	}
 	__syncthreads();                                          // the direction bytes are written; the sequences' LDS is free
 	int i0 = -1, j0 = -1;
-	if (!ez.zdropped && !(flag & EZ_EXTZ_ONLY)) i0 = tlen - 1, j0 = qlen - 1;
-	else if (!ez.zdropped && (flag & EZ_EXTZ_ONLY) && ez.mqe + end_bonus > ez.max) ez.reach_end = 1, i0 = ez.mqe_t, j0 = qlen - 1;
-	else if (ez.max_t >= 0 && ez.max_q >= 0) i0 = ez.max_t, j0 = ez.max_q;
+	if (!z_zdropped && !(flag & EZ_EXTZ_ONLY)) i0 = tlen - 1, j0 = qlen - 1;
+	else if (!z_zdropped && (flag & EZ_EXTZ_ONLY) && z_mqe + end_bonus > z_max) z_reach_end = 1, i0 = z_mqe_t, j0 = qlen - 1;
+	else if (z_max_t >= 0 && z_max_q >= 0) i0 = z_max_t, j0 = z_max_q;
 	int n_cigar = 0;
 	if (i0 >= 0 && j0 >= 0) n_cigar = walk_wg<NW>(qlen, tlen, wl, wr, ncol, p, cig, i0, j0, flag, sq, bc);
-	ez.n_cigar = wg_bcast0<NW>(n_cigar);
+	n_cigar = wg_bcast0<NW>(n_cigar);
+	ez_out.max = z_max, ez_out.zdropped = z_zdropped, ez_out.max_q = z_max_q, ez_out.max_t = z_max_t, ez_out.mqe = z_mqe, ez_out.mqe_t = z_mqe_t;
+	ez_out.score = z_score, ez_out.reach_end = z_reach_end, ez_out.n_cigar = n_cigar;
 	st_order<false, NW>();
 }
 
@@ -1632,9 +1695,13 @@ __host__ __device__ __forceinline__ AlignWs align_ws(long long state_max, long l
 // trips, only other waves hide them) and hands what does not fit to pass 2's list.
 // NW: waves per call.  The launches for the long calls (the workspace layouts) put four waves on one: a call of 1 500 x
 // 3 000 bases is 4 500 anti-diagonals of up to 751 cells, 27 ms on a single wave that a batch of divergent reads waits for.
-template <int NW>
+// C > 0: the calls that fit run with their cells in registers (ksw_wg<NW, C>, `lds_bytes` = LDS bytes per sequence there).
+// regime 1: this launch only works when the pass has at most `regime_n` calls, regime 2: only when it has more -- the long
+// calls are launched in both forms (few calls: sixteen waves each, every call as fast as it goes; many: four waves with
+// four cells a thread, four times as many side by side), and the count is only known on the device.
+template <int NW, int C = 0>
 __global__ __launch_bounds__(64 * NW) void mnc_dp_align(Batch B, uint8_t *ws_all, long long state_max, long long p_max, long long cig_max,
-                                                   int lds_bytes, int lds_p, int lds_cig, int big_pass)
+                                                   int lds_bytes, int lds_p, int lds_cig, int big_pass, int regime = 0, int regime_n = 0)
 {
 	extern __shared__ __align__(16) uint8_t smem[];
 	const int lane = threadIdx.x;
@@ -1647,6 +1714,7 @@ __global__ __launch_bounds__(64 * NW) void mnc_dp_align(Batch B, uint8_t *ws_all
 	if (big_pass != 0) __builtin_amdgcn_s_setprio(3);         // a few long calls on single waves beside chip-filling kernels: first in line for issue
 	const unsigned long long n_items = big_pass == 0 ? B.dp_ctr[20] : big_pass == 1 ? B.dp_ctr[6] : big_pass == 3 ? B.dp_ctr[28] : big_pass == 4 ? B.dp_ctr[56] : big_pass == 5 ? B.dp_ctr[58] : B.dp_ctr[12];
 	const int ctr_q = big_pass == 0 ? 21 : big_pass == 1 ? 7 : big_pass == 3 ? 29 : big_pass == 4 ? 57 : big_pass == 5 ? 59 : 15;
+	if ((regime == 1 && n_items > (unsigned long long)regime_n) || (regime == 2 && n_items <= (unsigned long long)regime_n)) return;   // the other form's
 	for (;;) {
 		unsigned long long qi = 0;
 		if (lane == 0) qi = atomicAdd(&B.dp_ctr[ctr_q], 1ULL);
@@ -1667,7 +1735,7 @@ __global__ __launch_bounds__(64 * NW) void mnc_dp_align(Batch B, uint8_t *ws_all
 			int ncw = g.qlen < g.tlen ? g.qlen : g.tlen;
 			{ const int wb = g.w < 0 ? (g.tlen > g.qlen ? g.tlen : g.qlen) : g.w; ncw = ((ncw < wb + 1 ? ncw : wb + 1) + 15) / 16 + 1; }
 			const long long p_bytes = ((long long)(g.qlen + g.tlen - 1) * ncw + 1) * 16;
-			const bool in_lds = 12 * T + Q <= lds_bytes;
+			const bool in_lds = NW == 1 && 12 * T + Q <= lds_bytes;
 			// small calls (the extensions of most reads) keep direction bytes and CIGAR in LDS as well
 			const bool all_lds = in_lds && p_bytes <= lds_p && g.qlen + g.tlen + 2 <= lds_cig;
 			if (big_pass == 0 && !all_lds) {                        // not for the small layout: pass 2 takes it
@@ -1691,15 +1759,15 @@ __global__ __launch_bounds__(64 * NW) void mnc_dp_align(Batch B, uint8_t *ws_all
 				for (int i = lane; i < Q; i += 64 * NW)
 					qr[i] = i < g.qlen ? (uint8_t)qcode(read, rlen, g.rev, g.kind == 0 ? g.qs + i : g.qs + g.qlen - 1 - i) : 0;
 				st_order<false, NW>();
-				// the widest workgroups hold the cells in registers (ksw_wg) unless the call's anti-diagonals or sequences outgrow that
-				// form; debug_route bit 6: never (the workspace form on this many waves, for the tests)
+				// the cells in registers (ksw_wg) unless the call's anti-diagonals or sequences outgrow that form; debug_route
+				// bit 6: never (the workspace form on this many waves, for the tests)
 				bool on_wg = false;
-				if constexpr (NW >= 8) on_wg = !(B.debug_route & 64) && wg_fits<NW>(g.qlen, g.tlen, g.w);
+				if constexpr (C > 0) on_wg = !(B.debug_route & 64) && wg_fits<NW, C>(g.qlen, g.tlen, g.w, lds_bytes);
 				auto call = [&](int zdrop, int end_bonus, int flag) {
-					if constexpr (NW >= 8) {
+					if constexpr (C > 0) {
 						if (on_wg) {
-							ksw_wg<NW>(g.qlen, g.tlen, (const uint8_t*)sf, (const uint8_t*)qr, (lds_u8p)smem, pbuf, cg, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2,
-							           sc_mch, sc_mis, sc_N, g.w, zdrop, end_bonus, flag, ez);
+							ksw_wg<NW, C>(g.qlen, g.tlen, (const uint8_t*)sf, (const uint8_t*)qr, (lds_u8p)smem, lds_bytes, pbuf, cg, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2,
+							              sc_mch, sc_mis, sc_N, g.w, zdrop, end_bonus, flag, ez);
 							return;
 						}
 					}
@@ -2576,27 +2644,38 @@ void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work,
 	}
 }
 size_t dp_align_ws_bytes(long long state_max, long long p_max, long long cig_max) { return align_ws(state_max, p_max, cig_max).total; }
-constexpr int ALIGN_WG_WAVES = 16;            // waves on one of the literal kernel's long calls (ksw_wg: one cell per thread, up to ~970 per anti-diagonal)
+// the literal kernel's long calls with the cells in registers: <16, 1> and <4, 4> (ksw_wg)
+constexpr int ALIGN_SEQ_WIDE = 40960, ALIGN_SEQ_NARROW = 16384;   // LDS bytes per sequence in the two forms
+constexpr int ALIGN_FEW = 256;                                    // up to this many calls in a pass: sixteen waves each (one call per CU at a time)
 int dp_align_prepare(int lds_bytes)
 {
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-	if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align<ALIGN_WG_WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, wg_lds_bytes<ALIGN_WG_WAVES>());
+	if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align<16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, wg_lds_bytes<16>(ALIGN_SEQ_WIDE));
+	if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, wg_lds_bytes<4>(ALIGN_SEQ_NARROW));
 	if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return MNC_ERR_HIP; }
 	return MNC_OK;
 }
 void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max, long long p_max, long long cig_max,
                      int lds_state, int lds_p, int lds_cig, int big_pass, hipStream_t st)
 {
-	// the long calls (passes 1, 3, 4, 5: state in the workspace) on several waves each: sixteen with the cells in registers
-	// (ksw_wg; the small-workspace class, pass 3, and debug_route bit 7: four waves on the workspace); debug_route bit 5:
-	// one wave, as the rest
-	if ((big_pass == 1 || big_pass >= 4) && !(B.debug_route & (32 | 128)))
-		hipLaunchKernelGGL(mnc_dp_align<ALIGN_WG_WAVES>, dim3(n_wg), dim3(64 * ALIGN_WG_WAVES), (size_t)wg_lds_bytes<ALIGN_WG_WAVES>(), st, B, ws, state_max, p_max, cig_max, 0, 0, 0, big_pass);
-	else if ((big_pass == 1 || big_pass >= 3) && !(B.debug_route & 32))
-		hipLaunchKernelGGL(mnc_dp_align<4>, dim3(n_wg), dim3(256), 0, st, B, ws, state_max, p_max, cig_max, 0, 0, 0, big_pass);
+	// The long calls (passes 1, 3, 4, 5: direction bytes in the workspace) on several waves each, cells in registers (ksw_wg):
+	// both forms are launched, the pass's call count -- known on the device only -- decides which of them works.
+	// debug_route bit 5: one wave each, as the rest; 7: four waves with the cells in the workspace (round 3's form); 8:
+	// always the sixteen-wave form; 9: always the four-wave form; (6: the launches below, but cells in the workspace)
+	const bool long_pass = big_pass == 1 || big_pass >= 3;
+	if (long_pass && !(B.debug_route & (32 | 128))) {
+		const int regime16 = (B.debug_route & 256) ? 0 : (B.debug_route & 512) ? -1 : 1, regime4 = (B.debug_route & 512) ? 0 : (B.debug_route & 256) ? -1 : 2;
+		if (regime16 >= 0)
+			hipLaunchKernelGGL((mnc_dp_align<16, 1>), dim3(n_wg), dim3(1024), (size_t)wg_lds_bytes<16>(ALIGN_SEQ_WIDE), st, B, ws, state_max, p_max, cig_max,
+			                   ALIGN_SEQ_WIDE, 0, 0, big_pass, regime16, ALIGN_FEW);
+		if (regime4 >= 0)
+			hipLaunchKernelGGL((mnc_dp_align<4, 4>), dim3(n_wg), dim3(256), (size_t)wg_lds_bytes<4>(ALIGN_SEQ_NARROW), st, B, ws, state_max, p_max, cig_max,
+			                   ALIGN_SEQ_NARROW, 0, 0, big_pass, regime4, ALIGN_FEW);
+	} else if (long_pass && !(B.debug_route & 32))
+		hipLaunchKernelGGL((mnc_dp_align<4>), dim3(n_wg), dim3(256), 0, st, B, ws, state_max, p_max, cig_max, 0, 0, 0, big_pass, 0, 0);
 	else
-		hipLaunchKernelGGL(mnc_dp_align<1>, dim3(n_wg), dim3(64), (size_t)lds_state + lds_p + lds_cig * 4, st, B, ws, state_max, p_max, cig_max,
-		                   lds_state, lds_p, lds_cig, big_pass);
+		hipLaunchKernelGGL((mnc_dp_align<1>), dim3(n_wg), dim3(64), (size_t)lds_state + lds_p + lds_cig * 4, st, B, ws, state_max, p_max, cig_max,
+		                   lds_state, lds_p, lds_cig, big_pass, 0, 0);
 }
 void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_list, int max_read_len, int n_wg, hipStream_t st)
 {

@@ -79,7 +79,10 @@ def test_module_surface_matches_reference():
     assert list(sig.parameters)[:8] == ["query_folder", "indexes_paths", "mode", "mapping_quality", "overnight",
                                         "n_threads", "focus_species", "output_folder"]
     assert sig.parameters["mapping_quality"].default == 60 and sig.parameters["overnight"].default is False
-    assert sig.parameters["mode"].default is None
+    assert sig.parameters["mode"].default is None and sig.parameters["n_threads"].default is None
+    # n_threads goes to ThreadPool as it is (aligner.py:89: None = one worker per core)
+    src = inspect.getsource(aligner.multi_threaded_aligner)
+    assert "ThreadPool(n_threads)" in src
     asig = inspect.signature(aligner.aligner)
     assert list(asig.parameters) == ["sample", "sample_name", "index", "mode", "hits_folder", "mapping_quality",
                                      "overnight", "focus_species", "mapped_folder", "unmapped_folder",

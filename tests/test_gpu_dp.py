@@ -266,9 +266,9 @@ def test_results_do_not_depend_on_scheduling(capi, world):
 
 
 @pytest.mark.parametrize("route", [0x20000, 0x40000, 0x80000 | 0x100000, 0x20000 | 0x40000 | 0x80000 | 0x100000, 0x400000,
-                                   20 << 8 | 20 << 24, 48 << 8 | 48 << 24, 0x10, 0x800000, 0x20, 0x40, 0x80,
-                                   0x20 | 0x20000 | 0x40000 | 0x80000 | 0x100000, 0x40 | 0x20000 | 0x40000 | 0x80000 | 0x100000,
-                                   0x80 | 0x20000 | 0x40000 | 0x80000 | 0x100000])
+                                   20 << 8 | 20 << 24, 48 << 8 | 48 << 24, 0x10, 0x800000, 0x20, 0x8, 0x1, 0x40 | 0x8, 0x40 | 0x1, 0x80,
+                                   0x20 | 0x20000 | 0x40000 | 0x80000 | 0x100000, 0x8 | 0x20000 | 0x40000 | 0x80000 | 0x100000,
+                                   0x1 | 0x20000 | 0x40000 | 0x80000 | 0x100000, 0x80 | 0x20000 | 0x40000 | 0x80000 | 0x100000])
 def test_every_kernel_family_can_be_taken_out(capi, oracle, world, route):
     """The alignment stage sorts its kernel calls over several kernels (packed gap filling, packed extensions, the
     long-call kernels, the step-by-step extension kernel, ksw2's kernel literally).  With a family switched off its
@@ -276,8 +276,10 @@ def test_every_kernel_family_can_be_taken_out(capi, oracle, world, route):
     without the 42-cell tier of the banded kernel; the last two: the planner sends every gap filling to the widest / to
     the narrowest band first -- which tier proves a band is a matter of speed, never of the result; 0x10 / 0x800000: every
     region planned by the plan kernel's wave form / by its lane form -- a batch this small takes the wave form by itself;
-    The literal kernel's long calls run on a workgroup of sixteen waves with the cells in registers (ksw_wg); 0x20: on one
-    wave each, 0x40: on sixteen waves with the cells in the workspace, 0x80: on four.)"""
+    The literal kernel's long calls run on a workgroup with the cells in registers (ksw_wg): sixteen waves a call when a
+    pass has few calls, four waves with four cells a thread when it has many; 0x8 / 0x1: always the one / the other form,
+    0x40 with either: that launch shape with the cells in the workspace, 0x80: round 3's four waves on the workspace, 0x20: one
+    wave each.)"""
     reads = [synth.reads(world["seqs"], 40, 3000, seed=31, sub=800, ins=600, dele=600), synth.reads(world["seqs"], 60, 5000, seed=0x5EED + 9)]
     g0 = world["seqs"][0]
     rng = np.random.default_rng(3)
@@ -308,7 +310,7 @@ def test_reads_with_many_errors_use_every_workspace_class(capi, oracle, world):
     try:
         eng.set_debug(0x200000)
         _compare_dp(capi, oracle, world, b[: o[120]], o[:121], min_mapq=0)
-        for form in (0x20, 0x40, 0x80):                        # the literal kernel's long calls on one wave each; sixteen / four waves on the workspace
+        for form in (0x20, 0x8, 0x1, 0x80):                    # the literal kernel's long calls on one wave each; always sixteen / always four waves with the cells in registers; round 3's form
             eng.set_debug(form)
             _compare_dp(capi, oracle, world, b, o, min_mapq=0)
     finally:
