@@ -792,7 +792,15 @@ static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream
 	// per-kernel timers: only when everything runs on one stream (debug bit 0x10000)
 	const bool timed = e->profiling && s0 == s1;
 	auto mark = [&](int stage, int which) { if (timed) { (void)hipEventRecord(e->ev[stage][which], s0); if (which) e->ev_used[stage] = true; } };
-	// the long gaps first, on the batch's own stream: single waves (one call each, ~2 ms) that are on the chip
+	// the literal kernel's few long calls first of all, on a stream of their own (`s3`: the side stream whose hardware queue no
+	// other uses): a call of the sixteen-wave form needs a whole CU's registers at once -- behind the persistent workgroups
+	// of the gap-filling tiers it would wait until a CU has drained (measured: 13 ms of a block's 36)
+	if (s3 != s0) {
+		launch_dp_align(B, e->ws->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 1, s3);
+		launch_dp_align(B, e->ws->dp_ws_mid.as<uint8_t>(), DP_WG_MID, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, 0, 3, s3);
+		launch_dp_align(B, e->ws->dp_ws_huge.as<uint8_t>(), DP_WG_HUGE, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE, DP_LDS_BYTES, 0, 0, 5, s3);
+	}
+	// the long gaps next, on the batch's own stream: single waves (one call each, ~2 ms) that are on the chip
 	// before the persistent workgroups of the gap-filling tiers take the wave slots
 	if (s2 != s0) launch_dp_lfill(B, B.lfill_list, 31, 61, B.fill_fb, 12, e->ws->lfill_p.as<uint8_t>(), DP_WG_LFILL, s2);
 	mark(MNC_STAGE_DP_FILL_T1, 0);
@@ -818,10 +826,11 @@ static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream
 	// the long extensions: beside the long gaps in a micro-batch (on the stream of the literal kernel, which has little
 	// to do there), behind them on the batch's stream otherwise
 	launch_dp_lext(B, B.lext_list, 62, 63, B.fill_fb, 12, e->ws->lext_p.as<uint8_t>(), DP_WG_LEXT, B.n_reads < 4096 ? s3 : s2);
-	// the literal kernel's long calls on a stream of their own (`s3`: the side stream whose hardware queue no other uses)
-	launch_dp_align(B, e->ws->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 1, s3);
-	launch_dp_align(B, e->ws->dp_ws_mid.as<uint8_t>(), DP_WG_MID, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, 0, 3, s3);
-	launch_dp_align(B, e->ws->dp_ws_huge.as<uint8_t>(), DP_WG_HUGE, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE, DP_LDS_BYTES, 0, 0, 5, s3);
+	if (s3 == s0) {                                            // one kernel at a time (profiling): in their old place
+		launch_dp_align(B, e->ws->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 1, s3);
+		launch_dp_align(B, e->ws->dp_ws_mid.as<uint8_t>(), DP_WG_MID, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, 0, 3, s3);
+		launch_dp_align(B, e->ws->dp_ws_huge.as<uint8_t>(), DP_WG_HUGE, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE, DP_LDS_BYTES, 0, 0, 5, s3);
+	}
 	launch_dp_align(B, e->ws->dp_ws.as<uint8_t>(), 2 * DP_WG_SMALL, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS0_STATE, DP_LDS0_P, DP_LDS0_CIG, 0, s2);
 }
 // what the other kernels handed back, on the literal kernel

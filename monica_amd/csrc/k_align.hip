@@ -1271,6 +1271,16 @@ __device__ void ksw_wave(int qlen, int tlen, S8 mem, S32 H, PP p, CP cig,
 // <4, 4>: four times the calls side by side at ~1.5 times the time each (a batch of divergent reads has thousands).
 #define MNC_DPPW(old, src, ctrl, rmask) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rmask), 0xf, false)
 typedef __attribute__((address_space(3))) unsigned long long *lds_u64p;
+#ifdef MNC_WG_TIMING
+// profiling build only: cycles of thread 0 per phase of a call, summed over the calls -- [0] sequences into LDS, [1] the
+// anti-diagonals, [2] the walk, [3] calls, [4] anti-diagonals, [5] mm_test_zdrop on lane 0, [6] the kernel's own set-up of a call
+__device__ unsigned long long g_wg_cycles[8];
+#define WG_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define WG_ADD(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_wg_cycles[i], (unsigned long long)(v)); } while (0)
+#else
+#define WG_T(var) do {} while (0)
+#define WG_ADD(i, v) do {} while (0)
+#endif
 constexpr int WG_TILE = 128;               // the walk's LDS tile: anti-diagonals x target positions
 // LDS of a workgroup: [2][NW] boundary records | [2][NW] maximum keys | [2][4] single cells | 16 words of the walk | the
 // reversed query's codes | the target's (`seq` bytes each; at least the walk's tile together)
@@ -1404,6 +1414,7 @@ __device__ __attribute__((noinline)) void ksw_wg(int qlen, int tlen, const uint8
 	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
 	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
 	const int T = (tlen + 15) / 16 * 16, Q = (qlen + 15) / 16 * 16 + 32;
+	WG_T(tm0);
 	__syncthreads();                                          // (the LDS may still hold the previous call's walk)
 	for (int i = lane; i < T; i += 64 * NW) stg[i] = sf_g[i];
 	for (int i = lane; i < Q; i += 64 * NW) sq[i] = qr_g[i];
@@ -1422,7 +1433,10 @@ __device__ __attribute__((noinline)) void ksw_wg(int qlen, int tlen, const uint8
 	int last_st = -1, last_en = -1, H0 = 0, last_H0_t = 0;
 	int p_st = 0, p_en = 0, p_st0 = 0, p_en0 = 0;
 	const int n_r = qlen + tlen - 1;
+	WG_T(tm1);
+	int r_done = 0;
 	for (int r = 0;; ++r) {
+		r_done = r;
 		// ---- the cells as step r - 1 left them, for whoever reads another thread's
 		lds_u64p bndb = bnd + (r & 1) * NW, slb = sl + (r & 1) * NW, oneb = one + (r & 1) * 4;
 		const unsigned top = (unsigned)(cx[C - 1] & 0xff) | (unsigned)(cv[C - 1] & 0xff) << 8 | (unsigned)(cx2[C - 1] & 0xff) << 16;
@@ -1602,6 +1616,8 @@ __device__ __attribute__((noinline)) void ksw_wg(int qlen, int tlen, const uint8
 		p_st = st, p_en = en, p_st0 = st0, p_en0 = en0;
 	}
 	__syncthreads();                                          // the direction bytes are written; the sequences' LDS is free
+	WG_T(tm2);
+	(void)r_done;
 	int i0 = -1, j0 = -1;
 	if (!z_zdropped && !(flag & EZ_EXTZ_ONLY)) i0 = tlen - 1, j0 = qlen - 1;
 	else if (!z_zdropped && (flag & EZ_EXTZ_ONLY) && z_mqe + end_bonus > z_max) z_reach_end = 1, i0 = z_mqe_t, j0 = qlen - 1;
@@ -1609,6 +1625,8 @@ __device__ __attribute__((noinline)) void ksw_wg(int qlen, int tlen, const uint8
 	int n_cigar = 0;
 	if (i0 >= 0 && j0 >= 0) n_cigar = walk_wg<NW>(qlen, tlen, wl, wr, ncol, p, cig, i0, j0, flag, sq, bc);
 	n_cigar = wg_bcast0<NW>(n_cigar);
+	WG_T(tm3);
+	WG_ADD(0, tm1 - tm0); WG_ADD(1, tm2 - tm1); WG_ADD(2, tm3 - tm2); WG_ADD(3, 1); WG_ADD(4, r_done);
 	ez_out.max = z_max, ez_out.zdropped = z_zdropped, ez_out.max_q = z_max_q, ez_out.max_t = z_max_t, ez_out.mqe = z_mqe, ez_out.mqe_t = z_mqe_t;
 	ez_out.score = z_score, ez_out.reach_end = z_reach_end, ez_out.n_cigar = n_cigar;
 	st_order<false, NW>();
@@ -1754,11 +1772,14 @@ __global__ __launch_bounds__(64 * NW) void mnc_dp_align(Batch B, uint8_t *ws_all
 			auto run = [&](auto mem, auto H, auto pbuf, auto cg) {
 				typedef typename PtrTraits<decltype(mem)>::u8 SU8;
 				SU8 sf = (SU8)(mem + 7 * (size_t)T), qr = sf + T;
+				WG_T(ts0);
 				// target / reversed query; the left extension runs on both sequences reversed
 				for (int i = lane; i < T; i += 64 * NW) sf[i] = i < g.tlen ? (uint8_t)tcode(B, coff, g.kind == 0 ? g.ts + g.tlen - 1 - i : g.ts + i) : 0;
 				for (int i = lane; i < Q; i += 64 * NW)
 					qr[i] = i < g.qlen ? (uint8_t)qcode(read, rlen, g.rev, g.kind == 0 ? g.qs + i : g.qs + g.qlen - 1 - i) : 0;
 				st_order<false, NW>();
+				WG_T(ts1);
+				WG_ADD(6, ts1 - ts0);
 				// the cells in registers (ksw_wg) unless the call's anti-diagonals or sequences outgrow that form; debug_route
 				// bit 6: never (the workspace form on this many waves, for the tests)
 				bool on_wg = false;
@@ -1779,8 +1800,11 @@ __global__ __launch_bounds__(64 * NW) void mnc_dp_align(Batch B, uint8_t *ws_all
 					// SSE buffer, where those are dead by then): restore them for the walk and the second pass
 					if (lane < 16) sf[lane] = lane < g.tlen ? (uint8_t)tcode(B, coff, g.ts + lane) : 0;
 					st_order<false, NW>();
+					WG_T(tz0);
 					if (lane == 0) zdrop_code = test_zdrop_lane0(B, g.qlen, g.tlen, sf, qr, ez.n_cigar, cg, sc_mch, sc_mis, sc_N,
 					                                              reinterpret_cast<int32_t*>(ws + W.sw), reinterpret_cast<int32_t*>(ws + W.sw) + cig_max);
+					WG_T(tz1);
+					WG_ADD(5, tz1 - tz0);
 					zdrop_code = wg_bcast0<NW>(zdrop_code);
 					if (zdrop_code != 0)                             // second pass: exact maximum, real Z-drop
 						call(zdrop_code == 2 ? B.zdrop_inv : B.zdrop, -1, 0);
@@ -2662,9 +2686,12 @@ void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max,
 	// both forms are launched, the pass's call count -- known on the device only -- decides which of them works.
 	// debug_route bit 5: one wave each, as the rest; 7: four waves with the cells in the workspace (round 3's form); 8:
 	// always the sixteen-wave form; 9: always the four-wave form; (6: the launches below, but cells in the workspace)
-	const bool long_pass = big_pass == 1 || big_pass >= 3;
+	// The sixteen-wave form needs a whole CU's registers for a workgroup: beside the chip-filling kernels of a large batch
+	// even an idle launch of it waits for CUs to drain (0.7 ms of a 100 000-read batch), so only a micro-batch launches it.
+	const bool long_pass = big_pass == 1 || big_pass >= 3, small_batch = B.n_reads < 4096;
 	if (long_pass && !(B.debug_route & (32 | 128))) {
-		const int regime16 = (B.debug_route & 256) ? 0 : (B.debug_route & 512) ? -1 : 1, regime4 = (B.debug_route & 512) ? 0 : (B.debug_route & 256) ? -1 : 2;
+		const int regime16 = (B.debug_route & 256) ? 0 : ((B.debug_route & 512) || !small_batch) ? -1 : 1;
+		const int regime4 = ((B.debug_route & 512) || (!small_batch && !(B.debug_route & 256))) ? 0 : (B.debug_route & 256) ? -1 : 2;
 		if (regime16 >= 0)
 			hipLaunchKernelGGL((mnc_dp_align<16, 1>), dim3(n_wg), dim3(1024), (size_t)wg_lds_bytes<16>(ALIGN_SEQ_WIDE), st, B, ws, state_max, p_max, cig_max,
 			                   ALIGN_SEQ_WIDE, 0, 0, big_pass, regime16, ALIGN_FEW);
@@ -2724,4 +2751,15 @@ int dp_stitch_prepare()
 	return MNC_OK;
 }
 
+#ifdef MNC_WG_TIMING
+} // namespace mnc
+extern "C" int mnc_debug_wg_cycles(long long *out8, int reset)
+{
+	unsigned long long z[8] = {0};
+	if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(mnc::g_wg_cycles), sizeof(z)) != hipSuccess) return -1;
+	if (reset && hipMemcpyToSymbol(HIP_SYMBOL(mnc::g_wg_cycles), z, sizeof(z)) != hipSuccess) return -1;
+	return 0;
+}
+namespace mnc {
+#endif
 } // namespace mnc
