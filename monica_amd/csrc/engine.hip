@@ -910,7 +910,8 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	B.gap_lut = e->gap_lut.as<int32_t>(), B.logf_lut = e->logf_lut.as<float>(), B.logf_a_lut = e->logf_a_lut.as<float>(), B.logf_n = e->logf_n;
 	B.debug_route = (e->debug >> 17 & 15) | ((e->debug >> 22 & 1) << 4) | ((e->debug >> 5 & 1) << 5)    // 0x20: the literal kernel's long calls on one wave each
 	              | ((e->debug >> 6 & 1) << 6) | ((e->debug >> 7 & 1) << 7)                                 // 0x40: several waves, but cells in the workspace; 0x80: round 3's four-wave form
-	              | ((e->debug >> 3 & 1) << 8) | ((e->debug & 1) << 9);                                     // 0x8: always the sixteen-wave form; 0x1: always the four-wave form
+	              | ((e->debug >> 3 & 1) << 8) | ((e->debug & 1) << 9)                                      // 0x8: always the sixteen-wave form; 0x1: always the four-wave form
+	              | (((unsigned)e->debug >> 31 & 1) << 10);                                                  // 0x80000000: the packed gap-filling kernels without the drifting frame
 	// tuning knobs: debug bits 8-15 and 24-30.  Trying a tier pays when the chance that its band can be proven outweighs
 	// the cost of running the next tier after it as well: 32 cells (1 unit) before 42 (4/3): above three in four;
 	// 42 before 64 (2 units): above two in three -- a read with 10 % errors scores 1.36 +- 0.13 per base

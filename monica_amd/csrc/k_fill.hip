@@ -412,7 +412,7 @@ __device__ __forceinline__ uint32_t fillp_opened(uint32_t x)
 	return a << 3 | b << 2 | c << 1 | d;
 }
 constexpr uint32_t PK_TAG_H = 0x000f000fu, PK_TAG_E = 0x00070007u, PK_TAG_F = 0x00030003u, PK_TAG_E2 = 0x00010001u;   // F2: 0
-struct PkConst { uint32_t kmatch, kmis, q8, q28, e8, e28; int bias; };
+struct PkConst { uint32_t kmatch, kmis, q8, q28, e8, e28, de28; int bias; };
 
 // the span of the scores a band of `cells` can hold, and the bias that centres it in 12 bits
 __host__ __device__ __forceinline__ bool fillp_bias(int cells, int a, int bmis_abs, int q, int e, int q2, int e2, int &bias)
@@ -421,13 +421,32 @@ __host__ __device__ __forceinline__ bool fillp_bias(int cells, int a, int bmis_a
 	bias = -(hi + lo) / 2;
 	return hi + bias < 2040 && lo + bias > -2040;
 }
+// The drifting frame (fillp_step<DRIFT>): every value of anti-diagonal r is kept as (value + e r).  A diagonal move spans two
+// anti-diagonals, so it adds a + 2 e for a match and b + 2 e for a mismatch -- nothing at all when the mismatch penalty is
+// 2 e (minimap2's map-ont scores: b = 4, e = 2) --, extending a gap of the first piece costs e - e = 0 and one of the
+// second piece e2 - e: three instructions of a step disappear (the mismatch term of the score, the two subtractions of e).
+// Comparisons within an anti-diagonal are not affected (all candidates carry the same drift); the true score of the last
+// cell is what is kept less e r.  Span: a cell (i, j) holds at most a min(i, j) + a + e (i + j) <= (a + 2 e) FILL_MAX_LEN,
+// and at least what the straight path to it gives, -(b - 2 e) min(i, j) - gap(|i - j|) + e |i - j| >= -(q2 + e2) - ...: the
+// bias below centres [-(q + e + q2 + e2) - 64, (a + 2 e) FILL_MAX_LEN]; anything lower clamps as before.
+__host__ __device__ __forceinline__ bool fillp_drifts(int bmis_abs, int e, int e2) { return bmis_abs == 2 * e && e >= e2; }
+__host__ __device__ __forceinline__ bool fillp_bias_drift(int a, int q, int e, int q2, int e2, int &bias)
+{
+	const int hi = (a + 2 * e) * FILL_MAX_LEN, lo = -(q + e + q2 + e2 + 64);
+	bias = -(hi + lo) / 2;
+	return hi + bias < 2040 && lo + bias > -2040;
+}
 
-template <int LANES, int ODD, bool EDGE, bool CAPTURE = true>
+// one base of a sequence word into a half of the pair register, straight from the LDS word (k = 0 .. 3: the byte)
+template <int K> __device__ __forceinline__ uint32_t fillp_next_q(uint32_t Q2, uint32_t w) { return __builtin_amdgcn_perm(Q2, w, 0x05040c00u + K); }      // old low half -> high, byte K -> low
+template <int K> __device__ __forceinline__ uint32_t fillp_next_t(uint32_t T2, uint32_t w) { return __builtin_amdgcn_perm(w, T2, 0x0c040302u + K * 0x10000u); }   // old high half -> low, byte K -> high
+
+template <int LANES, int ODD, bool EDGE, bool CAPTURE = true, bool DRIFT = false, int KB = -1>
 __device__ __forceinline__ void fillp_step(const PkConst &K, const int r, const int L, const int rows_m1, const uint8_t *st, const uint8_t *sq,
                                            const int q, const int e, const int q2, const int e2,
                                            int &t_lo, int &tn, int &jn, uint32_t &T2, uint32_t &Q2, uint32_t &Hs,
                                            uint32_t &E, uint32_t &E2, uint32_t &F, uint32_t &F2, uint32_t &Sc,
-                                           uint32_t &nb1, uint32_t &nb2, uint32_t &acc)
+                                           uint32_t &nb1, uint32_t &nb2, uint32_t &acc, const uint32_t wq = 0, const uint32_t wt = 0)
 {
 	constexpr int SHR = LANES == 16 ? 0x111 : 0x138, SHL = LANES == 16 ? 0x101 : 0x130;   // row_shr:1 / wave_shr:1
 	constexpr bool SEG_EDGES = LANES != 16 && LANES != 64;      // segments inside the reach of a wave shift: their edge lanes get the neighbouring segment's
@@ -440,22 +459,26 @@ __device__ __forceinline__ void fillp_step(const PkConst &K, const int r, const 
 		if (SEG_EDGES && L == 0) nb1 = nb2 = PK_NEG;                 // it got the other segment's
 		vE = __builtin_amdgcn_alignbit(E, nb1, 16), vE2 = __builtin_amdgcn_alignbit(E2, nb2, 16);
 		vF = F, vF2 = F2;
-		Q2 = __builtin_amdgcn_perm(Q2, (uint32_t)sq[jn], 0x05040100u), ++jn;   // (old low half -> high, the new base -> low)
+		// (old low half -> high, the new base -> low; KB >= 0: the base is byte KB & 3 of a word the caller loaded -- no extraction)
+		if constexpr (KB >= 0) Q2 = fillp_next_q<KB & 3>(Q2, wq);
+		else Q2 = __builtin_amdgcn_perm(Q2, (uint32_t)sq[jn], 0x05040100u), ++jn;
 	} else {
 		nb1 = (uint32_t)__builtin_amdgcn_update_dpp((int)nb1, (int)F, SHL, 0xf, 0xf, false);
 		nb2 = (uint32_t)__builtin_amdgcn_update_dpp((int)nb2, (int)F2, SHL, 0xf, 0xf, false);
 		if (SEG_EDGES && L == LANES - 1) nb1 = nb2 = PK_NEG;
 		vF = __builtin_amdgcn_alignbit(nb1, F, 16), vF2 = __builtin_amdgcn_alignbit(nb2, F2, 16);
 		vE = E, vE2 = E2;
-		T2 = __builtin_amdgcn_perm((uint32_t)st[tn], T2, 0x05040302u), ++tn;   // (old high half -> low, the new base -> high)
+		if constexpr (KB >= 0) T2 = fillp_next_t<KB & 3>(T2, wt);   // (old high half -> low, the new base -> high)
+		else T2 = __builtin_amdgcn_perm((uint32_t)st[tn], T2, 0x05040302u), ++tn;
 		if (EDGE) ++t_lo;
 	}
 	uint32_t hd = Hs;
 	if (EDGE) {
 		// the virtual row / column: gaps from the corner.  Cell (0, j) sits on step r = j, cell (t, 0) on r = t:
-		// the same three numbers for both, by the step alone
-		const int hb = -fill_gap(r + 1, q, e, q2, e2) + K.bias;
-		const uint32_t h0 = pk_rep(((r == 0 ? 0 : -fill_gap(r, q, e, q2, e2)) + K.bias) << 4) | PK_TAG_H;
+		// the same three numbers for both, by the step alone.  (DRIFT: the diagonal source belongs to anti-diagonal
+		// r - 2, the gap states to r)
+		const int hb = -fill_gap(r + 1, q, e, q2, e2) + K.bias + (DRIFT ? e * r : 0);
+		const uint32_t h0 = pk_rep(((r == 0 ? 0 : -fill_gap(r, q, e, q2, e2)) + K.bias + (DRIFT ? e * (r - 2) : 0)) << 4) | PK_TAG_H;
 		const uint32_t g1 = pk_rep((hb - q - e) << 4), g2 = pk_rep((hb - q2 - e2) << 4);
 		const uint32_t mt = t_lo == 0 ? 0x0000ffffu : t_lo == -1 ? 0xffff0000u : 0u;
 		const uint32_t mj = t_lo == r ? 0x0000ffffu : t_lo == r - 1 ? 0xffff0000u : 0u;
@@ -463,20 +486,27 @@ __device__ __forceinline__ void fillp_step(const PkConst &K, const int r, const 
 		vE = pk_bfi(mt, g1 | PK_TAG_E, vE), vE2 = pk_bfi(mt, g2 | PK_TAG_E2, vE2);
 		vF = pk_bfi(mj, g1 | PK_TAG_F, vF), vF2 = pk_bfi(mj, g2, vF2);
 	}
-	const uint32_t sc = pk_madu(pk_subsu(0x00010001u, T2 ^ Q2), K.kmatch, K.kmis);   // 1 - min(1, x): the bases are equal
-	uint32_t z = pk_adds(hd, sc);
+	uint32_t z;
+	if (DRIFT) z = pk_madu(pk_subsu(0x00010001u, T2 ^ Q2), K.kmatch, hd);        // + (a + 2 e) where the bases are equal, nothing where not
+	else z = pk_adds(hd, pk_madu(pk_subsu(0x00010001u, T2 ^ Q2), K.kmatch, K.kmis));   // 1 - min(1, x): the bases are equal
 	z = pk_maxs(z, vE), z = pk_maxs(z, vF), z = pk_maxs(z, vE2), z = pk_maxs(z, vF2);
 	const uint32_t zt = z | PK_TAG_H;
 	const uint32_t o1 = pk_subs(zt, K.q8), o2 = pk_subs(zt, K.q28);
 	const uint32_t mE = pk_maxs(vE, o1), mF = pk_maxs(vF, o1), mE2 = pk_maxs(vE2, o2), mF2 = pk_maxs(vF2, o2);
-	E = pk_subs(mE, K.e8) & 0xfff7fff7u;                       // tag 15 or 7 -> 7
-	F = pk_subs(mF, K.e8) & 0xfff3fff3u;                       // 15 or 3 -> 3
-	E2 = pk_subs(mE2, K.e28) & 0xfff1fff1u;
-	F2 = pk_subs(mF2, K.e28) & 0xfff0fff0u;
+	if (DRIFT) {
+		E = mE & 0xfff7fff7u, F = mF & 0xfff3fff3u;                 // (extending costs e - e)
+		E2 = pk_adds(mE2, K.de28) & 0xfff1fff1u, F2 = pk_adds(mF2, K.de28) & 0xfff0fff0u;   // (e2 - e)
+	} else {
+		E = pk_subs(mE, K.e8) & 0xfff7fff7u;                       // tag 15 or 7 -> 7
+		F = pk_subs(mF, K.e8) & 0xfff3fff3u;                       // 15 or 3 -> 3
+		E2 = pk_subs(mE2, K.e28) & 0xfff1fff1u;
+		F2 = pk_subs(mF2, K.e28) & 0xfff0fff0u;
+	}
 	// direction byte: bits 0-3 the winner's tag; bits 4-7 the XOR of the four gap states' tags (15 where a gap
 	// was opened, else 7 / 3 / 1 / 0 for E / F / E2 / F2), from which the walk solves the four "opened" bits:
-	// three cheap instructions instead of four field inserts (fillp_opened)
-	const uint32_t d = pk_bfi(0x000f000fu, z, (mE ^ mF ^ mE2 ^ mF2) << 4);
+	// three cheap instructions instead of four field inserts (fillp_opened) -- the XOR of three of them is one v_bitop3
+	const uint32_t x3 = (uint32_t)__builtin_amdgcn_bitop3_b32((int)mE, (int)mF, (int)mE2, 0x96);
+	const uint32_t d = pk_bfi(0x000f000fu, z, (x3 ^ mF2) << 4);
 	// two steps' direction bytes per register: (even step: cells 2 L, 2 L + 1; odd step: likewise)
 	acc = ODD ? __builtin_amdgcn_perm(d, acc, 0x06040100u) : __builtin_amdgcn_perm(d, d, 0x0c0c0200u);
 	if (CAPTURE) Sc = r == rows_m1 ? zt : Sc;                  // the corner's score: only the blocks that hold a segment's last step look for it
@@ -499,7 +529,7 @@ constexpr int FILLP_BLOCKS = (2 * FILL_MAX_LEN + 15) / 16 + 1;           // 16-s
 constexpr size_t FILLP_PASS_BYTES = (size_t)FILLP_BLOCKS * 64 * 32;
 constexpr size_t FILLP_SLOT = FILLP_G_MAX * FILLP_PASS_BYTES;
 
-template <int LANES>
+template <int LANES, bool DRIFT>
 __global__ __launch_bounds__(64) void mnc_dp_fillp(Batch B, const int32_t *list, int ctr_n, int ctr_q, int32_t *next_list, int ctr_next,
                                                    int32_t *fb_list, int ctr_fb, uint8_t *p_all, uint32_t *cig_all)
 {
@@ -515,8 +545,9 @@ __global__ __launch_bounds__(64) void mnc_dp_fillp(Batch B, const int32_t *list,
 	const bool leader = live && L == 0;
 	const int a = B.sc_a, bmis = -B.sc_b, q = B.gap_q, e = B.gap_e, q2 = B.gap_q2, e2 = B.gap_e2;
 	PkConst K;
-	K.kmatch = pk_rep((a - bmis) << 4), K.kmis = pk_rep(bmis << 4), K.q8 = pk_rep(q << 4), K.q28 = pk_rep(q2 << 4), K.e8 = pk_rep(e << 4), K.e28 = pk_rep(e2 << 4);
-	const bool fits = fillp_bias(W, a, -bmis > B.sc_ambi ? -bmis : B.sc_ambi, q, e, q2, e2, K.bias);
+	K.kmatch = pk_rep((DRIFT ? a + 2 * e : a - bmis) << 4), K.kmis = pk_rep(bmis << 4), K.q8 = pk_rep(q << 4), K.q28 = pk_rep(q2 << 4), K.e8 = pk_rep(e << 4), K.e28 = pk_rep(e2 << 4);
+	K.de28 = pk_rep((e - e2) << 4);
+	const bool fits = DRIFT ? fillp_bias_drift(a, q, e, q2, e2, K.bias) : fillp_bias(W, a, -bmis > B.sc_ambi ? -bmis : B.sc_ambi, q, e, q2, e2, K.bias);
 	uint8_t *p_wave = p_all + (size_t)blockIdx.x * FILLP_SLOT;
 	uint32_t *cg = cig_all + ((size_t)blockIdx.x * 64 + lane) * FILL_CIG_MAX;
 	const unsigned long long n_items = B.dp_ctr[ctr_n];
@@ -624,36 +655,35 @@ __global__ __launch_bounds__(64) void mnc_dp_fillp(Batch B, const int32_t *list,
 				uint32_t acc[8];
 #pragma unroll
 				for (int k = 0; k < 8; ++k) {
-					fillp_step<LANES, 0, true>(K, r + 2 * k, L, rows_m1, st, sq, q, e, q2, e2, t_lo, tn, jn, T2, Q2, He, E, E2, F, F2, Sc, nbe1, nbe2, acc[k]);
-					fillp_step<LANES, 1, true>(K, r + 2 * k + 1, L, rows_m1, st, sq, q, e, q2, e2, t_lo, tn, jn, T2, Q2, Ho, E, E2, F, F2, Sc, nbf1, nbf2, acc[k]);
+					fillp_step<LANES, 0, true, true, DRIFT>(K, r + 2 * k, L, rows_m1, st, sq, q, e, q2, e2, t_lo, tn, jn, T2, Q2, He, E, E2, F, F2, Sc, nbe1, nbe2, acc[k]);
+					fillp_step<LANES, 1, true, true, DRIFT>(K, r + 2 * k + 1, L, rows_m1, st, sq, q, e, q2, e2, t_lo, tn, jn, T2, Q2, Ho, E, E2, F, F2, Sc, nbf1, nbf2, acc[k]);
 				}
 				pblk[0] = make_uint4(acc[0], acc[1], acc[2], acc[3]), pblk[1] = make_uint4(acc[4], acc[5], acc[6], acc[7]);
 			}
-			for (; r < cap_from; r += 16, pblk += 2048 / 16) {
-				uint32_t acc[8];
-#pragma unroll
-				for (int k = 0; k < 8; ++k) {
-					fillp_step<LANES, 0, false, false>(K, r + 2 * k, L, rows_m1, st, sq, q, e, q2, e2, t_lo, tn, jn, T2, Q2, He, E, E2, F, F2, Sc, nbe1, nbe2, acc[k]);
-					fillp_step<LANES, 1, false, false>(K, r + 2 * k + 1, L, rows_m1, st, sq, q, e, q2, e2, t_lo, tn, jn, T2, Q2, Ho, E, E2, F, F2, Sc, nbf1, nbf2, acc[k]);
-				}
-				pblk[0] = make_uint4(acc[0], acc[1], acc[2], acc[3]), pblk[1] = make_uint4(acc[4], acc[5], acc[6], acc[7]);
-			}
-			for (; r < max_rows; r += 16, pblk += 2048 / 16) {
-				uint32_t acc[8];
-#pragma unroll
-				for (int k = 0; k < 8; ++k) {
-					fillp_step<LANES, 0, false>(K, r + 2 * k, L, rows_m1, st, sq, q, e, q2, e2, t_lo, tn, jn, T2, Q2, He, E, E2, F, F2, Sc, nbe1, nbe2, acc[k]);
-					fillp_step<LANES, 1, false>(K, r + 2 * k + 1, L, rows_m1, st, sq, q, e, q2, e2, t_lo, tn, jn, T2, Q2, Ho, E, E2, F, F2, Sc, nbf1, nbf2, acc[k]);
-				}
-				pblk[0] = make_uint4(acc[0], acc[1], acc[2], acc[3]), pblk[1] = make_uint4(acc[4], acc[5], acc[6], acc[7]);
-			}
+			// the bare steps: the eight query and the eight target bases of a block as two LDS words each, a base moved into
+			// its pair register by the step's own v_perm (no extraction)
+#define MNC_FILLP_PAIR(CAP, k) \
+	fillp_step<LANES, 0, false, CAP, DRIFT, k>(K, r + 2 * k, L, rows_m1, st, sq, q, e, q2, e2, t_lo, tn, jn, T2, Q2, He, E, E2, F, F2, Sc, nbe1, nbe2, acc[k], k < 4 ? wq.x : wq.y, 0u); \
+	fillp_step<LANES, 1, false, CAP, DRIFT, k>(K, r + 2 * k + 1, L, rows_m1, st, sq, q, e, q2, e2, t_lo, tn, jn, T2, Q2, Ho, E, E2, F, F2, Sc, nbf1, nbf2, acc[k], 0u, k < 4 ? wt.x : wt.y);
+#define MNC_FILLP_BLOCK(CAP) { \
+	uint32_t acc[8]; \
+	uint2 wq, wt; \
+	__builtin_memcpy(&wq, sq + jn, 8), __builtin_memcpy(&wt, st + tn, 8); \
+	jn += 8, tn += 8; \
+	MNC_FILLP_PAIR(CAP, 0) MNC_FILLP_PAIR(CAP, 1) MNC_FILLP_PAIR(CAP, 2) MNC_FILLP_PAIR(CAP, 3) \
+	MNC_FILLP_PAIR(CAP, 4) MNC_FILLP_PAIR(CAP, 5) MNC_FILLP_PAIR(CAP, 6) MNC_FILLP_PAIR(CAP, 7) \
+	pblk[0] = make_uint4(acc[0], acc[1], acc[2], acc[3]), pblk[1] = make_uint4(acc[4], acc[5], acc[6], acc[7]); }
+			for (; r < cap_from; r += 16, pblk += 2048 / 16) MNC_FILLP_BLOCK(false)
+			for (; r < max_rows; r += 16, pblk += 2048 / 16) MNC_FILLP_BLOCK(true)
+#undef MNC_FILLP_BLOCK
+#undef MNC_FILLP_PAIR
 			// the proof: every path that leaves the band scores at most U
 			int S = FILL_NEG;
 			{
 				int lc = ok ? n - 1 - ((rows - 1 + kmin + 1) >> 1) : 0;
 				lc = lc < 0 ? 0 : lc >= W ? W - 1 : lc;
 				const uint32_t v = (uint32_t)__shfl((int)Sc, lead + (lc >> 1));
-				S = ((int)(int16_t)(lc & 1 ? v >> 16 : v & 0xffffu) >> 4) - K.bias;
+				S = ((int)(int16_t)(lc & 1 ? v >> 16 : v & 0xffffu) >> 4) - K.bias - (DRIFT ? e * (rows - 1) : 0);
 				const int U = dp_band_bound(n, m, kmin, kmax, a, q, e, q2, e2);
 				if (ok && !(S > U)) ok = false;
 			}
@@ -1488,10 +1518,15 @@ void launch_dp_fill(const Batch &B, int lanes, const int32_t *list, int ctr_n, i
                     int32_t *fb_list, int ctr_fb, uint8_t *p_all, uint32_t *cig_all, int n_wg, hipStream_t st)
 {
 	// `lanes` = cells of the band
-	if (lanes == 32) hipLaunchKernelGGL((mnc_dp_fillp<16>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all, cig_all);
-	else if (lanes == FILL_MID_CELLS) hipLaunchKernelGGL((mnc_dp_fillp<FILL_MID_CELLS / 2>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all, cig_all);
-	else if (lanes == 64) hipLaunchKernelGGL((mnc_dp_fillp<32>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all, cig_all);
-	else hipLaunchKernelGGL((mnc_dp_fillp<64>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all, cig_all);
+	// the drifting frame when the scores allow it (b = 2 e: minimap2's map-ont), debug_route bit 10: never
+	const bool drift = fillp_drifts(B.sc_b, B.gap_e, B.gap_e2) && !(B.debug_route & 1024);
+#define MNC_LAUNCH_FILLP(LN) do { if (drift) hipLaunchKernelGGL((mnc_dp_fillp<LN, true>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all, cig_all); \
+	else hipLaunchKernelGGL((mnc_dp_fillp<LN, false>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all, cig_all); } while (0)
+	if (lanes == 32) MNC_LAUNCH_FILLP(16);
+	else if (lanes == FILL_MID_CELLS) MNC_LAUNCH_FILLP(FILL_MID_CELLS / 2);
+	else if (lanes == 64) MNC_LAUNCH_FILLP(32);
+	else MNC_LAUNCH_FILLP(64);
+#undef MNC_LAUNCH_FILLP
 }
 
 void launch_dp_ext(const Batch &B, int lanes, const int32_t *list, int ctr_n, int ctr_q, int32_t *fb_list, int ctr_fb, uint8_t *p_all, int n_wg, hipStream_t st)

@@ -266,7 +266,7 @@ def test_results_do_not_depend_on_scheduling(capi, world):
 
 
 @pytest.mark.parametrize("route", [0x20000, 0x40000, 0x80000 | 0x100000, 0x20000 | 0x40000 | 0x80000 | 0x100000, 0x400000,
-                                   20 << 8 | 20 << 24, 48 << 8 | 48 << 24, 0x10, 0x800000, 0x20, 0x8, 0x1, 0x40 | 0x8, 0x40 | 0x1, 0x80,
+                                   20 << 8 | 20 << 24, 48 << 8 | 48 << 24, 0x10, 0x800000, 0x20, 0x8, 0x1, 0x40 | 0x8, 0x40 | 0x1, 0x80, 0x80000000,
                                    0x20 | 0x20000 | 0x40000 | 0x80000 | 0x100000, 0x8 | 0x20000 | 0x40000 | 0x80000 | 0x100000,
                                    0x1 | 0x20000 | 0x40000 | 0x80000 | 0x100000, 0x80 | 0x20000 | 0x40000 | 0x80000 | 0x100000])
 def test_every_kernel_family_can_be_taken_out(capi, oracle, world, route):
@@ -279,7 +279,8 @@ def test_every_kernel_family_can_be_taken_out(capi, oracle, world, route):
     The literal kernel's long calls run on a workgroup with the cells in registers (ksw_wg): sixteen waves a call when a
     pass has few calls, four waves with four cells a thread when it has many; 0x8 / 0x1: always the one / the other form,
     0x40 with either: that launch shape with the cells in the workspace, 0x80: round 3's four waves on the workspace, 0x20: one
-    wave each.)"""
+    wave each.  0x80000000: the packed gap-filling kernels in their plain frame instead of the drifting one (values of
+    anti-diagonal r kept as value + e r, which makes a mismatch and a gap extension cost nothing in the recurrence).)"""
     reads = [synth.reads(world["seqs"], 40, 3000, seed=31, sub=800, ins=600, dele=600), synth.reads(world["seqs"], 60, 5000, seed=0x5EED + 9)]
     g0 = world["seqs"][0]
     rng = np.random.default_rng(3)
