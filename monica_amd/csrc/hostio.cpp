@@ -19,10 +19,18 @@
 #include <cstring>
 #include <fcntl.h>
 #include <sys/stat.h>
+#include <sys/uio.h>
+#include <sys/mman.h>
+#include <sys/statvfs.h>
+#include <climits>
+#ifndef IOV_MAX
+#define IOV_MAX 1024
+#endif
 #include <algorithm>
 #include <unistd.h>
 #include <omp.h>
 #include <mutex>
+#include <atomic>
 #include <vector>
 #include <string>
 #include <unordered_map>
@@ -64,6 +72,18 @@ struct BigCache {
 	}
 };
 BigCache g_big;
+
+// A block of file text that a reader and the batches it has handed out hold together: the batches' records lie in it
+// (written out of it by the routing pass), the reader goes on parsing behind them.  Whoever lets go last gives it back.
+struct SharedBuf {
+	char *p;
+	size_t cap;
+	std::atomic<int> refs;
+};
+void shared_drop(SharedBuf *sb)
+{
+	if (sb && sb->refs.fetch_sub(1) == 1) { g_big.give(sb->p, sb->cap); delete sb; }
+}
 
 struct LineReader {
 	int fd = -1;
@@ -171,6 +191,18 @@ struct LineReader {
 		int t = omp_get_max_threads();
 		return t < 1 ? 1 : t > cap ? cap : t;
 	}
+	// The aligner's pipeline runs a parse and a routing pass side by side: each may be given a team of its own size
+	// (MNC_PARSE_THREADS / MNC_ROUTE_THREADS; default: io_threads() each -- on the GPU box both passes still speed up
+	// from 6 to 16 threads while they run side by side, profiles/r04f_files_sweep.txt)
+	static int team_threads(const char *env)
+	{
+		const char *e = getenv(env);
+		const int v = e ? atoi(e) : 0;
+		const int all = io_threads();
+		return v > 0 ? (v < 64 ? v : 64) : all;
+	}
+	static int parse_threads() { static const int t = team_threads("MNC_PARSE_THREADS"); return t; }
+	static int route_threads() { static const int t = team_threads("MNC_ROUTE_THREADS"); return t; }
 };
 
 inline size_t rstrip_len(const char *p, size_t len)
@@ -227,6 +259,17 @@ struct mnc_fastq {
 	std::vector<uint64_t> title_off;  // n + 1
 	std::vector<uint32_t> id_len, id_off;   // seq_record.id = first word of the title
 	std::vector<size_t> nl;          // the four-line fast path: line ends of the buffered text
+	// A batch of four-line records keeps the file's own bytes: the routing pass writes a record that is not rewritten
+	// (unmapped, ambiguous, focus; the body of a mapped one) straight out of them, and the qualities are never copied.
+	bool pending_in_buf = false;     // the pending title line has not been consumed: its bytes start at in.lo
+	bool text_backed = false;        // this batch's records lie in `text` (the reader: in.data) at rec_off / seq_off / qual_off
+	const char *text = nullptr;      // a detached batch: the reader's buffer at the time, which it holds on to through `sb`
+	SharedBuf *sb = nullptr;         // batch: the block its text lies in; reader: the block in.data is, once a batch shares it
+	std::vector<uint64_t> rec_off, seq_off, qual_off;   // n + 1 / n / n offsets into the text
+	std::vector<uint8_t> verbatim;   // n: the record's text is byte for byte what the writer writes (no trailing blanks, a bare '+' line)
+	bool quals_ready = true;         // the quality array holds this batch's (a text-backed batch fills it on demand)
+	std::mutex q_mu;
+	const char *text_base() const { return text ? text : in.data; }
 };
 
 static int fq_io_fail(const mnc_fastq *fq)
@@ -266,6 +309,8 @@ extern "C" void mnc_fastq_close(mnc_fastq *fq)
 {
 	if (!fq) return;
 	if (fq->in.fd >= 0) close(fq->in.fd);
+	if (fq->sb && fq->in.data == fq->sb->p) fq->in.data = nullptr, fq->in.cap = 0;   // the reader's block is shared: let go of it, the last holder frees it
+	shared_drop(fq->sb);
 	fq->in.release();
 	fq->bases.release();
 	fq->quals.release();
@@ -280,7 +325,7 @@ extern "C" int mnc_fastq_remaining(const mnc_fastq *fq, int64_t *bytes)
 	if (fq->in.fd < 0 || !fq->in.seekable) return MNC_OK;
 	const off_t pos = lseek(fq->in.fd, 0, SEEK_CUR);
 	if (pos < 0) return MNC_OK;
-	const int64_t buffered = (int64_t)(fq->in.hi - fq->in.lo) + (fq->have_pending ? (int64_t)fq->pending.size() + 1 : 0);
+	const int64_t buffered = (int64_t)(fq->in.hi - fq->in.lo) + (fq->have_pending && !fq->pending_in_buf ? (int64_t)fq->pending.size() + 1 : 0);
 	*bytes = fq->done ? 0 : std::max<int64_t>(0, fq->file_size - (int64_t)pos) + buffered;
 	return MNC_OK;
 }
@@ -294,6 +339,10 @@ extern "C" int mnc_fastq_detach_batch(mnc_fastq *fq, mnc_fastq **out)
 	if (!fq || !out) return MNC_ERR_ARG;
 	mnc_fastq *b = new (std::nothrow) mnc_fastq();
 	if (!b) return MNC_ERR_NOMEM;
+	if (fq->text_backed && !fq->sb) {
+		fq->sb = new (std::nothrow) SharedBuf{ fq->in.data, fq->in.cap, { 1 } };
+		if (!fq->sb) { delete b; return MNC_ERR_NOMEM; }
+	}
 	b->in.fd = -1;
 	b->done = true;
 	b->bases.pinned = true;
@@ -301,6 +350,17 @@ extern "C" int mnc_fastq_detach_batch(mnc_fastq *fq, mnc_fastq **out)
 	std::swap(b->bases, fq->bases), std::swap(b->quals, fq->quals);
 	b->offsets.swap(fq->offsets), b->titles.swap(fq->titles), b->title_off.swap(fq->title_off);
 	b->id_len.swap(fq->id_len), b->id_off.swap(fq->id_off);
+	b->quals_ready = fq->quals_ready, fq->quals_ready = true;
+	if (fq->text_backed) {
+		// the batch and the reader share the buffer from here on: the batch's records lie in it, the reader parses on behind
+		// them; nothing is copied until the reader has to move its data (fastq_unshare)
+		LineReader &in = fq->in;
+		(void)in;
+		fq->sb->refs.fetch_add(1);
+		b->sb = fq->sb, b->text = in.data, b->text_backed = true;
+		b->rec_off.swap(fq->rec_off), b->seq_off.swap(fq->seq_off), b->qual_off.swap(fq->qual_off), b->verbatim.swap(fq->verbatim);
+		fq->text_backed = false;
+	}
 	fq->bases.pinned = true;
 	fq->n = 0;
 	fq->offsets.assign(1, 0), fq->title_off.assign(1, 0);
@@ -316,21 +376,46 @@ extern "C" int mnc_fastq_detach_batch(mnc_fastq *fq, mnc_fastq **out)
 // '@' first, '+' third with an empty or equal caption, equal lengths, a next line that starts
 // with '@'.  Anything else -- including what the general parser reports as an error -- leaves the
 // state untouched and is parsed (or reported) by the general parser.
+// The reader is about to move or grow its buffer while batches still hold records in it: it goes on in a block of its
+// own with what it has not consumed (what LineReader::compact would have moved anyway), the batches keep the old one.
+static bool fastq_unshare(mnc_fastq *fq, size_t room)
+{
+	if (!fq->sb) return true;
+	LineReader &in = fq->in;
+	if (fq->sb->refs.load() == 1) {                               // every batch has let go: the block is the reader's alone again
+		delete fq->sb;
+		fq->sb = nullptr;
+		return true;
+	}
+	const size_t tail = in.hi - in.lo;
+	size_t got = 0, need = std::max<size_t>(tail + IO_CHUNK, room);
+	char *nb = g_big.take(need, &got);
+	if (!nb) { nb = (char*)malloc(need); got = need; }
+	if (!nb) return false;
+	if (tail) memcpy(nb, in.data + in.lo, tail);
+	shared_drop(fq->sb);
+	fq->sb = nullptr;
+	in.data = nb, in.cap = got, in.lo = 0, in.hi = tail;
+	return true;
+}
+
 static int fastq_next_fast(mnc_fastq *fq, uint32_t max_reads, uint64_t max_bases, bool *handled)
 {
 	*handled = false;
 	LineReader &in = fq->in;
-	if (!fq->have_pending || !in.seekable || max_reads == 0) return MNC_OK;
+	// (the pending title line must still lie in the buffer, in front of its record: the batch keeps the records' own bytes)
+	if (!fq->have_pending || !fq->pending_in_buf || !in.seekable || max_reads == 0) return MNC_OK;
 	{
 		uint64_t want = 2 * max_bases + (uint64_t)max_reads * 512 + (1u << 20);
 		const uint64_t left = (uint64_t)fq->file_size + (1u << 20);       // never more than the file
 		if (want > left) want = left;
+		if (!(in.hi - in.lo >= want || in.eof) && !fastq_unshare(fq, (size_t)want + IO_CHUNK)) { set_error("out of host memory"); return MNC_ERR_NOMEM; }   // fill() is going to move the data
 		if (!in.fill((size_t)want)) return in.err == ENOMEM ? (set_error("out of host memory"), MNC_ERR_NOMEM) : MNC_OK;   // an I/O error: the general parser reports it
 	}
 	const char *base = in.data + in.lo;
 	const size_t avail = in.hi - in.lo;
 	if (avail == 0) return MNC_OK;
-	const int T = LineReader::io_threads();
+	const int T = LineReader::parse_threads();
 	// ---- line ends
 	std::vector<std::vector<size_t>> part((size_t)T);
 #pragma omp parallel num_threads(T)
@@ -354,35 +439,39 @@ static int fastq_next_fast(mnc_fastq *fq, uint32_t max_reads, uint64_t max_bases
 	if (in.eof && (nl.empty() || nl.back() != avail - 1)) nl.push_back(avail), open_end = true;
 	const size_t n_lines = nl.size();
 	auto line = [&](size_t i, const char *&p, size_t &len) { const size_t s0 = i ? nl[i - 1] + 1 : 0; p = base + s0, len = nl[i] - s0; };
-	// lines of the buffer: seq0 plus0 qual0 title1 seq1 ... (title0 is the pending line)
+	// lines of the buffer: title0 seq0 plus0 qual0 title1 seq1 ...
 	size_t R;
 	if (in.eof) {
-		if (n_lines % 4 != 3) return MNC_OK;                      // not whole four-line records to the end
-		R = (n_lines + 1) / 4;
-	} else R = n_lines / 4;                                       // only records whose next title is in the buffer
+		if (n_lines % 4 != 0) return MNC_OK;                      // not whole four-line records to the end
+		R = n_lines / 4;
+	} else R = n_lines ? (n_lines - 1) / 4 : 0;                   // only records whose next title is in the buffer
 	if (R > max_reads) R = max_reads;
 	if (R == 0) return MNC_OK;
-	std::vector<uint32_t> slen(R);
+	std::vector<uint32_t> slen(R), tlen(R);
+	fq->verbatim.resize(R);
 	int bad = 0;
 #pragma omp parallel for schedule(static) num_threads(T) reduction(|:bad)
 	for (int64_t r = 0; r < (int64_t)R; ++r) {
 		const char *tp, *sp, *pp, *qp;
 		size_t tl, sl, pl, ql;
-		if (r == 0) tp = fq->pending.data(), tl = fq->pending.size(); else line((size_t)(4 * r - 1), tp, tl);
-		line((size_t)(4 * r), sp, sl), line((size_t)(4 * r + 1), pp, pl), line((size_t)(4 * r + 2), qp, ql);
+		line((size_t)(4 * r), tp, tl), line((size_t)(4 * r + 1), sp, sl), line((size_t)(4 * r + 2), pp, pl), line((size_t)(4 * r + 3), qp, ql);
 		if (tl == 0 || tp[0] != '@' || pl == 0 || pp[0] != '+') { bad |= 1; continue; }
 		const size_t t_len = rstrip_len(tp + 1, tl - 1), c_len = rstrip_len(pp + 1, pl - 1);
 		if (c_len > 0 && (c_len != t_len || memcmp(pp + 1, tp + 1, t_len) != 0)) { bad |= 1; continue; }
 		const size_t s_len = rstrip_len(sp, sl), q_len = rstrip_len(qp, ql);
 		if (s_len != q_len || s_len > 0xffffffffu) { bad |= 1; continue; }
 		if (memchr(sp, ' ', s_len) || memchr(sp, '\t', s_len)) { bad |= 1; continue; }
-		for (size_t i = 0; i < q_len; ++i) if ((uint8_t)qp[i] < 33 || (uint8_t)qp[i] > 126) { bad |= 1; break; }
-		if ((size_t)(4 * r + 3) < n_lines) {
+		unsigned out_of_range = 0;                                // (no early exit: the loop is a vector OR)
+		for (size_t i = 0; i < q_len; ++i) out_of_range |= (unsigned)((uint8_t)(qp[i] - 33) > 93);
+		if (out_of_range) { bad |= 1; continue; }
+		if ((size_t)(4 * r + 4) < n_lines) {
 			const char *np_; size_t nl_;
-			line((size_t)(4 * r + 3), np_, nl_);
+			line((size_t)(4 * r + 4), np_, nl_);
 			if (nl_ == 0 || np_[0] != '@') bad |= 1;
 		}
-		slen[(size_t)r] = (uint32_t)s_len;
+		slen[(size_t)r] = (uint32_t)s_len, tlen[(size_t)r] = (uint32_t)t_len;
+		// the record's bytes are what FastqPhredWriter writes for it: nothing stripped, a bare '+', a line end behind the qualities
+		fq->verbatim[(size_t)r] = (t_len == tl - 1 && pl == 1 && s_len == sl && q_len == ql && !(open_end && (size_t)(4 * r + 3) == n_lines - 1)) ? 1 : 0;
 	}
 	if (bad) return MNC_OK;
 	// ---- how many records: the batch ends with the record that reaches max_bases
@@ -392,28 +481,25 @@ static int fastq_next_fast(mnc_fastq *fq, uint32_t max_reads, uint64_t max_bases
 		while (n < R) { nb += slen[n]; ++n; if (nb >= max_bases) break; }
 	}
 	fq->offsets.resize(n + 1), fq->title_off.resize(n + 1), fq->id_len.resize(n), fq->id_off.resize(n);
-	std::vector<uint32_t> tlen(n);
+	fq->rec_off.resize(n + 1), fq->seq_off.resize(n), fq->qual_off.resize(n), fq->verbatim.resize(n);
 	fq->offsets[0] = 0, fq->title_off[0] = 0;
 	for (size_t r = 0; r < n; ++r) {
-		const char *tp; size_t tl;
-		if (r == 0) tp = fq->pending.data(), tl = fq->pending.size(); else line(4 * r - 1, tp, tl);
-		tlen[r] = (uint32_t)rstrip_len(tp + 1, tl - 1);
 		fq->offsets[r + 1] = fq->offsets[r] + slen[r];
 		fq->title_off[r + 1] = fq->title_off[r] + tlen[r];
 	}
 	const int64_t nb = fq->offsets[n];
-	if (!fq->bases.ensure((size_t)nb + 64, 0) || !fq->quals.ensure((size_t)nb + 64, 0)) { set_error("out of host memory"); return MNC_ERR_NOMEM; }
+	if (!fq->bases.ensure((size_t)nb + 64, 0)) { set_error("out of host memory"); return MNC_ERR_NOMEM; }
 	fq->titles.resize((size_t)fq->title_off[n]);
+	const size_t text0 = in.lo;                                   // offsets into in.data (the batch's text)
 #pragma omp parallel for schedule(static) num_threads(T)
 	for (int64_t r = 0; r < (int64_t)n; ++r) {
 		const char *tp, *sp, *qp;
 		size_t tl, sl, ql;
-		if (r == 0) tp = fq->pending.data(), tl = fq->pending.size(); else line((size_t)(4 * r - 1), tp, tl);
-		line((size_t)(4 * r), sp, sl), line((size_t)(4 * r + 2), qp, ql);
+		line((size_t)(4 * r), tp, tl), line((size_t)(4 * r + 1), sp, sl), line((size_t)(4 * r + 3), qp, ql);
 		(void)tl, (void)sl, (void)ql;
 		const size_t s_len = slen[(size_t)r], t_len = tlen[(size_t)r];
 		memcpy(fq->bases.p + fq->offsets[(size_t)r], sp, s_len);
-		memcpy(fq->quals.p + fq->offsets[(size_t)r], qp, s_len);
+		fq->rec_off[(size_t)r] = text0 + (size_t)(tp - base), fq->seq_off[(size_t)r] = text0 + (size_t)(sp - base), fq->qual_off[(size_t)r] = text0 + (size_t)(qp - base);
 		char *t = &fq->titles[(size_t)fq->title_off[(size_t)r]];
 		memcpy(t, tp + 1, t_len);
 		size_t a = 0;
@@ -423,21 +509,32 @@ static int fastq_next_fast(mnc_fastq *fq, uint32_t max_reads, uint64_t max_bases
 		fq->id_len[(size_t)r] = (uint32_t)(b - a), fq->id_off[(size_t)r] = (uint32_t)a;
 	}
 	fq->n = (uint32_t)n;
-	// ---- what was consumed: through the title of the next record, which becomes the pending line
-	if (4 * n - 1 < n_lines) {
-		const char *tp; size_t tl;
-		line(4 * n - 1, tp, tl);
-		fq->pending.assign(tp, tl);
-		fq->have_pending = true;
-		const size_t end = nl[4 * n - 1];
-		in.lo += (open_end && 4 * n - 1 == n_lines - 1) ? end : end + 1;
-	} else {
-		fq->have_pending = false;
-		in.lo = in.hi;
-		fq->done = true;
-	}
+	fq->text_backed = true, fq->quals_ready = false;
+	// ---- what was consumed: the records; the next record's title line stays in the buffer (the pending line)
+	const size_t end = nl[4 * n - 1];
+	const bool last = 4 * n == n_lines;
+	in.lo += (open_end && last) ? end : end + 1;
+	fq->rec_off[n] = in.lo;
+	if (!last) fq->have_pending = true, fq->pending_in_buf = true;
+	else { fq->have_pending = false, fq->pending_in_buf = false; if (in.eof) fq->done = true; }
 	*handled = true;
 	return MNC_OK;
+}
+
+// the quality characters of a text-backed batch, copied out of its text when somebody asks for them
+static bool fastq_fill_quals(mnc_fastq *fq)
+{
+	std::lock_guard<std::mutex> g(fq->q_mu);
+	if (fq->quals_ready) return true;
+	const size_t n = fq->n;
+	if (!fq->quals.ensure((size_t)fq->offsets[n] + 64, 0)) return false;
+	const char *text = fq->text_base();
+	const int T = LineReader::parse_threads();
+#pragma omp parallel for schedule(static) num_threads(T)
+	for (int64_t r = 0; r < (int64_t)n; ++r)
+		memcpy(fq->quals.p + fq->offsets[(size_t)r], text + fq->qual_off[(size_t)r], (size_t)(fq->offsets[(size_t)r + 1] - fq->offsets[(size_t)r]));
+	fq->quals_ready = true;
+	return true;
 }
 
 extern "C" int mnc_fastq_next(mnc_fastq *fq, uint32_t max_reads, uint64_t max_bases, uint32_t *n_reads)
@@ -450,23 +547,38 @@ extern "C" int mnc_fastq_next(mnc_fastq *fq, uint32_t max_reads, uint64_t max_ba
 	fq->id_len.clear();
 	fq->id_off.clear();
 	*n_reads = 0;
+	fq->text_backed = false, fq->quals_ready = true;
+	fq->rec_off.clear(), fq->seq_off.clear(), fq->qual_off.clear(), fq->verbatim.clear();
 	if (fq->done || max_reads == 0) return MNC_OK;
 	const char *p;
 	size_t len;
 	if (!fq->started) {
 		fq->started = true;
-		if (!fq->in.next(p, len)) {
-			if (fq->in.err) return fq_io_fail(fq);
-			fq->done = true;                                                   // empty file
-			return MNC_OK;
+		if (fq->in.seekable && fq->file_size > 0) fq->have_pending = true, fq->pending_in_buf = true;   // the first title line: still in the file
+		else {
+			if (!fq->in.next(p, len)) {
+				if (fq->in.err) return fq_io_fail(fq);
+				fq->done = true;                                               // empty file
+				return MNC_OK;
+			}
+			fq->pending.assign(p, len);
+			fq->have_pending = true;
 		}
-		fq->pending.assign(p, len);
-		fq->have_pending = true;
 	}
 	{
 		bool handled = false;
 		if (int rc = fastq_next_fast(fq, max_reads, max_bases, &handled)) return rc;
 		if (handled) { *n_reads = fq->n; return MNC_OK; }
+	}
+	if (!fastq_unshare(fq, 0)) { set_error("out of host memory"); return MNC_ERR_NOMEM; }   // the general parser refills (and moves) the buffer as it goes
+	if (fq->have_pending && fq->pending_in_buf) {                           // the general parser holds the title line as a string
+		fq->pending_in_buf = false;
+		if (!fq->in.next(p, len)) {
+			if (fq->in.err) return fq_io_fail(fq);
+			fq->have_pending = false, fq->done = true;
+			return MNC_OK;
+		}
+		fq->pending.assign(p, len);
 	}
 	int64_t nb = 0;
 	if (!fq->bases.p && fq->file_size > 0) {
@@ -564,7 +676,12 @@ extern "C" int mnc_fastq_next(mnc_fastq *fq, uint32_t max_reads, uint64_t max_ba
 
 extern "C" const uint8_t *mnc_fastq_bases(const mnc_fastq *fq) { return fq ? fq->bases.p : nullptr; }
 extern "C" const int64_t *mnc_fastq_offsets(const mnc_fastq *fq) { return fq ? fq->offsets.data() : nullptr; }
-extern "C" const uint8_t *mnc_fastq_quals(const mnc_fastq *fq) { return fq ? fq->quals.p : nullptr; }
+extern "C" const uint8_t *mnc_fastq_quals(const mnc_fastq *fq)
+{
+	if (!fq) return nullptr;
+	if (!fq->quals_ready && !fastq_fill_quals(const_cast<mnc_fastq*>(fq))) return nullptr;
+	return fq->quals.p;
+}
 
 extern "C" int mnc_fastq_title(const mnc_fastq *fq, uint32_t r, const char **title, uint32_t *len, uint32_t *id_len)
 {
@@ -573,6 +690,195 @@ extern "C" int mnc_fastq_title(const mnc_fastq *fq, uint32_t r, const char **tit
 	if (len) *len = (uint32_t)(fq->title_off[r + 1] - fq->title_off[r]);
 	if (id_len) *id_len = fq->id_len[r];
 	return MNC_OK;
+}
+
+// A batch that still holds the file's bytes (four-line records, fastq_next_fast): a record that goes out as it came in --
+// unmapped, ambiguous, a focus copy, a mapped one whose id already is its label -- is written from those bytes, runs of
+// consecutive such records as one piece; a mapped record gets its new title line from a small arena and its body (sequence,
+// '+', qualities: two thirds... all but ~40 bytes of it) from the text.  pwritev gathers the pieces: no record is assembled
+// in memory first.  Same files, same bytes, same order as the formatting pass below.
+static int route_from_text(const mnc_fastq *fq, const uint8_t *dest, const int32_t *label, const char *const *labels, const char *const *paths)
+{
+	const char *text = fq->text_base();
+	const uint32_t n = fq->n;
+	const int T = std::max(1, std::min(LineReader::route_threads(), (int)(n / 2048 + 1)));
+	// title line of a mapped record: 0 = as it is, else the bytes of "@<label> " to put in front of the old title (or "@<label>" for an empty one)
+	auto relabel = [&](uint32_t r, int k) -> const char* {
+		if (k != 2 || !label || label[r] < 0) return nullptr;
+		const char *id = labels[label[r]];
+		const size_t idl = strlen(id), t_len = (size_t)(fq->title_off[r + 1] - fq->title_off[r]);
+		const char *tt = fq->titles.data() + fq->title_off[r];
+		if (t_len != 0 && fq->id_len[r] == idl && memcmp(tt + fq->id_off[r], id, idl) == 0) return nullptr;
+		return id;
+	};
+	auto rec_len = [&](uint32_t r, int k) -> size_t {
+		const size_t t_len = (size_t)(fq->title_off[r + 1] - fq->title_off[r]), l = (size_t)(fq->offsets[r + 1] - fq->offsets[r]);
+		size_t head = t_len;
+		if (const char *id = relabel(r, k)) head = t_len == 0 ? strlen(id) : strlen(id) + 1 + t_len;
+		return 1 + head + 1 + l + 3 + l + 1;
+	};
+	// bytes a thread has to make up itself (new title lines; whole records whose text is not what the writer writes)
+	auto arena_len = [&](uint32_t r, int k) -> size_t {
+		if (!fq->verbatim[r]) return rec_len(r, k);
+		if (const char *id = relabel(r, k)) return 1 + strlen(id) + 1;
+		return 0;
+	};
+	std::vector<size_t> slice_bytes((size_t)T * 4, 0), slice_arena((size_t)T, 0);
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+	for (int t = 0; t < T; ++t) {
+		const uint32_t r0 = (uint32_t)((uint64_t)n * (uint64_t)t / (uint64_t)T), r1 = (uint32_t)((uint64_t)n * (uint64_t)(t + 1) / (uint64_t)T);
+		for (uint32_t r = r0; r < r1; ++r)
+			for (int k = 0; k < 4; ++k)
+				if (dest[r] >> k & 1) slice_bytes[(size_t)t * 4 + k] += rec_len(r, k), slice_arena[(size_t)t] += arena_len(r, k);
+	}
+	int fds[4] = { -1, -1, -1, -1 };
+	off_t start[4] = { 0, 0, 0, 0 };
+	int rc = MNC_OK;
+	for (int k = 0; k < 4 && rc == MNC_OK; ++k) {
+		size_t total = 0;
+		for (int t = 0; t < T; ++t) total += slice_bytes[(size_t)t * 4 + k];
+		if (total == 0) continue;
+		fds[k] = open(paths[k], O_WRONLY | O_CREAT, 0666);
+		struct stat sb;
+		if (fds[k] < 0 || fstat(fds[k], &sb) != 0) { set_error("cannot open %s: %s", paths[k], strerror(errno)); rc = MNC_ERR_IO; break; }
+		start[k] = sb.st_size;                                // append: the new records follow what the file holds
+	}
+	// Buffered writes to ONE file take the inode's lock in turn: sixteen threads writing their slices of mapped/<sample>
+	// go one at a time (measured on ext4: 0.20 s for 477 MB into one file, 0.075 s into three).  With MNC_ROUTE_MMAP=1 a
+	// large append goes through a shared mapping of the file's new tail instead: the file is grown and its blocks reserved
+	// once, and the threads' copies fault their pages in side by side (0.10 s on that ext4; on the GPU box's /tmp it is the
+	// slower way, 0.18 against 0.12 s per GB, which is why it is not the default).  Free space is checked before: a store
+	// into a mapping has no error return.  Everything else takes pwritev.
+	char *map_base[4] = { nullptr, nullptr, nullptr, nullptr };
+	size_t map_len[4] = { 0, 0, 0, 0 };
+	off_t map_off[4] = { 0, 0, 0, 0 };
+	if (rc == MNC_OK && getenv("MNC_ROUTE_MMAP") && !getenv("MNC_ROUTE_PWRITE")) {
+		const long page = sysconf(_SC_PAGESIZE);
+		size_t all_bytes = 0;
+		for (size_t b : slice_bytes) all_bytes += b;
+		for (int k = 0; k < 4; ++k) {
+			size_t total = 0;
+			for (int t = 0; t < T; ++t) total += slice_bytes[(size_t)t * 4 + k];
+			// only the file that takes most of the batch (mapped/<sample>, as a rule): writes to different files do not wait
+			// for each other, and a page of a mapping costs more than a page of a write
+			if (fds[k] < 0 || total < (32u << 20) || total * 5 < all_bytes * 3) continue;
+			struct statvfs vfs;
+			if (fstatvfs(fds[k], &vfs) != 0 || (unsigned long long)vfs.f_bavail * vfs.f_frsize < (unsigned long long)total + (64ull << 20)) continue;
+			const int fd2 = open(paths[k], O_RDWR);                // (a mapping for writing wants a descriptor that can read)
+			if (fd2 < 0) continue;
+			// (reserve the blocks: without that every first touch of a page allocates one under the file system's locks --
+			// 0.23 s instead of 0.10 s for 477 MB on ext4 -- and a full disk would show up as a fault, not as an error)
+			if (posix_fallocate(fd2, start[k], (off_t)total) != 0) { close(fd2); continue; }
+			map_off[k] = start[k] / page * page;
+			map_len[k] = (size_t)(start[k] - map_off[k]) + total;
+			void *m = mmap(nullptr, map_len[k], PROT_READ | PROT_WRITE, MAP_SHARED, fd2, map_off[k]);
+			close(fd2);
+			if (m == MAP_FAILED) {                                  // back to the file's old length: pwritev appends
+				map_len[k] = 0;
+				if (ftruncate(fds[k], start[k]) != 0) { set_error("cannot restore %s: %s", paths[k], strerror(errno)); rc = MNC_ERR_IO; break; }
+				continue;
+			}
+			map_base[k] = (char*)m;
+		}
+	}
+	int fail[4] = { 0, 0, 0, 0 };
+	if (rc == MNC_OK) {
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+		for (int t = 0; t < T; ++t) {
+			const uint32_t r0 = (uint32_t)((uint64_t)n * (uint64_t)t / (uint64_t)T), r1 = (uint32_t)((uint64_t)n * (uint64_t)(t + 1) / (uint64_t)T);
+			std::vector<char> arena(slice_arena[(size_t)t] + 16);      // sized exactly: its pieces are pointed at until they are written
+			size_t used = 0;
+			constexpr int IOV_FLUSH = 512;
+			constexpr size_t BYTES_FLUSH = 16u << 20;
+			struct Out { std::vector<iovec> iov; size_t bytes = 0; off_t pos = 0; } out[4];
+			for (int k = 0; k < 4; ++k) {
+				out[k].pos = start[k];
+				for (int u = 0; u < t; ++u) out[k].pos += (off_t)slice_bytes[(size_t)u * 4 + k];
+				out[k].iov.reserve(IOV_FLUSH + 8);
+			}
+			auto flush = [&](int k) {
+				Out &o = out[k];
+				size_t i = 0;
+				off_t pos = o.pos;
+				while (i < o.iov.size()) {
+					const int cnt = (int)std::min<size_t>(o.iov.size() - i, IOV_MAX);
+					ssize_t w = pwritev(fds[k], o.iov.data() + i, cnt, pos);
+					if (w < 0 && errno == EINTR) continue;
+					if (w <= 0) {
+#pragma omp atomic write
+						fail[k] = errno ? errno : EIO;
+						break;
+					}
+					pos += (off_t)w;
+					while (w > 0 && i < o.iov.size()) {               // a short write: go on behind what was taken
+						if ((size_t)w >= o.iov[i].iov_len) { w -= (ssize_t)o.iov[i].iov_len; ++i; }
+						else { o.iov[i].iov_base = (char*)o.iov[i].iov_base + w; o.iov[i].iov_len -= (size_t)w; w = 0; }
+					}
+				}
+				o.pos += (off_t)o.bytes;
+				o.iov.clear(), o.bytes = 0;
+			};
+			auto put = [&](int k, const char *p, size_t len) {
+				Out &o = out[k];
+				if (map_base[k]) {                                   // the file's new tail is mapped: copy in place
+					memcpy(map_base[k] + (o.pos - map_off[k]), p, len);
+					o.pos += (off_t)len;
+					return;
+				}
+				if (!o.iov.empty() && (const char*)o.iov.back().iov_base + o.iov.back().iov_len == p) o.iov.back().iov_len += len;   // the next record of the file: one piece
+				else o.iov.push_back(iovec{ (void*)p, len });
+				o.bytes += len;
+			};
+			for (uint32_t r = r0; r < r1; ++r) {
+				const uint8_t d = dest[r];
+				if (!d) continue;
+				const int64_t l = fq->offsets[r + 1] - fq->offsets[r];
+				for (int k = 0; k < 4; ++k) {
+					if (!(d >> k & 1)) continue;
+					const char *id = relabel(r, k);
+					if (fq->verbatim[r]) {
+						if (!id) put(k, text + fq->rec_off[r], (size_t)(fq->rec_off[r + 1] - fq->rec_off[r]));
+						else {
+							// "@<label> " in front of the old title (the record's own '@' is skipped), or "@<label>" for an empty one
+							char *h = arena.data() + used;
+							const size_t idl = strlen(id), t_len = (size_t)(fq->title_off[r + 1] - fq->title_off[r]);
+							h[0] = '@';
+							memcpy(h + 1, id, idl);
+							size_t hl = 1 + idl;
+							if (t_len) h[hl++] = ' ';
+							used += 1 + idl + 1;
+							put(k, h, hl);
+							put(k, text + fq->rec_off[r] + 1, (size_t)(fq->rec_off[r + 1] - fq->rec_off[r] - 1));
+						}
+					} else {
+						// the record as the writer writes it, from the lines' stripped lengths
+						char *h = arena.data() + used, *w = h;
+						const char *tt = fq->titles.data() + fq->title_off[r];
+						const size_t t_len = (size_t)(fq->title_off[r + 1] - fq->title_off[r]);
+						*w++ = '@';
+						if (id) { const size_t idl = strlen(id); memcpy(w, id, idl), w += idl; if (t_len) *w++ = ' '; }
+						memcpy(w, tt, t_len), w += t_len;
+						*w++ = '\n';
+						memcpy(w, text + fq->seq_off[r], (size_t)l), w += l;
+						memcpy(w, "\n+\n", 3), w += 3;
+						memcpy(w, text + fq->qual_off[r], (size_t)l), w += l;
+						*w++ = '\n';
+						used += rec_len(r, k);
+						put(k, h, (size_t)(w - h));
+					}
+					if (out[k].iov.size() >= (size_t)IOV_FLUSH || out[k].bytes >= BYTES_FLUSH) flush(k);
+				}
+			}
+			for (int k = 0; k < 4; ++k) if (!out[k].iov.empty()) flush(k);
+		}
+	}
+	for (int k = 0; k < 4; ++k) {
+		if (map_base[k] && munmap(map_base[k], map_len[k]) != 0 && !fail[k]) fail[k] = errno ? errno : EIO;
+		if (fds[k] < 0) continue;
+		if (close(fds[k]) != 0 && !fail[k]) fail[k] = errno ? errno : EIO;
+		if (rc == MNC_OK && fail[k]) { set_error("write to %s failed: %s", paths[k], strerror(fail[k])); rc = MNC_ERR_IO; }
+	}
+	return rc;
 }
 
 extern "C" int mnc_fastq_route(const mnc_fastq *fq, const uint8_t *dest, const int32_t *label,
@@ -585,11 +891,18 @@ extern "C" int mnc_fastq_route(const mnc_fastq *fq, const uint8_t *dest, const i
 		for (int k = 0; k < 4; ++k) if ((d >> k & 1) && !paths[k]) { set_error("read %u is routed to a file that was not given", r); return MNC_ERR_ARG; }
 		if ((d >> 2 & 1) && label && label[r] >= 0 && (!labels || label[r] >= n_labels)) { set_error("label %d of read %u is out of range", label[r], r); return MNC_ERR_ARG; }
 	}
+	// (the file's own bytes gathered by pwritev: one copy less in this process, but the kernel then reads cold memory while
+	// it holds the file's lock -- on the GPU box 0.127 s per GB against 0.103 s for the pass below, which formats through
+	// small buffers that are still in the cache when pwrite copies them: profiles/r04f_files_sweep.txt)
+	if (fq->text_backed && fq->n > 0 && getenv("MNC_ROUTE_TEXT")) return route_from_text(fq, dest, label, labels, paths);
+	const bool from_text = fq->text_backed;                      // sequence and qualities straight out of the batch's text
+	if (!from_text && !fq->quals_ready && !fastq_fill_quals(const_cast<mnc_fastq*>(fq))) { set_error("out of host memory"); return MNC_ERR_NOMEM; }
+	const char *text = fq->text_base();
 	// Every record's length in its file is known before it is written (title, two lines of the read's
 	// length, six more characters, the label in front of a mapped record's title): offsets by a prefix
 	// sum, the files grown once, and every host thread formats its slice of the batch through a small
 	// buffer and writes it in place (pwrite) -- the order in each file is the reads' order.
-	const int T = std::max(1, std::min(LineReader::io_threads(), (int)(fq->n / 2048 + 1)));
+	const int T = std::max(1, std::min(LineReader::route_threads(), (int)(fq->n / 2048 + 1)));
 	auto rec_len = [&](uint32_t r, int k) -> size_t {
 		const size_t t_len = (size_t)(fq->title_off[r + 1] - fq->title_off[r]), l = (size_t)(fq->offsets[r + 1] - fq->offsets[r]);
 		size_t head = t_len;
@@ -667,9 +980,9 @@ extern "C" int mnc_fastq_route(const mnc_fastq *fq, const uint8_t *dest, const i
 						else { b.append(id, idl); b.push_back(' '); b.append(tt, t_len); }
 					} else b.append(tt, t_len);
 					b.push_back('\n');
-					b.append((const char*)fq->bases.p + o, (size_t)l);
+					b.append(from_text ? text + fq->seq_off[r] : (const char*)fq->bases.p + o, (size_t)l);
 					b.append("\n+\n", 3);
-					b.append((const char*)fq->quals.p + o, (size_t)l);
+					b.append(from_text ? text + fq->qual_off[r] : (const char*)fq->quals.p + o, (size_t)l);
 					b.push_back('\n');
 					if (b.size() > (2u << 20)) flush(k);
 				}

@@ -554,7 +554,10 @@ __global__ __launch_bounds__(64) void mnc_dp_fillp(Batch B, const int32_t *list,
 	const unsigned long long segmask = LANES == 64 ? ~0ULL : ((1ULL << (LANES & 63)) - 1) << lead;
 	const int thr = B.zdrop_inv < B.zdrop ? B.zdrop_inv : B.zdrop;
 	// few segments (a micro-batch): fewer forward passes per group, so that every workgroup has some
+	// ... and when a workgroup gets between one and two groups: two of equal size (20 passes' worth per workgroup as 16 + 4
+	// leaves three quarters of the workgroups idle while the others run their second group -- as 10 + 10 nobody waits)
 	int g_eff = (int)((n_items + (unsigned long long)gridDim.x * SEGS - 1) / ((unsigned long long)gridDim.x * SEGS));
+	if (g_eff > G_MAX && g_eff < 2 * G_MAX) g_eff = (g_eff + 1) / 2;   // (with more rounds the queue evens the load out, and full groups keep every lane of the walk phase busy)
 	g_eff = g_eff < 1 ? 1 : g_eff > G_MAX ? G_MAX : g_eff;
 	for (;;) {
 		unsigned long long q0 = 0;
@@ -1235,6 +1238,7 @@ __global__ __launch_bounds__(64) void mnc_dp_extp(Batch B, const int32_t *list, 
 	const uint32_t colmask = L == 0 ? 0x0000ffffu : 0u;
 	// few segments: smaller groups, so that every workgroup has some
 	int g_eff = (int)((n_items + (unsigned long long)gridDim.x * SEGS - 1) / ((unsigned long long)gridDim.x * SEGS));
+	if (g_eff > EXTP_G && g_eff < 2 * EXTP_G) g_eff = (g_eff + 1) / 2;
 	g_eff = g_eff < 1 ? 1 : g_eff > EXTP_G ? EXTP_G : g_eff;
 	for (;;) {
 		unsigned long long q0 = 0;

@@ -185,6 +185,65 @@ def test_many_records_parse_and_route_on_all_host_threads(tmp_path):
         assert open(paths[k], "rb").read() == want[k], k
 
 
+def test_large_appends_through_a_mapping_equal_the_formatted_writes(tmp_path, monkeypatch):
+    """SeqIO.write appends record after record (aligner.py:232-243, 265); here a batch's records for one file are
+    written by all routing threads at once: formatted through small buffers (the default), or -- MNC_ROUTE_TEXT=1 --
+    gathered by pwritev from the file's own bytes, or -- with MNC_ROUTE_MMAP=1 as well -- the file that takes most of a
+    large batch has its new tail reserved, mapped and filled in place (buffered writes to ONE file wait for each other).  All three must leave the same
+    bytes, also when the append starts in the middle of a page and when some records are not written as they were read
+    (a '+' line with the title repeated, trailing blanks, CRLF)."""
+    from monica_amd import _capi, synth
+    rng = np.random.default_rng(11)
+    n, L = 9000, 5000                                             # 90 MB of FASTQ: the mapped file's share is above the threshold
+    names, seqs = synth.genome_set(1, min_len=300_000, max_len=300_001, diverged_half=False)
+    bases, offsets, _ = synth.reads(seqs, n, L, seed=5)
+    raw = bases.tobytes()
+    parts = []
+    for r in range(n):
+        s_ = raw[offsets[r]:offsets[r + 1]]
+        q = bytes(rng.integers(33, 127, 1).astype(np.uint8)) * len(s_)
+        t = b"read%d ch=%d" % (r, r % 512)
+        if r % 1000 == 7:
+            parts.append(b"@" + t + b"  \n" + s_ + b"\n+" + t + b"\n" + q + b"\n")      # trailing blanks, the title repeated
+        elif r % 1000 == 9:
+            parts.append(b"@" + t + b"\r\n" + s_ + b"\r\n+\r\n" + q + b"\r\n")          # CRLF
+        else:
+            parts.append(b"@" + t + b"\n" + s_ + b"\n+\n" + q + b"\n")
+    src = tmp_path / "big.fastq"
+    src.write_bytes(b"".join(parts))
+    dest = rng.choice([_capi.TO_UNMAPPED, _capi.TO_AMBIGUOUS, _capi.TO_MAPPED, _capi.TO_MAPPED, _capi.TO_MAPPED, _capi.TO_MAPPED,
+                       _capi.TO_MAPPED | _capi.TO_FOCUS], n).astype(np.uint8)
+    label = np.where(dest & _capi.TO_MAPPED, rng.integers(0, 2, n), -1).astype(np.int32)
+    labels = ["Genus_a", "read17"]                                 # (read17: its own id -- that title stays as it is)
+    results = {}
+    for mode in ("mapped", "pwritev", "formatted"):
+        monkeypatch.delenv("MNC_ROUTE_TEXT", raising=False)
+        monkeypatch.delenv("MNC_ROUTE_MMAP", raising=False)
+        if mode != "formatted":
+            monkeypatch.setenv("MNC_ROUTE_TEXT", "1")
+        if mode == "mapped":
+            monkeypatch.setenv("MNC_ROUTE_MMAP", "1")
+        out = tmp_path / mode
+        out.mkdir()
+        paths = [str(out / k) for k in ("u.fq", "a.fq", "m.fq", "f.fq")]
+        (out / "m.fq").write_bytes(b"@old\nACG\n+\nIII\n")        # 15 bytes: the append starts inside a page
+        for _ in range(2):                                         # monica's loop calls again: a second append
+            rd = _capi.FastqReader(str(src))
+            assert rd.next(n, 1 << 40) == n
+            batch = rd.detach()
+            batch.route(dest, label, labels, paths)
+            batch.close(), rd.close()
+        results[mode] = [open(p_, "rb").read() for p_ in paths]
+    assert results["mapped"] == results["formatted"] and results["pwritev"] == results["formatted"]
+    m = results["mapped"][2]
+    assert m.startswith(b"@old\nACG\n+\nIII\n@")
+    first = int(np.flatnonzero(dest & _capi.TO_MAPPED)[0])
+    s0 = raw[offsets[first]:offsets[first + 1]]
+    assert m[15:].startswith(b"@" + labels[label[first]].encode() + b" read%d ch=%d\n" % (first, first % 512) + s0 + b"\n+\n")
+    assert len(m) == 15 + 2 * (len(m) - 15) // 2 and m.count(b"\r") == 0 and m.count(b"  \n") == 0
+    assert sum(len(x) for x in results["mapped"]) > 150_000_000
+
+
 def test_hitmap_is_sample_hits_with_best_hit(tmp_path):
     """Extending per-id lists part by part and reducing them with best_hit equals the carried summary."""
     import numpy as np

@@ -10,7 +10,8 @@
   config 4  the 500-genome recipe (seed 0x500) in 8 index parts of 62 / 63 genomes -- the split
             dist.shard_bounds gives 8 GPUs -- every part maps ALL reads, MAPQ and the gate per part
             (aligner.py:91-103), per-read summaries merged by best_hit's rule (aligner.py:219-233,
-            328-339): 4 000 reads against the oracle's multi-part loop, 100 000 reads against truth.
+            328-339): all 1 000 000 reads of the config, resident in HBM; 4 000 of them against the oracle's
+            multi-part loop, all of them against truth and the count table.
 The reference's call sequence for both is multi_threaded_aligner's loop (aligner.py:89-103).
 """
 import os
@@ -121,32 +122,56 @@ def _genomes_500():
 
 
 def test_config4_500_genomes_in_eight_parts(capi, oracle):
+    """BASELINE config 4 at its read count: 1 000 000 reads (generated in HBM by ordinal, 5 GB resident) against every one
+    of the 8 index parts, blocks of 100 000 per call, ONE engine rebound part by part; the per-read summaries of the parts
+    merged by best_hit's rule.  The first 4 000 reads (the host generator's same ordinals) against the oracle's multi-part
+    loop hit list by hit list; all 1 M against the generator's truth, and the count table that follows from them."""
     import torch
     from monica_amd import aligner, dist as mdist
+    dev = torch.device("cuda:0")
     names, seqs = _genomes_500()
     assert sum(len(s) for s in seqs) > 2_000_000_000
-    P, n_oracle, n_truth = 8, 4000, 100_000
+    P, n_oracle, n_reads, block, L = 8, 4000, 1_000_000, 100_000, 5000
+    seed = synth.SEED_READS + 4
     bounds = [mdist.shard_bounds(len(names), p, P) for p in range(P)]
     assert sorted(hi - lo for lo, hi in bounds) == [62] * 4 + [63] * 4 and bounds[-1][1] == 500
-    bases, offsets, truth = synth.reads(seqs, n_truth, 5000, seed=synth.SEED_READS + 4)
-    ob_, oo_ = bases[:offsets[n_oracle]], offsets[:n_oracle + 1]
+    gen = synth.DeviceReads(seqs, dev)
+    d_bases = torch.empty(n_reads * L, dtype=torch.uint8, device=dev)
+    d_truth = torch.empty(n_reads, dtype=torch.int32, device=dev)
+    for b0 in range(0, n_reads, 250_000):
+        gen.make(d_bases[b0 * L:], d_truth[b0:], 250_000, L, seed=seed, first=b0)
+    torch.cuda.synchronize()
+    truth = d_truth.cpu().numpy()
+    ob_, oo_, ot_ = synth.reads(seqs, n_oracle, L, seed=seed)
+    assert np.array_equal(ot_, truth[:n_oracle])
+    assert np.array_equal(d_bases[:n_oracle * L].cpu().numpy(), ob_)          # the same reads as the host generator's
+    d_off = torch.arange(block + 1, dtype=torch.int64, device=dev) * L
+    d_assign = torch.empty(n_reads, dtype=torch.int32, device=dev)
+    d_best = torch.zeros(n_reads * 4, dtype=torch.int32, device=dev)
+    d_nhits = torch.zeros(n_reads, dtype=torch.int32, device=dev)
     summaries, lists = [], [[] for _ in range(n_oracle)]
     eng = None
     for lo, hi in bounds:
         pn, ps = names[lo:hi], seqs[lo:hi]
-        idx = capi.Index.from_seqs(pn, ps)
+        idx = capi.Index.from_seqs(pn, ps, device=0)
         if eng is None:
             eng = capi.Engine(idx, 0)
         else:
             eng.set_index(idx)                                    # `index = index_loader(part)`: the same engine, the next part
-        assign, best, nhits = eng.classify(bases, offsets, 60)
-        summaries.append(mdist.shard_summary(assign, best, nhits, rid_offset=lo))
+        torch.cuda.synchronize()
+        for b0 in range(0, n_reads, block):
+            eng.classify_device(d_bases.data_ptr() + b0 * L, d_off.data_ptr(), block, block * L, L, 60,
+                                d_assign.data_ptr() + b0 * 4, d_best.data_ptr() + b0 * 16, d_nhits.data_ptr() + b0 * 4, 0)
+            eng.sync()
+        summaries.append(mdist.shard_summary(d_assign, d_best, d_nhits, rid_offset=lo))
+        assign, nhits = d_assign[:n_oracle].cpu().numpy(), d_nhits[:n_oracle].cpu().numpy()
+        best = d_best[:n_oracle * 4].cpu().numpy().view(capi.HIT_DTYPE)
         oidx = oracle.Index.from_seqs(pn, [s.tobytes() for s in ps])
         assert idx.mid_occ == oidx.mid_occ
         oa, ob, onh, flat = oidx.classify(ob_, oo_, 60, n_threads=N_THREADS)
-        assert np.array_equal(assign[:n_oracle], oa) and np.array_equal(nhits[:n_oracle], onh)
+        assert np.array_equal(assign, oa) and np.array_equal(nhits, onh)
         for k in capi.HIT_DTYPE.names:
-            assert np.array_equal(best[k][:n_oracle], ob[k]), k
+            assert np.array_equal(best[k][onh > 0], ob[k][onh > 0]), k
         k = 0
         for r in range(n_oracle):
             for h in flat[k:k + onh[r]]:
@@ -155,7 +180,7 @@ def test_config4_500_genomes_in_eight_parts(capi, oracle):
         del idx, oidx
     eng.close()
     got, nm, ml, tot = mdist.merge_summaries(torch.stack(summaries))
-    got, tot = got.numpy(), tot.numpy()
+    got, tot = got.cpu().numpy(), tot.cpu().numpy()
     # ---- the reference's multi-part loop on the oracle's hit lists (aligner.py:219-233)
     want = []
     for hits in lists:
@@ -166,9 +191,15 @@ def test_config4_500_genomes_in_eight_parts(capi, oracle):
             want.append(b[0] if b else mdist.AMBIGUOUS)
     assert got[:n_oracle].tolist() == want
     assert tot[:n_oracle].tolist() == [len(h) for h in lists]
-    # ---- all reads against the generator's truth (contig i of the concatenated parts = genome i)
+    # ---- all 1 M reads against the generator's truth (contig i of the concatenated parts = genome i)
     mapped = got >= 0
+    assert abs((truth < 0).mean() - 0.02) < 0.001
     assert mapped.mean() > 0.9
     assert (got[mapped] == truth[mapped]).mean() > 0.999
     assert (got[truth < 0] == mdist.UNMAPPED).all()
-    assert (got == mdist.AMBIGUOUS).sum() < 0.01 * n_truth
+    assert (got == mdist.AMBIGUOUS).sum() < 0.01 * n_reads
+    # ---- the count table of the job ('basic' mode, aligner.py:247-250): one count per mapped read, on its source genome
+    counts = np.bincount(got[mapped], minlength=len(names))
+    assert counts.sum() == mapped.sum() and (counts > 0).sum() >= 499
+    want_counts = np.bincount(truth[truth >= 0], minlength=len(names))
+    assert np.abs(counts - want_counts).sum() < 0.1 * n_reads                # what differs: the reads left unmapped or ambiguous

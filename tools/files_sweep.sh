@@ -1,10 +1,9 @@
-# files mode (bench.py --mode files, second call) against host-thread settings
-# (gpurun -- 'bash tools/files_sweep.sh > gpurun_out/r03_files_sweep.txt')
-for pol in active passive; do
-  for t in 16 12 8 6; do
-    OMP_WAIT_POLICY=$pol MNC_IO_THREADS=$t timeout 200 python3 bench.py --mode files 2>/dev/null | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['second_call']
-print('OMP_WAIT_POLICY=$pol MNC_IO_THREADS=$t second call', s['value'], 'reads/s wall', s['wall_s'], s['aligner_phase_s'])"
-  done
-done
+# files mode (bench.py --mode files, second call) against the write path, the team sizes and the batch size
+run() { env "$@" python bench.py --mode files 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.readline()); s=d['second_call']; print('$*: second call', s['value'], s['wall_s'], s['aligner_phase_s'])"; }
+run X=1
+run MNC_ROUTE_TEXT=1
+run MONICA_AMD_BATCH_READS=50000
+run MONICA_AMD_BATCH_READS=16000
+run MONICA_AMD_BATCH_READS=12500
+run MONICA_AMD_BATCH_READS=8000
