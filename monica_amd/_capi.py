@@ -487,7 +487,7 @@ class Engine:
     def counters(self):
         c = np.zeros(24, dtype=np.int64)
         check(lib().mnc_engine_get_counters(self._h, c.ctypes.data, 24))
-        keys = ["minimizers", "probe_hits", "anchors", "chains", "regions", "gated_hits", "ambiguous_reads", "_",
+        keys = ["minimizers", "probe_hits", "anchors", "chains", "regions", "gated_hits", "ambiguous_reads", "batch_redone",
                 "dp_segments", "dp_fill_tier1", "dp_fill_tier2", "dp_fill_handed_back",
                 "dp_fill_steps_t1", "dp_fill_steps_t2", "dp_fill_steps_t3", "dp_ext_cell_steps",
                 "dp_literal_big", "dp_literal_mid", "dp_long_gaps", "dp_literal_big_handed_back", "dp_long_extensions", "dp_fill_tier3",

@@ -56,7 +56,7 @@ size_t dp_inv_ws_words(int max_gap);
 void launch_dp_inv(const Batch &B, const int32_t *work_list, int32_t *next_list, int32_t *ws, int n_wg, hipStream_t st);
 size_t dp_stitch_pool_slack(int n_wg);
 void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max, long long p_max, long long cig_max,
-                     int lds_state, int lds_p, int lds_cig, int big_pass, hipStream_t st);
+                     int lds_state, int lds_p, int lds_cig, int big_pass, hipStream_t st, int forms = 3);
 void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_list, int max_read_len, int n_wg, hipStream_t st);
 size_t dp_fill_p_slot();
 size_t dp_fillp_slot();
@@ -429,6 +429,8 @@ struct mnc_engine {
 	Buf fill1, fill2, fill3, fill_mid, fill_fb, plan_long, extp, mid_list, lfill, lext, bigfb, ext1, ext2, ext3, ext4, gen_list;
 	size_t seg_cap_override = 0, cig_cap_override = 0;
 	uint32_t *mailbox = nullptr;             // 1 KiB of page-locked host memory the device writes its small read-backs to (mnc_mail)
+	int last_redos = 0;                      // how often the last batch was redone with larger budgets (query records; segment / CIGAR pools; region slots)
+	long long prev_wide_calls = 0;           // calls the last large batch planned for the literal kernel's large-workspace passes (1 and 5)
 	int slot_pad = 2;                        // region slots per read beyond anchors / 3 (device.h: reg_slot); grown when a batch runs out
 	Buf inv_ws;                              // mnc_dp_inv: two columns per workgroup
 	int cur_max_read_len = 0;                // of the batch being classified (sizes the stitch kernel's LDS)
@@ -792,13 +794,19 @@ static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream
 	// per-kernel timers: only when everything runs on one stream (debug bit 0x10000)
 	const bool timed = e->profiling && s0 == s1;
 	auto mark = [&](int stage, int which) { if (timed) { (void)hipEventRecord(e->ev[stage][which], s0); if (which) e->ev_used[stage] = true; } };
-	// the literal kernel's few long calls first of all, on a stream of their own (`s3`: the side stream whose hardware queue no
-	// other uses): a call of the sixteen-wave form needs a whole CU's registers at once -- behind the persistent workgroups
-	// of the gap-filling tiers it would wait until a CU has drained (measured: 13 ms of a block's 36)
+	// The literal kernel's long calls first of all, on a stream of their own (`s3`: the side stream whose hardware queue no
+	// other uses).  A pass has two forms and picks one on the device by its call count: up to 64 calls -- sixteen waves each
+	// (a workgroup needs a whole CU's registers at once: launched before the persistent workgroups of the gap-filling tiers
+	// take the chip, or it would wait for a CU to drain); more -- four waves each, many side by side.
+	// (In a large batch even an idle launch of the sixteen-wave form costs: 64 workgroups that each want a whole CU, 0.15 ms a
+	// launch beside the tiers.  Such a batch launches it for the passes of the truly long calls only, and only when the
+	// engine's previous large batch had any -- reads of one run look alike; the four-wave form takes every call otherwise.)
 	if (s3 != s0) {
-		launch_dp_align(B, e->ws->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 1, s3);
-		launch_dp_align(B, e->ws->dp_ws_mid.as<uint8_t>(), DP_WG_MID, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, 0, 3, s3);
-		launch_dp_align(B, e->ws->dp_ws_huge.as<uint8_t>(), DP_WG_HUGE, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE, DP_LDS_BYTES, 0, 0, 5, s3);
+		const bool small_batch = B.n_reads < 4096;
+		const int forms_long = small_batch || e->prev_wide_calls > 0 ? 3 : 1, forms_mid = small_batch ? 3 : 1;
+		launch_dp_align(B, e->ws->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 1, s3, forms_long | (forms_long == 1 ? 4 : 0));
+		launch_dp_align(B, e->ws->dp_ws_mid.as<uint8_t>(), DP_WG_MID, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, 0, 3, s3, forms_mid | (forms_mid == 1 ? 4 : 0));
+		launch_dp_align(B, e->ws->dp_ws_huge.as<uint8_t>(), DP_WG_HUGE, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE, DP_LDS_BYTES, 0, 0, 5, s3, forms_long | (forms_long == 1 ? 4 : 0));
 	}
 	// the long gaps next, on the batch's own stream: single waves (one call each, ~2 ms) that are on the chip
 	// before the persistent workgroups of the gap-filling tiers take the wave slots
@@ -1156,11 +1164,17 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 			unsigned long long ctr[6] = {0};
 			{
 				MailList ml;
-				ml.n = 1;
+				ml.n = 3;
 				ml.it[0] = { e->dp_ctr.p, 0, 12 };
+				ml.it[1] = { e->dp_ctr.as<unsigned long long>() + 6, 12, 2 }, ml.it[2] = { e->dp_ctr.as<unsigned long long>() + 58, 14, 2 };   // calls of the passes 1 and 5
 				hipLaunchKernelGGL(mnc_mail, dim3(1), dim3(64), 0, st, ml, e->mailbox);
 				HIP_TRY(hipStreamSynchronize(st));
 				memcpy(ctr, e->mailbox, sizeof(ctr));
+				if (round == 0 && n_reads >= 4096) {
+					unsigned long long big = 0, huge = 0;
+					memcpy(&big, e->mailbox + 12, 8), memcpy(&huge, e->mailbox + 14, 8);
+					e->prev_wide_calls = (long long)(big + huge);
+				}
 			}
 			if (ctr[4] != 0) {
 				if (ctr[4] >= 9) { set_error("a gap between two seeds is too large for the alignment workspace"); return MNC_ERR_UNSUPPORTED; }
@@ -1207,7 +1221,7 @@ extern "C" int mnc_classify_device(mnc_engine *e, const uint8_t *d_bases, const 
 		return MNC_OK;
 	}
 	int overflowed = 0, q_redone = 0, dp_redone = 0;
-	e->cur_max_read_len = max_read_len;
+	e->cur_max_read_len = max_read_len, e->last_redos = 0;
 	int rc = MNC_OK;
 	// A batch that outgrows a budget is redone with more room: the query records once (the second try has exact
 	// room), the alignment stage's pools four times as large per try (4^6 times the first budget is beyond any CIGAR
@@ -1215,6 +1229,7 @@ extern "C" int mnc_classify_device(mnc_engine *e, const uint8_t *d_bases, const 
 	for (;;) {
 		rc = classify_once(e, d_bases, d_offsets, n_reads, total_bases, min_mapq, d_assign, d_best, d_nhits, d_counts, &overflowed);
 		if (rc || !overflowed) break;
+		++e->last_redos;
 		if (overflowed == 1 && ++q_redone > 1) { set_error("query record budget exceeded twice"); rc = MNC_ERR_NOMEM; break; }
 		if (overflowed == 2 && ++dp_redone > 6) { set_error("segment / CIGAR pools of the alignment stage exceeded after %d enlargements", dp_redone - 1); rc = MNC_ERR_NOMEM; break; }
 	}
@@ -1380,7 +1395,7 @@ extern "C" int mnc_engine_get_counters(mnc_engine *e, int64_t *c, int n)
 	for (int i = 0; i < n; ++i) c[i] = 0;
 	for (size_t r = 0; r < nr; ++r) c[0] += a[r], c[1] += b[r], c[3] += d[r], c[4] += g[r], c[5] += h[r], c[6] += amb[r] ? 1 : 0;
 	c[2] = e->last_total_anchors;
-	c[7] = 0;
+	c[7] = e->last_redos;                                   // passes over the batch beyond the first (a budget was outgrown: the batch ran again with more room)
 	if (n >= 12 && B.contract == MNC_CONTRACT_DP && e->dp_ctr.p) {
 		unsigned long long d[64];
 		HIP_TRY(hipMemcpy(d, e->dp_ctr.p, sizeof(d), hipMemcpyDeviceToHost));

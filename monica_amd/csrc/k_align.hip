@@ -1453,7 +1453,10 @@ __device__ __attribute__((noinline)) void ksw_wg(int qlen, int tlen, const uint8
 				if (t == last_H0_t + 1) oneb[3] = (unsigned)(cu[c] & 0xff);
 			}
 		}
-		__syncthreads();
+		// the step's barrier: the LDS words above must have landed -- the direction bytes on their way to memory need not
+		// (__syncthreads would wait for them too: a round trip to L2 per anti-diagonal, several microseconds beside kernels
+		// that keep the memory system busy); the barrier behind the loop waits for all of them
+		asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 		// ---- what ksw2 does after the cells of an anti-diagonal, for step r - 1
 		if (r > 0) {
 			const int rp = r - 1;
@@ -2670,7 +2673,7 @@ void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work,
 size_t dp_align_ws_bytes(long long state_max, long long p_max, long long cig_max) { return align_ws(state_max, p_max, cig_max).total; }
 // the literal kernel's long calls with the cells in registers: <16, 1> and <4, 4> (ksw_wg)
 constexpr int ALIGN_SEQ_WIDE = 40960, ALIGN_SEQ_NARROW = 16384;   // LDS bytes per sequence in the two forms
-constexpr int ALIGN_FEW = 256;                                    // up to this many calls in a pass: sixteen waves each (one call per CU at a time)
+constexpr int ALIGN_FEW = 64;                                     // up to this many calls in a pass: sixteen waves each, a workgroup (= a whole CU) per call
 int dp_align_prepare(int lds_bytes)
 {
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -2679,28 +2682,36 @@ int dp_align_prepare(int lds_bytes)
 	if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return MNC_ERR_HIP; }
 	return MNC_OK;
 }
+// `forms`: 3 both forms of a long pass (the call count picks one on the device), 1 | 4 the four-wave form alone for every call.
 void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max, long long p_max, long long cig_max,
-                     int lds_state, int lds_p, int lds_cig, int big_pass, hipStream_t st)
+                     int lds_state, int lds_p, int lds_cig, int big_pass, hipStream_t st, int forms)
 {
 	// The long calls (passes 1, 3, 4, 5: direction bytes in the workspace) on several waves each, cells in registers (ksw_wg):
 	// both forms are launched, the pass's call count -- known on the device only -- decides which of them works.
 	// debug_route bit 5: one wave each, as the rest; 7: four waves with the cells in the workspace (round 3's form); 8:
 	// always the sixteen-wave form; 9: always the four-wave form; (6: the launches below, but cells in the workspace)
-	// The sixteen-wave form needs a whole CU's registers for a workgroup: beside the chip-filling kernels of a large batch
-	// even an idle launch of it waits for CUs to drain (0.7 ms of a 100 000-read batch), so only a micro-batch launches it.
-	const bool long_pass = big_pass == 1 || big_pass >= 3, small_batch = B.n_reads < 4096;
+	// (pass 2, what the banded kernels handed back, likewise: it runs behind the window's join, the chip is its own)
+	const bool long_pass = big_pass >= 1;
 	if (long_pass && !(B.debug_route & (32 | 128))) {
-		const int regime16 = (B.debug_route & 256) ? 0 : ((B.debug_route & 512) || !small_batch) ? -1 : 1;
-		const int regime4 = ((B.debug_route & 512) || (!small_batch && !(B.debug_route & 256))) ? 0 : (B.debug_route & 256) ? -1 : 2;
-		if (regime16 >= 0)
-			hipLaunchKernelGGL((mnc_dp_align<16, 1>), dim3(n_wg), dim3(1024), (size_t)wg_lds_bytes<16>(ALIGN_SEQ_WIDE), st, B, ws, state_max, p_max, cig_max,
+		// (forms bit 2: the four-wave form alone, whatever the count)
+		const int regime16 = (B.debug_route & 256) ? 0 : (B.debug_route & 512) ? -1 : 1;
+		const int regime4 = ((B.debug_route & 512) || ((forms & 4) && !(B.debug_route & 256))) ? 0 : (B.debug_route & 256) ? -1 : 2;
+		// (a workgroup of the sixteen-wave form takes a whole CU; its launch is as small as its regime: placing hundreds of
+		// such workgroups costs time even when they find nothing to do -- 0.7 ms of a 100 000-read batch with 768 of them)
+		if (regime16 >= 0 && (forms & 2))
+			hipLaunchKernelGGL((mnc_dp_align<16, 1>), dim3(n_wg < ALIGN_FEW ? n_wg : ALIGN_FEW), dim3(1024), (size_t)wg_lds_bytes<16>(ALIGN_SEQ_WIDE), st, B, ws, state_max, p_max, cig_max,
 			                   ALIGN_SEQ_WIDE, 0, 0, big_pass, regime16, ALIGN_FEW);
-		if (regime4 >= 0)
+		if (regime4 >= 0 && (forms & 1) && big_pass == 2 && !(B.debug_route & 512))
+			// what the banded kernels handed back is many small calls as a rule (1 300 per 30 000 reads at 16 % errors): one wave
+			// each out of LDS, two thousand side by side, unless they are few
+			hipLaunchKernelGGL((mnc_dp_align<1>), dim3(n_wg), dim3(64), (size_t)lds_state + lds_p + lds_cig * 4, st, B, ws, state_max, p_max, cig_max,
+			                   lds_state, lds_p, lds_cig, big_pass, regime4, ALIGN_FEW);
+		else if (regime4 >= 0 && (forms & 1))
 			hipLaunchKernelGGL((mnc_dp_align<4, 4>), dim3(n_wg), dim3(256), (size_t)wg_lds_bytes<4>(ALIGN_SEQ_NARROW), st, B, ws, state_max, p_max, cig_max,
 			                   ALIGN_SEQ_NARROW, 0, 0, big_pass, regime4, ALIGN_FEW);
-	} else if (long_pass && !(B.debug_route & 32))
-		hipLaunchKernelGGL((mnc_dp_align<4>), dim3(n_wg), dim3(256), 0, st, B, ws, state_max, p_max, cig_max, 0, 0, 0, big_pass, 0, 0);
-	else
+	} else if (long_pass && !(B.debug_route & 32)) {
+		if (forms & 1) hipLaunchKernelGGL((mnc_dp_align<4>), dim3(n_wg), dim3(256), 0, st, B, ws, state_max, p_max, cig_max, 0, 0, 0, big_pass, 0, 0);
+	} else if (forms & 1)
 		hipLaunchKernelGGL((mnc_dp_align<1>), dim3(n_wg), dim3(64), (size_t)lds_state + lds_p + lds_cig * 4, st, B, ws, state_max, p_max, cig_max,
 		                   lds_state, lds_p, lds_cig, big_pass, 0, 0);
 }
