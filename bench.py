@@ -310,7 +310,7 @@ def main():
                 fill_traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             pass
-        roofline_dp = {"bound": "valu", "kernel": "mnc_dp_fillp<16>", "achieved": round(ach, 2), "peak": round(peak, 1),
+        roofline_dp = {"bound": "valu", "kernel": "mnc_dp_fillp<16, true>", "achieved": round(ach, 2), "peak": round(peak, 1),
                        "unit": "Gcell/s", "frac": round(ach / peak, 4),
                        # the same launch against the guide's nominal issue rate (one wave64 instruction per 2 cycles and SIMD):
                        # the packed-16-bit / perm / DPP instructions this kernel is made of issue at half that (measured)

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # at once; with an ACTIVE wait policy their idle threads spin on every core and the pipeline of aligner.py runs 15x slower
 # (measured: 2.7 s instead of 0.16 s per GB of FASTQ).  Only a default: a policy the user has set is left alone.
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
-LIB_PATH = os.path.join(_HERE, "libmonica_amd.so")
+LIB_PATH = os.environ.get("MONICA_AMD_LIB") or os.path.join(_HERE, "libmonica_amd.so")   # (the override: an experimental build of the same ABI)
 
 OK = 0
 ERR_ARG, ERR_IO, ERR_FORMAT, ERR_NOMEM, ERR_HIP, ERR_NODEVICE, ERR_UNSUPPORTED, ERR_RANGE = range(-1, -9, -1)

@@ -795,10 +795,10 @@ static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream
 	const bool timed = e->profiling && s0 == s1;
 	auto mark = [&](int stage, int which) { if (timed) { (void)hipEventRecord(e->ev[stage][which], s0); if (which) e->ev_used[stage] = true; } };
 	// The literal kernel's long calls first of all, on a stream of their own (`s3`: the side stream whose hardware queue no
-	// other uses).  A pass has two forms and picks one on the device by its call count: up to 64 calls -- sixteen waves each
-	// (a workgroup needs a whole CU's registers at once: launched before the persistent workgroups of the gap-filling tiers
-	// take the chip, or it would wait for a CU to drain); more -- four waves each, many side by side.
-	// (In a large batch even an idle launch of the sixteen-wave form costs: 64 workgroups that each want a whole CU, 0.15 ms a
+	// other uses).  A pass has two forms and picks one on the device by its call count: up to 64 calls -- eight waves each,
+	// two cells a thread (a workgroup needs half a CU's registers at once: launched before the persistent workgroups of the
+	// gap-filling tiers take the chip, or it would wait for a CU to drain); more -- four waves each, many side by side.
+	// (In a large batch even an idle launch of the wide form costs: 64 workgroups that each want half a CU, 0.15 ms a
 	// launch beside the tiers.  Such a batch launches it for the passes of the truly long calls only, and only when the
 	// engine's previous large batch had any -- reads of one run look alike; the four-wave form takes every call otherwise.)
 	if (s3 != s0) {
@@ -918,7 +918,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	B.gap_lut = e->gap_lut.as<int32_t>(), B.logf_lut = e->logf_lut.as<float>(), B.logf_a_lut = e->logf_a_lut.as<float>(), B.logf_n = e->logf_n;
 	B.debug_route = (e->debug >> 17 & 15) | ((e->debug >> 22 & 1) << 4) | ((e->debug >> 5 & 1) << 5)    // 0x20: the literal kernel's long calls on one wave each
 	              | ((e->debug >> 6 & 1) << 6) | ((e->debug >> 7 & 1) << 7)                                 // 0x40: several waves, but cells in the workspace; 0x80: round 3's four-wave form
-	              | ((e->debug >> 3 & 1) << 8) | ((e->debug & 1) << 9)                                      // 0x8: always the sixteen-wave form; 0x1: always the four-wave form
+	              | ((e->debug >> 3 & 1) << 8) | ((e->debug & 1) << 9)                                      // 0x8: always the wide form; 0x1: always the four-wave form
 	              | (((unsigned)e->debug >> 31 & 1) << 10);                                                  // 0x80000000: the packed gap-filling kernels without the drifting frame
 	// tuning knobs: debug bits 8-15 and 24-30.  Trying a tier pays when the chance that its band can be proven outweighs
 	// the cost of running the next tier after it as well: 32 cells (1 unit) before 42 (4/3): above three in four;

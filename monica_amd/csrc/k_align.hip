@@ -1267,7 +1267,7 @@ __device__ void ksw_wave(int qlen, int tlen, S8 mem, S32 H, PP p, CP cig,
 // are never read: the walk starts at or below the maximum's anti-diagonal).
 // The sequences lie in LDS, one byte per base; the walk afterwards reads the direction bytes through LDS tiles of
 // 128 anti-diagonals x 128 target positions that all threads load (a walk step is an LDS round trip instead of one to L2).
-// <16, 1>: one call as fast as it goes (a micro-batch, a block with a handful of long calls waits for the longest);
+// <8, 2> (first <16, 1>): one call as fast as it goes (a micro-batch, a block with a handful of long calls waits for the longest);
 // <4, 4>: four times the calls side by side at ~1.5 times the time each (a batch of divergent reads has thousands).
 #define MNC_DPPW(old, src, ctrl, rmask) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rmask), 0xf, false)
 typedef __attribute__((address_space(3))) unsigned long long *lds_u64p;
@@ -1718,7 +1718,7 @@ __host__ __device__ __forceinline__ AlignWs align_ws(long long state_max, long l
 // 3 000 bases is 4 500 anti-diagonals of up to 751 cells, 27 ms on a single wave that a batch of divergent reads waits for.
 // C > 0: the calls that fit run with their cells in registers (ksw_wg<NW, C>, `lds_bytes` = LDS bytes per sequence there).
 // regime 1: this launch only works when the pass has at most `regime_n` calls, regime 2: only when it has more -- the long
-// calls are launched in both forms (few calls: sixteen waves each, every call as fast as it goes; many: four waves with
+// calls are launched in both forms (few calls: eight waves with two cells a thread, every call as fast as it goes; many: four waves with
 // four cells a thread, four times as many side by side), and the count is only known on the device.
 template <int NW, int C = 0>
 __global__ __launch_bounds__(64 * NW) void mnc_dp_align(Batch B, uint8_t *ws_all, long long state_max, long long p_max, long long cig_max,
@@ -2671,13 +2671,21 @@ void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work,
 	}
 }
 size_t dp_align_ws_bytes(long long state_max, long long p_max, long long cig_max) { return align_ws(state_max, p_max, cig_max).total; }
-// the literal kernel's long calls with the cells in registers: <16, 1> and <4, 4> (ksw_wg)
-constexpr int ALIGN_SEQ_WIDE = 40960, ALIGN_SEQ_NARROW = 16384;   // LDS bytes per sequence in the two forms
-constexpr int ALIGN_FEW = 64;                                     // up to this many calls in a pass: sixteen waves each, a workgroup (= a whole CU) per call
+// the literal kernel's long calls with the cells in registers (ksw_wg): <8, 2> for few calls, <4, 4> for many
+constexpr int ALIGN_SEQ_WIDE = 32768, ALIGN_SEQ_NARROW = 16384;   // LDS bytes per sequence in the two forms
+// the form for few calls: eight waves x two cells a thread (measured against sixteen x one: an anti-diagonal costs 8 x 370
+// instead of 16 x 260 vector instructions, and a workgroup needs half a CU instead of a whole one -- a config-4 block 33.1
+// instead of 35.1 ms, 30 000 reads with 13 % errors 37 instead of 39 ms: tools/ab_wide.sh)
+#ifndef MNC_WIDE_NW
+#define MNC_WIDE_NW 8
+#define MNC_WIDE_C 2
+#endif
+constexpr int WIDE_NW = MNC_WIDE_NW, WIDE_C = MNC_WIDE_C;
+constexpr int ALIGN_FEW = 64;                                     // up to this many calls in a pass: the wide form, a workgroup (half a CU's registers) per call
 int dp_align_prepare(int lds_bytes)
 {
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-	if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align<16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, wg_lds_bytes<16>(ALIGN_SEQ_WIDE));
+	if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align<WIDE_NW, WIDE_C>), hipFuncAttributeMaxDynamicSharedMemorySize, wg_lds_bytes<WIDE_NW>(ALIGN_SEQ_WIDE));
 	if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, wg_lds_bytes<4>(ALIGN_SEQ_NARROW));
 	if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return MNC_ERR_HIP; }
 	return MNC_OK;
@@ -2689,17 +2697,18 @@ void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max,
 	// The long calls (passes 1, 3, 4, 5: direction bytes in the workspace) on several waves each, cells in registers (ksw_wg):
 	// both forms are launched, the pass's call count -- known on the device only -- decides which of them works.
 	// debug_route bit 5: one wave each, as the rest; 7: four waves with the cells in the workspace (round 3's form); 8:
-	// always the sixteen-wave form; 9: always the four-wave form; (6: the launches below, but cells in the workspace)
+	// always the wide form; 9: always the four-wave form; (6: the launches below, but cells in the workspace)
 	// (pass 2, what the banded kernels handed back, likewise: it runs behind the window's join, the chip is its own)
 	const bool long_pass = big_pass >= 1;
 	if (long_pass && !(B.debug_route & (32 | 128))) {
 		// (forms bit 2: the four-wave form alone, whatever the count)
 		const int regime16 = (B.debug_route & 256) ? 0 : (B.debug_route & 512) ? -1 : 1;
 		const int regime4 = ((B.debug_route & 512) || ((forms & 4) && !(B.debug_route & 256))) ? 0 : (B.debug_route & 256) ? -1 : 2;
-		// (a workgroup of the sixteen-wave form takes a whole CU; its launch is as small as its regime: placing hundreds of
-		// such workgroups costs time even when they find nothing to do -- 0.7 ms of a 100 000-read batch with 768 of them)
+		// (a workgroup of the wide form takes half a CU's registers at once -- a whole CU's in its first, sixteen-wave shape --;
+		// its launch is as small as its regime: placing hundreds of such workgroups beside the tiers costs time even when
+		// they find nothing to do, 0.7 ms of a 100 000-read batch with 768 of them)
 		if (regime16 >= 0 && (forms & 2))
-			hipLaunchKernelGGL((mnc_dp_align<16, 1>), dim3(n_wg < ALIGN_FEW ? n_wg : ALIGN_FEW), dim3(1024), (size_t)wg_lds_bytes<16>(ALIGN_SEQ_WIDE), st, B, ws, state_max, p_max, cig_max,
+			hipLaunchKernelGGL((mnc_dp_align<WIDE_NW, WIDE_C>), dim3(n_wg < ALIGN_FEW ? n_wg : ALIGN_FEW), dim3(64 * WIDE_NW), (size_t)wg_lds_bytes<WIDE_NW>(ALIGN_SEQ_WIDE), st, B, ws, state_max, p_max, cig_max,
 			                   ALIGN_SEQ_WIDE, 0, 0, big_pass, regime16, ALIGN_FEW);
 		if (regime4 >= 0 && (forms & 1) && big_pass == 2 && !(B.debug_route & 512))
 			// what the banded kernels handed back is many small calls as a rule (1 300 per 30 000 reads at 16 % errors): one wave

@@ -276,8 +276,8 @@ def test_every_kernel_family_can_be_taken_out(capi, oracle, world, route):
     without the 42-cell tier of the banded kernel; the last two: the planner sends every gap filling to the widest / to
     the narrowest band first -- which tier proves a band is a matter of speed, never of the result; 0x10 / 0x800000: every
     region planned by the plan kernel's wave form / by its lane form -- a batch this small takes the wave form by itself;
-    The literal kernel's long calls run on a workgroup with the cells in registers (ksw_wg): sixteen waves a call when a
-    pass has few calls, four waves with four cells a thread when it has many; 0x8 / 0x1: always the one / the other form,
+    The literal kernel's long calls run on a workgroup with the cells in registers (ksw_wg): eight waves with two cells a
+    thread when a pass has few calls, four waves with four cells when it has many; 0x8 / 0x1: always the one / the other form,
     0x40 with either: that launch shape with the cells in the workspace, 0x80: round 3's four waves on the workspace, 0x20: one
     wave each.  0x80000000: the packed gap-filling kernels in their plain frame instead of the drifting one (values of
     anti-diagonal r kept as value + e r, which makes a mismatch and a gap extension cost nothing in the recurrence).)"""
@@ -311,7 +311,7 @@ def test_reads_with_many_errors_use_every_workspace_class(capi, oracle, world):
     try:
         eng.set_debug(0x200000)
         _compare_dp(capi, oracle, world, b[: o[120]], o[:121], min_mapq=0)
-        for form in (0x20, 0x8, 0x1, 0x80):                    # the literal kernel's long calls on one wave each; always sixteen / always four waves with the cells in registers; round 3's form
+        for form in (0x20, 0x8, 0x1, 0x80):                    # the literal kernel's long calls on one wave each; always the wide / always the four-wave form with the cells in registers; round 3's form
             eng.set_debug(form)
             _compare_dp(capi, oracle, world, b, o, min_mapq=0)
     finally:

@@ -56,10 +56,10 @@ if probe:
     json.dump(cur, open(path, "w"), indent=1)
     print(tag, "probe HBM bytes/launch", int(probe), "stage", int(sum(x for x in stage if x)))
 # the dominant kernel with base-level alignment: the 32-cell tier of the banded gap-filling kernel
-fk = [x for x in out if "mnc_dp_fillp<16>" in x]
+fk = [x for x in out if "mnc_dp_fillp<16" in x]
 if fk and "FETCH_SIZE" in out[fk[0]] and "WRITE_SIZE" in out[fk[0]]:
     c = out[fk[0]]
-    json.dump({"kernel": "mnc_dp_fillp<16>", "reads": 100000, "read_len": 5000,
+    json.dump({"kernel": fk[0].split("::")[-1], "reads": 100000, "read_len": 5000,
                "hbm_bytes_per_launch": int((2 * c["FETCH_SIZE"]["avg_per_launch"] + c["WRITE_SIZE"]["avg_per_launch"]) * 1024),
                "fetch_size_kib": c["FETCH_SIZE"]["avg_per_launch"], "write_size_kib": c["WRITE_SIZE"]["avg_per_launch"],
                "sq_insts_valu": c.get("SQ_INSTS_VALU", {}).get("avg_per_launch"), "sq_busy_cycles": c.get("SQ_BUSY_CYCLES", {}).get("avg_per_launch"),
@@ -75,3 +75,14 @@ b = os.path.join(root, "gpurun_out", f"prof_{tag}_bench_under_rocprof.json")
 if os.path.exists(b):
     import shutil
     shutil.copy(b, os.path.join(root, "profiles", f"{tag}_bench_under_rocprof.json"))
+
+# the chain DP kernel's issue counters (round 4: VERDICT r03 item 6)
+ck = [x for x in out if "mnc_chain_dp_ring" in x]
+if ck and "SQ_INSTS_VALU" in out[ck[0]]:
+    c = out[ck[0]]
+    g = lambda n: c.get(n, {}).get("avg_per_launch")
+    json.dump({"kernel": ck[0].split("::")[-1], "reads": 100000, "read_len": 5000, "sq_insts_valu": g("SQ_INSTS_VALU"), "sq_busy_cycles": g("SQ_BUSY_CYCLES"),
+               "sq_active_inst_valu": g("SQ_ACTIVE_INST_VALU"), "sq_wave_cycles": g("SQ_WAVE_CYCLES"), "sq_insts_salu": g("SQ_INSTS_SALU"), "sq_insts_lds": g("SQ_INSTS_LDS"),
+               "note": f"{tag}: separate rocprofv3 --pmc passes of bench.py --steps 2 --warmup 1 --contract chain (tools/prof_r04.sh)"},
+              open(os.path.join(root, "profiles", f"{tag}_sq_chain_dp.json"), "w"), indent=1)
+    print("chain DP SQ:", {n: g(n) for n in ("SQ_INSTS_VALU", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES")})
