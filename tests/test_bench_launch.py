@@ -48,7 +48,7 @@ def test_gpus_2_alone_reports_two_ranks():
     assert out["ranks"]["group_ranks"] == 2 and out["ranks"]["backend"] == "gloo"
     assert out["ranks"]["reads_per_rank"] == [12000, 12000]
     assert out["rccl_ranks"] == 0                         # gloo rehearsal: RCCL saw nothing, and the line says so
-    assert abs(out["value"] - 24000 / out["timed_region_s"]) / out["value"] < 1e-3
+    assert abs(out["value"] - 24000 / out["timed_region_s"]) / out["value"] < 2e-2      # (the region is rounded to 0.1 ms of ~20)
     # the all-reduced count table holds BOTH ranks' mapped reads (rank 0's own are `mapped_reads_last_step`)
     assert 1.8 * out["mapped_reads_last_step"] < out["counts_checksum"] < 2.2 * out["mapped_reads_last_step"]
 
