@@ -801,13 +801,20 @@ static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream
 	// (In a large batch even an idle launch of the wide form costs: 64 workgroups that each want half a CU, 0.15 ms a
 	// launch beside the tiers.  Such a batch launches it for the passes of the truly long calls only, and only when the
 	// engine's previous large batch had any -- reads of one run look alike; the four-wave form takes every call otherwise.)
-	if (s3 != s0) {
-		const bool small_batch = B.n_reads < 4096;
+	// A micro-batch does not fill the chip: its window is the longest chain of kernels on one stream, and the two long
+	// single-wave kernels (long gaps ~1.7 ms on `s2`, long extensions ~2.1 ms) each get a stream to themselves -- the long
+	// passes go behind the gap-filling tiers on `s0` (1.3 ms of short kernels) there, the long extensions alone on `s3`:
+	// behind a pass with one long call (2.5 ms) they made the slowest batches, 6.1 ms p99.
+	const bool small_batch = B.n_reads < 4096;
+	auto long_passes = [&](hipStream_t sl) {
 		const int forms_long = small_batch || e->prev_wide_calls > 0 ? 3 : 1, forms_mid = small_batch ? 3 : 1;
-		launch_dp_align(B, e->ws->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 1, s3, forms_long | (forms_long == 1 ? 4 : 0));
-		launch_dp_align(B, e->ws->dp_ws_mid.as<uint8_t>(), DP_WG_MID, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, 0, 3, s3, forms_mid | (forms_mid == 1 ? 4 : 0));
-		launch_dp_align(B, e->ws->dp_ws_huge.as<uint8_t>(), DP_WG_HUGE, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE, DP_LDS_BYTES, 0, 0, 5, s3, forms_long | (forms_long == 1 ? 4 : 0));
-	}
+		launch_dp_align(B, e->ws->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 1, sl, forms_long | (forms_long == 1 ? 4 : 0));
+		launch_dp_align(B, e->ws->dp_ws_mid.as<uint8_t>(), DP_WG_MID, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, 0, 3, sl, forms_mid | (forms_mid == 1 ? 4 : 0));
+		launch_dp_align(B, e->ws->dp_ws_huge.as<uint8_t>(), DP_WG_HUGE, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE, DP_LDS_BYTES, 0, 0, 5, sl, forms_long | (forms_long == 1 ? 4 : 0));
+	};
+	if (s3 != s0 && !small_batch) long_passes(s3);
+	// (... and are launched first: the longest kernel of a micro-batch's window)
+	if (s3 != s0 && small_batch) launch_dp_lext(B, B.lext_list, 62, 63, B.fill_fb, 12, e->ws->lext_p.as<uint8_t>(), DP_WG_LEXT, s3);
 	// the long gaps next, on the batch's own stream: single waves (one call each, ~2 ms) that are on the chip
 	// before the persistent workgroups of the gap-filling tiers take the wave slots
 	if (s2 != s0) launch_dp_lfill(B, B.lfill_list, 31, 61, B.fill_fb, 12, e->ws->lfill_p.as<uint8_t>(), DP_WG_LFILL, s2);
@@ -819,6 +826,7 @@ static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream
 	launch_dp_fill(B, 64, B.fill_list2, 11, 14, B.fill_list3, 22, B.fill_fb, 12, e->ws->fill_p.as<uint8_t>(), e->ws->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
 	mark(MNC_STAGE_DP_FILL_T2, 1), mark(MNC_STAGE_DP_FILL_T3, 0);
 	launch_dp_fill(B, 128, B.fill_list3, 22, 23, B.fill_fb, 12, B.fill_fb, 12, e->ws->fill_p.as<uint8_t>(), e->ws->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
+	if (s3 != s0 && small_batch) long_passes(s0);
 	mark(MNC_STAGE_DP_FILL_T3, 1), mark(MNC_STAGE_DP_LFILL, 0);
 	if (s2 == s0) launch_dp_lfill(B, B.lfill_list, 31, 61, B.fill_fb, 12, e->ws->lfill_p.as<uint8_t>(), DP_WG_LFILL, s0);   // one kernel at a time (profiling)
 	mark(MNC_STAGE_DP_LFILL, 1), mark(MNC_STAGE_DP_EXT, 0);
@@ -833,7 +841,7 @@ static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream
 	mark(MNC_STAGE_DP_EXT, 1);
 	// the long extensions: beside the long gaps in a micro-batch (on the stream of the literal kernel, which has little
 	// to do there), behind them on the batch's stream otherwise
-	launch_dp_lext(B, B.lext_list, 62, 63, B.fill_fb, 12, e->ws->lext_p.as<uint8_t>(), DP_WG_LEXT, B.n_reads < 4096 ? s3 : s2);
+	if (s3 == s0 || !small_batch) launch_dp_lext(B, B.lext_list, 62, 63, B.fill_fb, 12, e->ws->lext_p.as<uint8_t>(), DP_WG_LEXT, s2);
 	if (s3 == s0) {                                            // one kernel at a time (profiling): in their old place
 		launch_dp_align(B, e->ws->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 1, s3);
 		launch_dp_align(B, e->ws->dp_ws_mid.as<uint8_t>(), DP_WG_MID, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, 0, 3, s3);
