@@ -21,6 +21,7 @@ namespace mnc {
 void launch_pack(const Batch &B, hipStream_t st);
 void launch_sketch(const Batch &B, hipStream_t st);
 void launch_partition(const Batch &B, hipStream_t st);
+int partition_prepare();
 void launch_probe(const Batch &B, hipStream_t st);
 void launch_collect(const Batch &B, hipStream_t st);
 void launch_expand_sort(const Batch &B, const uint32_t *lists, const ClassSpans &spans, int NM, hipStream_t st);
@@ -634,6 +635,7 @@ extern "C" int mnc_engine_create(mnc_index *idx, int device, mnc_engine **out)
 	if (!rc) rc = chain_tail_prepare(chain_tail_lds_bytes(CHAIN_CLASSES.nm[CHAIN_CLASSES.n - 1]));
 	if (!rc) rc = expand_sort_prepare(CHAIN_CLASSES.nm[CHAIN_CLASSES.n - 1]);
 	if (!rc) rc = dp_stitch_prepare();
+	if (!rc) rc = partition_prepare();
 	if (!rc) rc = dp_gather_long_prepare(CHAIN_CLASSES.nm[CHAIN_CLASSES.n - 1]);
 	if (!rc) rc = dp_plan_prepare();
 	if (!rc) {

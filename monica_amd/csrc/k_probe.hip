@@ -114,6 +114,102 @@ __global__ __launch_bounds__(PA_THREADS) void mnc_partition_queries(Batch B)
 	}
 }
 
+// ---- K2a for an index with more than 256 table regions: G consecutive tiles a workgroup
+// With 512 / 1 024 regions a tile's runs shrink to 7 / 3.6 records, and the copy-out above writes eighteen address
+// segments per wave store instead of five (0.85 instead of 0.56 ms at 62 genomes).  The runs of consecutive tiles are
+// adjacent in a region's record array, so a workgroup over G = regions / 256 tiles (8 / 16 reads, a wave each) writes
+// runs of 14.5 records again.  The stage holds a record in six bytes -- the read is one of 4 G, the rest is rebuilt on
+// the way out -- and the copy-out goes run by run (sixteen lanes a run), so no region number is kept per record:
+// 60 KB of LDS for G = 2 (two workgroups a CU), 108 KB for G = 4 (one: sixteen waves a CU either way).
+template <int G, class OFF>
+__global__ __launch_bounds__(PA_THREADS * G) void mnc_partition_group(Batch B)
+{
+	constexpr int THREADS = PA_THREADS * G, STAGE = PA_STAGE * G;
+	extern __shared__ __align__(16) uint8_t pa_smem[];
+	const int pb_n = (int)B.pb_n, pb_bits = B.pb_bits;
+	uint32_t *s_lo = reinterpret_cast<uint32_t*>(pa_smem);                    // [STAGE] rest | strand | tandem | low byte of the position
+	OFF *s_off = reinterpret_cast<OFF*>(s_lo + STAGE);                        // [pb_n] start of the group's run in the record array
+	uint32_t *s_cur = reinterpret_cast<uint32_t*>(s_off + pb_n);              // [pb_n]
+	uint32_t *s_loc = s_cur + pb_n;                                           // [pb_n + 1] local exclusive offsets of the runs
+	uint16_t *s_hi = reinterpret_cast<uint16_t*>(s_loc + pb_n + 4);           // [STAGE] position >> 8 | read of the group << 12
+	const uint32_t n_groups = (B.n_tiles + G - 1) / G;
+	const uint32_t per_xcd = (n_groups + 7) / 8;
+	const uint32_t grp = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+	if (grp >= n_groups) return;
+	const uint32_t tile0 = grp * G;
+	const int tid = threadIdx.x, lane = lane_id();
+	const uint32_t r0 = tile0 * PT_READS, r = r0 + (tid >> 6);
+	const bool has = r < B.n_reads;
+	const int64_t off = has ? B.offsets[r] : 0;
+	const int n = has ? B.mz_cnt[r] : 0;
+	const uint2 *mz = B.mz + off;
+	uint2 pre[PA_PRE];
+#pragma unroll
+	for (int k = 0; k < PA_PRE; ++k) pre[k] = k * 64 + lane < n ? mz[k * 64 + lane] : make_uint2(0xffffffffu, 0);
+
+	for (int k = tid; k < pb_n; k += THREADS) {
+		uint32_t c = 0;
+#pragma unroll
+		for (int g = 0; g < G; ++g) if (tile0 + g < B.n_tiles) c += B.hist_tm[(size_t)(tile0 + g) * pb_n + k];
+		s_cur[k] = 0;
+		s_off[k] = (OFF)B.q_off[(size_t)tile0 * pb_n + k];
+		s_loc[k + 1] = c;
+	}
+	if (tid == 0) s_loc[0] = 0;
+	__syncthreads();
+	if (tid < 64) {
+		const int per = pb_n >> 6;
+		uint32_t sum = 0;
+		for (int k = 0; k < per; ++k) sum += s_loc[1 + tid * per + k];
+		uint32_t inc = sum;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (tid >= d) inc += o; }
+		uint32_t run = inc - sum;
+		for (int k = 0; k < per; ++k) { run += s_loc[1 + tid * per + k]; s_loc[1 + tid * per + k] = run; }
+	}
+	__syncthreads();
+	const uint32_t total = s_loc[pb_n];
+	const bool staged = total <= (uint32_t)STAGE;
+	const uint32_t lr = (uint32_t)(tid >> 6);
+	uint32_t prev_hash = 0xffffffffu;
+	for (int i0 = 0; i0 < n; i0 += 64) {
+		const int i = i0 + lane;
+		const bool valid = i < n;
+		uint2 q = make_uint2(0xffffffffu, 0);
+		if (i0 < PA_PRE * 64) {
+#pragma unroll
+			for (int k = 0; k < PA_PRE; ++k) if (i0 == k * 64) q = pre[k];
+		} else if (valid) q = mz[i];
+		uint32_t left = __shfl_up(q.x, 1), right = __shfl_down(q.x, 1);
+		if (lane == 0) left = prev_hash;
+		if (lane == 63 || i + 1 >= n) right = (i + 1 < n) ? mz[i + 1].x : 0xffffffffu;
+		const bool tandem = valid && (q.x == left || q.x == right);
+		prev_hash = __shfl(q.x, 63);
+		if (valid) {
+			const uint32_t b = pb_bucket(q.x, pb_bits);
+			const uint32_t rank = atomicAdd(&s_cur[b], 1u);
+			const int64_t dst = (int64_t)s_off[b] + rank;
+			const uint32_t lo24 = pb_rest(q.x, pb_bits) | (q.y & 1u) << 22 | (tandem ? 1u : 0u) << 23, qpos = q.y >> 1;
+			if (dst >= B.q_cap) *B.overflow = 1u;
+			else if (staged) { const uint32_t at = s_loc[b] + rank; s_lo[at] = lo24 | qpos << 24; s_hi[at] = (uint16_t)((qpos >> 8 & 0xfffu) | lr << 12); }
+			else B.qrec[dst] = (uint64_t)lo24 | (uint64_t)qpos << 24 | (uint64_t)r << 44;
+		}
+	}
+	__syncthreads();
+	if (staged) {
+		// sixteen lanes a run: consecutive lanes write consecutive records of the record array
+		const int sub = tid & 15;
+		for (int b = tid >> 4; b < pb_n; b += THREADS / 16) {
+			const uint32_t lo = s_loc[b], cnt = s_loc[b + 1] - lo;
+			const int64_t dst = (int64_t)s_off[b];
+			for (uint32_t i = sub; i < cnt; i += 16) {
+				const uint32_t a = s_lo[lo + i], h = s_hi[lo + i];
+				if (dst + i < B.q_cap) B.qrec[dst + i] = (uint64_t)a | (uint64_t)(h & 0xfffu) << 32 | (uint64_t)(r0 + (h >> 12)) << 44;
+			}
+		}
+	}
+}
+
 // ================================================================ K2b: probe
 // One wave per run = (bucket, super-tile of 256 reads), about 930 queries.  Workgroups are
 // dealt round-robin over the 8 XCDs, so workgroup g takes bucket (g/8 / W)*8 + g%8: every XCD
@@ -298,10 +394,35 @@ __global__ __launch_bounds__(CO_THREADS) void mnc_collect_hits(Batch B)
 	}
 }
 
+template <int G, class OFF>
+static void launch_partition_group(const Batch &B, hipStream_t st)
+{
+	const size_t lds = (size_t)PA_STAGE * G * 6 + (size_t)B.pb_n * (sizeof(OFF) + 8) + 16;
+	const uint32_t n_groups = (B.n_tiles + G - 1) / G;
+	hipLaunchKernelGGL((mnc_partition_group<G, OFF>), dim3((n_groups + 7) / 8 * 8), dim3(PA_THREADS * G), lds, st, B);
+}
+
+// dynamic LDS above 64 KiB is opted into once per function (and device: called when an engine is made)
+int partition_prepare()
+{
+	const int lds = PA_STAGE * 4 * 6 + PB_N_MAX * 16 + 16;
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_partition_group<4, uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+	if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_partition_group<4, int64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+	if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return MNC_ERR_HIP; }
+	return MNC_OK;
+}
+
 void launch_partition(const Batch &B, hipStream_t st)
 {
 	if (B.n_tiles == 0) return;
 	const bool small = B.q_cap < (1LL << 32);
+	// more than 256 regions: a workgroup over regions / 256 tiles (MNC_PARTITION_TILES=1: the one-tile form, for comparison)
+	static const bool one_tile = getenv("MNC_PARTITION_TILES") && atoi(getenv("MNC_PARTITION_TILES")) == 1;
+	if (B.pb_n > 256 && !one_tile) {
+		if (B.pb_n <= 512) { if (small) launch_partition_group<2, uint32_t>(B, st); else launch_partition_group<2, int64_t>(B, st); }
+		else { if (small) launch_partition_group<4, uint32_t>(B, st); else launch_partition_group<4, int64_t>(B, st); }
+		return;
+	}
 	const size_t fixed = (size_t)PA_STAGE * 8 + (size_t)B.pb_n * (small ? 12 : 16) + 16, bk = (size_t)PA_STAGE * (B.pb_n <= 256 ? 1 : 2);
 	const dim3 grid((B.n_tiles + 7) / 8 * 8);
 	if (B.pb_n <= 256 && small) hipLaunchKernelGGL((mnc_partition_queries<uint8_t, uint32_t>), grid, dim3(PA_THREADS), fixed + bk, st, B);
