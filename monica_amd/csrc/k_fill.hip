@@ -529,8 +529,11 @@ constexpr int FILLP_BLOCKS = (2 * FILL_MAX_LEN + 15) / 16 + 1;           // 16-s
 constexpr size_t FILLP_PASS_BYTES = (size_t)FILLP_BLOCKS * 64 * 32;
 constexpr size_t FILLP_SLOT = FILLP_G_MAX * FILLP_PASS_BYTES;
 
+#ifndef MNC_FILLP_WAVES
+#define MNC_FILLP_WAVES 4      // at most 128 registers a lane: four waves a SIMD (the drifting frame took 164 left alone: three)
+#endif
 template <int LANES, bool DRIFT>
-__global__ __launch_bounds__(64) void mnc_dp_fillp(Batch B, const int32_t *list, int ctr_n, int ctr_q, int32_t *next_list, int ctr_next,
+__global__ __launch_bounds__(64, MNC_FILLP_WAVES) void mnc_dp_fillp(Batch B, const int32_t *list, int ctr_n, int ctr_q, int32_t *next_list, int ctr_next,
                                                    int32_t *fb_list, int ctr_fb, uint8_t *p_all, uint32_t *cig_all)
 {
 	constexpr int SEGS = FillpShape<LANES>::SEGS, G_MAX = FillpShape<LANES>::G, W = 2 * LANES, PAD = 2 * W, SEQ = FILL_MAX_LEN + 1 + 4 * W;
@@ -1214,8 +1217,11 @@ template <int LANES> __device__ __forceinline__ unsigned seg_min_u32(unsigned v)
 }
 __device__ __forceinline__ int pk_half(uint32_t v, int h) { return (int)(int16_t)(h ? v >> 16 : v & 0xffffu); }
 
+#ifndef MNC_EXTP_WAVES
+#define MNC_EXTP_WAVES 4
+#endif
 template <int LANES, int CPL, int RGT>
-__global__ __launch_bounds__(64) void mnc_dp_extp(Batch B, const int32_t *list, int ctr_n, int ctr_q, uint8_t *p_all, uint32_t *cig_all)
+__global__ __launch_bounds__(64, MNC_EXTP_WAVES) void mnc_dp_extp(Batch B, const int32_t *list, int ctr_n, int ctr_q, uint8_t *p_all, uint32_t *cig_all)
 {
 	constexpr int SEGS = 64 / LANES, WC = 2 * CPL * LANES, PAD = WC + 2, SEQ = PAD + EXTP_ROWS + 48;
 	constexpr bool LIVE = SEGS > 1;
