@@ -1898,7 +1898,9 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 	extern __shared__ __align__(16) uint8_t st_smem[];
 	uint32_t *s_c = reinterpret_cast<uint32_t*>(st_smem);
 	int8_t *s_d = reinterpret_cast<int8_t*>(st_smem + ST_CIG_MAX * 4);
-	uint8_t *s_q = st_smem + ST_CIG_MAX * 4 + ev_max, *s_t = s_q + seq_q_max;      // ev_max: a multiple of 16
+	// (the codes four bits a base, eight to a word, base i at bits 4 (i & 7) of word i >> 3 -- the index's own layout of a contig:
+	// a byte a base was 11.4 of a region's 17.6 KB, nine regions a CU)
+	uint32_t *s_q = reinterpret_cast<uint32_t*>(st_smem + ST_CIG_MAX * 4 + ev_max), *s_t = s_q + seq_q_max / 8;      // ev_max: a multiple of 16; seq_q_max: of 64
 	const int lane = threadIdx.x;
 	const unsigned long long n_work = B.dp_ctr[9];
 	const bool chunked = n_work >= 4ull * gridDim.x;
@@ -2102,42 +2104,52 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 			bool acgt_only = false;                                   // no ambiguous base in the region's read or target words
 			if (in_lds) {
 				if (!B.ambig[rd]) {
-					// a read of A C G T only: its bases from the sketch stage's 2-bit words, 16 per lane and load
+					// a read of A C G T only: its bases from the sketch stage's 2-bit words (sixteen a word, the first in the top
+					// bits).  A lane builds a word of eight codes from the sixteen bits that hold them: on the read's own strand
+					// the eight fields are turned round first; on the other one they already lie last base first, and are complemented
 					const int64_t g_lo = d.read_off + (rev ? qlen - qe1 : qs1), g_hi = g_lo + ql;
-					for (int64_t wd = (g_lo >> 4) + lane; wd <= (g_hi - 1) >> 4; wd += 64) {
-						const uint32_t v = B.packed[wd];
-#pragma unroll
-						for (int b16 = 0; b16 < 16; ++b16) {
-							const int64_t g = wd * 16 + b16;
-							const int c = (int)(v >> (30 - 2 * b16) & 3u);
-							const int i = rev ? (int)(g_hi - 1 - g) : (int)(g - g_lo);
-							if (g >= g_lo && g < g_hi) s_q[i] = (uint8_t)(rev ? 3 - c : c);
+					for (int w = lane; w * 8 < ql; w += 64) {
+						int64_t g0 = rev ? g_hi - 8 * w - 8 : g_lo + 8 * w;             // first of the eight bases on the read's strand
+						int skip = 0;
+						if (g0 < 0) skip = (int)-g0, g0 = 0;                           // (the batch's very first bases: the word's tail, beyond ql)
+						const uint32_t hi = B.packed[g0 >> 4], lo = B.packed[(g0 >> 4) + 1];
+						const uint32_t sh2 = 2 * (uint32_t)(g0 & 15);
+						uint32_t f = (sh2 ? __builtin_amdgcn_alignbit(hi, lo, 32 - sh2) : hi) >> 16;    // base g0 in bits 15:14 .. g0 + 7 in 1:0
+						if (rev) f = (~f & 0xffffu) >> (2 * skip);
+						else {
+							f = __builtin_bitreverse32(f) >> 16;
+							f = (f & 0x5555u) << 1 | (f >> 1 & 0x5555u);
 						}
+						f = (f | f << 8) & 0x00ff00ffu, f = (f | f << 4) & 0x0f0f0f0fu, f = (f | f << 2) & 0x33333333u;
+						s_q[w] = f;
 					}
 				} else
-					for (int i = lane; i < ql; i += 64) s_q[i] = (uint8_t)qcode(read, qlen, rev, qs1 + i);
-				// eight target bases per word
-				const int64_t o0 = coff + rs1, w0 = o0 >> 3, w1 = (o0 + tl + 7) >> 3;
-				uint32_t t_amb = 0;
-				for (int64_t wd = w0 + lane; wd < w1; wd += 64) {
-					const uint32_t v = B.seq4[wd];
-					t_amb |= v & 0xccccccccu;                            // a code above 3 somewhere in these eight bases (or next to the region)
-#pragma unroll
-					for (int b8 = 0; b8 < 8; ++b8) {
-						const int64_t idx = wd * 8 + b8 - o0;
-						if (idx >= 0 && idx < tl) s_t[idx] = (uint8_t)(v >> (b8 * 4) & 15u);
+					for (int w = lane; w * 8 < ql; w += 64) {
+						uint32_t f = 0;
+						for (int b8 = 0; b8 < 8 && w * 8 + b8 < ql; ++b8) f |= (uint32_t)qcode(read, qlen, rev, qs1 + w * 8 + b8) << (4 * b8);
+						s_q[w] = f;
 					}
+				// the target's codes: the contig's own words, moved to the region's first base
+				const int64_t o0 = coff + rs1;
+				const uint32_t sh = (uint32_t)(o0 & 7) * 4;
+				uint32_t t_amb = 0;
+				for (int w = lane; w * 8 < tl; w += 64) {
+					const bool more = sh != 0 && w * 8 + 8 - (int)(o0 & 7) < tl;    // (the next word holds bases of the region: never read past them)
+					const uint32_t a0 = B.seq4[(o0 >> 3) + w], a1 = more ? B.seq4[(o0 >> 3) + w + 1] : 0u;
+					const uint32_t v = sh ? __builtin_amdgcn_alignbit(a1, a0, sh) : a0;
+					t_amb |= v & 0xccccccccu;                                // a code above 3 somewhere in these eight bases (or next to the region)
+					s_t[w] = v;
 				}
 				acgt_only = !B.ambig[rd] && !__any(t_amb != 0);
 			}
 			c_order();
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-			auto Q = [&](int i) -> int { return in_lds ? (int)s_q[i] : qcode(read, qlen, rev, qs1 + i); };
-			auto Tg = [&](int i) -> int { return in_lds ? (int)s_t[i] : tcode(B, coff, rs1 + i); };
-			// four bytes from byte offset `at` of an LDS array (4-aligned base; reads up to three bytes past the last one asked for)
-			auto lds4 = [&](const uint8_t *base, int at) -> uint32_t {
-				const uint32_t *w = reinterpret_cast<const uint32_t*>(base) + (at >> 2);
-				return __builtin_amdgcn_alignbyte(w[1], w[0], (uint32_t)at & 3u);
+			auto Q = [&](int i) -> int { return in_lds ? (int)(s_q[i >> 3] >> (4 * (i & 7)) & 15u) : qcode(read, qlen, rev, qs1 + i); };
+			auto Tg = [&](int i) -> int { return in_lds ? (int)(s_t[i >> 3] >> (4 * (i & 7)) & 15u) : tcode(B, coff, rs1 + i); };
+			// eight codes from base `at` of an LDS array (reads one word past the one that holds the last code asked for)
+			auto lds8 = [&](const uint32_t *base, int at) -> uint32_t {
+				const uint32_t *w = base + (at >> 3);
+				return __builtin_amdgcn_alignbit(w[1], w[0], ((uint32_t)at & 7u) * 4u);
 			};
 			int qshift = 0, tshift = 0;
 			// ---- mm_fix_cigar.  Its common work -- sliding every indel between two M runs to the left
@@ -2384,23 +2396,20 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 						if (!done && pos < len) {
 							const int n = len - pos < 8 ? len - pos : 8;
 							pos += n;
-							const uint32_t q4[2] = { lds4(s_q, qo), lds4(s_q, qo + 4) }, t4[2] = { lds4(s_t, to), lds4(s_t, to + 4) };
+							const uint32_t q8 = lds8(s_q, qo), t8 = lds8(s_t, to);
 							const bool is_m = op == 0;
 							const int sc_match = is_m ? B.sc_a : 0, sc_mis = is_m ? -B.sc_b : 0, sc_amb = is_m ? -B.sc_ambi : 0;
+							// an M run compares the two; an insertion looks at the query's codes only, a deletion at the target's
+							const uint32_t qv = op == 2 ? 0u : q8, tv = op == 1 ? 0u : t8;
+							const uint32_t x8 = qv ^ tv, a8 = (qv | tv) & 0xccccccccu;
 #pragma unroll
-							for (int h = 0; h < 2; ++h) {
-								// an M run compares the two; an insertion looks at the query's codes only, a deletion at the target's
-								const uint32_t qv = op == 2 ? 0u : q4[h], tv = op == 1 ? 0u : t4[h];
-								const uint32_t x4 = qv ^ tv, a4 = (qv | tv) & 0x0c0c0c0cu;
-#pragma unroll
-								for (int b4 = 0; b4 < 4; ++b4) {
-									const bool valid = h * 4 + b4 < n;
-									const bool amb = valid && (a4 >> (8 * b4) & 0xffu) != 0, dif = valid && (x4 >> (8 * b4) & 0xffu) != 0;
-									const int dlt = !valid ? 0 : amb ? sc_amb : dif ? sc_mis : sc_match;
-									c_amb += is_m && amb ? 1 : 0, c_diff += is_m && !amb && dif ? 1 : 0, c_gamb += !is_m && amb ? 1 : 0;
-									A += dlt, Bv = Bv + dlt > 0 ? Bv + dlt : 0;
-									MA = MA > A ? MA : A, MB = MB > Bv ? MB : Bv;
-								}
+							for (int b8 = 0; b8 < 8; ++b8) {
+								const bool valid = b8 < n;
+								const bool amb = valid && (a8 >> (4 * b8) & 0xfu) != 0, dif = valid && (x8 >> (4 * b8) & 0xfu) != 0;
+								const int dlt = !valid ? 0 : amb ? sc_amb : dif ? sc_mis : sc_match;
+								c_amb += is_m && amb ? 1 : 0, c_diff += is_m && !amb && dif ? 1 : 0, c_gamb += !is_m && amb ? 1 : 0;
+								A += dlt, Bv = Bv + dlt > 0 ? Bv + dlt : 0;
+								MA = MA > A ? MA : A, MB = MB > Bv ? MB : Bv;
 							}
 							qo += op == 2 ? 0 : n, to += op == 1 ? 0 : n;
 						}
@@ -2734,7 +2743,7 @@ void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_li
 		t_max = (q_max + q_max / 4 + 127) / 64 * 64;
 	};
 	auto launch = [&](int q_max, int t_max, int q_lo, int t_lo, int q_hi, int t_hi, int ev_max, int wgs) {
-		const size_t lds = (size_t)ST_CIG_MAX * 4 + ev_max + q_max + t_max + 16;   // + 16: the stitch reads whole words, up to eleven bytes past a region's last base
+		const size_t lds = (size_t)ST_CIG_MAX * 4 + ev_max + q_max / 2 + t_max / 2 + 16;   // four bits a base; + 16: the stitch reads a word past the one with a region's last base
 		hipLaunchKernelGGL(mnc_dp_stitch, dim3(wgs), dim3(64), lds, st, B, work_list, next_list, q_max, t_max, q_lo, t_lo, q_hi, t_hi, ev_max);
 	};
 	constexpr int ST_SMALL = 6144;                   // up to here one launch: nine regions per CU (17.6 .. 20 KB of LDS each)
@@ -2766,7 +2775,7 @@ void launch_dp_inv(const Batch &B, const int32_t *work_list, int32_t *next_list,
 int dp_stitch_prepare()
 {
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_stitch), hipFuncAttributeMaxDynamicSharedMemorySize,
-	                                   ST_CIG_MAX * 4 + ST_EV_LONG + ST_LONG_Q + (ST_LONG_Q + ST_LONG_Q / 4 + 127) / 64 * 64 + 16);
+	                                   ST_CIG_MAX * 4 + ST_EV_LONG + ST_LONG_Q / 2 + (ST_LONG_Q + ST_LONG_Q / 4 + 127) / 64 * 64 / 2 + 16);
 	if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return MNC_ERR_HIP; }
 	return MNC_OK;
 }
