@@ -1879,7 +1879,7 @@ __device__ __forceinline__ void dpp_scan_maps(int &a, int &b)
 // LDS: the region's query and target codes (when they fit), the joined CIGAR is built in the
 // region pool.  One wave per region; lane 0 does the sequential bookkeeping, all lanes the walks.
 constexpr int ST_CIG_MAX = 1024;                            // CIGAR words in LDS
-constexpr int ST_EV_MAX = 2048;                             // score events (one byte each) buffered for one scan
+constexpr int ST_EV_MAX = 1024;                             // score events (one byte each) buffered for one scan
 constexpr int ST_EV_LONG = 8192, ST_LONG_Q = 61440;         // ... and in the launch for the regions of long reads; its longest query in LDS
 constexpr unsigned long long ST_POOL_CHUNK = 4096;           // words of the region CIGAR pool a wave reserves at a time
 constexpr int ST_EV_LIM = 127;                              // a gap that costs more is applied directly
@@ -1890,7 +1890,7 @@ __device__ __forceinline__ void append_op(uint32_t *c, int &n, uint32_t word)
 	else c[n++] = word;
 }
 
-__global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work_list, int32_t *next_list, int seq_q_max, int seq_t_max,
+__global__ __launch_bounds__(64, 4) void mnc_dp_stitch(Batch B, const int32_t *work_list, int32_t *next_list, int seq_q_max, int seq_t_max,
                                                     int q_lo, int t_lo, int q_hi, int t_hi, int ev_max)
 {
 	// LDS (dynamic: the sequences are sized for the batch's longest read, so that many regions share a CU):
@@ -1898,9 +1898,10 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 	extern __shared__ __align__(16) uint8_t st_smem[];
 	uint32_t *s_c = reinterpret_cast<uint32_t*>(st_smem);
 	int8_t *s_d = reinterpret_cast<int8_t*>(st_smem + ST_CIG_MAX * 4);
-	// (the codes four bits a base, eight to a word, base i at bits 4 (i & 7) of word i >> 3 -- the index's own layout of a contig:
-	// a byte a base was 11.4 of a region's 17.6 KB, nine regions a CU)
-	uint32_t *s_q = reinterpret_cast<uint32_t*>(st_smem + ST_CIG_MAX * 4 + ev_max), *s_t = s_q + seq_q_max / 8;      // ev_max: a multiple of 16; seq_q_max: of 64
+	// (the target's codes four bits a base, eight to a word, base i at bits 4 (i & 7) of word i >> 3 -- the index's own layout of a
+	// contig; the read's two bits a base, sixteen to a word, base i at bits 2 (i & 15): a read with an ambiguous base is read in place.
+	// A byte a base was 11.4 of a region's 17.6 KB, nine regions a CU; now 4.5 of 9.6 KB, sixteen)
+	uint32_t *s_q = reinterpret_cast<uint32_t*>(st_smem + ST_CIG_MAX * 4 + ev_max), *s_t = s_q + seq_q_max / 16;      // ev_max: a multiple of 16; seq_q_max: of 64
 	const int lane = threadIdx.x;
 	const unsigned long long n_work = B.dp_ctr[9];
 	const bool chunked = n_work >= 4ull * gridDim.x;
@@ -2101,34 +2102,29 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 			// ---- sequences of [qs1, qe1) x [rs1, re1) into LDS (or read in place when too long)
 			const int ql = qe1 - qs1, tl = re1 - rs1;
 			const bool in_lds = ql <= seq_q_max && tl <= seq_t_max;
+			const bool q_lds = in_lds && !B.ambig[rd];                // (two bits hold no ambiguous code: such a read's bases are read in place)
 			bool acgt_only = false;                                   // no ambiguous base in the region's read or target words
 			if (in_lds) {
 				if (!B.ambig[rd]) {
 					// a read of A C G T only: its bases from the sketch stage's 2-bit words (sixteen a word, the first in the top
-					// bits).  A lane builds a word of eight codes from the sixteen bits that hold them: on the read's own strand
-					// the eight fields are turned round first; on the other one they already lie last base first, and are complemented
+					// bits).  A lane builds a word of sixteen codes from the 32 bits that hold them: on the read's own strand the
+					// sixteen fields are turned round; on the other one they already lie last base first, and are complemented
 					const int64_t g_lo = d.read_off + (rev ? qlen - qe1 : qs1), g_hi = g_lo + ql;
-					for (int w = lane; w * 8 < ql; w += 64) {
-						int64_t g0 = rev ? g_hi - 8 * w - 8 : g_lo + 8 * w;             // first of the eight bases on the read's strand
+					for (int w = lane; w * 16 < ql; w += 64) {
+						int64_t g0 = rev ? g_hi - 16 * w - 16 : g_lo + 16 * w;          // first of the sixteen bases on the read's strand
 						int skip = 0;
 						if (g0 < 0) skip = (int)-g0, g0 = 0;                           // (the batch's very first bases: the word's tail, beyond ql)
 						const uint32_t hi = B.packed[g0 >> 4], lo = B.packed[(g0 >> 4) + 1];
 						const uint32_t sh2 = 2 * (uint32_t)(g0 & 15);
-						uint32_t f = (sh2 ? __builtin_amdgcn_alignbit(hi, lo, 32 - sh2) : hi) >> 16;    // base g0 in bits 15:14 .. g0 + 7 in 1:0
-						if (rev) f = (~f & 0xffffu) >> (2 * skip);
+						uint32_t f = sh2 ? __builtin_amdgcn_alignbit(hi, lo, 32 - sh2) : hi;    // base g0 in bits 31:30 .. g0 + 15 in 1:0
+						if (rev) f = ~f >> (2 * skip);
 						else {
-							f = __builtin_bitreverse32(f) >> 16;
-							f = (f & 0x5555u) << 1 | (f >> 1 & 0x5555u);
+							f = __builtin_bitreverse32(f);
+							f = (f & 0x55555555u) << 1 | (f >> 1 & 0x55555555u);
 						}
-						f = (f | f << 8) & 0x00ff00ffu, f = (f | f << 4) & 0x0f0f0f0fu, f = (f | f << 2) & 0x33333333u;
 						s_q[w] = f;
 					}
-				} else
-					for (int w = lane; w * 8 < ql; w += 64) {
-						uint32_t f = 0;
-						for (int b8 = 0; b8 < 8 && w * 8 + b8 < ql; ++b8) f |= (uint32_t)qcode(read, qlen, rev, qs1 + w * 8 + b8) << (4 * b8);
-						s_q[w] = f;
-					}
+				}
 				// the target's codes: the contig's own words, moved to the region's first base
 				const int64_t o0 = coff + rs1;
 				const uint32_t sh = (uint32_t)(o0 & 7) * 4;
@@ -2144,12 +2140,19 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 			}
 			c_order();
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-			auto Q = [&](int i) -> int { return in_lds ? (int)(s_q[i >> 3] >> (4 * (i & 7)) & 15u) : qcode(read, qlen, rev, qs1 + i); };
+			auto Q = [&](int i) -> int { return q_lds ? (int)(s_q[i >> 4] >> (2 * (i & 15)) & 3u) : qcode(read, qlen, rev, qs1 + i); };
 			auto Tg = [&](int i) -> int { return in_lds ? (int)(s_t[i >> 3] >> (4 * (i & 7)) & 15u) : tcode(B, coff, rs1 + i); };
-			// eight codes from base `at` of an LDS array (reads one word past the one that holds the last code asked for)
+			// eight codes from base `at` of the target's LDS array (reads one word past the one that holds the last code asked for);
+			// of the read's: sixteen bits, spread to four bits a code
 			auto lds8 = [&](const uint32_t *base, int at) -> uint32_t {
 				const uint32_t *w = base + (at >> 3);
 				return __builtin_amdgcn_alignbit(w[1], w[0], ((uint32_t)at & 7u) * 4u);
+			};
+			auto lds8q = [&](int at) -> uint32_t {
+				const uint32_t *w = s_q + (at >> 4);
+				uint32_t f = __builtin_amdgcn_alignbit(w[1], w[0], ((uint32_t)at & 15u) * 2u) & 0xffffu;
+				f = (f | f << 8) & 0x00ff00ffu, f = (f | f << 4) & 0x0f0f0f0fu, f = (f | f << 2) & 0x33333333u;
+				return f;
 			};
 			int qshift = 0, tshift = 0;
 			// ---- mm_fix_cigar.  Its common work -- sliding every indel between two M runs to the left
@@ -2386,8 +2389,8 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 						}
 					}
 					if (!__any(!done)) break;
-					if (in_lds) {
-						// up to eight bases per lane and turn, from three aligned LDS words each: the turn's time is the LDS round
+					if (q_lds) {
+						// up to eight bases per lane and turn, from two aligned LDS words each: the turn's time is the LDS round
 						// trip, not the arithmetic
 						// one body for every operation, without branches: a gap's bases only count ambiguous codes (its score
 						// event was applied when it was fetched), and a base beyond the operation's end is an event of 0 -- which
@@ -2396,7 +2399,7 @@ __global__ __launch_bounds__(64) void mnc_dp_stitch(Batch B, const int32_t *work
 						if (!done && pos < len) {
 							const int n = len - pos < 8 ? len - pos : 8;
 							pos += n;
-							const uint32_t q8 = lds8(s_q, qo), t8 = lds8(s_t, to);
+							const uint32_t q8 = lds8q(qo), t8 = lds8(s_t, to);
 							const bool is_m = op == 0;
 							const int sc_match = is_m ? B.sc_a : 0, sc_mis = is_m ? -B.sc_b : 0, sc_amb = is_m ? -B.sc_ambi : 0;
 							// an M run compares the two; an insertion looks at the query's codes only, a deletion at the target's
@@ -2743,7 +2746,7 @@ void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_li
 		t_max = (q_max + q_max / 4 + 127) / 64 * 64;
 	};
 	auto launch = [&](int q_max, int t_max, int q_lo, int t_lo, int q_hi, int t_hi, int ev_max, int wgs) {
-		const size_t lds = (size_t)ST_CIG_MAX * 4 + ev_max + q_max / 2 + t_max / 2 + 16;   // four bits a base; + 16: the stitch reads a word past the one with a region's last base
+		const size_t lds = (size_t)ST_CIG_MAX * 4 + ev_max + q_max / 4 + t_max / 2 + 16;   // two bits a base of the read, four of the contig; + 16: the stitch reads a word past the one with a region's last base
 		hipLaunchKernelGGL(mnc_dp_stitch, dim3(wgs), dim3(64), lds, st, B, work_list, next_list, q_max, t_max, q_lo, t_lo, q_hi, t_hi, ev_max);
 	};
 	constexpr int ST_SMALL = 6144;                   // up to here one launch: nine regions per CU (17.6 .. 20 KB of LDS each)
@@ -2775,7 +2778,7 @@ void launch_dp_inv(const Batch &B, const int32_t *work_list, int32_t *next_list,
 int dp_stitch_prepare()
 {
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_stitch), hipFuncAttributeMaxDynamicSharedMemorySize,
-	                                   ST_CIG_MAX * 4 + ST_EV_LONG + ST_LONG_Q / 2 + (ST_LONG_Q + ST_LONG_Q / 4 + 127) / 64 * 64 / 2 + 16);
+	                                   ST_CIG_MAX * 4 + ST_EV_LONG + ST_LONG_Q / 4 + (ST_LONG_Q + ST_LONG_Q / 4 + 127) / 64 * 64 / 2 + 16);
 	if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return MNC_ERR_HIP; }
 	return MNC_OK;
 }
