@@ -2368,8 +2368,11 @@ __global__ __launch_bounds__(64, 4) void mnc_dp_stitch(Batch B, const int32_t *w
 				// comes early and, when the CIGAR is in LDS, as an LDS read.
 				auto cword = [&](int kk) -> uint32_t { return kk >= k_end ? 0u : c_lds ? s_c[kk] : C[kk]; };
 				uint32_t nxt = cword(k);
+				// scores that fit a signed four-bit field: a turn's eight events as one word (the fast form below)
+				const bool nib_ok = acgt_only && B.sc_a >= 0 && B.sc_a <= 7 && B.sc_b >= 1 && B.sc_b <= 8;
 				for (;;) {
-					if (!done && pos == len) {
+					// (a gap whose bases need no turn is applied on the spot and the next operation fetched in the same turn)
+					while (!done && pos == len) {
 						if (k >= k_end) done = true;
 						else {
 							const uint32_t wd = nxt;
@@ -2389,7 +2392,30 @@ __global__ __launch_bounds__(64, 4) void mnc_dp_stitch(Batch B, const int32_t *w
 						}
 					}
 					if (!__any(!done)) break;
-					if (q_lds) {
+					if (nib_ok) {
+						// no ambiguous code in the region (only M runs have turns: gaps are applied when fetched) and scores that fit
+						// four signed bits: the eight events of a turn are built as ONE word -- a for a base inside the run, less
+						// a + b where the two codes differ, 0 beyond the run's end -- and a base costs one field extract and the map's
+						// five operations instead of fifteen
+						if (!done && pos < len) {
+							const int n = len - pos < 8 ? len - pos : 8;
+							pos += n;
+							const uint32_t x8 = lds8q(qo) ^ lds8(s_t, to);
+							uint32_t y = x8 | x8 >> 1;
+							y |= y >> 2;
+							const uint32_t vm = n < 8 ? 0x11111111u & ((1u << (4 * n)) - 1u) : 0x11111111u;
+							y &= vm;
+							c_diff += __popc(y);
+							const uint32_t D = vm * (uint32_t)B.sc_a + y * (uint32_t)(16 - B.sc_a - B.sc_b);
+#pragma unroll
+							for (int b8 = 0; b8 < 8; ++b8) {
+								const int dlt = (int)(D << (28 - 4 * b8)) >> 28;
+								A += dlt, Bv = Bv + dlt > 0 ? Bv + dlt : 0;
+								MA = MA > A ? MA : A, MB = MB > Bv ? MB : Bv;
+							}
+							qo += n, to += n;
+						}
+					} else if (q_lds) {
 						// up to eight bases per lane and turn, from two aligned LDS words each: the turn's time is the LDS round
 						// trip, not the arithmetic
 						// one body for every operation, without branches: a gap's bases only count ambiguous codes (its score
