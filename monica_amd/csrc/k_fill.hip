@@ -59,6 +59,21 @@ __device__ __forceinline__ int fill_nt4(uint8_t c)
 	}
 }
 
+// base `pq` of strand `rev` of a read as a code 0 .. 3 (4: anything else).  A read of A C G T only (B.ambig, from the sketch
+// stage) is read from that stage's 2-bit words: the switch over the text's letters is a chain of divergent branches, and in
+// the packed kernels it was half of what a forward pass costs beside its anti-diagonals
+__device__ __forceinline__ int fill_qcode(const Batch &B, bool acgt, int64_t roff, const uint8_t *read, int rlen, int rev, int pq)
+{
+	const int p = rev ? rlen - 1 - pq : pq;
+	if (acgt) {
+		const int64_t g = roff + p;
+		const int c = (int)(B.packed[g >> 4] >> (30 - 2 * (int)(g & 15)) & 3u);
+		return rev ? 3 - c : c;
+	}
+	const int c = fill_nt4(read[p]);
+	return rev ? (c < 4 ? 3 - c : 4) : c;
+}
+
 __host__ __device__ __forceinline__ int fill_gap(int l, int q, int e, int q2, int e2)
 {
 	const int g1 = q + e * l, g2 = q2 + e2 * l;
@@ -215,11 +230,9 @@ __global__ __launch_bounds__(64) void mnc_dp_fill(Batch B, const int32_t *list, 
 				const int64_t o = coff + i;
 				s_t[sg][i] = (uint8_t)(B.seq4[o >> 3] >> ((o & 7) * 4) & 15u);
 			}
-			for (int i = L; i < m; i += LANES) {
-				const int pq = g.qs + i;
-				const int c = fill_nt4(read[g.rev ? rlen - 1 - pq : pq]);
-				s_q[sg][i] = (uint8_t)(g.rev ? (c < 4 ? 3 - c : 4) : c);
-			}
+			const bool acgt = !B.ambig[g.read];
+			const int64_t roff = B.offsets[g.read];
+			for (int i = L; i < m; i += LANES) s_q[sg][i] = (uint8_t)fill_qcode(B, acgt, roff, read, rlen, g.rev, g.qs + i);
 		}
 		fill_order();
 		const int rows = ok ? n + m - 1 : 0;
@@ -536,8 +549,15 @@ template <int LANES, bool DRIFT>
 __global__ __launch_bounds__(64, MNC_FILLP_WAVES) void mnc_dp_fillp(Batch B, const int32_t *list, int ctr_n, int ctr_q, int32_t *next_list, int ctr_next,
                                                    int32_t *fb_list, int ctr_fb, uint8_t *p_all, uint32_t *cig_all)
 {
-	constexpr int SEGS = FillpShape<LANES>::SEGS, G_MAX = FillpShape<LANES>::G, W = 2 * LANES, PAD = 2 * W, SEQ = FILL_MAX_LEN + 1 + 4 * W;
+	constexpr int SEGS = FillpShape<LANES>::SEGS, G_MAX = FillpShape<LANES>::G, W = 2 * LANES, PAD = 2 * W, SEQ = FILL_MAX_LEN + 1 + 4 * W + 8;
 	static_assert(SEGS * G_MAX <= 64, "one walk per lane");
+	// The drifting frame has no step with overrides.  Both sequences get a base in front that matches nothing (V = 1): row 0 and
+	// column 0 of the matrix are then ksw2's virtual row and column, and the recurrence itself fills them -- H(0, 0) = 0 is given to the
+	// corner cell as its diagonal source (the two bases in front differ: nothing is added), the gap states it opens run along
+	// row 0 and column 0 as -(q + e l) and -(q2 + e2 l), and H there is their maximum: what the overrides wrote, by the same
+	// comparisons and with the same tags.  A pass runs two steps longer; the steps with overrides cost 1 079 instead of 503
+	// instructions per sixteen, three or four blocks of every pass (a tenth of the kernel).
+	constexpr int V = DRIFT ? 1 : 0;
 	__shared__ uint8_t s_t[SEGS][SEQ], s_q[SEGS][SEQ];        // bases at [PAD + i]; what lies around them feeds cells outside the matrix only
 	__shared__ __align__(16) uint8_t s_chunk[64][32];         // the walk: the 32 direction bytes a lane is reading from
 	__shared__ int32_t s_n[64], s_m[64], s_kmin[64], s_S[64], s_si[64], s_state[64];   // per segment of the group; state 0 none, 1 walk, 2 next tier, 3 literal kernel
@@ -609,22 +629,24 @@ __global__ __launch_bounds__(64, MNC_FILLP_WAVES) void mnc_dp_fillp(Batch B, con
 					const int64_t o = coff + i;
 					const uint32_t c = B.seq4[o >> 3] >> ((o & 7) * 4) & 15u;
 					ambiguous |= c > 3;
-					s_t[sg][PAD + i] = (uint8_t)(c & 3);
+					s_t[sg][PAD + V + i] = (uint8_t)(c & 3);
 				}
+				const bool acgt = !B.ambig[g.read];
+				const int64_t roff = B.offsets[g.read];
 #pragma unroll 1
 				for (int i = L; i < m; i += LANES) {
-					const int pq = g.qs + i;
-					const int c = fill_nt4(read[g.rev ? rlen - 1 - pq : pq]);
+					const int c = fill_qcode(B, acgt, roff, read, rlen, g.rev, g.qs + i);
 					ambiguous |= c > 3;
-					s_q[sg][PAD + i] = (uint8_t)((g.rev ? 3 - c : c) & 3);
+					s_q[sg][PAD + V + i] = (uint8_t)(c & 3);
 				}
+				if (V && L == 0) s_t[sg][PAD] = 4, s_q[sg][PAD] = 5;
 			}
 			const bool seg_amb = (__ballot(ambiguous && live) & segmask) != 0;
 			const bool to_fb = ok && seg_amb;                       // the literal kernel scores an ambiguous base
 			ok = ok && !seg_amb;
 			fill_order();
-			const int rows = ok ? n + m - 1 : 0;
-			int max_rows = (rows + 15) & ~15, edge_rows = ok ? ((-kmin > kmax ? -kmin : kmax) + 2 + 15) & ~15 : 0;
+			const int rows = ok ? n + m - 1 + 2 * V : 0;
+			int max_rows = (rows + 15) & ~15, edge_rows = ok && !V ? ((-kmin > kmax ? -kmin : kmax) + 2 + 15) & ~15 : 0;
 			{
 				// the pass runs as long as its longest segment: the maximum over the segments' first lanes
 				int mr = 0, er = 0;
@@ -654,6 +676,11 @@ __global__ __launch_bounds__(64, MNC_FILLP_WAVES) void mnc_dp_fillp(Batch B, con
 			int tn = PAD + t_lo + 2, jn = PAD - t_lo;
 			uint32_t He = PK_NEG | PK_TAG_H, Ho = He, E = PK_NEG | PK_TAG_E, F = PK_NEG | PK_TAG_F, E2 = PK_NEG | PK_TAG_E2, F2 = PK_NEG, Sc = PK_NEG;
 			uint32_t nbe1 = PK_NEG, nbe2 = PK_NEG, nbf1 = PK_NEG, nbf2 = PK_NEG;
+			if (V && ok) {
+				// the corner: cell -kmin / 2 of step 0 (offset 0); its H comes out as what it is given here
+				const int cc = -kmin >> 1;
+				if (L == cc >> 1) He = pk_bfi(cc & 1 ? 0xffff0000u : 0x0000ffffu, pk_rep(K.bias << 4) | PK_TAG_H, He);
+			}
 			const int rows_m1 = rows - 1;
 			uint4 *pblk = reinterpret_cast<uint4*>(p_wave + (size_t)u * FILLP_PASS_BYTES + lane * 32);
 			int r = 0;
@@ -686,7 +713,7 @@ __global__ __launch_bounds__(64, MNC_FILLP_WAVES) void mnc_dp_fillp(Batch B, con
 			// the proof: every path that leaves the band scores at most U
 			int S = FILL_NEG;
 			{
-				int lc = ok ? n - 1 - ((rows - 1 + kmin + 1) >> 1) : 0;
+				int lc = ok ? n - 1 + V - ((rows - 1 + kmin + 1) >> 1) : 0;
 				lc = lc < 0 ? 0 : lc >= W ? W - 1 : lc;
 				const uint32_t v = (uint32_t)__shfl((int)Sc, lead + (lc >> 1));
 				S = ((int)(int16_t)(lc & 1 ? v >> 16 : v & 0xffffu) >> 4) - K.bias - (DRIFT ? e * (rows - 1) : 0);
@@ -695,7 +722,7 @@ __global__ __launch_bounds__(64, MNC_FILLP_WAVES) void mnc_dp_fillp(Batch B, con
 			}
 			if (leader && has) {
 				const int w = u * SEGS + sg;
-				s_n[w] = n, s_m[w] = m, s_kmin[w] = kmin, s_S[w] = S, s_si[w] = (int32_t)si;
+				s_n[w] = n + V, s_m[w] = m + V, s_kmin[w] = kmin, s_S[w] = S, s_si[w] = (int32_t)si;   // (the walk's matrix: with row and column 0)
 				s_state[w] = ok ? 1 : to_fb ? 3 : 2;
 			}
 			fill_order();                                          // the next pass overwrites the sequences
@@ -711,7 +738,7 @@ __global__ __launch_bounds__(64, MNC_FILLP_WAVES) void mnc_dp_fillp(Batch B, con
 			int bi = n - 1, bj = m - 1, state = 0, cid = -1, mcols = 0, g2 = 0, kd = 0, kbest = 0;   // kd / kbest: see mnc_dp_fill's mm_test_zdrop
 			uint32_t cur = 0, hm32 = 0;
 			bool walking = state_w == 1;
-			while (walking && bi >= 0 && bj >= 0) {
+			while (walking && bi >= V && bj >= V) {
 				const int r = bi + bj, idx = bi - ((r + kmin + 1) >> 1);
 				if (idx < 0 || idx >= W) { state_w = 2; walking = false; break; }   // cannot happen after the proof
 				const int c = (r >> 4) * 64 + (idx >> 1);
@@ -734,7 +761,7 @@ __global__ __launch_bounds__(64, MNC_FILLP_WAVES) void mnc_dp_fillp(Batch B, con
 					const uint32_t m8 = hm32 >> (8 * ((rho & 1) * 2 + (idx & 1))) & 0xffu;
 					const uint32_t zeros = ~m8 & ((2u << bp) - 1u);
 					int run = zeros ? bp - (31 - __clz((int)zeros)) : bp + 1;
-					const int lim = (bi < bj ? bi : bj) + 1;
+					const int lim = (bi < bj ? bi : bj) + 1 - V;
 					run = run < lim ? run : lim;
 					if (run > 0) {
 						if (cur != 0 && (cur & 0xf) == 0) cur += (uint32_t)run << 4;
@@ -778,8 +805,8 @@ __global__ __launch_bounds__(64, MNC_FILLP_WAVES) void mnc_dp_fillp(Batch B, con
 					else g2 += fill_gap(len, q, e, q2, e2), kd += q + e * len, kbest = kbest > kd ? kbest : kd;
 					cg[n_c++] = w;
 				};
-				if (bi >= 0) { if (cur != 0 && (cur & 0xf) == 2) cur += (uint32_t)(bi + 1) << 4; else { if (cur != 0) push(cur); cur = (uint32_t)(bi + 1) << 4 | 2; } }
-				if (bj >= 0) { if (cur != 0 && (cur & 0xf) == 1) cur += (uint32_t)(bj + 1) << 4; else { if (cur != 0) push(cur); cur = (uint32_t)(bj + 1) << 4 | 1; } }
+				if (bi >= V) { if (cur != 0 && (cur & 0xf) == 2) cur += (uint32_t)(bi + 1 - V) << 4; else { if (cur != 0) push(cur); cur = (uint32_t)(bi + 1 - V) << 4 | 2; } }
+				if (bj >= V) { if (cur != 0 && (cur & 0xf) == 1) cur += (uint32_t)(bj + 1 - V) << 4; else { if (cur != 0) push(cur); cur = (uint32_t)(bj + 1 - V) << 4 | 1; } }
 				if (cur != 0) push(cur);
 				// mm_test_zdrop: the drop it looks for is at most (largest sum over contiguous operations of gap costs
 				// less a per M column) + (what all columns that do not match cost against matches, from the score); see
@@ -907,11 +934,9 @@ __global__ __launch_bounds__(64) void mnc_dp_ext(Batch B, const int32_t *list, i
 				const int64_t o = coff + (rv ? g.ts + n - 1 - i : g.ts + i);
 				s_t[sg][i] = (uint8_t)(B.seq4[o >> 3] >> ((o & 7) * 4) & 15u);
 			}
-			for (int i = L; i < m; i += LANES) {
-				const int pq = rv ? g.qs + m - 1 - i : g.qs + i;
-				const int c = fill_nt4(read[g.rev ? rlen - 1 - pq : pq]);
-				s_q[sg][i] = (uint8_t)(g.rev ? (c < 4 ? 3 - c : 4) : c);
-			}
+			const bool acgt = !B.ambig[g.read];
+			const int64_t roff = B.offsets[g.read];
+			for (int i = L; i < m; i += LANES) s_q[sg][i] = (uint8_t)fill_qcode(B, acgt, roff, read, rlen, g.rev, rv ? g.qs + m - 1 - i : g.qs + i);
 		}
 		fill_order();
 		const int rows = ok ? n + m - 1 : 0;
@@ -1290,14 +1315,15 @@ __global__ __launch_bounds__(64, MNC_EXTP_WAVES) void mnc_dp_extp(Batch B, const
 				}
 #pragma unroll 1
 				for (int i = n + L; i < max_rows + 16; i += LANES) s_t[sg][PAD + i] = 4;
+				const bool acgt = !B.ambig[g.read];
+				const int64_t roff = B.offsets[g.read];
 #pragma unroll 1
 				for (int i = L; i < WC; i += LANES) {
 					int c = 5;
 					if (i < m) {
-						const int pq = rv ? g.qs + m - 1 - i : g.qs + i;
-						c = fill_nt4(read[g.rev ? rlen - 1 - pq : pq]);
+						c = fill_qcode(B, acgt, roff, read, rlen, g.rev, rv ? g.qs + m - 1 - i : g.qs + i);
 						ambiguous |= c > 3;
-						c = (g.rev ? 3 - c : c) & 3;
+						c &= 3;
 					}
 					s_q[sg][i] = (uint8_t)c;
 				}
