@@ -74,6 +74,22 @@ __device__ __forceinline__ int fill_qcode(const Batch &B, bool acgt, int64_t rof
 	return rev ? (c < 4 ? 3 - c : 4) : c;
 }
 
+// sixteen bases of strand `rev` of a read of A C G T only, from strand position pq on, as 2-bit codes (base pq + j at bits 2 j):
+// on the read's own strand the sixteen fields of the sketch stage's word are turned round; on the other one they lie last base
+// first already, and are complemented.  Bases beyond the read's end are whatever the neighbouring words hold.
+__device__ __forceinline__ uint32_t fill_qcodes16(const Batch &B, int64_t roff, int rlen, int rev, int pq)
+{
+	int64_t g0 = rev ? roff + rlen - 16 - pq : roff + pq;         // the first of the sixteen bases in the batch's text
+	int skip = 0;
+	if (g0 < 0) skip = (int)-g0, g0 = 0;
+	const uint32_t hi = B.packed[g0 >> 4], lo = B.packed[(g0 >> 4) + 1];
+	const uint32_t sh2 = 2 * (uint32_t)(g0 & 15);
+	uint32_t f = sh2 ? __builtin_amdgcn_alignbit(hi, lo, 32 - sh2) : hi;    // base g0 in bits 31:30 .. g0 + 15 in 1:0
+	if (rev) return ~f >> (2 * skip);
+	f = __builtin_bitreverse32(f);
+	return (f & 0x55555555u) << 1 | (f >> 1 & 0x55555555u);
+}
+
 __host__ __device__ __forceinline__ int fill_gap(int l, int q, int e, int q2, int e2)
 {
 	const int g1 = q + e * l, g2 = q2 + e2 * l;
@@ -549,7 +565,9 @@ template <int LANES, bool DRIFT>
 __global__ __launch_bounds__(64, MNC_FILLP_WAVES) void mnc_dp_fillp(Batch B, const int32_t *list, int ctr_n, int ctr_q, int32_t *next_list, int ctr_next,
                                                    int32_t *fb_list, int ctr_fb, uint8_t *p_all, uint32_t *cig_all)
 {
-	constexpr int SEGS = FillpShape<LANES>::SEGS, G_MAX = FillpShape<LANES>::G, W = 2 * LANES, PAD = 2 * W, SEQ = FILL_MAX_LEN + 1 + 4 * W + 8;
+	constexpr int SEGS = FillpShape<LANES>::SEGS, G_MAX = FillpShape<LANES>::G, W = 2 * LANES;
+	// PAD + 1 (the first real base of the drifting frame's sequences, see V below) is a multiple of eight: whole words go in
+	constexpr int PAD = ((2 * W + 8) & ~7) - 1, SEQ = (FILL_MAX_LEN + 1 + 4 * W + 32 + 7) & ~7;
 	static_assert(SEGS * G_MAX <= 64, "one walk per lane");
 	// The drifting frame has no step with overrides.  Both sequences get a base in front that matches nothing (V = 1): row 0 and
 	// column 0 of the matrix are then ksw2's virtual row and column, and the recurrence itself fills them -- H(0, 0) = 0 is given to the
@@ -558,7 +576,7 @@ __global__ __launch_bounds__(64, MNC_FILLP_WAVES) void mnc_dp_fillp(Batch B, con
 	// comparisons and with the same tags.  A pass runs two steps longer; the steps with overrides cost 1 079 instead of 503
 	// instructions per sixteen, three or four blocks of every pass (a tenth of the kernel).
 	constexpr int V = DRIFT ? 1 : 0;
-	__shared__ uint8_t s_t[SEGS][SEQ], s_q[SEGS][SEQ];        // bases at [PAD + i]; what lies around them feeds cells outside the matrix only
+	__shared__ __align__(16) uint8_t s_t[SEGS][SEQ], s_q[SEGS][SEQ];   // bases at [PAD + i]; what lies around them feeds cells outside the matrix only
 	__shared__ __align__(16) uint8_t s_chunk[64][32];         // the walk: the 32 direction bytes a lane is reading from
 	__shared__ int32_t s_n[64], s_m[64], s_kmin[64], s_S[64], s_si[64], s_state[64];   // per segment of the group; state 0 none, 1 walk, 2 next tier, 3 literal kernel
 	__shared__ int32_t s_item[64];                             // the group's segments, shortest first
@@ -624,22 +642,60 @@ __global__ __launch_bounds__(64, MNC_FILLP_WAVES) void mnc_dp_fillp(Batch B, con
 				const uint8_t *read = B.bases + B.offsets[g.read];
 				const int rlen = (int)(B.offsets[g.read + 1] - B.offsets[g.read]);
 				const int64_t coff = B.seq_off[g.rid] + g.ts;
-#pragma unroll 1
-				for (int i = L; i < n; i += LANES) {
-					const int64_t o = coff + i;
-					const uint32_t c = B.seq4[o >> 3] >> ((o & 7) * 4) & 15u;
-					ambiguous |= c > 3;
-					s_t[sg][PAD + V + i] = (uint8_t)(c & 3);
-				}
 				const bool acgt = !B.ambig[g.read];
 				const int64_t roff = B.offsets[g.read];
+				if (V) {
+					// whole words: eight bases of the contig's 4-bit words, sixteen of the read's 2-bit words per lane and turn, spread to a
+					// byte a base and stored eight bytes at a time (what is written past a sequence's end feeds cells outside the matrix)
+					const uint32_t sh = (uint32_t)(coff & 7) * 4;
 #pragma unroll 1
-				for (int i = L; i < m; i += LANES) {
-					const int c = fill_qcode(B, acgt, roff, read, rlen, g.rev, g.qs + i);
-					ambiguous |= c > 3;
-					s_q[sg][PAD + V + i] = (uint8_t)(c & 3);
+					for (int i = 8 * L; i < n; i += 8 * LANES) {
+						const bool more = sh != 0 && i + 8 - (int)(coff & 7) < n;    // (the next word holds bases of the segment: never read past them)
+						const uint32_t a0 = B.seq4[((coff + i) >> 3)], a1 = more ? B.seq4[((coff + i) >> 3) + 1] : 0u;
+						const uint32_t v = sh ? __builtin_amdgcn_alignbit(a1, a0, sh) : a0;
+						ambiguous |= (v & 0xccccccccu & (n - i < 8 ? (1u << (4 * (n - i))) - 1u : ~0u)) != 0;
+						uint2 w;
+						w.x = v & 0xffffu, w.x = (w.x | w.x << 8) & 0x00ff00ffu, w.x = (w.x | w.x << 4) & 0x03030303u;
+						w.y = v >> 16, w.y = (w.y | w.y << 8) & 0x00ff00ffu, w.y = (w.y | w.y << 4) & 0x03030303u;
+						*reinterpret_cast<uint2*>(&s_t[sg][PAD + 1 + i]) = w;
+					}
+					if (acgt) {
+#pragma unroll 1
+						for (int i = 16 * L; i < m; i += 16 * LANES) {
+							const uint32_t f = fill_qcodes16(B, roff, rlen, g.rev, g.qs + i);
+							uint32_t x[4];
+#pragma unroll
+							for (int k = 0; k < 4; ++k) {
+								const uint32_t b8 = f >> (8 * k) & 0xffu;
+								x[k] = (b8 | b8 << 12) & 0x000f000fu, x[k] = (x[k] | x[k] << 6) & 0x03030303u;
+							}
+							*reinterpret_cast<uint2*>(&s_q[sg][PAD + 1 + i]) = make_uint2(x[0], x[1]);
+							*reinterpret_cast<uint2*>(&s_q[sg][PAD + 1 + i + 8]) = make_uint2(x[2], x[3]);
+						}
+					} else {
+#pragma unroll 1
+						for (int i = L; i < m; i += LANES) {
+							const int c = fill_qcode(B, false, roff, read, rlen, g.rev, g.qs + i);
+							ambiguous |= c > 3;
+							s_q[sg][PAD + 1 + i] = (uint8_t)(c & 3);
+						}
+					}
+					if (L == 0) s_t[sg][PAD] = 4, s_q[sg][PAD] = 5;
+				} else {
+#pragma unroll 1
+					for (int i = L; i < n; i += LANES) {
+						const int64_t o = coff + i;
+						const uint32_t c = B.seq4[o >> 3] >> ((o & 7) * 4) & 15u;
+						ambiguous |= c > 3;
+						s_t[sg][PAD + i] = (uint8_t)(c & 3);
+					}
+#pragma unroll 1
+					for (int i = L; i < m; i += LANES) {
+						const int c = fill_qcode(B, acgt, roff, read, rlen, g.rev, g.qs + i);
+						ambiguous |= c > 3;
+						s_q[sg][PAD + i] = (uint8_t)(c & 3);
+					}
 				}
-				if (V && L == 0) s_t[sg][PAD] = 4, s_q[sg][PAD] = 5;
 			}
 			const bool seg_amb = (__ballot(ambiguous && live) & segmask) != 0;
 			const bool to_fb = ok && seg_amb;                       // the literal kernel scores an ambiguous base
