@@ -537,7 +537,8 @@ __device__ __forceinline__ void fillp_step(const PkConst &K, const int r, const 
 	const uint32_t x3 = (uint32_t)__builtin_amdgcn_bitop3_b32((int)mE, (int)mF, (int)mE2, 0x96);
 	const uint32_t d = pk_bfi(0x000f000fu, z, (x3 ^ mF2) << 4);
 	// two steps' direction bytes per register: (even step: cells 2 L, 2 L + 1; odd step: likewise)
-	acc = ODD ? __builtin_amdgcn_perm(d, acc, 0x06040100u) : __builtin_amdgcn_perm(d, d, 0x0c0c0200u);
+	// (the even step leaves its word as it is; the odd one picks the four bytes out of both -- steps come in pairs)
+	acc = ODD ? __builtin_amdgcn_perm(d, acc, 0x06040200u) : d;
 	if (CAPTURE) Sc = r == rows_m1 ? zt : Sc;                  // the corner's score: only the blocks that hold a segment's last step look for it
 	Hs = zt;
 }
