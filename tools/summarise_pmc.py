@@ -23,6 +23,8 @@ json.dump(out, open(os.path.join(root, "profiles", f"{tag}_pmc_hbm_counters.json
 
 def hbm(kernel):          # FETCH_SIZE / WRITE_SIZE are in KiB; FETCH doubled (gfx950 correction for coalesced streams)
     k = [x for x in out if x.endswith(kernel) or kernel + "<" in x]
+    if not k and kernel == "mnc_partition_queries":        # 512 / 1 024 table regions: the form over several tiles a workgroup
+        k = [x for x in out if "mnc_partition_group<" in x]
     if not k:
         return None
     c = out[k[0]]
