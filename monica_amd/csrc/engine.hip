@@ -75,7 +75,10 @@ void launch_dp_ext(const Batch &B, int lanes, const int32_t *list, int ctr_n, in
 #ifndef MNC_DP_WG_FILL
 #define MNC_DP_WG_FILL (256 * 16)
 #endif
-constexpr int DP_WG_FILL = MNC_DP_WG_FILL, DP_WG_EXT = 256 * 8, DP_WG_STITCH = 4096, DP_WG_INV = 256;
+#ifndef MNC_DP_WG_EXT
+#define MNC_DP_WG_EXT (256 * 8)
+#endif
+constexpr int DP_WG_FILL = MNC_DP_WG_FILL, DP_WG_EXT = MNC_DP_WG_EXT, DP_WG_STITCH = 4096, DP_WG_INV = 256;
 // workspace classes of the alignment kernel: a normal slot per workgroup, a few large ones
 constexpr int DP_LDS_BYTES = 16 * 1024;
 constexpr int DP_LDS0_STATE = 4 * 1024, DP_LDS0_P = 10 * 1024, DP_LDS0_CIG = 256;   // pass 0: 15 KB per workgroup
