@@ -420,7 +420,9 @@ __global__ __launch_bounds__(64) void mnc_dp_fill(Batch B, const int32_t *list, 
 // 1, 0 for E, F, E2, F2, so the four flags of the direction byte are one bit-field insert each.
 // Cell c = 2 L + h of the band: lane L, half h; the neighbour cells' gap states are a DPP move of the
 // neighbouring lane and one v_alignbit.  The virtual row and column only touch the band during its
-// first max(-kmin, kmax) steps: those run a variant of the step with the overrides, the rest without.
+// first max(-kmin, kmax) steps: in the plain frame those run a variant of the step with the overrides, the
+// rest without; in the drifting frame (minimap2's scores) row 0 and column 0 of the matrix ARE the virtual
+// row and column -- a base in front of both sequences -- and every step is the bare one (mnc_dp_fillp, V).
 // A segment with an ambiguous base goes to the literal kernel.
 typedef short pk_s16 __attribute__((ext_vector_type(2)));
 typedef unsigned short pk_u16 __attribute__((ext_vector_type(2)));
