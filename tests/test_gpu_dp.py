@@ -346,3 +346,29 @@ def test_a_batch_of_many_short_regions_fits_the_cigar_pools(capi, oracle, world)
             assert np.array_equal(regs[reg_off[r]:reg_off[r + 1]][name], oregs[name]), f"read {r}: {name}"
     mapped = assign >= 0
     assert mapped.sum() > 0.7 * n and (assign[mapped] == truth[mapped]).mean() > 0.99      # 600-base reads: four in five reach MAPQ 60
+
+
+def test_packed_sequence_loads_at_every_alignment(capi, oracle, world):
+    """The gap-filling and the stitch kernels take a read's bases from the sketch stage's 2-bit words (sixteen a word) and a
+    contig's from its 4-bit words (eight a word), whole words at a time, turned round or complemented by strand.  Reads on the
+    reverse strand at the very start of the batch (the words in front of them do not exist), reads whose offset in the batch
+    is any residue modulo sixteen, regions that start at any residue modulo eight of their contig, reads shorter than a word."""
+    g0, g1 = world["seqs"][0], world["seqs"][1]
+    rng = np.random.default_rng(99)
+
+    def noisy(r):
+        r = r.copy()
+        pos = rng.choice(len(r), len(r) // 25, replace=False)
+        r[pos] = util.ACGT[rng.integers(0, 4, len(pos))]
+        return r
+
+    for lead in range(0, 17, 3):
+        reads = [util.revcomp(noisy(g0[50000 + lead:52500 + 2 * lead]))]                  # read 0 on the reverse strand, batch offset 0
+        for k in range(18):                                                              # every residue of the read's offset and of the contig start
+            s = 60000 + 1013 * k + k
+            piece = noisy((g0 if k & 1 else g1)[s:s + 1800 + k])
+            reads.append(util.revcomp(piece) if k % 3 == 0 else piece)
+            reads.append(util.ACGT[rng.integers(0, 4, 1 + (k + lead) % 23)])              # shifts what follows by 1 .. 23 bases
+        reads.append(util.revcomp(noisy(g1[70000:70300])))                               # the batch's last read: the words behind it are the slack
+        bases, offsets = util.pack_reads(reads)
+        _compare_dp(capi, oracle, world, bases, offsets, min_mapq=0)
