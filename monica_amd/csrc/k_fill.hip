@@ -1435,6 +1435,23 @@ __global__ __launch_bounds__(64, MNC_EXTP_WAVES) void mnc_dp_extp(Batch B, const
 				gv = seg_max_i32<LANES>(gv) - K.bias, av = seg_max_i32<LANES>(av) - K.bias;
 				gv = gv > 0 ? gv : 0;
 				if (ok && g.zdrop >= 0 && rl < rows && gv - av > g.zdrop - slack) suspect = true;
+				// ---- nothing left to find?  From step r + 16 on every cell lies below the diagonal by at least l = r + 16 - 2 m + 2
+				// target bases: H(t, c) <= a (c + 1) - gap(t - c) <= a m - gap(l).  Once that is no more than the best score so far
+				// AND than the best of the query's last row so far, no later cell changes either (an equal score does not replace
+				// the first one): the target window is about twice the query flank, and its last third is such cells.
+				bool fin = !ok || !has;
+				{
+					const int cm = ok ? m - 1 : 0, src = lead + cm / (2 * CPL), km = cm % (2 * CPL) / 2;
+					uint32_t bq = 0;
+#pragma unroll
+					for (int k = 0; k < CPL; ++k) { const uint32_t x = (uint32_t)__shfl((int)best[k], src); if (k == km) bq = x; }
+					if (!fin && r + 16 >= 2 * m) {
+						const int mq = (pk_half(bq, cm & 1) >> 4) - K.bias;
+						const int bound = a * m - fill_gap(r + 16 - 2 * m + 2, q, e, q2, e2);
+						fin = bound <= gv && bound <= mq;
+					}
+				}
+				if (!__any(!fin)) break;
 			}
 			// ---- the best cell: the first step that reached the best score, then the SSE scan's order on that step
 			int ez_max = 0, ez_max_t = -1, ez_max_q = -1, ez_mqe = DP_NEG_INF, ez_mqe_t = -1;
