@@ -1435,19 +1435,33 @@ __global__ __launch_bounds__(64, MNC_EXTP_WAVES) void mnc_dp_extp(Batch B, const
 				gv = seg_max_i32<LANES>(gv) - K.bias, av = seg_max_i32<LANES>(av) - K.bias;
 				gv = gv > 0 ? gv : 0;
 				if (ok && g.zdrop >= 0 && rl < rows && gv - av > g.zdrop - slack) suspect = true;
-				// ---- nothing left to find?  From step r + 16 on every cell lies below the diagonal by at least l = r + 16 - 2 m + 2
-				// target bases: H(t, c) <= a (c + 1) - gap(t - c) <= a m - gap(l).  Once that is no more than the best score so far
-				// AND than the best of the query's last row so far, no later cell changes either (an equal score does not replace
-				// the first one): the target window is about twice the query flank, and its last third is such cells.
-				bool fin = !ok || !has;
+				// ---- nothing left to find?  Every later cell is reached from this block's last two anti-diagonals (the gap states a
+				// cell hands on are below its own H, and lead to cells with no more query left than it has) or from the virtual
+				// column: its score is at most H(cell c) + a (m - 1 - c) -- a diagonal step takes a query base, a gap gains nothing --
+				// or a m - gap(step + 1).  Once that bound is no more than the best score so far AND than the best of the query's
+				// last row so far, no later cell changes either (an equal score does not replace the first one): the target window
+				// is about twice the query flank, and from the step where the query's end passes the diagonal on there is little to find.
+				bool fin = !ok || !has || r + 16 >= rows;
 				{
 					const int cm = ok ? m - 1 : 0, src = lead + cm / (2 * CPL), km = cm % (2 * CPL) / 2;
 					uint32_t bq = 0;
 #pragma unroll
 					for (int k = 0; k < CPL; ++k) { const uint32_t x = (uint32_t)__shfl((int)best[k], src); if (k == km) bq = x; }
-					if (!fin && r + 16 >= 2 * m) {
+					int fv = -(1 << 20);
+#pragma unroll
+					for (int k = 0; k < CPL; ++k) {
+						const uint32_t hm = pk_maxs(H1[k], H2[k]);
+#pragma unroll
+						for (int h = 0; h < 2; ++h) {
+							const int c = 2 * CPL * L + 2 * k + h, fc = (pk_half(hm, h) >> 4) + a * (m - 1 - c);
+							if (c < m) fv = fv > fc ? fv : fc;
+						}
+					}
+					fv = seg_max_i32<LANES>(fv) - K.bias;
+					if (!fin && r + 16 >= m) {                              // (every cell has started: the virtual row is behind)
 						const int mq = (pk_half(bq, cm & 1) >> 4) - K.bias;
-						const int bound = a * m - fill_gap(r + 16 - 2 * m + 2, q, e, q2, e2);
+						const int vc = a * m - fill_gap(r + 17, q, e, q2, e2);
+						const int bound = fv > vc ? fv : vc;
 						fin = bound <= gv && bound <= mq;
 					}
 				}
