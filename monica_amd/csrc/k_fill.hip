@@ -443,7 +443,7 @@ __device__ __forceinline__ uint32_t fillp_opened(uint32_t x)
 	return a << 3 | b << 2 | c << 1 | d;
 }
 constexpr uint32_t PK_TAG_H = 0x000f000fu, PK_TAG_E = 0x00070007u, PK_TAG_F = 0x00030003u, PK_TAG_E2 = 0x00010001u;   // F2: 0
-struct PkConst { uint32_t kmatch, kmis, q8, q28, e8, e28, de28; int bias; };
+struct PkConst { uint32_t kmatch, kmis, q8, q28, e8, e28, de28, dstep; int bias; };
 
 // the span of the scores a band of `cells` can hold, and the bias that centres it in 12 bits
 __host__ __device__ __forceinline__ bool fillp_bias(int cells, int a, int bmis_abs, int q, int e, int q2, int e2, int &bias)
@@ -472,6 +472,9 @@ __host__ __device__ __forceinline__ bool fillp_bias_drift(int a, int q, int e, i
 template <int K> __device__ __forceinline__ uint32_t fillp_next_q(uint32_t Q2, uint32_t w) { return __builtin_amdgcn_perm(Q2, w, 0x05040c00u + K); }      // old low half -> high, byte K -> low
 template <int K> __device__ __forceinline__ uint32_t fillp_next_t(uint32_t T2, uint32_t w) { return __builtin_amdgcn_perm(w, T2, 0x0c040302u + K * 0x10000u); }   // old high half -> low, byte K -> high
 
+#ifndef MNC_FILLP_FRAME2
+#define MNC_FILLP_FRAME2 1
+#endif
 template <int LANES, int ODD, bool EDGE, bool CAPTURE = true, bool DRIFT = false, int KB = -1>
 __device__ __forceinline__ void fillp_step(const PkConst &K, const int r, const int L, const int rows_m1, const uint8_t *st, const uint8_t *sq,
                                            const int q, const int e, const int q2, const int e2,
@@ -520,11 +523,25 @@ __device__ __forceinline__ void fillp_step(const PkConst &K, const int r, const 
 	uint32_t z;
 	if (DRIFT) z = pk_madu(pk_subsu(0x00010001u, T2 ^ Q2), K.kmatch, hd);        // + (a + 2 e) where the bases are equal, nothing where not
 	else z = pk_adds(hd, pk_madu(pk_subsu(0x00010001u, T2 ^ Q2), K.kmatch, K.kmis));   // 1 - min(1, x): the bases are equal
-	z = pk_maxs(z, vE), z = pk_maxs(z, vF), z = pk_maxs(z, vE2), z = pk_maxs(z, vF2);
+	uint32_t o2sub = K.q28;
+	constexpr bool FRAME2 = DRIFT && MNC_FILLP_FRAME2 && LANES <= 32;   // (not the 128-cell tier: the margin below is a few points there)
+	if (FRAME2) {
+		// the second gap piece drifts by e2 a step, not by e: extending it costs nothing either.  Its two states are compared with
+		// each other as they are and brought to H's frame by one add of (e - e2) r; the opening candidate goes the other way,
+		// (e - e2) r off together with q2.  Values of cells no good path visits clamp earlier in this frame (they lie lower by
+		// (e - e2) r), and a state nobody has written reads as the floor + (e - e2) r in H's frame: both stay below every cell of
+		// a path that passes the band proof as long as S > a (n + m) / 2 + floor, which the proof's S > U gives with a margin of
+		// 255 points at 64 cells ("the second piece's frame")
+		const uint32_t Dr = (uint32_t)r * K.dstep;                 // ((e - e2) r) << 4 in both halves (below 2^16: no carry between them)
+		z = pk_maxs(z, vE), z = pk_maxs(z, vF), z = pk_maxs(z, pk_adds(pk_maxs(vE2, vF2), Dr));
+		o2sub = K.q28 + Dr;
+	} else z = pk_maxs(z, vE), z = pk_maxs(z, vF), z = pk_maxs(z, vE2), z = pk_maxs(z, vF2);
 	const uint32_t zt = z | PK_TAG_H;
-	const uint32_t o1 = pk_subs(zt, K.q8), o2 = pk_subs(zt, K.q28);
+	const uint32_t o1 = pk_subs(zt, K.q8), o2 = pk_subs(zt, o2sub);
 	const uint32_t mE = pk_maxs(vE, o1), mF = pk_maxs(vF, o1), mE2 = pk_maxs(vE2, o2), mF2 = pk_maxs(vF2, o2);
-	if (DRIFT) {
+	if (FRAME2) {
+		E = mE & 0xfff7fff7u, F = mF & 0xfff3fff3u, E2 = mE2 & 0xfff1fff1u, F2 = mF2 & 0xfff0fff0u;
+	} else if (DRIFT) {
 		E = mE & 0xfff7fff7u, F = mF & 0xfff3fff3u;                 // (extending costs e - e)
 		E2 = pk_adds(mE2, K.de28) & 0xfff1fff1u, F2 = pk_adds(mF2, K.de28) & 0xfff0fff0u;   // (e2 - e)
 	} else {
@@ -590,7 +607,7 @@ __global__ __launch_bounds__(64, MNC_FILLP_WAVES) void mnc_dp_fillp(Batch B, con
 	const int a = B.sc_a, bmis = -B.sc_b, q = B.gap_q, e = B.gap_e, q2 = B.gap_q2, e2 = B.gap_e2;
 	PkConst K;
 	K.kmatch = pk_rep((DRIFT ? a + 2 * e : a - bmis) << 4), K.kmis = pk_rep(bmis << 4), K.q8 = pk_rep(q << 4), K.q28 = pk_rep(q2 << 4), K.e8 = pk_rep(e << 4), K.e28 = pk_rep(e2 << 4);
-	K.de28 = pk_rep((e - e2) << 4);
+	K.de28 = pk_rep((e - e2) << 4), K.dstep = K.de28;
 	const bool fits = DRIFT ? fillp_bias_drift(a, q, e, q2, e2, K.bias) : fillp_bias(W, a, -bmis > B.sc_ambi ? -bmis : B.sc_ambi, q, e, q2, e2, K.bias);
 	uint8_t *p_wave = p_all + (size_t)blockIdx.x * FILLP_SLOT;
 	uint32_t *cg = cig_all + ((size_t)blockIdx.x * 64 + lane) * FILL_CIG_MAX;
