@@ -293,7 +293,7 @@ def main():
     # roof is that many cell updates/s.  Algorithmic work per launch = the anti-diagonals of the gap
     # fillings given to this tier (counter dp_fill_steps_t1) x 32 cells.
     VALU_PEAK = 256 * 4 * 2.4e9 / 4
-    FILLP_INSTR_PER_STEP = 480 / 16                      # vector instructions of the unrolled 16-step block of the main loop (ISA listing of the round's last build: profiles/README.md; 521 with the earlier form of the drifting frame, 568 before it)
+    FILLP_INSTR_PER_STEP = 464 / 16                      # vector instructions of the unrolled 16-step block of the main loop (ISA listing of the round's last build: profiles/README.md; 480 before the second gap piece got its own frame, 521 with the first form of the drifting frame, 568 before it)
     VALU_PEAK_GUIDE = 256 * 4 * 2.4e9 / 2                # the guide's nominal 2-cycle wave64 issue (MI355X_MICROARCH.md), for comparison
     roofline_dp = None
     if dp_kernel_ms and dp_kernel_ms.get("dp_fill_t1", 0) > 0 and counters.get("dp_fill_steps_t1", 0) > 0:
