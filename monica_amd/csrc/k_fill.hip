@@ -1662,7 +1662,17 @@ void launch_dp_fill(const Batch &B, int lanes, const int32_t *list, int ctr_n, i
 {
 	// `lanes` = cells of the band
 	// the drifting frame when the scores allow it (b = 2 e: minimap2's map-ont), debug_route bit 10: never
-	const bool drift = fillp_drifts(B.sc_b, B.gap_e, B.gap_e2) && !(B.debug_route & 1024);
+	bool drift = fillp_drifts(B.sc_b, B.gap_e, B.gap_e2) && !(B.debug_route & 1024);
+	if (drift && MNC_FILLP_FRAME2 && lanes <= 64) {
+		// the second piece's frame needs room between the 12-bit floor and what the band proof guarantees:
+		// a (cells + 1) + gap(D0) + gap(I0) + one opening, with D0 + I0 = 2 (cells + 1); scores that do not leave it take the plain frame
+		int bias = 0;
+		const bool fits = fillp_bias_drift(B.sc_a, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, bias);
+		const int floor_pts = 2048 + bias;                       // the floor is -floor_pts points
+		const int qmax = B.gap_q > B.gap_q2 ? B.gap_q : B.gap_q2, emax = B.gap_e > B.gap_e2 ? B.gap_e : B.gap_e2;
+		const int need = B.sc_a * (lanes + 1) + 2 * qmax + emax * 2 * (lanes + 1) + (B.gap_q2 + B.gap_e2) + 16;
+		if (!fits || need >= floor_pts) drift = false;
+	}
 #define MNC_LAUNCH_FILLP(LN) do { if (drift) hipLaunchKernelGGL((mnc_dp_fillp<LN, true>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all, cig_all); \
 	else hipLaunchKernelGGL((mnc_dp_fillp<LN, false>), dim3(n_wg), dim3(64), 0, st, B, list, ctr_n, ctr_q, next_list, ctr_next, fb_list, ctr_fb, p_all, cig_all); } while (0)
 	if (lanes == 32) MNC_LAUNCH_FILLP(16);
