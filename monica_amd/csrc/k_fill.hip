@@ -1479,7 +1479,17 @@ __global__ __launch_bounds__(64, MNC_EXTP_WAVES) void mnc_dp_extp(Batch B, const
 						const int mq = (pk_half(bq, cm & 1) >> 4) - K.bias;
 						const int vc = a * m - fill_gap(r + 17, q, e, q2, e2);
 						const int bound = fv > vc ? fv : vc;
-						fin = bound <= gv && bound <= mq;
+						// ... and ksw2's Z-drop must not fire in the steps left out either (it would clear reach_end): the maximum of a
+						// later anti-diagonal, k steps on, is at least this one's less two gap openings and k extensions (from its best
+						// cell some way down and some way right, inside the matrix), the threshold at least zdrop
+						const int left = rows - 1 - rl;
+#ifdef MNC_EXT_STOP_IGNORES_ZDROP                                             // (a test build: tests/test_gpu_dp.py's flanks must then differ from the oracle)
+						const bool no_drop = true;
+						(void)left;
+#else
+						const bool no_drop = g.zdrop < 0 || gv - av + 2 * q2 + e2 * left <= g.zdrop;   // (a gap costs at most its second piece)
+#endif
+						fin = bound <= gv && bound <= mq && no_drop;
 					}
 				}
 				if (!__any(!fin)) break;

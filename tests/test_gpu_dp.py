@@ -372,3 +372,32 @@ def test_packed_sequence_loads_at_every_alignment(capi, oracle, world):
         reads.append(util.revcomp(noisy(g1[70000:70300])))                               # the batch's last read: the words behind it are the slack
         bases, offsets = util.pack_reads(reads)
         _compare_dp(capi, oracle, world, bases, offsets, min_mapq=0)
+
+
+def test_flanks_that_zdrop_after_the_query_has_ended(capi, oracle, world):
+    """An extension whose best score comes early, whose query then declines by less than zdrop until it ends, and whose
+    anti-diagonals go on declining through the rest of the target window: ksw2's Z-drop fires AFTER the query's last row has
+    been passed, which clears reach_end.  The packed extension kernel may leave the end of the window out only when it can
+    rule that out (k_fill.hip: the stop bound and its Z-drop condition; on these reads the bound alone already keeps it from
+    stopping -- a best score far from the query's end leaves too much query to gain from --, the condition is the net below it)."""
+    g0, g1 = world["seqs"][0], world["seqs"][1]
+    rng = np.random.default_rng(123)
+    junk = lambda n: util.ACGT[rng.integers(0, 4, n)]
+
+    def sparse(piece):                    # ~90 % identity without a 15-mer in common: a base changed every ten
+        p = piece.copy()
+        for i in range(4, len(p), 10):
+            p[i] = util.ACGT[(np.searchsorted(util.ACGT, p[i]) + 1 + rng.integers(0, 3)) % 4]
+        return p
+
+    reads = []
+    for k, (nj, ns) in enumerate([(120, 40), (160, 60), (190, 60), (220, 30), (240, 10), (100, 90), (180, 70), (250, 0)]):
+        s = 20000 + 5000 * k
+        core = (g0 if k & 1 else g1)[s:s + 2500]
+        left = np.concatenate([junk(nj), sparse((g0 if k & 1 else g1)[s - ns:s])]) if ns else junk(nj)
+        right = np.concatenate([sparse((g0 if k & 1 else g1)[s + 2500:s + 2500 + ns]), junk(nj)]) if ns else junk(nj)
+        r = np.concatenate([left, core, right])
+        reads.append(r)
+        reads.append(util.revcomp(r))
+    bases, offsets = util.pack_reads(reads)
+    _compare_dp(capi, oracle, world, bases, offsets, min_mapq=0)
