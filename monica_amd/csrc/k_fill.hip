@@ -1024,8 +1024,9 @@ __global__ __launch_bounds__(64) void mnc_dp_ext(Batch B, const int32_t *list, i
 #pragma unroll
 		for (int k = 0; k < CPL; ++k) H1[k] = H2[k] = En[k] = E2n[k] = Fn[k] = F2n[k] = FILL_NEG;
 		uint8_t *prow = p_wave + lead * CPL + L;
+		int done = 0;                                          // nothing left to find (see mnc_dp_extp's stop bound): the steps that remain are left out
 		for (int r = 0; r < max_rows; ++r, prow += ROWB) {
-			if (__all(zdropped || r >= rows)) break;
+			if (__all(zdropped || done || r >= rows)) break;
 			// cell c = L + LANES * k holds t = st0 + c, st0 = max(0, r - m + 1): while r < m the upper
 			// neighbour and the diagonal one are the previous cell; from r = m on the left neighbour is the
 			// next cell (and the diagonal one, from r = m + 1 on)
@@ -1056,7 +1057,7 @@ __global__ __launch_bounds__(64) void mnc_dp_ext(Batch B, const int32_t *list, i
 			for (int k = 0; k < CPL; ++k) {
 				int sE = sE_[k], sE2 = sE2_[k], sF = sF_[k], sF2 = sF2_[k], hd = hd_[k];
 				const int t = st0 + L + LANES * k, j = r - t;
-				const bool act = !zdropped && r < rows && t <= en0;
+				const bool act = !zdropped && !done && r < rows && t <= en0;
 				int Hn = FILL_NEG, nEn = FILL_NEG, nE2n = FILL_NEG, nFn = FILL_NEG, nF2n = FILL_NEG;
 				if (act) {
 					const int ct = s_t[sg][t], cq = s_q[sg][j];
@@ -1098,7 +1099,7 @@ __global__ __launch_bounds__(64) void mnc_dp_ext(Batch B, const int32_t *list, i
 			}
 			const unsigned long long kseg = (unsigned long long)__shfl((long long)key, lead + LANES - 1);
 			const int h_lead = __shfl(h_first, lead);              // H of the cell in the query's last row, when there is one
-			if (!zdropped && r < rows) {
+			if (!zdropped && !done && r < rows) {
 				const int max_H = (int)(unsigned)(kseg >> 32) - (1 << 30);
 				const unsigned mr = 0xffffffffu - (unsigned)kseg;
 				int max_t;
@@ -1112,6 +1113,22 @@ __global__ __launch_bounds__(64) void mnc_dp_ext(Batch B, const int32_t *list, i
 					const int tl = max_t - ez_max_t, ql = (r - max_t) - ez_max_q;
 					const int l = tl > ql ? tl - ql : ql - tl;
 					if (g.zdrop >= 0 && ez_max - max_H > g.zdrop + l * e2) zdropped = 1;
+				}
+				// every 16 steps, once the query's last row has been reached: the bound of mnc_dp_extp (here cell c holds query base
+				// m - 1 - c from step m - 1 on: it has c query bases left), and its condition that the Z-drop cannot fire later
+				if ((r & 15) == 15 && r >= m && !zdropped) {
+					int fv = FILL_NEG;
+#pragma unroll
+					for (int k = 0; k < CPL; ++k) {
+						const int v = H1[k] > H2[k] ? H1[k] : H2[k], c = L + LANES * k;
+						if (v > FILL_NEG / 2) fv = fv > v + a * c ? fv : v + a * c;
+					}
+#pragma unroll
+					for (int sft = 1; sft < LANES; sft <<= 1) { const int o = __shfl_xor(fv, sft); fv = fv > o ? fv : o; }
+					const int vc = a * m - fill_gap(r + 1, q, e, q2, e2);   // (from the virtual column: its cell beside step r + 1's first query base holds -gap(r + 1))
+					const int bound = fv > vc ? fv : vc;
+					const bool no_drop = g.zdrop < 0 || ez_max - max_H + 2 * q2 + e2 * (rows - 1 - r) <= g.zdrop;
+					if (bound <= ez_max && bound <= ez_mqe && no_drop) done = 1;
 				}
 			}
 		}
@@ -1455,7 +1472,7 @@ __global__ __launch_bounds__(64, MNC_EXTP_WAVES) void mnc_dp_extp(Batch B, const
 				// ---- nothing left to find?  Every later cell is reached from this block's last two anti-diagonals (the gap states a
 				// cell hands on are below its own H, and lead to cells with no more query left than it has) or from the virtual
 				// column: its score is at most H(cell c) + a (m - 1 - c) -- a diagonal step takes a query base, a gap gains nothing --
-				// or a m - gap(step + 1).  Once that bound is no more than the best score so far AND than the best of the query's
+				// or a m - gap(step).  Once that bound is no more than the best score so far AND than the best of the query's
 				// last row so far, no later cell changes either (an equal score does not replace the first one): the target window
 				// is about twice the query flank, and from the step where the query's end passes the diagonal on there is little to find.
 				bool fin = !ok || !has || r + 16 >= rows;
@@ -1477,7 +1494,7 @@ __global__ __launch_bounds__(64, MNC_EXTP_WAVES) void mnc_dp_extp(Batch B, const
 					fv = seg_max_i32<LANES>(fv) - K.bias;
 					if (!fin && r + 16 >= m) {                              // (every cell has started: the virtual row is behind)
 						const int mq = (pk_half(bq, cm & 1) >> 4) - K.bias;
-						const int vc = a * m - fill_gap(r + 17, q, e, q2, e2);
+						const int vc = a * m - fill_gap(r + 16, q, e, q2, e2);   // (the virtual column's cell beside step r + 16's first query base holds -gap(r + 16))
 						const int bound = fv > vc ? fv : vc;
 						// ... and ksw2's Z-drop must not fire in the steps left out either (it would clear reach_end): the maximum of a
 						// later anti-diagonal, k steps on, is at least this one's less two gap openings and k extensions (from its best
