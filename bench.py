@@ -302,12 +302,13 @@ def main():
         instr_per_cell = FILLP_INSTR_PER_STEP / 128
         peak = VALU_PEAK / instr_per_cell / 1e9
         ach = cells / t_s / 1e9
-        fill_traffic = None
+        fill_traffic = fill_insts = None
         try:
             with open(os.path.join(os.path.dirname(os.path.abspath(args.traffic_json)), "fill_traffic.json")) as f:
                 tj = json.load(f)
             if tj.get("reads") == args.reads and tj.get("read_len") == args.read_len:
                 fill_traffic = tj.get("hbm_bytes_per_launch")
+                fill_insts = tj.get("sq_insts_valu")               # SQ_INSTS_VALU of one launch (a separate --pmc pass, profiles/)
         except Exception:
             pass
         roofline_dp = {"bound": "valu", "kernel": "mnc_dp_fillp<16, true>", "achieved": round(ach, 2), "peak": round(peak, 1),
@@ -319,6 +320,10 @@ def main():
                        "traffic": fill_traffic,
                        "algorithmic_cells_per_launch": int(cells), "avg_launch_ms": round(dp_kernel_ms["dp_fill_t1"], 4),
                        "vector_instructions_per_cell": round(instr_per_cell, 4),
+                       # independent of the instruction count above: the vector instructions the launch issued (SQ counter of the
+                       # profiled build, all of the kernel -- walks and loads too) over what the chip can issue in the launch's time
+                       "issue_rate_frac": round(fill_insts / t_s / VALU_PEAK, 4) if fill_insts else None,
+                       "vector_instructions_per_launch": int(fill_insts) if fill_insts else None,
                        "bound_note": "int16 pair arithmetic on the vector ALU: the roof is the VALU issue rate (6.144e11 wave64 "
                                      "instructions/s, measured: profiles/r02_valu_issue_rates.json), not HBM (the kernel writes 1 byte per cell: "
                                      f"{cells / t_s / 1e9:.0f} GB/s) and not MFMA",
