@@ -89,6 +89,9 @@ struct ChainRec {
 
 // ---------------------------------------------------------------- base-level alignment stage
 constexpr uint64_t SEED_LONG_JOIN = 1ULL << 40, SEED_IGNORE = 1ULL << 41, SEED_TANDEM = 1ULL << 42;
+// ours, on the first chained anchor of a region (mnc_dp_gather): no two consecutive anchors of the region differ by more than ten
+// bases in their query and target steps -- mm_filter_bad_seeds(_alt) then find nothing to do, and the plan kernel skips their two scans
+constexpr uint64_t SEED_NOGAP10 = 1ULL << 43;
 constexpr int REG_HAS_DP = 1, REG_SPLIT_L = 2, REG_SPLIT_R = 4, REG_SPLIT_INV = 8, REG_INV = 16;   // REG_INV: mm_reg1_t::inv (mm_align1_inv's region)
 constexpr int EZ_RIGHT = 0x02, EZ_APPROX_MAX = 0x08, EZ_EXTZ_ONLY = 0x40, EZ_REV_CIGAR = 0x80;
 constexpr int SEG_NEEDS_BIG_WS = 0x10000;                 // Seg.flag, ours: the literal kernel needs its large workspace for this call

@@ -71,6 +71,7 @@ constexpr int GATHER_LONG = 1024;       // reads with more anchors: mnc_dp_gathe
 __global__ __launch_bounds__(64) void mnc_dp_gather(Batch B)
 {
 	__shared__ int32_t s_p[GATHER_LONG], s_j[GATHER_LONG];
+	__shared__ unsigned long long s_gapb[GATHER_LONG / 64 + 1], s_startb[GATHER_LONG / 64 + 1];   // per position: a step of more than ten bases; a region's first anchor (or a hole)
 	const uint32_t rd = blockIdx.x;
 	const int lane = threadIdx.x;
 	const int n = B.n_chain[rd];
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(64) void mnc_dp_gather(Batch B)
 		const int dst = d & ((1 << 30) - 1), cnt = ch[c].cnt;
 		int j = ch[c].as;                                   // the chain's last anchor; p[] leads back
 		for (int k = cnt - 1; k >= 0; --k) {
-			s_j[dst + k] = k == 0 && (d >> 30 & 1) ? j | INT32_MIN : j;      // the sign: first anchor of a long-joined chain
+			s_j[dst + k] = k != 0 ? j : (d >> 30 & 1) ? j | INT32_MIN : j | 1 << 30;   // the sign: first anchor of a long-joined chain; bit 30: of a region
 			j = s_p[j];
 		}
 		total = total > dst + cnt ? total : dst + cnt;
@@ -99,11 +100,42 @@ __global__ __launch_bounds__(64) void mnc_dp_gather(Batch B)
 #pragma unroll
 	for (int sft = 32; sft > 0; sft >>= 1) { const int o = __shfl_xor(total, sft); total = total > o ? total : o; }
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	// the copy, and on the way: where do consecutive anchors of a region step more than ten bases apart in query and target?
+	// (what mm_filter_bad_seeds and mm_filter_bad_seeds_alt look for first; a region without such a step gets SEED_NOGAP10)
+	int cx = 0, cy = 0, ce = 1;                             // anchor i0 - 1: its coordinates; nothing there
+	for (int i0 = 0; i0 < total; i0 += 64) {
+		const int i = i0 + lane;
+		const int jj = i < total ? s_j[i] : INT32_MAX;
+		const bool empty = jj == INT32_MAX;                 // (no chain put an anchor here)
+		Anchor x;
+		x.x = x.y = 0;
+		if (!empty) x = a[jj & ((1 << 30) - 1)];
+		const bool rstart = !empty && jj >= 0 && (jj >> 30 & 1);
+		if (jj < 0) x.y |= SEED_LONG_JOIN;
+		int px = __shfl_up((int)(uint32_t)x.x, 1), py = __shfl_up((int)(uint32_t)x.y, 1), pe = __shfl_up((int)empty, 1);
+		if (lane == 0) px = cx, py = cy, pe = ce;
+		cx = __shfl((int)(uint32_t)x.x, 63), cy = __shfl((int)(uint32_t)x.y, 63), ce = __shfl((int)empty, 63);
+		const int gap = ((int32_t)(uint32_t)x.y - py) - ((int32_t)(uint32_t)x.x - px);
+		const bool big = !empty && !rstart && (pe || gap < -10 || gap > 10);
+		const unsigned long long bg = __ballot(big), bs = __ballot(rstart || empty);
+		if (lane == 0) s_gapb[i0 >> 6] = bg, s_startb[i0 >> 6] = bs;
+		if (!empty && !rstart) ca[i] = x;
+	}
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	for (int i = lane; i < total; i += 64) {
 		const int jj = s_j[i];
-		if (jj == INT32_MAX) continue;                       // (no chain put an anchor here)
-		Anchor x = a[jj & INT32_MAX];
-		if (jj < 0) x.y |= SEED_LONG_JOIN;
+		if (jj == INT32_MAX || jj < 0 || !(jj >> 30 & 1)) continue;
+		// a region's first anchor: any long step between here and the next first anchor (or the end)?
+		bool any = false;
+		for (int w = i >> 6, first = 1; w <= (total - 1) >> 6; ++w, first = 0) {
+			const unsigned long long after = first ? ((i & 63) == 63 ? 0ULL : ~0ULL << ((i & 63) + 1)) : ~0ULL;
+			const unsigned long long st = s_startb[w] & after;
+			const unsigned long long upto = st ? (st & (0 - st)) - 1ULL : ~0ULL;            // the positions before the next first anchor
+			if (s_gapb[w] & after & upto) { any = true; break; }
+			if (st) break;
+		}
+		Anchor x = a[jj & ((1 << 30) - 1)];
+		if (!any) x.y |= SEED_NOGAP10;
 		ca[i] = x;
 	}
 }
@@ -374,8 +406,11 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 		}
 	}
 	b = a + as1;
+	// (a region whose consecutive anchors never step more than ten bases apart -- mnc_dp_gather saw it while it copied them --
+	// has nothing for either filter: both begin by collecting such steps)
+	const bool nogap10 = (a[r.as].y & SEED_NOGAP10) != 0;
 	// ---- mm_filter_bad_seeds(as1, cnt1, a, 10, 40, max_gap >> 1, 10)
-	{
+	if (!nogap10) {
 		const int n = collect_long_gaps(b, cnt1, 10, K);
 		if (n > 0) {
 			const int diff_thres = 40, max_ext_len = B.max_gap >> 1, max_ext_cnt = 10;
@@ -405,7 +440,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 		}
 	}
 	// ---- mm_filter_bad_seeds_alt(as1, cnt1, a, 30, max_gap >> 1)
-	{
+	if (!nogap10) {
 		const int n = collect_long_gaps(b, cnt1, 30, K);
 		const int max_ext = B.max_gap >> 1;
 		for (int k = 0; k < n;) {
