@@ -526,6 +526,10 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 	// ---- segments: count, allocate, fill
 	const bool left = !inv && qs > 0 && rs > 0;
 	int n_fill = 0;
+	// the seeds the gap fillings end at: counted here (the segments' places are reserved before they are written), and kept from
+	// the END of the region's scratch downwards, so that the pass that writes the records loads those twenty seeds instead of
+	// walking all anchors again (the front of the scratch takes the records' tier codes below)
+	int32_t *KI = K + (r.cnt > 0 ? r.cnt - 1 : 0);
 	{
 		int prs = rs, pqs = qs;
 		for (int i0 = 1; i0 < cnt1; i0 += 8) {
@@ -538,7 +542,10 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 				if (i >= cnt1) break;
 				if ((by[u] & (SEED_IGNORE | SEED_TANDEM)) && i != cnt1 - 1) continue;
 				const int cre = (int32_t)bx[u] - k2, cqe = (int32_t)by[u] - k2;
-				if (i == cnt1 - 1 || (by[u] & SEED_LONG_JOIN) || (cqe - pqs >= B.min_ksw_len && cre - prs >= B.min_ksw_len)) ++n_fill, prs = cre, pqs = cqe;
+				if (i == cnt1 - 1 || (by[u] & SEED_LONG_JOIN) || (cqe - pqs >= B.min_ksw_len && cre - prs >= B.min_ksw_len)) {
+					if (n_fill < r.cnt) KI[-n_fill] = i;
+					++n_fill, prs = cre, pqs = cqe;
+				}
 			}
 		}
 	}
@@ -575,6 +582,30 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 				emit(g);
 			}
 			int prs = rs, pqs = qs;
+			if (n_seg + n_fill <= r.cnt) {
+				// the end seeds from the scratch's end (the tier codes at its front stay clear of them), eight at a time
+				for (int k0 = 0; k0 < n_fill; k0 += 8) {
+					int32_t ix[8];
+					uint64_t bx[8], by[8];
+#pragma unroll
+					for (int u = 0; u < 8; ++u) ix[u] = KI[-(k0 + u < n_fill ? k0 + u : n_fill - 1)];
+#pragma unroll
+					for (int u = 0; u < 8; ++u) bx[u] = b[ix[u]].x, by[u] = b[ix[u]].y;
+					for (int u = 0; u < 8 && k0 + u < n_fill; ++u) {
+						int i = ix[0];
+						uint64_t vx = bx[0], vy = by[0];
+#pragma unroll
+						for (int w8 = 1; w8 < 8; ++w8) if (u == w8) i = ix[w8], vx = bx[w8], vy = by[w8];
+						const int cre = (int32_t)vx - k2, cqe = (int32_t)vy - k2;
+						Seg g;
+						g.kind = 1, g.ts = prs, g.tlen = cre - prs, g.qs = pqs, g.qlen = cqe - pqs;
+						g.w = (vy & SEED_LONG_JOIN) ? (cqe - pqs > cre - prs ? cqe - pqs : cre - prs) : bw;
+						g.zdrop = B.zdrop, g.flag = EZ_APPROX_MAX, g.ai = i;
+						emit(g);
+						prs = cre, pqs = cqe;
+					}
+				}
+			} else
 			for (int i0 = 1; i0 < cnt1; i0 += 8) {
 				uint64_t bx[8], by[8];
 #pragma unroll
