@@ -380,29 +380,64 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 	// ---- mm_fix_bad_ends
 	if (r.cnt >= 3) {
 		const int min_match = B.min_sc * 2;
+		// (eight anchors a turn, loaded before any is looked at: anchor by anchor each of the ~40 steps from either end was a
+		// round trip to memory of its own -- more of them than all the other passes of this kernel together)
 		int m, l;
-		m = l = (int)(a[r.as].y >> 32 & 0xff);
-		for (int i = r.as + 1; i < r.as + r.cnt - 1; ++i) {
-			const int q_span = (int)(a[i].y >> 32 & 0xff);
-			if (a[i].y & SEED_LONG_JOIN) break;
-			const int lr = (int32_t)a[i].x - (int32_t)a[i - 1].x, lq = (int32_t)a[i].y - (int32_t)a[i - 1].y;
-			const int mn = lr < lq ? lr : lq, mx = lr > lq ? lr : lq;
-			if (mx - mn > l >> 1) as1 = i;
-			l += mn;
-			m += mn < q_span ? mn : q_span;
-			if (l >= B.bw << 1 || (m >= min_match && m >= B.bw) || m >= r.mlen >> 1) break;
+		{
+			uint64_t px = a[r.as].x, py = a[r.as].y;            // the anchor before
+			m = l = (int)(py >> 32 & 0xff);
+			const int i_end = r.as + r.cnt - 1;                   // (the last anchor is not visited)
+			bool go = true;
+			for (int i0 = r.as + 1; i0 < i_end && go; i0 += 8) {
+				uint64_t bx[8], by[8];
+#pragma unroll
+				for (int u = 0; u < 8; ++u) { const int ii = i0 + u < i_end ? i0 + u : i_end - 1; bx[u] = a[ii].x, by[u] = a[ii].y; }
+#pragma unroll
+				for (int u = 0; u < 8; ++u) {
+					const int i = i0 + u;
+					if (go && i < i_end) {
+						const int q_span = (int)(by[u] >> 32 & 0xff);
+						if (by[u] & SEED_LONG_JOIN) go = false;
+						else {
+							const int lr = (int32_t)bx[u] - (int32_t)px, lq = (int32_t)by[u] - (int32_t)py;
+							const int mn = lr < lq ? lr : lq, mx = lr > lq ? lr : lq;
+							if (mx - mn > l >> 1) as1 = i;
+							l += mn;
+							m += mn < q_span ? mn : q_span;
+							px = bx[u], py = by[u];
+							if (l >= B.bw << 1 || (m >= min_match && m >= B.bw) || m >= r.mlen >> 1) go = false;
+						}
+					}
+				}
+			}
 		}
 		cnt1 = r.as + r.cnt - as1;
-		m = l = (int)(a[r.as + r.cnt - 1].y >> 32 & 0xff);
-		for (int i = r.as + r.cnt - 2; i > as1; --i) {
-			const int q_span = (int)(a[i + 1].y >> 32 & 0xff);
-			if (a[i + 1].y & SEED_LONG_JOIN) break;
-			const int lr = (int32_t)a[i + 1].x - (int32_t)a[i].x, lq = (int32_t)a[i + 1].y - (int32_t)a[i].y;
-			const int mn = lr < lq ? lr : lq, mx = lr > lq ? lr : lq;
-			if (mx - mn > l >> 1) cnt1 = i + 1 - as1;
-			l += mn;
-			m += mn < q_span ? mn : q_span;
-			if (l >= B.bw << 1 || (m >= min_match && m >= B.bw) || m >= r.mlen >> 1) break;
+		{
+			uint64_t nx = a[r.as + r.cnt - 1].x, ny = a[r.as + r.cnt - 1].y;   // the anchor after
+			m = l = (int)(ny >> 32 & 0xff);
+			bool go = true;
+			for (int i0 = r.as + r.cnt - 2; i0 > as1 && go; i0 -= 8) {
+				uint64_t bx[8], by[8];
+#pragma unroll
+				for (int u = 0; u < 8; ++u) { const int ii = i0 - u > as1 ? i0 - u : as1 + 1; bx[u] = a[ii].x, by[u] = a[ii].y; }
+#pragma unroll
+				for (int u = 0; u < 8; ++u) {
+					const int i = i0 - u;
+					if (go && i > as1) {
+						const int q_span = (int)(ny >> 32 & 0xff);
+						if (ny & SEED_LONG_JOIN) go = false;
+						else {
+							const int lr = (int32_t)nx - (int32_t)bx[u], lq = (int32_t)ny - (int32_t)by[u];
+							const int mn = lr < lq ? lr : lq, mx = lr > lq ? lr : lq;
+							if (mx - mn > l >> 1) cnt1 = i + 1 - as1;
+							l += mn;
+							m += mn < q_span ? mn : q_span;
+							nx = bx[u], ny = by[u];
+							if (l >= B.bw << 1 || (m >= min_match && m >= B.bw) || m >= r.mlen >> 1) go = false;
+						}
+					}
+				}
+			}
 		}
 	}
 	b = a + as1;
