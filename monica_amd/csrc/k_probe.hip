@@ -418,8 +418,9 @@ void launch_partition(const Batch &B, hipStream_t st)
 	const bool small = B.q_cap < (1LL << 32);
 	// more than 256 regions: a workgroup over regions / 256 tiles (MNC_PARTITION_TILES=1: the one-tile form, for comparison)
 	static const bool one_tile = getenv("MNC_PARTITION_TILES") && atoi(getenv("MNC_PARTITION_TILES")) == 1;
+	static const int force_g = getenv("MNC_PARTITION_G") ? atoi(getenv("MNC_PARTITION_G")) : 0;   // (2: two tiles a workgroup at 1 024 regions too, for comparison)
 	if (B.pb_n > 256 && !one_tile) {
-		if (B.pb_n <= 512) { if (small) launch_partition_group<2, uint32_t>(B, st); else launch_partition_group<2, int64_t>(B, st); }
+		if (B.pb_n <= 512 || force_g == 2) { if (small) launch_partition_group<2, uint32_t>(B, st); else launch_partition_group<2, int64_t>(B, st); }
 		else { if (small) launch_partition_group<4, uint32_t>(B, st); else launch_partition_group<4, int64_t>(B, st); }
 		return;
 	}
