@@ -575,7 +575,7 @@ def shard_mode(args, names, seqs, rank, local_rank, world, dev):
     if P % world:
         raise SystemExit(f"--parts {P} must be a multiple of the number of ranks {world}")
     bounds = [mdist.shard_bounds(G, p, P) for p in range(P)]
-    mine = [p for p in range(P) if p % world == rank]
+    mine = list(range(rank * (P // world), (rank + 1) * (P // world)))      # consecutive parts: rank order = part order
     parts = []
     for p in mine:
         lo, hi = bounds[p]
@@ -601,22 +601,26 @@ def shard_mode(args, names, seqs, rank, local_rank, world, dev):
     blocks = [(b0, min(n, b0 + args.block)) for b0 in range(0, n, args.block)]
     d_off_blk = torch.arange(args.block + 1, dtype=torch.int64, device=dev) * L
 
+    # C2 through the library's own entry points (include/monica_amd.h): a part's 20-byte records written by
+    # mnc_shard_summary on the engine's stream, all parts' records in part order in ONE buffer (rank r holds parts
+    # r * P / world ...: rank order is part order, so the all-gather leaves them in hit order), merged by mnc_merge_summaries
+    n_local = len(parts)
+    d_local = torch.empty((n_local, n, 5), dtype=torch.int32, device=dev)
+    d_all = torch.empty((P, n, 5), dtype=torch.int32, device=dev) if world > 1 else d_local
+    d_merged = torch.empty(n, dtype=torch.int32, device=dev)
+
     def step():
-        local = []
-        for lo, idx in parts:
-            torch.cuda.current_stream().synchronize()
-            eng.set_index(idx)
+        for k, (lo, idx) in enumerate(parts):
+            eng.set_index(idx)                                        # (waits for the engine's stream)
             for b0, b1 in blocks:
                 eng.classify_device(d_bases.data_ptr() + b0 * L, d_off_blk.data_ptr(), b1 - b0, (b1 - b0) * L, L, args.min_mapq,
                                     d_assign.data_ptr() + b0 * 4, d_best.data_ptr() + b0 * 16, d_nhits.data_ptr() + b0 * 4, 0)
-                eng.sync()
-            local.append(mdist.shard_summary(d_assign, d_best, d_nhits, rid_offset=lo))
-        stacked = torch.stack(local)                                  # [local parts, n, 5]
+            _capi.shard_summary_device(d_assign.data_ptr(), d_best.data_ptr(), d_nhits.data_ptr(), n, lo, d_local[k].data_ptr(), eng.stream())
+            eng.sync()
         if world > 1:
-            gathered = [torch.empty_like(stacked) for _ in range(world)]
-            dist.all_gather(gathered, stacked)                        # RCCL over xGMI
-            stacked = torch.cat(gathered)
-        result["assign"], _, _, _ = mdist.merge_summaries(stacked)
+            dist.all_gather_into_tensor(d_all, d_local)               # RCCL over xGMI
+        _capi.merge_summaries_device(d_all.data_ptr(), P, n, d_merged.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        result["assign"] = d_merged
 
     for _ in range(args.warmup):
         step()

@@ -361,6 +361,24 @@ int mnc_comm_count(void *comm, int *n_ranks);   /* ncclCommCount: the ranks the 
 int mnc_allreduce_counts(int64_t *d_counts, int n, void *comm, void *stream);
 int mnc_allgather_summaries(const void *d_send, void *d_recv, size_t bytes_per_rank, void *comm, void *stream);
 
+/* ---------------------------------------------------------------- C2: the merge over index parts, on the device
+ * The reference carries a read's gated hits from index part to index part (sample_hits[read_id].extend(...),
+ * aligner.py:196-203, 218-223; pickled between passes, aligner.py:184-188, 267-273) and lets best_hit
+ * (aligner.py:328-339) decide over the union (aligner.py:219-233).  best_hit only asks for the smallest NM/mlen and
+ * whether the last update of its running minimum was a tie, so one part's list is the 20-byte record
+ * {hits, nm, mlen, global contig | -1, tied} per read (the same record mnc_hitmap_update carries on the host).
+ *   mnc_shard_summary     writes a part's records [n][5] from mnc_classify_device's outputs of that part
+ *                         (d_assign, d_best, d_nhits); rid_offset = the part's first contig in the global numbering
+ *   mnc_merge_summaries   best_hit over the parts: d_parts = [n_parts][n][5] int32 in part order (= hit order: what
+ *                         mnc_allgather_summaries leaves when rank order is part order); d_assign[n] = global contig |
+ *                         MNC_UNMAPPED | MNC_AMBIGUOUS; d_nm / d_mlen / d_total (the minimal hit's NM and mlen, the
+ *                         number of gated hits over all parts) may be NULL.  int64 cross-products: mnc_best_hit's rule.
+ * All pointers are device pointers; both calls are asynchronous on `stream` (a hipStream_t, NULL = the default stream). */
+int mnc_shard_summary(const int32_t *d_assign, const mnc_hit_t *d_best, const int32_t *d_nhits, int64_t n,
+                      int32_t rid_offset, int32_t *d_out, void *stream);
+int mnc_merge_summaries(const int32_t *d_parts, int n_parts, int64_t n, int32_t *d_assign, int32_t *d_nm, int32_t *d_mlen,
+                        int32_t *d_total, void *stream);
+
 /* page-locked host memory for batch buffers (plain malloc when no GPU is present) */
 void *mnc_host_alloc(size_t bytes);
 void mnc_host_free(void *p);

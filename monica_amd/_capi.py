@@ -53,7 +53,7 @@ EXPORTS = [
     "mnc_classify_batch", "mnc_engine_prefetch", "mnc_engine_prefetch_cancel", "mnc_classify_device", "mnc_engine_sync", "mnc_engine_fetch_hits",
     "mnc_counts", "mnc_best_hit",
     "mnc_engine_set_profiling", "mnc_engine_set_debug", "mnc_engine_set_contract", "mnc_index_set_host_tables", "mnc_index_set_region_bits", "mnc_engine_dump_tables",
-    "mnc_comm_unique_id", "mnc_comm_init_rank", "mnc_comm_destroy", "mnc_comm_count", "mnc_allreduce_counts", "mnc_allgather_summaries", "mnc_engine_get_timings", "mnc_stage_name", "mnc_stage_kernel",
+    "mnc_comm_unique_id", "mnc_comm_init_rank", "mnc_comm_destroy", "mnc_comm_count", "mnc_allreduce_counts", "mnc_allgather_summaries", "mnc_shard_summary", "mnc_merge_summaries", "mnc_engine_get_timings", "mnc_stage_name", "mnc_stage_kernel",
     "mnc_engine_get_counters", "mnc_engine_dump",
     "mnc_fastq_open", "mnc_fastq_close", "mnc_fastq_next", "mnc_fastq_detach_batch", "mnc_fastq_remaining", "mnc_fastq_bases", "mnc_fastq_offsets",
     "mnc_fastq_quals", "mnc_fastq_title", "mnc_fastq_route",
@@ -151,6 +151,8 @@ def lib():
     sig("mnc_comm_count", i32, [vp, C.POINTER(i32)])
     sig("mnc_allreduce_counts", i32, [vp, i32, vp, vp])
     sig("mnc_allgather_summaries", i32, [vp, vp, C.c_size_t, vp, vp])
+    sig("mnc_shard_summary", i32, [vp, vp, vp, i64, i32, vp, vp])
+    sig("mnc_merge_summaries", i32, [vp, i32, i64, vp, vp, vp, vp, vp])
     sig("mnc_engine_get_timings", i32, [vp, vp, vp, i32])
     sig("mnc_stage_name", cp, [i32])
     sig("mnc_stage_kernel", cp, [i32])
@@ -234,6 +236,19 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+def shard_summary_device(d_assign, d_best, d_nhits, n, rid_offset, d_out, stream=None):
+    """`mnc_shard_summary`: one index part's 20-byte per-read records [n][5] from the device outputs of
+    `mnc_classify_device`; all arguments but `n` / `rid_offset` are device addresses."""
+    check(lib().mnc_shard_summary(C.c_void_p(d_assign), C.c_void_p(d_best), C.c_void_p(d_nhits), int(n), int(rid_offset),
+                                  C.c_void_p(d_out), C.c_void_p(stream or 0)))
+
+
+def merge_summaries_device(d_parts, n_parts, n, d_assign, d_nm=0, d_mlen=0, d_total=0, stream=None):
+    """`mnc_merge_summaries`: best_hit over [n_parts][n][5] records in part order (device addresses)."""
+    check(lib().mnc_merge_summaries(C.c_void_p(d_parts), int(n_parts), int(n), C.c_void_p(d_assign), C.c_void_p(d_nm or 0),
+                                    C.c_void_p(d_mlen or 0), C.c_void_p(d_total or 0), C.c_void_p(stream or 0)))
 
 
 def pinned_array(a):

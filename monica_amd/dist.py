@@ -86,13 +86,26 @@ def allreduce_counts(counts, group=None):
     return counts
 
 
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
 def shard_summary(assign, best, nhits, rid_offset=0):
     """Per-read summary of one index part: int32[n, 5] = {hits, nm, mlen, global contig, tied}.
-    `best` is the engine's minimal gated hit (also for AMBIGUOUS reads)."""
+    `best` is the engine's minimal gated hit (also for AMBIGUOUS reads).  Device tensors (the outputs of
+    `mnc_classify_device`) go through the library's kernel `mnc_shard_summary`; host arrays -- what
+    `mnc_classify_batch` returned -- are summarised on the host."""
     t = torch.as_tensor
     assign, nhits = t(assign), t(nhits)
     best = t(np.ascontiguousarray(best).view(np.int32).reshape(-1, 4)) if isinstance(best, np.ndarray) else best.reshape(-1, 4)
-    out = torch.zeros((assign.shape[0], 5), dtype=torch.int32, device=assign.device)
+    n = assign.shape[0]
+    if assign.is_cuda:
+        from monica_amd import _capi
+        assign, best, nhits = assign.contiguous(), best.contiguous(), nhits.contiguous()
+        out = torch.empty((n, 5), dtype=torch.int32, device=assign.device)
+        _capi.shard_summary_device(assign.data_ptr(), best.data_ptr(), nhits.data_ptr(), n, rid_offset, out.data_ptr(), _stream(assign))
+        return out
+    out = torch.zeros((n, 5), dtype=torch.int32)
     has = nhits > 0
     out[:, 0] = nhits
     out[:, 1] = best[:, 2]                       # nm
@@ -104,16 +117,26 @@ def shard_summary(assign, best, nhits, rid_offset=0):
 
 def merge_summaries(stacked):
     """best_hit over the union of the parts.  stacked: int32[parts, n, 5] in part order.
-    Returns (assign int32[n] with global contig ids, nm, mlen, total hits)."""
+    Returns (assign int32[n] with global contig ids, nm, mlen, total hits).  On a device this is the library's
+    kernel `mnc_merge_summaries` (C2 behind the C-ABI); host tensors (gloo, `PipeGroup`) take the same rule below."""
+    if stacked.is_cuda:
+        from monica_amd import _capi
+        stacked = stacked.contiguous()
+        if stacked.dtype != torch.int32:
+            raise TypeError("summaries are int32 records")
+        P, n = int(stacked.shape[0]), int(stacked.shape[1])
+        out = torch.empty((4, n), dtype=torch.int32, device=stacked.device)
+        _capi.merge_summaries_device(stacked.data_ptr(), P, n, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
+                                     _stream(stacked))
+        return out[0], out[1], out[2], out[3]
     s = stacked.to(torch.int64)
     n = s.shape[1]
-    dev = s.device
-    has = torch.zeros(n, dtype=torch.bool, device=dev)
-    nm = torch.zeros(n, dtype=torch.int64, device=dev)
-    ml = torch.ones(n, dtype=torch.int64, device=dev)
-    rid = torch.full((n,), -1, dtype=torch.int64, device=dev)
-    tied = torch.zeros(n, dtype=torch.bool, device=dev)
-    total = torch.zeros(n, dtype=torch.int64, device=dev)
+    has = torch.zeros(n, dtype=torch.bool)
+    nm = torch.zeros(n, dtype=torch.int64)
+    ml = torch.ones(n, dtype=torch.int64)
+    rid = torch.full((n,), -1, dtype=torch.int64)
+    tied = torch.zeros(n, dtype=torch.bool)
+    total = torch.zeros(n, dtype=torch.int64)
     for p in range(s.shape[0]):
         c_has = s[p, :, 0] > 0
         c_nm, c_ml, c_rid, c_tied = s[p, :, 1], torch.clamp(s[p, :, 2], min=1), s[p, :, 3], s[p, :, 4] > 0

@@ -187,6 +187,13 @@ def test_no_cpu_fallback(capi, world):
     with pytest.raises(capi.MncError) as e:
         capi.Engine(idx, 0)
     assert e.value.code == capi.ERR_NODEVICE
+    # the merge over index parts (C2) is a kernel of the library too: no host form behind the entry points
+    with pytest.raises(capi.MncError) as e:
+        capi.merge_summaries_device(0x1000, 2, 4, 0x2000)
+    assert e.value.code == capi.ERR_NODEVICE
+    with pytest.raises(capi.MncError) as e:
+        capi.shard_summary_device(0x1000, 0x1000, 0x1000, 4, 0, 0x2000)
+    assert e.value.code == capi.ERR_NODEVICE
 
 
 def test_product_does_not_touch_the_oracle():
