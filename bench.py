@@ -82,6 +82,18 @@ def launch_ranks(n):
     never touches the GPU (no torch import, no HIP call) and never execs: the child processes own the devices."""
     import socket
     import subprocess
+    if "--one-device" not in sys.argv:
+        # more ranks than devices: say so in one line and fail BEFORE any rank starts.  The count comes from a child
+        # process (the library's mnc_device_count through ctypes): this parent stays away from the HIP runtime.
+        probe = subprocess.run([sys.executable, "-c", "from monica_amd import _capi; print(_capi.device_count())"],
+                               cwd=ROOT, capture_output=True, text=True)
+        try:
+            have = int(probe.stdout.strip().splitlines()[-1])
+        except (ValueError, IndexError):
+            have = 0
+        if n > have:
+            print(f"[bench] --gpus {n} but {have} device(s) visible: not starting any rank", file=sys.stderr)
+            sys.exit(2)
     with socket.socket() as s:                       # a free rendezvous port on the loopback interface
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -104,19 +116,21 @@ def launch_ranks(n):
     sys.exit(rc)
 
 
-def rank_report(world, backend, reads_done, dev):
-    """What the collective backend saw, for the JSON line: the size of the process group the count all-reduce ran on
-    (`rccl_ranks`: ranks of the RCCL communicator when the backend is nccl) and the reads every rank classified in
-    the timed region (gathered over that same group) -- "did RCCL see N ranks" is answerable from the record."""
+def rank_report(world, backend, reads_done, dev, comm=None):
+    """What the collective backend saw, for the JSON line: `group_ranks` = the size of the torch.distributed group the
+    collectives ran on; `rccl_ranks` = ncclCommCount of the library's own communicator (`--collective capi`), None when
+    RCCL was not asked directly (torch's nccl backend does not hand out its communicator); `reads_per_rank` = the reads
+    each rank's engine reported as classified inside the timed region (`reads_done`: a count the caller kept per
+    successful classify call), gathered over that same group."""
     import torch
     import torch.distributed as dist
+    rccl = comm.count() if comm is not None else None
     if world <= 1:
-        return {"backend": None, "group_ranks": 1, "rccl_ranks": None, "reads_per_rank": [int(reads_done)]}
+        return {"backend": None, "group_ranks": 1, "rccl_ranks": rccl, "reads_per_rank": [int(reads_done)]}
     mine = torch.tensor([int(reads_done)], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
     got = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(got, mine)
-    n = dist.get_world_size()
-    return {"backend": dist.get_backend(), "group_ranks": n, "rccl_ranks": n if dist.get_backend() == "nccl" else 0,
+    return {"backend": dist.get_backend(), "group_ranks": dist.get_world_size(), "rccl_ranks": rccl,
             "reads_per_rank": [int(g.item()) for g in got]}
 
 
@@ -202,12 +216,15 @@ def main():
     total_bases = int(offsets[-1])
     torch.cuda.synchronize()
 
+    done = [0]                                 # reads whose classify call returned, counted as they happen
+
     def step():
         d_counts.zero_()
         torch.cuda.current_stream().synchronize()
         engine.classify_device(d_bases.data_ptr(), d_off.data_ptr(), args.reads, total_bases, args.read_len,
                                args.min_mapq, d_assign.data_ptr(), d_best.data_ptr(), d_nhits.data_ptr(),
                                d_counts.data_ptr())
+        done[0] += engine.n_reads
         if comm is not None:                   # on the engine's stream, behind the batch's last kernel
             comm.allreduce_counts(d_counts.data_ptr(), n_genomes * 3, engine.stream)
         engine.sync()
@@ -222,6 +239,7 @@ def main():
     engine.set_profiling(True)
     engine.timings(reset=True)
     torch.cuda.synchronize()
+    done[0] = 0
     t1 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -230,6 +248,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t1
+    reads_timed = done[0]
     engine.set_profiling(False)
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -276,7 +295,7 @@ def main():
         engine.set_debug(base_debug | (0x10000 if os.environ.get("MNC_DP_SERIAL") else 0))
         dp_kernel_ms = {k: tk[k][0] / max(tk[k][1], 1) for k in ("dp_fill_t1", "dp_fill_tm", "dp_fill_t2", "dp_fill_t3", "dp_lfill", "dp_ext", "dp_stitch") if k in tk}
 
-    ranks = rank_report(world, args.backend, args.reads * args.steps, dev)
+    ranks = rank_report(world, args.backend, reads_timed, dev, comm)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -493,7 +512,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "timed_region_s": round(elapsed, 4),
-        "rccl_ranks": ranks["rccl_ranks"] if comm is None else comm.count(),
+        "group_ranks": ranks["group_ranks"], "rccl_ranks": ranks["rccl_ranks"],
         "ranks": ranks,
         "higher_is_better": True,
         "scaling": args.scaling,
@@ -609,16 +628,19 @@ def shard_mode(args, names, seqs, rank, local_rank, world, dev):
     d_all = torch.empty((P, n, 5), dtype=torch.int32, device=dev) if world > 1 else d_local
     d_merged = torch.empty(n, dtype=torch.int32, device=dev)
 
+    done = [0]                                                        # reads x parts whose classify call returned
+
     def step():
         for k, (lo, idx) in enumerate(parts):
             eng.set_index(idx)                                        # (waits for the engine's stream)
             for b0, b1 in blocks:
                 eng.classify_device(d_bases.data_ptr() + b0 * L, d_off_blk.data_ptr(), b1 - b0, (b1 - b0) * L, L, args.min_mapq,
                                     d_assign.data_ptr() + b0 * 4, d_best.data_ptr() + b0 * 16, d_nhits.data_ptr() + b0 * 4, 0)
+                done[0] += eng.n_reads
             _capi.shard_summary_device(d_assign.data_ptr(), d_best.data_ptr(), d_nhits.data_ptr(), n, lo, d_local[k].data_ptr(), eng.stream())
             eng.sync()
         if world > 1:
-            dist.all_gather_into_tensor(d_all, d_local)               # RCCL over xGMI
+            dist.all_gather(list(d_all.view(world, n_local, n, 5).unbind(0)), d_local)   # RCCL over xGMI; rank order = part order
         _capi.merge_summaries_device(d_all.data_ptr(), P, n, d_merged.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
         result["assign"] = d_merged
 
@@ -628,6 +650,7 @@ def shard_mode(args, names, seqs, rank, local_rank, world, dev):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    done[0] = 0
     t1 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -641,14 +664,14 @@ def shard_mode(args, names, seqs, rank, local_rank, world, dev):
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     assign = result["assign"].cpu().numpy()
-    ranks = rank_report(world, args.backend, n * len(parts) * args.steps, dev)
+    ranks = rank_report(world, args.backend, done[0], dev)
     if rank == 0:
         ok = truth >= 0
         print(json.dumps({
             "metric": "reads/sec classified, index sharded (BASELINE config 4)", "value": round(n * args.steps / elapsed, 1),
             "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "timed_region_s": round(elapsed, 4),
-            "rccl_ranks": ranks["rccl_ranks"], "ranks": ranks, "higher_is_better": True, "scaling": "weak",
+            "group_ranks": ranks["group_ranks"], "rccl_ranks": ranks["rccl_ranks"], "ranks": ranks, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32/u64 integer", "data": "synthetic",
             "config": {"workload": f"{n} synthetic {args.read_len} nt reads vs {G} genomes "
                                    f"({sum(len(s) for s in seqs)} bp) in {P} index parts, {P // world} per GPU; "
@@ -694,6 +717,8 @@ def config3_mode(args, names, seqs, rank, local_rank, world, dev):
     d_counts = torch.zeros(n_genomes * 3, dtype=torch.int64, device=dev)
     t_setup = time.time() - t0
 
+    done = [0]                                                 # reads whose classify call returned
+
     def step():
         d_counts.zero_()
         torch.cuda.current_stream().synchronize()
@@ -701,6 +726,7 @@ def config3_mode(args, names, seqs, rank, local_rank, world, dev):
             m = min(blk, n - b0)
             engine.classify_device(d_bases.data_ptr() + b0 * L, d_off.data_ptr(), m, m * L, L, args.min_mapq,
                                    d_assign.data_ptr() + b0 * 4, d_best.data_ptr() + b0 * 16, 0, d_counts.data_ptr())
+            done[0] += engine.n_reads
         engine.sync()
         if world > 1:
             dist.all_reduce(d_counts)                          # the job's one collective
@@ -711,6 +737,7 @@ def config3_mode(args, names, seqs, rank, local_rank, world, dev):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    done[0] = 0
     t1 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -730,14 +757,14 @@ def config3_mode(args, names, seqs, rank, local_rank, world, dev):
                          dtype=torch.int64, device=dev)
     if world > 1:
         dist.all_reduce(local)
-    ranks = rank_report(world, args.backend, n * args.steps, dev)
+    ranks = rank_report(world, args.backend, done[0], dev)
     if rank == 0:
         mp, ok, bad = (int(x) for x in local.cpu())
         print(json.dumps({
             "metric": "reads/sec classified, 10 M-read job (BASELINE config 3)", "value": round(total * args.steps / elapsed, 1),
             "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "timed_region_s": round(elapsed, 4),
-            "rccl_ranks": ranks["rccl_ranks"], "ranks": ranks, "higher_is_better": True, "scaling": "strong",
+            "group_ranks": ranks["group_ranks"], "rccl_ranks": ranks["rccl_ranks"], "ranks": ranks, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u32/u64 integer; int16 pairs in the alignment kernels", "data": "synthetic",
             "config": {"workload": f"{total} synthetic {L} nt reads in all ({n} on rank 0, blocks of {blk}) vs {args.genomes}-genome "
                                    f"minimizer index ({info.total_len} bp)", "contract": args.contract,
