@@ -637,7 +637,7 @@ def shard_mode(args, names, seqs, rank, local_rank, world, dev):
                 eng.classify_device(d_bases.data_ptr() + b0 * L, d_off_blk.data_ptr(), b1 - b0, (b1 - b0) * L, L, args.min_mapq,
                                     d_assign.data_ptr() + b0 * 4, d_best.data_ptr() + b0 * 16, d_nhits.data_ptr() + b0 * 4, 0)
                 done[0] += eng.n_reads
-            _capi.shard_summary_device(d_assign.data_ptr(), d_best.data_ptr(), d_nhits.data_ptr(), n, lo, d_local[k].data_ptr(), eng.stream())
+            _capi.shard_summary_device(d_assign.data_ptr(), d_best.data_ptr(), d_nhits.data_ptr(), n, lo, d_local[k].data_ptr(), eng.stream)
             eng.sync()
         if world > 1:
             dist.all_gather(list(d_all.view(world, n_local, n, 5).unbind(0)), d_local)   # RCCL over xGMI; rank order = part order

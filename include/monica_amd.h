@@ -43,6 +43,9 @@ extern "C" {
 /* per-read decision codes in out_assign[] (aligner.py:218-233, 264-265) */
 #define MNC_UNMAPPED   (-1)        /* no gated hit        -> unmapped/<sample>             */
 #define MNC_AMBIGUOUS  (-2)        /* best_hit() returned 0 -> ambiguous/<sample>          */
+#define MNC_SKIPPED    (-3)        /* the read is outside what the kernels hold (see "Limits" below): not classified; no
+                                      gated hits.  index.map() has no such case (aligner.py:193, 215): the host side
+                                      routes the read as unmapped and says so, the rest of its batch is unaffected      */
 
 typedef struct mnc_index  mnc_index;
 typedef struct mnc_engine mnc_engine;
@@ -135,6 +138,24 @@ int  mnc_engine_set_index(mnc_engine *eng, mnc_index *idx);
 void *mnc_engine_stream(mnc_engine *eng);                              /* hipStream_t */
 int  mnc_index_device_bytes(const mnc_index *idx, int device, int64_t *bytes); /* HBM the index holds on that one device */
 int  mnc_engine_device_bytes(mnc_engine *eng, int64_t *bytes);         /* HBM held by the engine's own batch buffers */
+
+/* ---------------------------------------------------------------- limits, and what happens at each
+ *   k = 15, w = 10 only                          mnc_index_build*: MNC_ERR_UNSUPPORTED (the one setting monica uses,
+ *                                                aligner.py:45: preset 'map-ont')
+ *   a read of 2^20 bases or more                 mnc_classify_batch: that read alone comes back MNC_SKIPPED (no hits); the
+ *                                                other reads of the batch are classified as ever.  mnc_classify_device
+ *                                                (device-resident batches; the caller states max_read_len): MNC_ERR_UNSUPPORTED
+ *   one kernel call of a read's alignment whose  that read alone comes back MNC_SKIPPED.  (tlen x qlen <= 1e8 with more
+ *   direction matrix exceeds 256 MB              than 256 MB of direction bytes: a few hundred query bases against > 300 000
+ *                                                target bases -- mm_align1 makes no such call with max_gap = 5 000)
+ *   more than 2^20 reads in one call             MNC_ERR_UNSUPPORTED before anything runs (the probe's records hold a 20-bit
+ *                                                read ordinal); monica_amd.aligner passes at most 100 000 per call
+ *   2^40 bases or more in one call               MNC_ERR_UNSUPPORTED before anything runs
+ *   reads with > 8 192 anchors or >= 65 536      exact; slower forms (sort in HBM, sequential backtrack, a wave per region
+ *   bases                                        in the plan, bases read in place by the stitch kernel)
+ *   a batch that outgrows a pool (query records, exact: the batch is redone with more room (mnc_engine_get_counters [7] counts
+ *   segments, CIGAR words, region slots)         the passes); MNC_ERR_NOMEM when HBM itself is exhausted
+ */
 
 /* ---------------------------------------------------------------- classify
  * mnc_classify_batch   <- the per-read loop body aligner.py:212-233 for one index part:
@@ -379,6 +400,10 @@ int mnc_shard_summary(const int32_t *d_assign, const mnc_hit_t *d_best, const in
 int mnc_merge_summaries(const int32_t *d_parts, int n_parts, int64_t n, int32_t *d_assign, int32_t *d_nm, int32_t *d_mlen,
                         int32_t *d_total, void *stream);
 
+/* how many sample files the host works on side by side -- monica's ThreadPool runs aligner() once per sample,
+ * aligner.py:89-103: every FASTQ reader's parse and routing passes then take cores / n_workers threads (1, the
+ * default: all of them, at most 16) */
+int mnc_host_set_io_workers(int n_workers);
 /* page-locked host memory for batch buffers (plain malloc when no GPU is present) */
 void *mnc_host_alloc(size_t bytes);
 void mnc_host_free(void *p);

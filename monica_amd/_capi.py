@@ -20,6 +20,7 @@ OK = 0
 ERR_ARG, ERR_IO, ERR_FORMAT, ERR_NOMEM, ERR_HIP, ERR_NODEVICE, ERR_UNSUPPORTED, ERR_RANGE = range(-1, -9, -1)
 UNMAPPED = -1
 AMBIGUOUS = -2
+SKIPPED = -3            # MNC_SKIPPED: a read outside the kernels' limits (include/monica_amd.h, "limits"): not classified, no hits
 
 HIT_DTYPE = np.dtype([("rid", "<i4"), ("mapq", "<i4"), ("nm", "<i4"), ("mlen", "<i4")])
 REG_DTYPE = np.dtype([("id", "<i4"), ("parent", "<i4"), ("rid", "<i4"), ("rev", "<i4"),
@@ -58,7 +59,7 @@ EXPORTS = [
     "mnc_fastq_open", "mnc_fastq_close", "mnc_fastq_next", "mnc_fastq_detach_batch", "mnc_fastq_remaining", "mnc_fastq_bases", "mnc_fastq_offsets",
     "mnc_fastq_quals", "mnc_fastq_title", "mnc_fastq_route",
     "mnc_hitmap_create", "mnc_hitmap_load", "mnc_hitmap_save", "mnc_hitmap_free", "mnc_hitmap_size",
-    "mnc_hitmap_update", "mnc_hitmap_n_names", "mnc_hitmap_name", "mnc_host_alloc", "mnc_host_free",
+    "mnc_hitmap_update", "mnc_hitmap_n_names", "mnc_hitmap_name", "mnc_host_alloc", "mnc_host_free", "mnc_host_set_io_workers",
     "mnc_synth_genome", "mnc_synth_diverge", "mnc_synth_reads", "mnc_synth_reads_device", "mnc_version",
 ]
 
@@ -183,6 +184,7 @@ def lib():
     sig("mnc_hitmap_name", cp, [vp, i32])
     sig("mnc_host_alloc", vp, [C.c_size_t])
     sig("mnc_host_free", None, [vp])
+    sig("mnc_host_set_io_workers", i32, [i32])
     _LIB = L
     return L
 
@@ -249,6 +251,11 @@ def merge_summaries_device(d_parts, n_parts, n, d_assign, d_nm=0, d_mlen=0, d_to
     """`mnc_merge_summaries`: best_hit over [n_parts][n][5] records in part order (device addresses)."""
     check(lib().mnc_merge_summaries(C.c_void_p(d_parts), int(n_parts), int(n), C.c_void_p(d_assign), C.c_void_p(d_nm or 0),
                                     C.c_void_p(d_mlen or 0), C.c_void_p(d_total or 0), C.c_void_p(stream or 0)))
+
+
+def set_io_workers(n):
+    """`mnc_host_set_io_workers`: the FASTQ readers' parse / routing teams share the cores over `n` samples in flight."""
+    check(lib().mnc_host_set_io_workers(int(max(1, n))))
 
 
 def pinned_array(a):

@@ -59,6 +59,7 @@ FOCUS_FILES_FOLDER = "focus"
 # parsed, one on the GPU, one being written out)
 BATCH_READS = int(os.environ.get("MONICA_AMD_BATCH_READS", "25000"))
 BATCH_BASES = min(1 << 27, BATCH_READS * 6000)
+DEFAULT_MAX_WORKERS = int(os.environ.get("MONICA_AMD_MAX_WORKERS", "8"))   # `n_threads=None`: at most this many samples in flight
 TIMINGS = {}                      # per sample name: seconds spent per phase of aligner() (diagnostics)
 
 
@@ -129,7 +130,14 @@ def multi_threaded_aligner(query_folder, indexes_paths, mode=None, mapping_quali
         if focus_species:
             os.mkdir(folders["focus"])
 
-    pool = ThreadPool(n_threads)                  # None: one worker per core (aligner.py:89)
+    # aligner.py:89 is `ThreadPool(n_threads)`; None there means one worker per core, sized for CPU mappers.  Here a worker
+    # feeds a GPU: it owns an engine (HBM batch buffers), three pipeline threads and two OpenMP teams, and all engines
+    # of a device take turns on one alignment workspace -- so an explicit n_threads is kept as given, None is capped at
+    # DEFAULT_MAX_WORKERS (and at the number of samples), and the readers' teams share the cores over the workers.
+    workers = n_threads if n_threads else min(os.cpu_count() or 1, DEFAULT_MAX_WORKERS)
+    workers = max(1, min(int(workers), len(samples)))
+    _capi.set_io_workers(workers)
+    pool = ThreadPool(workers)
     rep = itertools.repeat
     mappy.reserve_index_cache(len(indexes_paths))
     try:
@@ -144,6 +152,7 @@ def multi_threaded_aligner(query_folder, indexes_paths, mode=None, mapping_quali
                                             rep(folders["ambiguous"]), rep(folders["focus"]), rep(True)))
     finally:
         pool.close()
+        _capi.set_io_workers(1)
     return alignment_update(results, output_folder)
 
 
@@ -261,6 +270,11 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
             mappy.release_idle(index.index)
             out = engine.classify_ptr(batch.bases_ptr, batch.offsets_ptr, batch.n, mapping_quality)
         clock["classify"] += time.perf_counter() - t1
+        n_skipped = int((out[0] == _capi.SKIPPED).sum())
+        if n_skipped:
+            # index.map() takes a read of any length (aligner.py:193, 215); the kernels stop at 2^20 bases.  Such a read
+            # costs neither its sample nor its batch: it has no hits (-> unmapped/), and the run says so
+            print(f"{sample_name}: {n_skipped} read(s) beyond the device limits (2^20 bases or more) not classified -> unmapped")
         return out
 
     def batches():

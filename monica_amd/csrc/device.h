@@ -95,6 +95,7 @@ constexpr uint64_t SEED_NOGAP10 = 1ULL << 43;
 constexpr int REG_HAS_DP = 1, REG_SPLIT_L = 2, REG_SPLIT_R = 4, REG_SPLIT_INV = 8, REG_INV = 16;   // REG_INV: mm_reg1_t::inv (mm_align1_inv's region)
 constexpr int EZ_RIGHT = 0x02, EZ_APPROX_MAX = 0x08, EZ_EXTZ_ONLY = 0x40, EZ_REV_CIGAR = 0x80;
 constexpr int SEG_NEEDS_BIG_WS = 0x10000;                 // Seg.flag, ours: the literal kernel needs its large workspace for this call
+constexpr int SEG_SKIPPED = 0x20000;                      // Seg.flag, ours: the call outgrows every workspace class -- not aligned, its read is reported MNC_SKIPPED
 constexpr int DP_NEG_INF = -0x40000000;
 constexpr int FILL_MAX_LEN = 511;     // longest target / query of a gap filling the banded kernel (k_fill.hip) takes
 constexpr int FILL_MID_CELLS = 42;    // the band between the 32- and the 64-cell tier: 21 lanes a segment, three segments a wave
@@ -170,6 +171,7 @@ struct Batch {
 	// ---- per base-slot arrays (capacity total_bases)
 	uint32_t *packed;             // 2-bit bases, 16 per word, first base in the top bits
 	uint32_t *ambig;              // per read: 1 if it holds a non-ACGTU byte
+	uint32_t *skip;               // per read: 1 if a kernel call of its alignment outgrew every workspace class (-> MNC_SKIPPED)
 	uint2 *mz;                    // minimizers of read r at [offsets[r], offsets[r]+mz_cnt[r])
 	HitRec *hits;                 // probe hits of read r at [offsets[r], offsets[r]+hit_cnt[r])
 	// ---- partitioned probe

@@ -423,7 +423,7 @@ struct mnc_engine {
 	Buf packed, mz, hits, hist_tm, q_off, qrec, bhits, bhit_cnt;
 	size_t q_cap_override = 0;              // grown after an overflowing batch
 	// per read
-	Buf ambig, mz_cnt, hit_cnt, rep_len, an_cnt, an_off, n_chain, n_reg, scan_sums, hit_off, best_mlen, hist_sums, hist_offs;
+	Buf ambig, skip, mz_cnt, hit_cnt, rep_len, an_cnt, an_off, n_chain, n_reg, scan_sums, hit_off, best_mlen, hist_sums, hist_offs;
 	// per anchor
 	Buf a, f, p, v, t, u;
 	// per chain slot
@@ -552,7 +552,7 @@ template <class F> static void engine_bufs(mnc_engine *e, F f)
 {
 	Buf *all[] = { &e->gap_lut, &e->logf_lut, &e->logf_a_lut, &e->ca, &e->ca_cnt, &e->chain_dst, &e->regdp, &e->segs, &e->cig_seg, &e->cig_reg, &e->dp_ctr,
 	               &e->work_a, &e->work_b, &e->big_list, &e->huge_list, &e->reg_cnt, &e->regs2, &e->inv_ws, &e->fill1, &e->fill2, &e->fill3, &e->fill_mid, &e->fill_fb, &e->plan_long, &e->extp, &e->mid_list, &e->lfill, &e->lext, &e->bigfb, &e->ext1, &e->ext2, &e->ext3, &e->ext4, &e->gen_list, &e->in_bases, &e->in_offsets, &e->pf_bases_buf, &e->pf_offsets_buf, &e->out_assign, &e->out_best, &e->out_nhits,
-	               &e->packed, &e->mz, &e->hits, &e->hist_tm, &e->q_off, &e->qrec, &e->bhits, &e->bhit_cnt, &e->ambig, &e->mz_cnt, &e->hit_cnt, &e->rep_len, &e->an_cnt, &e->an_off,
+	               &e->packed, &e->mz, &e->hits, &e->hist_tm, &e->q_off, &e->qrec, &e->bhits, &e->bhit_cnt, &e->ambig, &e->skip, &e->mz_cnt, &e->hit_cnt, &e->rep_len, &e->an_cnt, &e->an_off,
 	               &e->n_chain, &e->n_reg, &e->best_mlen, &e->hist_sums, &e->hist_offs, &e->scan_sums, &e->hit_off, &e->a, &e->f, &e->p, &e->v, &e->t, &e->u,
 	               &e->chains_tmp, &e->regs, &e->regx, &e->k64a, &e->k64b, &e->tmp_i32, &e->gated,
 	               &e->hits_csr, &e->stats, &e->cls_count, &e->cls_list };
@@ -887,6 +887,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	ENS(mz, (nb + 1) * sizeof(uint2));
 	ENS(hits, (nb + 1) * sizeof(HitRec));
 	ENS(ambig, (nr + 1) * 4);
+	ENS(skip, (nr + 1) * 4);
 	ENS(mz_cnt, (nr + 1) * 4);
 	ENS(hit_cnt, (nr + 1) * 4);
 	ENS(rep_len, (nr + 1) * 4);
@@ -945,7 +946,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	B.sc_a = P.a, B.sc_b = P.b, B.gap_q = P.q, B.gap_e = P.e, B.gap_q2 = P.q2, B.gap_e2 = P.e2, B.sc_ambi = P.sc_ambi;
 	B.zdrop = P.zdrop, B.zdrop_inv = P.zdrop_inv, B.end_bonus = P.end_bonus, B.min_dp_max = P.min_dp_max, B.min_ksw_len = P.min_ksw_len;
 	B.max_sw_mat = P.max_sw_mat;
-	B.packed = e->packed.as<uint32_t>(), B.ambig = e->ambig.as<uint32_t>(), B.mz = e->mz.as<uint2>(), B.hits = e->hits.as<HitRec>();
+	B.packed = e->packed.as<uint32_t>(), B.ambig = e->ambig.as<uint32_t>(), B.skip = e->skip.as<uint32_t>(), B.mz = e->mz.as<uint2>(), B.hits = e->hits.as<HitRec>();
 	B.mz_cnt = e->mz_cnt.as<int32_t>(), B.hit_cnt = e->hit_cnt.as<int32_t>(), B.rep_len = e->rep_len.as<int32_t>();
 	B.an_cnt = e->an_cnt.as<int64_t>(), B.an_off = e->an_off.as<int64_t>(), B.n_chain = e->n_chain.as<int32_t>(), B.n_reg = e->n_reg.as<int32_t>(), B.best_mlen = e->best_mlen.as<int32_t>();
 	B.n_tiles = (uint32_t)n_tiles, B.n_super = (uint32_t)n_super;
@@ -956,6 +957,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	B.stats = e->stats.as<int64_t>();
 
 	HIP_TRY(hipMemsetAsync(B.ambig, 0, (nr + 1) * 4, st));
+	HIP_TRY(hipMemsetAsync(B.skip, 0, (nr + 1) * 4, st));
 	HIP_TRY(hipMemsetAsync(B.packed + nb / 16, 0, 16, st));
 	HIP_TRY(hipMemsetAsync(B.overflow, 0, 8, st));
 
@@ -1296,7 +1298,8 @@ extern "C" int mnc_engine_prefetch_cancel(mnc_engine *e)
 {
 	if (!e) return MNC_ERR_ARG;
 	std::lock_guard<std::mutex> lk(e->pf_mu);
-	if (!e->pf_valid) return MNC_OK;
+	// whether or not an announcement stands: mnc_engine_prefetch sets pf_valid only after its last copy is queued, so a
+	// call that failed half-way has left copies from the caller's arrays in flight with pf_valid still false
 	e->pf_valid = false, e->pf_bases = nullptr, e->pf_offsets = nullptr;
 	HIP_TRY(hipSetDevice(e->device));
 	HIP_TRY(hipStreamSynchronize(e->copy_stream));
@@ -1311,11 +1314,36 @@ extern "C" int mnc_classify_batch(mnc_engine *e, const uint8_t *bases, const int
 	const int64_t total = offsets[n_reads] - offsets[0];
 	if (offsets[0] != 0 || total < 0 || (total > 0 && !bases)) { set_error("offsets must start at 0 and be non-decreasing"); return MNC_ERR_ARG; }
 	int max_len = 0;
+	size_t n_over = 0;
 	for (uint32_t r = 0; r < n_reads; ++r) {
 		const int64_t l = offsets[r + 1] - offsets[r];
 		if (l < 0) { set_error("offsets must be non-decreasing"); return MNC_ERR_ARG; }
-		if (l >= (1 << 20)) { set_error("read %u has %lld bases; 2^20 or more is not supported", r, (long long)l); return MNC_ERR_UNSUPPORTED; }
-		if (l > max_len) max_len = (int)l;
+		if (l >= (1 << 20)) ++n_over;
+		else if (l > max_len) max_len = (int)l;
+	}
+	if (n_over) {
+		// Reads of 2^20 bases or more are outside what the kernels hold (a query position is a 20-bit field of the
+		// probe's records and of the packed anchors).  index.map() takes any length (aligner.py:193, 215), so such a read
+		// must not cost the batch: it is taken out (an empty read in its place), the others are classified as ever, and
+		// it comes back as MNC_SKIPPED -- the one limit of this entry point that shows in its results.
+		std::vector<int64_t> foff((size_t)n_reads + 1);
+		std::vector<uint8_t> fb;
+		try { fb.reserve((size_t)total); } catch (const std::bad_alloc &) { return MNC_ERR_NOMEM; }
+		foff[0] = 0;
+		for (uint32_t r = 0; r < n_reads; ++r) {
+			const int64_t l = offsets[r + 1] - offsets[r];
+			if (l < (1 << 20)) fb.insert(fb.end(), bases + offsets[r], bases + offsets[r + 1]);
+			foff[r + 1] = (int64_t)fb.size();
+		}
+		const int rc = mnc_classify_batch(e, fb.empty() ? bases : fb.data(), foff.data(), n_reads, min_mapq, out_assign, out_best, out_nhits);
+		if (rc) return rc;
+		for (uint32_t r = 0; r < n_reads; ++r)
+			if (offsets[r + 1] - offsets[r] >= (1 << 20)) {
+				out_assign[r] = MNC_SKIPPED;
+				if (out_best) memset(&out_best[r], 0, sizeof(mnc_hit_t));
+				if (out_nhits) out_nhits[r] = 0;
+			}
+		return MNC_OK;
 	}
 	HIP_TRY(hipSetDevice(e->device));
 	const size_t nr = n_reads;

@@ -40,6 +40,8 @@ using namespace mnc;
 namespace {
 
 constexpr size_t IO_CHUNK = 8u << 20;
+// sample files being worked on side by side (mnc_host_set_io_workers): the parse / routing teams share the cores
+std::atomic<int> g_io_workers{1};
 
 // Giving a gigabyte back to the system and asking for it again per file costs ~0.1 s of page work each
 // way: the readers' large buffers are kept (up to CACHE_KEEP bytes) and handed to the next reader.
@@ -48,12 +50,14 @@ struct BigCache {
 	std::vector<std::pair<char*, size_t>> kept;
 	size_t kept_bytes = 0;
 	static constexpr size_t CACHE_KEEP = 6ull << 30, BIG = 16u << 20;
-	char *take(size_t need, size_t *got)
+	// `most`: no kept buffer larger than this (0: any) -- a reader that leaves a shared block takes a block of the size it
+	// needs, not a kept gigabyte that would then be pinned by the next small batch
+	char *take(size_t need, size_t *got, size_t most = 0)
 	{
 		std::lock_guard<std::mutex> g(mu);
 		size_t best = kept.size();
 		for (size_t i = 0; i < kept.size(); ++i)
-			if (kept[i].second >= need && (best == kept.size() || kept[i].second < kept[best].second)) best = i;
+			if (kept[i].second >= need && (most == 0 || kept[i].second <= most) && (best == kept.size() || kept[i].second < kept[best].second)) best = i;
 		if (best == kept.size()) return nullptr;
 		char *p = kept[best].first;
 		*got = kept[best].second;
@@ -184,11 +188,13 @@ struct LineReader {
 		return true;
 	}
 	// Host threads of one parse or routing pass (MNC_IO_THREADS caps it: the aligner's pipeline runs a parse and a
-	// routing pass side by side with the thread that launches kernels).
+	// routing pass side by side with the thread that launches kernels).  A host that works on several sample files at
+	// once (monica's ThreadPool, aligner.py:89-103: one sample per worker) says so with mnc_host_set_io_workers: the
+	// cores are shared out over the workers, or W workers x 2 passes x 16 threads oversubscribe a large GPU host.
 	static int io_threads()
 	{
 		static const int cap = [] { const char *e = getenv("MNC_IO_THREADS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 16; }();
-		int t = omp_get_max_threads();
+		int t = omp_get_max_threads() / std::max(1, g_io_workers.load(std::memory_order_relaxed));
 		return t < 1 ? 1 : t > cap ? cap : t;
 	}
 	// The aligner's pipeline runs a parse and a routing pass side by side: each may be given a team of its own size
@@ -201,8 +207,8 @@ struct LineReader {
 		const int all = io_threads();
 		return v > 0 ? (v < 64 ? v : 64) : all;
 	}
-	static int parse_threads() { static const int t = team_threads("MNC_PARSE_THREADS"); return t; }
-	static int route_threads() { static const int t = team_threads("MNC_ROUTE_THREADS"); return t; }
+	static int parse_threads() { return team_threads("MNC_PARSE_THREADS"); }
+	static int route_threads() { return team_threads("MNC_ROUTE_THREADS"); }
 };
 
 inline size_t rstrip_len(const char *p, size_t len)
@@ -267,7 +273,7 @@ struct mnc_fastq {
 	SharedBuf *sb = nullptr;         // batch: the block its text lies in; reader: the block in.data is, once a batch shares it
 	std::vector<uint64_t> rec_off, seq_off, qual_off;   // n + 1 / n / n offsets into the text
 	std::vector<uint8_t> verbatim;   // n: the record's text is byte for byte what the writer writes (no trailing blanks, a bare '+' line)
-	bool quals_ready = true;         // the quality array holds this batch's (a text-backed batch fills it on demand)
+	std::atomic<bool> quals_ready{true};   // the quality array holds this batch's (a text-backed batch fills it on demand)
 	std::mutex q_mu;
 	const char *text_base() const { return text ? text : in.data; }
 };
@@ -282,6 +288,15 @@ static int fq_fail(const char *msg)
 {
 	set_error("%s", msg);
 	return MNC_ERR_FORMAT;
+}
+
+// A host that works on `n_workers` sample files at once (monica's ThreadPool, aligner.py:89-103): the parse / routing
+// teams of every reader take cores / n_workers threads each from now on (1: a reader may use them all).
+extern "C" int mnc_host_set_io_workers(int n_workers)
+{
+	if (n_workers < 1) return MNC_ERR_ARG;
+	g_io_workers.store(n_workers, std::memory_order_relaxed);
+	return MNC_OK;
 }
 
 extern "C" int mnc_fastq_open(const char *path, mnc_fastq **out)
@@ -350,7 +365,7 @@ extern "C" int mnc_fastq_detach_batch(mnc_fastq *fq, mnc_fastq **out)
 	std::swap(b->bases, fq->bases), std::swap(b->quals, fq->quals);
 	b->offsets.swap(fq->offsets), b->titles.swap(fq->titles), b->title_off.swap(fq->title_off);
 	b->id_len.swap(fq->id_len), b->id_off.swap(fq->id_off);
-	b->quals_ready = fq->quals_ready, fq->quals_ready = true;
+	b->quals_ready.store(fq->quals_ready.load()), fq->quals_ready.store(true);
 	if (fq->text_backed) {
 		// the batch and the reader share the buffer from here on: the batch's records lie in it, the reader parses on behind
 		// them; nothing is copied until the reader has to move its data (fastq_unshare)
@@ -389,7 +404,10 @@ static bool fastq_unshare(mnc_fastq *fq, size_t room)
 	}
 	const size_t tail = in.hi - in.lo;
 	size_t got = 0, need = std::max<size_t>(tail + IO_CHUNK, room);
-	char *nb = g_big.take(need, &got);
+	// (the tail plus the next refill, or what the caller is about to read: every detached batch keeps the block it was
+	// parsed in alive, so a block is sized by what it will hold, and at most three batches are in flight per sample --
+	// parsed, on the GPU, being written: monica_amd/aligner.py)
+	char *nb = g_big.take(need, &got, 2 * need + (64u << 20));
 	if (!nb) { nb = (char*)malloc(need); got = need; }
 	if (!nb) return false;
 	if (tail) memcpy(nb, in.data + in.lo, tail);

@@ -241,8 +241,11 @@ __device__ void plan_seg_class(const Batch &B, const PlanLimits &lim, int bw, ui
 	else if (12 * T + Q > lim.big_state_max || p_bytes > lim.big_p_max || g.qlen + g.tlen + 8 > lim.big_cig_max) {
 		g.big = 3;                                              // the few largest: a class of their own, a handful of very large slots
 		if (12 * T + Q > lim.huge_state_max || p_bytes > lim.huge_p_max || g.qlen + g.tlen + 8 > lim.huge_cig_max) {
-			g.big = 2;                                          // beyond even those: the batch fails
-			atomicMax(&B.dp_ctr[4], 9ULL);
+			// beyond even those (a direction matrix of more than 256 MB with tlen x qlen <= max_sw_mat: a few hundred
+			// query bases against hundreds of thousands of target bases -- nothing mm_align1 makes with max_gap 5 000):
+			// the call is not run, the read is reported MNC_SKIPPED and the rest of the batch is classified
+			g.big = 0, g.flag |= SEG_SKIPPED;
+			B.skip[rd] = 1;
 		}
 	}
 	bool lfill = false;
@@ -1850,8 +1853,8 @@ __global__ __launch_bounds__(64 * NW) void mnc_dp_align(Batch B, uint8_t *ws_all
 		unsigned long long off = 0;
 		if (g.qlen <= 0 || g.tlen <= 0) {
 			// ksw_extd2 returns at once
-		} else if ((long long)g.tlen * g.qlen > B.max_sw_mat) {
-			ez.zdropped = 1;                                   // mm_align_pair: too large, treated as a Z-drop
+		} else if ((long long)g.tlen * g.qlen > B.max_sw_mat || (g.flag & SEG_SKIPPED)) {
+			ez.zdropped = 1;                                   // mm_align_pair: too large, treated as a Z-drop (SEG_SKIPPED: too large for this library: the read is reported as skipped)
 		} else {
 			const int T = (g.tlen + 15) / 16 * 16, Q = (g.qlen + 15) / 16 * 16 + 32;
 			int ncw = g.qlen < g.tlen ? g.qlen : g.tlen;

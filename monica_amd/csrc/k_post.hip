@@ -553,6 +553,10 @@ __global__ __launch_bounds__(64) void mnc_regions_post(Batch B, mnc_reg_t *work_
 		gate_and_decide(B, n_regs, r, gated, assign, best, nhits);
 		for (int i = 0; i < n_regs; ++i) src[i] = r[i], B.regdp[slot + i].cig_off = (int64_t)ex[i].x0, B.regdp[slot + i].n_cigar = r[i].n_cigar;
 	}
+	if (B.skip[rd]) {                                         // a kernel call of this read outgrew every workspace class: no decision
+		assign = MNC_SKIPPED, nhits = 0;
+		memset(&best, 0, sizeof(best));
+	}
 	B.n_reg[rd] = n_regs;
 	B.assign[rd] = assign;
 	if (B.best) B.best[rd] = best;

@@ -408,6 +408,9 @@ int partition_prepare()
 	const int lds = PA_STAGE * 4 * 6 + PB_N_MAX * 16 + 16;
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_partition_group<4, uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 	if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_partition_group<4, int64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+	// (two tiles a workgroup at 1 024 regions -- MNC_PARTITION_G=2 -- with 64-bit run offsets is 65 552 bytes: above 64 KiB too)
+	if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_partition_group<2, uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+	if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_partition_group<2, int64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 	if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return MNC_ERR_HIP; }
 	return MNC_OK;
 }

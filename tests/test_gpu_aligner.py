@@ -229,3 +229,69 @@ def test_a_failed_sample_leaves_the_engine_usable(oracle, tmp_path, monkeypatch)
     want, route = expected_from_oracle(oracle, [(names, seqs, 0)], names, b2, o2, "basic")
     assert got == {"s": want}
     assert count_records(str(query / "mapped" / "s.fastq")) == sum(r.startswith("mapped") for r in route)
+
+
+def test_default_thread_count_with_many_samples(oracle, tmp_path, monkeypatch):
+    """`n_threads=None` (aligner.py:65, 89: one worker per core in the reference) with more samples than workers: the
+    default is capped (a worker here is a GPU feeder with an engine, pipeline threads and OpenMP teams of its own), an
+    explicit count is kept, and the per-sample results do not depend on either."""
+    names, seqs = util.small_genomes(4, 120_000, 150_000)
+    dbs = tmp_path / "databases"
+    dbs.mkdir()
+    synth.write_fasta(str(dbs / "database0.fna.gz"), names, seqs)
+    paths = sorted(aligner.indexer(str(dbs), str(tmp_path / "indexes")))
+    bases, offsets, truth = synth.reads(seqs, 12 * 40, 2000, seed=5)
+    sizes = []
+    real_pool = aligner.ThreadPool
+    monkeypatch.setattr(aligner, "ThreadPool", lambda n=None: (sizes.append(n), real_pool(n))[1])
+    monkeypatch.setattr(aligner, "DEFAULT_MAX_WORKERS", 3)
+    results = []
+    cwd = os.getcwd()
+    for n_threads in (None, 20, 1):
+        query = tmp_path / f"query_{n_threads}"
+        query.mkdir()
+        for s in range(12):
+            lo, hi = offsets[s * 40], offsets[(s + 1) * 40]
+            synth.write_fastq(str(query / f"s{s:02d}.fastq"), bases[lo:hi], offsets[s * 40:(s + 1) * 40 + 1] - lo, ids=[f"r{i}" for i in range(40)])
+        out = tmp_path / f"out_{n_threads}"
+        out.mkdir()
+        try:
+            results.append(aligner.multi_threaded_aligner(str(query), paths, mode="basic", n_threads=n_threads, output_folder=str(out)))
+        finally:
+            os.chdir(cwd)
+    assert sizes == [3, 12, 1]                  # None: the cap; 20 threads for 12 samples: one each; 1: as given
+    assert results[0] == results[1] == results[2] and len(results[0]) == 12
+    want, _ = expected_from_oracle(oracle, [(names, seqs, 0)], names, bases[:offsets[40]], offsets[:41], "basic")
+    assert results[0]["s00"] == want
+
+
+def test_a_read_beyond_the_device_limits_does_not_cost_its_sample(oracle, tmp_path, capsys):
+    """aligner.py:212-279 never drops a sample for one record.  A FASTQ file holding a 1.1 Mb read among ordinary ones:
+    the file is consumed, the ordinary reads are counted and routed as without it (the oracle's answers), the long
+    read is written to unmapped/ and the run says what it did."""
+    g = synth.genome(0x2A2A, 1_400_000)
+    names, seqs = [synth.contig_name(0), synth.contig_name(1)], [g, synth.genome(0x2A2B, 200_000)]
+    dbs = tmp_path / "databases"
+    dbs.mkdir()
+    synth.write_fasta(str(dbs / "database0.fna.gz"), names, seqs)
+    paths = sorted(aligner.indexer(str(dbs), str(tmp_path / "indexes")))
+    bases, offsets, truth = synth.reads(seqs, 60, 3000, seed=8)
+    reads = [bases[offsets[i]:offsets[i + 1]] for i in range(60)]
+    reads.insert(25, g[50_000:50_000 + 1_100_000].copy())
+    eb, eo = util.pack_reads(reads)
+    query, out = tmp_path / "query", tmp_path / "output"
+    query.mkdir(), out.mkdir()
+    synth.write_fastq(str(query / "long.fastq"), eb, eo, ids=[f"r{i}" for i in range(61)])
+    cwd = os.getcwd()
+    try:
+        got = aligner.multi_threaded_aligner(str(query), paths, mode="basic", n_threads=1, output_folder=str(out))
+    finally:
+        os.chdir(cwd)
+    want, route = expected_from_oracle(oracle, [(names, seqs, 0)], names, bases, offsets, "basic")
+    assert got == {"long": want}
+    assert not os.path.exists(query / "long.fastq")
+    assert count_records(str(query / "mapped" / "long.fastq")) == sum(r.startswith("mapped") for r in route)
+    assert count_records(str(query / "unmapped" / "long.fastq")) == route.count("unmapped") + 1
+    unm = [b for b in fastq.read_batches(str(query / "unmapped" / "long.fastq"))]
+    assert "r25" in [i for b in unm for i in b.ids]
+    assert "1 read(s) beyond the device limits" in capsys.readouterr().out

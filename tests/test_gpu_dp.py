@@ -401,3 +401,82 @@ def test_flanks_that_zdrop_after_the_query_has_ended(capi, oracle, world):
         reads.append(util.revcomp(r))
     bases, offsets = util.pack_reads(reads)
     _compare_dp(capi, oracle, world, bases, offsets, min_mapq=0)
+
+
+# ---------------------------------------------------------------- reads of hundreds of kilobases; the length limit
+def _noisy_indels(rng, seg, rate):
+    """`rate` errors per base: 40 % substitutions, 30 % deletions, 30 % one-base insertions."""
+    seg = seg.copy()
+    r = rng.random(len(seg))
+    sub = r < rate * 0.4
+    seg[sub] = util.ACGT[rng.integers(0, 4, int(sub.sum()))]
+    keep = ~((r >= rate * 0.4) & (r < rate * 0.7))
+    ins = np.flatnonzero((r >= rate * 0.7) & (r < rate))
+    pieces, last = [], 0
+    for i in ins:
+        pieces += [seg[last:i][keep[last:i]], util.ACGT[rng.integers(0, 4, 1)]]
+        last = i
+    pieces.append(seg[last:][keep[last:]])
+    return np.concatenate(pieces)
+
+
+@pytest.fixture(scope="module")
+def world_2mbp(capi, oracle):
+    g = synth.genome(0x2A2A, 2_000_000)
+    other = synth.genome(0x2A2B, 300_000)
+    return _world_from(capi, oracle, [synth.contig_name(0), synth.contig_name(1)], [g, other])
+
+
+def test_reads_of_250_kb_and_900_kb(capi, oracle, world_2mbp):
+    """index.map() takes a read of any length (aligner.py:193, 215).  Reads of 250 kb and 900 kb from a 2 Mbp contig --
+    8 % errors, a 5 kb deletion in each, one on the reverse strand, short reads beside them -- region by region and
+    CIGAR by CIGAR against the oracle: tens of thousands of anchors a read (the sort in HBM, the sequential backtrack),
+    thousands of kernel calls a region, a region whose bases no LDS holds."""
+    g = world_2mbp["seqs"][0]
+    rng = np.random.default_rng(250)
+
+    def long_read(start, length, indel_at, rate=0.08):
+        return np.concatenate([_noisy_indels(rng, g[start:start + indel_at], rate),
+                               _noisy_indels(rng, g[start + indel_at + 5000:start + length], rate)])
+
+    short_b, short_o, _ = synth.reads(world_2mbp["seqs"], 5, 3000, seed=9)
+    reads = [long_read(100_000, 250_000, 120_000), short_b[short_o[0]:short_o[1]],
+             util.revcomp(long_read(600_000, 900_000, 400_000)), short_b[short_o[1]:short_o[2]]]
+    assert 200_000 < len(reads[0]) < 260_000 and 800_000 < len(reads[2]) < (1 << 20)
+    bases, offsets = util.pack_reads(reads)
+    assign, best, nhits = _compare_dp(capi, oracle, world_2mbp, bases, offsets, min_mapq=0)
+    assert assign[0] == 0 and assign[2] == 0
+    regs = world_2mbp["eng"].dump(capi.DUMP_REGS, capi.REG_DTYPE)
+    assert (regs["qe"] - regs["qs"]).max() > 800_000 and regs["n_cigar"].max() > 50_000
+    _compare_dp(capi, oracle, world_2mbp, bases, offsets, min_mapq=60)
+
+
+def test_a_read_beyond_the_length_limit_costs_only_itself(capi, oracle, world_2mbp):
+    """A read of 2^20 bases or more is outside what the kernels hold: it alone comes back MNC_SKIPPED (no hits); every
+    other read of its batch is classified exactly as without it (the oracle's answers)."""
+    g = world_2mbp["seqs"][0]
+    rng = np.random.default_rng(12)
+    b, o, truth = synth.reads(world_2mbp["seqs"], 40, 4000, seed=3)
+    normal = [b[o[i]:o[i + 1]] for i in range(40)]
+    huge = _noisy_indels(rng, g[200_000:1_450_000], 0.05)
+    exact = g[100_000:100_000 + (1 << 20)].copy()                        # exactly 2^20 bases: the first length refused
+    just_below = g[300_000:300_000 + (1 << 20) - 1].copy()               # the longest length taken
+    assert len(huge) > 1_150_000 and len(exact) == 1 << 20
+    reads = normal[:20] + [huge] + normal[20:] + [exact, just_below]
+    bases, offsets = util.pack_reads(reads)
+    eng = world_2mbp["eng"]
+    eng.set_contract(capi.CONTRACT_DP)
+    assign, best, nhits = eng.classify(bases, offsets, 60)
+    assert assign[20] == capi.SKIPPED and assign[41] == capi.SKIPPED and nhits[20] == 0 and nhits[41] == 0
+    assert best[20].tolist() == (0, 0, 0, 0)
+    keep = np.array([i for i in range(len(reads)) if i not in (20, 41)])
+    kb, ko = util.pack_reads([reads[i] for i in keep])
+    world_2mbp["oidx"].opt.cigar = 1
+    oa, ob, onh, _ = world_2mbp["oidx"].classify(kb, ko, 60)
+    assert np.array_equal(assign[keep], oa) and np.array_equal(nhits[keep], onh)
+    for k in capi.HIT_DTYPE.names:
+        assert np.array_equal(best[k][keep], ob[k]), k
+    assert assign[42] == 0 and best["mlen"][42] == (1 << 20) - 1 and best["nm"][42] == 0     # an error-free read one base below the limit
+    # a batch of nothing but such reads
+    a2, b2, n2 = eng.classify(*util.pack_reads([exact, huge]), 60)
+    assert a2.tolist() == [capi.SKIPPED] * 2 and n2.tolist() == [0, 0]
