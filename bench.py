@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--reads", type=int, default=100_000, help="reads per rank per step")
     ap.add_argument("--read-len", type=int, default=5000)
     ap.add_argument("--genomes", type=int, default=20)
+    ap.add_argument("--genome-model", choices=["iid", "repeats"], default="iid",
+                    help="iid: SURVEY 8d's i.i.d. contigs (the BASELINE workload); repeats: the same contigs with rRNA-like operons, "
+                         "insertion sequences and stretches shared between neighbours (synth.genome_set_repeats) -- a sensitivity row")
     ap.add_argument("--min-len", type=int, default=2_000_000)
     ap.add_argument("--max-len", type=int, default=7_000_000)
     ap.add_argument("--min-mapq", type=int, default=60)
@@ -168,7 +171,8 @@ def main():
 
     # ---------------------------------------------------------------- workload (deterministic)
     t0 = time.time()
-    names, seqs = synth.genome_set(args.genomes, min_len=args.min_len, max_len=args.max_len)
+    make_genomes = synth.genome_set_repeats if args.genome_model == "repeats" else synth.genome_set
+    names, seqs = make_genomes(args.genomes, min_len=args.min_len, max_len=args.max_len)
     if args.mode == "shard":
         return shard_mode(args, names, seqs, rank, local_rank, world, dev)
     if args.mode == "config3":
@@ -523,6 +527,7 @@ def main():
                                f"{args.genomes}-genome minimizer index ({info.total_len} bp, {info.n_keys} keys, "
                                f"mid_occ {info.mid_occ})",
                    "reads_per_gpu_per_step": args.reads, "read_len": args.read_len, "genomes": args.genomes,
+                   "genome_model": args.genome_model,
                    "contract": "base-level alignment of every region (mappy's MM_F_CIGAR)" if args.contract == "dp" else "chain level",
                    "collective": "mnc_allreduce_counts (C-ABI, RCCL communicator from mnc_comm_init_rank)" if comm is not None else "torch.distributed all_reduce (RCCL)",
                    "parallelism": f"read-sharded x{world}, index replicated, RCCL all-reduce of "

@@ -27,7 +27,10 @@
 // every anti-diagonal, in-place update, int8 wrap-around -- because at band edges ksw2 reads
 // cells outside the band whose contents only that layout defines; tests/ compare it with the
 // CPU oracle's simulation of the same layout, CIGAR for CIGAR.
+#include <cstring>
+#include <cstdlib>
 #include "device.h"
+#include "ksw_pk.h"
 
 namespace mnc {
 
@@ -1411,7 +1414,8 @@ template <int NW, int C> __device__ __forceinline__ bool wg_fits(int qlen, int t
 	return width + 30 + 16 + 17 <= 64 * NW * C && (tlen + 15) / 16 * 16 <= seq && (qlen + 15) / 16 * 16 + 32 <= seq;
 }
 
-template <int NW, class PP, class CP>
+// DEC: 0 the direction bytes are ksw2's; 1 / 2 the packed kernel's codes (left- / right-aligned gaps: kpk::decode)
+template <int NW, class PP, class CP, int DEC = 0>
 __device__ int walk_wg(int qlen, int tlen, int wl, int wr, int ncol, PP p, CP cig, int i0, int j0, int flag, lds_u8p tile, lds_i32p bc)
 {
 	constexpr int CW = 64 * NW, TR = WG_TILE;
@@ -1456,7 +1460,9 @@ __device__ int walk_wg(int qlen, int tlen, int wl, int wr, int ncol, PP p, CP ci
 				int force_state = -1;
 				if (i < st) force_state = 2;
 				if (i > en) force_state = 1;
-				const uint32_t tmp = force_state < 0 ? tile[k * TR + c] : 0;
+				uint32_t tmp = force_state < 0 ? tile[k * TR + c] : 0;
+				if (DEC == 1 && force_state < 0) tmp = kpk::decode<false>(tmp);
+				if (DEC == 2 && force_state < 0) tmp = kpk::decode<true>(tmp);
 				if (state == 0) state = tmp & 7;
 				else if (!(tmp >> (state + 2) & 1)) state = 0;
 				if (state == 0) state = tmp & 7;
@@ -1739,6 +1745,264 @@ __device__ __attribute__((noinline)) void ksw_wg(int qlen, int tlen, const uint8
 	st_order<false, NW>();
 }
 
+// ================================================================ ksw_extd2 on ONE wave, packed pairs in registers
+// The same call once more (round 5): one wave, C consecutive cells per lane held as C / 2 packed pairs -- two cells per
+// 32-bit register, the recurrence on VOP3P with tags in the low byte of every 16-bit lane (ksw_pk.h: the value byte IS
+// ksw2's int8, the tags do the work of its comparison chains, the direction byte is the XOR of five tag bytes).  What
+// stays as in ksw_wg: ksw2's arrays indexed by the target position t, cell t in lane (t mod 64 C) / C for as long as it
+// is inside the window [st - 16, st - 16 + 64 C), the 16-lane rounding of both ends, stale cells outside the band, scores
+// refreshed on [st0, st0 + 16 n) only, the exact-maximum scan's tie order, the approximate-maximum walk.  What goes: the
+// barrier and the LDS words between waves (the cell below a lane's first comes by ONE DPP rotation -- the window is
+// circular, lane 0's neighbour is lane 63), the int8 emulation (~4 vector instructions per cell in 32-bit lanes), the
+// target's codes in LDS (a lane reads its C codes when it takes new cells: every 64 C / 16 anti-diagonals or so).
+// Per anti-diagonal and PAIR of cells: 3 v_alignbit (the cells below), 28 for the cell (kpk::cell_pair), 1 + 3 + 2 for the
+// query window, the score and its stale-cell mask; per lane a dozen more and, with the exact maximum, 2 per cell for H.
+//   C = 16: anti-diagonals of up to 961 cells (any band minimap2 uses: 751 + rounding); C = 8 / 4: up to 449 / 193 -- the
+//   small calls, with their registers (and twice / four times the waves a SIMD).
+// Calls with an ambiguous base, or scores outside kpk::params_fit, keep the forms above.
+constexpr int WP_NEG = -(1 << 26);                        // H of a cell no anti-diagonal has reached (ksw2: -2^30; only its sign and size matter)
+constexpr int wp_lds_bytes(int seq) { return 64 + (seq > WG_TILE * WG_TILE ? seq : WG_TILE * WG_TILE); }
+template <int C> __device__ __forceinline__ bool wp_fits(int qlen, int tlen, int w, int seq)
+{
+	if (w < 0) w = tlen > qlen ? tlen : qlen;
+	int width = qlen < tlen ? qlen : tlen;
+	if (w + 1 < width) width = w + 1;
+	return width + 30 + 16 + 17 <= 64 * C && (qlen + 15) / 16 * 16 + 32 <= seq;
+}
+#define MNC_DPP_ROR1(v) __builtin_amdgcn_update_dpp(0, (v), 0x13C, 0xf, 0xf, false)      // wave_ror:1 -- lane i reads lane i - 1, lane 0 lane 63
+
+template <int C, bool RIGHT, bool APPROX, class PP, class CP>
+__device__ __attribute__((noinline)) void ksw_wp(int qlen, int tlen, const uint8_t *sf_g, const uint8_t *qr_g, lds_u8p lds, PP p, CP cig,
+                                                 int q, int e, int q2, int e2, int sc_mch, int sc_mis, int w, int zdrop, int end_bonus, int flag, Ez &ez_out)
+{
+	constexpr int CW = 64 * C, M = CW - 1, NP = C / 2, CB = C - 1;
+	static_assert(C == 4 || C == 8 || C == 16, "cells per lane: a divisor of 16, whole pairs");
+	{
+		auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+		auto unip = [&](auto ptr) { const unsigned long long v = (unsigned long long)ptr; return (decltype(ptr))((unsigned long long)(unsigned)uni((int)(unsigned)v) | (unsigned long long)(unsigned)uni((int)(unsigned)(v >> 32)) << 32); };
+		qlen = uni(qlen), tlen = uni(tlen), q = uni(q), e = uni(e), q2 = uni(q2), e2 = uni(e2), sc_mch = uni(sc_mch), sc_mis = uni(sc_mis);
+		w = uni(w), zdrop = uni(zdrop), end_bonus = uni(end_bonus), flag = uni(flag);
+		sf_g = unip(sf_g), qr_g = unip(qr_g), p = unip(p), cig = unip(cig);
+		lds = (lds_u8p)(unsigned)uni((int)(unsigned)(unsigned long long)lds);
+	}
+	const int lane = threadIdx.x;
+	lds_i32p bc = (lds_i32p)lds;                              // 16 words for the walk
+	lds_u8p sq = (lds_u8p)(bc + 16);                          // the reversed query's codes; afterwards the walk's tile
+	const kpk::Consts K = kpk::make_consts<RIGHT>(q, e, q2, e2, sc_mch, sc_mis);
+	int z_max = 0, z_zdropped = 0, z_max_q = -1, z_max_t = -1, z_mqe_t = -1, z_mqe = DP_NEG_INF, z_score = DP_NEG_INF, z_reach_end = 0;
+	const int qe = q + e;
+	if (w < 0) w = tlen > qlen ? tlen : qlen;
+	const int wl = w, wr = w;
+	int n_col_ = qlen < tlen ? qlen : tlen;
+	n_col_ = ((n_col_ < w + 1 ? n_col_ : w + 1) + 15) / 16 + 1;
+	const int ncol = n_col_ * 16;
+	int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+	const int T = (tlen + 15) / 16 * 16, Q = (qlen + 15) / 16 * 16 + 32;
+	__syncthreads();                                          // (the LDS may still hold the previous call's walk)
+	for (int i = lane; i < Q / 4; i += 64) reinterpret_cast<lds_u32p>(sq)[i] = reinterpret_cast<const uint32_t*>(qr_g)[i];
+	__syncthreads();
+
+	// ---- this lane's cells t0 .. t0 + C - 1, pair k = cells t0 + 2 k (low half), t0 + 2 k + 1 (high half)
+	uint32_t U[NP], V[NP], X[NP], Y[NP], X2[NP], Y2[NP], S[NP], TB[NP], QB[NP];
+	int H[C];
+	auto take_cells = [&](int tn, int r) {                    // the arrays' initial values; the target's codes; the query window of step r
+#pragma unroll
+		for (int k = 0; k < NP; ++k) U[k] = V[k] = K.iuv, X[k] = K.ix, Y[k] = K.iy, X2[k] = K.ix2, Y2[k] = K.iy2, S[k] = K.is;
+		if (!APPROX) {
+#pragma unroll
+			for (int c = 0; c < C; ++c) H[c] = WP_NEG;
+		}
+		uint32_t tw[C / 4];
+#pragma unroll
+		for (int j = 0; j < C / 4; ++j) tw[j] = tn >= 0 && tn < T ? reinterpret_cast<const uint32_t*>(sf_g + tn)[j] : 0u;
+#pragma unroll
+		for (int j = 0; j < C / 4; ++j) TB[2 * j] = (tw[j] & 0xffu) | (tw[j] & 0xff00u) << 8, TB[2 * j + 1] = (tw[j] >> 16 & 0xffu) | (tw[j] >> 24) << 16;
+#pragma unroll
+		for (int k = 0; k < NP; ++k) {
+			int i0 = qlen - 1 - r + tn + 2 * k, i1 = i0 + 1;
+			i0 = i0 < 0 ? 0 : i0 > Q - 1 ? Q - 1 : i0, i1 = i1 < 0 ? 0 : i1 > Q - 1 ? Q - 1 : i1;
+			QB[k] = (uint32_t)sq[i0] | (uint32_t)sq[i1] << 16;
+		}
+	};
+	int t0 = -16 + ((lane * C + 16) & M);
+	take_cells(t0, 0);
+	// one cell's value out of a packed array: lane and pair are wave-uniform
+	auto cell_value = [&](const uint32_t (&A)[NP], int t) -> int {
+		const int L = (t & M) / C, kk = (t & CB) >> 1;
+		uint32_t v = 0;
+#pragma unroll
+		for (int k = 0; k < NP; ++k) if (k == kk) v = (uint32_t)__builtin_amdgcn_readlane((int)A[k], L);
+		return kpk::value_of(v, t & 1);
+	};
+	int last_st = -1, last_en = -1, H0 = 0, last_H0_t = 0, p_st0 = 0;
+	const int n_r = qlen + tlen - 1;
+	for (int r = 0; r < n_r; ++r) {
+		int st = 0, en = tlen - 1;
+		if (st < r - qlen + 1) st = r - qlen + 1;
+		if (en > r) en = r;
+		if (st < (r - wr + 1) >> 1) st = (r - wr + 1) >> 1;
+		if (en > (r + wl) >> 1) en = (r + wl) >> 1;
+		if (st > en) { z_zdropped = 1; break; }
+		const int st0 = st, en0 = en;
+		st = st / 16 * 16, en = (en + 16) / 16 * 16 - 1;
+		const int v_edge = r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
+		// ---- the cell below this lane's first, as the last step left it (its values in the HIGH halves)
+		uint32_t nbX = (uint32_t)MNC_DPP_ROR1((int)X[NP - 1]), nbV = (uint32_t)MNC_DPP_ROR1((int)V[NP - 1]), nbX2 = (uint32_t)MNC_DPP_ROR1((int)X2[NP - 1]);
+		int nbH = 0;
+		if (!APPROX) nbH = MNC_DPP_ROR1(H[C - 1]);
+		// ---- the query window moves down one base; the window of cells moves up with st
+		if (r > 0) {
+			int qi = qlen - 1 - r + t0;
+			qi = qi < 0 ? 0 : qi > Q - 1 ? Q - 1 : qi;
+			const uint32_t qn = sq[qi];
+#pragma unroll
+			for (int k = NP - 1; k > 0; --k) QB[k] = kpk::shift16(QB[k], QB[k - 1]);
+			QB[0] = QB[0] << 16 | qn;
+		}
+		{
+			const int base = st - 16;
+			const int tn = base + ((lane * C - base) & M);
+			if (tn != t0) { t0 = tn; take_cells(tn, r); }
+		}
+		if (t0 == st) {                                        // ksw2's x1, x21, v1
+			if (st > 0) {
+				if (!(st - 1 >= last_st && st - 1 <= last_en)) nbX = K.ix, nbX2 = K.ix2, nbV = K.iuv;
+			} else nbX = K.ix, nbX2 = K.ix2, nbV = kpk::lane(v_edge, 0);
+		}
+		if (en >= r) {                                         // y[r], y2[r], u[r]: the cell the virtual row enters at
+			const int kk = (r & CB) >> 1;
+			const uint32_t m = lane == (r & M) / C ? ((r & 1) ? 0xffff0000u : 0x0000ffffu) : 0u;
+			const uint32_t ue = kpk::lane(v_edge, 0);
+#pragma unroll
+			for (int k = 0; k < NP; ++k)
+				if (k == kk) Y[k] = kpk::bitsel(m, K.iy, Y[k]), Y2[k] = kpk::bitsel(m, K.iy2, Y2[k]), U[k] = kpk::bitsel(m, ue, U[k]);
+		}
+		// ---- scores, fresh on [st0, lim) only: both ends share their offset in a block of C cells (lim - st0 is a multiple
+		// of 16), so a lane's mask is one of {none, all, cells >= oc, cells < oc} of ONE wave-uniform pattern
+		{
+			const int lim = st0 + ((en0 - st0) / 16 + 1) * 16, oc = st0 & CB, sblk = st0 & ~CB, lblk = lim & ~CB;
+			const bool is_lo = t0 == sblk, is_hi = t0 == lblk, is_mid = t0 > sblk && t0 < lblk;
+			const uint32_t ma = (is_lo || is_hi) ? 0xffffffffu : 0u, mb = (is_hi || is_mid) ? 0xffffffffu : 0u;
+#pragma unroll
+			for (int k = 0; k < NP; ++k) {
+				const uint32_t pat = (2 * k >= oc ? 0x0000ffffu : 0u) | (2 * k + 1 >= oc ? 0xffff0000u : 0u);    // uniform
+				const uint32_t mask = (pat & ma) ^ mb;
+				S[k] = kpk::bitsel(mask, kpk::scores(K, TB[k], QB[k]), S[k]);
+			}
+		}
+		// ---- the cells: all C of a lane are inside [st, en] or none (both ends are multiples of 16, C divides 16)
+		const bool in_row = t0 >= st && t0 <= en;
+		if (in_row) {
+			uint32_t d[NP];
+#pragma unroll
+			for (int k = NP - 1; k >= 0; --k) {                   // from the top: [k - 1] is still old
+				const uint32_t xb = kpk::shift16(X[k], k ? X[k - 1] : nbX), vb = kpk::shift16(V[k], k ? V[k - 1] : nbV), x2b = kpk::shift16(X2[k], k ? X2[k - 1] : nbX2);
+				d[k] = kpk::cell_pair<RIGHT>(K, xb, vb, x2b, S[k], U[k], V[k], X[k], Y[k], X2[k], Y2[k]);
+			}
+			uint32_t dw[C / 4];
+#pragma unroll
+			for (int j = 0; j < C / 4; ++j) dw[j] = __builtin_amdgcn_perm(d[2 * j + 1], d[2 * j], 0x06040200u);
+			uint32_t *pr = reinterpret_cast<uint32_t*>(&p[(size_t)r * ncol + (size_t)(t0 - st)]);
+			if constexpr (C == 16) *reinterpret_cast<uint4*>(pr) = make_uint4(dw[0], dw[1], dw[2], dw[3]);
+			else if constexpr (C == 8) *reinterpret_cast<uint2*>(pr) = make_uint2(dw[0], dw[1]);
+			else pr[0] = dw[0];
+		}
+		if (!APPROX) {
+			int max_H, max_t = 0;
+			if (r > 0) {
+				// H[en0] = the OLD H[en0 - 1] + u[en0]; H[t] += v[t] on [st0, en0); the maximum in the SSE scan's tie order.
+				// Every lane adds v to all its cells: a cell above en0 is ASSIGNED when the band reaches it, and until then it
+				// stays near WP_NEG; a cell that has just fallen below st0 is sent back there, so the maximum over all cells
+				// of the wave is the maximum over [st0, en0].
+				const int ce = en0 & CB, Le = (en0 & M) / C;
+				int he = 0;
+#pragma unroll
+				for (int c = 0; c < C; ++c) if (c == ce) he = (c ? H[c > 0 ? c - 1 : 0] : nbH) + kpk::value_of(U[c >> 1], c & 1);
+#pragma unroll
+				for (int c = 0; c < C; ++c) H[c] += kpk::value_of(V[c >> 1], c & 1);
+				if (en0 > 0) {
+#pragma unroll
+					for (int c = 0; c < C; ++c) if (c == ce) H[c] = lane == Le ? he : H[c];
+				}
+				if (st0 > p_st0) {
+					const int cp = (st0 - 1) & CB, Lp = ((st0 - 1) & M) / C;
+#pragma unroll
+					for (int c = 0; c < C; ++c) if (c == cp) H[c] = lane == Lp ? WP_NEG : H[c];
+				}
+				int tm = H[0];
+#pragma unroll
+				for (int c = 1; c < C; ++c) tm = tm > H[c] ? tm : H[c];
+				max_H = wave_max_dpp(tm);
+				// where: only a new maximum or a possible Z-drop asks (ksw_apply_zdrop reads max_t in no other case)
+				if (max_H > z_max || (zdrop >= 0 && z_max - max_H > zdrop)) {
+					const int en1 = st0 + (en0 - st0) / 4 * 4, base = st - 16;
+					unsigned best = 0xffffffffu;
+#pragma unroll
+					for (int c = 0; c < C; ++c) {
+						unsigned long long m = __ballot(H[c] == max_H);
+						while (m) {
+							const int L = __builtin_ctzll(m);
+							m &= m - 1;
+							const int t = base + ((L * C - base) & M) + c;
+							const unsigned rank = t == en0 ? 0u : t < en1 ? 1u + ((unsigned)(t - st0) & 3u) * 0x1000000u + ((unsigned)(t - st0) >> 2) : 1u + 4u * 0x1000000u + (unsigned)(t - en1);
+							if (t >= st0 && t <= en0 && rank < best) best = rank, max_t = t;
+						}
+					}
+				}
+			} else {
+				if (lane == 0) H[0] = kpk::value_of(V[0], 0) - qe;      // t0 == 0 there
+				max_H = __builtin_amdgcn_readlane(H[0], 0), max_t = 0;
+			}
+			if (r - st0 == qlen - 1) {
+				const int cs = st0 & CB, Ls = (st0 & M) / C;
+				int hs = 0;
+#pragma unroll
+				for (int c = 0; c < C; ++c) if (c == cs) hs = __builtin_amdgcn_readlane(H[c], Ls);
+				if (hs > z_mqe) z_mqe = hs, z_mqe_t = st0;
+			}
+			// ksw_apply_zdrop
+			if (max_H > z_max) z_max = max_H, z_max_t = max_t, z_max_q = r - max_t;
+			else if (zdrop >= 0 && z_max - max_H > zdrop && max_t >= z_max_t && r - max_t >= z_max_q) {
+				const int tl = max_t - z_max_t, ql = (r - max_t) - z_max_q;
+				const int l = tl > ql ? tl - ql : ql - tl;
+				if (z_max - max_H > zdrop + l * e2) { z_zdropped = 1; break; }
+			}
+			if (r == qlen + tlen - 2 && en0 == tlen - 1) {
+				const int cs = (tlen - 1) & CB, Ls = ((tlen - 1) & M) / C;
+#pragma unroll
+				for (int c = 0; c < C; ++c) if (c == cs) z_score = __builtin_amdgcn_readlane(H[c], Ls);
+			}
+		} else {
+			if (r > 0) {
+				if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
+					const int d0 = cell_value(V, last_H0_t), d1 = cell_value(U, last_H0_t + 1);
+					if (d0 > d1) H0 += d0;
+					else H0 += d1, ++last_H0_t;
+				} else if (last_H0_t >= st0 && last_H0_t <= en0) {
+					H0 += cell_value(V, last_H0_t);
+				} else {
+					++last_H0_t, H0 += cell_value(U, last_H0_t);
+				}
+			} else H0 = cell_value(V, 0) - qe, last_H0_t = 0;
+			if (r == qlen + tlen - 2 && en0 == tlen - 1) z_score = H0;
+		}
+		last_st = st, last_en = en, p_st0 = st0;
+	}
+	__syncthreads();                                          // the direction codes are written; the query's LDS is free
+	int i0 = -1, j0 = -1;
+	if (!z_zdropped && !(flag & EZ_EXTZ_ONLY)) i0 = tlen - 1, j0 = qlen - 1;
+	else if (!z_zdropped && (flag & EZ_EXTZ_ONLY) && z_mqe + end_bonus > z_max) z_reach_end = 1, i0 = z_mqe_t, j0 = qlen - 1;
+	else if (z_max_t >= 0 && z_max_q >= 0) i0 = z_max_t, j0 = z_max_q;
+	int n_cigar = 0;
+	if (i0 >= 0 && j0 >= 0) n_cigar = walk_wg<1, PP, CP, RIGHT ? 2 : 1>(qlen, tlen, wl, wr, ncol, p, cig, i0, j0, flag, sq, bc);
+	n_cigar = wg_bcast0<1>(n_cigar);
+	ez_out.max = z_max, ez_out.zdropped = z_zdropped, ez_out.max_q = z_max_q, ez_out.max_t = z_max_t, ez_out.mqe = z_mqe, ez_out.mqe_t = z_mqe_t;
+	ez_out.score = z_score, ez_out.reach_end = z_reach_end, ez_out.n_cigar = n_cigar;
+	st_order<false, 1>();
+}
+
 // mm_test_zdrop on a finished gap-filling CIGAR: 0 fine, 1 the score drops by more than zdrop, 2 and
 // the dropped stretch aligns to its own reverse complement.  One lane; sequences come from `mem`.
 template <class SU8, class CP>
@@ -1860,7 +2124,7 @@ __global__ __launch_bounds__(64 * NW) void mnc_dp_align(Batch B, uint8_t *ws_all
 			int ncw = g.qlen < g.tlen ? g.qlen : g.tlen;
 			{ const int wb = g.w < 0 ? (g.tlen > g.qlen ? g.tlen : g.qlen) : g.w; ncw = ((ncw < wb + 1 ? ncw : wb + 1) + 15) / 16 + 1; }
 			const long long p_bytes = ((long long)(g.qlen + g.tlen - 1) * ncw + 1) * 16;
-			const bool in_lds = NW == 1 && 12 * T + Q <= lds_bytes;
+			const bool in_lds = NW == 1 && C == 0 && 12 * T + Q <= lds_bytes;    // (one wave with C > 0: the packed form -- LDS holds the query and the walk's tile, the state is in registers, sequences and direction codes in the workspace)
 			// small calls (the extensions of most reads) keep direction bytes and CIGAR in LDS as well
 			const bool all_lds = in_lds && p_bytes <= lds_p && g.qlen + g.tlen + 2 <= lds_cig;
 			if (big_pass == 0 && !all_lds) {                        // not for the small layout: pass 2 takes it
@@ -1881,21 +2145,38 @@ __global__ __launch_bounds__(64 * NW) void mnc_dp_align(Batch B, uint8_t *ws_all
 				SU8 sf = (SU8)(mem + 7 * (size_t)T), qr = sf + T;
 				WG_T(ts0);
 				// target / reversed query; the left extension runs on both sequences reversed
-				for (int i = lane; i < T; i += 64 * NW) sf[i] = i < g.tlen ? (uint8_t)tcode(B, coff, g.kind == 0 ? g.ts + g.tlen - 1 - i : g.ts + i) : 0;
-				for (int i = lane; i < Q; i += 64 * NW)
-					qr[i] = i < g.qlen ? (uint8_t)qcode(read, rlen, g.rev, g.kind == 0 ? g.qs + i : g.qs + g.qlen - 1 - i) : 0;
+				int any_ambi = 0;
+				for (int i = lane; i < T; i += 64 * NW) { const int c = i < g.tlen ? tcode(B, coff, g.kind == 0 ? g.ts + g.tlen - 1 - i : g.ts + i) : 0; sf[i] = (uint8_t)c, any_ambi |= c >> 2; }
+				for (int i = lane; i < Q; i += 64 * NW) {
+					const int c = i < g.qlen ? qcode(read, rlen, g.rev, g.kind == 0 ? g.qs + i : g.qs + g.qlen - 1 - i) : 0;
+					qr[i] = (uint8_t)c, any_ambi |= c >> 2;
+				}
 				st_order<false, NW>();
 				WG_T(ts1);
 				WG_ADD(6, ts1 - ts0);
-				// the cells in registers (ksw_wg) unless the call's anti-diagonals or sequences outgrow that form; debug_route
-				// bit 6: never (the workspace form on this many waves, for the tests)
+				// the cells in registers (ksw_wg: NW waves, C cells a thread; one wave: ksw_wp, C cells a lane as packed pairs)
+				// unless the call's anti-diagonals or sequences outgrow that form; debug_route bit 6: never (the workspace form
+				// on this many waves, for the tests)
 				bool on_wg = false;
-				if constexpr (C > 0) on_wg = !(B.debug_route & 64) && wg_fits<NW, C>(g.qlen, g.tlen, g.w, lds_bytes);
+				if constexpr (C > 0 && NW > 1) on_wg = !(B.debug_route & 64) && wg_fits<NW, C>(g.qlen, g.tlen, g.w, lds_bytes);
+				// (the packed form: no ambiguous base in either sequence, scores that keep every intermediate inside int8)
+				if constexpr (C > 0 && NW == 1)
+					on_wg = !(B.debug_route & 64) && !__any(any_ambi) && wp_fits<C>(g.qlen, g.tlen, g.w, lds_bytes) &&
+					        kpk::params_fit(B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, sc_N);
 				auto call = [&](int zdrop, int end_bonus, int flag) {
-					if constexpr (C > 0) {
+					if constexpr (C > 0 && NW > 1) {
 						if (on_wg) {
 							ksw_wg<NW, C>(g.qlen, g.tlen, (const uint8_t*)sf, (const uint8_t*)qr, (lds_u8p)smem, lds_bytes, pbuf, cg, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2,
 							              sc_mch, sc_mis, sc_N, g.w, zdrop, end_bonus, flag, ez);
+							return;
+						}
+					}
+					if constexpr (C > 0 && NW == 1) {
+						if (on_wg) {
+#define MNC_WP_CALL(R, A) ksw_wp<C, R, A>(g.qlen, g.tlen, (const uint8_t*)sf, (const uint8_t*)qr, (lds_u8p)smem, pbuf, cg, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, g.w, zdrop, end_bonus, flag, ez)
+							if (flag & EZ_RIGHT) { if (flag & EZ_APPROX_MAX) MNC_WP_CALL(true, true); else MNC_WP_CALL(true, false); }
+							else { if (flag & EZ_APPROX_MAX) MNC_WP_CALL(false, true); else MNC_WP_CALL(false, false); }
+#undef MNC_WP_CALL
 							return;
 						}
 					}
@@ -1927,7 +2208,7 @@ __global__ __launch_bounds__(64 * NW) void mnc_dp_align(Batch B, uint8_t *ws_all
 				}
 			};
 			const size_t h_off = (size_t)(8 * T + Q + 15) / 16 * 16;
-			if constexpr (NW == 1) {
+			if constexpr (NW == 1 && C == 0) {
 				if (all_lds)
 					run((lds_i8p)smem, (lds_i32p)(smem + h_off), (lds_u8p)(smem + lds_bytes), (lds_u32p)(smem + lds_bytes + lds_p));
 				else if (in_lds)
@@ -2815,6 +3096,7 @@ void launch_dp_plan(const Batch &B, const int32_t *work_list, unsigned max_work,
 size_t dp_align_ws_bytes(long long state_max, long long p_max, long long cig_max) { return align_ws(state_max, p_max, cig_max).total; }
 // the literal kernel's long calls with the cells in registers (ksw_wg): <8, 2> for few calls, <4, 4> for many
 constexpr int ALIGN_SEQ_WIDE = 32768, ALIGN_SEQ_NARROW = 16384;   // LDS bytes per sequence in the two forms
+constexpr int ALIGN_SEQ_PACKED = 16384;                           // ... and of the query in the packed one-wave form (a longer query: the workspace form)
 // the form for few calls: eight waves x two cells a thread (measured against sixteen x one: an anti-diagonal costs 8 x 370
 // instead of 16 x 260 vector instructions, and a workgroup needs half a CU instead of a whole one -- a config-4 block 33.1
 // instead of 35.1 ms, 30 000 reads with 13 % errors 37 instead of 39 ms: tools/ab_wide.sh)
@@ -2829,6 +3111,7 @@ int dp_align_prepare(int lds_bytes)
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
 	if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align<WIDE_NW, WIDE_C>), hipFuncAttributeMaxDynamicSharedMemorySize, wg_lds_bytes<WIDE_NW>(ALIGN_SEQ_WIDE));
 	if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, wg_lds_bytes<4>(ALIGN_SEQ_NARROW));
+	if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align<1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, wp_lds_bytes(ALIGN_SEQ_PACKED));
 	if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return MNC_ERR_HIP; }
 	return MNC_OK;
 }
@@ -2842,6 +3125,14 @@ void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max,
 	// always the wide form; 9: always the four-wave form; (6: the launches below, but cells in the workspace)
 	// (pass 2, what the banded kernels handed back, likewise: it runs behind the window's join, the chip is its own)
 	const bool long_pass = big_pass >= 1;
+	// round 5: every pass with its direction bytes in the workspace on ONE wave per call, sixteen cells a lane as packed
+	// pairs (ksw_wp).  MNC_KSW_FORMS=old (or any of the debug_route bits that name an older form) brings those back.
+	static const bool old_forms = getenv("MNC_KSW_FORMS") && !strcmp(getenv("MNC_KSW_FORMS"), "old");
+	if (long_pass && !old_forms && !(B.debug_route & (32 | 64 | 128 | 256 | 512))) {
+		if (forms & 1) hipLaunchKernelGGL((mnc_dp_align<1, 16>), dim3(n_wg), dim3(64), (size_t)wp_lds_bytes(ALIGN_SEQ_PACKED), st, B, ws, state_max, p_max, cig_max,
+		                                  ALIGN_SEQ_PACKED, 0, 0, big_pass, 0, 0);
+		return;
+	}
 	if (long_pass && !(B.debug_route & (32 | 128))) {
 		// (forms bit 2: the four-wave form alone, whatever the count)
 		const int regime16 = (B.debug_route & 256) ? 0 : (B.debug_route & 512) ? -1 : 1;

@@ -24,8 +24,8 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIP_DEVICE_COMPILE__)
-#define KPK_FN __device__ __forceinline__
+#if defined(__HIPCC__)
+#define KPK_FN __host__ __device__ __forceinline__
 #else
 #define KPK_FN static inline
 #endif

@@ -61,6 +61,58 @@ def genome_set(n_genomes, seed=SEED_20, div_seed=SEED_20_DIV, min_len=2_000_000,
     return names, seqs
 
 
+def genome_set_repeats(n_genomes, seed=SEED_20, div_seed=SEED_20_DIV, min_len=2_000_000, max_len=7_000_000,
+                       diverged_half=True, rate_ppm=30_000, rep_seed=0x4E9):
+    """`genome_set`, made bacteria-like (opt-in: a sensitivity workload, not the BASELINE's headline): what the databases
+    monica builds hold (database.py:52-67: whole bacterial genomes) and i.i.d. contigs do not --
+      * 5-7 copies per genome of a 5 kb operon (rRNA-like): one ancestral operon, each genome's own 3-10 % away from it,
+        its copies within the genome at 99.5-100 % identity;
+      * 15-30 copies per genome of 1.3 kb insertion sequences at 97-100 % identity, drawn from five families that all
+        genomes share;
+      * 5 % of each genome shared with its neighbour (genome i + 1) at 85-95 % identity, in blocks of 10-50 kb.
+    The elements overwrite stretches of the i.i.d. contigs in place (lengths stay what `genome_set` gives them);
+    the diverged copies of the second half are made AFTER that, so they carry the same elements 3 % away.  Everything is
+    a function of the seeds (numpy's PCG64 + the library's counter-based generators)."""
+    base = n_genomes // 2 if diverged_half else n_genomes
+    names, seqs = genome_set(base, seed=seed, div_seed=div_seed, min_len=min_len, max_len=max_len, diverged_half=False)
+    rng = np.random.default_rng(rep_seed)
+    operon0 = genome(_mix(rep_seed) + 1, 5000)
+    families = [genome(_mix(rep_seed) + 10 + f, 1300) for f in range(5)]
+    seqs = [np.array(s, copy=True) for s in seqs]
+
+    def place(dst, piece, taken):
+        for _ in range(100):                                   # a free stretch (elements do not overwrite one another)
+            at = int(rng.integers(0, len(dst) - len(piece)))
+            if not any(at < b and a < at + len(piece) for a, b in taken):
+                dst[at:at + len(piece)] = piece
+                taken.append((at, at + len(piece)))
+                return
+    for i, g in enumerate(seqs):
+        taken = []
+        own = diverge(operon0, _mix(rep_seed) + 1000 + i, int(rng.integers(30_000, 100_001)))
+        for c in range(int(rng.integers(5, 8))):
+            place(g, diverge(own, _mix(rep_seed) + 2000 + 16 * i + c, int(rng.integers(0, 5001))), taken)
+        for c in range(int(rng.integers(15, 31))):
+            fam = families[int(rng.integers(0, 5))]
+            place(g, diverge(fam, _mix(rep_seed) + 3000 + 64 * i + c, int(rng.integers(0, 30_001))), taken)
+    originals = [s.copy() for s in seqs]
+    for i, g in enumerate(seqs):                               # 5 % from the neighbour, 85-95 % identical
+        nb = originals[(i + 1) % len(seqs)]
+        left = len(g) // 20
+        k = 0
+        while left > 0 and len(seqs) > 1:
+            blk = min(left, int(rng.integers(10_000, 50_001)), len(nb) - 1, len(g) - 1)
+            src = int(rng.integers(0, len(nb) - blk))
+            at = int(rng.integers(0, len(g) - blk))
+            g[at:at + blk] = diverge(nb[src:src + blk], _mix(rep_seed) + 5000 + 256 * i + k, int(rng.integers(50_000, 150_001)))
+            left -= blk
+            k += 1
+    for i in range(base, n_genomes):
+        seqs.append(diverge(seqs[i - base], _mix(div_seed) + i, rate_ppm))
+        names.append(contig_name(i))
+    return names, seqs
+
+
 def ecoli_like():
     return [contig_name(0)], [genome(SEED_ECOLI, 4_641_652)]
 

@@ -4,7 +4,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from monica_amd import _capi, synth
 sub, ins, dele, n = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 30000
-names, seqs = synth.genome_set(20, min_len=2_000_000, max_len=7_000_000)
+names, seqs = (synth.genome_set_repeats if os.environ.get("MNC_GENOME_MODEL") == "repeats" else synth.genome_set)(20, min_len=2_000_000, max_len=7_000_000)
 index = _capi.Index.from_seqs(names, seqs)
 eng = _capi.Engine(index, 0)
 if len(sys.argv) > 5:

@@ -7,12 +7,18 @@ sys.path.insert(0, ROOT)
 from monica_amd import _capi, synth
 from oracle import pyoracle
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30000
-names, seqs = synth.genome_set(20, min_len=2_000_000, max_len=7_000_000)
+model = sys.argv[2] if len(sys.argv) > 2 else "iid"            # "repeats": synth.genome_set_repeats (operons, insertion sequences, shared stretches)
+rates = sys.argv[3:]                                           # e.g. "20": a 20 % row as well
+names, seqs = (synth.genome_set_repeats if model == "repeats" else synth.genome_set)(20, min_len=2_000_000, max_len=7_000_000)
 index = _capi.Index.from_seqs(names, seqs)
 oidx = pyoracle.Index.from_seqs(names, [s.tobytes() for s in seqs])
 oidx.opt.cigar = 1
 eng = _capi.Engine(index, 0)
-for label, kw in (("10% errors", dict(seed=777)), ("16% errors", dict(seed=778, sub=700, ins=450, dele=450)), ("3% errors", dict(seed=779, sub=120, ins=90, dele=90))):
+rows = [("10% errors", dict(seed=777)), ("16% errors", dict(seed=778, sub=700, ins=450, dele=450)), ("3% errors", dict(seed=779, sub=120, ins=90, dele=90))]
+if "20" in rates:
+    rows.append(("20% errors", dict(seed=780, sub=800, ins=600, dele=600)))
+print("genome model", model, "mid_occ", index.mid_occ)
+for label, kw in rows:
     bases, offsets, truth = synth.reads(seqs, n, 5000, **kw)
     t = time.time(); a, best, nh = eng.classify(bases, offsets, 60); tg = time.time() - t
     t = time.time(); oa, ob, onh, _ = oidx.classify(bases, offsets, 60, n_threads=16); tc = time.time() - t
