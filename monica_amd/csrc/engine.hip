@@ -59,6 +59,10 @@ size_t dp_stitch_pool_slack(int n_wg);
 void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max, long long p_max, long long cig_max,
                      int lds_state, int lds_p, int lds_cig, int big_pass, hipStream_t st, int forms = 3);
 void launch_dp_stitch(const Batch &B, const int32_t *work_list, int32_t *next_list, int max_read_len, int n_wg, hipStream_t st);
+bool dp_align_long_packed(const Batch &B);
+void launch_dp_align_long(const Batch &B, uint8_t *ws_huge, int n_huge, long long st_huge, long long p_huge, long long cig_huge,
+                          uint8_t *ws_big, int n_big, long long st_big, long long p_big, long long cig_big,
+                          uint8_t *ws_small, int n_small, long long st_small, long long p_small, long long cig_small, hipStream_t st);
 size_t dp_fill_p_slot();
 size_t dp_fillp_slot();
 size_t dp_fillp_cig_slot();
@@ -82,7 +86,7 @@ constexpr int DP_WG_FILL = MNC_DP_WG_FILL, DP_WG_EXT = MNC_DP_WG_EXT, DP_WG_STIT
 // workspace classes of the alignment kernel: a normal slot per workgroup, a few large ones
 constexpr int DP_LDS_BYTES = 16 * 1024;
 constexpr int DP_LDS0_STATE = 4 * 1024, DP_LDS0_P = 10 * 1024, DP_LDS0_CIG = 256;   // pass 0: 15 KB per workgroup
-constexpr int DP_WG_SMALL = 2048, DP_WG_BIG = 768, DP_WG_HUGE = 8, DP_WG_MID = 512, DP_WG_LFILL = 2048, DP_WG_LEXT = 512;
+constexpr int DP_WG_SMALL = 2048, DP_WG_BIG = 768, DP_WG_HUGE = 8, DP_WG_MID = 1536, DP_WG_LFILL = 4096, DP_WG_LEXT = 2048, DP_WG_BIGFB = 256;   // (BIGFB: large slots of pass 4's round inside the window, beside pass 1's)
 constexpr long long DP_STATE_SMALL = 96 * 1024, DP_P_SMALL = 1 << 20, DP_CIG_SMALL = 4096;
 constexpr long long DP_STATE_BIG = 13 * 32768, DP_P_BIG = 8LL << 20, DP_CIG_BIG = 65536;       // 768 slots of 9 MB: any extension (max_gap 5000 on both sides: 7.7 MB of direction bytes)
 constexpr long long DP_STATE_HUGE = 13 * 32768, DP_P_HUGE = 256LL << 20, DP_CIG_HUGE = 65536;   // and 8 of 257 MB for anything up to max_sw_mat
@@ -164,8 +168,8 @@ struct Buf {
 struct SharedWs {
 	std::mutex mu;
 	int refs = 0;
-	Buf fill_p, fill_cig, extp_p, extp_cig, ext_p, lfill_p, lext_p, dp_ws, dp_ws_mid, dp_ws_big, dp_ws_huge;
-	void release() { for (Buf *b : { &fill_p, &fill_cig, &extp_p, &extp_cig, &ext_p, &lfill_p, &lext_p, &dp_ws, &dp_ws_mid, &dp_ws_big, &dp_ws_huge }) b->release(); }
+	Buf fill_p, fill_cig, extp_p, extp_cig, ext_p, lfill_p, lext_p, dp_ws, dp_ws_mid, dp_ws_big, dp_ws_bigfb, dp_ws_huge;
+	void release() { for (Buf *b : { &fill_p, &fill_cig, &extp_p, &extp_cig, &ext_p, &lfill_p, &lext_p, &dp_ws, &dp_ws_mid, &dp_ws_big, &dp_ws_bigfb, &dp_ws_huge }) b->release(); }
 };
 static std::mutex g_ws_mu;
 static SharedWs *g_ws[64];
@@ -403,7 +407,7 @@ struct mnc_engine {
 	// side streams: the per-size-class launches of one stage are independent and run side by side
 	static constexpr int N_SIDE = 4;
 	hipStream_t side[N_SIDE]{};
-	hipEvent_t ev_fork = nullptr, ev_join[N_SIDE]{};
+	hipEvent_t ev_fork = nullptr, ev_join[N_SIDE]{}, ev_lfill = nullptr;
 	// constant tables
 	Buf gap_lut, logf_lut, logf_a_lut;
 	int logf_n = 0;
@@ -573,6 +577,7 @@ extern "C" void mnc_engine_destroy(mnc_engine *e)
 		if (e->ev_join[k]) (void)hipEventDestroy(e->ev_join[k]);
 	}
 	if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+	if (e->ev_lfill) (void)hipEventDestroy(e->ev_lfill);
 	if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
 	if (e->ev_prefetch) (void)hipEventDestroy(e->ev_prefetch);
 	if (e->mailbox) (void)hipHostFree(e->mailbox);
@@ -601,10 +606,14 @@ extern "C" int mnc_engine_create(mnc_index *idx, int device, mnc_engine **out)
 		he = hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, greatest);
 	}
 	for (int k = 0; k < mnc_engine::N_SIDE && he == hipSuccess; ++k) {
-		he = hipStreamCreateWithFlags(&e->side[k], hipStreamNonBlocking);
+		// (three streams of the default class get a hardware queue each; a fourth shares one with the first -- measured:
+		// the long extensions behind the literal kernel's long passes, profiles/r05j_timeline.txt -- so the fourth is
+		// made in the batch stream's class, whose queues only that stream uses)
+		he = k < 3 ? hipStreamCreateWithFlags(&e->side[k], hipStreamNonBlocking) : hipStreamCreateWithPriority(&e->side[k], hipStreamNonBlocking, greatest);
 		if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming);
 	}
 	if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+	if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_lfill, hipEventDisableTiming);
 	// The copy stream gets the LOWEST priority -- not for the priority: the runtime keeps one set of hardware queues per
 	// priority class and deals a class's streams round-robin over its queues, so a fifth stream of the side streams' class
 	// shares a queue with one of them, and the barrier packet behind a half-gigabyte copy (the event record of
@@ -797,35 +806,49 @@ struct StageTimer {
 //   s3  (the side stream with a hardware queue of its own) the literal kernel's few long calls
 // The chip-filling kernels (s0, s1) are bound by vector issue; the others are serial work on single waves that
 // fills the gaps.  With debug bit 0x10000 all four are the same stream (one kernel at a time, per-kernel timers).
-static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream_t s1, hipStream_t s2, hipStream_t s3)
+static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream_t s1, hipStream_t s2, hipStream_t s3, hipStream_t s4)
 {
 	// per-kernel timers: only when everything runs on one stream (debug bit 0x10000)
 	const bool timed = e->profiling && s0 == s1;
+	const bool serial = s0 == s1;
 	auto mark = [&](int stage, int which) { if (timed) { (void)hipEventRecord(e->ev[stage][which], s0); if (which) e->ev_used[stage] = true; } };
-	// The literal kernel's long calls first of all, on a stream of their own (`s3`: the side stream whose hardware queue no
-	// other uses).  A pass has two forms and picks one on the device by its call count: up to 64 calls -- eight waves each,
-	// two cells a thread (a workgroup needs half a CU's registers at once: launched before the persistent workgroups of the
-	// gap-filling tiers take the chip, or it would wait for a CU to drain); more -- four waves each, many side by side.
-	// (In a large batch even an idle launch of the wide form costs: 64 workgroups that each want half a CU, 0.15 ms a
-	// launch beside the tiers.  Such a batch launches it for the passes of the truly long calls only, and only when the
-	// engine's previous large batch had any -- reads of one run look alike; the four-wave form takes every call otherwise.)
-	// A micro-batch does not fill the chip: its window is the longest chain of kernels on one stream, and the two long
-	// single-wave kernels (long gaps ~1.7 ms on `s2`, long extensions ~2.1 ms) each get a stream to themselves -- the long
-	// passes go behind the gap-filling tiers on `s0` (1.3 ms of short kernels) there, the long extensions alone on `s3`:
-	// behind a pass with one long call (2.5 ms) they made the slowest batches, 6.1 ms p99.
+	// Five streams side by side (round 5: the long extensions have one of their own, and what the long kernels hand back
+	// that needs the large workspace is aligned INSIDE the window):
+	//   s0  gap fillings on the packed banded kernel, tier by tier          (chip-filling, bound by vector issue)
+	//   s1  the extensions: the packed kernel by class, then the step-by-step kernel (chip-filling)
+	//   s2  (the batch's own stream) the long gaps, then the literal kernel's small calls
+	//   s3  the literal kernel's long passes: one launch of one-wave workgroups that stay until their queues are empty
+	//   s4  the long extensions, and behind them (and behind the long gaps) the first round of pass 4
+	// The single-wave kernels (s2 .. s4) are launched FIRST: their waves are on the chip before the persistent
+	// workgroups of the tiers take every wave slot, and each is a chain of long calls whose length is a latency, not
+	// work -- behind one another on one stream they were the window of a batch of divergent reads
+	// (profiles/r05h_timeline.txt: long gaps 22 ms, then long extensions 23 ms at 16 % errors).
 	const bool small_batch = B.n_reads < 4096;
 	auto long_passes = [&](hipStream_t sl) {
+		if (dp_align_long_packed(B)) {                          // round 5: the three passes as one launch of one-wave workgroups (packed pairs in registers)
+			// (a micro-batch has a handful of such calls: a launch of thousands of workgroups that find nothing costs it more
+			// than the calls themselves)
+			launch_dp_align_long(B, e->ws->dp_ws_huge.as<uint8_t>(), DP_WG_HUGE, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE,
+			                     e->ws->dp_ws_big.as<uint8_t>(), small_batch ? 64 : DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG,
+			                     e->ws->dp_ws_mid.as<uint8_t>(), small_batch ? 128 : DP_WG_MID, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, sl);
+			return;
+		}
 		const int forms_long = small_batch || e->prev_wide_calls > 0 ? 3 : 1, forms_mid = small_batch ? 3 : 1;
 		launch_dp_align(B, e->ws->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 1, sl, forms_long | (forms_long == 1 ? 4 : 0));
 		launch_dp_align(B, e->ws->dp_ws_mid.as<uint8_t>(), DP_WG_MID, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, 0, 3, sl, forms_mid | (forms_mid == 1 ? 4 : 0));
 		launch_dp_align(B, e->ws->dp_ws_huge.as<uint8_t>(), DP_WG_HUGE, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE, DP_LDS_BYTES, 0, 0, 5, sl, forms_long | (forms_long == 1 ? 4 : 0));
 	};
-	if (s3 != s0 && !small_batch) long_passes(s3);
-	// (... and are launched first: the longest kernel of a micro-batch's window)
-	if (s3 != s0 && small_batch) launch_dp_lext(B, B.lext_list, 62, 63, B.fill_fb, 12, e->ws->lext_p.as<uint8_t>(), DP_WG_LEXT, s3);
-	// the long gaps next, on the batch's own stream: single waves (one call each, ~2 ms) that are on the chip
-	// before the persistent workgroups of the gap-filling tiers take the wave slots
-	if (s2 != s0) launch_dp_lfill(B, B.lfill_list, 31, 61, B.fill_fb, 12, e->ws->lfill_p.as<uint8_t>(), DP_WG_LFILL, s2);
+	const bool packed_long = dp_align_long_packed(B);
+	if (!serial) {
+		if (packed_long || !small_batch) long_passes(s3);
+		launch_dp_lext(B, B.lext_list, 62, 63, B.fill_fb, 12, e->ws->lext_p.as<uint8_t>(), small_batch ? 256 : DP_WG_LEXT, s4);
+		launch_dp_lfill(B, B.lfill_list, 31, 61, B.fill_fb, 12, e->ws->lfill_p.as<uint8_t>(), small_batch ? 512 : DP_WG_LFILL, s2);
+		// what the two have handed back for the large workspace (a long extension whose Z-drop may fire is one literal
+		// call of thousands of anti-diagonals): aligned now, beside the tiers, not behind the window's join
+		(void)hipEventRecord(e->ev_lfill, s2);
+		(void)hipStreamWaitEvent(s4, e->ev_lfill, 0);
+		launch_dp_align(B, e->ws->dp_ws_bigfb.as<uint8_t>(), small_batch ? 32 : DP_WG_BIGFB, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 4, s4);
+	}
 	mark(MNC_STAGE_DP_FILL_T1, 0);
 	launch_dp_fill(B, 32, B.fill_list1, 10, 13, B.fill_list_mid, 30, B.fill_fb, 12, e->ws->fill_p.as<uint8_t>(), e->ws->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
 	mark(MNC_STAGE_DP_FILL_T1, 1), mark(MNC_STAGE_DP_FILL_TM, 0);
@@ -834,9 +857,9 @@ static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream
 	launch_dp_fill(B, 64, B.fill_list2, 11, 14, B.fill_list3, 22, B.fill_fb, 12, e->ws->fill_p.as<uint8_t>(), e->ws->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
 	mark(MNC_STAGE_DP_FILL_T2, 1), mark(MNC_STAGE_DP_FILL_T3, 0);
 	launch_dp_fill(B, 128, B.fill_list3, 22, 23, B.fill_fb, 12, B.fill_fb, 12, e->ws->fill_p.as<uint8_t>(), e->ws->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);
-	if (s3 != s0 && small_batch) long_passes(s0);
+	if (!serial && !packed_long && small_batch) long_passes(s0);   // (the older forms in a micro-batch: behind the tiers)
 	mark(MNC_STAGE_DP_FILL_T3, 1), mark(MNC_STAGE_DP_LFILL, 0);
-	if (s2 == s0) launch_dp_lfill(B, B.lfill_list, 31, 61, B.fill_fb, 12, e->ws->lfill_p.as<uint8_t>(), DP_WG_LFILL, s0);   // one kernel at a time (profiling)
+	if (serial) launch_dp_lfill(B, B.lfill_list, 31, 61, B.fill_fb, 12, e->ws->lfill_p.as<uint8_t>(), DP_WG_LFILL, s0);   // one kernel at a time (profiling)
 	mark(MNC_STAGE_DP_LFILL, 1), mark(MNC_STAGE_DP_EXT, 0);
 	// the classes with the longest queries first: few calls, each long -- at the end of the stream they would be a tail
 	// of a few busy waves; the short ones (most of the calls) drain evenly
@@ -847,13 +870,9 @@ static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream
 	launch_dp_ext(B, 128, B.ext_list3, 24, 26, B.fill_fb, 12, e->ws->ext_p.as<uint8_t>(), DP_WG_EXT / 2, s1);
 	launch_dp_ext(B, 256, B.ext_list4, 25, 27, B.fill_fb, 12, e->ws->ext_p.as<uint8_t>(), DP_WG_EXT / 4, s1);
 	mark(MNC_STAGE_DP_EXT, 1);
-	// the long extensions: beside the long gaps in a micro-batch (on the stream of the literal kernel, which has little
-	// to do there), behind them on the batch's stream otherwise
-	if (s3 == s0 || !small_batch) launch_dp_lext(B, B.lext_list, 62, 63, B.fill_fb, 12, e->ws->lext_p.as<uint8_t>(), DP_WG_LEXT, s2);
-	if (s3 == s0) {                                            // one kernel at a time (profiling): in their old place
-		launch_dp_align(B, e->ws->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 1, s3);
-		launch_dp_align(B, e->ws->dp_ws_mid.as<uint8_t>(), DP_WG_MID, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, 0, 3, s3);
-		launch_dp_align(B, e->ws->dp_ws_huge.as<uint8_t>(), DP_WG_HUGE, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE, DP_LDS_BYTES, 0, 0, 5, s3);
+	if (serial) {                                              // one kernel at a time (profiling)
+		launch_dp_lext(B, B.lext_list, 62, 63, B.fill_fb, 12, e->ws->lext_p.as<uint8_t>(), DP_WG_LEXT, s0);
+		long_passes(s0);
 	}
 	launch_dp_align(B, e->ws->dp_ws.as<uint8_t>(), 2 * DP_WG_SMALL, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS0_STATE, DP_LDS0_P, DP_LDS0_CIG, 0, s2);
 }
@@ -1110,7 +1129,7 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 		ENS2(segs, seg_cap * sizeof(Seg)); ENS2(cig_seg, cig_cap * 4); ENS2(cig_reg, cig_reg_cap * 4);
 		ENS2(work_a, nsr * 4); ENS2(work_b, nsr * 4); ENS2(big_list, seg_cap * 4); ENS2(reg_cnt, (nr + 1) * 4); ENS2(regs2, nsr * sizeof(mnc_reg_t));
 		const size_t ws_small = dp_align_ws_bytes(DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL), ws_big = dp_align_ws_bytes(DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG), ws_huge = dp_align_ws_bytes(DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE);
-		ENSW(dp_ws, ws_small * DP_WG_SMALL * 2); ENSW(dp_ws_big, ws_big * DP_WG_BIG); ENSW(dp_ws_huge, ws_huge * DP_WG_HUGE); ENS2(huge_list, seg_cap * 4); ENSW(dp_ws_mid, ws_small * DP_WG_MID); ENS2(mid_list, seg_cap * 4); ENS2(lfill, seg_cap * 4); ENSW(lfill_p, dp_lfill_p_slot() * DP_WG_LFILL); ENS2(lext, seg_cap * 4); ENS2(bigfb, seg_cap * 4); ENSW(lext_p, dp_lext_p_slot() * DP_WG_LEXT);
+		ENSW(dp_ws, ws_small * DP_WG_SMALL * 2); ENSW(dp_ws_big, ws_big * DP_WG_BIG); ENSW(dp_ws_bigfb, ws_big * DP_WG_BIGFB); ENSW(dp_ws_huge, ws_huge * DP_WG_HUGE); ENS2(huge_list, seg_cap * 4); ENSW(dp_ws_mid, ws_small * DP_WG_MID); ENS2(mid_list, seg_cap * 4); ENS2(lfill, seg_cap * 4); ENSW(lfill_p, dp_lfill_p_slot() * DP_WG_LFILL); ENS2(lext, seg_cap * 4); ENS2(bigfb, seg_cap * 4); ENSW(lext_p, dp_lext_p_slot() * DP_WG_LEXT);
 		ENS2(plan_long, (nr * 4 + 1024) * 4);
 		ENS2(fill1, seg_cap * 4); ENS2(fill2, seg_cap * 4); ENS2(fill3, seg_cap * 4); ENS2(fill_mid, seg_cap * 4); ENS2(fill_fb, seg_cap * 4); ENSW(fill_p, dp_fillp_slot() * DP_WG_FILL); ENSW(fill_cig, dp_fillp_cig_slot() * DP_WG_FILL); ENS2(extp, seg_cap * 4 * 8); ENSW(extp_p, dp_extp_slot() * DP_WG_EXT); ENSW(extp_cig, dp_extp_cig_slot() * DP_WG_EXT); ENS2(ext1, seg_cap * 4); ENS2(ext2, seg_cap * 4); ENS2(ext3, seg_cap * 4); ENS2(ext4, seg_cap * 4); ENS2(gen_list, seg_cap * 4); ENSW(ext_p, dp_fill_p_slot() * DP_WG_EXT);
 #undef ENS2
@@ -1156,8 +1175,8 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 				{
 					StageTimer t(e, MNC_STAGE_DP_FILL);               // the four streams, fork to join
 					if (int rcf = fork()) return rcf;
-					if (e->debug & 0x10000) align_round(B, e, e->side[0], e->side[0], e->side[0], e->side[0]);   // profiling: one kernel at a time
-					else align_round(B, e, e->side[0], e->side[1], st, e->side[2]);
+					if (e->debug & 0x10000) align_round(B, e, e->side[0], e->side[0], e->side[0], e->side[0], e->side[0]);   // profiling: one kernel at a time
+					else align_round(B, e, e->side[0], e->side[1], st, e->side[2], e->side[3]);
 					if (int rcj = join()) return rcj;
 				}
 				{
@@ -1168,8 +1187,8 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 			} else {
 				launch_dp_plan(B, work, max_work, long_reads, (int)DP_STATE_SMALL, DP_P_SMALL, (int)DP_CIG_SMALL, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE, st);
 				if (int rcf = fork()) return rcf;
-				if (e->debug & 0x10000) align_round(B, e, e->side[0], e->side[0], e->side[0], e->side[0]);
-				else align_round(B, e, e->side[0], e->side[1], st, e->side[2]);
+				if (e->debug & 0x10000) align_round(B, e, e->side[0], e->side[0], e->side[0], e->side[0], e->side[0]);
+				else align_round(B, e, e->side[0], e->side[1], st, e->side[2], e->side[3]);
 				if (int rcj = join()) return rcj;
 				align_rest(B, e, st);
 				launch_dp_stitch(B, work, next, (e->debug & 0x200000) ? 0 : e->cur_max_read_len > 0 ? e->cur_max_read_len : 8192, DP_WG_STITCH, st);

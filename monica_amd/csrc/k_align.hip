@@ -1800,13 +1800,16 @@ __device__ __attribute__((noinline)) void ksw_wp(int qlen, int tlen, const uint8
 	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
 	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
 	const int T = (tlen + 15) / 16 * 16, Q = (qlen + 15) / 16 * 16 + 32;
+	WG_T(tm0);
 	__syncthreads();                                          // (the LDS may still hold the previous call's walk)
 	for (int i = lane; i < Q / 4; i += 64) reinterpret_cast<lds_u32p>(sq)[i] = reinterpret_cast<const uint32_t*>(qr_g)[i];
 	__syncthreads();
 
 	// ---- this lane's cells t0 .. t0 + C - 1, pair k = cells t0 + 2 k (low half), t0 + 2 k + 1 (high half)
-	uint32_t U[NP], V[NP], X[NP], Y[NP], X2[NP], Y2[NP], S[NP], TB[NP], QB[NP];
-	int H[C];
+	typedef int hvec_t __attribute__((ext_vector_type(C)));
+	typedef uint32_t pvec_t __attribute__((ext_vector_type(NP)));
+	pvec_t U, V, X, Y, X2, Y2, S, TB, QB;
+	hvec_t H;                                              // (vectors: a wave-uniform index into them is an indirect register access, not a chain of compares)
 	auto take_cells = [&](int tn, int r) {                    // the arrays' initial values; the target's codes; the query window of step r
 #pragma unroll
 		for (int k = 0; k < NP; ++k) U[k] = V[k] = K.iuv, X[k] = K.ix, Y[k] = K.iy, X2[k] = K.ix2, Y2[k] = K.iy2, S[k] = K.is;
@@ -1829,16 +1832,17 @@ __device__ __attribute__((noinline)) void ksw_wp(int qlen, int tlen, const uint8
 	int t0 = -16 + ((lane * C + 16) & M);
 	take_cells(t0, 0);
 	// one cell's value out of a packed array: lane and pair are wave-uniform
-	auto cell_value = [&](const uint32_t (&A)[NP], int t) -> int {
+	auto cell_value = [&](const pvec_t &A, int t) -> int {
 		const int L = (t & M) / C, kk = (t & CB) >> 1;
-		uint32_t v = 0;
-#pragma unroll
-		for (int k = 0; k < NP; ++k) if (k == kk) v = (uint32_t)__builtin_amdgcn_readlane((int)A[k], L);
+		const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)A[kk], L);
 		return kpk::value_of(v, t & 1);
 	};
 	int last_st = -1, last_en = -1, H0 = 0, last_H0_t = 0, p_st0 = 0;
 	const int n_r = qlen + tlen - 1;
+	WG_T(tm1);
+	int r_done = 0;
 	for (int r = 0; r < n_r; ++r) {
+		r_done = r;
 		int st = 0, en = tlen - 1;
 		if (st < r - qlen + 1) st = r - qlen + 1;
 		if (en > r) en = r;
@@ -1875,9 +1879,7 @@ __device__ __attribute__((noinline)) void ksw_wp(int qlen, int tlen, const uint8
 			const int kk = (r & CB) >> 1;
 			const uint32_t m = lane == (r & M) / C ? ((r & 1) ? 0xffff0000u : 0x0000ffffu) : 0u;
 			const uint32_t ue = kpk::lane(v_edge, 0);
-#pragma unroll
-			for (int k = 0; k < NP; ++k)
-				if (k == kk) Y[k] = kpk::bitsel(m, K.iy, Y[k]), Y2[k] = kpk::bitsel(m, K.iy2, Y2[k]), U[k] = kpk::bitsel(m, ue, U[k]);
+			Y[kk] = kpk::bitsel(m, K.iy, Y[kk]), Y2[kk] = kpk::bitsel(m, K.iy2, Y2[kk]), U[kk] = kpk::bitsel(m, ue, U[kk]);
 		}
 		// ---- scores, fresh on [st0, lim) only: both ends share their offset in a block of C cells (lim - st0 is a multiple
 		// of 16), so a lane's mask is one of {none, all, cells >= oc, cells < oc} of ONE wave-uniform pattern
@@ -1899,7 +1901,9 @@ __device__ __attribute__((noinline)) void ksw_wp(int qlen, int tlen, const uint8
 #pragma unroll
 			for (int k = NP - 1; k >= 0; --k) {                   // from the top: [k - 1] is still old
 				const uint32_t xb = kpk::shift16(X[k], k ? X[k - 1] : nbX), vb = kpk::shift16(V[k], k ? V[k - 1] : nbV), x2b = kpk::shift16(X2[k], k ? X2[k - 1] : nbX2);
-				d[k] = kpk::cell_pair<RIGHT>(K, xb, vb, x2b, S[k], U[k], V[k], X[k], Y[k], X2[k], Y2[k]);
+				uint32_t cu = U[k], cv = V[k], cx = X[k], cy = Y[k], cx2 = X2[k], cy2 = Y2[k];
+				d[k] = kpk::cell_pair<RIGHT>(K, xb, vb, x2b, S[k], cu, cv, cx, cy, cx2, cy2);
+				U[k] = cu, V[k] = cv, X[k] = cx, Y[k] = cy, X2[k] = cx2, Y2[k] = cy2;
 			}
 			uint32_t dw[C / 4];
 #pragma unroll
@@ -1917,19 +1921,13 @@ __device__ __attribute__((noinline)) void ksw_wp(int qlen, int tlen, const uint8
 				// stays near WP_NEG; a cell that has just fallen below st0 is sent back there, so the maximum over all cells
 				// of the wave is the maximum over [st0, en0].
 				const int ce = en0 & CB, Le = (en0 & M) / C;
-				int he = 0;
-#pragma unroll
-				for (int c = 0; c < C; ++c) if (c == ce) he = (c ? H[c > 0 ? c - 1 : 0] : nbH) + kpk::value_of(U[c >> 1], c & 1);
+				const int he = (ce ? H[(ce - 1) & CB] : nbH) + kpk::value_of(U[ce >> 1], ce & 1);
 #pragma unroll
 				for (int c = 0; c < C; ++c) H[c] += kpk::value_of(V[c >> 1], c & 1);
-				if (en0 > 0) {
-#pragma unroll
-					for (int c = 0; c < C; ++c) if (c == ce) H[c] = lane == Le ? he : H[c];
-				}
+				if (en0 > 0) H[ce] = lane == Le ? he : H[ce];
 				if (st0 > p_st0) {
 					const int cp = (st0 - 1) & CB, Lp = ((st0 - 1) & M) / C;
-#pragma unroll
-					for (int c = 0; c < C; ++c) if (c == cp) H[c] = lane == Lp ? WP_NEG : H[c];
+					H[cp] = lane == Lp ? WP_NEG : H[cp];
 				}
 				int tm = H[0];
 #pragma unroll
@@ -1957,9 +1955,7 @@ __device__ __attribute__((noinline)) void ksw_wp(int qlen, int tlen, const uint8
 			}
 			if (r - st0 == qlen - 1) {
 				const int cs = st0 & CB, Ls = (st0 & M) / C;
-				int hs = 0;
-#pragma unroll
-				for (int c = 0; c < C; ++c) if (c == cs) hs = __builtin_amdgcn_readlane(H[c], Ls);
+				const int hs = __builtin_amdgcn_readlane(H[cs], Ls);
 				if (hs > z_mqe) z_mqe = hs, z_mqe_t = st0;
 			}
 			// ksw_apply_zdrop
@@ -1971,8 +1967,7 @@ __device__ __attribute__((noinline)) void ksw_wp(int qlen, int tlen, const uint8
 			}
 			if (r == qlen + tlen - 2 && en0 == tlen - 1) {
 				const int cs = (tlen - 1) & CB, Ls = ((tlen - 1) & M) / C;
-#pragma unroll
-				for (int c = 0; c < C; ++c) if (c == cs) z_score = __builtin_amdgcn_readlane(H[c], Ls);
+				z_score = __builtin_amdgcn_readlane(H[cs], Ls);
 			}
 		} else {
 			if (r > 0) {
@@ -1991,6 +1986,8 @@ __device__ __attribute__((noinline)) void ksw_wp(int qlen, int tlen, const uint8
 		last_st = st, last_en = en, p_st0 = st0;
 	}
 	__syncthreads();                                          // the direction codes are written; the query's LDS is free
+	WG_T(tm2);
+	(void)r_done;
 	int i0 = -1, j0 = -1;
 	if (!z_zdropped && !(flag & EZ_EXTZ_ONLY)) i0 = tlen - 1, j0 = qlen - 1;
 	else if (!z_zdropped && (flag & EZ_EXTZ_ONLY) && z_mqe + end_bonus > z_max) z_reach_end = 1, i0 = z_mqe_t, j0 = qlen - 1;
@@ -1998,6 +1995,8 @@ __device__ __attribute__((noinline)) void ksw_wp(int qlen, int tlen, const uint8
 	int n_cigar = 0;
 	if (i0 >= 0 && j0 >= 0) n_cigar = walk_wg<1, PP, CP, RIGHT ? 2 : 1>(qlen, tlen, wl, wr, ncol, p, cig, i0, j0, flag, sq, bc);
 	n_cigar = wg_bcast0<1>(n_cigar);
+	WG_T(tm3);
+	WG_ADD(0, tm1 - tm0); WG_ADD(1, tm2 - tm1); WG_ADD(2, tm3 - tm2); WG_ADD(3, 1); WG_ADD(4, r_done);
 	ez_out.max = z_max, ez_out.zdropped = z_zdropped, ez_out.max_q = z_max_q, ez_out.max_t = z_max_t, ez_out.mqe = z_mqe, ez_out.mqe_t = z_mqe_t;
 	ez_out.score = z_score, ez_out.reach_end = z_reach_end, ez_out.n_cigar = n_cigar;
 	st_order<false, 1>();
@@ -2088,14 +2087,13 @@ __host__ __device__ __forceinline__ AlignWs align_ws(long long state_max, long l
 // regime 1: this launch only works when the pass has at most `regime_n` calls, regime 2: only when it has more -- the long
 // calls are launched in both forms (few calls: eight waves with two cells a thread, every call as fast as it goes; many: four waves with
 // four cells a thread, four times as many side by side), and the count is only known on the device.
-template <int NW, int C = 0>
-__global__ __launch_bounds__(64 * NW) void mnc_dp_align(Batch B, uint8_t *ws_all, long long state_max, long long p_max, long long cig_max,
-                                                   int lds_bytes, int lds_p, int lds_cig, int big_pass, int regime = 0, int regime_n = 0)
+// one queue of calls (`big_pass`) on this workgroup's workspace slot `ws`
+template <int NW, int C>
+__device__ __forceinline__ void dp_align_queue(const Batch &B, uint8_t *smem, uint8_t *ws, long long state_max, long long p_max, long long cig_max,
+                                               int lds_bytes, int lds_p, int lds_cig, int big_pass, int regime, int regime_n)
 {
-	extern __shared__ __align__(16) uint8_t smem[];
 	const int lane = threadIdx.x;
 	const AlignWs W = align_ws(state_max, p_max, cig_max);
-	uint8_t *ws = ws_all + (size_t)blockIdx.x * W.total;
 	const int sc_mch = B.sc_a, sc_mis = -B.sc_b, sc_N = -B.sc_ambi;
 	// pass 0: the segments of the round that are neither large nor another kernel's and fit the LDS
 	// layout; 3: those that do not; 1: the large ones; 5: the few largest; 2: what the banded kernels handed back (4: those
@@ -2106,7 +2104,19 @@ __global__ __launch_bounds__(64 * NW) void mnc_dp_align(Batch B, uint8_t *ws_all
 	if ((regime == 1 && n_items > (unsigned long long)regime_n) || (regime == 2 && n_items <= (unsigned long long)regime_n)) return;   // the other form's
 	for (;;) {
 		unsigned long long qi = 0;
-		if (lane == 0) qi = atomicAdd(&B.dp_ctr[ctr_q], 1ULL);
+		if (lane == 0) {
+			if (big_pass == 4) {
+				// this queue is drained twice -- inside the window (what the long kernels have handed back by then) and behind
+				// its join (the rest): a claim that fails must leave the counter at the calls really taken
+				unsigned long long cur = atomicAdd(&B.dp_ctr[ctr_q], 0ULL);
+				for (;;) {
+					if (cur >= n_items) { qi = n_items; break; }
+					const unsigned long long old = atomicCAS(&B.dp_ctr[ctr_q], cur, cur + 1ULL);
+					if (old == cur) { qi = cur; break; }
+					cur = old;
+				}
+			} else qi = atomicAdd(&B.dp_ctr[ctr_q], 1ULL);
+		}
 		qi = wg_bcast0_u64<NW>(qi);
 		if (qi >= n_items) break;                              // every wave reaches this: the queue is finite
 		const long long si = big_pass == 0 ? (long long)B.gen_list[qi] : big_pass == 1 ? (long long)B.big_list[qi] : big_pass == 3 ? (long long)B.mid_list[qi] : big_pass == 4 ? (long long)B.bigfb_list[qi] : big_pass == 5 ? (long long)B.huge_list[qi] : (long long)B.fill_fb[qi];
@@ -2228,6 +2238,34 @@ __global__ __launch_bounds__(64 * NW) void mnc_dp_align(Batch B, uint8_t *ws_all
 		}
 		st_order<false, NW>();
 	}
+}
+
+template <int NW, int C = 0>
+__global__ __launch_bounds__(64 * NW) void mnc_dp_align(Batch B, uint8_t *ws_all, long long state_max, long long p_max, long long cig_max,
+                                                   int lds_bytes, int lds_p, int lds_cig, int big_pass, int regime = 0, int regime_n = 0)
+{
+	extern __shared__ __align__(16) uint8_t smem[];
+	const AlignWs W = align_ws(state_max, p_max, cig_max);
+	dp_align_queue<NW, C>(B, smem, ws_all + (size_t)blockIdx.x * W.total, state_max, p_max, cig_max, lds_bytes, lds_p, lds_cig, big_pass, regime, regime_n);
+}
+
+// The long passes (1: large workspace, 3: small workspace but not LDS, 5: the few largest) as ONE launch of one-wave
+// workgroups that stay until all three queues are empty (round 5).  As three launches one behind the other on their
+// stream, the second and third found the chip taken by the persistent workgroups of the gap-filling tiers -- launched
+// meanwhile -- and their waves got on a SIMD only as those retired.  A workgroup owns a workspace slot of one class and
+// takes every call its slot holds: the few with the largest slots first those calls, then the large ones, then the rest.
+struct LongWs { uint8_t *ws[3]; long long state[3], p[3], cig[3]; int n_wg[3]; };      // classes: 0 the largest slots, 1 large, 2 small
+template <int C>
+__global__ __launch_bounds__(64) void mnc_dp_align_long(Batch B, LongWs L, int lds_bytes)
+{
+	extern __shared__ __align__(16) uint8_t smem[];
+	int cls = 0, idx = (int)blockIdx.x;
+	while (cls < 2 && idx >= L.n_wg[cls]) idx -= L.n_wg[cls], ++cls;
+	const AlignWs W = align_ws(L.state[cls], L.p[cls], L.cig[cls]);
+	uint8_t *ws = L.ws[cls] + (size_t)idx * W.total;
+	if (cls == 0) dp_align_queue<1, C>(B, smem, ws, L.state[cls], L.p[cls], L.cig[cls], lds_bytes, 0, 0, 5, 0, 0);
+	if (cls <= 1) dp_align_queue<1, C>(B, smem, ws, L.state[cls], L.p[cls], L.cig[cls], lds_bytes, 0, 0, 1, 0, 0);
+	dp_align_queue<1, C>(B, smem, ws, L.state[cls], L.p[cls], L.cig[cls], lds_bytes, 0, 0, 3, 0, 0);
 }
 
 // ---- wave-wide scans with DPP (GFX9: row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143).
@@ -3112,8 +3150,25 @@ int dp_align_prepare(int lds_bytes)
 	if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align<WIDE_NW, WIDE_C>), hipFuncAttributeMaxDynamicSharedMemorySize, wg_lds_bytes<WIDE_NW>(ALIGN_SEQ_WIDE));
 	if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, wg_lds_bytes<4>(ALIGN_SEQ_NARROW));
 	if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align<1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, wp_lds_bytes(ALIGN_SEQ_PACKED));
+	if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align_long<16>), hipFuncAttributeMaxDynamicSharedMemorySize, wp_lds_bytes(ALIGN_SEQ_PACKED));
 	if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return MNC_ERR_HIP; }
 	return MNC_OK;
+}
+// the long passes 5, 1, 3 as one launch of one-wave workgroups, each on a slot of its class (mnc_dp_align_long)
+bool dp_align_long_packed(const Batch &B)
+{
+	static const bool old_forms = getenv("MNC_KSW_FORMS") && !strcmp(getenv("MNC_KSW_FORMS"), "old");
+	return !old_forms && !(B.debug_route & (32 | 64 | 128 | 256 | 512));
+}
+void launch_dp_align_long(const Batch &B, uint8_t *ws_huge, int n_huge, long long st_huge, long long p_huge, long long cig_huge,
+                          uint8_t *ws_big, int n_big, long long st_big, long long p_big, long long cig_big,
+                          uint8_t *ws_small, int n_small, long long st_small, long long p_small, long long cig_small, hipStream_t st)
+{
+	LongWs L;
+	L.ws[0] = ws_huge, L.n_wg[0] = n_huge, L.state[0] = st_huge, L.p[0] = p_huge, L.cig[0] = cig_huge;
+	L.ws[1] = ws_big, L.n_wg[1] = n_big, L.state[1] = st_big, L.p[1] = p_big, L.cig[1] = cig_big;
+	L.ws[2] = ws_small, L.n_wg[2] = n_small, L.state[2] = st_small, L.p[2] = p_small, L.cig[2] = cig_small;
+	hipLaunchKernelGGL((mnc_dp_align_long<16>), dim3(n_huge + n_big + n_small), dim3(64), (size_t)wp_lds_bytes(ALIGN_SEQ_PACKED), st, B, L, ALIGN_SEQ_PACKED);
 }
 // `forms`: 3 both forms of a long pass (the call count picks one on the device), 1 | 4 the four-wave form alone for every call.
 void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max, long long p_max, long long cig_max,

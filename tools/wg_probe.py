@@ -34,3 +34,13 @@ for mode in modes:
         ref = key
     c = eng.counters()
     print(f"mode {mode:#x}: {dt * 1e3:8.2f} ms per batch; big {c['dp_literal_big']} mid {c['dp_literal_mid']} lext {c['dp_long_extensions']}; same as first: {key == ref}")
+    import ctypes
+    L = _capi.lib()
+    if hasattr(L, "mnc_debug_wg_cycles"):                       # a build with -DMNC_WG_TIMING (k_align.hip)
+        out = (ctypes.c_longlong * 8)()
+        L.mnc_debug_wg_cycles(out, 1)
+        eng.classify(bases, offsets, 0)
+        L.mnc_debug_wg_cycles(out, 0)
+        v = list(out)
+        print("   thread-0 cycles: lds %d, steps %d, walk %d, calls %d, anti-diagonals %d, test_zdrop %d, call set-up %d -> %.0f cycles per anti-diagonal, %.0f walk cycles per call" %
+              (v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[1] / max(v[4], 1), v[2] / max(v[3], 1)))
