@@ -2183,9 +2183,15 @@ __device__ __forceinline__ void dp_align_queue(const Batch &B, uint8_t *smem, ui
 					}
 					if constexpr (C > 0 && NW == 1) {
 						if (on_wg) {
-#define MNC_WP_CALL(R, A) ksw_wp<C, R, A>(g.qlen, g.tlen, (const uint8_t*)sf, (const uint8_t*)qr, (lds_u8p)smem, pbuf, cg, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, g.w, zdrop, end_bonus, flag, ez)
-							if (flag & EZ_RIGHT) { if (flag & EZ_APPROX_MAX) MNC_WP_CALL(true, true); else MNC_WP_CALL(true, false); }
-							else { if (flag & EZ_APPROX_MAX) MNC_WP_CALL(false, true); else MNC_WP_CALL(false, false); }
+							// as few cells a lane as hold the call's widest anti-diagonal: a step costs a lane's pairs plus a fixed
+							// part, and a lone call's length is its steps times that (4 cells: up to 193 wide, 8: 449, 16: 961)
+#define MNC_WP_CALL(CC, R, A) ksw_wp<CC, R, A>(g.qlen, g.tlen, (const uint8_t*)sf, (const uint8_t*)qr, (lds_u8p)smem, pbuf, cg, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, g.w, zdrop, end_bonus, flag, ez)
+#define MNC_WP_FLAGS(CC) do { if (flag & EZ_RIGHT) { if (flag & EZ_APPROX_MAX) MNC_WP_CALL(CC, true, true); else MNC_WP_CALL(CC, true, false); } \
+else { if (flag & EZ_APPROX_MAX) MNC_WP_CALL(CC, false, true); else MNC_WP_CALL(CC, false, false); } } while (0)
+							if (C >= 4 && wp_fits<4>(g.qlen, g.tlen, g.w, lds_bytes)) MNC_WP_FLAGS(4);
+							else if (C >= 8 && wp_fits<8>(g.qlen, g.tlen, g.w, lds_bytes)) MNC_WP_FLAGS(8);
+							else MNC_WP_FLAGS(C);
+#undef MNC_WP_FLAGS
 #undef MNC_WP_CALL
 							return;
 						}
