@@ -1924,10 +1924,12 @@ __device__ __attribute__((noinline)) void ksw_wp(int qlen, int tlen, const uint8
 				const int he = (ce ? H[(ce - 1) & CB] : nbH) + kpk::value_of(U[ce >> 1], ce & 1);
 #pragma unroll
 				for (int c = 0; c < C; ++c) H[c] += kpk::value_of(V[c >> 1], c & 1);
-				if (en0 > 0) H[ce] = lane == Le ? he : H[ce];
-				if (st0 > p_st0) {
+				{                                                    // (one unconditional insert each: a conditional one copies the vector)
+					const int hv = (en0 > 0 && lane == Le) ? he : H[ce];
+					H[ce] = hv;
 					const int cp = (st0 - 1) & CB, Lp = ((st0 - 1) & M) / C;
-					H[cp] = lane == Lp ? WP_NEG : H[cp];
+					const int pv = (st0 > p_st0 && lane == Lp) ? WP_NEG : H[cp];
+					H[cp] = pv;
 				}
 				int tm = H[0];
 #pragma unroll
@@ -1935,15 +1937,22 @@ __device__ __attribute__((noinline)) void ksw_wp(int qlen, int tlen, const uint8
 				max_H = wave_max_dpp(tm);
 				// where: only a new maximum or a possible Z-drop asks (ksw_apply_zdrop reads max_t in no other case)
 				if (max_H > z_max || (zdrop >= 0 && z_max - max_H > zdrop)) {
+					// every lane marks its cells that hold the maximum (one word); the few lanes that have any -- one, as a rule --
+					// are looked at one by one on the scalar unit, their cells ranked in the scan's order
 					const int en1 = st0 + (en0 - st0) / 4 * 4, base = st - 16;
-					unsigned best = 0xffffffffu;
+					unsigned cmask = 0;
 #pragma unroll
-					for (int c = 0; c < C; ++c) {
-						unsigned long long m = __ballot(H[c] == max_H);
-						while (m) {
-							const int L = __builtin_ctzll(m);
-							m &= m - 1;
-							const int t = base + ((L * C - base) & M) + c;
+					for (int c = 0; c < C; ++c) cmask |= H[c] == max_H ? 1u << c : 0u;
+					unsigned long long lanes = __ballot(cmask != 0);
+					unsigned best = 0xffffffffu;
+					while (lanes) {
+						const int L = __builtin_ctzll(lanes);
+						lanes &= lanes - 1;
+						unsigned cm = (unsigned)__builtin_amdgcn_readlane((int)cmask, L);
+						const int tl = base + ((L * C - base) & M);
+						while (cm) {
+							const int t = tl + __builtin_ctz(cm);
+							cm &= cm - 1;
 							const unsigned rank = t == en0 ? 0u : t < en1 ? 1u + ((unsigned)(t - st0) & 3u) * 0x1000000u + ((unsigned)(t - st0) >> 2) : 1u + 4u * 0x1000000u + (unsigned)(t - en1);
 							if (t >= st0 && t <= en0 && rank < best) best = rank, max_t = t;
 						}
