@@ -315,7 +315,14 @@ def main():
     # band cells of a wave (4 segments x 32) in `FILLP_INSTR_PER_STEP` vector instructions (its ISA): the
     # roof is that many cell updates/s.  Algorithmic work per launch = the anti-diagonals of the gap
     # fillings given to this tier (counter dp_fill_steps_t1) x 32 cells.
-    VALU_PEAK = 256 * 4 * 2.4e9 / 4
+    # Round 5: the roof in MEASURED cycles at the MEASURED clock -- tools/micro/valu_rate.hip reads s_memtime against the
+    # 100 MHz counter in every launch: 2 365 MHz while it ran, 4.15 cycles per v_pk_max_i16 / v_perm_b32 / DPP move with 8
+    # waves a SIMD (profiles/r05s_valu_issue_rates.json, r05s_valu_clock.json): 1 024 SIMDs x 2.365e9 / 4.15 = 5.84e11
+    # wave64 instructions/s.  (Rounds 2-4 priced against 2.4 GHz / 4 cycles = 6.144e11, 5 % above what the chip does:
+    # `frac` moved up by that much with no change in the kernel; `frac_at_r04_peak` is the old convention.)
+    VALU_CLOCK_HZ, VALU_CYCLES_PER_INSTR = 2.3648e9, 4.15
+    VALU_PEAK = 256 * 4 * VALU_CLOCK_HZ / VALU_CYCLES_PER_INSTR
+    VALU_PEAK_R04 = 256 * 4 * 2.4e9 / 4
     FILLP_INSTR_PER_STEP = 464 / 16                      # vector instructions of the unrolled 16-step block of the main loop (ISA listing of the round's last build: profiles/README.md; 480 before the second gap piece got its own frame, 521 with the first form of the drifting frame, 568 before it)
     VALU_PEAK_GUIDE = 256 * 4 * 2.4e9 / 2                # the guide's nominal 2-cycle wave64 issue (MI355X_MICROARCH.md), for comparison
     roofline_dp = None
@@ -336,6 +343,8 @@ def main():
             pass
         roofline_dp = {"bound": "valu", "kernel": "mnc_dp_fillp<16, true>", "achieved": round(ach, 2), "peak": round(peak, 1),
                        "unit": "Gcell/s", "frac": round(ach / peak, 4),
+                       "frac_at_r04_peak": round(ach / (VALU_PEAK_R04 / instr_per_cell / 1e9), 4),
+                       "peak_clock_mhz_measured": round(VALU_CLOCK_HZ / 1e6, 1), "peak_cycles_per_instruction_measured": VALU_CYCLES_PER_INSTR,
                        # the same launch against the guide's nominal issue rate (one wave64 instruction per 2 cycles and SIMD):
                        # the packed-16-bit / perm / DPP instructions this kernel is made of issue at half that (measured)
                        "frac_guide_nominal": round(ach / (VALU_PEAK_GUIDE / instr_per_cell / 1e9), 4),
@@ -347,8 +356,8 @@ def main():
                        # profiled build, all of the kernel -- walks and loads too) over what the chip can issue in the launch's time
                        "issue_rate_frac": round(fill_insts / t_s / VALU_PEAK, 4) if fill_insts else None,
                        "vector_instructions_per_launch": int(fill_insts) if fill_insts else None,
-                       "bound_note": "int16 pair arithmetic on the vector ALU: the roof is the VALU issue rate (6.144e11 wave64 "
-                                     "instructions/s, measured: profiles/r02_valu_issue_rates.json), not HBM (the kernel writes 1 byte per cell: "
+                       "bound_note": "int16 pair arithmetic on the vector ALU: the roof is the VALU issue rate (5.84e11 wave64 "
+                                     "instructions/s = 1 024 SIMDs x 2 365 MHz / 4.15 cycles, both measured: profiles/r05s_valu_issue_rates.json, r05s_valu_clock.json), not HBM (the kernel writes 1 byte per cell: "
                                      f"{cells / t_s / 1e9:.0f} GB/s) and not MFMA",
                        # the same launch against the HBM roof, for comparison with the contract's "hbm" bound: algorithmic
                        # bytes = one direction byte written per band cell

@@ -827,10 +827,11 @@ static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream
 	auto long_passes = [&](hipStream_t sl) {
 		if (dp_align_long_packed(B)) {                          // round 5: the three passes as one launch of one-wave workgroups (packed pairs in registers)
 			// (a micro-batch has a handful of such calls: a launch of thousands of workgroups that find nothing costs it more
-			// than the calls themselves)
+			// than the calls themselves: workgroups by the batch's reads -- a read rarely has more than two such calls)
+			const int n_big = std::min<int>(DP_WG_BIG, std::max<int>(64, (int)B.n_reads / 2)), n_mid = std::min<int>(DP_WG_MID, std::max<int>(128, (int)B.n_reads));
 			launch_dp_align_long(B, e->ws->dp_ws_huge.as<uint8_t>(), DP_WG_HUGE, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE,
-			                     e->ws->dp_ws_big.as<uint8_t>(), small_batch ? 64 : DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG,
-			                     e->ws->dp_ws_mid.as<uint8_t>(), small_batch ? 128 : DP_WG_MID, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, sl);
+			                     e->ws->dp_ws_big.as<uint8_t>(), n_big, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG,
+			                     e->ws->dp_ws_mid.as<uint8_t>(), n_mid, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, sl);
 			return;
 		}
 		const int forms_long = small_batch || e->prev_wide_calls > 0 ? 3 : 1, forms_mid = small_batch ? 3 : 1;
@@ -841,13 +842,13 @@ static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream
 	const bool packed_long = dp_align_long_packed(B);
 	if (!serial) {
 		if (packed_long || !small_batch) long_passes(s3);
-		launch_dp_lext(B, B.lext_list, 62, 63, B.fill_fb, 12, e->ws->lext_p.as<uint8_t>(), small_batch ? 256 : DP_WG_LEXT, s4);
-		launch_dp_lfill(B, B.lfill_list, 31, 61, B.fill_fb, 12, e->ws->lfill_p.as<uint8_t>(), small_batch ? 512 : DP_WG_LFILL, s2);
+		launch_dp_lext(B, B.lext_list, 62, 63, B.fill_fb, 12, e->ws->lext_p.as<uint8_t>(), std::min<int>(DP_WG_LEXT, std::max<int>(256, (int)B.n_reads)), s4);
+		launch_dp_lfill(B, B.lfill_list, 31, 61, B.fill_fb, 12, e->ws->lfill_p.as<uint8_t>(), std::min<int>(DP_WG_LFILL, std::max<int>(512, (int)B.n_reads * 2)), s2);
 		// what the two have handed back for the large workspace (a long extension whose Z-drop may fire is one literal
 		// call of thousands of anti-diagonals): aligned now, beside the tiers, not behind the window's join
 		(void)hipEventRecord(e->ev_lfill, s2);
 		(void)hipStreamWaitEvent(s4, e->ev_lfill, 0);
-		launch_dp_align(B, e->ws->dp_ws_bigfb.as<uint8_t>(), small_batch ? 32 : DP_WG_BIGFB, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 4, s4);
+		launch_dp_align(B, e->ws->dp_ws_bigfb.as<uint8_t>(), std::min<int>(DP_WG_BIGFB, std::max<int>(32, (int)B.n_reads / 8)), DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 4, s4);
 	}
 	mark(MNC_STAGE_DP_FILL_T1, 0);
 	launch_dp_fill(B, 32, B.fill_list1, 10, 13, B.fill_list_mid, 30, B.fill_fb, 12, e->ws->fill_p.as<uint8_t>(), e->ws->fill_cig.as<uint32_t>(), DP_WG_FILL, s0);

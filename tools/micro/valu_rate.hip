@@ -1,5 +1,8 @@
 // Issue rate of the vector instructions the alignment kernels are made of, on gfx950: cycles per wave64
 // instruction and SIMD with 1, 2, 4, 8 waves per SIMD.  hipcc --offload-arch=gfx950 -O3 valu_rate.hip -o valu_rate
+// Round 5: the shader clock is READ, not assumed -- wave 0 of every launch takes s_memtime (shader cycles) and
+// s_memrealtime (the constant 100 MHz counter) at both ends; the rows are in measured cycles, "clock_mhz" is what the
+// launches ran at, and "at_2p4_ghz" repeats the figures of the earlier rounds' convention (time x 2.4 GHz).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -7,8 +10,9 @@
 
 #define REP16(x) x x x x x x x x x x x x x x x x
 template <int OP>
-__global__ __launch_bounds__(64) void k(uint32_t *out, int iters, uint32_t seed)
+__global__ __launch_bounds__(64) void k(uint32_t *out, int iters, uint32_t seed, unsigned long long *clk)
 {
+	const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
 	uint32_t a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
 	const uint32_t b = seed * 2654435761u | 0x00010001u;
 	for (int i = 0; i < iters; ++i) {
@@ -27,23 +31,33 @@ __global__ __launch_bounds__(64) void k(uint32_t *out, int iters, uint32_t seed)
 		if (OP == 11) { REP16(ONE("v_pk_max_f16 %0, %0, %8\n v_pk_max_f16 %1, %1, %8\n v_pk_max_f16 %2, %2, %8\n v_pk_max_f16 %3, %3, %8\n v_pk_max_f16 %4, %4, %8\n v_pk_max_f16 %5, %5, %8\n v_pk_max_f16 %6, %6, %8\n v_pk_max_f16 %7, %7, %8")) }
 	}
 	out[blockIdx.x * 64 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+	if (blockIdx.x == 0 && threadIdx.x == 0) clk[0] = __builtin_readcyclecounter() - c0, clk[1] = wall_clock64() - w0;
 }
 
+static double g_mhz_sum = 0, g_cyc2p4[16][4];
+static int g_mhz_n = 0;
 template <int OP> double run(uint32_t *d, int waves_per_simd, int iters)
 {
+	static unsigned long long *clk = nullptr;
+	if (!clk) hipHostMalloc((void**)&clk, 16, hipHostMallocDefault);
 	const int n_wg = 256 * 4 * waves_per_simd;
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0), hipEventCreate(&e1);
-	hipLaunchKernelGGL(k<OP>, dim3(n_wg), dim3(64), 0, 0, d, 10, 1u);
+	hipLaunchKernelGGL(k<OP>, dim3(n_wg), dim3(64), 0, 0, d, 10, 1u, clk);
 	hipDeviceSynchronize();
 	hipEventRecord(e0, 0);
-	hipLaunchKernelGGL(k<OP>, dim3(n_wg), dim3(64), 0, 0, d, iters, 1u);
+	hipLaunchKernelGGL(k<OP>, dim3(n_wg), dim3(64), 0, 0, d, iters, 1u, clk);
 	hipEventRecord(e1, 0);
 	hipEventSynchronize(e1);
 	float ms = 0;
 	hipEventElapsedTime(&ms, e0, e1);
 	const double instr_per_simd = (double)waves_per_simd * iters * 16 * 8;
-	return ms * 1e-3 * 2.4e9 / instr_per_simd;            // cycles per wave64 instruction and SIMD, at 2.4 GHz
+	hipDeviceSynchronize();
+	const double mhz = clk[1] ? (double)clk[0] / (double)clk[1] * 100.0 : 0;       // shader cycles per tick of the 100 MHz counter
+	g_mhz_sum += mhz, ++g_mhz_n;
+	const int wi = waves_per_simd == 1 ? 0 : waves_per_simd == 2 ? 1 : waves_per_simd == 4 ? 2 : 3;
+	g_cyc2p4[OP][wi] = ms * 1e-3 * 2.4e9 / instr_per_simd;
+	return ms * 1e-3 * mhz * 1e6 / instr_per_simd;        // cycles per wave64 instruction and SIMD, at the clock the launch ran at
 }
 
 int main()
@@ -55,5 +69,7 @@ int main()
 #define ROW(OP) printf(" \"%s\": {\"1\": %.2f, \"2\": %.2f, \"4\": %.2f, \"8\": %.2f}%s\n", names[OP], run<OP>(d, 1, 4000), run<OP>(d, 2, 4000), run<OP>(d, 4, 2000), run<OP>(d, 8, 1000), OP == 11 ? "" : ",");
 	ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(5) ROW(6) ROW(7) ROW(8) ROW(9) ROW(10) ROW(11)
 	printf("}\n");
+	fprintf(stderr, "{\"clock_mhz\": %.1f, \"at_2p4_ghz\": {\"v_pk_max_i16\": {\"1\": %.2f, \"8\": %.2f}, \"v_perm_b32\": {\"1\": %.2f, \"8\": %.2f}, \"v_add_u32\": {\"1\": %.2f, \"8\": %.2f}}}\n",
+	        g_mhz_sum / (g_mhz_n ? g_mhz_n : 1), g_cyc2p4[1][0], g_cyc2p4[1][3], g_cyc2p4[4][0], g_cyc2p4[4][3], g_cyc2p4[0][0], g_cyc2p4[0][3]);
 	return 0;
 }
