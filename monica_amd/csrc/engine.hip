@@ -86,7 +86,7 @@ constexpr int DP_WG_FILL = MNC_DP_WG_FILL, DP_WG_EXT = MNC_DP_WG_EXT, DP_WG_STIT
 // workspace classes of the alignment kernel: a normal slot per workgroup, a few large ones
 constexpr int DP_LDS_BYTES = 16 * 1024;
 constexpr int DP_LDS0_STATE = 4 * 1024, DP_LDS0_P = 10 * 1024, DP_LDS0_CIG = 256;   // pass 0: 15 KB per workgroup
-constexpr int DP_WG_SMALL = 2048, DP_WG_BIG = 768, DP_WG_HUGE = 8, DP_WG_MID = 1536, DP_WG_LFILL = 4096, DP_WG_LEXT = 2048, DP_WG_BIGFB = 256;   // (BIGFB: large slots of pass 4's round inside the window, beside pass 1's)
+constexpr int DP_WG_SMALL = 2048, DP_WG_BIG = 768, DP_WG_HUGE = 8, DP_WG_MID = 1536, DP_WG_LFILL = 4096, DP_WG_LEXT = 2048, DP_WG_BIGFB = 512;   // (BIGFB: large slots of pass 4's round inside the window, beside pass 1's)
 constexpr long long DP_STATE_SMALL = 96 * 1024, DP_P_SMALL = 1 << 20, DP_CIG_SMALL = 4096;
 constexpr long long DP_STATE_BIG = 13 * 32768, DP_P_BIG = 8LL << 20, DP_CIG_BIG = 65536;       // 768 slots of 9 MB: any extension (max_gap 5000 on both sides: 7.7 MB of direction bytes)
 constexpr long long DP_STATE_HUGE = 13 * 32768, DP_P_HUGE = 256LL << 20, DP_CIG_HUGE = 65536;   // and 8 of 257 MB for anything up to max_sw_mat
@@ -881,7 +881,9 @@ static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream
 static void align_rest(const Batch &B, mnc_engine *e, hipStream_t st)
 {
 	launch_dp_align(B, e->ws->dp_ws.as<uint8_t>(), DP_WG_SMALL, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, 0, 2, st);
-	launch_dp_align(B, e->ws->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 4, st);
+	// (pass 4 has run inside the window on what the long kernels handed back -- all of it, as a rule: this second round
+	// goes on where that one stopped, with a launch sized for leftovers unless the older forms are asked for)
+	launch_dp_align(B, e->ws->dp_ws_big.as<uint8_t>(), dp_align_long_packed(B) ? 64 : DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 4, st);
 }
 
 // ---------------------------------------------------------------- one batch, device-resident
