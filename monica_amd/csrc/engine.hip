@@ -883,7 +883,7 @@ static void align_rest(const Batch &B, mnc_engine *e, hipStream_t st)
 	launch_dp_align(B, e->ws->dp_ws.as<uint8_t>(), DP_WG_SMALL, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, 0, 2, st);
 	// (pass 4 has run inside the window on what the long kernels handed back -- all of it, as a rule: this second round
 	// goes on where that one stopped, with a launch sized for leftovers unless the older forms are asked for)
-	launch_dp_align(B, e->ws->dp_ws_big.as<uint8_t>(), dp_align_long_packed(B) ? 64 : DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 4, st);
+	launch_dp_align(B, e->ws->dp_ws_big.as<uint8_t>(), (dp_align_long_packed(B) && !(e->debug & 0x10000)) ? 64 : DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 4, st);
 }
 
 // ---------------------------------------------------------------- one batch, device-resident
