@@ -57,10 +57,11 @@ FOCUS_FILES_FOLDER = "focus"
 
 # reads / bases per C-ABI call: a sample file is worked through in batches of this size, three at a time (one being
 # parsed, one on the GPU, one being written out)
-# (50 000 since round 5: over three rounds' sweeps -- profiles/r04y2_, r04zz_, r05z_files_sweep.txt -- the second call on a 1 GB
-# file ran at 0.74-0.82 M reads/s with it and at 0.59-0.82 M with 25 000; the first batch of a file is a quarter of it)
-BATCH_READS = int(os.environ.get("MONICA_AMD_BATCH_READS", "50000"))
-BATCH_BASES = min(1 << 28, BATCH_READS * 6000)
+# (12 500 since round 5: the second call on a 1 GB file over four sweeps -- profiles/r04y2_, r04zz_, r05z_, r05v_files_sweep.txt --
+# ran at 0.68 / 0.74 / 0.82 / 0.84 M reads/s with it, at 0.82 / 0.60 / 0.59 / 0.61 M with 25 000 and at 0.58-0.64 M with true
+# 50 000-read batches: the stages get cheaper per gigabyte as batches grow, the pipeline's fill and drain cost more than that)
+BATCH_READS = int(os.environ.get("MONICA_AMD_BATCH_READS", "12500"))
+BATCH_BASES = min(1 << 27, BATCH_READS * 6000)
 DEFAULT_MAX_WORKERS = int(os.environ.get("MONICA_AMD_MAX_WORKERS", "8"))   # `n_threads=None`: at most this many samples in flight
 TIMINGS = {}                      # per sample name: seconds spent per phase of aligner() (diagnostics)
 
