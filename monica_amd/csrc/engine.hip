@@ -825,6 +825,14 @@ static void align_round(const Batch &B, mnc_engine *e, hipStream_t s0, hipStream
 	// (profiles/r05h_timeline.txt: long gaps 22 ms, then long extensions 23 ms at 16 % errors).
 	const bool small_batch = B.n_reads < 4096;
 	auto long_passes = [&](hipStream_t sl) {
+		if (dp_align_long_packed(B) && small_batch) {
+			// a micro-batch has a handful of long calls and waits for the longest: each pass in both packed forms, the
+			// pass's call count picks one on the device -- four waves on a call for up to 64 calls, one wave a call for more
+			launch_dp_align(B, e->ws->dp_ws_big.as<uint8_t>(), DP_WG_BIG, DP_STATE_BIG, DP_P_BIG, DP_CIG_BIG, DP_LDS_BYTES, 0, 0, 1, sl);
+			launch_dp_align(B, e->ws->dp_ws_mid.as<uint8_t>(), DP_WG_MID, DP_STATE_SMALL, DP_P_SMALL, DP_CIG_SMALL, DP_LDS_BYTES, 0, 0, 3, sl);
+			launch_dp_align(B, e->ws->dp_ws_huge.as<uint8_t>(), DP_WG_HUGE, DP_STATE_HUGE, DP_P_HUGE, DP_CIG_HUGE, DP_LDS_BYTES, 0, 0, 5, sl);
+			return;
+		}
 		if (dp_align_long_packed(B)) {                          // round 5: the three passes as one launch of one-wave workgroups (packed pairs in registers)
 			// (a micro-batch has a handful of such calls: a launch of thousands of workgroups that find nothing costs it more
 			// than the calls themselves: workgroups by the batch's reads -- a read rarely has more than two such calls)

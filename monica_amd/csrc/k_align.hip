@@ -1761,21 +1761,22 @@ __device__ __attribute__((noinline)) void ksw_wg(int qlen, int tlen, const uint8
 //   small calls, with their registers (and twice / four times the waves a SIMD).
 // Calls with an ambiguous base, or scores outside kpk::params_fit, keep the forms above.
 constexpr int WP_NEG = -(1 << 26);                        // H of a cell no anti-diagonal has reached (ksw2: -2^30; only its sign and size matter)
-constexpr int wp_lds_bytes(int seq) { return 64 + (seq > WG_TILE * WG_TILE ? seq : WG_TILE * WG_TILE); }
-template <int C> __device__ __forceinline__ bool wp_fits(int qlen, int tlen, int w, int seq)
+constexpr int wp_lds_bytes(int seq, int nw = 1) { return (nw > 1 ? 256 : 64) + (seq > WG_TILE * WG_TILE ? seq : WG_TILE * WG_TILE); }
+template <int C, int NW = 1> __device__ __forceinline__ bool wp_fits(int qlen, int tlen, int w, int seq)
 {
 	if (w < 0) w = tlen > qlen ? tlen : qlen;
 	int width = qlen < tlen ? qlen : tlen;
 	if (w + 1 < width) width = w + 1;
-	return width + 30 + 16 + 17 <= 64 * C && (qlen + 15) / 16 * 16 + 32 <= seq;
+	return width + 30 + 16 + 17 <= 64 * NW * C && (qlen + 15) / 16 * 16 + 32 <= seq;
 }
 #define MNC_DPP_ROR1(v) __builtin_amdgcn_update_dpp(0, (v), 0x13C, 0xf, 0xf, false)      // wave_ror:1 -- lane i reads lane i - 1, lane 0 lane 63
 
-template <int C, bool RIGHT, bool APPROX, class PP, class CP>
+template <int C, bool RIGHT, bool APPROX, int NW, class PP, class CP>
 __device__ __attribute__((noinline)) void ksw_wp(int qlen, int tlen, const uint8_t *sf_g, const uint8_t *qr_g, lds_u8p lds, PP p, CP cig,
                                                  int q, int e, int q2, int e2, int sc_mch, int sc_mis, int w, int zdrop, int end_bonus, int flag, Ez &ez_out)
 {
-	constexpr int CW = 64 * C, M = CW - 1, NP = C / 2, CB = C - 1;
+	constexpr int CW = 64 * NW * C, M = CW - 1, NP = C / 2, CB = C - 1;
+	static_assert(NW == 1 || NW == 2 || NW == 4, "waves on one call: one, or one a SIMD");
 	static_assert(C == 4 || C == 8 || C == 16, "cells per lane: a divisor of 16, whole pairs");
 	{
 		auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
@@ -1785,9 +1786,19 @@ __device__ __attribute__((noinline)) void ksw_wp(int qlen, int tlen, const uint8
 		sf_g = unip(sf_g), qr_g = unip(qr_g), p = unip(p), cig = unip(cig);
 		lds = (lds_u8p)(unsigned)uni((int)(unsigned)(unsigned long long)lds);
 	}
-	const int lane = threadIdx.x;
+	// NW > 1 (round 5, for a pass with a handful of calls: a lone call's length is its steps times a wave's instructions a
+	// step): the call's cells over NW waves, thread `tid` of the workgroup where the one-wave form has lane `tid` -- cell t
+	// in thread (t mod 64 NW C) / C.  What crosses a wave's edge goes through LDS words and barriers that wait for LDS only:
+	// [1] the top cell of each wave's last lane, for the first lane of the next wave; [2] each wave's maximum and the four
+	// single cells ksw2's bookkeeping reads; [3] (when the maximum's position is asked for) each wave's best rank.  Every
+	// wave keeps ksw2's per-call state itself, from the same words: all take the same branches and meet at every barrier.
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	lds_i32p bc = (lds_i32p)lds;                              // 16 words for the walk
-	lds_u8p sq = (lds_u8p)(bc + 16);                          // the reversed query's codes; afterwards the walk's tile
+	lds_i32p xw = bc + 16;                                    // [NW][4] x, v, x2, H of the top cell of a wave's last lane
+	lds_i32p red = xw + 16;                                   // [NW] the waves' maxima; [NW][2] their best (rank, t)
+	lds_i32p one = red + 16;                                  // [4] H[st0], H[tlen - 1], v[last_H0_t], u[last_H0_t + 1]
+	lds_u8p sq = (lds_u8p)(bc + (NW > 1 ? 64 : 16));          // the reversed query's codes; afterwards the walk's tile
+#define MNC_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 	const kpk::Consts K = kpk::make_consts<RIGHT>(q, e, q2, e2, sc_mch, sc_mis);
 	int z_max = 0, z_zdropped = 0, z_max_q = -1, z_max_t = -1, z_mqe_t = -1, z_mqe = DP_NEG_INF, z_score = DP_NEG_INF, z_reach_end = 0;
 	const int qe = q + e;
@@ -1802,7 +1813,7 @@ __device__ __attribute__((noinline)) void ksw_wp(int qlen, int tlen, const uint8
 	const int T = (tlen + 15) / 16 * 16, Q = (qlen + 15) / 16 * 16 + 32;
 	WG_T(tm0);
 	__syncthreads();                                          // (the LDS may still hold the previous call's walk)
-	for (int i = lane; i < Q / 4; i += 64) reinterpret_cast<lds_u32p>(sq)[i] = reinterpret_cast<const uint32_t*>(qr_g)[i];
+	for (int i = tid; i < Q / 4; i += 64 * NW) reinterpret_cast<lds_u32p>(sq)[i] = reinterpret_cast<const uint32_t*>(qr_g)[i];
 	__syncthreads();
 
 	// ---- this lane's cells t0 .. t0 + C - 1, pair k = cells t0 + 2 k (low half), t0 + 2 k + 1 (high half)
@@ -1829,14 +1840,18 @@ __device__ __attribute__((noinline)) void ksw_wp(int qlen, int tlen, const uint8
 			QB[k] = (uint32_t)sq[i0] | (uint32_t)sq[i1] << 16;
 		}
 	};
-	int t0 = -16 + ((lane * C + 16) & M);
+	int t0 = -16 + ((tid * C + 16) & M);
 	take_cells(t0, 0);
 	// one cell's value out of a packed array: lane and pair are wave-uniform
-	auto cell_value = [&](const pvec_t &A, int t) -> int {
+	auto cell_value = [&](const pvec_t &A, int t) -> int {   // (one wave)
 		const int L = (t & M) / C, kk = (t & CB) >> 1;
 		const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)A[kk], L);
 		return kpk::value_of(v, t & 1);
 	};
+	auto cell_to_lds = [&](const pvec_t &A, int t, int slot) {   // (several waves: the owner writes, everybody reads behind the barrier)
+		if (tid == (t & M) / C) one[slot] = kpk::value_of(A[(t & CB) >> 1], t & 1);
+	};
+	auto lds_uniform = [&](lds_i32p ptr) { return __builtin_amdgcn_readfirstlane(*ptr); };
 	int last_st = -1, last_en = -1, H0 = 0, last_H0_t = 0, p_st0 = 0;
 	const int n_r = qlen + tlen - 1;
 	WG_T(tm1);
@@ -1853,9 +1868,21 @@ __device__ __attribute__((noinline)) void ksw_wp(int qlen, int tlen, const uint8
 		st = st / 16 * 16, en = (en + 16) / 16 * 16 - 1;
 		const int v_edge = r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
 		// ---- the cell below this lane's first, as the last step left it (its values in the HIGH halves)
+		if (NW > 1) {                                          // [1]
+			if (lane == 63) {
+				xw[wv * 4 + 0] = (int)X[NP - 1], xw[wv * 4 + 1] = (int)V[NP - 1], xw[wv * 4 + 2] = (int)X2[NP - 1];
+				if (!APPROX) xw[wv * 4 + 3] = H[C - 1];
+			}
+			MNC_LDS_BARRIER();
+		}
 		uint32_t nbX = (uint32_t)MNC_DPP_ROR1((int)X[NP - 1]), nbV = (uint32_t)MNC_DPP_ROR1((int)V[NP - 1]), nbX2 = (uint32_t)MNC_DPP_ROR1((int)X2[NP - 1]);
 		int nbH = 0;
 		if (!APPROX) nbH = MNC_DPP_ROR1(H[C - 1]);
+		if (NW > 1 && lane == 0) {
+			const int pw = (wv + NW - 1) & (NW - 1);
+			nbX = (uint32_t)xw[pw * 4 + 0], nbV = (uint32_t)xw[pw * 4 + 1], nbX2 = (uint32_t)xw[pw * 4 + 2];
+			if (!APPROX) nbH = xw[pw * 4 + 3];
+		}
 		// ---- the query window moves down one base; the window of cells moves up with st
 		if (r > 0) {
 			int qi = qlen - 1 - r + t0;
@@ -1867,7 +1894,7 @@ __device__ __attribute__((noinline)) void ksw_wp(int qlen, int tlen, const uint8
 		}
 		{
 			const int base = st - 16;
-			const int tn = base + ((lane * C - base) & M);
+			const int tn = base + ((tid * C - base) & M);
 			if (tn != t0) { t0 = tn; take_cells(tn, r); }
 		}
 		if (t0 == st) {                                        // ksw2's x1, x21, v1
@@ -1877,7 +1904,7 @@ __device__ __attribute__((noinline)) void ksw_wp(int qlen, int tlen, const uint8
 		}
 		if (en >= r) {                                         // y[r], y2[r], u[r]: the cell the virtual row enters at
 			const int kk = (r & CB) >> 1;
-			const uint32_t m = lane == (r & M) / C ? ((r & 1) ? 0xffff0000u : 0x0000ffffu) : 0u;
+			const uint32_t m = tid == (r & M) / C ? ((r & 1) ? 0xffff0000u : 0x0000ffffu) : 0u;
 			const uint32_t ue = kpk::lane(v_edge, 0);
 			Y[kk] = kpk::bitsel(m, K.iy, Y[kk]), Y2[kk] = kpk::bitsel(m, K.iy2, Y2[kk]), U[kk] = kpk::bitsel(m, ue, U[kk]);
 		}
@@ -1925,16 +1952,25 @@ __device__ __attribute__((noinline)) void ksw_wp(int qlen, int tlen, const uint8
 #pragma unroll
 				for (int c = 0; c < C; ++c) H[c] += kpk::value_of(V[c >> 1], c & 1);
 				{                                                    // (one unconditional insert each: a conditional one copies the vector)
-					const int hv = (en0 > 0 && lane == Le) ? he : H[ce];
+					const int hv = (en0 > 0 && tid == Le) ? he : H[ce];
 					H[ce] = hv;
 					const int cp = (st0 - 1) & CB, Lp = ((st0 - 1) & M) / C;
-					const int pv = (st0 > p_st0 && lane == Lp) ? WP_NEG : H[cp];
+					const int pv = (st0 > p_st0 && tid == Lp) ? WP_NEG : H[cp];
 					H[cp] = pv;
 				}
 				int tm = H[0];
 #pragma unroll
 				for (int c = 1; c < C; ++c) tm = tm > H[c] ? tm : H[c];
 				max_H = wave_max_dpp(tm);
+				if (NW > 1) {                                      // [2]
+					if (lane == 0) red[wv] = max_H;
+					if (tid == (st0 & M) / C) one[0] = H[st0 & CB];
+					if (tid == ((tlen - 1) & M) / C) one[1] = H[(tlen - 1) & CB];
+					MNC_LDS_BARRIER();
+					max_H = lds_uniform(red);
+#pragma unroll
+					for (int k = 1; k < NW; ++k) { const int o = lds_uniform(red + k); max_H = max_H > o ? max_H : o; }
+				}
 				// where: only a new maximum or a possible Z-drop asks (ksw_apply_zdrop reads max_t in no other case)
 				if (max_H > z_max || (zdrop >= 0 && z_max - max_H > zdrop)) {
 					// every lane marks its cells that hold the maximum (one word); the few lanes that have any -- one, as a rule --
@@ -1949,7 +1985,7 @@ __device__ __attribute__((noinline)) void ksw_wp(int qlen, int tlen, const uint8
 						const int L = __builtin_ctzll(lanes);
 						lanes &= lanes - 1;
 						unsigned cm = (unsigned)__builtin_amdgcn_readlane((int)cmask, L);
-						const int tl = base + ((L * C - base) & M);
+						const int tl = base + (((wv * 64 + L) * C - base) & M);
 						while (cm) {
 							const int t = tl + __builtin_ctz(cm);
 							cm &= cm - 1;
@@ -1957,14 +1993,28 @@ __device__ __attribute__((noinline)) void ksw_wp(int qlen, int tlen, const uint8
 							if (t >= st0 && t <= en0 && rank < best) best = rank, max_t = t;
 						}
 					}
+					if (NW > 1) {                                  // [3]
+						if (lane == 0) red[4 + wv * 2] = (int)best, red[5 + wv * 2] = max_t;
+						MNC_LDS_BARRIER();
+#pragma unroll
+						for (int k = 0; k < NW; ++k) {
+							const unsigned ob = (unsigned)lds_uniform(red + 4 + k * 2);
+							const int ot = lds_uniform(red + 5 + k * 2);
+							if (k == 0 || ob < best) best = ob, max_t = ot;
+						}
+					}
 				}
 			} else {
-				if (lane == 0) H[0] = kpk::value_of(V[0], 0) - qe;      // t0 == 0 there
-				max_H = __builtin_amdgcn_readlane(H[0], 0), max_t = 0;
+				if (tid == 0) H[0] = kpk::value_of(V[0], 0) - qe;       // t0 == 0 there
+				if (NW > 1) {
+					if (tid == 0) one[0] = H[0];
+					MNC_LDS_BARRIER();
+					max_H = lds_uniform(one), max_t = 0;
+				} else max_H = __builtin_amdgcn_readlane(H[0], 0), max_t = 0;
 			}
 			if (r - st0 == qlen - 1) {
 				const int cs = st0 & CB, Ls = (st0 & M) / C;
-				const int hs = __builtin_amdgcn_readlane(H[cs], Ls);
+				const int hs = NW > 1 ? lds_uniform(one) : __builtin_amdgcn_readlane(H[cs], Ls);
 				if (hs > z_mqe) z_mqe = hs, z_mqe_t = st0;
 			}
 			// ksw_apply_zdrop
@@ -1976,20 +2026,26 @@ __device__ __attribute__((noinline)) void ksw_wp(int qlen, int tlen, const uint8
 			}
 			if (r == qlen + tlen - 2 && en0 == tlen - 1) {
 				const int cs = (tlen - 1) & CB, Ls = ((tlen - 1) & M) / C;
-				z_score = __builtin_amdgcn_readlane(H[cs], Ls);
+				z_score = NW > 1 ? lds_uniform(one + 1) : __builtin_amdgcn_readlane(H[cs], Ls);
 			}
 		} else {
+			if (NW > 1) {                                          // [2]: v[last_H0_t], u[last_H0_t + 1] of this step
+				cell_to_lds(V, r > 0 ? last_H0_t : 0, 2), cell_to_lds(U, last_H0_t + 1, 3);
+				MNC_LDS_BARRIER();
+			}
+			auto v_at = [&](int t) { return NW > 1 ? lds_uniform(one + 2) : cell_value(V, t); };
+			auto u_at = [&](int t) { return NW > 1 ? lds_uniform(one + 3) : cell_value(U, t); };
 			if (r > 0) {
 				if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
-					const int d0 = cell_value(V, last_H0_t), d1 = cell_value(U, last_H0_t + 1);
+					const int d0 = v_at(last_H0_t), d1 = u_at(last_H0_t + 1);
 					if (d0 > d1) H0 += d0;
 					else H0 += d1, ++last_H0_t;
 				} else if (last_H0_t >= st0 && last_H0_t <= en0) {
-					H0 += cell_value(V, last_H0_t);
+					H0 += v_at(last_H0_t);
 				} else {
-					++last_H0_t, H0 += cell_value(U, last_H0_t);
+					++last_H0_t, H0 += u_at(last_H0_t);
 				}
-			} else H0 = cell_value(V, 0) - qe, last_H0_t = 0;
+			} else H0 = v_at(0) - qe, last_H0_t = 0;
 			if (r == qlen + tlen - 2 && en0 == tlen - 1) z_score = H0;
 		}
 		last_st = st, last_en = en, p_st0 = st0;
@@ -2002,13 +2058,14 @@ __device__ __attribute__((noinline)) void ksw_wp(int qlen, int tlen, const uint8
 	else if (!z_zdropped && (flag & EZ_EXTZ_ONLY) && z_mqe + end_bonus > z_max) z_reach_end = 1, i0 = z_mqe_t, j0 = qlen - 1;
 	else if (z_max_t >= 0 && z_max_q >= 0) i0 = z_max_t, j0 = z_max_q;
 	int n_cigar = 0;
-	if (i0 >= 0 && j0 >= 0) n_cigar = walk_wg<1, PP, CP, RIGHT ? 2 : 1>(qlen, tlen, wl, wr, ncol, p, cig, i0, j0, flag, sq, bc);
-	n_cigar = wg_bcast0<1>(n_cigar);
+	if (i0 >= 0 && j0 >= 0) n_cigar = walk_wg<NW, PP, CP, RIGHT ? 2 : 1>(qlen, tlen, wl, wr, ncol, p, cig, i0, j0, flag, sq, bc);
+	n_cigar = wg_bcast0<NW>(n_cigar);
 	WG_T(tm3);
 	WG_ADD(0, tm1 - tm0); WG_ADD(1, tm2 - tm1); WG_ADD(2, tm3 - tm2); WG_ADD(3, 1); WG_ADD(4, r_done);
 	ez_out.max = z_max, ez_out.zdropped = z_zdropped, ez_out.max_q = z_max_q, ez_out.max_t = z_max_t, ez_out.mqe = z_mqe, ez_out.mqe_t = z_mqe_t;
 	ez_out.score = z_score, ez_out.reach_end = z_reach_end, ez_out.n_cigar = n_cigar;
-	st_order<false, 1>();
+	st_order<false, NW>();
+#undef MNC_LDS_BARRIER
 }
 
 // mm_test_zdrop on a finished gap-filling CIGAR: 0 fine, 1 the score drops by more than zdrop, 2 and
@@ -2097,7 +2154,8 @@ __host__ __device__ __forceinline__ AlignWs align_ws(long long state_max, long l
 // calls are launched in both forms (few calls: eight waves with two cells a thread, every call as fast as it goes; many: four waves with
 // four cells a thread, four times as many side by side), and the count is only known on the device.
 // one queue of calls (`big_pass`) on this workgroup's workspace slot `ws`
-template <int NW, int C>
+// PK: the cells as packed 16-bit pairs in registers (ksw_wp: one wave a call, or NW waves on one call)
+template <int NW, int C, bool PK = (NW == 1 && C > 0)>
 __device__ __forceinline__ void dp_align_queue(const Batch &B, uint8_t *smem, uint8_t *ws, long long state_max, long long p_max, long long cig_max,
                                                int lds_bytes, int lds_p, int lds_cig, int big_pass, int regime, int regime_n)
 {
@@ -2143,7 +2201,7 @@ __device__ __forceinline__ void dp_align_queue(const Batch &B, uint8_t *smem, ui
 			int ncw = g.qlen < g.tlen ? g.qlen : g.tlen;
 			{ const int wb = g.w < 0 ? (g.tlen > g.qlen ? g.tlen : g.qlen) : g.w; ncw = ((ncw < wb + 1 ? ncw : wb + 1) + 15) / 16 + 1; }
 			const long long p_bytes = ((long long)(g.qlen + g.tlen - 1) * ncw + 1) * 16;
-			const bool in_lds = NW == 1 && C == 0 && 12 * T + Q <= lds_bytes;    // (one wave with C > 0: the packed form -- LDS holds the query and the walk's tile, the state is in registers, sequences and direction codes in the workspace)
+			const bool in_lds = NW == 1 && C == 0 && !PK && 12 * T + Q <= lds_bytes;    // (one wave with C > 0: the packed form -- LDS holds the query and the walk's tile, the state is in registers, sequences and direction codes in the workspace)
 			// small calls (the extensions of most reads) keep direction bytes and CIGAR in LDS as well
 			const bool all_lds = in_lds && p_bytes <= lds_p && g.qlen + g.tlen + 2 <= lds_cig;
 			if (big_pass == 0 && !all_lds) {                        // not for the small layout: pass 2 takes it
@@ -2177,29 +2235,41 @@ __device__ __forceinline__ void dp_align_queue(const Batch &B, uint8_t *smem, ui
 				// unless the call's anti-diagonals or sequences outgrow that form; debug_route bit 6: never (the workspace form
 				// on this many waves, for the tests)
 				bool on_wg = false;
-				if constexpr (C > 0 && NW > 1) on_wg = !(B.debug_route & 64) && wg_fits<NW, C>(g.qlen, g.tlen, g.w, lds_bytes);
+				if constexpr (C > 0 && !PK) on_wg = !(B.debug_route & 64) && wg_fits<NW, C>(g.qlen, g.tlen, g.w, lds_bytes);
 				// (the packed form: no ambiguous base in either sequence, scores that keep every intermediate inside int8)
-				if constexpr (C > 0 && NW == 1)
-					on_wg = !(B.debug_route & 64) && !__any(any_ambi) && wp_fits<C>(g.qlen, g.tlen, g.w, lds_bytes) &&
+				if constexpr (PK) {
+					if (NW > 1) {                                   // one flag for the workgroup: every wave takes the same form
+						__shared__ int s_ambi;
+						__syncthreads();
+						if (threadIdx.x == 0) s_ambi = 0;
+						__syncthreads();
+						if (any_ambi) s_ambi = 1;
+						__syncthreads();
+						any_ambi = s_ambi;
+					}
+					on_wg = !(B.debug_route & 64) && !__any(any_ambi) && wp_fits<C, NW>(g.qlen, g.tlen, g.w, lds_bytes) &&
 					        kpk::params_fit(B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, sc_N);
+				}
 				auto call = [&](int zdrop, int end_bonus, int flag) {
-					if constexpr (C > 0 && NW > 1) {
+					if constexpr (C > 0 && !PK) {
 						if (on_wg) {
 							ksw_wg<NW, C>(g.qlen, g.tlen, (const uint8_t*)sf, (const uint8_t*)qr, (lds_u8p)smem, lds_bytes, pbuf, cg, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2,
 							              sc_mch, sc_mis, sc_N, g.w, zdrop, end_bonus, flag, ez);
 							return;
 						}
 					}
-					if constexpr (C > 0 && NW == 1) {
+					if constexpr (PK) {
 						if (on_wg) {
 							// as few cells a lane as hold the call's widest anti-diagonal: a step costs a lane's pairs plus a fixed
 							// part, and a lone call's length is its steps times that (4 cells: up to 193 wide, 8: 449, 16: 961)
-#define MNC_WP_CALL(CC, R, A) ksw_wp<CC, R, A>(g.qlen, g.tlen, (const uint8_t*)sf, (const uint8_t*)qr, (lds_u8p)smem, pbuf, cg, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, g.w, zdrop, end_bonus, flag, ez)
+#define MNC_WP_CALL(CC, R, A) ksw_wp<CC, R, A, NW>(g.qlen, g.tlen, (const uint8_t*)sf, (const uint8_t*)qr, (lds_u8p)smem, pbuf, cg, B.gap_q, B.gap_e, B.gap_q2, B.gap_e2, sc_mch, sc_mis, g.w, zdrop, end_bonus, flag, ez)
 #define MNC_WP_FLAGS(CC) do { if (flag & EZ_RIGHT) { if (flag & EZ_APPROX_MAX) MNC_WP_CALL(CC, true, true); else MNC_WP_CALL(CC, true, false); } \
 else { if (flag & EZ_APPROX_MAX) MNC_WP_CALL(CC, false, true); else MNC_WP_CALL(CC, false, false); } } while (0)
-							if (C >= 4 && wp_fits<4>(g.qlen, g.tlen, g.w, lds_bytes)) MNC_WP_FLAGS(4);
-							else if (C >= 8 && wp_fits<8>(g.qlen, g.tlen, g.w, lds_bytes)) MNC_WP_FLAGS(8);
-							else MNC_WP_FLAGS(C);
+							if constexpr (NW == 1 && C == 16) {
+								if (wp_fits<4>(g.qlen, g.tlen, g.w, lds_bytes)) MNC_WP_FLAGS(4);
+								else if (wp_fits<8>(g.qlen, g.tlen, g.w, lds_bytes)) MNC_WP_FLAGS(8);
+								else MNC_WP_FLAGS(16);
+							} else MNC_WP_FLAGS(C);
 #undef MNC_WP_FLAGS
 #undef MNC_WP_CALL
 							return;
@@ -2255,13 +2325,13 @@ else { if (flag & EZ_APPROX_MAX) MNC_WP_CALL(CC, false, true); else MNC_WP_CALL(
 	}
 }
 
-template <int NW, int C = 0>
+template <int NW, int C = 0, bool PK = (NW == 1 && C > 0)>
 __global__ __launch_bounds__(64 * NW) void mnc_dp_align(Batch B, uint8_t *ws_all, long long state_max, long long p_max, long long cig_max,
                                                    int lds_bytes, int lds_p, int lds_cig, int big_pass, int regime = 0, int regime_n = 0)
 {
 	extern __shared__ __align__(16) uint8_t smem[];
 	const AlignWs W = align_ws(state_max, p_max, cig_max);
-	dp_align_queue<NW, C>(B, smem, ws_all + (size_t)blockIdx.x * W.total, state_max, p_max, cig_max, lds_bytes, lds_p, lds_cig, big_pass, regime, regime_n);
+	dp_align_queue<NW, C, PK>(B, smem, ws_all + (size_t)blockIdx.x * W.total, state_max, p_max, cig_max, lds_bytes, lds_p, lds_cig, big_pass, regime, regime_n);
 }
 
 // The long passes (1: large workspace, 3: small workspace but not LDS, 5: the few largest) as ONE launch of one-wave
@@ -3166,6 +3236,7 @@ int dp_align_prepare(int lds_bytes)
 	if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, wg_lds_bytes<4>(ALIGN_SEQ_NARROW));
 	if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align<1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, wp_lds_bytes(ALIGN_SEQ_PACKED));
 	if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align_long<16>), hipFuncAttributeMaxDynamicSharedMemorySize, wp_lds_bytes(ALIGN_SEQ_PACKED));
+	if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnc_dp_align<4, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, wp_lds_bytes(ALIGN_SEQ_PACKED, 4));
 	if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return MNC_ERR_HIP; }
 	return MNC_OK;
 }
@@ -3199,8 +3270,14 @@ void launch_dp_align(const Batch &B, uint8_t *ws, int n_wg, long long state_max,
 	// pairs (ksw_wp).  MNC_KSW_FORMS=old (or any of the debug_route bits that name an older form) brings those back.
 	static const bool old_forms = getenv("MNC_KSW_FORMS") && !strcmp(getenv("MNC_KSW_FORMS"), "old");
 	if (long_pass && !old_forms && !(B.debug_route & (32 | 64 | 128 | 256 | 512))) {
-		if (forms & 1) hipLaunchKernelGGL((mnc_dp_align<1, 16>), dim3(n_wg), dim3(64), (size_t)wp_lds_bytes(ALIGN_SEQ_PACKED), st, B, ws, state_max, p_max, cig_max,
-		                                  ALIGN_SEQ_PACKED, 0, 0, big_pass, 0, 0);
+		// two forms, the pass's call count -- known on the device only -- picks one: up to ALIGN_FEW calls four waves on each
+		// (a lone call's length is its steps times a wave's instructions a step: a quarter of the cells a wave), more one wave each
+		if (forms & 1) {
+			hipLaunchKernelGGL((mnc_dp_align<4, 4, true>), dim3(n_wg < ALIGN_FEW ? n_wg : ALIGN_FEW), dim3(256), (size_t)wp_lds_bytes(ALIGN_SEQ_PACKED, 4), st, B, ws, state_max, p_max, cig_max,
+			                   ALIGN_SEQ_PACKED, 0, 0, big_pass, 1, ALIGN_FEW);
+			hipLaunchKernelGGL((mnc_dp_align<1, 16>), dim3(n_wg), dim3(64), (size_t)wp_lds_bytes(ALIGN_SEQ_PACKED), st, B, ws, state_max, p_max, cig_max,
+			                   ALIGN_SEQ_PACKED, 0, 0, big_pass, 2, ALIGN_FEW);
+		}
 		return;
 	}
 	if (long_pass && !(B.debug_route & (32 | 128))) {
