@@ -1,4 +1,4 @@
-# Round 4, the literal kernel's long calls: 13 / 16 % errors, one config-4 block, kernel trace of each (max launch durations)
+# Round 5 (as round 4's prof_r04_tails.sh), the literal kernel's long calls: 13 / 16 % errors, one config-4 block, kernel stats of each (max launch durations)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 summ() {
