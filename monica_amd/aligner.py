@@ -92,7 +92,7 @@ def indexer(databases, indexes_path=INDEXES_PATH):
         index = mappy.Aligner(fn_idx_in=os.path.join(databases, database), preset="map-ont", best_n=BEST_N,
                               fn_idx_out=target)
         if not index:
-            raise Exception("Index building failed")
+            raise Exception("Index building failed") from getattr(index, "error", None)
         built.append(target)
     print("Finished building {} index".format(indexes_path))
     _marker("finished_indexing")
@@ -106,7 +106,7 @@ def index_loader(index_file):
         t0 = time.perf_counter()
         index = mappy.Aligner(fn_idx_in=index_file)
         if not index:
-            raise Exception("Damaged or empty index")
+            raise Exception("Damaged or empty index") from getattr(index, "error", None)
         TIMINGS.setdefault("_index_loader", {"load": 0.0})["load"] += time.perf_counter() - t0
         return index
 

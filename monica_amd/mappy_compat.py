@@ -14,6 +14,7 @@ the DP branch of minimap2's formula, `mlen` / `blen` / `NM = blen - mlen + n_amb
 (the restatement is unpinned against the real library, see there).
 """
 import os
+import sys
 import threading
 
 import numpy as np
@@ -25,7 +26,9 @@ from . import _capi
 # monica.py:437-439); the loaded index and its device-resident tables are kept across those
 # calls, keyed by the file's identity, so a pass does not pay the load and upload again.
 _INDEX_CACHE = {}
-_INDEX_CACHE_LOCK = threading.Lock()
+# re-entrant: `Aligner.__del__` takes it, and the collector may run a finaliser on the thread that already holds it
+# (any allocation inside a locked region can start a collection); the locked regions below iterate over snapshots
+_INDEX_CACHE_LOCK = threading.RLock()
 _INDEX_CACHE_MAX = 4
 # ... and by bytes: the reference holds ONE part at a time (aligner.py:91-103 rebinds `index` per part); a
 # database of many parts kept resident would exhaust host memory or HBM.  Host side: the file sizes of the
@@ -66,8 +69,8 @@ def _device_budget(device):
 
 
 def _device_bytes_locked(device):
-    n = sum(index.device_bytes(device) for index in _INDEX_CACHE.values())
-    return n + sum(eng.device_bytes() for eng in _ENGINE_POOLS.get(device, []))
+    n = sum(index.device_bytes(device) for index in list(_INDEX_CACHE.values()))
+    return n + sum(eng.device_bytes() for eng in list(_ENGINE_POOLS.get(device, [])))
 
 
 def _drop_locked(key):
@@ -210,9 +213,10 @@ class Aligner:
                 self._index.save(fn_idx_out, mmi=True)
             else:
                 self._index = _capi.Index.build(fn_idx_in, fn_idx_out, kk, ww, device=_build_device(self._device))
-        except (_capi.MncError, OSError, ValueError) as e:      # mappy: a falsy Aligner, no exception
+        except (_capi.MncError, OSError, ValueError) as e:      # mappy: a falsy Aligner, no exception ...
             self.error = e
             self._index = None
+            print(f"[monica_amd] {fn_idx_in}: {type(e).__name__}: {e}", file=sys.stderr)     # ... and the C layer's line on stderr
 
     @staticmethod
     def _is_index_file(path):

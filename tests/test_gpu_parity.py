@@ -496,3 +496,25 @@ def test_more_table_regions_change_nothing(capi, oracle, bits):
     ta, tb = w["eng"].dump_tables(), capi.Engine(host_form, 0).dump_tables()
     assert len(ta) == len(tb) and np.array_equal(ta, tb)
     assert int(ta[:4].view(np.int32)[0]) >> 16 == bits
+
+
+def test_bacteria_like_genomes_with_operons_insertion_sequences_and_shared_stretches(capi, oracle):
+    """`synth.genome_set_repeats` (the sensitivity workload of BASELINE.md: what the databases monica builds hold,
+    database.py:52-67 -- rRNA-like operons in 5-7 copies, insertion sequences in 15-30, stretches shared between
+    neighbours at 85-95 %) at test size: reads that start inside an element, cross one, or lie in a shared stretch have
+    secondaries, sub-optimal chains and MAPQ < 60; stage by stage at the chain level and region by region with
+    base-level alignment against the oracle."""
+    names, seqs = synth.genome_set_repeats(6, min_len=300_000, max_len=420_000)
+    plain_names, plain = synth.genome_set(6, min_len=300_000, max_len=420_000)
+    assert [len(s) for s in seqs] == [len(s) for s in plain] and 0.03 < (seqs[0] != plain[0]).mean() < 0.2
+    again = synth.genome_set_repeats(6, min_len=300_000, max_len=420_000)[1]
+    assert all(np.array_equal(a, b) for a, b in zip(seqs, again))                       # a function of the seeds
+    w = _world_from(capi, oracle, names, seqs)
+    assert w["idx"].mid_occ >= capi.Index.from_seqs(plain_names, plain).mid_occ          # the elements can only raise the cut-off
+    b, o, truth = synth.reads(seqs, 160, 4000, seed=23)
+    assign, best, nhits = _compare_batch(capi, oracle, w, b, o, min_mapq=0)
+    regs = w["eng"].dump(capi.DUMP_REGS, capi.REG_DTYPE)
+    assert (regs["mapq"] < 60).any() and (regs["parent"] != regs["id"]).any()           # secondaries and doubtful mappings exist
+    _compare_batch(capi, oracle, w, b, o, min_mapq=60)
+    hard, _, _ = synth.reads(seqs, 60, 4000, seed=24, sub=700, ins=450, dele=450)        # 16 % errors: the literal kernel's share
+    _compare_dp(capi, oracle, w, hard, np.arange(61, dtype=np.int64) * 4000, min_mapq=0)

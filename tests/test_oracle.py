@@ -273,3 +273,24 @@ def test_oracle_reproduces_golden_fixture(oracle):
         for name in g["regs"].dtype.names:
             assert np.array_equal(got[name], regs[name][k:k + len(got)]), (r, name)
         k += len(got)
+
+
+def test_the_repeats_genome_model_is_a_function_of_its_seeds():
+    """`synth.genome_set_repeats` (bench.py --genome-model repeats): same lengths as the i.i.d. set, a few per cent of the
+    bases replaced by repeated elements, identical on every call, the diverged second half 3 % from the first."""
+    from monica_amd import synth
+    names, seqs = synth.genome_set_repeats(4, min_len=200_000, max_len=260_000)
+    _, plain = synth.genome_set(4, min_len=200_000, max_len=260_000)
+    assert [len(s) for s in seqs] == [len(s) for s in plain]
+    assert all(0.02 < (a != b).mean() < 0.25 for a, b in zip(seqs[:2], plain[:2]))
+    again = synth.genome_set_repeats(4, min_len=200_000, max_len=260_000)[1]
+    assert all(np.array_equal(a, b) for a, b in zip(seqs, again))
+    assert 0.02 < (seqs[2] != seqs[0]).mean() < 0.04                  # point-diverged copy of genome 0, elements included
+    # an operon copy occurs more than once in a genome: some 31-mer of the genome is repeated
+    g = seqs[0].tobytes()
+    seen, repeated = set(), 0
+    for i in range(0, len(g) - 31, 7):
+        k = g[i:i + 31]
+        repeated += k in seen
+        seen.add(k)
+    assert repeated > 100
