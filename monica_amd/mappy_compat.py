@@ -69,8 +69,9 @@ def _device_budget(device):
 
 
 def _device_bytes_locked(device):
-    n = sum(index.device_bytes(device) for index in list(_INDEX_CACHE.values()))
-    return n + sum(eng.device_bytes() for eng in list(_ENGINE_POOLS.get(device, [])))
+    # (a closed handle holds nothing)
+    n = sum(index.device_bytes(device) for index in list(_INDEX_CACHE.values()) if getattr(index, "_h", True))
+    return n + sum(eng.device_bytes() for eng in list(_ENGINE_POOLS.get(device, [])) if getattr(eng, "_h", True))
 
 
 def _drop_locked(key):
