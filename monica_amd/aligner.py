@@ -62,8 +62,16 @@ FOCUS_FILES_FOLDER = "focus"
 # 50 000-read batches: the stages get cheaper per gigabyte as batches grow, the pipeline's fill and drain cost more than that)
 BATCH_READS = int(os.environ.get("MONICA_AMD_BATCH_READS", "12500"))
 BATCH_BASES = min(1 << 27, BATCH_READS * 6000)
+# the first batches of a file, as fractions of BATCH_READS: the stages behind the parser wait for the first batch, so it is small
+BATCH_RAMP = tuple(float(x) for x in os.environ.get("MONICA_AMD_BATCH_RAMP", "0.25").split(",") if x.strip())
 DEFAULT_MAX_WORKERS = int(os.environ.get("MONICA_AMD_MAX_WORKERS", "8"))   # `n_threads=None`: at most this many samples in flight
 TIMINGS = {}                      # per sample name: seconds spent per phase of aligner() (diagnostics)
+PIPE_TRACE = [] if os.environ.get("MONICA_AMD_PIPE_TRACE") else None   # (stage, reads, start, end) per batch and stage (diagnostics)
+
+
+def _trace(stage, n, t0):
+    if PIPE_TRACE is not None:
+        PIPE_TRACE.append((stage, int(n), t0, time.perf_counter()))
 
 
 def _marker(name):
@@ -149,14 +157,20 @@ def multi_threaded_aligner(query_folder, indexes_paths, mode=None, mapping_quali
             pool.starmap(aligner, zip(samples, samples_name, rep(index), rep(mode), rep(folders["hits"]),
                                       rep(mapping_quality)))
         index = index_loader(indexes_paths[-1])
+        _trace("loaded", 0, time.perf_counter())
         results = pool.starmap(aligner, zip(samples, samples_name, rep(index), rep(mode), rep(folders["hits"]),
                                             rep(mapping_quality), rep(overnight), rep(focus_species),
                                             rep(folders["mapped"]), rep(folders["unmapped"]),
                                             rep(folders["ambiguous"]), rep(folders["focus"]), rep(True)))
     finally:
+        _trace("mapped", 0, time.perf_counter())
         pool.close()
         _capi.set_io_workers(1)
-    return alignment_update(results, output_folder)
+    t0 = time.perf_counter()
+    try:
+        return alignment_update(results, output_folder)
+    finally:
+        _trace("update", 0, t0)
 
 
 def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_quality=None, overnight=False,
@@ -207,30 +221,42 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
     def parse_stage():
         # The first and the last batches are small: the other stages wait for the first one, and the last one's
         # classification, carry and output follow when nothing else is left to overlap them with.
-        taken_reads, taken_bytes, total_bytes = 0, 0, reader.remaining()
+        taken_reads, taken_bytes, total_bytes, k = 0, 0, reader.remaining(), 0
         try:
             while not stop.is_set():
                 t0 = time.perf_counter()
                 want = BATCH_READS
-                if taken_reads == 0:
-                    want = max(BATCH_READS // 4, 1)
+                k += 1
+                if k <= len(BATCH_RAMP):
+                    want = max(int(BATCH_READS * BATCH_RAMP[k - 1]), 1)
                 elif total_bytes > 0:
                     left = reader.remaining()
                     per_read = max(taken_bytes / taken_reads, 1.0)
                     reads_left = left / per_read
-                    if reads_left < 1.75 * BATCH_READS:              # the tail: halves, down to an eighth of a batch
+                    # the tail in halves, down to an eighth of a batch -- when the GPU is what the file waits for: the last
+                    # batch's carry and routing then come after everything else.  When the routing pass is (one file takes
+                    # 14 GB/s from however many threads: tools/micro/page_cache_write.c), it is busy to the end whatever the
+                    # batches' sizes, and small batches only add their fixed costs
+                    gpu_bound = not last_index or clock["classify"] > 1.15 * clock["route"]
+                    if gpu_bound and reads_left < 1.75 * BATCH_READS:
                         want = int(reads_left) + 64 if reads_left < BATCH_READS / 8 else max(int(reads_left / 2), BATCH_READS // 8)
-                if not reader.next(max(want, 1), BATCH_BASES):
+                    elif not gpu_bound and reads_left < 1.5 * BATCH_READS:
+                        want = int(reads_left) + 64                   # one last batch of up to a batch and a half
+                # (bases in proportion: the parser reads ahead what a batch may hold, and the first batch is waited for)
+                if not reader.next(max(want, 1), max(min(1 << 27, max(want, 1) * 6000), 1 << 20)):
                     break
                 taken_reads += reader.n
                 taken_bytes = total_bytes - reader.remaining() if total_bytes > 0 else 0
                 batch = reader.detach()
                 clock["parse"] += time.perf_counter() - t0
+                _trace("parse", batch.n, t0)
+                t_ann = time.perf_counter()
                 try:
                     _announce(batch)
                 except BaseException:
                     batch.close()
                     raise
+                _trace("announce", batch.n, t_ann)
                 if not put(parsed, batch):
                     batch.close()
                     return
@@ -273,6 +299,7 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
             mappy.release_idle(index.index)
             out = engine.classify_ptr(batch.bases_ptr, batch.offsets_ptr, batch.n, mapping_quality)
         clock["classify"] += time.perf_counter() - t1
+        _trace("classify", batch.n, t1)
         n_skipped = int((out[0] == _capi.SKIPPED).sum())
         if n_skipped:
             # index.map() takes a read of any length (aligner.py:193, 215); the kernels stop at 2^20 bases.  Such a read
@@ -331,6 +358,7 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
                 t2 = time.perf_counter()
                 state = sample_hits.update(batch, index.index, assign, best, nhits)
                 clock["carry"] += time.perf_counter() - t2
+                _trace("carry", batch.n, t2)
                 if not last_index:
                     batch.close()
                 elif not put(to_write, (batch, state, sample_hits.names())):
@@ -352,7 +380,9 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
                 batch, state, names_now = item
                 try:
                     if not post_error:
+                        t3 = time.perf_counter()
                         _route_and_count(batch, state, names_now, decoded, acc, mode, overnight, focus_species, paths, clock)
+                        _trace("route", batch.n, t3)
                 finally:
                     batch.close()
         except BaseException as e:
@@ -379,6 +409,7 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
         to_route.put(None)
         carrier.join()
         writer.join()
+        _trace("joined", 0, time.perf_counter())
         stop.set()
         leftover = []
         while parser.is_alive():                          # unblock a parser waiting on a full queue
@@ -405,6 +436,7 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
         t0 = time.perf_counter()
         reader.close()
         clock["close"] += time.perf_counter() - t0
+    _trace("closed", 0, time.perf_counter())
     if post_error:
         raise post_error[0]
     if not last_index:
@@ -421,6 +453,10 @@ def aligner(sample, sample_name, index, mode=None, hits_folder=None, mapping_qua
     t0 = time.perf_counter()
     _remove_consumed(sample)
     clock["remove"] += time.perf_counter() - t0
+    # the carried hits of 100 000 reads are as many small blocks: giving them back takes 10 ms, as long as routing a batch
+    # (a thread of its own, not a daemon: it finishes before the interpreter exits)
+    threading.Thread(target=sample_hits.close, name="mnc-hits-free").start()
+    _trace("return", 0, time.perf_counter())
     return sample_alignment, sample_name
 
 

@@ -28,7 +28,7 @@
 #endif
 #include <algorithm>
 #include <unistd.h>
-#include <omp.h>
+#include "team.h"
 #include <mutex>
 #include <atomic>
 #include <vector>
@@ -158,21 +158,22 @@ struct LineReader {
 			const size_t slice = 16u << 20;
 			const int64_t n_slices = (int64_t)((n + slice - 1) / slice);
 			int fail = 0;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(io_threads())
-			for (int64_t k = 0; k < n_slices; ++k) {
+			std::atomic<int64_t> next_slice{0};
+			team().run((int)std::min<int64_t>(io_threads(), n_slices), [&](int, int) {
+			for (int64_t k; (k = next_slice.fetch_add(1, std::memory_order_relaxed)) < n_slices;) {
 				size_t done = 0;
 				const size_t len = std::min(slice, n - (size_t)k * slice);
 				while (done < len) {
 					const ssize_t r = pread(fd, data + hi + (size_t)k * slice + done, len - done, pos + (off_t)((size_t)k * slice + done));
 					if (r < 0 && errno == EINTR) continue;
 					if (r <= 0) {
-#pragma omp atomic write
-						fail = r < 0 ? (errno ? errno : EIO) : EIO;
+						__atomic_store_n(&fail, r < 0 ? (errno ? errno : EIO) : EIO, __ATOMIC_RELAXED);
 						break;
 					}
 					done += (size_t)r;
 				}
 			}
+			});
 			if (fail) { err = fail; eof = true; return false; }
 			hi += n;
 			if (lseek(fd, pos + (off_t)n, SEEK_SET) < 0) { err = errno ? errno : EIO; eof = true; return false; }
@@ -191,10 +192,29 @@ struct LineReader {
 	// routing pass side by side with the thread that launches kernels).  A host that works on several sample files at
 	// once (monica's ThreadPool, aligner.py:89-103: one sample per worker) says so with mnc_host_set_io_workers: the
 	// cores are shared out over the workers, or W workers x 2 passes x 16 threads oversubscribe a large GPU host.
+	// the host threads this process may keep busy: the hardware's, or the share its control group is given of them
+	// (cpu.max: the GPU box shows 256 hardware threads and grants 16 -- a team of 256 would only queue up for them)
+	static int host_cores()
+	{
+		static const int n = [] {
+			int hw = (int)std::thread::hardware_concurrency();
+			if (hw < 1) hw = 1;
+			if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+				long long quota = 0, period = 0;
+				if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) {
+					const int share = (int)((quota + period - 1) / period);
+					if (share >= 1 && share < hw) hw = share;
+				}
+				fclose(f);
+			}
+			return hw;
+		}();
+		return n;
+	}
 	static int io_threads()
 	{
 		static const int cap = [] { const char *e = getenv("MNC_IO_THREADS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 16; }();
-		int t = omp_get_max_threads() / std::max(1, g_io_workers.load(std::memory_order_relaxed));
+		int t = host_cores() / std::max(1, g_io_workers.load(std::memory_order_relaxed));
 		return t < 1 ? 1 : t > cap ? cap : t;
 	}
 	// The aligner's pipeline runs a parse and a routing pass side by side: each may be given a team of its own size
@@ -436,9 +456,7 @@ static int fastq_next_fast(mnc_fastq *fq, uint32_t max_reads, uint64_t max_bases
 	const int T = LineReader::parse_threads();
 	// ---- line ends
 	std::vector<std::vector<size_t>> part((size_t)T);
-#pragma omp parallel num_threads(T)
-	{
-		const int t = omp_get_thread_num(), nt = omp_get_num_threads();
+	team().run(T, [&](int t, int nt) {
 		const size_t a = avail * (size_t)t / (size_t)nt, b = avail * (size_t)(t + 1) / (size_t)nt;
 		std::vector<size_t> &v = part[(size_t)t];
 		v.reserve((b - a) / 1024 + 16);
@@ -449,7 +467,7 @@ static int fastq_next_fast(mnc_fastq *fq, uint32_t max_reads, uint64_t max_bases
 			v.push_back((size_t)(q - base));
 			p = q + 1;
 		}
-	}
+	});
 	std::vector<size_t> &nl = fq->nl;
 	nl.clear();
 	for (const auto &v : part) nl.insert(nl.end(), v.begin(), v.end());
@@ -467,31 +485,30 @@ static int fastq_next_fast(mnc_fastq *fq, uint32_t max_reads, uint64_t max_bases
 	if (R == 0) return MNC_OK;
 	std::vector<uint32_t> slen(R), tlen(R);
 	fq->verbatim.resize(R);
-	int bad = 0;
-#pragma omp parallel for schedule(static) num_threads(T) reduction(|:bad)
-	for (int64_t r = 0; r < (int64_t)R; ++r) {
+	std::atomic<int> bad_any{0};
+	team().slices(T, (int64_t)R, [&](int64_t r) {
 		const char *tp, *sp, *pp, *qp;
 		size_t tl, sl, pl, ql;
 		line((size_t)(4 * r), tp, tl), line((size_t)(4 * r + 1), sp, sl), line((size_t)(4 * r + 2), pp, pl), line((size_t)(4 * r + 3), qp, ql);
-		if (tl == 0 || tp[0] != '@' || pl == 0 || pp[0] != '+') { bad |= 1; continue; }
+		if (tl == 0 || tp[0] != '@' || pl == 0 || pp[0] != '+') { bad_any.store(1, std::memory_order_relaxed); return; }
 		const size_t t_len = rstrip_len(tp + 1, tl - 1), c_len = rstrip_len(pp + 1, pl - 1);
-		if (c_len > 0 && (c_len != t_len || memcmp(pp + 1, tp + 1, t_len) != 0)) { bad |= 1; continue; }
+		if (c_len > 0 && (c_len != t_len || memcmp(pp + 1, tp + 1, t_len) != 0)) { bad_any.store(1, std::memory_order_relaxed); return; }
 		const size_t s_len = rstrip_len(sp, sl), q_len = rstrip_len(qp, ql);
-		if (s_len != q_len || s_len > 0xffffffffu) { bad |= 1; continue; }
-		if (memchr(sp, ' ', s_len) || memchr(sp, '\t', s_len)) { bad |= 1; continue; }
+		if (s_len != q_len || s_len > 0xffffffffu) { bad_any.store(1, std::memory_order_relaxed); return; }
+		if (memchr(sp, ' ', s_len) || memchr(sp, '\t', s_len)) { bad_any.store(1, std::memory_order_relaxed); return; }
 		unsigned out_of_range = 0;                                // (no early exit: the loop is a vector OR)
 		for (size_t i = 0; i < q_len; ++i) out_of_range |= (unsigned)((uint8_t)(qp[i] - 33) > 93);
-		if (out_of_range) { bad |= 1; continue; }
+		if (out_of_range) { bad_any.store(1, std::memory_order_relaxed); return; }
 		if ((size_t)(4 * r + 4) < n_lines) {
 			const char *np_; size_t nl_;
 			line((size_t)(4 * r + 4), np_, nl_);
-			if (nl_ == 0 || np_[0] != '@') bad |= 1;
+			if (nl_ == 0 || np_[0] != '@') bad_any.store(1, std::memory_order_relaxed);
 		}
 		slen[(size_t)r] = (uint32_t)s_len, tlen[(size_t)r] = (uint32_t)t_len;
 		// the record's bytes are what FastqPhredWriter writes for it: nothing stripped, a bare '+', a line end behind the qualities
 		fq->verbatim[(size_t)r] = (t_len == tl - 1 && pl == 1 && s_len == sl && q_len == ql && !(open_end && (size_t)(4 * r + 3) == n_lines - 1)) ? 1 : 0;
-	}
-	if (bad) return MNC_OK;
+	});
+	if (bad_any.load()) return MNC_OK;
 	// ---- how many records: the batch ends with the record that reaches max_bases
 	size_t n = 0;
 	{
@@ -509,8 +526,7 @@ static int fastq_next_fast(mnc_fastq *fq, uint32_t max_reads, uint64_t max_bases
 	if (!fq->bases.ensure((size_t)nb + 64, 0)) { set_error("out of host memory"); return MNC_ERR_NOMEM; }
 	fq->titles.resize((size_t)fq->title_off[n]);
 	const size_t text0 = in.lo;                                   // offsets into in.data (the batch's text)
-#pragma omp parallel for schedule(static) num_threads(T)
-	for (int64_t r = 0; r < (int64_t)n; ++r) {
+	team().slices(T, (int64_t)n, [&](int64_t r) {
 		const char *tp, *sp, *qp;
 		size_t tl, sl, ql;
 		line((size_t)(4 * r), tp, tl), line((size_t)(4 * r + 1), sp, sl), line((size_t)(4 * r + 3), qp, ql);
@@ -525,7 +541,7 @@ static int fastq_next_fast(mnc_fastq *fq, uint32_t max_reads, uint64_t max_bases
 		size_t b = a;
 		while (b < t_len && !(t[b] == ' ' || (t[b] >= 9 && t[b] <= 13))) ++b;
 		fq->id_len[(size_t)r] = (uint32_t)(b - a), fq->id_off[(size_t)r] = (uint32_t)a;
-	}
+	});
 	fq->n = (uint32_t)n;
 	fq->text_backed = true, fq->quals_ready = false;
 	// ---- what was consumed: the records; the next record's title line stays in the buffer (the pending line)
@@ -548,9 +564,9 @@ static bool fastq_fill_quals(mnc_fastq *fq)
 	if (!fq->quals.ensure((size_t)fq->offsets[n] + 64, 0)) return false;
 	const char *text = fq->text_base();
 	const int T = LineReader::parse_threads();
-#pragma omp parallel for schedule(static) num_threads(T)
-	for (int64_t r = 0; r < (int64_t)n; ++r)
+	team().slices(T, (int64_t)n, [&](int64_t r) {
 		memcpy(fq->quals.p + fq->offsets[(size_t)r], text + fq->qual_off[(size_t)r], (size_t)(fq->offsets[(size_t)r + 1] - fq->offsets[(size_t)r]));
+	});
 	fq->quals_ready = true;
 	return true;
 }
@@ -742,13 +758,12 @@ static int route_from_text(const mnc_fastq *fq, const uint8_t *dest, const int32
 		return 0;
 	};
 	std::vector<size_t> slice_bytes((size_t)T * 4, 0), slice_arena((size_t)T, 0);
-#pragma omp parallel for schedule(static, 1) num_threads(T)
-	for (int t = 0; t < T; ++t) {
+	team().run(T, [&](int t, int) {
 		const uint32_t r0 = (uint32_t)((uint64_t)n * (uint64_t)t / (uint64_t)T), r1 = (uint32_t)((uint64_t)n * (uint64_t)(t + 1) / (uint64_t)T);
 		for (uint32_t r = r0; r < r1; ++r)
 			for (int k = 0; k < 4; ++k)
 				if (dest[r] >> k & 1) slice_bytes[(size_t)t * 4 + k] += rec_len(r, k), slice_arena[(size_t)t] += arena_len(r, k);
-	}
+	});
 	int fds[4] = { -1, -1, -1, -1 };
 	off_t start[4] = { 0, 0, 0, 0 };
 	int rc = MNC_OK;
@@ -801,8 +816,7 @@ static int route_from_text(const mnc_fastq *fq, const uint8_t *dest, const int32
 	}
 	int fail[4] = { 0, 0, 0, 0 };
 	if (rc == MNC_OK) {
-#pragma omp parallel for schedule(static, 1) num_threads(T)
-		for (int t = 0; t < T; ++t) {
+		team().run(T, [&](int t, int) {
 			const uint32_t r0 = (uint32_t)((uint64_t)n * (uint64_t)t / (uint64_t)T), r1 = (uint32_t)((uint64_t)n * (uint64_t)(t + 1) / (uint64_t)T);
 			std::vector<char> arena(slice_arena[(size_t)t] + 16);      // sized exactly: its pieces are pointed at until they are written
 			size_t used = 0;
@@ -823,8 +837,7 @@ static int route_from_text(const mnc_fastq *fq, const uint8_t *dest, const int32
 					ssize_t w = pwritev(fds[k], o.iov.data() + i, cnt, pos);
 					if (w < 0 && errno == EINTR) continue;
 					if (w <= 0) {
-#pragma omp atomic write
-						fail[k] = errno ? errno : EIO;
+						__atomic_store_n(&fail[k], errno ? errno : EIO, __ATOMIC_RELAXED);
 						break;
 					}
 					pos += (off_t)w;
@@ -888,7 +901,7 @@ static int route_from_text(const mnc_fastq *fq, const uint8_t *dest, const int32
 				}
 			}
 			for (int k = 0; k < 4; ++k) if (!out[k].iov.empty()) flush(k);
-		}
+		});
 	}
 	for (int k = 0; k < 4; ++k) {
 		if (map_base[k] && munmap(map_base[k], map_len[k]) != 0 && !fail[k]) fail[k] = errno ? errno : EIO;
@@ -934,13 +947,12 @@ extern "C" int mnc_fastq_route(const mnc_fastq *fq, const uint8_t *dest, const i
 		return 1 + head + 1 + l + 3 + l + 1;
 	};
 	std::vector<size_t> slice_bytes((size_t)T * 4, 0);
-#pragma omp parallel for schedule(static, 1) num_threads(T)
-	for (int t = 0; t < T; ++t) {
+	team().run(T, [&](int t, int) {
 		const uint32_t r0 = (uint32_t)((uint64_t)fq->n * (uint64_t)t / (uint64_t)T), r1 = (uint32_t)((uint64_t)fq->n * (uint64_t)(t + 1) / (uint64_t)T);
 		for (uint32_t r = r0; r < r1; ++r)
 			for (int k = 0; k < 4; ++k)
 				if (dest[r] >> k & 1) slice_bytes[(size_t)t * 4 + k] += rec_len(r, k);
-	}
+	});
 	int fds[4] = { -1, -1, -1, -1 };
 	off_t start[4] = { 0, 0, 0, 0 };
 	size_t total[4] = { 0, 0, 0, 0 };
@@ -955,8 +967,7 @@ extern "C" int mnc_fastq_route(const mnc_fastq *fq, const uint8_t *dest, const i
 	}
 	int fail[4] = { 0, 0, 0, 0 };
 	if (rc == MNC_OK) {
-#pragma omp parallel for schedule(static, 1) num_threads(T)
-		for (int t = 0; t < T; ++t) {
+		team().run(T, [&](int t, int) {
 			const uint32_t r0 = (uint32_t)((uint64_t)fq->n * (uint64_t)t / (uint64_t)T), r1 = (uint32_t)((uint64_t)fq->n * (uint64_t)(t + 1) / (uint64_t)T);
 			off_t pos[4];
 			std::string buf[4];
@@ -971,8 +982,7 @@ extern "C" int mnc_fastq_route(const mnc_fastq *fq, const uint8_t *dest, const i
 					const ssize_t w = pwrite(fds[k], b.data() + done, b.size() - done, pos[k] + (off_t)done);
 					if (w < 0 && errno == EINTR) continue;
 					if (w <= 0) {
-#pragma omp atomic write
-						fail[k] = errno ? errno : EIO;
+						__atomic_store_n(&fail[k], errno ? errno : EIO, __ATOMIC_RELAXED);
 						break;
 					}
 					done += (size_t)w;
@@ -1006,7 +1016,7 @@ extern "C" int mnc_fastq_route(const mnc_fastq *fq, const uint8_t *dest, const i
 				}
 			}
 			for (int k = 0; k < 4; ++k) if (!buf[k].empty()) flush(k);
-		}
+		});
 	}
 	for (int k = 0; k < 4; ++k) {
 		if (fds[k] < 0) continue;
