@@ -142,7 +142,7 @@ def multi_threaded_aligner(query_folder, indexes_paths, mode=None, mapping_quali
             os.mkdir(folders["focus"])
 
     # aligner.py:89 is `ThreadPool(n_threads)`; None there means one worker per core, sized for CPU mappers.  Here a worker
-    # feeds a GPU: it owns an engine (HBM batch buffers), three pipeline threads and two OpenMP teams, and all engines
+    # feeds a GPU: it owns an engine (HBM batch buffers), three pipeline threads and two teams of helper threads (csrc/team.h), and all engines
     # of a device take turns on one alignment workspace -- so an explicit n_threads is kept as given, None is capped at
     # DEFAULT_MAX_WORKERS (and at the number of samples), and the readers' teams share the cores over the workers.
     workers = n_threads if n_threads else min(os.cpu_count() or 1, DEFAULT_MAX_WORKERS)
