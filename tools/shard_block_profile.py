@@ -17,3 +17,10 @@ tm = eng.timings()
 print("reads with their genome (or its diverged copy) in the part:", int(((truth >= lo) & (truth < hi)).sum()), "mapped", int((a >= 0).sum()), "call ms", round(dt * 1e3, 1))
 print({k: round(v[0], 2) for k, v in tm.items() if v[1]})
 print(eng.counters())
+# ... and its alignment kernels one at a time (debug 0x10000: one stream, per-kernel timers)
+eng.set_debug(0x10000)
+eng.classify(bases, offsets, 60)
+eng.timings(reset=True)
+eng.classify(bases, offsets, 60)
+tm = eng.timings()
+print("one kernel at a time:", {k: round(v[0], 2) for k, v in tm.items() if v[1] and k.startswith("dp_")})
