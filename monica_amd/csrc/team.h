@@ -22,6 +22,7 @@ class Team {
 	int width = 0, pending = 0;
 	uint64_t gen = 0;
 	bool quit = false;
+	bool busy = false;                                         // the owner is inside run(): a pass started from within a pass runs on the caller alone
 
 	void loop(int id, uint64_t seen)
 	{
@@ -56,7 +57,11 @@ public:
 	// fn(t, T) for t = 0 .. T - 1, t = 0 on the calling thread; returns when all are done.  fn must not throw.
 	void run(int T, const std::function<void(int, int)> &fn)
 	{
-		if (T <= 1) { fn(0, 1); return; }
+		if (T <= 1 || busy) {                                    // (busy: only the owner's own share of a pass can get here -- its helpers have teams of their own)
+			for (int t = 0; t < (T < 1 ? 1 : T); ++t) fn(t, T < 1 ? 1 : T);
+			return;
+		}
+		struct Busy { bool &b; Busy(bool &b_) : b(b_) { b = true; } ~Busy() { b = false; } } in_pass(busy);
 		{
 			std::lock_guard<std::mutex> lk(m);
 			while ((int)helpers.size() < T - 1) {
