@@ -28,6 +28,7 @@
 #endif
 #include <algorithm>
 #include <unistd.h>
+#include <sched.h>
 #include "team.h"
 #include <mutex>
 #include <atomic>
@@ -199,13 +200,22 @@ struct LineReader {
 		static const int n = [] {
 			int hw = (int)std::thread::hardware_concurrency();
 			if (hw < 1) hw = 1;
-			if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-				long long quota = 0, period = 0;
-				if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) {
-					const int share = (int)((quota + period - 1) / period);
-					if (share >= 1 && share < hw) hw = share;
-				}
+			cpu_set_t set;                                        // (a process started under taskset / numactl)
+			if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int a = CPU_COUNT(&set); if (a >= 1 && a < hw) hw = a; }
+			long long quota = 0, period = 0;
+			bool have = false;
+			if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                     // control groups v2: "<quota | max> <period>"
+				have = fscanf(f, "%lld %lld", &quota, &period) == 2;
 				fclose(f);
+			} else {                                                                   // v1
+				FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"), *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+				if (fq && fp) have = fscanf(fq, "%lld", &quota) == 1 && fscanf(fp, "%lld", &period) == 1;
+				if (fq) fclose(fq);
+				if (fp) fclose(fp);
+			}
+			if (have && quota > 0 && period > 0) {
+				const int share = (int)((quota + period - 1) / period);
+				if (share >= 1 && share < hw) hw = share;
 			}
 			return hw;
 		}();
