@@ -325,6 +325,15 @@ def main():
     VALU_PEAK_R04 = 256 * 4 * 2.4e9 / 4
     FILLP_INSTR_PER_STEP = 464 / 16                      # vector instructions of the unrolled 16-step block of the main loop (ISA listing of the round's last build: profiles/README.md; 480 before the second gap piece got its own frame, 521 with the first form of the drifting frame, 568 before it)
     VALU_PEAK_GUIDE = 256 * 4 * 2.4e9 / 2                # the guide's nominal 2-cycle wave64 issue (MI355X_MICROARCH.md), for comparison
+    # Round 5, by instruction class: not every opcode of the loop costs 4.15 cycles.  With 4 waves a SIMD (what the kernel runs
+    # with) v_add / v_sub / v_and / v_or / v_xor / v_mov issue in 2.32 cycles, v_bitop3 in 3.8, everything else the loop uses --
+    # v_pk_*, v_perm, v_alignbit, v_bfi, v_lshlrev, DPP moves -- in 4.22 (profiles/r05y_valu_issue_rates.json).  The 16-step
+    # block's 464 vector instructions are 118 of the first kind (64 v_and, 32 v_xor, 16 v_or, 5 v_add, 1 v_mov), 16 v_bitop3
+    # and 330 of the rest (128 v_pk_max_i16, 32 DPP moves, 32 v_alignbit, 32 v_pk_sub_i16, 24 v_perm, ...): 1 727 cycles,
+    # 3.72 an instruction -- the roof `frac_by_instruction_class` is priced against (the loop alone: the walks and the
+    # sequence loads of a launch are further instructions, which `issue_rate_frac` counts)
+    FILLP_BLOCK_CYCLES = 118 * 2.32 + 16 * 3.8 + 330 * 4.22
+    VALU_PEAK_FILLP_CELLS = 256 * 4 * VALU_CLOCK_HZ / (FILLP_BLOCK_CYCLES / 16 / 128)
     roofline_dp = None
     if dp_kernel_ms and dp_kernel_ms.get("dp_fill_t1", 0) > 0 and counters.get("dp_fill_steps_t1", 0) > 0:
         cells = counters["dp_fill_steps_t1"] * 32
@@ -345,6 +354,10 @@ def main():
                        "unit": "Gcell/s", "frac": round(ach / peak, 4),
                        "frac_at_r04_peak": round(ach / (VALU_PEAK_R04 / instr_per_cell / 1e9), 4),
                        "peak_clock_mhz_measured": round(VALU_CLOCK_HZ / 1e6, 1), "peak_cycles_per_instruction_measured": VALU_CYCLES_PER_INSTR,
+                       # the stricter roof: every opcode of the loop at its own measured rate (see FILLP_BLOCK_CYCLES above)
+                       "frac_by_instruction_class": round(ach / (VALU_PEAK_FILLP_CELLS / 1e9), 4),
+                       "peak_by_instruction_class": round(VALU_PEAK_FILLP_CELLS / 1e9, 1),
+                       "cycles_per_16_steps_by_instruction_class": round(FILLP_BLOCK_CYCLES, 1),
                        # the same launch against the guide's nominal issue rate (one wave64 instruction per 2 cycles and SIMD):
                        # the packed-16-bit / perm / DPP instructions this kernel is made of issue at half that (measured)
                        "frac_guide_nominal": round(ach / (VALU_PEAK_GUIDE / instr_per_cell / 1e9), 4),

@@ -29,12 +29,32 @@ __global__ __launch_bounds__(64) void k(uint32_t *out, int iters, uint32_t seed,
 		if (OP == 9) { REP16(ONE("v_pk_mad_u16 %0, %0, %8, %8\n v_pk_mad_u16 %1, %1, %8, %8\n v_pk_mad_u16 %2, %2, %8, %8\n v_pk_mad_u16 %3, %3, %8, %8\n v_pk_mad_u16 %4, %4, %8, %8\n v_pk_mad_u16 %5, %5, %8, %8\n v_pk_mad_u16 %6, %6, %8, %8\n v_pk_mad_u16 %7, %7, %8, %8")) }
 		if (OP == 10) { REP16(ONE("v_max_f32 %0, %0, %8\n v_max_f32 %1, %1, %8\n v_max_f32 %2, %2, %8\n v_max_f32 %3, %3, %8\n v_max_f32 %4, %4, %8\n v_max_f32 %5, %5, %8\n v_max_f32 %6, %6, %8\n v_max_f32 %7, %7, %8")) }
 		if (OP == 11) { REP16(ONE("v_pk_max_f16 %0, %0, %8\n v_pk_max_f16 %1, %1, %8\n v_pk_max_f16 %2, %2, %8\n v_pk_max_f16 %3, %3, %8\n v_pk_max_f16 %4, %4, %8\n v_pk_max_f16 %5, %5, %8\n v_pk_max_f16 %6, %6, %8\n v_pk_max_f16 %7, %7, %8")) }
+		if (OP == 12) { REP16(ONE("v_sub_u32 %0, %0, %8\n v_sub_u32 %1, %1, %8\n v_sub_u32 %2, %2, %8\n v_sub_u32 %3, %3, %8\n v_sub_u32 %4, %4, %8\n v_sub_u32 %5, %5, %8\n v_sub_u32 %6, %6, %8\n v_sub_u32 %7, %7, %8")) }
+		if (OP == 13) { REP16(ONE("v_and_b32 %0, %0, %8\n v_and_b32 %1, %1, %8\n v_and_b32 %2, %2, %8\n v_and_b32 %3, %3, %8\n v_and_b32 %4, %4, %8\n v_and_b32 %5, %5, %8\n v_and_b32 %6, %6, %8\n v_and_b32 %7, %7, %8")) }
+		if (OP == 14) { REP16(ONE("v_or_b32 %0, %0, %8\n v_or_b32 %1, %1, %8\n v_or_b32 %2, %2, %8\n v_or_b32 %3, %3, %8\n v_or_b32 %4, %4, %8\n v_or_b32 %5, %5, %8\n v_or_b32 %6, %6, %8\n v_or_b32 %7, %7, %8")) }
+		if (OP == 15) { REP16(ONE("v_xor_b32 %0, %0, %8\n v_xor_b32 %1, %1, %8\n v_xor_b32 %2, %2, %8\n v_xor_b32 %3, %3, %8\n v_xor_b32 %4, %4, %8\n v_xor_b32 %5, %5, %8\n v_xor_b32 %6, %6, %8\n v_xor_b32 %7, %7, %8")) }
+		if (OP == 16) { REP16(ONE("v_lshlrev_b32 %0, 4, %0\n v_lshlrev_b32 %1, 4, %1\n v_lshlrev_b32 %2, 4, %2\n v_lshlrev_b32 %3, 4, %3\n v_lshlrev_b32 %4, 4, %4\n v_lshlrev_b32 %5, 4, %5\n v_lshlrev_b32 %6, 4, %6\n v_lshlrev_b32 %7, 4, %7")) }
+		if (OP == 17) { REP16(ONE("v_alignbit_b32 %0, %0, %8, 16\n v_alignbit_b32 %1, %1, %8, 16\n v_alignbit_b32 %2, %2, %8, 16\n v_alignbit_b32 %3, %3, %8, 16\n v_alignbit_b32 %4, %4, %8, 16\n v_alignbit_b32 %5, %5, %8, 16\n v_alignbit_b32 %6, %6, %8, 16\n v_alignbit_b32 %7, %7, %8, 16")) }
+		if (OP == 18) { REP16(ONE("v_bfi_b32 %0, %8, %0, %8\n v_bfi_b32 %1, %8, %1, %8\n v_bfi_b32 %2, %8, %2, %8\n v_bfi_b32 %3, %8, %3, %8\n v_bfi_b32 %4, %8, %4, %8\n v_bfi_b32 %5, %8, %5, %8\n v_bfi_b32 %6, %8, %6, %8\n v_bfi_b32 %7, %8, %7, %8")) }
+		if (OP == 19) { REP16(ONE("v_bitop3_b32 %0, %0, %8, %8 bitop3:0x96\n v_bitop3_b32 %1, %1, %8, %8 bitop3:0x96\n v_bitop3_b32 %2, %2, %8, %8 bitop3:0x96\n v_bitop3_b32 %3, %3, %8, %8 bitop3:0x96\n v_bitop3_b32 %4, %4, %8, %8 bitop3:0x96\n v_bitop3_b32 %5, %5, %8, %8 bitop3:0x96\n v_bitop3_b32 %6, %6, %8, %8 bitop3:0x96\n v_bitop3_b32 %7, %7, %8, %8 bitop3:0x96")) }
+		if (OP == 20) { REP16(ONE("v_min_u32 %0, %0, %8\n v_min_u32 %1, %1, %8\n v_min_u32 %2, %2, %8\n v_min_u32 %3, %3, %8\n v_min_u32 %4, %4, %8\n v_min_u32 %5, %5, %8\n v_min_u32 %6, %6, %8\n v_min_u32 %7, %7, %8")) }
+		if (OP == 21) { REP16(ONE("v_pk_sub_u16 %0, %0, %8\n v_pk_sub_u16 %1, %1, %8\n v_pk_sub_u16 %2, %2, %8\n v_pk_sub_u16 %3, %3, %8\n v_pk_sub_u16 %4, %4, %8\n v_pk_sub_u16 %5, %5, %8\n v_pk_sub_u16 %6, %6, %8\n v_pk_sub_u16 %7, %7, %8")) }
+		if (OP == 22) { REP16(ONE("v_pk_add_u16 %0, %0, %8\n v_pk_add_u16 %1, %1, %8\n v_pk_add_u16 %2, %2, %8\n v_pk_add_u16 %3, %3, %8\n v_pk_add_u16 %4, %4, %8\n v_pk_add_u16 %5, %5, %8\n v_pk_add_u16 %6, %6, %8\n v_pk_add_u16 %7, %7, %8")) }
+		if (OP == 23) { REP16(ONE("v_pk_max_u16 %0, %0, %8\n v_pk_max_u16 %1, %1, %8\n v_pk_max_u16 %2, %2, %8\n v_pk_max_u16 %3, %3, %8\n v_pk_max_u16 %4, %4, %8\n v_pk_max_u16 %5, %5, %8\n v_pk_max_u16 %6, %6, %8\n v_pk_max_u16 %7, %7, %8")) }
+		if (OP == 24) { REP16(ONE("v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8")) }
+		if (OP == 25) { REP16(ONE("v_add3_u32 %0, %0, %8, %8\n v_add3_u32 %1, %1, %8, %8\n v_add3_u32 %2, %2, %8, %8\n v_add3_u32 %3, %3, %8, %8\n v_add3_u32 %4, %4, %8, %8\n v_add3_u32 %5, %5, %8, %8\n v_add3_u32 %6, %6, %8, %8\n v_add3_u32 %7, %7, %8, %8")) }
+		if (OP == 26) { REP16(ONE("v_lshl_add_u32 %0, %0, 4, %8\n v_lshl_add_u32 %1, %1, 4, %8\n v_lshl_add_u32 %2, %2, 4, %8\n v_lshl_add_u32 %3, %3, 4, %8\n v_lshl_add_u32 %4, %4, 4, %8\n v_lshl_add_u32 %5, %5, 4, %8\n v_lshl_add_u32 %6, %6, 4, %8\n v_lshl_add_u32 %7, %7, 4, %8")) }
+		if (OP == 27) { REP16(ONE("v_and_or_b32 %0, %0, %8, %8\n v_and_or_b32 %1, %1, %8, %8\n v_and_or_b32 %2, %2, %8, %8\n v_and_or_b32 %3, %3, %8, %8\n v_and_or_b32 %4, %4, %8, %8\n v_and_or_b32 %5, %5, %8, %8\n v_and_or_b32 %6, %6, %8, %8\n v_and_or_b32 %7, %7, %8, %8")) }
+		if (OP == 28) { REP16(ONE("v_lshl_or_b32 %0, %0, 4, %8\n v_lshl_or_b32 %1, %1, 4, %8\n v_lshl_or_b32 %2, %2, 4, %8\n v_lshl_or_b32 %3, %3, 4, %8\n v_lshl_or_b32 %4, %4, 4, %8\n v_lshl_or_b32 %5, %5, 4, %8\n v_lshl_or_b32 %6, %6, 4, %8\n v_lshl_or_b32 %7, %7, 4, %8")) }
+		if (OP == 29) { REP16(ONE("v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %5 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %7 wave_shr:1 row_mask:0xf bank_mask:0xf")) }
+		if (OP == 30) { REP16(ONE("v_max_i16 %0, %0, %8\n v_max_i16 %1, %1, %8\n v_max_i16 %2, %2, %8\n v_max_i16 %3, %3, %8\n v_max_i16 %4, %4, %8\n v_max_i16 %5, %5, %8\n v_max_i16 %6, %6, %8\n v_max_i16 %7, %7, %8")) }
+		if (OP == 31) { REP16(ONE("v_add_u16 %0, %0, %8\n v_add_u16 %1, %1, %8\n v_add_u16 %2, %2, %8\n v_add_u16 %3, %3, %8\n v_add_u16 %4, %4, %8\n v_add_u16 %5, %5, %8\n v_add_u16 %6, %6, %8\n v_add_u16 %7, %7, %8")) }
 	}
 	out[blockIdx.x * 64 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
 	if (blockIdx.x == 0 && threadIdx.x == 0) clk[0] = __builtin_readcyclecounter() - c0, clk[1] = wall_clock64() - w0;
 }
 
-static double g_mhz_sum = 0, g_cyc2p4[16][4];
+static double g_mhz_sum = 0, g_cyc2p4[40][4];
 static int g_mhz_n = 0;
 template <int OP> double run(uint32_t *d, int waves_per_simd, int iters)
 {
@@ -64,10 +84,10 @@ int main()
 {
 	uint32_t *d;
 	hipMalloc(&d, 256 * 4 * 8 * 64 * 4);
-	const char *names[] = { "v_add_u32", "v_pk_max_i16", "v_pk_add_i16 clamp", "v_fma_f32", "v_perm_b32", "v_mov_b32_dpp row_shr:1", "and/or/alignbit/xor mix", "v_pk_fma_f16", "v_max_i32", "v_pk_mad_u16", "v_max_f32", "v_pk_max_f16" };
+	const char *names[] = { "v_add_u32", "v_pk_max_i16", "v_pk_add_i16 clamp", "v_fma_f32", "v_perm_b32", "v_mov_b32_dpp row_shr:1", "and/or/alignbit/xor mix", "v_pk_fma_f16", "v_max_i32", "v_pk_mad_u16", "v_max_f32", "v_pk_max_f16", "v_sub_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshlrev_b32", "v_alignbit_b32", "v_bfi_b32", "v_bitop3_b32", "v_min_u32", "v_pk_sub_u16", "v_pk_add_u16", "v_pk_max_u16", "v_mov_b32", "v_add3_u32", "v_lshl_add_u32", "v_and_or_b32", "v_lshl_or_b32", "v_mov_b32_dpp wave_shr:1", "v_max_i16", "v_add_u16" };
 	printf("{\n");
-#define ROW(OP) printf(" \"%s\": {\"1\": %.2f, \"2\": %.2f, \"4\": %.2f, \"8\": %.2f}%s\n", names[OP], run<OP>(d, 1, 4000), run<OP>(d, 2, 4000), run<OP>(d, 4, 2000), run<OP>(d, 8, 1000), OP == 11 ? "" : ",");
-	ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(5) ROW(6) ROW(7) ROW(8) ROW(9) ROW(10) ROW(11)
+#define ROW(OP) printf(" \"%s\": {\"1\": %.2f, \"2\": %.2f, \"4\": %.2f, \"8\": %.2f}%s\n", names[OP], run<OP>(d, 1, 4000), run<OP>(d, 2, 4000), run<OP>(d, 4, 2000), run<OP>(d, 8, 1000), OP == 31 ? "" : ",");
+	ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(5) ROW(6) ROW(7) ROW(8) ROW(9) ROW(10) ROW(11) ROW(12) ROW(13) ROW(14) ROW(15) ROW(16) ROW(17) ROW(18) ROW(19) ROW(20) ROW(21) ROW(22) ROW(23) ROW(24) ROW(25) ROW(26) ROW(27) ROW(28) ROW(29) ROW(30) ROW(31)
 	printf("}\n");
 	fprintf(stderr, "{\"clock_mhz\": %.1f, \"at_2p4_ghz\": {\"v_pk_max_i16\": {\"1\": %.2f, \"8\": %.2f}, \"v_perm_b32\": {\"1\": %.2f, \"8\": %.2f}, \"v_add_u32\": {\"1\": %.2f, \"8\": %.2f}}}\n",
 	        g_mhz_sum / (g_mhz_n ? g_mhz_n : 1), g_cyc2p4[1][0], g_cyc2p4[1][3], g_cyc2p4[4][0], g_cyc2p4[4][3], g_cyc2p4[0][0], g_cyc2p4[0][3]);
