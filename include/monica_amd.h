@@ -402,7 +402,10 @@ int mnc_merge_summaries(const int32_t *d_parts, int n_parts, int64_t n, int32_t 
 
 /* how many sample files the host works on side by side -- monica's ThreadPool runs aligner() once per sample,
  * aligner.py:89-103: every FASTQ reader's parse and routing passes then take cores / n_workers threads (1, the
- * default: all of them, at most 16) */
+ * default: all of them, at most 16).  "cores" = what the process may keep busy: the hardware threads, less what its
+ * CPU affinity and its control group's quota (cpu.max / cpu.cfs_quota_us) leave of them.  The passes' helper threads
+ * belong to the calling thread, sleep between passes and end with it (csrc/team.h); like an OpenMP runtime's, they do
+ * not survive fork(). */
 int mnc_host_set_io_workers(int n_workers);
 /* page-locked host memory for batch buffers (plain malloc when no GPU is present) */
 void *mnc_host_alloc(size_t bytes);
