@@ -213,6 +213,7 @@ struct Batch {
 	int debug_route;              // test switch: 1 no packed extension kernel, 2 no packed gap-filling kernel, 4 no long tiers, 16 no 42-cell tier
 	int fill_pred;                // a gap filling tries the 32-cell tier when its bound is below fill_pred / 25 per base
 	int fill_pred_mid;            // ... and the 42-cell tier likewise
+	int fill_pred_auto;           // 1: both from the region's own anchor density instead (k_align.hip: fill_pred_of); minimap2's map-ont scores only
 	const uint32_t *seq4;         // contig bases, 4 bits each
 	const int64_t *seq_off;       // [n_contigs + 1]
 	int sc_a, sc_b, gap_q, gap_e, gap_q2, gap_e2, sc_ambi, zdrop, zdrop_inv, end_bonus, min_dp_max, min_ksw_len;

@@ -972,6 +972,9 @@ static int classify_once(mnc_engine *e, const uint8_t *d_bases, const int64_t *d
 	// 42 before 64 (2 units): above two in three -- a read with 10 % errors scores 1.36 +- 0.13 per base
 	B.fill_pred = (e->debug >> 8 & 0xff) ? (e->debug >> 8 & 0xff) : 32;
 	B.fill_pred_mid = (e->debug >> 24 & 0x7f) ? (e->debug >> 24 & 0x7f) : 34;   // (tools/sweep_pred.sh: flat around 32 / 34)
+	// (neither given: by the region's anchor density -- the law it uses was fitted with the scores mappy maps with)
+	B.fill_pred_auto = !(e->debug >> 8 & 0xff) && !(e->debug >> 24 & 0x7f) && P.a == 2 && P.b == 4 && P.q == 4 && P.e == 2 &&
+	                   P.q2 == 24 && P.e2 == 1 && !getenv("MNC_FILL_PRED_FIXED");
 	B.contract = e->contract, B.seq4 = e->didx->seq4, B.seq_off = e->didx->seq_off;
 	B.sc_a = P.a, B.sc_b = P.b, B.gap_q = P.q, B.gap_e = P.e, B.gap_q2 = P.q2, B.gap_e2 = P.e2, B.sc_ambi = P.sc_ambi;
 	B.zdrop = P.zdrop, B.zdrop_inv = P.zdrop_inv, B.end_bonus = P.end_bonus, B.min_dp_max = P.min_dp_max, B.min_ksw_len = P.min_ksw_len;

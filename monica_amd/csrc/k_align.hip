@@ -227,7 +227,37 @@ __device__ int collect_long_gaps(const Anchor *a, int cnt1, int min_gap, int32_t
 // The kernel a segment goes to (Seg.big: 0..3 the literal kernel's workspace classes, 4 + t the work list t of a banded /
 // extension kernel) and its bookkeeping fields; `widx` / `wamt`: what it adds to the work counters dp_ctr[48 + widx].
 struct PlanLimits { int slot_state_max; long long slot_p_max; int slot_cig_max; long long big_state_max, big_p_max, big_cig_max, huge_state_max, huge_p_max, huge_cig_max; };
-__device__ void plan_seg_class(const Batch &B, const PlanLimits &lim, int bw, uint32_t rd, int64_t rslot, int rid, int rev, int32_t seg_index,
+// The score per base (x 100) a gap filling of a region has to be expected to reach for a tier to be worth trying: Batch.fill_pred
+// / fill_pred_mid / 32, all x 4 -- fitted on reads with 10 % errors -- or, round 5, from the region itself.  The density of
+// its chained anchors, rho = cnt (w + 1) / (2 x query span), is (1 - eps)^k in expectation, and it is that to half a per cent
+// of eps read by read (3 / 7 / 10 / 13 / 16 % errors: 3.1 / 7.2 / 10.3 / 13.3 / 16.3 % from rho, tools/pred_fit.py); with
+// minimap2's map-ont scores a gap filling reaches 2 - 6.0 eps per base of its shorter side (1.81 / 1.57 / 1.40 / 1.23 / 1.07).
+// The constants sit 0.115 (32- and wider tiers) and 0.035 (42 cells) under that at 10 %: the same distances here.  A read at
+// 13 % used to send a quarter of its 42-cell tries on to the next tier; a read at 3 % took wide tiers it did not need.
+struct FillPred { int t1, mid, wide, last; };
+__device__ __forceinline__ FillPred fill_pred_of(const Batch &B, int cnt, int q_span)
+{
+	FillPred p = { B.fill_pred * 4, B.fill_pred_mid * 4, 32 * 4, 32 * 4 };
+	if (B.fill_pred_auto && cnt >= 20 && q_span >= 500) {
+		float rho = (float)cnt * 11.0f / (2.0f * (float)q_span);            // (k = 15, w = 10: the only sketch there is, check_kw)
+		rho = rho < 0.02f ? 0.02f : rho > 1.0f ? 1.0f : rho;
+		float eps = 1.0f - __expf(__logf(rho) * (1.0f / 15.0f)) - 0.003f;
+		eps = eps < 0.0f ? 0.0f : eps > 0.25f ? 0.25f : eps;
+		const float mu = 2.0f - 6.0f * eps;
+		// What stands behind a tier decides how sure it has to be: trying a tier that costs a before one that costs b pays
+		// when the chance of its proof is above a / b.  A segment's step costs 1 : 1.35 : 3.1 : 8.6 in the four tiers as they
+		// run (not 1 : 4/3 : 2 : 4 as their cells: the wide tiers fill fewer lanes and waves), so 32 cells want three chances
+		// in four, 42 cells and 64 cells less than even odds -- quantiles of the score per base, whose spread from segment
+		// to segment is 0.39 sqrt(eps (1 - eps)) (0.12 at 10 %).  The 128-cell tier stands before the literal kernel, a
+		// call of milliseconds on a wave of its own: tried on any chance at all, never below the fixed threshold.
+		const float sd = 0.39f * __fsqrt_rn(eps * (1.0f - eps) + 1e-4f);
+		p.t1 = (int)(100.0f * (mu - 0.64f * sd)), p.mid = (int)(100.0f * (mu + 0.15f * sd)), p.wide = (int)(100.0f * (mu + 0.36f * sd));
+		const int opt = (int)(100.0f * (mu + 2.0f * sd));
+		p.last = opt > p.last ? opt : p.last;
+	}
+	return p;
+}
+__device__ void plan_seg_class(const Batch &B, const PlanLimits &lim, const FillPred &pred, int bw, uint32_t rd, int64_t rslot, int rid, int rev, int32_t seg_index,
                                Seg &g, int &widx, unsigned long long &wamt)
 {
 	widx = -1, wamt = 0;
@@ -286,25 +316,25 @@ __device__ void plan_seg_class(const Batch &B, const PlanLimits &lim, int bw, ui
 			const int bb = (62 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
 			const int g1 = B.gap_q + B.gap_e * (bb + 1), g2 = B.gap_q2 + B.gap_e2 * (bb + 1);
 			const int U = B.sc_a * (mn - bb - 1) - 2 * (g1 < g2 ? g1 : g2);
-			if (U * 25 > mn * B.fill_pred) tier = 18;         // trying costs one unit, failing more than that again: worth it below even odds
+			if (U * 100 > mn * pred.t1) tier = 18;         // trying costs one unit, failing more than that again: worth it below even odds
 		}
 		if (tier == 18) {                                     // the 42-cell tier (three segments a wave: 4/3 units) against the 64-cell one (2 units)
 			const int bb = (2 * FILL_MID_CELLS - 2 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
 			const int g1 = B.gap_q + B.gap_e * (bb + 1), g2 = B.gap_q2 + B.gap_e2 * (bb + 1);
 			const int U = B.sc_a * (mn - bb - 1) - 2 * (g1 < g2 ? g1 : g2);
-			if ((B.debug_route & 16) || bb < 8 || U * 25 > mn * B.fill_pred_mid) tier = 2;
+			if ((B.debug_route & 16) || bb < 8 || U * 100 > mn * pred.mid) tier = 2;
 		}
 		if (tier == 2) {                                      // and the 64-lane tier likewise, against the literal kernel
 			const int bb = (126 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
 			const int g1 = B.gap_q + B.gap_e * (bb + 1), g2 = B.gap_q2 + B.gap_e2 * (bb + 1);
 			const int U = B.sc_a * (mn - bb - 1) - 2 * (g1 < g2 ? g1 : g2);
-			if (U * 25 > mn * 32) tier = 6;                   // two cells per lane: a band of 128
+			if (U * 100 > mn * pred.wide) tier = 6;                   // two cells per lane: a band of 128
 		}
 		if (tier == 6) {
 			const int bb = (254 - ad) / 2, mn = g.tlen < g.qlen ? g.tlen : g.qlen;
 			const int g1 = B.gap_q + B.gap_e * (bb + 1), g2 = B.gap_q2 + B.gap_e2 * (bb + 1);
 			const int U = B.sc_a * (mn - bb - 1) - 2 * (g1 < g2 ? g1 : g2);
-			if (bb < 8 || U * 25 > mn * 32) tier = 0;
+			if (bb < 8 || U * 100 > mn * pred.last) tier = 0;
 		}
 		if (tier) g.big = 3 + tier;          // not for the literal kernel's first pass
 		if (tier) widx = tier == 1 ? 0 : tier == 2 ? 1 : tier == 18 ? 4 : 2, wamt = (unsigned long long)(g.tlen + g.qlen - 1);
@@ -606,10 +636,11 @@ __global__ __launch_bounds__(64) void mnc_dp_plan(Batch B, const int32_t *work_l
 			int n_tier[20] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 			unsigned long long work[5] = { 0, 0, 0, 0, 0 };          // anti-diagonals given to the banded tiers (32 / 64 / 128 cells; [4]: 42 cells); [3]: steps x cells of the packed extensions
 			const PlanLimits lim = { slot_state_max, slot_p_max, slot_cig_max, big_state_max, big_p_max, big_cig_max, huge_state_max, huge_p_max, huge_cig_max };
+			const FillPred pred = fill_pred_of(B, cnt1, qe - qs);
 			auto emit = [&](Seg g) {
 				int widx;
 				unsigned long long wamt;
-				plan_seg_class(B, lim, bw, rd, rslot, rid, rev, (int32_t)(sg - B.segs), g, widx, wamt);
+				plan_seg_class(B, lim, pred, bw, rd, rslot, rid, rev, (int32_t)(sg - B.segs), g, widx, wamt);
 				if (g.big >= 4) ++n_tier[g.big - 4];
 				if (widx >= 0) work[widx] += wamt;
 				if (k_ok) K[sg - (B.segs + s0)] = g.big;                // for the lists below (the scratch ints are free again)
@@ -946,6 +977,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan_long(Batch B, int lds_anchors,
 					d.n_seg = 0, d.has_left = d.has_right = 0;
 				} else {
 					// one segment per lane, 64 at a time
+					const FillPred pred = fill_pred_of(B, cnt1, qe - qs);
 					for (int k0 = 0; k0 < n_seg; k0 += 64) {
 						const int k = k0 + lane;
 						const bool in = k < n_seg;
@@ -970,7 +1002,7 @@ __global__ __launch_bounds__(64) void mnc_dp_plan_long(Batch B, int lds_anchors,
 								g.w = (vy & SEED_LONG_JOIN) ? (cqe - pqs > cre - prs ? cqe - pqs : cre - prs) : bw;
 								g.zdrop = B.zdrop, g.flag = EZ_APPROX_MAX, g.ai = i;
 							}
-							plan_seg_class(B, lim, bw, rd, rslot, rid, rev, (int32_t)(s0 + k), g, widx, wamt);
+							plan_seg_class(B, lim, pred, bw, rd, rslot, rid, rev, (int32_t)(s0 + k), g, widx, wamt);
 							B.segs[s0 + k] = g;
 						}
 						// the work counters and the kernels' lists: one reservation per tier and 64 segments
