@@ -298,6 +298,29 @@ def test_every_kernel_family_can_be_taken_out(capi, oracle, world, route):
         eng.set_debug(0)
 
 
+def test_tiers_planned_by_anchor_density_on_reads_of_mixed_quality(capi, oracle, world):
+    """Round 5: the gap-filling tier a segment tries first comes from its region's anchor density (k_align.hip: fill_pred_of;
+    rho = cnt (w + 1) / (2 x query span) = (1 - eps)^k), where rounds 3-4 compared with two thresholds fitted at 10 %
+    errors (debug bits 8-15 / 24-30 still give those).  A batch of reads at 2, 7, 10, 14 and 18 % errors: against the oracle
+    as planned by density, the same region for region with the fixed thresholds, and the plans do differ."""
+    parts = [synth.reads(world["seqs"], 60, 4000, seed=960 + i, sub=s_, ins=i_, dele=d_)
+             for i, (s_, i_, d_) in enumerate(((80, 60, 60), (280, 210, 210), (400, 300, 300), (560, 420, 420), (720, 540, 540)))]
+    bases = np.concatenate([p[0] for p in parts])
+    offsets = np.arange(len(bases) // 4000 + 1, dtype=np.int64) * 4000
+    eng = world["eng"]
+    _compare_dp(capi, oracle, world, bases, offsets, min_mapq=0)
+    by_density = (eng.dump(capi.DUMP_REGS, capi.REG_DTYPE), eng.cigars(), eng.counters())
+    try:
+        eng.set_debug(32 << 8 | 34 << 24)
+        _compare_dp(capi, oracle, world, bases, offsets, min_mapq=0)
+        fixed = (eng.dump(capi.DUMP_REGS, capi.REG_DTYPE), eng.cigars(), eng.counters())
+    finally:
+        eng.set_debug(0)
+    assert by_density[0].tobytes() == fixed[0].tobytes() and by_density[1] == fixed[1]
+    tiers = lambda c: [c[k] for k in ("dp_fill_tier1", "dp_fill_tier_mid", "dp_fill_tier2", "dp_fill_tier3")]
+    assert tiers(by_density[2]) != tiers(fixed[2]) and by_density[2]["dp_segments"] == fixed[2]["dp_segments"]
+
+
 def test_reads_with_many_errors_use_every_workspace_class(capi, oracle, world):
     """16 % errors: seeds are sparse, so gaps between them are long, the banded kernels' proofs fail more often and
     read flanks without seeds become extensions of thousands of bases -- calls for the literal kernel's large
